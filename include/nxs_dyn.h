@@ -1,0 +1,233 @@
+/*
+ * nxs_dyn.h -- C ABI of libnxsdyn.so: the MI355X (gfx950) implementation of neXtSIM's
+ * per-time-step sea-ice dynamics hot path.
+ *
+ * The reference (nansencenter/nextsim) has no plugin / FFI interface for this path: it is two
+ * member functions of class FiniteElement that work on ~40 member vectors
+ * (model/finiteelement.hpp:386-838).  This header *creates* the boundary: one entry point per
+ * reference call site, taking exactly the arrays that call site reads and writes, as plain
+ * pointers + sizes (no C++ types, no torch types).  "FE.cpp" = model/finiteelement.cpp.
+ *
+ *   reference call site                         replaced by
+ *   ------------------------------------------  ------------------------------------------
+ *   FiniteElement::initOptAndParam/init         nxs_dyn_create          (FE.cpp:1066-1209, 6993-6999)
+ *   distributedMeshProcessing (per (re)mesh)    nxs_dyn_set_mesh        (FE.cpp:50-143, 150-271)
+ *   initUpdateGhosts                            nxs_dyn_set_halo        (FE.cpp:14003-14088)
+ *   ExternalData::getVector() snapshots         nxs_dyn_set_forcing     (model/externaldata.cpp:441-459)
+ *   member vectors M_VT, M_conc, ...            nxs_dyn_put_state / nxs_dyn_get_state
+ *   step(): UM_P=M_UM; explicitSolve(); update  nxs_dyn_step            (FE.cpp:8197-8214)
+ *   explicitSolve()                             nxs_dyn_explicit_solve  (FE.cpp:10182-10643)
+ *   update(UM_P)                                nxs_dyn_update          (FE.cpp:3919-4132)
+ *   updateFreeDriftVelocity()                   (inside nxs_dyn_step)   (FE.cpp:10140-10176)
+ *   checkRegridding()                           nxs_dyn_check_regridding(FE.cpp:8298-8309)
+ *   checkFieldsFast()                           nxs_dyn_check_fields_fast (FE.cpp:14536-14655)
+ *   M_surface, D_tau_a, D_tau_w, ...            nxs_dyn_get_diag
+ *   BamgConvertMeshx connectivity tables        nxs_mesh_connectivity   (contrib/bamg/src/Mesh.cpp:495-865)
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error (never throws across the ABI; the reference
+ *     throws std::runtime_error and aborts, FE.cpp:14653).  nxs_dyn_last_error() gives the text.
+ *   - all reals are fp64, all indices int32.  Nodal vectors are [u(0..Nn-1) | v(0..Nn-1)]
+ *     (FE.cpp:10152-10153).  Element indices are 1-based local node ids (core/include/entities.hpp:151).
+ *   - caller owns every host buffer; the library owns the device mirrors.
+ *   - a handle is driven by one host thread and one HIP stream; handles are independent.
+ *   - there is NO CPU fallback: without a HIP device nxs_dyn_create fails with NXS_ERR_NO_DEVICE.
+ */
+#ifndef NXS_DYN_H
+#define NXS_DYN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NXS_DYN_ABI_VERSION 1
+
+/* error codes */
+#define NXS_OK 0
+#define NXS_ERR_INVALID (-1)   /* bad argument / inconsistent sizes */
+#define NXS_ERR_NO_DEVICE (-2) /* no HIP device: the product path never falls back to the CPU */
+#define NXS_ERR_HIP (-3)       /* a HIP runtime call failed */
+#define NXS_ERR_STATE (-4)     /* call order (e.g. step before set_mesh) */
+#define NXS_ERR_COMM (-5)      /* RCCL failure */
+
+/* setup::DynamicsType, model/enums.hpp:142-149 */
+enum { NXS_DYN_BBM = 0, NXS_DYN_NO_MOTION = 1, NXS_DYN_FREE_DRIFT = 2, NXS_DYN_EVP = 3, NXS_DYN_MEVP = 4 };
+/* setup::BasalStressType, model/enums.hpp:82-86 */
+enum { NXS_BASAL_NONE = 0, NXS_BASAL_LEMIEUX = 1 };
+/* setup::IceCategoryType, model/enums.hpp:88-93 */
+enum { NXS_ICECAT_CLASSIC = 0, NXS_ICECAT_YOUNG_ICE = 1 };
+
+/* Everything explicitSolve()/update() read from vm[] or from members set in initOptAndParam/init.
+ * Defaults: model/options.cpp:43,80,314-376.  compr_strength is the value AFTER the scale_coef
+ * multiplication of FE.cpp:6996-6999 (cohesion arrives per element in nxs_dyn_state). */
+typedef struct nxs_dyn_params {
+    double dtime_step;                      /* simul.timestep [s] (FE.cpp: dtime_step) */
+    int32_t substeps;                       /* dynamics.substeps (options.cpp:363) */
+    int32_t dynamics_type;                  /* NXS_DYN_* */
+    int32_t basal_stress_type;              /* NXS_BASAL_* */
+    int32_t ice_cat_type;                   /* NXS_ICECAT_* (thermo.newice_type==4 -> YOUNG_ICE, FE.cpp:1206-1209) */
+    int32_t newice_type;                    /* thermo.newice_type (FE.cpp:3943) */
+    int32_t equal_ridging;                  /* age.equal_ridging (FE.cpp:3942) */
+    int32_t use_young_ice_in_myi_reset;     /* age.include_young_ice (FE.cpp:3944) */
+    int32_t reserved0;
+    double young;                           /* dynamics.young */
+    double nu0;                             /* dynamics.nu0 */
+    double tan_phi;                         /* dynamics.tan_phi */
+    double compr_strength;                  /* dynamics.compr_strength * scale_coef */
+    double compaction_param;                /* dynamics.compaction_param */
+    double undamaged_time_relaxation_sigma; /* dynamics.undamaged_time_relaxation_sigma */
+    double exponent_relaxation_sigma;       /* dynamics.exponent_relaxation_sigma */
+    double compression_factor;              /* dynamics.compression_factor */
+    double exponent_compression_factor;     /* dynamics.exponent_compression_factor */
+    double min_h;                           /* dynamics.min_h */
+    double min_c;                           /* dynamics.min_c (used by update() only, FE.cpp:4063) */
+    double quad_drag_coef_water;            /* dynamics.quad_drag_coef_water */
+    double lin_drag_coef_water;             /* dynamics.lin_drag_coef_water (free drift only) */
+    double quad_drag_coef_air;              /* <atm>_quad_drag_coef_air (free drift only; BBM uses state.drag_ui) */
+    double lin_drag_coef_air;               /* dynamics.lin_drag_coef_air (free drift only) */
+    double ocean_turning_angle_rad;         /* FE.cpp:1167-1172 */
+    double basal_k1, basal_k2, basal_Cb, basal_u_0; /* dynamics.Lemieux_basal_* */
+    double evp_e, evp_Pstar, evp_C, evp_dmin;       /* dynamics.evp.* */
+    double mevp_alpha, mevp_beta;                   /* dynamics.mevp.* */
+    double regrid_angle;                    /* numerics.regrid_angle [deg] */
+} nxs_dyn_params;
+
+/* The per-rank mesh as FiniteElement holds it after distributedMeshProcessing().
+ * Ordering contract (core/src/gmshmesh.cpp:1165-1169, 1379-1417): nodes [0,local_ndof) are owned,
+ * then ghosts; elements [0,local_nelements) are owned, then ghost elements.  Every owned node has
+ * its complete element fan locally. */
+typedef struct nxs_dyn_mesh {
+    int32_t num_nodes;              /* M_num_nodes  (owned + ghost) */
+    int32_t num_elements;           /* M_num_elements (owned + ghost) */
+    int32_t local_ndof;             /* M_local_ndof (owned nodes) */
+    int32_t local_nelements;        /* M_local_nelements (owned elements) */
+    const int32_t *indices;         /* [3*Ne] M_elements[e].indices[k], 1-based local node ids */
+    const uint8_t *ghost_nodes;     /* [3*Ne] M_elements[e].ghostNodes[k] (gmshmesh.cpp:1289-1301) */
+    const double *coord_x;          /* [Nn] M_mesh.coordX()  (undisplaced) */
+    const double *coord_y;          /* [Nn] M_mesh.coordY() */
+    const double *lat;              /* [Nn] M_mesh.lat() in degrees (gmshmesh.cpp:1800-1824) */
+    const uint8_t *mask_dirichlet;  /* [Nn] M_mask_dirichlet (false on ghosts, FE.cpp:228-234) */
+    int32_t num_neumann_flags;      /* M_neumann_flags.size() */
+    int32_t reserved0;
+    const int32_t *neumann_flags;   /* sorted, 0-based local node ids incl. ghosts (FE.cpp:236-252) */
+    /* bamgmesh tables exactly as BamgConvertMeshx leaves them (doubles, 1-based, NaN / 0 padded).
+     * Either may be NULL: the library then builds an identical table with nxs_mesh_connectivity(). */
+    const double *nodal_element_connectivity;  /* bamgmesh->NodalElementConnectivity [Nn*nec_width] */
+    const double *nodal_connectivity;          /* bamgmesh->NodalConnectivity [Nn*nc_width], last col = count */
+    int32_t nec_width;                         /* NodalElementConnectivitySize[1] */
+    int32_t nc_width;                          /* NodalConnectivitySize[1] */
+} nxs_dyn_mesh;
+
+/* Halo lists of initUpdateGhosts() (FE.hpp:615-618), flattened CSR-style.
+ * send_index = M_extract_local_index[q][], recv_index = M_local_ghosts_local_index[q][]. */
+typedef struct nxs_dyn_halo {
+    int32_t rank, nranks;
+    int32_t num_send_procs;        /* M_recipients_proc_id.size() */
+    int32_t num_recv_procs;        /* M_local_ghosts_proc_id.size() */
+    const int32_t *send_procs;     /* [num_send_procs] */
+    const int32_t *send_offsets;   /* [num_send_procs+1] into send_index */
+    const int32_t *send_index;     /* 0-based local node ids */
+    const int32_t *recv_procs;     /* [num_recv_procs] */
+    const int32_t *recv_offsets;   /* [num_recv_procs+1] into recv_index */
+    const int32_t *recv_index;     /* 0-based local (ghost) node ids */
+} nxs_dyn_halo;
+
+/* Prognostic state touched by the path (FE.hpp:712-746).  put: host -> device, get: device -> host.
+ * A NULL member is skipped on get; on put every non-const member must be non-NULL. */
+typedef struct nxs_dyn_state {
+    double *VT, *UM, *UT;                 /* [2*Nn] M_VT, M_UM, M_UT */
+    double *conc, *thick, *snow_thick;    /* [Ne] M_conc, M_thick, M_snow_thick */
+    double *damage, *ridge_ratio;         /* [Ne] M_damage, M_ridge_ratio */
+    double *sigma[3];                     /* [Ne] M_sigma[0..2] = s11, s22, s12 */
+    double *conc_young, *h_young, *hs_young; /* [Ne] young-ice category */
+    double *conc_myi, *thick_myi;         /* [Ne] multi-year ice */
+    /* inputs only (written by thermo / calcCohesion in the reference) */
+    const double *cohesion;               /* [Ne] M_Cohesion (FE.cpp:3909-3914) */
+    const double *time_relaxation_damage; /* [Ne] M_time_relaxation_damage [s] */
+    const double *drag_ui;                /* [Ne] M_drag_ui */
+    const double *drag_ui_young;          /* [Ne] M_drag_ui_young */
+} nxs_dyn_state;
+
+/* Flat per-step forcing snapshot (ExternalData::getVector semantics). */
+typedef struct nxs_dyn_forcing {
+    const double *wind;          /* [2*Nn] M_wind */
+    const double *ocean;         /* [2*Nn] M_ocean */
+    const double *ssh;           /* [Nn]   M_ssh */
+    const double *element_depth; /* [Ne]   M_element_depth */
+} nxs_dyn_forcing;
+
+/* Side outputs other parts of the model consume (moorings, coupler, exporter). NULL = skip. */
+typedef struct nxs_dyn_diag {
+    double *surface;            /* [Ne] M_surface */
+    double *delta_x;            /* [Ne] M_delta_x */
+    double *D_tau_a;            /* [2*Nn] */
+    double *D_tau_w;            /* [2*Nn] */
+    double *D_del_ci_ridge_myi; /* [Ne] */
+} nxs_dyn_diag;
+
+/* Per-phase device time of the last nxs_dyn_step (HIP events on the handle's stream), named after
+ * the reference's Timer rows (FE.cpp:8197-8221, 10217-10642). Milliseconds. */
+typedef struct nxs_dyn_timing {
+    double prep_ms;        /* "prep elements" + "prep nodes" */
+    double substeps_ms;    /* "sub-time stepping" (all sub-steps, halo included) */
+    double smoother_ms;    /* "OW smoother" (+ open-water mesh move) */
+    double update_ms;      /* "update" */
+    double total_ms;       /* "dynamics" */
+    int32_t substep_launches; /* kernel launches inside substeps_ms */
+    int32_t reserved0;
+} nxs_dyn_timing;
+
+typedef struct nxs_dyn_handle nxs_dyn_handle;
+
+int nxs_dyn_abi_version(void);
+const char *nxs_dyn_last_error(const nxs_dyn_handle *h); /* h may be NULL: last create() error */
+
+int nxs_dyn_default_params(nxs_dyn_params *p); /* model/options.cpp defaults, bbm */
+int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out);
+int nxs_dyn_destroy(nxs_dyn_handle *h);
+int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p);
+
+int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m);
+int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo);
+/* RCCL communicator for the halo exchange: every rank passes the same 128-byte ncclUniqueId
+ * (nxs_dyn_comm_unique_id on rank 0, broadcast by the host launcher). */
+int nxs_dyn_comm_unique_id(void *id128);
+int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks);
+
+int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s);
+int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s);
+int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f);
+int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *d);
+
+/* One dynamics step on the device-resident state: FE.cpp:8197-8214.  Asynchronous on the
+ * handle's stream; nxs_dyn_synchronize() waits for it. */
+int nxs_dyn_step(nxs_dyn_handle *h);
+int nxs_dyn_explicit_solve(nxs_dyn_handle *h);
+int nxs_dyn_update(nxs_dyn_handle *h);
+int nxs_dyn_synchronize(nxs_dyn_handle *h);
+/* Literal drop-in for the three lines of step(): put_state + set_forcing + step + get_state. */
+int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f);
+
+/* checkRegridding(): local minimum angle [deg] and flip test; the cross-rank reduction
+ * (FE.cpp:8306, 1812) is left to the caller's communicator. */
+int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32_t *flip, int32_t *regrid_local);
+/* checkFieldsFast(): crash_local != 0 when a field is out of range / NaN (FE.cpp:14541-14629). */
+int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local);
+
+int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
+/* 0 = one kernel launch per reference loop; 1 = sub-step loop captured in a hipGraph (default). */
+int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);
+
+/* Connectivity tables with the exact content and ordering of BamgConvertMeshx -> Mesh::WriteMesh
+ * (contrib/bamg/src/Mesh.cpp:514-543, 798-865) for a mesh given as 1-based triangles.
+ * Pass NULL outputs to query the widths first. Tables are doubles (NaN / 0 padded) like bamg's. */
+int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
+                          int32_t *nec_width, double *nodal_element_connectivity,
+                          int32_t *nc_width, double *nodal_connectivity);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NXS_DYN_H */

@@ -1,0 +1,59 @@
+/*
+ * bamg_shim.cpp -- TEST INFRASTRUCTURE.  extern "C" doors into the REAL reference library
+ * contrib/bamg (built by oracle/Makefile into oracle/_ref/libbamg_ref.so from the sources where
+ * they lie under /root/reference).  Compiled against the reference's headers in place
+ * (-I/root/reference/contrib/bamg/include); nothing of the reference is copied here.
+ *
+ * Used by tests to pin
+ *   - the connectivity tables the hot path reads (bamgmesh->NodalElementConnectivity /
+ *     NodalConnectivity as built at FE.cpp:77-80 by BamgConvertMeshx), and
+ *   - the mesh-to-mesh P1 interpolation used at regrid (FE.cpp:3131, InterpFromMeshToMesh2dx).
+ */
+#include <cstring>
+#include <cmath>
+
+#include "BamgMesh.h"
+#include "BamgGeom.h"
+#include "BamgConvertMeshx.h"
+#include "InterpFromMeshToMesh2dx.h"
+
+extern "C" {
+
+/* Runs BamgConvertMeshx exactly as FiniteElement::distributedMeshProcessing does (FE.cpp:77-80)
+ * and copies the two tables out.  Call once with nec/nc == NULL to get the widths. */
+int shim_bamg_connectivity(const int *index, const double *x, const double *y, int nods, int nels,
+                           int *nec_width, double *nec, int *nc_width, double *nc) {
+    BamgMesh *bamgmesh = new BamgMesh();
+    BamgGeom *bamggeom = new BamgGeom();
+    int rc = BamgConvertMeshx(bamgmesh, bamggeom, const_cast<int *>(index), const_cast<double *>(x),
+                              const_cast<double *>(y), nods, nels);
+    int w1 = bamgmesh->NodalElementConnectivitySize[1];
+    int w2 = bamgmesh->NodalConnectivitySize[1];
+    if (nec_width) *nec_width = w1;
+    if (nc_width) *nc_width = w2;
+    if (nec) std::memcpy(nec, bamgmesh->NodalElementConnectivity, sizeof(double) * (size_t)w1 * nods);
+    if (nc) std::memcpy(nc, bamgmesh->NodalConnectivity, sizeof(double) * (size_t)w2 * nods);
+    delete bamggeom;
+    delete bamgmesh;
+    return rc == 1 ? 0 : -1;
+}
+
+/* InterpFromMeshToMesh2dx as called at FE.cpp:3131-3139 (M_data = nods_data: nodal data). */
+int shim_bamg_interp_mesh_to_mesh(const int *index_data, const double *x_data, const double *y_data,
+                                  int nods_data, int nels_data, const double *data, int M_data, int N_data,
+                                  const double *x_interp, const double *y_interp, int N_interp,
+                                  int isdefault, double defaultvalue, double *out) {
+    double *res = NULL;
+    int rc = InterpFromMeshToMesh2dx(&res, const_cast<int *>(index_data), const_cast<double *>(x_data),
+                                     const_cast<double *>(y_data), nods_data, nels_data,
+                                     const_cast<double *>(data), M_data, N_data,
+                                     const_cast<double *>(x_interp), const_cast<double *>(y_interp), N_interp,
+                                     isdefault != 0, defaultvalue);
+    if (res) {
+        std::memcpy(out, res, sizeof(double) * (size_t)N_interp * N_data);
+        delete[] res; /* xNew<double> == new double[] in contrib/bamg/include/MemOps.h */
+    }
+    return rc == 1 ? 0 : -1;
+}
+
+} /* extern "C" */

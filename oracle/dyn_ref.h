@@ -1,0 +1,95 @@
+/*
+ * dyn_ref.h -- CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A line-faithful, single-threaded, fp64 restatement in plain C of the reference dynamics path of
+ * nansencenter/nextsim (FiniteElement::explicitSolve + update and helpers).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library; the product
+ * (libnxsdyn.so) never links, loads or calls it.
+ *
+ * Parity status: the reference ships NO golden vectors / known-answer tests for this path and its
+ * own translation units cannot be built here (Boost, Gmsh, NetCDF absent) -- see DESIGN.md.  The
+ * oracle is pinned by (1) hand-computed single-triangle known answers, (2) the reference's own
+ * runtime invariants, (3) the real contrib/bamg compiled into oracle/_ref for the connectivity
+ * tables.  For the time-stepping arithmetic itself: PARITY UNPINNED beyond (1)-(2).
+ *
+ * The struct types are the ABI PODs of include/nxs_dyn.h so that a test fills one set of structs
+ * for both sides.  "FE.cpp" = /root/reference/model/finiteelement.cpp.
+ */
+#ifndef DYN_REF_H
+#define DYN_REF_H
+
+#include "../include/nxs_dyn.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* scratch + side outputs of explicitSolve()/update() (locals and D_* members of the reference) */
+typedef struct ref_work {
+    int32_t Nn, Ne;
+    double Dunit[9];       /* M_Dunit, FE.cpp:1491-1507 */
+    double *delta_x;       /* [Ne] M_delta_x */
+    double *surface;       /* [Ne] M_surface */
+    double *shape_coeff;   /* [6*Ne] M_shape_coeff[e][0..5] */
+    double *B0T;           /* [18*Ne] M_B0T[e][0..17] */
+    double *element_mass;  /* [Ne] */
+    double *rlmass_matrix; /* [Nn] */
+    double *node_mass;     /* [Nn] */
+    double *C_bu;          /* [Nn] */
+    double *grad_ssh;      /* [2Nn] */
+    double *grad_terms;    /* [2Nn] */
+    double *fcor;          /* [Nn] */
+    double *VTM;           /* [2Nn] */
+    double *tmp;           /* [2Nn] copies (UM_P, u) */
+    double *D_tau_a;       /* [2Nn] */
+    double *D_tau_w;       /* [2Nn] */
+    double *D_del_ci_ridge_myi; /* [Ne] */
+} ref_work;
+
+typedef void (*ref_ghost_fn)(void *ctx, double *nodal_vec);
+
+ref_work *ref_work_create(int32_t Nn, int32_t Ne);
+void ref_work_destroy(ref_work *w);
+
+void ref_default_params(nxs_dyn_params *p);
+
+/* phases of explicitSolve(), split where the reference calls updateGhosts() */
+void ref_prep(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+              const nxs_dyn_forcing *f, ref_work *w);                  /* FE.cpp:10213-10418 */
+void ref_update_sigma_damage(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+                             ref_work *w, double dt);                   /* FE.cpp:4137-4260 */
+void ref_update_sigma_vp(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+                         ref_work *w, double ralpha1, double ralpha2);  /* FE.cpp:10649-10699 */
+void ref_substep_solve(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+                       const nxs_dyn_forcing *f, ref_work *w);         /* FE.cpp:10425-10530 */
+void ref_move_mesh(const nxs_dyn_mesh *m, nxs_dyn_state *s, ref_work *w, double dt); /* :10539-10553 */
+void ref_smoother_sweep(const nxs_dyn_mesh *m, nxs_dyn_state *s, ref_work *w);       /* :10582-10608 */
+void ref_ow_tail(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+                 const nxs_dyn_forcing *f, ref_work *w);               /* FE.cpp:10613-10640 */
+
+/* whole functions */
+void ref_explicit_solve(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+                        const nxs_dyn_forcing *f, ref_work *w, ref_ghost_fn ghosts, void *ctx);
+void ref_update(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s, ref_work *w);
+void ref_free_drift(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+                    const nxs_dyn_forcing *f);                         /* FE.cpp:10140-10176 */
+/* step(): FE.cpp:8197-8214 */
+void ref_step(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,
+              const nxs_dyn_forcing *f, ref_work *w, ref_ghost_fn ghosts, void *ctx);
+
+int ref_check_regridding(const nxs_dyn_mesh *m, const nxs_dyn_params *p, const nxs_dyn_state *s,
+                         double *min_angle, int32_t *flip);            /* FE.cpp:8298-8309 */
+int ref_check_fields_fast(const nxs_dyn_mesh *m, const nxs_dyn_params *p, const nxs_dyn_state *s); /* :14536 */
+
+/* updateGhosts() halves (FE.cpp:13963-13996): pack what I send to neighbour k / unpack what k sent */
+void ref_ghosts_pack(const nxs_dyn_halo *h, int32_t Nn, const double *vec, int k, double *buf);
+void ref_ghosts_unpack(const nxs_dyn_halo *h, int32_t Nn, double *vec, int k, const double *buf);
+
+/* restatement of Mesh::WriteMesh's two connectivity tables (contrib/bamg/src/Mesh.cpp:514-543, 798-865) */
+int ref_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
+                          int32_t *nec_width, double *nec, int32_t *nc_width, double *nc);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,234 @@
+"""Python door into the CPU oracle (oracle/liboracle*.so) -- TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg, nowhere
+else: the product path (nextsim_amd/) never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from nextsim_amd import _abi
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Work(C.Structure):
+    _fields_ = [("Nn", C.c_int32), ("Ne", C.c_int32), ("Dunit", C.c_double * 9)] + [
+        (k, _abi.c_double_p) for k in (
+            "delta_x", "surface", "shape_coeff", "B0T", "element_mass", "rlmass_matrix", "node_mass",
+            "C_bu", "grad_ssh", "grad_terms", "fcor", "VTM", "tmp", "D_tau_a", "D_tau_w",
+            "D_del_ci_ridge_myi")]
+
+
+GHOST_FN = C.CFUNCTYPE(None, C.c_void_p, _abi.c_double_p)
+
+
+def build(fast: bool = False) -> str:
+    name = "liboracle_fast.so" if fast else "liboracle.so"
+    path = os.path.join(HERE, name)
+    src = os.path.join(HERE, "dyn_ref.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", HERE, name])
+    return path
+
+
+_libs: dict = {}
+
+
+def lib(fast: bool = False):
+    if fast in _libs:
+        return _libs[fast]
+    L = C.CDLL(build(fast))
+    P = C.POINTER
+    Mp, Pp, Sp, Fp, Wp = P(_abi.Mesh), P(_abi.Params), P(_abi.State), P(_abi.Forcing), P(Work)
+    L.ref_work_create.restype = Wp
+    L.ref_work_create.argtypes = [C.c_int32, C.c_int32]
+    L.ref_work_destroy.argtypes = [Wp]
+    L.ref_default_params.argtypes = [Pp]
+    L.ref_prep.argtypes = [Mp, Pp, Sp, Fp, Wp]
+    L.ref_update_sigma_damage.argtypes = [Mp, Pp, Sp, Wp, C.c_double]
+    L.ref_update_sigma_vp.argtypes = [Mp, Pp, Sp, Wp, C.c_double, C.c_double]
+    L.ref_substep_solve.argtypes = [Mp, Pp, Sp, Fp, Wp]
+    L.ref_move_mesh.argtypes = [Mp, Sp, Wp, C.c_double]
+    L.ref_smoother_sweep.argtypes = [Mp, Sp, Wp]
+    L.ref_ow_tail.argtypes = [Mp, Pp, Sp, Fp, Wp]
+    L.ref_explicit_solve.argtypes = [Mp, Pp, Sp, Fp, Wp, C.c_void_p, C.c_void_p]
+    L.ref_update.argtypes = [Mp, Pp, Sp, Wp]
+    L.ref_free_drift.argtypes = [Mp, Pp, Sp, Fp]
+    L.ref_step.argtypes = [Mp, Pp, Sp, Fp, Wp, C.c_void_p, C.c_void_p]
+    L.ref_check_regridding.argtypes = [Mp, Pp, Sp, P(C.c_double), P(C.c_int32)]
+    L.ref_check_regridding.restype = C.c_int
+    L.ref_check_fields_fast.argtypes = [Mp, Pp, Sp]
+    L.ref_check_fields_fast.restype = C.c_int
+    L.ref_ghosts_pack.argtypes = [P(_abi.Halo), C.c_int32, _abi.c_double_p, C.c_int, _abi.c_double_p]
+    L.ref_ghosts_unpack.argtypes = [P(_abi.Halo), C.c_int32, _abi.c_double_p, C.c_int, _abi.c_double_p]
+    L.ref_mesh_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, P(C.c_int32), _abi.c_double_p,
+                                        P(C.c_int32), _abi.c_double_p]
+    L.ref_mesh_connectivity.restype = C.c_int
+    _libs[fast] = L
+    return L
+
+
+def connectivity(indices: np.ndarray, num_nodes: int):
+    """(nec, nc) double tables in bamg layout from the oracle's restatement of Mesh::WriteMesh."""
+    L = lib()
+    ne = indices.size // 3
+    w1, w2 = C.c_int32(), C.c_int32()
+    rc = L.ref_mesh_connectivity(_abi.iptr(indices), num_nodes, ne, C.byref(w1), None, C.byref(w2), None)
+    assert rc == 0
+    nec = np.empty((num_nodes, w1.value)); nc = np.empty((num_nodes, w2.value))
+    rc = L.ref_mesh_connectivity(_abi.iptr(indices), num_nodes, ne, C.byref(w1), _abi.dptr(nec), C.byref(w2), _abi.dptr(nc))
+    assert rc == 0
+    return nec, nc
+
+
+def bamg_shim():
+    """The REAL contrib/bamg behind oracle/_ref/libbamg_shim.so, or None when it was never built
+    (it is built from /root/reference, which only exists in the build container)."""
+    path = os.path.join(HERE, "_ref", "libbamg_shim.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    P = C.POINTER
+    L.shim_bamg_connectivity.argtypes = [P(C.c_int), _abi.c_double_p, _abi.c_double_p, C.c_int, C.c_int,
+                                         P(C.c_int), _abi.c_double_p, P(C.c_int), _abi.c_double_p]
+    L.shim_bamg_connectivity.restype = C.c_int
+    L.shim_bamg_interp_mesh_to_mesh.argtypes = [P(C.c_int), _abi.c_double_p, _abi.c_double_p, C.c_int, C.c_int,
+                                                _abi.c_double_p, C.c_int, C.c_int, _abi.c_double_p, _abi.c_double_p,
+                                                C.c_int, C.c_int, C.c_double, _abi.c_double_p]
+    L.shim_bamg_interp_mesh_to_mesh.restype = C.c_int
+    return L
+
+
+def bamg_connectivity(indices: np.ndarray, x: np.ndarray, y: np.ndarray):
+    L = bamg_shim()
+    assert L is not None
+    nn, ne = x.size, indices.size // 3
+    idx = np.ascontiguousarray(indices.astype(np.intc))
+    w1, w2 = C.c_int(), C.c_int()
+    ip = idx.ctypes.data_as(C.POINTER(C.c_int))
+    assert L.shim_bamg_connectivity(ip, _abi.dptr(x), _abi.dptr(y), nn, ne, C.byref(w1), None, C.byref(w2), None) == 0
+    nec = np.empty((nn, w1.value)); nc = np.empty((nn, w2.value))
+    assert L.shim_bamg_connectivity(ip, _abi.dptr(x), _abi.dptr(y), nn, ne, C.byref(w1), _abi.dptr(nec), C.byref(w2), _abi.dptr(nc)) == 0
+    return nec, nc
+
+
+class OracleRank:
+    """One rank of the restated reference: owns copies of the state arrays and a ref_work."""
+
+    def __init__(self, lm, params: _abi.Params, fields: dict, tables=None, fast: bool = False):
+        self.L = lib(fast)
+        self.lm = lm
+        self.params = params.copy()
+        self.arr = {k: np.array(v, dtype=np.float64, copy=True) for k, v in fields.items()}
+        self.tables = tables if tables is not None else connectivity(lm.indices, lm.num_nodes)
+        self.mesh = _abi.mesh_struct(lm, self.tables)
+        self.state = _abi.state_struct(self.arr)
+        self.forcing = _abi.forcing_struct(self.arr)
+        self.halo = _abi.halo_struct(lm)
+        self.work = self.L.ref_work_create(lm.num_nodes, lm.num_elements)
+
+    def __del__(self):
+        try:
+            self.L.ref_work_destroy(self.work)
+        except Exception:
+            pass
+
+    def _a(self):
+        return C.byref(self.mesh), C.byref(self.params), C.byref(self.state), C.byref(self.forcing), self.work
+
+    # whole functions (single rank: no ghosts callback)
+    def step(self):
+        m, p, s, f, w = self._a()
+        self.L.ref_step(m, p, s, f, w, None, None)
+
+    def explicit_solve(self):
+        m, p, s, f, w = self._a()
+        self.L.ref_explicit_solve(m, p, s, f, w, None, None)
+
+    def update(self):
+        m, p, s, f, w = self._a()
+        self.L.ref_update(m, p, s, w)
+
+    # phases
+    def prep(self):
+        m, p, s, f, w = self._a(); self.L.ref_prep(m, p, s, f, w)
+
+    def substep_solve(self):
+        m, p, s, f, w = self._a(); self.L.ref_substep_solve(m, p, s, f, w)
+
+    def move_mesh(self, dt):
+        m, p, s, f, w = self._a(); self.L.ref_move_mesh(m, s, w, dt)
+
+    def smoother_sweep(self):
+        m, p, s, f, w = self._a(); self.L.ref_smoother_sweep(m, s, w)
+
+    def ow_tail(self):
+        m, p, s, f, w = self._a(); self.L.ref_ow_tail(m, p, s, f, w)
+
+    def update_sigma_damage(self, dt):
+        m, p, s, f, w = self._a(); self.L.ref_update_sigma_damage(m, p, s, w, dt)
+
+    def check_regridding(self):
+        m, p, s, f, w = self._a()
+        ang, flip = C.c_double(), C.c_int32()
+        r = self.L.ref_check_regridding(m, p, s, C.byref(ang), C.byref(flip))
+        return ang.value, flip.value, r
+
+    def check_fields_fast(self):
+        m, p, s, f, w = self._a()
+        return self.L.ref_check_fields_fast(m, p, s)
+
+    def work_array(self, name: str, n: int) -> np.ndarray:
+        ptr = getattr(self.work.contents, name)
+        return np.ctypeslib.as_array(ptr, shape=(n,)).copy()
+
+    def pack(self, k: int) -> np.ndarray:
+        n = int(self.lm.send_offsets[k + 1] - self.lm.send_offsets[k])
+        buf = np.empty(2 * n)
+        self.L.ref_ghosts_pack(C.byref(self.halo), self.lm.num_nodes, _abi.dptr(self.arr["VT"]), k, _abi.dptr(buf))
+        return buf
+
+    def unpack(self, k: int, buf: np.ndarray):
+        self.L.ref_ghosts_unpack(C.byref(self.halo), self.lm.num_nodes, _abi.dptr(self.arr["VT"]), k, _abi.dptr(buf))
+
+
+def exchange_ghosts(ranks: list):
+    """updateGhosts(M_VT) across in-process oracle ranks (FE.cpp:13963-13996)."""
+    bufs = {}
+    for r in ranks:
+        for k, q in enumerate(r.lm.send_procs):
+            bufs[(r.lm.rank, int(q))] = r.pack(k)
+    for r in ranks:
+        for k, q in enumerate(r.lm.recv_procs):
+            r.unpack(k, bufs[(int(q), r.lm.rank)])
+
+
+def multirank_step(ranks: list):
+    """step() on P in-process ranks in lock-step (explicitSolve with real halo exchanges + update)."""
+    p = ranks[0].params
+    steps = p.substeps
+    dte = p.dtime_step / float(steps)
+    for r in ranks:
+        r.prep()
+    for _ in range(steps):
+        for r in ranks:
+            r.substep_solve()
+        exchange_ghosts(ranks)
+        if p.dynamics_type != _abi.NXS_DYN_MEVP:
+            for r in ranks:
+                r.move_mesh(dte)
+    if p.dynamics_type == _abi.NXS_DYN_MEVP:
+        for r in ranks:
+            r.move_mesh(p.dtime_step)
+    for _ in range(50):
+        for r in ranks:
+            r.smoother_sweep()
+        exchange_ghosts(ranks)
+    for r in ranks:
+        r.ow_tail()
+        r.update()
