@@ -181,49 +181,59 @@ typedef struct nxs_dyn_timing {
 
 typedef struct nxs_dyn_handle nxs_dyn_handle;
 
-int nxs_dyn_abi_version(void);
-const char *nxs_dyn_last_error(const nxs_dyn_handle *h); /* h may be NULL: last create() error */
+#if defined(__GNUC__)
+#define NXS_API __attribute__((visibility("default")))
+#else
+#define NXS_API
+#endif
 
-int nxs_dyn_default_params(nxs_dyn_params *p); /* model/options.cpp defaults, bbm */
-int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out);
-int nxs_dyn_destroy(nxs_dyn_handle *h);
-int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p);
+NXS_API int nxs_dyn_abi_version(void);
+NXS_API const char *nxs_dyn_last_error(const nxs_dyn_handle *h); /* h may be NULL: last create() error */
 
-int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m);
-int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo);
+NXS_API int nxs_dyn_default_params(nxs_dyn_params *p); /* model/options.cpp defaults, bbm */
+NXS_API int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out);
+NXS_API int nxs_dyn_destroy(nxs_dyn_handle *h);
+NXS_API int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p);
+
+NXS_API int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m);
+NXS_API int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo);
 /* RCCL communicator for the halo exchange: every rank passes the same 128-byte ncclUniqueId
  * (nxs_dyn_comm_unique_id on rank 0, broadcast by the host launcher). */
-int nxs_dyn_comm_unique_id(void *id128);
-int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks);
+NXS_API int nxs_dyn_comm_unique_id(void *id128);
+NXS_API int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks);
 
-int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s);
-int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s);
-int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f);
-int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *d);
+NXS_API int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s);
+NXS_API int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s);
+NXS_API int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f);
+NXS_API int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *d);
 
 /* One dynamics step on the device-resident state: FE.cpp:8197-8214.  Asynchronous on the
  * handle's stream; nxs_dyn_synchronize() waits for it. */
-int nxs_dyn_step(nxs_dyn_handle *h);
-int nxs_dyn_explicit_solve(nxs_dyn_handle *h);
-int nxs_dyn_update(nxs_dyn_handle *h);
-int nxs_dyn_synchronize(nxs_dyn_handle *h);
+NXS_API int nxs_dyn_step(nxs_dyn_handle *h);
+NXS_API int nxs_dyn_explicit_solve(nxs_dyn_handle *h);
+NXS_API int nxs_dyn_update(nxs_dyn_handle *h);
+NXS_API int nxs_dyn_synchronize(nxs_dyn_handle *h);
 /* Literal drop-in for the three lines of step(): put_state + set_forcing + step + get_state. */
-int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f);
+NXS_API int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f);
 
 /* checkRegridding(): local minimum angle [deg] and flip test; the cross-rank reduction
  * (FE.cpp:8306, 1812) is left to the caller's communicator. */
-int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32_t *flip, int32_t *regrid_local);
+NXS_API int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32_t *flip, int32_t *regrid_local);
 /* checkFieldsFast(): crash_local != 0 when a field is out of range / NaN (FE.cpp:14541-14629). */
-int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local);
+NXS_API int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local);
 
-int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
+NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
 /* 0 = one kernel launch per reference loop; 1 = sub-step loop captured in a hipGraph (default). */
-int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);
+NXS_API int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);
+
+/* Test door: copies a named internal work array (rlmass, node_mass, C_bu, grad_ssh, fcor, VTM, shape,
+ * emass, ecbu, force, volume, expC) to the host so that parity tests can localise a difference. */
+NXS_API int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_t n);
 
 /* Connectivity tables with the exact content and ordering of BamgConvertMeshx -> Mesh::WriteMesh
  * (contrib/bamg/src/Mesh.cpp:514-543, 798-865) for a mesh given as 1-based triangles.
  * Pass NULL outputs to query the widths first. Tables are doubles (NaN / 0 padded) like bamg's. */
-int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
+NXS_API int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
                           int32_t *nec_width, double *nodal_element_connectivity,
                           int32_t *nc_width, double *nodal_connectivity);
 

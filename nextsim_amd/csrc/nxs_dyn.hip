@@ -1,0 +1,1569 @@
+// nxs_dyn.hip -- libnxsdyn.so: neXtSIM's per-time-step dynamics (explicitSolve + update) on MI355X.
+//
+// gfx950 only.  fp64 throughout; memory-bound (no MFMA).  One handle = one GPU = one HIP stream.
+// Compiled with -ffp-contract=off: the reference is built without FMA contraction
+// (model/Makefile:5-8, -O3 and no -march), so every a*b+c below is two roundings, like there.
+//
+// Kernel inventory ("v1": one kernel per reference loop; FE.cpp = model/finiteelement.cpp):
+//   k_prep_elements   FE.cpp:10235-10308  geometry, slab mass, basal C_bu, per-step element constants
+//   k_prep_nodes      FE.cpp:10309-10416  node-centric gather of the element->node scatters + prep nodes
+//   k_sigma_bbm       FE.cpp:4137-4260    updateSigmaDamage; also emits the 6 corner forces of K4
+//   k_sigma_vp        FE.cpp:10649-10726  EVP / mEVP stress
+//   k_solve_move      FE.cpp:10445-10553  grad_terms gather + nodal solve + mesh move (owned nodes)
+//   k_halo_pack/unpack FE.cpp:13963-13996 updateGhosts (unpack also moves the ghost nodes)
+//   k_smooth          FE.cpp:10580-10608  one Jacobi sweep of the open-water smoother
+//   k_ow_tail         FE.cpp:10613-10640  D_tau_w, open-water mesh move
+//   k_update          FE.cpp:3946-4131    update()
+//   k_free_drift      FE.cpp:10140-10176
+//   k_regrid_*/k_check_* FE.cpp:8298-8309, 14536-14655 reductions
+//
+// Determinism: the reference scatters element contributions into nodes in ascending element
+// order.  Here every node GATHERS over its element fan sorted ascending, which performs the same
+// floating-point additions in the same order: no atomics, bit-reproducible, and identical to the
+// serial loop.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <dlfcn.h>
+#include <string>
+#include <vector>
+
+#include "nxs_dyn.h"
+
+// ------------------------------------------------------------------------------------------------
+// constants (model/constants.hpp:56-87, model/finiteelement.hpp:549)
+#define NXS_RHOI 917.
+#define NXS_RHOW 1025.
+#define NXS_RHOS 330.
+#define NXS_RHOA 1.22
+#define NXS_GRAVITY 9.80616
+#define NXS_OMEGA 7.292e-5
+#define NXS_PI 3.141592653589793238462643383279502884197169399375105820974944592308
+#define NXS_DAYS_IN_SEC 86400.
+
+#define STD_MAX(a, b) (((a) < (b)) ? (b) : (a))  // std::max
+#define STD_MIN(a, b) (((b) < (a)) ? (b) : (a))  // std::min
+
+static constexpr int BLOCK = 256;
+
+// node flag bits
+#define NF_DIRICHLET 1
+#define NF_NEUMANN 2
+// element flag bits (static, per mesh)
+#define EF_ON_NEUMANN 8  // any vertex in M_neumann_flags (FE.cpp:3957-3961)
+
+// everything the kernels need from nxs_dyn_params, plus host-precomputed scalars
+struct DevParams {
+    double dtime_step, dte;
+    int substeps, dynamics_type, basal_stress_type, young_cat, newice_type, equal_ridging, use_young_myi;
+    double young, nu0, tan_phi, compr_strength, compaction_param, utrs, ers_m1, compression_factor, ecf;
+    double min_h, min_c, min_m, qdw, ldw, qda, lda;
+    double cos_ota, sin_ota;
+    double k1, k2, Cb, u0;
+    double evp_e, evp_Pstar, evp_C, evp_dmin, ralpha1, ralpha2, mevp_beta;
+    double sqrt_nu_rhoi;
+    double D[9];
+};
+
+struct DevMesh {
+    int Nn, Ne, No, Neo;
+    const int *t0, *t1, *t2;     // [Ne] 0-based node ids
+    const unsigned char *eflags; // [Ne] bits 0-2 ghostNodes[k], bit 3 on-neumann
+    const double *x0, *y0, *lat; // [Nn]
+    const unsigned char *nflags; // [Nn]
+    int W;  const int *fan;      // [W][Nn] ascending fan: (e<<3)|(ghost<<2)|corner, -1 pad
+    int W1; const int *n2e;      // [W1][Nn] bamg row order, 0-based element, -1 pad
+    int W2; const int *n2n;      // [W2][Nn] bamg row order, 0-based node
+    const int *n2n_cnt;          // [Nn]
+};
+
+struct DevState {
+    double *VT, *VT2, *UM, *UT;  // VT2: second buffer of the Jacobi smoother
+    double *conc, *thick, *snow, *damage, *ridge, *s0, *s1, *s2;
+    double *cyoung, *hyoung, *hsyoung, *cmyi, *tmyi;
+    double *cohesion, *theal, *drag_ui, *drag_ui_young;
+    double *wind, *ocean, *ssh, *depth;
+};
+
+struct DevWork {
+    double *delta_x, *surface, *shape /*[6][Ne]*/, *emass, *ecbu;
+    double *expC, *pmax, *heal, *dxs, *volume;  // per-step element constants of the sub-step loop
+    unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
+    double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
+    double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
+    double *D_tau_a, *D_tau_w, *D_del;
+};
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+
+__device__ __forceinline__ void load_vertices(const DevMesh &m, const double *__restrict__ UM, int e,
+                                              double vx[3], double vy[3]) {
+    // GmshMesh::vertices(indices, um, 1.), gmshmesh.cpp:1929-1939
+    const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        vx[i] = m.x0[n[i]] + 1. * UM[n[i]];
+        vy[i] = m.y0[n[i]] + 1. * UM[n[i] + m.Nn];
+    }
+}
+
+__device__ __forceinline__ double jacobian(const double vx[3], const double vy[3]) {  // FE.cpp:1613-1618
+    double jac = (vx[1] - vx[0]) * (vy[2] - vy[0]);
+    jac -= (vx[2] - vx[0]) * (vy[1] - vy[0]);
+    return jac;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a  prep elements, FE.cpp:10235-10308
+__global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, DevWork w, DevParams p) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= m.Ne) return;
+    double vx[3], vy[3];
+    load_vertices(m, s.UM, e, vx, vy);
+
+    // Q1 (FE.cpp:10239): int accumulator, then unsigned integer division by 3
+    const double side0 = hypot(vx[1] - vx[0], vy[1] - vy[0]);
+    const double side1 = hypot(vx[2] - vx[1], vy[2] - vy[1]);
+    const double side2 = hypot(vx[2] - vx[0], vy[2] - vy[0]);
+    int acc = 0;
+    acc = (int)(acc + side0);
+    acc = (int)(acc + side1);
+    acc = (int)(acc + side2);
+    const double delta_x = (double)((unsigned long)acc / 3ul);
+    w.delta_x[e] = delta_x;
+
+    const double jac = jacobian(vx, vy);
+    const double surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
+    w.surface[e] = surface;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {  // FE.cpp:1956-1962
+        const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+        w.shape[(size_t)k * m.Ne + e] = (vy[kp1] - vy[kp2]) / jac;
+        w.shape[(size_t)(k + 3) * m.Ne + e] = (vx[kp2] - vx[kp1]) / jac;
+    }
+
+    // slab mass, FE.cpp:10255-10269
+    const double conc = s.conc[e], thick = s.thick[e];
+    double total_concentration = conc, total_thickness = thick, total_snow = s.snow[e];
+    if (p.young_cat) {
+        total_concentration += s.cyoung[e];
+        total_thickness += s.hyoung[e];
+        total_snow += s.hsyoung[e];
+    }
+    double element_mass = 0.;
+    if (total_concentration > 0.)
+        element_mass = (NXS_RHOI * total_thickness + NXS_RHOS * total_snow) / total_concentration;
+    w.emass[e] = element_mass;
+
+    // basal stress numerator, FE.cpp:10273-10308
+    double element_ssh = 0;
+    element_ssh += s.ssh[m.t0[e]];
+    element_ssh += s.ssh[m.t1[e]];
+    element_ssh += s.ssh[m.t2[e]];
+    element_ssh /= 3.;
+    const double max_keel_depth = 28;
+    const double min_water_depth = 2.;
+    const double depth_eff = STD_MAX(0., element_ssh + STD_MAX(min_water_depth, s.depth[e]));
+    double critical_h = 0., critical_h_mod = 0.;
+    if (p.basal_stress_type == NXS_BASAL_LEMIEUX) {
+        double mean_keel_depth = p.k1 * thick;
+        mean_keel_depth = STD_MIN(mean_keel_depth, conc * max_keel_depth);
+        critical_h = conc * depth_eff / p.k1;
+        critical_h_mod = mean_keel_depth / p.k1;
+    }
+    w.ecbu[e] = p.k2 * STD_MAX(0., critical_h_mod - critical_h) * exp(-p.Cb * (1. - conc));
+
+    // Per-step constants of the sub-step loop.  M_conc, M_thick, M_delta_x, M_surface do not change
+    // while sub-cycling (Q4), so exp/pow of them are evaluated once here instead of S times; the
+    // expressions are the reference's, operand for operand.
+    if (p.dynamics_type == NXS_DYN_BBM) {
+        const double expC = exp(p.compaction_param * (1. - conc));             // FE.cpp:4185
+        w.expC[e] = expC;
+        w.pmax[e] = pow(thick, p.ecf) * p.compression_factor * expC;          // FE.cpp:4192
+        w.heal[e] = p.dte / s.theal[e] * expC;                                 // FE.cpp:4257
+        w.dxs[e] = delta_x * p.sqrt_nu_rhoi;                                   // FE.cpp:4232
+        w.eskip[e] = (conc <= 0.1) ? 1 : 0;                                    // Q5, FE.cpp:4146-4151
+    } else {
+        w.expC[e] = p.evp_Pstar * exp(-p.evp_C * (1. - conc));                 // FE.cpp:10684 (P)
+        w.eskip[e] = (thick == 0.) ? 1 : 0;                                    // FE.cpp:10656
+    }
+    w.volume[e] = thick * surface;                                             // FE.cpp:10450
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1b + K2  the nodal side of prep elements (as a gather) and prep nodes, FE.cpp:10309-10416
+__global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, DevWork w, DevParams p) {
+    const int n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= m.Nn) return;
+    const int Nn = m.Nn, Ne = m.Ne;
+    const bool dirichlet = m.nflags[n] & NF_DIRICHLET;
+    const double g3rd = NXS_GRAVITY / 3.;
+
+    double rl = 0., nm = 0., cb = 0., gu = 0., gv = 0.;
+    for (int slot = 0; slot < m.W; ++slot) {
+        const int ent = m.fan[(size_t)slot * Nn + n];
+        if (ent < 0) break;
+        const int e = ent >> 3;
+        const bool ghost_corner = ent & 4;
+        const double A = w.surface[e], me = w.emass[e];
+        rl += A;                                       // FE.cpp:10313
+        nm += me * A;                                  // FE.cpp:10314
+        const double ecbu = w.ecbu[e];
+        cb = STD_MAX(cb, ecbu);                        // FE.cpp:10317
+        // Q7: the skip test sees node_mass as accumulated so far (elements <= e)
+        if (dirichlet || nm == 0. || ghost_corner) continue;
+        const double m_g_A3rd = me * A * g3rd;         // FE.cpp:10321
+        const int nj[3] = {m.t0[e], m.t1[e], m.t2[e]};
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                  // FE.cpp:10334-10339
+            const double sshj = s.ssh[nj[j]];
+            gu -= w.shape[(size_t)j * Ne + e] * m_g_A3rd * sshj;
+            gv -= w.shape[(size_t)(j + 3) * Ne + e] * m_g_A3rd * sshj;
+        }
+    }
+    w.C_bu[n] = cb;
+    w.grad_ssh[n] = gu;
+    w.grad_ssh[n + Nn] = gv;
+
+    // prep nodes, FE.cpp:10356-10416
+    double vu = s.VT[n], vv = s.VT[n + Nn];
+    if (nm == 0.) { vu = 0.; vv = 0.; s.VT[n] = 0.; s.VT[n + Nn] = 0.; }
+
+    double drag = 0., surface = 0;
+    for (int j = 0; j < m.W1; ++j) {                  // bamg row order (summation order!)
+        const int e = m.n2e[(size_t)j * Nn + n];
+        if (e < 0) continue;                           // Q2
+        double dragp = s.drag_ui[e];
+        if (p.young_cat) {
+            const double c = s.conc[e], cy = s.cyoung[e];
+            if (c + cy > 0.) dragp = (s.drag_ui[e] * c + s.drag_ui_young[e] * cy) / (c + cy);
+        }
+        const double A = w.surface[e];
+        drag += dragp * A;
+        surface += A;
+    }
+    const double wu = s.wind[n], wv = s.wind[n + Nn];
+    drag *= NXS_RHOA * hypot(wu, wv) / surface;        // Q6
+    w.D_tau_a[n] = drag * wu;
+    w.D_tau_a[n + Nn] = drag * wv;
+
+    w.fcor[n] = 2 * NXS_OMEGA * sin(m.lat[n] * NXS_PI / 180.);
+
+    rl = 1. / rl;                                      // FE.cpp:10400-10402
+    nm *= rl;
+    rl *= 3.;
+    w.rlmass[n] = rl;
+    w.node_mass[n] = nm;
+
+    w.VTM[n] = vu;
+    w.VTM[n + Nn] = vv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3a  updateSigmaDamage, FE.cpp:4137-4260, + the element half of K4 (corner forces)
+__global__ void __launch_bounds__(BLOCK) k_sigma_bbm(DevMesh m, DevState s, DevWork w, DevParams p) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= m.Ne) return;
+    const int Ne = m.Ne, Nn = m.Nn;
+    const double dt = p.dte;
+    double dxN[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
+    double sig[3];
+
+    if (w.eskip[e]) {  // FE.cpp:4151-4159
+        s.damage[e] = 0.;
+        sig[0] = sig[1] = sig[2] = 0.;
+    } else {
+        const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
+        double u[3], v[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { u[j] = s.VT[n[j]]; v[j] = s.VT[n[j] + Nn]; }
+        // M_B0T (FE.cpp:10242-10249) rebuilt in registers, zeros included so that the sums below
+        // are the reference's term for term (FE.cpp:4167-4176)
+        double B0T[18];
+#pragma unroll
+        for (int i = 0; i < 18; ++i) B0T[i] = 0.;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            B0T[2 * i] = dxN[i];
+            B0T[2 * i + 13] = dxN[i];
+            B0T[2 * i + 7] = dxN[i + 3];
+            B0T[2 * i + 12] = dxN[i + 3];
+        }
+        double eps[3] = {0., 0., 0.};
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                eps[i] += B0T[i * 6 + 2 * j] * u[j];
+                eps[i] += B0T[i * 6 + 2 * j + 1] * v[j];
+            }
+
+        sig[0] = s.s0[e]; sig[1] = s.s1[e]; sig[2] = s.s2[e];
+        double damage = s.damage[e];
+        const double expC = w.expC[e];
+        double sigma_n = (sig[0] + sig[1]) * 0.5;                                    // FE.cpp:4184
+        const double time_viscous = p.utrs * pow((1. - damage) * expC, p.ers_m1);    // FE.cpp:4186
+        double tildeP;
+        if (sigma_n < 0.) {
+            const double Pmax = w.pmax[e];
+            tildeP = STD_MIN(1., -Pmax / sigma_n);                                   // FE.cpp:4194
+        } else {
+            tildeP = 0.;
+        }
+        const double multiplicator = STD_MIN(1. - 1e-12, time_viscous / (time_viscous + dt * (1. - tildeP)));  // Q3
+        const double elasticity = p.young * (1. - damage) * expC;                    // FE.cpp:4202
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {                                                // FE.cpp:4204-4210
+#pragma unroll
+            for (int j = 0; j < 3; ++j) sig[i] += dt * elasticity * p.D[3 * i + j] * eps[j];
+            sig[i] *= multiplicator;
+        }
+        const double sigma_s = hypot((sig[0] - sig[1]) / 2., sig[2]);                // FE.cpp:4218
+        sigma_n = (sig[0] + sig[1]) * 0.5;
+        double dcrit;
+        if (sigma_n < -p.compr_strength)
+            dcrit = -p.compr_strength / sigma_n;
+        else
+            dcrit = s.cohesion[e] / (sigma_s + p.tan_phi * sigma_n);
+        if ((0. < dcrit) && (dcrit < 1.)) {                                          // FE.cpp:4229-4243
+            const double rtd = sqrt(elasticity) / w.dxs[e];
+            const double del_damage = (1.0 - damage) * (1.0 - dcrit) * dt * rtd;
+            damage += del_damage;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) sig[i] -= sig[i] * (1. - dcrit) * dt * rtd;
+        }
+        damage = STD_MAX(0., damage - w.heal[e]);                                    // FE.cpp:4256
+        s.damage[e] = damage;
+    }
+    s.s0[e] = sig[0]; s.s1[e] = sig[1]; s.s2[e] = sig[2];
+
+    // element half of "gradient sigma" (FE.cpp:10449-10465): the term each corner will subtract
+    const double volume = w.volume[e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        w.force[(size_t)i * Ne + e] = volume * (sig[0] * dxN[i] + sig[2] * dxN[i + 3]);
+        w.force[(size_t)(i + 3) * Ne + e] = volume * (sig[2] * dxN[i] + sig[1] * dxN[i + 3]);
+    }
+}
+
+// K3b  updateSigmaVP, FE.cpp:10649-10699
+__global__ void __launch_bounds__(BLOCK) k_sigma_vp(DevMesh m, DevState s, DevWork w, DevParams p) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= m.Ne) return;
+    const int Ne = m.Ne, Nn = m.Nn;
+    double dxN[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
+    double sig0, sig1, sig2;
+    if (w.eskip[e]) {
+        sig0 = sig1 = sig2 = 0.;
+    } else {
+        const double re2 = 1. / (p.evp_e * p.evp_e);
+        const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
+        double eps11 = 0., eps22 = 0., eps12 = 0.;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double u = s.VT[n[i]], v = s.VT[n[i] + Nn];
+            eps11 += dxN[i] * u;
+            eps22 += dxN[i + 3] * v;
+            eps12 += 0.5 * (dxN[i] * v + dxN[i + 3] * u);
+        }
+        const double eps1 = eps11 + eps22, eps2 = eps11 - eps22;
+        const double delta = sqrt(eps1 * eps1 + (eps2 * eps2 + 4 * eps12 * eps12) * re2);
+        const double P = w.expC[e];
+        const double zeta = P / (delta + p.evp_dmin);
+        sig0 = s.s0[e]; sig1 = s.s1[e]; sig2 = s.s2[e];
+        double sigma1 = sig0 + sig1, sigma2 = sig0 - sig1;
+        sigma1 += p.ralpha1 * (zeta * (eps1 - delta) - sigma1);
+        sigma2 += p.ralpha2 * (zeta * eps2 * re2 - sigma2);
+        sig2 += p.ralpha2 * (zeta * eps12 * re2 - sig2);
+        sig0 = 0.5 * (sigma1 + sigma2);
+        sig1 = 0.5 * (sigma1 - sigma2);
+    }
+    s.s0[e] = sig0; s.s1[e] = sig1; s.s2[e] = sig2;
+    const double volume = w.volume[e];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        w.force[(size_t)i * Ne + e] = volume * (sig0 * dxN[i] + sig2 * dxN[i + 3]);
+        w.force[(size_t)(i + 3) * Ne + e] = volume * (sig2 * dxN[i] + sig1 * dxN[i + 3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K4 (node half) + K5 + K7 for owned nodes, FE.cpp:10445-10553
+// move_dt == 0 -> no mesh move here (mEVP moves once after the loop, FE.cpp:10559-10573)
+__global__ void __launch_bounds__(BLOCK) k_solve_move(DevMesh m, DevState s, DevWork w, DevParams p, double move_dt) {
+    const int n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= m.No) return;
+    const int Nn = m.Nn, Ne = m.Ne;
+    const unsigned char nf = m.nflags[n];
+    const double node_mass = w.node_mass[n];
+    double uice = s.VT[n], vice = s.VT[n + Nn];
+
+    if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
+        // grad_terms = grad_ssh, then minus the corner forces of the fan in ascending element order
+        double gx = w.grad_ssh[n], gy = w.grad_ssh[n + Nn];
+        for (int slot = 0; slot < m.W; ++slot) {
+            const int ent = m.fan[(size_t)slot * Nn + n];
+            if (ent < 0) break;
+            if (ent & 4) continue;  // ghostNodes[i] (FE.cpp:10456)
+            const int e = ent >> 3, c = ent & 3;
+            gx -= w.force[(size_t)c * Ne + e];
+            gy -= w.force[(size_t)(c + 3) * Ne + e];
+        }
+
+        double dtep, delu, delv;
+        if (p.dynamics_type == NXS_DYN_MEVP) {  // FE.cpp:10483-10493
+            const double b_mevp = p.mevp_beta + 1.;
+            delu = (w.VTM[n] - uice) / b_mevp;
+            delv = (w.VTM[n + Nn] - vice) / b_mevp;
+            dtep = p.dte / b_mevp;
+        } else {
+            delu = 0.; delv = 0.; dtep = p.dte;
+        }
+        const double lat = m.lat[n];
+        const double ou = s.ocean[n], ov = s.ocean[n + Nn];
+        const double dte_over_mass = dtep / STD_MAX(p.min_m, node_mass);
+        const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
+        const double tau_b = w.C_bu[n] / (hypot(uice, vice) + p.u0);
+        const double alpha = 1. + dte_over_mass * (c_prime * p.cos_ota + tau_b);
+        const double beta = dtep * w.fcor[n] + dte_over_mass * c_prime * copysign(p.sin_ota, lat);
+        const double rdenom = 1. / (alpha * alpha + beta * beta);
+        const double tau_x = w.D_tau_a[n] + c_prime * (ou * p.cos_ota - ov * copysign(p.sin_ota, lat));
+        const double tau_y = w.D_tau_a[n + Nn] + c_prime * (ov * p.cos_ota + ou * copysign(p.sin_ota, lat));
+        const double rlm = w.rlmass[n];
+        const double grad_x = gx * rlm, grad_y = gy * rlm;
+        double nu_ = alpha * uice + beta * vice + dte_over_mass * (alpha * (grad_x + tau_x) + beta * (grad_y + tau_y)) + alpha * delu + beta * delv;
+        nu_ *= rdenom;
+        double nv_ = alpha * vice - beta * uice + dte_over_mass * (alpha * (grad_y + tau_y) - beta * (grad_x + tau_x)) + alpha * delv - beta * delu;
+        nv_ *= rdenom;
+        uice = nu_; vice = nv_;
+        s.VT[n] = uice;
+        s.VT[n + Nn] = vice;
+    }
+    if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
+        if (!(nf & NF_NEUMANN)) {
+            s.UM[n] += move_dt * uice;
+            s.UM[n + Nn] += move_dt * vice;
+        }
+        s.UT[n] += move_dt * uice;
+        s.UT[n + Nn] += move_dt * vice;
+    }
+}
+
+// mesh move for a node range (mEVP end-of-loop move; ghosts when there is no halo kernel)
+__global__ void __launch_bounds__(BLOCK) k_move(DevMesh m, DevState s, int first, int last, double dt) {
+    const int n = first + blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= last) return;
+    const int Nn = m.Nn;
+    const double u = s.VT[n], v = s.VT[n + Nn];
+    if (!(m.nflags[n] & NF_NEUMANN)) {
+        s.UM[n] += dt * u;
+        s.UM[n + Nn] += dt * v;
+    }
+    s.UT[n] += dt * u;
+    s.UT[n + Nn] += dt * v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6 updateGhosts, FE.cpp:13963-13996.  buf holds, per neighbour k, [u-block | v-block] at 2*off[k].
+__global__ void __launch_bounds__(BLOCK) k_halo_pack(const double *__restrict__ vec, int Nn, int total,
+                                                     const int *__restrict__ index, const int *__restrict__ seg_of,
+                                                     const int *__restrict__ offsets, double *__restrict__ buf) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= total) return;
+    const int k = seg_of[j];
+    const int off = offsets[k], srl = offsets[k + 1] - off;
+    const int idx = index[j];
+    buf[2 * (size_t)off + (j - off)] = vec[idx];
+    buf[2 * (size_t)off + (j - off) + srl] = vec[idx + Nn];
+}
+
+// unpack + (optionally) move the ghost nodes: every ghost node is in exactly one recv list
+__global__ void __launch_bounds__(BLOCK) k_halo_unpack(double *__restrict__ vec, DevMesh m, DevState s, int total,
+                                                       const int *__restrict__ index, const int *__restrict__ seg_of,
+                                                       const int *__restrict__ offsets, const double *__restrict__ buf,
+                                                       double move_dt) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= total) return;
+    const int Nn = m.Nn;
+    const int k = seg_of[j];
+    const int off = offsets[k], srl = offsets[k + 1] - off;
+    const int n = index[j];
+    const double u = buf[2 * (size_t)off + (j - off)];
+    const double v = buf[2 * (size_t)off + (j - off) + srl];
+    vec[n] = u;
+    vec[n + Nn] = v;
+    if (move_dt != 0.) {
+        if (!(m.nflags[n] & NF_NEUMANN)) {
+            s.UM[n] += move_dt * u;
+            s.UM[n + Nn] += move_dt * v;
+        }
+        s.UT[n] += move_dt * u;
+        s.UT[n + Nn] += move_dt * v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8 one Jacobi sweep of the open-water smoother, FE.cpp:10582-10608: src -> dst for every node
+__global__ void __launch_bounds__(BLOCK) k_smooth(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst) {
+    const int n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= m.Nn) return;
+    const int Nn = m.Nn;
+    double u = src[n], v = src[n + Nn];
+    if (n < m.No && !((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) {
+        u = 0.; v = 0.;
+        const int num_neighbours = m.n2n_cnt[n];
+        for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
+            const int nni = m.n2n[(size_t)j * Nn + n];
+            u += src[nni];
+            v += src[nni + Nn];
+        }
+        u /= num_neighbours;
+        v /= num_neighbours;
+    }
+    dst[n] = u;
+    dst[n + Nn] = v;
+}
+
+// K9 FE.cpp:10613-10640
+__global__ void __launch_bounds__(BLOCK) k_ow_tail(DevMesh m, DevState s, DevWork w, DevParams p) {
+    const int n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= m.Nn) return;
+    const int Nn = m.Nn;
+    const double vu = s.VT[n], vv = s.VT[n + Nn];
+    const double uice = 0.5 * (vu + w.VTM[n]);
+    const double vice = 0.5 * (vv + w.VTM[n + Nn]);
+    const double ou = s.ocean[n], ov = s.ocean[n + Nn];
+    const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
+    w.D_tau_w[n] = c_prime * (uice - ou);
+    w.D_tau_w[n + Nn] = c_prime * (vice - ov);
+    const unsigned char nf = m.nflags[n];
+    if ((nf & NF_DIRICHLET) || w.node_mass[n] != 0.) return;
+    if (!(nf & NF_NEUMANN)) {
+        s.UM[n] += p.dtime_step * vu;
+        s.UM[n + Nn] += p.dtime_step * vv;
+    }
+    s.UT[n] += p.dtime_step * vu;
+    s.UT[n + Nn] += p.dtime_step * vv;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K10 update(), FE.cpp:3946-4131
+__global__ void __launch_bounds__(BLOCK) k_update(DevMesh m, DevState s, DevWork w, DevParams p) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= m.Ne) return;
+    const bool to_be_updated = !(m.eflags[e] & EF_ON_NEUMANN);
+    double D_del = 0.;
+    const double surface_old = w.surface[e];
+    double conc = s.conc[e], thick = s.thick[e], snow = s.snow[e], tmyi = s.tmyi[e], cmyi = s.cmyi[e];
+    double ridge = s.ridge[e];
+    double cy = 0., hy = 0., hsy = 0.;
+    if (p.young_cat) { cy = s.cyoung[e]; hy = s.hyoung[e]; hsy = s.hsyoung[e]; }
+    const double old_conc = conc;
+    double vx[3], vy[3];
+    load_vertices(m, s.UM, e, vx, vy);
+    const double surface = (1. / 2) * fabs(jacobian(vx, vy));
+    w.surface[e] = surface;
+    if ((conc > 0.) && to_be_updated) {
+        const double surf_ratio = surface_old / surface;
+        conc *= surf_ratio; thick *= surf_ratio; snow *= surf_ratio; tmyi *= surf_ratio;
+        s.s0[e] *= surf_ratio; s.s1[e] *= surf_ratio; s.s2[e] *= surf_ratio;
+        ridge = 1. - (1. - ridge) * STD_MIN(1., conc) / (old_conc * surf_ratio);
+        if (p.young_cat) { hy *= surf_ratio; cy *= surf_ratio; hsy *= surf_ratio; }
+        if (p.equal_ridging) {
+            const double conc_ratio = STD_MIN(1., conc) / old_conc;
+            cmyi *= conc_ratio;
+            D_del = 0.;
+        } else {
+            cmyi *= surf_ratio;
+            D_del = -cmyi;
+            cmyi = STD_MIN(cmyi, 1.);
+            D_del += cmyi;
+        }
+        D_del *= NXS_DAYS_IN_SEC / p.dtime_step;
+    }
+    double open_water_concentration = 1. - conc;
+    if (p.young_cat) open_water_concentration -= cy;
+    open_water_concentration = (open_water_concentration < 0.) ? 0. : open_water_concentration;
+    open_water_concentration = (open_water_concentration > 1.) ? 1. : open_water_concentration;
+    double new_conc_young = 0., new_h_young = 0., new_hs_young = 0., newice = 0., del_c = 0., newsnow = 0.;
+    const double ridge_young_ice_aspect_ratio = 10.;
+    if (p.young_cat) {
+        if (cy > 0.) {
+            new_conc_young = STD_MIN(1., STD_MAX(0., 1. - conc - open_water_concentration));
+            if ((conc > p.min_c) && (thick > p.min_h) && (new_conc_young < cy)) {
+                new_h_young = new_conc_young * hy / cy;
+                new_hs_young = new_conc_young * hsy / cy;
+                newice = hy - new_h_young;
+                del_c = (cy - new_conc_young) / ridge_young_ice_aspect_ratio;
+                newsnow = hsy - new_hs_young;
+                hy = new_h_young;
+                hsy = new_hs_young;
+                ridge = 1. - (1. - ridge) * thick / (thick + newice);
+                thick += newice;
+                snow += newsnow;
+            }
+        } else {
+            hy = 0.;
+            hsy = 0.;
+        }
+    }
+    conc = STD_MIN(1., STD_MAX(0., 1. - new_conc_young - open_water_concentration + del_c));
+    if (p.young_cat) {
+        new_conc_young = STD_MAX(0., STD_MIN(new_conc_young, 1. - conc));
+        cy = new_conc_young;
+    }
+    const double max_true_thickness = 50.;
+    if (conc > 0.) {
+        double test_h_thick = thick / conc;
+        test_h_thick = (test_h_thick > max_true_thickness) ? max_true_thickness : test_h_thick;
+        conc = STD_MIN(1. - new_conc_young, thick / test_h_thick);
+    } else {
+        ridge = 0.; thick = 0.; snow = 0.;
+    }
+    conc = ((conc > 0.) ? conc : 0.);
+    thick = ((thick > 0.) ? thick : 0.);
+    tmyi = ((tmyi > 0.) ? tmyi : 0.);
+    snow = ((snow > 0.) ? snow : 0.);
+    D_del = -cmyi;
+    if (p.newice_type == 4 && p.use_young_myi)
+        cmyi = STD_MAX(0., STD_MIN(cmyi, conc + cy));
+    else
+        cmyi = STD_MAX(0., STD_MIN(cmyi, conc));
+    D_del += cmyi;
+    s.conc[e] = conc; s.thick[e] = thick; s.snow[e] = snow; s.tmyi[e] = tmyi; s.cmyi[e] = cmyi;
+    s.ridge[e] = ridge;
+    if (p.young_cat) { s.cyoung[e] = cy; s.hyoung[e] = hy; s.hsyoung[e] = hsy; }
+    w.D_del[e] = D_del;
+}
+
+// K13 updateFreeDriftVelocity, FE.cpp:10140-10176
+__global__ void __launch_bounds__(BLOCK) k_free_drift(DevMesh m, DevState s, DevParams p) {
+    const int nd = blockIdx.x * BLOCK + threadIdx.x;
+    if (nd >= m.Nn) return;
+    if (m.nflags[nd] & NF_DIRICHLET) return;
+    const int Nn = m.Nn;
+    const double u = s.VT[nd], v = s.VT[nd + Nn];
+    const double ou = s.ocean[nd], ov = s.ocean[nd + Nn], wu = s.wind[nd], wv = s.wind[nd + Nn];
+    double norm_Voce_ice = hypot(u - ou, v - ov);
+    norm_Voce_ice = (norm_Voce_ice > 0.01) ? norm_Voce_ice : 0.01;
+    double coef_Voce = p.ldw + p.qdw * norm_Voce_ice;
+    coef_Voce *= NXS_RHOW;
+    double norm_Vair_ice = hypot(u - wu, v - wv);
+    norm_Vair_ice = (norm_Vair_ice > 0.01) ? norm_Vair_ice : 0.01;
+    double coef_Vair = p.lda + p.qda * norm_Vair_ice;
+    coef_Vair *= NXS_RHOA;
+    const double nu_ = (coef_Vair * wu + coef_Voce * ou) / (coef_Vair + coef_Voce);
+    const double nv_ = (coef_Vair * wv + coef_Voce * ov) / (coef_Vair + coef_Voce);
+    s.VT[nd] = nu_;
+    s.VT[nd + Nn] = nv_;
+    s.UT[nd] += p.dtime_step * nu_;
+    s.UT[nd + Nn] += p.dtime_step * nv_;
+}
+
+// ------------------------------------------------------------------------------------------------
+// reductions: wave (64 lanes) shuffle -> LDS across the 4 waves of a block -> one partial per block
+struct RegridPartial { double min_angle, min_jac, max_jac; };
+
+__device__ __forceinline__ double wave_min(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = (y < x) ? y : x; }
+    return x;
+}
+__device__ __forceinline__ double wave_max(double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = (x < y) ? y : x; }
+    return x;
+}
+
+// K11 minAngles (FE.cpp:1758-1768) + flip's jacobians (FE.cpp:1824-1839)
+__global__ void __launch_bounds__(BLOCK) k_regrid_partials(DevMesh m, DevState s, RegridPartial *out) {
+    __shared__ double sh[3][BLOCK / 64];
+    double ang = INFINITY, jmin = INFINITY, jmax = -INFINITY;
+    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < m.Ne; e += gridDim.x * BLOCK) {
+        double vx[3], vy[3];
+        load_vertices(m, s.UM, e, vx, vy);
+        double a = hypot(vx[1] - vx[0], vy[1] - vy[0]);
+        double b = hypot(vx[2] - vx[1], vy[2] - vy[1]);
+        double c = hypot(vx[2] - vx[0], vy[2] - vy[0]);
+        double t;  // std::sort of 3
+        if (b < a) { t = a; a = b; b = t; }
+        if (c < b) { t = b; b = c; c = t; }
+        if (b < a) { t = a; a = b; b = t; }
+        double minang = acos((pow(b, 2.) + pow(c, 2.) - pow(a, 2.)) / (2 * b * c));
+        minang = minang * 45.0 / atan(1.0);
+        ang = (minang < ang) ? minang : ang;
+        const double jac = jacobian(vx, vy);
+        jmin = (jac < jmin) ? jac : jmin;
+        jmax = (jmax < jac) ? jac : jmax;
+    }
+    ang = wave_min(ang); jmin = wave_min(jmin); jmax = wave_max(jmax);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][wv] = ang; sh[1][wv] = jmin; sh[2][wv] = jmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < BLOCK / 64; ++i) {
+            ang = (sh[0][i] < ang) ? sh[0][i] : ang;
+            jmin = (sh[1][i] < jmin) ? sh[1][i] : jmin;
+            jmax = (jmax < sh[2][i]) ? sh[2][i] : jmax;
+        }
+        out[blockIdx.x] = RegridPartial{ang, jmin, jmax};
+    }
+}
+
+__global__ void k_regrid_final(const RegridPartial *in, int n, RegridPartial *out) {
+    double ang = INFINITY, jmin = INFINITY, jmax = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += 64) {
+        ang = (in[i].min_angle < ang) ? in[i].min_angle : ang;
+        jmin = (in[i].min_jac < jmin) ? in[i].min_jac : jmin;
+        jmax = (jmax < in[i].max_jac) ? in[i].max_jac : jmax;
+    }
+    ang = wave_min(ang); jmin = wave_min(jmin); jmax = wave_max(jmax);
+    if (threadIdx.x == 0) *out = RegridPartial{ang, jmin, jmax};
+}
+
+// K12 checkFieldsFast (FE.cpp:14536-14655) restricted to this path's fields
+__device__ __forceinline__ bool bad_range(double val, double lo, double hi) {
+    return (val > hi) || (val < lo) || isnan(val);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_check_fields(DevMesh m, DevState s, DevParams p, int *crash) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    bool bad = false;
+    if (i < m.Ne) {
+        bad |= bad_range(s.thick[i], 0., 50.);
+        bad |= bad_range(s.snow[i], 0., 10.);
+        bad |= bad_range(s.conc[i], 0., 1.);
+        bad |= bad_range(s.damage[i], 0., 1.);
+        bad |= bad_range(s.ridge[i], 0., 1.);
+        if (p.young_cat) {
+            bad |= bad_range(s.hyoung[i], 0., 2.);
+            bad |= bad_range(s.hsyoung[i], 0., 2.);
+            bad |= bad_range(s.cyoung[i], 0., 1.);
+        }
+    }
+    if (i < m.Nn) {
+        const double u = s.VT[i], v = s.VT[i + m.Nn];
+        bad |= hypot(u, v) > 5.;
+        bad |= isnan(u + v);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(crash, 1);
+}
+
+// ================================================================================================
+// host side
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Rccl {  // RCCL entry points, resolved at comm_init (no link-time dependency)
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    void *CommInitRank = nullptr;  // ncclCommInitRank(comm*, nranks, ncclUniqueId by value (128 B), rank)
+    int (*CommDestroy)(void *) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+
+}  // namespace
+
+struct NcclId { char internal[128]; };
+typedef int (*nccl_comm_init_rank_t)(void **, int, NcclId, int);
+
+struct nxs_dyn_handle {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    nxs_dyn_params params{};
+    DevParams dp{};
+    bool have_mesh = false, have_state = false, have_forcing = false;
+    DevMesh dm{};
+    DevState ds{};
+    DevWork dw{};
+    std::vector<void *> mesh_allocs, state_allocs;
+    // halo
+    bool have_halo = false;
+    int rank = 0, nranks = 1;
+    std::vector<int> send_procs, send_offsets, recv_procs, recv_offsets;
+    int *d_send_index = nullptr, *d_send_seg = nullptr, *d_send_off = nullptr;
+    int *d_recv_index = nullptr, *d_recv_seg = nullptr, *d_recv_off = nullptr;
+    double *d_send_buf = nullptr, *d_recv_buf = nullptr;
+    std::vector<void *> halo_allocs;
+    Rccl rccl;
+    void *comm = nullptr;
+    // reductions
+    RegridPartial *d_partials = nullptr, *d_regrid = nullptr;
+    int *d_crash = nullptr;
+    int n_partials = 0;
+    // graph of the sub-step loop
+    int use_graph = 1;
+    hipGraphExec_t substep_graph = nullptr;
+    bool graph_valid = false;
+    // timing
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool timing_pending = false, timing_has_update = false;
+    nxs_dyn_timing timing{};
+    int timing_enabled = 1;
+    std::string err;
+};
+
+namespace {
+
+int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, call)                                                                         \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return fail(h, NXS_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(nxs_dyn_handle *h, std::vector<void *> &pool, T **out, size_t count) {
+    void *p = nullptr;
+    HIPCHK(h, hipMalloc(&p, std::max<size_t>(count, 1) * sizeof(T)));
+    pool.push_back(p);
+    *out = static_cast<T *>(p);
+    return NXS_OK;
+}
+
+template <typename T>
+int dev_upload(nxs_dyn_handle *h, std::vector<void *> &pool, const T **out, const std::vector<T> &v) {
+    T *p = nullptr;
+    int rc = dev_alloc(h, pool, &p, v.size());
+    if (rc) return rc;
+    if (!v.empty()) HIPCHK(h, hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // v may be a temporary of the caller
+    *out = p;
+    return NXS_OK;
+}
+
+void free_pool(std::vector<void *> &pool) {
+    for (void *p : pool) (void)hipFree(p);
+    pool.clear();
+}
+
+inline int nblocks(int n) { return n > 0 ? (n + BLOCK - 1) / BLOCK : 1; }
+
+void derive_params(nxs_dyn_handle *h) {
+    const nxs_dyn_params &p = h->params;
+    DevParams &d = h->dp;
+    d.dtime_step = p.dtime_step;
+    d.substeps = p.substeps;
+    d.dte = p.dtime_step / (double)p.substeps;  // FE.cpp:10185
+    d.dynamics_type = p.dynamics_type;
+    d.basal_stress_type = p.basal_stress_type;
+    d.young_cat = p.ice_cat_type == NXS_ICECAT_YOUNG_ICE;
+    d.newice_type = p.newice_type;
+    d.equal_ridging = p.equal_ridging;
+    d.use_young_myi = p.use_young_ice_in_myi_reset;
+    d.young = p.young; d.nu0 = p.nu0; d.tan_phi = p.tan_phi; d.compr_strength = p.compr_strength;
+    d.compaction_param = p.compaction_param;
+    d.utrs = p.undamaged_time_relaxation_sigma;
+    d.ers_m1 = p.exponent_relaxation_sigma - 1.;  // FE.cpp:4186
+    d.compression_factor = p.compression_factor;
+    d.ecf = p.exponent_compression_factor;
+    d.min_h = p.min_h; d.min_c = p.min_c;
+    d.min_m = NXS_RHOI * p.min_h;  // FE.cpp:10191
+    d.qdw = p.quad_drag_coef_water; d.ldw = p.lin_drag_coef_water;
+    d.qda = p.quad_drag_coef_air; d.lda = p.lin_drag_coef_air;
+    d.cos_ota = std::cos(p.ocean_turning_angle_rad);  // FE.cpp:10187-10188
+    d.sin_ota = std::sin(p.ocean_turning_angle_rad);
+    d.k1 = p.basal_k1; d.k2 = p.basal_k2; d.Cb = p.basal_Cb; d.u0 = p.basal_u_0;
+    d.evp_e = p.evp_e; d.evp_Pstar = p.evp_Pstar; d.evp_C = p.evp_C; d.evp_dmin = p.evp_dmin;
+    d.mevp_beta = p.mevp_beta;
+    if (p.dynamics_type == NXS_DYN_EVP) {  // FE.cpp:10705-10713
+        const double T = p.dtime_step / 3.;
+        d.ralpha1 = 0.5 * d.dte / T;
+        d.ralpha2 = 0.5 * d.dte / T * p.evp_e * p.evp_e;
+    } else {  // FE.cpp:10724
+        d.ralpha1 = 1. / p.mevp_alpha;
+        d.ralpha2 = 1. / p.mevp_alpha;
+    }
+    d.sqrt_nu_rhoi = std::sqrt(2. * (1. + p.nu0) * NXS_RHOI);  // FE.cpp:4140
+    // initFETensors, FE.cpp:1491-1507
+    for (double &x : d.D) x = 0.;
+    const double Dunit_factor = 1. / (1. - p.nu0 * p.nu0);
+    d.D[0] = Dunit_factor * 1.;
+    d.D[1] = Dunit_factor * p.nu0;
+    d.D[3] = Dunit_factor * p.nu0;
+    d.D[4] = Dunit_factor * 1.;
+    d.D[8] = Dunit_factor * (1. - p.nu0) / 2.;
+    h->graph_valid = false;
+}
+
+int check_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
+    if (!p) return fail(h, NXS_ERR_INVALID, "params is NULL");
+    if (!(p->dtime_step > 0.) || p->substeps < 1) return fail(h, NXS_ERR_INVALID, "dtime_step/substeps invalid");
+    if (p->dynamics_type < NXS_DYN_BBM || p->dynamics_type > NXS_DYN_MEVP)
+        return fail(h, NXS_ERR_INVALID, "unknown dynamics_type %d (FE.cpp:1352-1358 allows bbm|no_motion|free_drift|evp|mevp)", p->dynamics_type);
+    if (p->basal_stress_type != NXS_BASAL_NONE && p->basal_stress_type != NXS_BASAL_LEMIEUX)
+        return fail(h, NXS_ERR_INVALID, "unknown basal_stress_type %d", p->basal_stress_type);
+    return NXS_OK;
+}
+
+void release_graph(nxs_dyn_handle *h) {
+    if (h->substep_graph) { (void)hipGraphExecDestroy(h->substep_graph); h->substep_graph = nullptr; }
+    h->graph_valid = false;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int nxs_dyn_abi_version(void) { return NXS_DYN_ABI_VERSION; }
+
+const char *nxs_dyn_last_error(const nxs_dyn_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int nxs_dyn_default_params(nxs_dyn_params *p) {  // model/options.cpp:43,80,109-111,314-376,397,545-547
+    if (!p) return NXS_ERR_INVALID;
+    std::memset(p, 0, sizeof *p);
+    p->dtime_step = 200.; p->substeps = 120;
+    p->dynamics_type = NXS_DYN_BBM; p->basal_stress_type = NXS_BASAL_LEMIEUX; p->ice_cat_type = NXS_ICECAT_YOUNG_ICE;
+    p->newice_type = 4; p->equal_ridging = 0; p->use_young_ice_in_myi_reset = 1;
+    p->young = 5.9605e+08; p->nu0 = 1. / 3.; p->tan_phi = 0.7; p->compr_strength = 1e10; p->compaction_param = -20.;
+    p->undamaged_time_relaxation_sigma = 1e7; p->exponent_relaxation_sigma = 5.;
+    p->compression_factor = 10e3; p->exponent_compression_factor = 1.5;
+    p->min_h = 0.05; p->min_c = 0.01;
+    p->quad_drag_coef_water = 0.0055; p->lin_drag_coef_water = 0.; p->quad_drag_coef_air = 0.0049; p->lin_drag_coef_air = 0.;
+    p->ocean_turning_angle_rad = (NXS_PI / 180.) * 25.;
+    p->basal_k1 = 10.; p->basal_k2 = 15.; p->basal_Cb = 20.; p->basal_u_0 = 5e-5;
+    p->evp_e = 2.; p->evp_Pstar = 27.5e3; p->evp_C = 20.; p->evp_dmin = 1e-9;
+    p->mevp_alpha = 500.; p->mevp_beta = 500.;
+    p->regrid_angle = 10.;
+    return NXS_OK;
+}
+
+int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) {
+    if (!out) return fail(nullptr, NXS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NXS_ERR_NO_DEVICE, "no HIP device visible (%s): libnxsdyn has no CPU path",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, NXS_ERR_INVALID, "device %d out of range [0,%d)", device, ndev);
+    nxs_dyn_handle *h = new nxs_dyn_handle();
+    int rc = check_params(h, p);
+    if (rc) { g_create_error = h->err; delete h; return rc; }
+    h->device = device;
+    h->params = *p;
+#define CREATE_CHK(call)                                                                       \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess) {                                                                 \
+            fail(nullptr, NXS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e));           \
+            delete h;                                                                           \
+            return NXS_ERR_HIP;                                                                 \
+        }                                                                                       \
+    } while (0)
+    CREATE_CHK(hipSetDevice(device));
+    CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto &ev : h->ev) CREATE_CHK(hipEventCreate(&ev));
+    CREATE_CHK(hipMalloc((void **)&h->d_regrid, sizeof(RegridPartial)));
+    CREATE_CHK(hipMalloc((void **)&h->d_crash, sizeof(int)));
+#undef CREATE_CHK
+    derive_params(h);
+    *out = h;
+    return NXS_OK;
+}
+
+int nxs_dyn_destroy(nxs_dyn_handle *h) {
+    if (!h) return NXS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    release_graph(h);
+    if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    free_pool(h->mesh_allocs);
+    free_pool(h->state_allocs);
+    free_pool(h->halo_allocs);
+    if (h->d_partials) (void)hipFree(h->d_partials);
+    if (h->d_regrid) (void)hipFree(h->d_regrid);
+    if (h->d_crash) (void)hipFree(h->d_crash);
+    for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return NXS_OK;
+}
+
+int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
+    if (!h) return NXS_ERR_INVALID;
+    int rc = check_params(h, p);
+    if (rc) return rc;
+    h->params = *p;
+    derive_params(h);
+    return NXS_OK;
+}
+
+int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
+    if (!h || !key) return NXS_ERR_INVALID;
+    if (!std::strcmp(key, "graph")) { h->use_graph = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "timing")) { h->timing_enabled = value != 0; return NXS_OK; }
+    return fail(h, NXS_ERR_INVALID, "unknown option '%s'", key);
+}
+
+// ------------------------------------------------------------------------------------------------
+int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
+    if (!h || !m) return NXS_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    const int Nn = m->num_nodes, Ne = m->num_elements, No = m->local_ndof, Neo = m->local_nelements;
+    if (Nn <= 0 || Ne <= 0 || No < 0 || No > Nn || Neo < 0 || Neo > Ne)
+        return fail(h, NXS_ERR_INVALID, "mesh sizes invalid: Nn=%d Ne=%d No=%d Neo=%d", Nn, Ne, No, Neo);
+    if (Ne >= (1 << 28)) return fail(h, NXS_ERR_INVALID, "too many elements for the packed fan entries");
+    if (!m->indices || !m->ghost_nodes || !m->coord_x || !m->coord_y || !m->lat || !m->mask_dirichlet)
+        return fail(h, NXS_ERR_INVALID, "mesh has NULL arrays");
+    if (m->num_neumann_flags < 0 || (m->num_neumann_flags > 0 && !m->neumann_flags))
+        return fail(h, NXS_ERR_INVALID, "neumann_flags invalid");
+    for (int64_t i = 0; i < 3ll * Ne; ++i)
+        if (m->indices[i] < 1 || m->indices[i] > Nn)
+            return fail(h, NXS_ERR_INVALID, "indices[%lld]=%d outside [1,%d] (1-based local ids expected)", (long long)i, m->indices[i], Nn);
+    for (int i = 0; i < m->num_neumann_flags; ++i) {
+        if (m->neumann_flags[i] < 0 || m->neumann_flags[i] >= Nn) return fail(h, NXS_ERR_INVALID, "neumann_flags[%d] out of range", i);
+        if (i > 0 && m->neumann_flags[i] <= m->neumann_flags[i - 1]) return fail(h, NXS_ERR_INVALID, "neumann_flags must be sorted and unique (FE.cpp:251-252)");
+    }
+
+    if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
+    release_graph(h);
+    free_pool(h->mesh_allocs);
+    free_pool(h->state_allocs);
+    free_pool(h->halo_allocs);
+    h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
+    h->rank = 0; h->nranks = 1;
+    h->send_procs.clear(); h->recv_procs.clear(); h->send_offsets.assign(1, 0); h->recv_offsets.assign(1, 0);
+
+    DevMesh &d = h->dm;
+    d = DevMesh{};
+    d.Nn = Nn; d.Ne = Ne; d.No = No; d.Neo = Neo;
+    int rc;
+    // triangles, SoA, 0-based
+    std::vector<int> t[3];
+    for (int k = 0; k < 3; ++k) { t[k].resize(Ne); for (int e = 0; e < Ne; ++e) t[k][e] = m->indices[3 * e + k] - 1; }
+    if ((rc = dev_upload(h, h->mesh_allocs, &d.t0, t[0]))) return rc;
+    if ((rc = dev_upload(h, h->mesh_allocs, &d.t1, t[1]))) return rc;
+    if ((rc = dev_upload(h, h->mesh_allocs, &d.t2, t[2]))) return rc;
+    // node flags
+    std::vector<unsigned char> nf(Nn, 0);
+    for (int n = 0; n < Nn; ++n) if (m->mask_dirichlet[n]) nf[n] |= NF_DIRICHLET;
+    for (int i = 0; i < m->num_neumann_flags; ++i) nf[m->neumann_flags[i]] |= NF_NEUMANN;
+    if ((rc = dev_upload(h, h->mesh_allocs, &d.nflags, nf))) return rc;
+    // element flags
+    std::vector<unsigned char> ef(Ne, 0);
+    for (int e = 0; e < Ne; ++e) {
+        for (int k = 0; k < 3; ++k) {
+            if (m->ghost_nodes[3 * e + k]) ef[e] |= (1 << k);
+            if (nf[t[k][e]] & NF_NEUMANN) ef[e] |= EF_ON_NEUMANN;
+        }
+    }
+    if ((rc = dev_upload(h, h->mesh_allocs, &d.eflags, ef))) return rc;
+    // coordinates
+    {
+        std::vector<double> tmp(m->coord_x, m->coord_x + Nn);
+        if ((rc = dev_upload(h, h->mesh_allocs, &d.x0, tmp))) return rc;
+        tmp.assign(m->coord_y, m->coord_y + Nn);
+        if ((rc = dev_upload(h, h->mesh_allocs, &d.y0, tmp))) return rc;
+        tmp.assign(m->lat, m->lat + Nn);
+        if ((rc = dev_upload(h, h->mesh_allocs, &d.lat, tmp))) return rc;
+    }
+    // ascending element fan of every node (ELL, slot-major)
+    {
+        std::vector<int> deg(Nn, 0);
+        for (int e = 0; e < Ne; ++e) for (int k = 0; k < 3; ++k) deg[t[k][e]]++;
+        int W = 0;
+        for (int n = 0; n < Nn; ++n) W = std::max(W, deg[n]);
+        std::vector<int> fan((size_t)W * Nn, -1), fill(Nn, 0);
+        for (int e = 0; e < Ne; ++e)  // ascending e => ascending rows
+            for (int k = 0; k < 3; ++k) {
+                const int n = t[k][e];
+                fan[(size_t)(fill[n]++) * Nn + n] = (e << 3) | (m->ghost_nodes[3 * e + k] ? 4 : 0) | k;
+            }
+        d.W = W;
+        if ((rc = dev_upload(h, h->mesh_allocs, &d.fan, fan))) return rc;
+    }
+    // bamg tables (given, or built with identical ordering)
+    {
+        std::vector<double> nec_own, nc_own;
+        const double *nec = m->nodal_element_connectivity, *nc = m->nodal_connectivity;
+        int w1 = m->nec_width, w2 = m->nc_width;
+        if (!nec || !nc) {
+            int bw1 = 0, bw2 = 0;
+            if (nxs_mesh_connectivity(m->indices, Nn, Ne, &bw1, nullptr, &bw2, nullptr)) return fail(h, NXS_ERR_INVALID, "connectivity build failed");
+            nec_own.resize((size_t)bw1 * Nn); nc_own.resize((size_t)bw2 * Nn);
+            nxs_mesh_connectivity(m->indices, Nn, Ne, &bw1, nec_own.data(), &bw2, nc_own.data());
+            if (!nec) { nec = nec_own.data(); w1 = bw1; }
+            if (!nc) { nc = nc_own.data(); w2 = bw2; }
+        }
+        if (w1 <= 0 || w2 <= 1) return fail(h, NXS_ERR_INVALID, "connectivity widths invalid (%d, %d)", w1, w2);
+        std::vector<int> n2e((size_t)w1 * Nn, -1);
+        for (int n = 0; n < Nn; ++n)
+            for (int j = 0; j < w1; ++j) {
+                const double v = nec[(size_t)n * w1 + j];
+                if (std::isnan(v)) continue;  // Q2: NaN pad -> skipped
+                const int e = (int)(v - 1);
+                if (e < 0) continue;
+                if (e >= Ne) return fail(h, NXS_ERR_INVALID, "NodalElementConnectivity[%d][%d]=%g beyond %d elements", n, j, v, Ne);
+                n2e[(size_t)j * Nn + n] = e;
+            }
+        std::vector<int> n2n((size_t)(w2 - 1) * Nn, 0), cnt(Nn, 0);
+        for (int n = 0; n < Nn; ++n) {
+            const int c = (int)nc[(size_t)n * w2 + (w2 - 1)];
+            if (c < 0 || c > w2 - 1) return fail(h, NXS_ERR_INVALID, "NodalConnectivity count of node %d invalid (%d)", n, c);
+            cnt[n] = c;
+            for (int j = 0; j < c; ++j) {
+                const int nb = (int)(nc[(size_t)n * w2 + j] - 1);
+                if (nb < 0 || nb >= Nn) return fail(h, NXS_ERR_INVALID, "NodalConnectivity[%d][%d] out of range", n, j);
+                n2n[(size_t)j * Nn + n] = nb;
+            }
+        }
+        d.W1 = w1; d.W2 = w2 - 1;
+        if ((rc = dev_upload(h, h->mesh_allocs, &d.n2e, n2e))) return rc;
+        if ((rc = dev_upload(h, h->mesh_allocs, &d.n2n, n2n))) return rc;
+        if ((rc = dev_upload(h, h->mesh_allocs, &d.n2n_cnt, cnt))) return rc;
+    }
+
+    // state + work arrays
+    DevState &s = h->ds;
+    DevWork &w = h->dw;
+    s = DevState{}; w = DevWork{};
+    auto &P = h->state_allocs;
+    const size_t n2 = 2 * (size_t)Nn, ne = Ne;
+#define A(ptr, cnt) if ((rc = dev_alloc(h, P, &(ptr), (cnt)))) return rc
+    A(s.VT, n2); A(s.VT2, n2); A(s.UM, n2); A(s.UT, n2);
+    A(s.conc, ne); A(s.thick, ne); A(s.snow, ne); A(s.damage, ne); A(s.ridge, ne);
+    A(s.s0, ne); A(s.s1, ne); A(s.s2, ne);
+    A(s.cyoung, ne); A(s.hyoung, ne); A(s.hsyoung, ne); A(s.cmyi, ne); A(s.tmyi, ne);
+    A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
+    A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
+    A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne);
+    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne);
+    A(w.force, 6 * ne);
+    A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
+    A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
+#undef A
+    HIPCHK(h, hipMemsetAsync(w.surface, 0, ne * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(w.delta_x, 0, ne * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(w.D_tau_a, 0, n2 * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(w.D_tau_w, 0, n2 * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(w.D_del, 0, ne * sizeof(double), h->stream));
+
+    if (h->d_partials) { (void)hipFree(h->d_partials); h->d_partials = nullptr; }
+    h->n_partials = std::min(nblocks(Ne), 1024);
+    HIPCHK(h, hipMalloc((void **)&h->d_partials, sizeof(RegridPartial) * h->n_partials));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_mesh = true;
+    return NXS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
+    if (!h || !halo) return NXS_ERR_INVALID;
+    if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "set_halo before set_mesh");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    release_graph(h);
+    free_pool(h->halo_allocs);
+    h->have_halo = false;
+    const int Nn = h->dm.Nn, No = h->dm.No;
+    if (halo->nranks < 1 || halo->rank < 0 || halo->rank >= halo->nranks) return fail(h, NXS_ERR_INVALID, "rank/nranks invalid");
+    const int ns = halo->num_send_procs, nr = halo->num_recv_procs;
+    if (ns < 0 || nr < 0) return fail(h, NXS_ERR_INVALID, "negative neighbour count");
+    h->rank = halo->rank; h->nranks = halo->nranks;
+    h->send_procs.assign(halo->send_procs, halo->send_procs + ns);
+    h->recv_procs.assign(halo->recv_procs, halo->recv_procs + nr);
+    h->send_offsets.assign(halo->send_offsets, halo->send_offsets + ns + 1);
+    h->recv_offsets.assign(halo->recv_offsets, halo->recv_offsets + nr + 1);
+    const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
+    std::vector<int> sidx(halo->send_index, halo->send_index + ts), ridx(halo->recv_index, halo->recv_index + tr);
+    std::vector<int> sseg(ts), rseg(tr);
+    for (int k = 0; k < ns; ++k) {
+        if (h->send_procs[k] < 0 || h->send_procs[k] >= halo->nranks || h->send_procs[k] == halo->rank) return fail(h, NXS_ERR_INVALID, "send_procs[%d] invalid", k);
+        for (int j = h->send_offsets[k]; j < h->send_offsets[k + 1]; ++j) {
+            if (sidx[j] < 0 || sidx[j] >= No) return fail(h, NXS_ERR_INVALID, "send_index[%d]=%d is not an owned node", j, sidx[j]);
+            sseg[j] = k;
+        }
+    }
+    std::vector<char> seen(Nn, 0);
+    for (int k = 0; k < nr; ++k) {
+        if (h->recv_procs[k] < 0 || h->recv_procs[k] >= halo->nranks || h->recv_procs[k] == halo->rank) return fail(h, NXS_ERR_INVALID, "recv_procs[%d] invalid", k);
+        for (int j = h->recv_offsets[k]; j < h->recv_offsets[k + 1]; ++j) {
+            if (ridx[j] < No || ridx[j] >= Nn) return fail(h, NXS_ERR_INVALID, "recv_index[%d]=%d is not a ghost node", j, ridx[j]);
+            if (seen[ridx[j]]) return fail(h, NXS_ERR_INVALID, "ghost node %d received twice", ridx[j]);
+            seen[ridx[j]] = 1;
+            rseg[j] = k;
+        }
+    }
+    if (tr != Nn - No) return fail(h, NXS_ERR_INVALID, "recv lists cover %d of %d ghost nodes", tr, Nn - No);
+    int rc;
+    const int *cp;
+    if ((rc = dev_upload(h, h->halo_allocs, &cp, sidx))) return rc; h->d_send_index = const_cast<int *>(cp);
+    if ((rc = dev_upload(h, h->halo_allocs, &cp, sseg))) return rc; h->d_send_seg = const_cast<int *>(cp);
+    if ((rc = dev_upload(h, h->halo_allocs, &cp, h->send_offsets))) return rc; h->d_send_off = const_cast<int *>(cp);
+    if ((rc = dev_upload(h, h->halo_allocs, &cp, ridx))) return rc; h->d_recv_index = const_cast<int *>(cp);
+    if ((rc = dev_upload(h, h->halo_allocs, &cp, rseg))) return rc; h->d_recv_seg = const_cast<int *>(cp);
+    if ((rc = dev_upload(h, h->halo_allocs, &cp, h->recv_offsets))) return rc; h->d_recv_off = const_cast<int *>(cp);
+    if ((rc = dev_alloc(h, h->halo_allocs, &h->d_send_buf, 2 * (size_t)ts))) return rc;
+    if ((rc = dev_alloc(h, h->halo_allocs, &h->d_recv_buf, 2 * (size_t)tr))) return rc;
+    h->have_halo = true;
+    return NXS_OK;
+}
+
+static int load_rccl(nxs_dyn_handle *h, Rccl &r) {
+    if (r.lib) return NXS_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        r.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (r.lib) break;
+    }
+    if (!r.lib) return fail(h, NXS_ERR_COMM, "cannot dlopen librccl: %s", dlerror());
+#define SYM(field, name)                                                       \
+    *(void **)(&r.field) = dlsym(r.lib, name);                                 \
+    if (!r.field) return fail(h, NXS_ERR_COMM, "librccl lacks %s", name)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return NXS_OK;
+}
+
+int nxs_dyn_comm_unique_id(void *id128) {
+    if (!id128) return NXS_ERR_INVALID;
+    Rccl r;
+    int rc = load_rccl(nullptr, r);
+    if (rc) return rc;
+    int e = r.GetUniqueId(id128);
+    return e == 0 ? NXS_OK : fail(nullptr, NXS_ERR_COMM, "ncclGetUniqueId: %s", r.GetErrorString(e));
+}
+
+int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks) {
+    if (!h || !id128) return NXS_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = load_rccl(h, h->rccl);
+    if (rc) return rc;
+    NcclId id;
+    std::memcpy(id.internal, id128, 128);
+    nccl_comm_init_rank_t init = (nccl_comm_init_rank_t)h->rccl.CommInitRank;
+    int e = init(&h->comm, nranks, id, rank);
+    if (e != 0) return fail(h, NXS_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, h->rccl.GetErrorString(e));
+    return NXS_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s) {
+    if (!h || !s) return NXS_ERR_INVALID;
+    if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "put_state before set_mesh");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n2 = 2 * (size_t)h->dm.Nn * sizeof(double), ne = (size_t)h->dm.Ne * sizeof(double);
+    DevState &d = h->ds;
+    struct { double *dst; const double *src; size_t bytes; const char *name; } cp[] = {
+        {d.VT, s->VT, n2, "VT"}, {d.UM, s->UM, n2, "UM"}, {d.UT, s->UT, n2, "UT"},
+        {d.conc, s->conc, ne, "conc"}, {d.thick, s->thick, ne, "thick"}, {d.snow, s->snow_thick, ne, "snow_thick"},
+        {d.damage, s->damage, ne, "damage"}, {d.ridge, s->ridge_ratio, ne, "ridge_ratio"},
+        {d.s0, s->sigma[0], ne, "sigma[0]"}, {d.s1, s->sigma[1], ne, "sigma[1]"}, {d.s2, s->sigma[2], ne, "sigma[2]"},
+        {d.cyoung, s->conc_young, ne, "conc_young"}, {d.hyoung, s->h_young, ne, "h_young"}, {d.hsyoung, s->hs_young, ne, "hs_young"},
+        {d.cmyi, s->conc_myi, ne, "conc_myi"}, {d.tmyi, s->thick_myi, ne, "thick_myi"},
+        {d.cohesion, s->cohesion, ne, "cohesion"}, {d.theal, s->time_relaxation_damage, ne, "time_relaxation_damage"},
+        {d.drag_ui, s->drag_ui, ne, "drag_ui"}, {d.drag_ui_young, s->drag_ui_young, ne, "drag_ui_young"},
+    };
+    for (auto &c : cp) if (!c.src) return fail(h, NXS_ERR_INVALID, "put_state: %s is NULL", c.name);
+    for (auto &c : cp) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_state = true;
+    return NXS_OK;
+}
+
+int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s) {
+    if (!h || !s) return NXS_ERR_INVALID;
+    if (!h->have_state) return fail(h, NXS_ERR_STATE, "get_state before put_state");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n2 = 2 * (size_t)h->dm.Nn * sizeof(double), ne = (size_t)h->dm.Ne * sizeof(double);
+    DevState &d = h->ds;
+    struct { double *dst; const double *src; size_t bytes; } cp[] = {
+        {s->VT, d.VT, n2}, {s->UM, d.UM, n2}, {s->UT, d.UT, n2},
+        {s->conc, d.conc, ne}, {s->thick, d.thick, ne}, {s->snow_thick, d.snow, ne},
+        {s->damage, d.damage, ne}, {s->ridge_ratio, d.ridge, ne},
+        {s->sigma[0], d.s0, ne}, {s->sigma[1], d.s1, ne}, {s->sigma[2], d.s2, ne},
+        {s->conc_young, d.cyoung, ne}, {s->h_young, d.hyoung, ne}, {s->hs_young, d.hsyoung, ne},
+        {s->conc_myi, d.cmyi, ne}, {s->thick_myi, d.tmyi, ne},
+    };
+    for (auto &c : cp) if (c.dst) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return NXS_OK;
+}
+
+int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f) {
+    if (!h || !f) return NXS_ERR_INVALID;
+    if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "set_forcing before set_mesh");
+    if (!f->wind || !f->ocean || !f->ssh || !f->element_depth) return fail(h, NXS_ERR_INVALID, "forcing has NULL arrays");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t Nn = h->dm.Nn, Ne = h->dm.Ne;
+    HIPCHK(h, hipMemcpyAsync(h->ds.wind, f->wind, 2 * Nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->ds.ocean, f->ocean, 2 * Nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->ds.ssh, f->ssh, Nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->ds.depth, f->element_depth, Ne * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_forcing = true;
+    return NXS_OK;
+}
+
+int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *dg) {
+    if (!h || !dg) return NXS_ERR_INVALID;
+    if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "get_diag before set_mesh");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t n2 = 2 * (size_t)h->dm.Nn * sizeof(double), ne = (size_t)h->dm.Ne * sizeof(double);
+    if (dg->surface) HIPCHK(h, hipMemcpyAsync(dg->surface, h->dw.surface, ne, hipMemcpyDeviceToHost, h->stream));
+    if (dg->delta_x) HIPCHK(h, hipMemcpyAsync(dg->delta_x, h->dw.delta_x, ne, hipMemcpyDeviceToHost, h->stream));
+    if (dg->D_tau_a) HIPCHK(h, hipMemcpyAsync(dg->D_tau_a, h->dw.D_tau_a, n2, hipMemcpyDeviceToHost, h->stream));
+    if (dg->D_tau_w) HIPCHK(h, hipMemcpyAsync(dg->D_tau_w, h->dw.D_tau_w, n2, hipMemcpyDeviceToHost, h->stream));
+    if (dg->D_del_ci_ridge_myi) HIPCHK(h, hipMemcpyAsync(dg->D_del_ci_ridge_myi, h->dw.D_del, ne, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return NXS_OK;
+}
+
+// debug / test door: copy a named work array to the host (n doubles)
+int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_t n) {
+    if (!h || !name || !out) return NXS_ERR_INVALID;
+    if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "debug_array before set_mesh");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int64_t Nn = h->dm.Nn, Ne = h->dm.Ne;
+    struct { const char *nm; const double *p; int64_t len; } tab[] = {
+        {"rlmass", h->dw.rlmass, Nn}, {"node_mass", h->dw.node_mass, Nn}, {"C_bu", h->dw.C_bu, Nn},
+        {"grad_ssh", h->dw.grad_ssh, 2 * Nn}, {"fcor", h->dw.fcor, Nn}, {"VTM", h->dw.VTM, 2 * Nn},
+        {"shape", h->dw.shape, 6 * Ne}, {"emass", h->dw.emass, Ne}, {"ecbu", h->dw.ecbu, Ne},
+        {"force", h->dw.force, 6 * Ne}, {"volume", h->dw.volume, Ne}, {"expC", h->dw.expC, Ne},
+    };
+    for (auto &t : tab)
+        if (!std::strcmp(t.nm, name)) {
+            if (n != t.len) return fail(h, NXS_ERR_INVALID, "debug_array %s has %lld entries, caller asked %lld", name, (long long)t.len, (long long)n);
+            HIPCHK(h, hipMemcpyAsync(out, t.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            return NXS_OK;
+        }
+    return fail(h, NXS_ERR_INVALID, "unknown debug array '%s'", name);
+}
+
+// ------------------------------------------------------------------------------------------------
+// the launches
+
+namespace {
+
+#define LAUNCH(h, kern, n, ...)                                                              \
+    do {                                                                                      \
+        hipLaunchKernelGGL(kern, dim3(nblocks(n)), dim3(BLOCK), 0, (h)->stream, __VA_ARGS__); \
+    } while (0)
+
+int halo_exchange(nxs_dyn_handle *h, double *vec, double move_dt) {
+    // updateGhosts (FE.cpp:13963-13996): pack -> grouped send/recv -> unpack
+    const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
+    const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
+    if (!h->comm) return fail(h, NXS_ERR_STATE, "halo exchange needs nxs_dyn_comm_init");
+    if (ts > 0) LAUNCH(h, k_halo_pack, ts, vec, h->dm.Nn, ts, h->d_send_index, h->d_send_seg, h->d_send_off, h->d_send_buf);
+    const int ncclDouble = 8;  // ncclFloat64
+    int e = h->rccl.GroupStart();
+    for (int k = 0; k < ns && e == 0; ++k)
+        e = h->rccl.Send(h->d_send_buf + 2 * (size_t)h->send_offsets[k], 2 * (size_t)(h->send_offsets[k + 1] - h->send_offsets[k]),
+                         ncclDouble, h->send_procs[k], h->comm, h->stream);
+    for (int k = 0; k < nr && e == 0; ++k)
+        e = h->rccl.Recv(h->d_recv_buf + 2 * (size_t)h->recv_offsets[k], 2 * (size_t)(h->recv_offsets[k + 1] - h->recv_offsets[k]),
+                         ncclDouble, h->recv_procs[k], h->comm, h->stream);
+    int e2 = h->rccl.GroupEnd();
+    if (e == 0) e = e2;
+    if (e != 0) return fail(h, NXS_ERR_COMM, "halo send/recv: %s", h->rccl.GetErrorString(e));
+    if (tr > 0) LAUNCH(h, k_halo_unpack, tr, vec, h->dm, h->ds, tr, h->d_recv_index, h->d_recv_seg, h->d_recv_off, h->d_recv_buf, move_dt);
+    return NXS_OK;
+}
+
+bool multi_rank(const nxs_dyn_handle *h) { return h->nranks > 1; }
+
+void launch_substep(nxs_dyn_handle *h, double move_dt) {
+    if (h->dp.dynamics_type == NXS_DYN_BBM)
+        LAUNCH(h, k_sigma_bbm, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    else
+        LAUNCH(h, k_sigma_vp, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    LAUNCH(h, k_solve_move, h->dm.No, h->dm, h->ds, h->dw, h->dp, move_dt);
+}
+
+int run_substeps(nxs_dyn_handle *h) {
+    const int S = h->dp.substeps;
+    const double move_dt = (h->dp.dynamics_type == NXS_DYN_MEVP) ? 0. : h->dp.dte;
+    if (multi_rank(h)) {
+        for (int s = 0; s < S; ++s) {
+            launch_substep(h, move_dt);
+            int rc = halo_exchange(h, h->ds.VT, move_dt);
+            if (rc) return rc;
+        }
+        h->timing.substep_launches = S * 4;
+        return NXS_OK;
+    }
+    h->timing.substep_launches = S * 2;
+    if (!h->use_graph) {
+        for (int s = 0; s < S; ++s) launch_substep(h, move_dt);
+        return NXS_OK;
+    }
+    if (!h->graph_valid) {
+        release_graph(h);
+        hipGraph_t g = nullptr;
+        HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+        for (int s = 0; s < S; ++s) launch_substep(h, move_dt);
+        HIPCHK(h, hipStreamEndCapture(h->stream, &g));
+        hipError_t e = hipGraphInstantiate(&h->substep_graph, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e != hipSuccess) return fail(h, NXS_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        h->graph_valid = true;
+    }
+    HIPCHK(h, hipGraphLaunch(h->substep_graph, h->stream));
+    return NXS_OK;
+}
+
+int ready(nxs_dyn_handle *h) {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->have_mesh || !h->have_state || !h->have_forcing)
+        return fail(h, NXS_ERR_STATE, "step needs set_mesh, put_state and set_forcing first");
+    if (multi_rank(h) && !h->have_halo) return fail(h, NXS_ERR_STATE, "nranks>1 needs set_halo");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(h, NXS_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+    return NXS_OK;
+}
+
+int explicit_solve(nxs_dyn_handle *h, bool timed) {
+    // FE.cpp:10182-10643
+    const DevMesh &m = h->dm;
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    LAUNCH(h, k_prep_elements, m.Ne, m, h->ds, h->dw, h->dp);
+    LAUNCH(h, k_prep_nodes, m.Nn, m, h->ds, h->dw, h->dp);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    int rc = run_substeps(h);
+    if (rc) return rc;
+    if (h->dp.dynamics_type == NXS_DYN_MEVP)  // FE.cpp:10559-10573
+        LAUNCH(h, k_move, m.Nn, m, h->ds, 0, m.Nn, h->dp.dtime_step);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    // Q9: 50 sweeps, hard-coded (FE.cpp:10580)
+    double *a = h->ds.VT, *b = h->ds.VT2;
+    for (int nit = 0; nit < 50; ++nit) {
+        LAUNCH(h, k_smooth, m.Nn, m, h->dw, a, b);
+        if (multi_rank(h)) { rc = halo_exchange(h, b, 0.); if (rc) return rc; }
+        std::swap(a, b);
+    }
+    // 50 is even: the result is back in ds.VT
+    LAUNCH(h, k_ow_tail, m.Nn, m, h->ds, h->dw, h->dp);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    return NXS_OK;
+}
+
+}  // namespace
+
+int nxs_dyn_explicit_solve(nxs_dyn_handle *h) {
+    int rc = ready(h);
+    if (rc) return rc;
+    h->timing_pending = false;
+    return explicit_solve(h, false);
+}
+
+int nxs_dyn_update(nxs_dyn_handle *h) {
+    int rc = ready(h);
+    if (rc) return rc;
+    LAUNCH(h, k_update, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    return NXS_OK;
+}
+
+int nxs_dyn_step(nxs_dyn_handle *h) {  // FE.cpp:8197-8214
+    int rc = ready(h);
+    if (rc) return rc;
+    const int type = h->dp.dynamics_type;
+    if (type == NXS_DYN_FREE_DRIFT) {
+        LAUNCH(h, k_free_drift, h->dm.Nn, h->dm, h->ds, h->dp);
+        return NXS_OK;
+    }
+    if (type == NXS_DYN_NO_MOTION) return NXS_OK;
+    const bool timed = h->timing_enabled;
+    rc = explicit_solve(h, timed);
+    if (rc) return rc;
+    LAUNCH(h, k_update, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    if (timed) { HIPCHK(h, hipEventRecord(h->ev[4], h->stream)); h->timing_pending = true; }
+    return NXS_OK;
+}
+
+int nxs_dyn_synchronize(nxs_dyn_handle *h) {
+    if (!h) return NXS_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    HIPCHK(h, hipGetLastError());
+    return NXS_OK;
+}
+
+int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t) {
+    if (!h || !t) return NXS_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (h->timing_pending) {
+        HIPCHK(h, hipEventSynchronize(h->ev[4]));
+        float ms[4];
+        for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
+        h->timing.prep_ms = ms[0]; h->timing.substeps_ms = ms[1]; h->timing.smoother_ms = ms[2]; h->timing.update_ms = ms[3];
+        h->timing.total_ms = (double)ms[0] + ms[1] + ms[2] + ms[3];
+        h->timing_pending = false;
+    }
+    *t = h->timing;
+    return NXS_OK;
+}
+
+int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f) {
+    int rc;
+    if ((rc = nxs_dyn_put_state(h, s))) return rc;
+    if ((rc = nxs_dyn_set_forcing(h, f))) return rc;
+    if ((rc = nxs_dyn_step(h))) return rc;
+    return nxs_dyn_get_state(h, s);
+}
+
+int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32_t *flip, int32_t *regrid_local) {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->have_mesh || !h->have_state) return fail(h, NXS_ERR_STATE, "check_regridding needs set_mesh and put_state");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_regrid_partials, dim3(h->n_partials), dim3(BLOCK), 0, h->stream, h->dm, h->ds, h->d_partials);
+    hipLaunchKernelGGL(k_regrid_final, dim3(1), dim3(64), 0, h->stream, h->d_partials, h->n_partials, h->d_regrid);
+    RegridPartial r;
+    HIPCHK(h, hipMemcpyAsync(&r, h->d_regrid, sizeof r, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const int fl = (r.min_jac <= 0.) && (r.max_jac >= 0.);  // FE.cpp:1838
+    if (min_angle) *min_angle = r.min_angle;
+    if (flip) *flip = fl;
+    if (regrid_local) *regrid_local = (r.min_angle < h->params.regrid_angle) || fl;  // FE.cpp:8303-8305
+    return NXS_OK;
+}
+
+int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local) {
+    if (!h || !crash_local) return NXS_ERR_INVALID;
+    if (!h->have_mesh || !h->have_state) return fail(h, NXS_ERR_STATE, "check_fields_fast needs set_mesh and put_state");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemsetAsync(h->d_crash, 0, sizeof(int), h->stream));
+    LAUNCH(h, k_check_fields, std::max(h->dm.Ne, h->dm.Nn), h->dm, h->ds, h->dp, h->d_crash);
+    int c = 0;
+    HIPCHK(h, hipMemcpyAsync(&c, h->d_crash, sizeof c, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *crash_local = c;
+    return NXS_OK;
+}
+
+}  // extern "C"

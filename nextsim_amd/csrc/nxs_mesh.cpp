@@ -1,0 +1,100 @@
+// nxs_mesh.cpp -- host-side mesh tables for libnxsdyn.so.
+//
+// nxs_mesh_connectivity() produces the two tables the hot path reads from bamgmesh
+// (FE.cpp:10376-10379 NodalElementConnectivity, FE.cpp:10578-10602 NodalConnectivity) with the
+// same content AND the same row ordering as BamgConvertMeshx -> Mesh::WriteMesh
+// (contrib/bamg/src/Mesh.cpp:514-543, 579-630, 798-865), because the row order is the
+// floating-point summation order of the air-drag average and of the open-water smoother.
+//
+//   element fan of a vertex : elements in DESCENDING number (bamg walks a LIFO chain)
+//   neighbours of a vertex  : edge ends in reverse order of edge creation, where edges are created
+//                             by first appearance over triangles 0..Ne-1, local edges
+//                             (1,2),(2,0),(0,1); an edge is stored oriented as in the triangle
+//                             that created it.
+//
+// Checked against the real contrib/bamg in tests/test_connectivity.py.
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "nxs_dyn.h"
+
+namespace {
+
+struct EdgeRec {
+    int32_t a, b;      // sorted ends (0-based)
+    int32_t first, second;  // oriented ends as seen in the creating triangle (0-based)
+};
+
+}  // namespace
+
+extern "C" int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
+                                     int32_t *nec_width, double *nec, int32_t *nc_width, double *nc) {
+    if (!indices || num_nodes <= 0 || num_elements <= 0) return NXS_ERR_INVALID;
+    const int64_t Nn = num_nodes, Ne = num_elements;
+    for (int64_t i = 0; i < 3 * Ne; ++i)
+        if (indices[i] < 1 || indices[i] > num_nodes) return NXS_ERR_INVALID;
+
+    // ---- element fans: count, then fill back to front so rows come out in descending order ----
+    std::vector<int32_t> deg(Nn, 0);
+    for (int64_t i = 0; i < 3 * Ne; ++i) deg[indices[i] - 1]++;
+    int32_t w1 = 0;
+    for (int64_t v = 0; v < Nn; ++v) w1 = deg[v] > w1 ? deg[v] : w1;
+    if (nec_width) *nec_width = w1;
+    if (nec) {
+        const double nan = std::nan("");
+        for (int64_t i = 0; i < Nn * w1; ++i) nec[i] = nan;
+        std::vector<int32_t> left(deg);  // entries still to place per vertex
+        for (int64_t e = 0; e < Ne; ++e)
+            for (int k = 0; k < 3; ++k) {
+                const int64_t v = indices[3 * e + k] - 1;
+                // the j-th visit (0-based) of v ends up at column deg-1-j
+                nec[v * w1 + (--left[v])] = double(e + 1);
+            }
+    }
+
+    // ---- unique edges in creation order (hash chain on the smaller end, like SetOfEdges4) ----
+    static const int LE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+    std::vector<EdgeRec> edges;
+    edges.reserve(size_t(3 * Ne / 2 + Nn));
+    std::vector<int32_t> head(Nn, -1), nxt;
+    nxt.reserve(edges.capacity());
+    for (int64_t t = 0; t < Ne; ++t)
+        for (int j = 0; j < 3; ++j) {
+            const int32_t p = indices[3 * t + LE[j][0]] - 1, q = indices[3 * t + LE[j][1]] - 1;
+            const int32_t a = p <= q ? p : q, b = p <= q ? q : p;
+            int32_t n = head[a];
+            while (n >= 0 && !(edges[n].a == a && edges[n].b == b)) n = nxt[n];
+            if (n >= 0) continue;
+            // orientation: find the sorted-first end `a` in the triangle; if its successor is `b`
+            // keep (a,b) else store (b,a)   (Mesh.cpp:609-627)
+            EdgeRec r{a, b, a, b};
+            for (int k = 0; k < 3; ++k)
+                if (indices[3 * t + k] - 1 == a) {
+                    if (indices[3 * t + (k + 1) % 3] - 1 != b) { r.first = b; r.second = a; }
+                    break;
+                }
+            nxt.push_back(head[a]);
+            head[a] = int32_t(edges.size());
+            edges.push_back(r);
+        }
+
+    std::vector<int32_t> ndeg(Nn, 0);
+    for (const EdgeRec &r : edges) { ndeg[r.first]++; ndeg[r.second]++; }
+    int32_t w2 = 0;
+    for (int64_t v = 0; v < Nn; ++v) w2 = ndeg[v] > w2 ? ndeg[v] : w2;
+    w2 += 1;  // last column = neighbour count
+    if (nc_width) *nc_width = w2;
+    if (nc) {
+        for (int64_t i = 0; i < Nn * w2; ++i) nc[i] = 0.;
+        std::vector<int32_t> left(ndeg);
+        // chain insertion order is edge 0 end 0, edge 0 end 1, edge 1 end 0, ... ; rows are read
+        // newest first, so the j-th insertion for v lands at column ndeg-1-j
+        for (const EdgeRec &r : edges) {
+            nc[int64_t(r.first) * w2 + (--left[r.first])] = double(r.second + 1);
+            nc[int64_t(r.second) * w2 + (--left[r.second])] = double(r.first + 1);
+        }
+        for (int64_t v = 0; v < Nn; ++v) nc[v * w2 + (w2 - 1)] = double(ndeg[v]);
+    }
+    return NXS_OK;
+}

@@ -1,0 +1,242 @@
+"""Host-side mirror of the reference's call surface for the dynamics path, over the C ABI.
+
+`FiniteElementDynamics` keeps the names of FiniteElement's methods on this path
+(model/finiteelement.hpp:162-164 and FE.cpp:8197-8214): `explicitSolve()`, `update()`, `step()`,
+`checkRegridding()`, `checkFieldsFast()`, `updateGhosts` happens inside.  Every call goes through
+libnxsdyn.so (include/nxs_dyn.h); there is no Python or CPU compute path here, and a missing
+library or GPU is an error, never a fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import _abi
+
+_LIB = None
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnxsdyn.so")
+
+
+class NxsError(RuntimeError):
+    def __init__(self, code: int, what: str):
+        super().__init__(f"{_abi.ERRORS.get(code, code)}: {what}")
+        self.code = code
+
+
+def build_library(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of nextsim_amd/csrc (cross-compiles without a GPU)."""
+    src_dir = os.path.dirname(_LIB_PATH)
+    args = ["make", "-s", "-C", src_dir]
+    if force:
+        args.insert(1, "-B")
+    subprocess.check_call(args)
+    return _LIB_PATH
+
+
+def load_library():
+    """dlopen libnxsdyn.so and declare every symbol of include/nxs_dyn.h.  Raises if absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(_LIB_PATH):
+        raise NxsError(-2, f"{_LIB_PATH} is missing: build it with __graft_entry__.build() "
+                           "(there is no CPU fallback for the dynamics path)")
+    L = C.CDLL(_LIB_PATH)
+    P = C.POINTER
+    H = C.c_void_p
+    L.nxs_dyn_abi_version.restype = C.c_int
+    L.nxs_dyn_last_error.restype = C.c_char_p
+    L.nxs_dyn_last_error.argtypes = [H]
+    L.nxs_dyn_default_params.argtypes = [P(_abi.Params)]
+    L.nxs_dyn_create.argtypes = [P(_abi.Params), C.c_int, P(H)]
+    L.nxs_dyn_destroy.argtypes = [H]
+    L.nxs_dyn_set_params.argtypes = [H, P(_abi.Params)]
+    L.nxs_dyn_set_mesh.argtypes = [H, P(_abi.Mesh)]
+    L.nxs_dyn_set_halo.argtypes = [H, P(_abi.Halo)]
+    L.nxs_dyn_comm_unique_id.argtypes = [C.c_void_p]
+    L.nxs_dyn_comm_init.argtypes = [H, C.c_void_p, C.c_int, C.c_int]
+    L.nxs_dyn_put_state.argtypes = [H, P(_abi.State)]
+    L.nxs_dyn_get_state.argtypes = [H, P(_abi.State)]
+    L.nxs_dyn_set_forcing.argtypes = [H, P(_abi.Forcing)]
+    L.nxs_dyn_get_diag.argtypes = [H, P(_abi.Diag)]
+    L.nxs_dyn_step.argtypes = [H]
+    L.nxs_dyn_explicit_solve.argtypes = [H]
+    L.nxs_dyn_update.argtypes = [H]
+    L.nxs_dyn_synchronize.argtypes = [H]
+    L.nxs_dyn_step_host.argtypes = [H, P(_abi.State), P(_abi.Forcing)]
+    L.nxs_dyn_check_regridding.argtypes = [H, P(C.c_double), P(C.c_int32), P(C.c_int32)]
+    L.nxs_dyn_check_fields_fast.argtypes = [H, P(C.c_int32)]
+    L.nxs_dyn_get_timing.argtypes = [H, P(_abi.Timing)]
+    L.nxs_dyn_set_option.argtypes = [H, C.c_char_p, C.c_int64]
+    L.nxs_dyn_debug_array.argtypes = [H, C.c_char_p, _abi.c_double_p, C.c_int64]
+    L.nxs_mesh_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, P(C.c_int32), _abi.c_double_p,
+                                        P(C.c_int32), _abi.c_double_p]
+    for name in EXPORTS:
+        getattr(L, name)  # raises AttributeError if a declared symbol is not exported
+        if name not in ("nxs_dyn_last_error",):
+            getattr(L, name).restype = C.c_int
+    L.nxs_dyn_last_error.restype = C.c_char_p
+    if L.nxs_dyn_abi_version() != 1:
+        raise NxsError(-1, "libnxsdyn.so ABI version mismatch")
+    _LIB = L
+    return L
+
+
+# every symbol include/nxs_dyn.h declares
+EXPORTS = (
+    "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_create", "nxs_dyn_destroy",
+    "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init",
+    "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_get_diag", "nxs_dyn_step",
+    "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
+    "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
+    "nxs_dyn_debug_array", "nxs_mesh_connectivity",
+)
+
+
+def mesh_connectivity(indices: np.ndarray, num_nodes: int):
+    """(NodalElementConnectivity, NodalConnectivity) in bamg's layout and row order (host code of the
+    product library; the stand-in for BamgConvertMeshx at FE.cpp:77-80)."""
+    L = load_library()
+    ne = indices.size // 3
+    w1, w2 = C.c_int32(), C.c_int32()
+    rc = L.nxs_mesh_connectivity(_abi.iptr(indices), num_nodes, ne, C.byref(w1), None, C.byref(w2), None)
+    if rc:
+        raise NxsError(rc, "nxs_mesh_connectivity")
+    nec = np.empty((num_nodes, w1.value))
+    nc = np.empty((num_nodes, w2.value))
+    rc = L.nxs_mesh_connectivity(_abi.iptr(indices), num_nodes, ne, C.byref(w1), _abi.dptr(nec), C.byref(w2), _abi.dptr(nc))
+    if rc:
+        raise NxsError(rc, "nxs_mesh_connectivity")
+    return nec, nc
+
+
+class FiniteElementDynamics:
+    """The dynamics part of FiniteElement on one GPU (one MPI-rank equivalent)."""
+
+    def __init__(self, params: _abi.Params, device: int = 0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        self.params = params.copy()
+        rc = self.L.nxs_dyn_create(C.byref(self.params), device, C.byref(self.h))
+        if rc:
+            raise NxsError(rc, (self.L.nxs_dyn_last_error(None) or b"").decode())
+        self.lm = None
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.nxs_dyn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc:
+            raise NxsError(rc, (self.L.nxs_dyn_last_error(self.h) or b"").decode())
+
+    # ---- setup (distributedMeshProcessing / initUpdateGhosts) ----
+    def set_params(self, params: _abi.Params):
+        self.params = params.copy()
+        self._chk(self.L.nxs_dyn_set_params(self.h, C.byref(self.params)))
+
+    def set_mesh(self, lm, tables=None):
+        m = _abi.mesh_struct(lm, tables)
+        self._chk(self.L.nxs_dyn_set_mesh(self.h, C.byref(m)))
+        self.lm = lm
+        if lm.nranks > 1:
+            hs = _abi.halo_struct(lm)
+            self._chk(self.L.nxs_dyn_set_halo(self.h, C.byref(hs)))
+
+    def comm_init(self, unique_id: bytes, rank: int, nranks: int):
+        buf = C.create_string_buffer(unique_id, 128)
+        self._chk(self.L.nxs_dyn_comm_init(self.h, buf, rank, nranks))
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        L = load_library()
+        buf = C.create_string_buffer(128)
+        rc = L.nxs_dyn_comm_unique_id(buf)
+        if rc:
+            raise NxsError(rc, (L.nxs_dyn_last_error(None) or b"").decode())
+        return buf.raw
+
+    def set_option(self, key: str, value: int):
+        self._chk(self.L.nxs_dyn_set_option(self.h, key.encode(), int(value)))
+
+    # ---- data movement ----
+    def put_state(self, arrays: dict):
+        s = _abi.state_struct(arrays)
+        self._chk(self.L.nxs_dyn_put_state(self.h, C.byref(s)))
+
+    def set_forcing(self, arrays: dict):
+        f = _abi.forcing_struct(arrays)
+        self._chk(self.L.nxs_dyn_set_forcing(self.h, C.byref(f)))
+
+    def get_state(self) -> dict:
+        Nn, Ne = self.lm.num_nodes, self.lm.num_elements
+        out = {k: np.empty(2 * Nn) for k in _abi.STATE_NODAL}
+        out.update({k: np.empty(Ne) for k in _abi.STATE_ELEMENT})
+        s = _abi.State()
+        for k in _abi.STATE_NODAL:
+            setattr(s, k, _abi.dptr(out[k]))
+        for k in _abi.STATE_ELEMENT:
+            if k.startswith("sigma"):
+                s.sigma[int(k[-1])] = _abi.dptr(out[k])
+            else:
+                setattr(s, k, _abi.dptr(out[k]))
+        self._chk(self.L.nxs_dyn_get_state(self.h, C.byref(s)))
+        return out
+
+    def get_diag(self) -> dict:
+        Nn, Ne = self.lm.num_nodes, self.lm.num_elements
+        out = {"surface": np.empty(Ne), "delta_x": np.empty(Ne), "D_tau_a": np.empty(2 * Nn),
+               "D_tau_w": np.empty(2 * Nn), "D_del_ci_ridge_myi": np.empty(Ne)}
+        d = _abi.Diag()
+        for k, v in out.items():
+            setattr(d, k, _abi.dptr(v))
+        self._chk(self.L.nxs_dyn_get_diag(self.h, C.byref(d)))
+        return out
+
+    def debug_array(self, name: str) -> np.ndarray:
+        Nn, Ne = self.lm.num_nodes, self.lm.num_elements
+        n = {"rlmass": Nn, "node_mass": Nn, "C_bu": Nn, "grad_ssh": 2 * Nn, "fcor": Nn, "VTM": 2 * Nn,
+             "shape": 6 * Ne, "emass": Ne, "ecbu": Ne, "force": 6 * Ne, "volume": Ne, "expC": Ne}[name]
+        out = np.empty(n)
+        self._chk(self.L.nxs_dyn_debug_array(self.h, name.encode(), _abi.dptr(out), n))
+        return out
+
+    # ---- the reference's call surface ----
+    def step(self):
+        """FE.cpp:8197-8214: UM_P = M_UM; explicitSolve(); update(UM_P) (or free drift / no motion)."""
+        self._chk(self.L.nxs_dyn_step(self.h))
+
+    def explicitSolve(self):
+        self._chk(self.L.nxs_dyn_explicit_solve(self.h))
+
+    def update(self):
+        self._chk(self.L.nxs_dyn_update(self.h))
+
+    def synchronize(self):
+        self._chk(self.L.nxs_dyn_synchronize(self.h))
+
+    def checkRegridding(self):
+        ang, flip, rg = C.c_double(), C.c_int32(), C.c_int32()
+        self._chk(self.L.nxs_dyn_check_regridding(self.h, C.byref(ang), C.byref(flip), C.byref(rg)))
+        return ang.value, flip.value, rg.value
+
+    def checkFieldsFast(self) -> int:
+        c = C.c_int32()
+        self._chk(self.L.nxs_dyn_check_fields_fast(self.h, C.byref(c)))
+        return c.value
+
+    def timing(self) -> dict:
+        t = _abi.Timing()
+        self._chk(self.L.nxs_dyn_get_timing(self.h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in _abi.Timing._fields_ if k != "reserved0"}

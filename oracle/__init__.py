@@ -1,0 +1,1 @@
+"""CPU oracle -- test infrastructure only (see oracle/dyn_ref.h)."""
