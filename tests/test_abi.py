@@ -1,0 +1,85 @@
+"""The C-ABI library: loads, exports every symbol include/nxs_dyn.h declares, ctypes layouts match the
+C structs, and -- on a box without a GPU -- refuses to work instead of falling back to the CPU."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from nextsim_amd import _abi, dynamics
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nxs_dyn.h")
+
+
+def test_every_declared_symbol_is_exported():
+    text = open(HEADER).read()
+    declared = set(re.findall(r"NXS_API\s+(?:const\s+char\s*\*|int)\s*(nxs_\w+)\s*\(", text))
+    assert declared and declared == set(dynamics.EXPORTS)
+    L = dynamics.load_library()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.nxs_dyn_abi_version() == 1
+
+
+def test_library_does_not_depend_on_the_oracle_or_torch():
+    out = subprocess.check_output(["readelf", "-d", dynamics._LIB_PATH], text=True)
+    needed = re.findall(r"NEEDED.*\[(.*)\]", out)
+    assert not any("oracle" in n or "torch" in n or "c10" in n for n in needed), needed
+    assert any("amdhip64" in n for n in needed)
+
+
+def test_ctypes_layouts_match_the_header(tmp_path):
+    src = tmp_path / "sz.c"
+    structs = {"nxs_dyn_params": _abi.Params, "nxs_dyn_mesh": _abi.Mesh, "nxs_dyn_halo": _abi.Halo,
+               "nxs_dyn_state": _abi.State, "nxs_dyn_forcing": _abi.Forcing, "nxs_dyn_diag": _abi.Diag,
+               "nxs_dyn_timing": _abi.Timing}
+    probes = [("nxs_dyn_params", "regrid_angle"), ("nxs_dyn_params", "young"), ("nxs_dyn_mesh", "nc_width"),
+              ("nxs_dyn_mesh", "neumann_flags"), ("nxs_dyn_halo", "recv_index"), ("nxs_dyn_state", "drag_ui_young"),
+              ("nxs_dyn_state", "conc_young"), ("nxs_dyn_timing", "substep_launches")]
+    body = "".join(f'printf("%zu\\n", sizeof({s}));' for s in structs)
+    body += "".join(f'printf("%zu\\n", offsetof({s}, {f}));' for s, f in probes)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "nxs_dyn.h"\nint main(void){{{body}return 0;}}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    vals = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    expect = [C.sizeof(t) for t in structs.values()] + [getattr(structs[s], f).offset for s, f in probes]
+    assert vals == expect
+
+
+def test_default_params_match_options_cpp():
+    L = dynamics.load_library()
+    p = _abi.Params()
+    assert L.nxs_dyn_default_params(C.byref(p)) == 0
+    from nextsim_amd.forcing import default_params
+    q = default_params()
+    for name, _ in _abi.Params._fields_:
+        assert getattr(p, name) == getattr(q, name), name
+    assert (p.dtime_step, p.substeps, p.young, p.compaction_param) == (200.0, 120, 5.9605e8, -20.0)
+
+
+def _has_gpu():
+    try:
+        out = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=30).stdout
+        return "gfx9" in out
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_has_gpu(), reason="a GPU is present: the no-device path cannot be exercised")
+def test_no_gpu_means_error_not_cpu_fallback():
+    from nextsim_amd.forcing import default_params
+    with pytest.raises(dynamics.NxsError) as e:
+        dynamics.FiniteElementDynamics(default_params())
+    assert e.value.code == -2 and "no CPU path" in str(e.value)
+
+
+def test_product_package_never_imports_the_oracle():
+    """Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may touch oracle/."""
+    pkg = os.path.join(ROOT, "nextsim_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")) or fn == "Makefile":
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "pyoracle" not in text and "dyn_ref" not in text and "liboracle" not in text, fn

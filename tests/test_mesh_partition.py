@@ -1,0 +1,70 @@
+"""The per-rank layout contract the hot path relies on (core/src/gmshmesh.cpp:1165-1169, 1289-1301,
+1379-1417; FE.cpp:150-271, 14003-14088), checked on the synthetic partitioner."""
+import numpy as np
+import pytest
+
+import cases
+from nextsim_amd import mesh as M
+
+
+@pytest.mark.parametrize("kind,nparts", [("toy", 2), ("small", 3), ("small", 8), ("40km", 4)])
+def test_layout_contract(kind, nparts):
+    gm = cases.global_mesh(kind)
+    lms = M.localize(gm, nparts)
+    owner_count = np.zeros(gm.num_nodes, int)
+    elem_count = np.zeros(gm.num_elements, int)
+    gtri = gm.tri
+    for lm in lms:
+        No, Nn, Neo, Ne = lm.local_ndof, lm.num_nodes, lm.local_nelements, lm.num_elements
+        tri = lm.indices.reshape(-1, 3) - 1
+        assert tri.min() == 0 and tri.max() == Nn - 1
+        # owned first, each block ascending in global id
+        assert np.all(np.diff(lm.node_gid[:No]) > 0) and np.all(np.diff(lm.node_gid[No:]) > 0)
+        assert np.all(np.diff(lm.elem_gid[:Neo]) > 0) and np.all(np.diff(lm.elem_gid[Neo:]) > 0)
+        owner_count[lm.node_gid[:No]] += 1
+        elem_count[lm.elem_gid[:Neo]] += 1
+        # ghostNodes flag == "node is a ghost node"
+        assert np.array_equal(lm.ghost_nodes.reshape(-1, 3), (tri >= No).astype(np.uint8))
+        # local triangles are the global ones
+        assert np.array_equal(lm.node_gid[tri], gtri[lm.elem_gid])
+        # every owned node has its COMPLETE fan locally
+        gfan = np.zeros(gm.num_nodes, int); np.add.at(gfan, gtri.ravel(), 1)
+        lfan = np.zeros(Nn, int); np.add.at(lfan, tri.ravel(), 1)
+        assert np.array_equal(lfan[:No], gfan[lm.node_gid[:No]])
+        # masks: Dirichlet only on owned nodes, Neumann flags sorted and including ghosts
+        assert not lm.mask_dirichlet[No:].any()
+        assert np.array_equal(lm.mask_dirichlet[:No].astype(bool), gm.dirichlet[lm.node_gid[:No]])
+        assert np.all(np.diff(lm.neumann_flags) > 0)
+        assert np.array_equal(np.flatnonzero(gm.neumann[lm.node_gid]), lm.neumann_flags)
+        # every ghost node is received exactly once; send lists only hold owned nodes
+        assert np.array_equal(np.sort(lm.recv_index), np.arange(No, Nn))
+        assert lm.send_index.size == 0 or lm.send_index.max() < No
+    assert np.all(owner_count == 1) and np.all(elem_count == 1)
+    # halo symmetry: what r sends to q is what q expects from r, in the same (ascending global id) order
+    for r, lm in enumerate(lms):
+        for k, q in enumerate(lm.send_procs):
+            other = lms[q]
+            kk = int(np.flatnonzero(other.recv_procs == r)[0])
+            sent = lm.node_gid[lm.send_index[lm.send_offsets[k]:lm.send_offsets[k + 1]]]
+            recv = other.node_gid[other.recv_index[other.recv_offsets[kk]:other.recv_offsets[kk + 1]]]
+            assert np.array_equal(sent, recv) and np.all(np.diff(sent) > 0)
+
+
+def test_generators_are_seeded_and_sane():
+    a, b = M.make_mesh("small"), M.make_mesh("small")
+    assert np.array_equal(a.x, b.x) and np.array_equal(a.tri, b.tri)
+    x, y, t = a.x, a.y, a.tri
+    jac = (x[t[:, 1]] - x[t[:, 0]]) * (y[t[:, 2]] - y[t[:, 0]]) - (x[t[:, 2]] - x[t[:, 0]]) * (y[t[:, 1]] - y[t[:, 0]])
+    assert jac.min() > 0                      # counter-clockwise, no degenerate triangle
+    assert (a.dirichlet & a.neumann).sum() == 0 and a.dirichlet.sum() > 0 and a.neumann.sum() > 0
+    assert 55 < a.lat.min() and a.lat.max() <= 90
+
+
+def test_minstd_uniform01_matches_the_lcg():
+    from nextsim_amd.forcing import minstd_uniform01
+    x, ref = 1, []
+    for _ in range(1000):
+        x = (48271 * x) % 2147483647
+        ref.append((x - 1) / 2147483646.0)
+    assert np.array_equal(minstd_uniform01(1000), np.array(ref))
+    assert minstd_uniform01(1)[0] == 48270 / 2147483646.0  # boost::minstd_rand, seed 1, first draw 48271

@@ -1,0 +1,83 @@
+"""Domain decomposition of the reference algorithm on the CPU oracle: P in-process ranks with real
+updateGhosts exchanges (FE.cpp:13963-13996) against the single-rank run.
+
+Ghost elements are recomputed, not reduced (FE.cpp:10446, 10456): no cross-rank sum exists.  The
+owned results still differ from the 1-rank run in the last bits, because a rank numbers its ghost
+elements after its owned ones (gmshmesh.cpp:1379-1417) and the serial element loop therefore adds a
+boundary node's fan in a different order (true of the reference itself)."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import pyoracle as O
+
+KEYS_N = ("VT", "UM", "UT")
+KEYS_E = ("sigma0", "sigma1", "sigma2", "damage", "conc", "thick", "ridge_ratio", "conc_young", "h_young")
+
+
+def _run(kind, nparts, nsteps, **over):
+    gm, p, g, lms, fields = cases.make_case(kind, nparts=nparts, **over)
+    ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    for _ in range(nsteps):
+        if nparts == 1:
+            ranks[0].step()
+        else:
+            O.multirank_step(ranks)
+    return gm, lms, ranks
+
+
+def _gather(gm, lms, ranks):
+    Nn, Ne = gm.num_nodes, gm.num_elements
+    out = {k: np.full(2 * Nn, np.nan) for k in KEYS_N}
+    out.update({k: np.full(Ne, np.nan) for k in KEYS_E})
+    for lm, r in zip(lms, ranks):
+        No, Neo = lm.local_ndof, lm.local_nelements
+        for k in KEYS_N:
+            out[k][lm.node_gid[:No]] = r.arr[k][:No]
+            out[k][Nn + lm.node_gid[:No]] = r.arr[k][lm.num_nodes:lm.num_nodes + No]
+        for k in KEYS_E:
+            out[k][lm.elem_gid[:Neo]] = r.arr[k][:Neo]
+    return out
+
+
+@pytest.mark.parametrize("nparts", [2, 4])
+def test_full_cover_partitioned_equals_serial_to_roundoff(nparts):
+    """Full ice cover (no node ever has zero mass): owned values equal to summation-order round-off."""
+    def full_cover(kind, n):
+        gm, p, g, lms, fields = cases.make_case(kind, nparts=n)
+        for f in fields:
+            f["conc"][:] = 1.0; f["thick"][:] = np.maximum(f["thick"], 0.5); f["conc_young"][:] = 0; f["h_young"][:] = 0
+        ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+        for _ in range(2):
+            O.multirank_step(ranks) if n > 1 else ranks[0].step()
+        return _gather(gm, lms, ranks)
+    a, b = full_cover("small", 1), full_cover("small", nparts)
+    for k in KEYS_N + KEYS_E:
+        assert not np.isnan(b[k]).any()
+        assert cases.rel_err(b[k], a[k]) < 1e-13, k
+
+
+def test_partial_cover_partitioned_matches_serial():
+    """With open water the reference's per-rank semantics differ slightly from the serial run (a ghost
+    node's node_mass is summed over a partial fan: FE.cpp:10366 zeroes M_VT on ghosts that only touch
+    ice-free elements locally), so owned values agree to round-off rather than bitwise."""
+    gm, lms1, r1 = _run("small", 1, 2)
+    gm, lms3, r3 = _run("small", 3, 2)
+    a, b = _gather(gm, lms1, r1), _gather(gm, lms3, r3)
+    for k in KEYS_N + KEYS_E:
+        assert cases.rel_err(b[k], a[k]) < 1e-9, k
+
+
+def test_callback_form_of_explicit_solve_matches_phase_form():
+    """ref_explicit_solve with a ghosts callback == the phase functions driven from Python."""
+    import ctypes as C
+    gm, p, g, lms, fields = cases.make_case("toy")
+    a = O.OracleRank(lms[0], p, fields[0]); a.step()
+    b = O.OracleRank(lms[0], p, fields[0])
+    calls = []
+    cb = O.GHOST_FN(lambda ctx, vec: calls.append(1))
+    m, pp, s, f, w = b._a()
+    b.L.ref_step(m, pp, s, f, w, C.cast(cb, C.c_void_p), None)
+    assert len(calls) == 120 + 50
+    for k in KEYS_N + KEYS_E:
+        assert np.array_equal(a.arr[k], b.arr[k])
