@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py -- element-updates/s of one dynamics step (explicitSolve + update) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--mesh 2km|10km|40km] [--no-cpu-baseline]
+
+N > 1 is launched by the driver as one rank per GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+A "step" is one pass of the hot path: FiniteElement::step()'s dynamics block (FE.cpp:8197-8214) =
+explicitSolve() with dynamics.substeps = 120 BBM sub-steps + 50 smoother sweeps + update(), on the
+synthetic pan-Arctic mesh with inputs resident in HBM.  The mesh is domain-decomposed over the N
+ranks (total work fixed => "strong" scaling), halo exchange of M_VT over RCCL.
+
+Rank 0 prints ONE JSON line.  metric = element-updates/s = Ne_global * substeps * K / t.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic HBM bytes per element-update of the sub-step loop (DESIGN.md "Roofline model"):
+# 172 B per element + 217 B per node per sub-step.
+BYTES_PER_ELEMENT = 172.0
+BYTES_PER_NODE = 217.0
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mesh", default="2km", help="2km (~1.5M triangles, default: the mesh north_star's target and "
+                    "HBM roofline are quoted on), 10km (~60k), 40km, small")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-aux", action="store_true", help="skip the secondary 10 km measurement")
+    return ap.parse_args()
+
+
+def build_case(kind, nparts, rank):
+    from nextsim_amd import forcing as F, mesh as M
+    gm = M.make_mesh(kind)
+    p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
+    g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
+    lm = M.localize(gm, nparts)[rank]
+    f = F.localize_fields(g, lm, gm.num_nodes)
+    return gm, p, lm, f
+
+
+def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn):
+    from nextsim_amd import dynamics
+    gm, p, lm, f = build_case(kind, world, rank)
+    fe = dynamics.FiniteElementDynamics(p, device=local_rank)
+    fe.set_mesh(lm)
+    if world > 1:
+        fe.comm_init(unique_id_fn(), rank, world)
+    fe.put_state(f)
+    fe.set_forcing(f)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        fe.step()
+    fe.synchronize()
+    fe.set_option("timing_reset", 1)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fe.step()
+    fe.synchronize(); torch.cuda.synchronize(); barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    tm = fe.timing()
+    crash = fe.checkFieldsFast()
+    fe.close()
+    return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash)
+
+
+def cpu_baseline(kind, nsteps=1):
+    """The restated reference CPU path (oracle/dyn_ref.c, -O3 -march=native, 1 thread) on the same mesh
+    and forcing: `nsteps` full dynamics steps.  kind 'port': the reference binary itself cannot be
+    built without Boost/Gmsh/NetCDF."""
+    from oracle import pyoracle as O
+    gm, p, lm, f = build_case(kind, 1, 0)
+    r = O.OracleRank(lm, p, f, fast=True)
+    t0 = time.perf_counter()
+    for _ in range(nsteps):
+        r.step()
+    dt = time.perf_counter() - t0
+    return gm.num_elements * p.substeps * nsteps / dt, dt
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    # load the HIP library before torch so that its HIP runtime (ROCm 7.2, /opt/rocm) is the one in
+    # the process; torch then binds to the same libamdhip64.so.7
+    from nextsim_amd import dynamics
+    dynamics.load_library()
+    import torch
+    import torch.distributed as dist
+
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the dynamics path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+
+    unique_id_fn = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # control plane (barrier, max-reduce, id broadcast) on gloo; the data path (halo exchange of
+        # M_VT) is RCCL inside libnxsdyn.so
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+
+        def unique_id_fn():
+            ids = [dynamics.FiniteElementDynamics.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            return ids[0]
+
+    res = run_gpu(args.mesh, args, rank, world, local_rank, dist, torch, unique_id_fn)
+    gm, p, lm, tm = res["gm"], res["p"], res["lm"], res["timing"]
+    S = p.substeps
+    value = gm.num_elements * S * args.steps / res["dt"]
+
+    # roofline of the dominant kernel(s): the sub-step loop (sigma/damage + assembly + nodal solve)
+    launches_per_substep = max(tm["substep_launches"] // S, 1)
+    substep_ms = tm["substeps_ms"] / S                      # HIP events on the kernel's stream, avg over timed steps
+    bytes_per_substep = BYTES_PER_ELEMENT * lm.num_elements + BYTES_PER_NODE * lm.num_nodes
+    achieved = bytes_per_substep / (substep_ms * 1e-3) / 1e9
+    out = {
+        "metric": "element-updates/sec per dynamics step",
+        "value": value,
+        "unit": "element-updates/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": res["dt"] / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": f"pan-Arctic-like synthetic mesh '{args.mesh}' ({gm.num_elements} triangles, {gm.num_nodes} nodes), "
+                        f"BBM rheology, dt=200 s, {S} sub-steps, 50 smoother sweeps, update(); "
+                        f"domain-decomposed over {world} GPU(s)",
+            "mesh": args.mesh, "elements": gm.num_elements, "nodes": gm.num_nodes, "substeps": S,
+            "rheology": "bbm", "partitions": world,
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "sub-step loop (k_sigma_bbm + k_solve_move per sub-step)" if launches_per_substep == 2
+                      else f"sub-step loop ({launches_per_substep} launches per sub-step)",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "bytes_per_launch_group": bytes_per_substep,
+            "avg_ms_per_launch_group": substep_ms,
+            "note": "rank-0 partition; algorithmic bytes = 172 B/element + 217 B/node per sub-step",
+        },
+        "phases_ms": {k: tm[k] for k in ("prep_ms", "substeps_ms", "smoother_ms", "update_ms", "total_ms")},
+        "fields_ok": res["crash"] == 0,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        v, secs = cpu_baseline(args.mesh, 1)
+        out["cpu_baseline"] = {
+            "value": v, "unit": "element-updates/s", "cores": 1, "kind": "port",
+            "sample": f"1 full dynamics step ({S} sub-steps) of the same '{args.mesh}' mesh and forcing, "
+                      f"oracle/dyn_ref.c -O3 -march=native, single thread, {secs:.1f} s",
+        }
+    if world == 1 and not args.no_aux and args.mesh != "10km":
+        aux_args = argparse.Namespace(**vars(args)); aux_args.steps = max(args.steps, 20); aux_args.warmup = max(args.warmup, 3)
+        r2 = run_gpu("10km", aux_args, 0, 1, local_rank, dist, torch, None)
+        out["aux_10km"] = {
+            "workload": f"mesh '10km' ({r2['gm'].num_elements} triangles): BASELINE config 2, latency-bound (working set in cache)",
+            "value": r2["gm"].num_elements * S * aux_args.steps / r2["dt"], "unit": "element-updates/s",
+            "ms_per_step": r2["dt"] / aux_args.steps * 1e3,
+        }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

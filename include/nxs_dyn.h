@@ -167,8 +167,9 @@ typedef struct nxs_dyn_diag {
     double *D_del_ci_ridge_myi; /* [Ne] */
 } nxs_dyn_diag;
 
-/* Per-phase device time of the last nxs_dyn_step (HIP events on the handle's stream), named after
- * the reference's Timer rows (FE.cpp:8197-8221, 10217-10642). Milliseconds. */
+/* Per-phase device time of nxs_dyn_step, averaged over the steps since the last "timing_reset"
+ * option (HIP events on the handle's stream; steps stay asynchronous), named after the reference's
+ * Timer rows (FE.cpp:8197-8221, 10217-10642). Milliseconds per step. */
 typedef struct nxs_dyn_timing {
     double prep_ms;        /* "prep elements" + "prep nodes" */
     double substeps_ms;    /* "sub-time stepping" (all sub-steps, halo included) */
@@ -176,7 +177,7 @@ typedef struct nxs_dyn_timing {
     double update_ms;      /* "update" */
     double total_ms;       /* "dynamics" */
     int32_t substep_launches; /* kernel launches inside substeps_ms */
-    int32_t reserved0;
+    int32_t steps_averaged;   /* number of steps the averages cover */
 } nxs_dyn_timing;
 
 typedef struct nxs_dyn_handle nxs_dyn_handle;
@@ -202,6 +203,13 @@ NXS_API int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo);
 NXS_API int nxs_dyn_comm_unique_id(void *id128);
 NXS_API int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks);
 
+/* Alternative transport: host-staged exchange through the CALLER's communicator -- the literal
+ * M_comm.send / M_comm.recv of FE.cpp:13981-13985.  send holds, per send neighbour k, 2*n_k doubles
+ * [u-block | v-block] at offset 2*send_offsets[k]; recv is laid out the same way from recv_offsets.
+ * fn must fill recv and return 0.  Takes precedence over RCCL when set; NULL unsets it. */
+typedef int (*nxs_dyn_halo_fn)(void *ctx, const double *send, double *recv);
+NXS_API int nxs_dyn_set_halo_exchange_fn(nxs_dyn_handle *h, nxs_dyn_halo_fn fn, void *ctx);
+
 NXS_API int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s);
 NXS_API int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s);
 NXS_API int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f);
@@ -223,7 +231,8 @@ NXS_API int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32
 NXS_API int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local);
 
 NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
-/* 0 = one kernel launch per reference loop; 1 = sub-step loop captured in a hipGraph (default). */
+/* Options: "graph" (1 = sub-step loop replayed from a hipGraph, default; 0 = plain launches),
+ * "timing" (1 = record the per-phase events, default), "timing_reset" (any value: zero the averages). */
 NXS_API int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);
 
 /* Test door: copies a named internal work array (rlmass, node_mass, C_bu, grad_ssh, fcor, VTM, shape,

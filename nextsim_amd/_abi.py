@@ -133,7 +133,7 @@ class Diag(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("substeps_ms", C.c_double), ("smoother_ms", C.c_double),
                 ("update_ms", C.c_double), ("total_ms", C.c_double),
-                ("substep_launches", C.c_int32), ("reserved0", C.c_int32)]
+                ("substep_launches", C.c_int32), ("steps_averaged", C.c_int32)]
 
 
 # ---- numpy helpers --------------------------------------------------------------------------

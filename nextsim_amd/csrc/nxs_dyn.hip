@@ -802,6 +802,9 @@ struct nxs_dyn_handle {
     std::vector<void *> halo_allocs;
     Rccl rccl;
     void *comm = nullptr;
+    nxs_dyn_halo_fn halo_fn = nullptr;  // host-staged exchange through the caller's communicator
+    void *halo_ctx = nullptr;
+    double *h_send = nullptr, *h_recv = nullptr;  // pinned staging buffers
     // reductions
     RegridPartial *d_partials = nullptr, *d_regrid = nullptr;
     int *d_crash = nullptr;
@@ -810,9 +813,15 @@ struct nxs_dyn_handle {
     int use_graph = 1;
     hipGraphExec_t substep_graph = nullptr;
     bool graph_valid = false;
-    // timing
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    bool timing_pending = false, timing_has_update = false;
+    // timing: a ring of event sets so that steps can be enqueued back to back; a set is harvested
+    // (its elapsed times added to the sums) when it is about to be reused or when timing is read
+    static constexpr int NSETS = 8;
+    hipEvent_t ev[NSETS][5] = {};
+    bool set_pending[NSETS] = {};
+    int set_next = 0;
+    double sum_ms[4] = {0, 0, 0, 0};
+    int sum_steps = 0;
+    hipEvent_t *cur = nullptr;  // event set of the step being enqueued (nullptr: untimed)
     nxs_dyn_timing timing{};
     int timing_enabled = 1;
     std::string err;
@@ -921,6 +930,19 @@ int check_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
     return NXS_OK;
 }
 
+int harvest(nxs_dyn_handle *h, int k) {
+    if (!h->set_pending[k]) return NXS_OK;
+    HIPCHK(h, hipEventSynchronize(h->ev[k][4]));
+    for (int i = 0; i < 4; ++i) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev[k][i], h->ev[k][i + 1]));
+        h->sum_ms[i] += ms;
+    }
+    h->sum_steps++;
+    h->set_pending[k] = false;
+    return NXS_OK;
+}
+
 void release_graph(nxs_dyn_handle *h) {
     if (h->substep_graph) { (void)hipGraphExecDestroy(h->substep_graph); h->substep_graph = nullptr; }
     h->graph_valid = false;
@@ -979,7 +1001,7 @@ int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) {
     } while (0)
     CREATE_CHK(hipSetDevice(device));
     CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
-    for (auto &ev : h->ev) CREATE_CHK(hipEventCreate(&ev));
+    for (auto &set : h->ev) for (auto &ev : set) CREATE_CHK(hipEventCreate(&ev));
     CREATE_CHK(hipMalloc((void **)&h->d_regrid, sizeof(RegridPartial)));
     CREATE_CHK(hipMalloc((void **)&h->d_crash, sizeof(int)));
 #undef CREATE_CHK
@@ -997,10 +1019,12 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->mesh_allocs);
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
+    if (h->h_send) (void)hipHostFree(h->h_send);
+    if (h->h_recv) (void)hipHostFree(h->h_recv);
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_regrid) (void)hipFree(h->d_regrid);
     if (h->d_crash) (void)hipFree(h->d_crash);
-    for (auto &ev : h->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &set : h->ev) for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NXS_OK;
@@ -1019,6 +1043,12 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     if (!h || !key) return NXS_ERR_INVALID;
     if (!std::strcmp(key, "graph")) { h->use_graph = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "timing")) { h->timing_enabled = value != 0; return NXS_OK; }
+    if (!std::strcmp(key, "timing_reset")) {  // drop what was accumulated so far (e.g. after warm-up)
+        for (int k = 0; k < nxs_dyn_handle::NSETS; ++k) { int rc = harvest(h, k); if (rc) return rc; }
+        for (double &x : h->sum_ms) x = 0.;
+        h->sum_steps = 0;
+        return NXS_OK;
+    }
     return fail(h, NXS_ERR_INVALID, "unknown option '%s'", key);
 }
 
@@ -1222,6 +1252,10 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
     if ((rc = dev_upload(h, h->halo_allocs, &cp, h->recv_offsets))) return rc; h->d_recv_off = const_cast<int *>(cp);
     if ((rc = dev_alloc(h, h->halo_allocs, &h->d_send_buf, 2 * (size_t)ts))) return rc;
     if ((rc = dev_alloc(h, h->halo_allocs, &h->d_recv_buf, 2 * (size_t)tr))) return rc;
+    if (h->h_send) { (void)hipHostFree(h->h_send); h->h_send = nullptr; }
+    if (h->h_recv) { (void)hipHostFree(h->h_recv); h->h_recv = nullptr; }
+    HIPCHK(h, hipHostMalloc((void **)&h->h_send, std::max<size_t>(2 * (size_t)ts, 1) * sizeof(double), hipHostMallocDefault));
+    HIPCHK(h, hipHostMalloc((void **)&h->h_recv, std::max<size_t>(2 * (size_t)tr, 1) * sizeof(double), hipHostMallocDefault));
     h->have_halo = true;
     return NXS_OK;
 }
@@ -1268,6 +1302,13 @@ int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks
     nccl_comm_init_rank_t init = (nccl_comm_init_rank_t)h->rccl.CommInitRank;
     int e = init(&h->comm, nranks, id, rank);
     if (e != 0) return fail(h, NXS_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, h->rccl.GetErrorString(e));
+    return NXS_OK;
+}
+
+int nxs_dyn_set_halo_exchange_fn(nxs_dyn_handle *h, nxs_dyn_halo_fn fn, void *ctx) {
+    if (!h) return NXS_ERR_INVALID;
+    h->halo_fn = fn;
+    h->halo_ctx = ctx;
     return NXS_OK;
 }
 
@@ -1379,8 +1420,20 @@ int halo_exchange(nxs_dyn_handle *h, double *vec, double move_dt) {
     // updateGhosts (FE.cpp:13963-13996): pack -> grouped send/recv -> unpack
     const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
     const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
-    if (!h->comm) return fail(h, NXS_ERR_STATE, "halo exchange needs nxs_dyn_comm_init");
+    if (!h->comm && !h->halo_fn) return fail(h, NXS_ERR_STATE, "halo exchange needs nxs_dyn_comm_init or nxs_dyn_set_halo_exchange_fn");
     if (ts > 0) LAUNCH(h, k_halo_pack, ts, vec, h->dm.Nn, ts, h->d_send_index, h->d_send_seg, h->d_send_off, h->d_send_buf);
+    if (h->halo_fn) {
+        // host-staged: exactly the reference's M_comm.send / M_comm.recv of packed std::vector<double>
+        if (ts > 0) HIPCHK(h, hipMemcpyAsync(h->h_send, h->d_send_buf, 2 * (size_t)ts * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const int rc = h->halo_fn(h->halo_ctx, h->h_send, h->h_recv);
+        if (rc != 0) return fail(h, NXS_ERR_COMM, "halo exchange callback returned %d", rc);
+        if (tr > 0) {
+            HIPCHK(h, hipMemcpyAsync(h->d_recv_buf, h->h_recv, 2 * (size_t)tr * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            LAUNCH(h, k_halo_unpack, tr, vec, h->dm, h->ds, tr, h->d_recv_index, h->d_recv_seg, h->d_recv_off, h->d_recv_buf, move_dt);
+        }
+        return NXS_OK;
+    }
     const int ncclDouble = 8;  // ncclFloat64
     int e = h->rccl.GroupStart();
     for (int k = 0; k < ns && e == 0; ++k)
@@ -1448,18 +1501,19 @@ int ready(nxs_dyn_handle *h) {
     return NXS_OK;
 }
 
-int explicit_solve(nxs_dyn_handle *h, bool timed) {
+int explicit_solve(nxs_dyn_handle *h) {
+    const bool timed = h->cur != nullptr;
     // FE.cpp:10182-10643
     const DevMesh &m = h->dm;
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[0], h->stream));
+    if (timed) HIPCHK(h, hipEventRecord(h->cur[0], h->stream));
     LAUNCH(h, k_prep_elements, m.Ne, m, h->ds, h->dw, h->dp);
     LAUNCH(h, k_prep_nodes, m.Nn, m, h->ds, h->dw, h->dp);
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[1], h->stream));
+    if (timed) HIPCHK(h, hipEventRecord(h->cur[1], h->stream));
     int rc = run_substeps(h);
     if (rc) return rc;
     if (h->dp.dynamics_type == NXS_DYN_MEVP)  // FE.cpp:10559-10573
         LAUNCH(h, k_move, m.Nn, m, h->ds, 0, m.Nn, h->dp.dtime_step);
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[2], h->stream));
+    if (timed) HIPCHK(h, hipEventRecord(h->cur[2], h->stream));
     // Q9: 50 sweeps, hard-coded (FE.cpp:10580)
     double *a = h->ds.VT, *b = h->ds.VT2;
     for (int nit = 0; nit < 50; ++nit) {
@@ -1469,7 +1523,7 @@ int explicit_solve(nxs_dyn_handle *h, bool timed) {
     }
     // 50 is even: the result is back in ds.VT
     LAUNCH(h, k_ow_tail, m.Nn, m, h->ds, h->dw, h->dp);
-    if (timed) HIPCHK(h, hipEventRecord(h->ev[3], h->stream));
+    if (timed) HIPCHK(h, hipEventRecord(h->cur[3], h->stream));
     return NXS_OK;
 }
 
@@ -1478,8 +1532,8 @@ int explicit_solve(nxs_dyn_handle *h, bool timed) {
 int nxs_dyn_explicit_solve(nxs_dyn_handle *h) {
     int rc = ready(h);
     if (rc) return rc;
-    h->timing_pending = false;
-    return explicit_solve(h, false);
+    h->cur = nullptr;
+    return explicit_solve(h);
 }
 
 int nxs_dyn_update(nxs_dyn_handle *h) {
@@ -1498,11 +1552,22 @@ int nxs_dyn_step(nxs_dyn_handle *h) {  // FE.cpp:8197-8214
         return NXS_OK;
     }
     if (type == NXS_DYN_NO_MOTION) return NXS_OK;
-    const bool timed = h->timing_enabled;
-    rc = explicit_solve(h, timed);
-    if (rc) return rc;
+    int k = -1;
+    h->cur = nullptr;
+    if (h->timing_enabled) {
+        k = h->set_next;
+        if ((rc = harvest(h, k))) return rc;
+        h->cur = h->ev[k];
+    }
+    rc = explicit_solve(h);
+    if (rc) { h->cur = nullptr; return rc; }
     LAUNCH(h, k_update, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
-    if (timed) { HIPCHK(h, hipEventRecord(h->ev[4], h->stream)); h->timing_pending = true; }
+    if (k >= 0) {
+        HIPCHK(h, hipEventRecord(h->cur[4], h->stream));
+        h->set_pending[k] = true;
+        h->set_next = (k + 1) % nxs_dyn_handle::NSETS;
+        h->cur = nullptr;
+    }
     return NXS_OK;
 }
 
@@ -1517,14 +1582,15 @@ int nxs_dyn_synchronize(nxs_dyn_handle *h) {
 int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t) {
     if (!h || !t) return NXS_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
-    if (h->timing_pending) {
-        HIPCHK(h, hipEventSynchronize(h->ev[4]));
-        float ms[4];
-        for (int i = 0; i < 4; ++i) HIPCHK(h, hipEventElapsedTime(&ms[i], h->ev[i], h->ev[i + 1]));
-        h->timing.prep_ms = ms[0]; h->timing.substeps_ms = ms[1]; h->timing.smoother_ms = ms[2]; h->timing.update_ms = ms[3];
-        h->timing.total_ms = (double)ms[0] + ms[1] + ms[2] + ms[3];
-        h->timing_pending = false;
+    for (int k = 0; k < nxs_dyn_handle::NSETS; ++k) {
+        int rc = harvest(h, k);
+        if (rc) return rc;
     }
+    const double n = h->sum_steps > 0 ? (double)h->sum_steps : 1.;
+    h->timing.prep_ms = h->sum_ms[0] / n; h->timing.substeps_ms = h->sum_ms[1] / n;
+    h->timing.smoother_ms = h->sum_ms[2] / n; h->timing.update_ms = h->sum_ms[3] / n;
+    h->timing.total_ms = (h->sum_ms[0] + h->sum_ms[1] + h->sum_ms[2] + h->sum_ms[3]) / n;
+    h->timing.steps_averaged = h->sum_steps;
     *t = h->timing;
     return NXS_OK;
 }

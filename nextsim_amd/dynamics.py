@@ -58,6 +58,7 @@ def load_library():
     L.nxs_dyn_set_halo.argtypes = [H, P(_abi.Halo)]
     L.nxs_dyn_comm_unique_id.argtypes = [C.c_void_p]
     L.nxs_dyn_comm_init.argtypes = [H, C.c_void_p, C.c_int, C.c_int]
+    L.nxs_dyn_set_halo_exchange_fn.argtypes = [H, HALO_FN, C.c_void_p]
     L.nxs_dyn_put_state.argtypes = [H, P(_abi.State)]
     L.nxs_dyn_get_state.argtypes = [H, P(_abi.State)]
     L.nxs_dyn_set_forcing.argtypes = [H, P(_abi.Forcing)]
@@ -85,8 +86,11 @@ def load_library():
     return L
 
 
+HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _abi.c_double_p, _abi.c_double_p)
+
 # every symbol include/nxs_dyn.h declares
 EXPORTS = (
+    "nxs_dyn_set_halo_exchange_fn",
     "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_create", "nxs_dyn_destroy",
     "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init",
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_get_diag", "nxs_dyn_step",
@@ -157,6 +161,25 @@ class FiniteElementDynamics:
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self.L.nxs_dyn_comm_init(self.h, buf, rank, nranks))
+
+    def set_halo_exchange(self, fn):
+        """fn(send: np.ndarray, recv: np.ndarray) -> None : host-staged updateGhosts through the caller's
+        communicator (send/recv are views laid out per neighbour as [u-block | v-block])."""
+        lm = self.lm
+        ns, nr = 2 * int(lm.send_offsets[-1]), 2 * int(lm.recv_offsets[-1])
+
+        def tramp(ctx, send, recv):
+            try:
+                sv = np.ctypeslib.as_array(send, shape=(max(ns, 1),))[:ns]
+                rv = np.ctypeslib.as_array(recv, shape=(max(nr, 1),))[:nr]
+                fn(sv, rv)
+                return 0
+            except Exception:  # noqa: BLE001 -- never unwind through the C ABI
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._halo_cb = HALO_FN(tramp)
+        self._chk(self.L.nxs_dyn_set_halo_exchange_fn(self.h, self._halo_cb, None))
 
     @staticmethod
     def comm_unique_id() -> bytes:
@@ -239,4 +262,4 @@ class FiniteElementDynamics:
     def timing(self) -> dict:
         t = _abi.Timing()
         self._chk(self.L.nxs_dyn_get_timing(self.h, C.byref(t)))
-        return {k: getattr(t, k) for k, _ in _abi.Timing._fields_ if k != "reserved0"}
+        return {k: getattr(t, k) for k, _ in _abi.Timing._fields_}

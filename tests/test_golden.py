@@ -1,7 +1,7 @@
 """Committed fixtures (tests/golden/, made by tests/golden/make_golden.py).
 
 oracle_tiny.npz holds the oracle's own state on the seeded 'tiny' toy case after 1 sub-step, 1 step
-and 10 steps; the CPU test is a regression net for the oracle, the GPU test compares the HIP path
+and 3 steps; the CPU test is a regression net for the oracle, the GPU test compares the HIP path
 with the same fixture without touching the oracle at run time."""
 import os
 
@@ -13,7 +13,7 @@ import cases
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "oracle_tiny.npz")
 KEYS = ("VT", "UM", "UT", "sigma0", "sigma1", "sigma2", "damage", "conc", "thick", "snow_thick", "ridge_ratio",
         "conc_young", "h_young", "hs_young", "conc_myi", "thick_myi")
-CASES = (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step10", 10, {}))
+CASES = (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step3", 3, {}))
 
 
 @pytest.mark.parametrize("tag,nsteps,over", CASES)
@@ -30,7 +30,7 @@ def test_oracle_reproduces_fixture(tag, nsteps, over):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("tag,nsteps,over,tol", [(c[0], c[1], c[2], t) for c, t in zip(CASES, (1e-13, 1e-10, 1e-8))])
+@pytest.mark.parametrize("tag,nsteps,over,tol", [(c[0], c[1], c[2], t) for c, t in zip(CASES, (1e-13, 1e-10, 1e-9))])
 def test_gpu_matches_fixture(tag, nsteps, over, tol):
     from nextsim_amd import dynamics
     z = np.load(GOLD)
