@@ -110,12 +110,13 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    # load the HIP library before torch so that its HIP runtime (ROCm 7.2, /opt/rocm) is the one in
-    # the process; torch then binds to the same libamdhip64.so.7
-    from nextsim_amd import dynamics
-    dynamics.load_library()
+    # torch FIRST: it bundles its own libamdhip64.so.7 / libhsa-runtime64 and they must be the ones in
+    # the process (loading /opt/rocm's runtime first and torch second leaves HIP without devices);
+    # libnxsdyn.so then binds to the runtime that is already loaded.
     import torch
     import torch.distributed as dist
+    from nextsim_amd import dynamics
+    dynamics.load_library()
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the dynamics path has no CPU fallback")
