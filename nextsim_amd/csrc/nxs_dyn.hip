@@ -67,6 +67,7 @@ struct DevParams {
     double evp_e, evp_Pstar, evp_C, evp_dmin, ralpha1, ralpha2, mevp_beta;
     double sqrt_nu_rhoi;
     double D[9];
+    int ers_int;  // exponent_relaxation_sigma - 1 when it is an integer in [0,16], else -1
 };
 
 struct DevMesh {
@@ -82,11 +83,29 @@ struct DevMesh {
 };
 
 struct DevState {
-    double *VT, *VT2, *UM, *UT;  // VT2: second buffer of the Jacobi smoother
+    double *VT, *VT2, *UM, *UT;  // VT2: second buffer (Jacobi smoother; ping-pong of the fused sub-step)
     double *conc, *thick, *snow, *damage, *ridge, *s0, *s1, *s2;
+    double *damage_b, *s0_b, *s1_b, *s2_b;  // ping-pong partners of damage, sigma (fused sub-step)
     double *cyoung, *hyoung, *hsyoung, *cmyi, *tmyi;
     double *cohesion, *theal, *drag_ui, *drag_ui_young;
     double *wind, *ocean, *ssh, *depth;
+};
+
+// v2: node patches.  One workgroup owns up to Pmax nodes ("own" nodes) and processes every element
+// that touches one of them; elements shared with a neighbouring patch are recomputed by both (like the
+// MPI ghost layer, one level down) and written by exactly one.  Element->node traffic stays in LDS.
+struct DevPatches {
+    int nP, Pmax, Emax, Mmax, Wp;
+    const int *own_cnt, *elem_cnt, *node_cnt;  // [nP]
+    const int *pnodes;            // [nP][Mmax] global node id of each patch-local node slot (own nodes first)
+    const int *pelem;             // [nP][Emax] global element id, ascending; ~id when another patch writes it
+    const unsigned short *ptri;   // [nP][Emax][4] patch-local node slots of the 3 corners (+ pad)
+    const unsigned short *pfan;   // [nP][Wp][Pmax] (element slot << 3 | ghost << 2 | corner), 0xFFFF pad
+};
+
+struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
+    const double *VTc, *s0c, *s1c, *s2c, *dc;
+    double *VTn, *s0n, *s1n, *s2n, *dn;
 };
 
 struct DevWork {
@@ -265,17 +284,149 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
 }
 
 // ------------------------------------------------------------------------------------------------
+// Arithmetic shared by the v1 kernels (one per reference loop) and the v2 fused sub-step kernel, so
+// that both perform literally the same operations in the same order.
+
+// updateSigmaDamage body for one element, FE.cpp:4161-4257 (the conc <= 0.1 early-out is the caller's)
+template <bool POW4>
+__device__ __forceinline__ void bbm_stress(const DevParams &p, const double dxN[6], const double u[3], const double v[3],
+                                           double sig[3], double &damage, const double expC, const double Pmax,
+                                           const double heal, const double dxs, const double cohesion) {
+    const double dt = p.dte;
+    // M_B0T (FE.cpp:10242-10249) rebuilt in registers, zeros included so that the sums below are the
+    // reference's term for term (FE.cpp:4167-4176)
+    double B0T[18];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) B0T[i] = 0.;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        B0T[2 * i] = dxN[i];
+        B0T[2 * i + 13] = dxN[i];
+        B0T[2 * i + 7] = dxN[i + 3];
+        B0T[2 * i + 12] = dxN[i + 3];
+    }
+    double eps[3] = {0., 0., 0.};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            eps[i] += B0T[i * 6 + 2 * j] * u[j];
+            eps[i] += B0T[i * 6 + 2 * j + 1] * v[j];
+        }
+    double sigma_n = (sig[0] + sig[1]) * 0.5;                                    // FE.cpp:4184
+    // FE.cpp:4186: std::pow(x, exponent_relaxation_sigma - 1.).  For the default exponent (5 - 1 = 4) the
+    // power is formed by two squarings: <= 1.5 ulp from the correctly rounded value, i.e. inside the error
+    // band of any libm pow, and it removes ~400 instructions and ~50 VGPRs from the hot loop.  Any other
+    // exponent takes the general pow (POW4 == false).
+    const double pw_x = (1. - damage) * expC;
+    double pw;
+    if (POW4) { const double x2 = pw_x * pw_x; pw = x2 * x2; }
+    else pw = pow(pw_x, p.ers_m1);
+    const double time_viscous = p.utrs * pw;
+    double tildeP;
+    if (sigma_n < 0.) {
+        tildeP = STD_MIN(1., -Pmax / sigma_n);                                   // FE.cpp:4194
+    } else {
+        tildeP = 0.;
+    }
+    const double multiplicator = STD_MIN(1. - 1e-12, time_viscous / (time_viscous + dt * (1. - tildeP)));  // Q3
+    const double elasticity = p.young * (1. - damage) * expC;                    // FE.cpp:4202
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                                                // FE.cpp:4204-4210
+#pragma unroll
+        for (int j = 0; j < 3; ++j) sig[i] += dt * elasticity * p.D[3 * i + j] * eps[j];
+        sig[i] *= multiplicator;
+    }
+    const double sigma_s = hypot((sig[0] - sig[1]) / 2., sig[2]);                // FE.cpp:4218
+    sigma_n = (sig[0] + sig[1]) * 0.5;
+    double dcrit;
+    if (sigma_n < -p.compr_strength)
+        dcrit = -p.compr_strength / sigma_n;
+    else
+        dcrit = cohesion / (sigma_s + p.tan_phi * sigma_n);
+    if ((0. < dcrit) && (dcrit < 1.)) {                                          // FE.cpp:4229-4243
+        const double rtd = sqrt(elasticity) / dxs;
+        const double del_damage = (1.0 - damage) * (1.0 - dcrit) * dt * rtd;
+        damage += del_damage;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) sig[i] -= sig[i] * (1. - dcrit) * dt * rtd;
+    }
+    damage = STD_MAX(0., damage - heal);                                         // FE.cpp:4256
+}
+
+// updateSigmaVP body for one element, FE.cpp:10664-10696 (P = Pstar*exp(-C(1-A)) precomputed)
+__device__ __forceinline__ void vp_stress(const DevParams &p, const double dxN[6], const double u[3], const double v[3],
+                                          double sig[3], const double P) {
+    const double re2 = 1. / (p.evp_e * p.evp_e);
+    double eps11 = 0., eps22 = 0., eps12 = 0.;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        eps11 += dxN[i] * u[i];
+        eps22 += dxN[i + 3] * v[i];
+        eps12 += 0.5 * (dxN[i] * v[i] + dxN[i + 3] * u[i]);
+    }
+    const double eps1 = eps11 + eps22, eps2 = eps11 - eps22;
+    const double delta = sqrt(eps1 * eps1 + (eps2 * eps2 + 4 * eps12 * eps12) * re2);
+    const double zeta = P / (delta + p.evp_dmin);
+    double sigma1 = sig[0] + sig[1], sigma2 = sig[0] - sig[1];
+    sigma1 += p.ralpha1 * (zeta * (eps1 - delta) - sigma1);
+    sigma2 += p.ralpha2 * (zeta * eps2 * re2 - sigma2);
+    sig[2] += p.ralpha2 * (zeta * eps12 * re2 - sig[2]);
+    sig[0] = 0.5 * (sigma1 + sigma2);
+    sig[1] = 0.5 * (sigma1 - sigma2);
+}
+
+// element half of "gradient sigma" (FE.cpp:10449-10465): the term corner i subtracts from its node
+__device__ __forceinline__ void corner_forces(const double volume, const double sig[3], const double dxN[6], double F[6]) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        F[i] = volume * (sig[0] * dxN[i] + sig[2] * dxN[i + 3]);
+        F[i + 3] = volume * (sig[2] * dxN[i] + sig[1] * dxN[i + 3]);
+    }
+}
+
+// "sub-solve" for one node, FE.cpp:10481-10528: (uice, vice) in -> new velocity out
+__device__ __forceinline__ void nodal_solve(const DevParams &p, const double gx, const double gy, double &uice, double &vice,
+                                            const double node_mass, const double rlm, const double C_bu, const double fcor,
+                                            const double lat, const double tau_ax, const double tau_ay, const double ou,
+                                            const double ov, const double vtm_u, const double vtm_v) {
+    double dtep, delu, delv;
+    if (p.dynamics_type == NXS_DYN_MEVP) {  // FE.cpp:10483-10493
+        const double b_mevp = p.mevp_beta + 1.;
+        delu = (vtm_u - uice) / b_mevp;
+        delv = (vtm_v - vice) / b_mevp;
+        dtep = p.dte / b_mevp;
+    } else {
+        delu = 0.; delv = 0.; dtep = p.dte;
+    }
+    const double dte_over_mass = dtep / STD_MAX(p.min_m, node_mass);
+    const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
+    const double tau_b = C_bu / (hypot(uice, vice) + p.u0);
+    const double alpha = 1. + dte_over_mass * (c_prime * p.cos_ota + tau_b);
+    const double beta = dtep * fcor + dte_over_mass * c_prime * copysign(p.sin_ota, lat);
+    const double rdenom = 1. / (alpha * alpha + beta * beta);
+    const double tau_x = tau_ax + c_prime * (ou * p.cos_ota - ov * copysign(p.sin_ota, lat));
+    const double tau_y = tau_ay + c_prime * (ov * p.cos_ota + ou * copysign(p.sin_ota, lat));
+    const double grad_x = gx * rlm, grad_y = gy * rlm;
+    double nu_ = alpha * uice + beta * vice + dte_over_mass * (alpha * (grad_x + tau_x) + beta * (grad_y + tau_y)) + alpha * delu + beta * delv;
+    nu_ *= rdenom;
+    double nv_ = alpha * vice - beta * uice + dte_over_mass * (alpha * (grad_y + tau_y) - beta * (grad_x + tau_x)) + alpha * delv - beta * delu;
+    nv_ *= rdenom;
+    uice = nu_;
+    vice = nv_;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K3a  updateSigmaDamage, FE.cpp:4137-4260, + the element half of K4 (corner forces)
+template <bool POW4>
 __global__ void __launch_bounds__(BLOCK) k_sigma_bbm(DevMesh m, DevState s, DevWork w, DevParams p) {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= m.Ne) return;
     const int Ne = m.Ne, Nn = m.Nn;
-    const double dt = p.dte;
     double dxN[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
     double sig[3];
-
     if (w.eskip[e]) {  // FE.cpp:4151-4159
         s.damage[e] = 0.;
         sig[0] = sig[1] = sig[2] = 0.;
@@ -284,73 +435,16 @@ __global__ void __launch_bounds__(BLOCK) k_sigma_bbm(DevMesh m, DevState s, DevW
         double u[3], v[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) { u[j] = s.VT[n[j]]; v[j] = s.VT[n[j] + Nn]; }
-        // M_B0T (FE.cpp:10242-10249) rebuilt in registers, zeros included so that the sums below
-        // are the reference's term for term (FE.cpp:4167-4176)
-        double B0T[18];
-#pragma unroll
-        for (int i = 0; i < 18; ++i) B0T[i] = 0.;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            B0T[2 * i] = dxN[i];
-            B0T[2 * i + 13] = dxN[i];
-            B0T[2 * i + 7] = dxN[i + 3];
-            B0T[2 * i + 12] = dxN[i + 3];
-        }
-        double eps[3] = {0., 0., 0.};
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                eps[i] += B0T[i * 6 + 2 * j] * u[j];
-                eps[i] += B0T[i * 6 + 2 * j + 1] * v[j];
-            }
-
         sig[0] = s.s0[e]; sig[1] = s.s1[e]; sig[2] = s.s2[e];
         double damage = s.damage[e];
-        const double expC = w.expC[e];
-        double sigma_n = (sig[0] + sig[1]) * 0.5;                                    // FE.cpp:4184
-        const double time_viscous = p.utrs * pow((1. - damage) * expC, p.ers_m1);    // FE.cpp:4186
-        double tildeP;
-        if (sigma_n < 0.) {
-            const double Pmax = w.pmax[e];
-            tildeP = STD_MIN(1., -Pmax / sigma_n);                                   // FE.cpp:4194
-        } else {
-            tildeP = 0.;
-        }
-        const double multiplicator = STD_MIN(1. - 1e-12, time_viscous / (time_viscous + dt * (1. - tildeP)));  // Q3
-        const double elasticity = p.young * (1. - damage) * expC;                    // FE.cpp:4202
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {                                                // FE.cpp:4204-4210
-#pragma unroll
-            for (int j = 0; j < 3; ++j) sig[i] += dt * elasticity * p.D[3 * i + j] * eps[j];
-            sig[i] *= multiplicator;
-        }
-        const double sigma_s = hypot((sig[0] - sig[1]) / 2., sig[2]);                // FE.cpp:4218
-        sigma_n = (sig[0] + sig[1]) * 0.5;
-        double dcrit;
-        if (sigma_n < -p.compr_strength)
-            dcrit = -p.compr_strength / sigma_n;
-        else
-            dcrit = s.cohesion[e] / (sigma_s + p.tan_phi * sigma_n);
-        if ((0. < dcrit) && (dcrit < 1.)) {                                          // FE.cpp:4229-4243
-            const double rtd = sqrt(elasticity) / w.dxs[e];
-            const double del_damage = (1.0 - damage) * (1.0 - dcrit) * dt * rtd;
-            damage += del_damage;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) sig[i] -= sig[i] * (1. - dcrit) * dt * rtd;
-        }
-        damage = STD_MAX(0., damage - w.heal[e]);                                    // FE.cpp:4256
+        bbm_stress<POW4>(p, dxN, u, v, sig, damage, w.expC[e], w.pmax[e], w.heal[e], w.dxs[e], s.cohesion[e]);
         s.damage[e] = damage;
     }
     s.s0[e] = sig[0]; s.s1[e] = sig[1]; s.s2[e] = sig[2];
-
-    // element half of "gradient sigma" (FE.cpp:10449-10465): the term each corner will subtract
-    const double volume = w.volume[e];
+    double F[6];
+    corner_forces(w.volume[e], sig, dxN, F);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        w.force[(size_t)i * Ne + e] = volume * (sig[0] * dxN[i] + sig[2] * dxN[i + 3]);
-        w.force[(size_t)(i + 3) * Ne + e] = volume * (sig[2] * dxN[i] + sig[1] * dxN[i + 3]);
-    }
+    for (int i = 0; i < 6; ++i) w.force[(size_t)i * Ne + e] = F[i];
 }
 
 // K3b  updateSigmaVP, FE.cpp:10649-10699
@@ -361,39 +455,22 @@ __global__ void __launch_bounds__(BLOCK) k_sigma_vp(DevMesh m, DevState s, DevWo
     double dxN[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
-    double sig0, sig1, sig2;
+    double sig[3];
     if (w.eskip[e]) {
-        sig0 = sig1 = sig2 = 0.;
+        sig[0] = sig[1] = sig[2] = 0.;
     } else {
-        const double re2 = 1. / (p.evp_e * p.evp_e);
         const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
-        double eps11 = 0., eps22 = 0., eps12 = 0.;
+        double u[3], v[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const double u = s.VT[n[i]], v = s.VT[n[i] + Nn];
-            eps11 += dxN[i] * u;
-            eps22 += dxN[i + 3] * v;
-            eps12 += 0.5 * (dxN[i] * v + dxN[i + 3] * u);
-        }
-        const double eps1 = eps11 + eps22, eps2 = eps11 - eps22;
-        const double delta = sqrt(eps1 * eps1 + (eps2 * eps2 + 4 * eps12 * eps12) * re2);
-        const double P = w.expC[e];
-        const double zeta = P / (delta + p.evp_dmin);
-        sig0 = s.s0[e]; sig1 = s.s1[e]; sig2 = s.s2[e];
-        double sigma1 = sig0 + sig1, sigma2 = sig0 - sig1;
-        sigma1 += p.ralpha1 * (zeta * (eps1 - delta) - sigma1);
-        sigma2 += p.ralpha2 * (zeta * eps2 * re2 - sigma2);
-        sig2 += p.ralpha2 * (zeta * eps12 * re2 - sig2);
-        sig0 = 0.5 * (sigma1 + sigma2);
-        sig1 = 0.5 * (sigma1 - sigma2);
+        for (int j = 0; j < 3; ++j) { u[j] = s.VT[n[j]]; v[j] = s.VT[n[j] + Nn]; }
+        sig[0] = s.s0[e]; sig[1] = s.s1[e]; sig[2] = s.s2[e];
+        vp_stress(p, dxN, u, v, sig, w.expC[e]);
     }
-    s.s0[e] = sig0; s.s1[e] = sig1; s.s2[e] = sig2;
-    const double volume = w.volume[e];
+    s.s0[e] = sig[0]; s.s1[e] = sig[1]; s.s2[e] = sig[2];
+    double F[6];
+    corner_forces(w.volume[e], sig, dxN, F);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        w.force[(size_t)i * Ne + e] = volume * (sig0 * dxN[i] + sig2 * dxN[i + 3]);
-        w.force[(size_t)(i + 3) * Ne + e] = volume * (sig2 * dxN[i] + sig1 * dxN[i + 3]);
-    }
+    for (int i = 0; i < 6; ++i) w.force[(size_t)i * Ne + e] = F[i];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -418,33 +495,8 @@ __global__ void __launch_bounds__(BLOCK) k_solve_move(DevMesh m, DevState s, Dev
             gx -= w.force[(size_t)c * Ne + e];
             gy -= w.force[(size_t)(c + 3) * Ne + e];
         }
-
-        double dtep, delu, delv;
-        if (p.dynamics_type == NXS_DYN_MEVP) {  // FE.cpp:10483-10493
-            const double b_mevp = p.mevp_beta + 1.;
-            delu = (w.VTM[n] - uice) / b_mevp;
-            delv = (w.VTM[n + Nn] - vice) / b_mevp;
-            dtep = p.dte / b_mevp;
-        } else {
-            delu = 0.; delv = 0.; dtep = p.dte;
-        }
-        const double lat = m.lat[n];
-        const double ou = s.ocean[n], ov = s.ocean[n + Nn];
-        const double dte_over_mass = dtep / STD_MAX(p.min_m, node_mass);
-        const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
-        const double tau_b = w.C_bu[n] / (hypot(uice, vice) + p.u0);
-        const double alpha = 1. + dte_over_mass * (c_prime * p.cos_ota + tau_b);
-        const double beta = dtep * w.fcor[n] + dte_over_mass * c_prime * copysign(p.sin_ota, lat);
-        const double rdenom = 1. / (alpha * alpha + beta * beta);
-        const double tau_x = w.D_tau_a[n] + c_prime * (ou * p.cos_ota - ov * copysign(p.sin_ota, lat));
-        const double tau_y = w.D_tau_a[n + Nn] + c_prime * (ov * p.cos_ota + ou * copysign(p.sin_ota, lat));
-        const double rlm = w.rlmass[n];
-        const double grad_x = gx * rlm, grad_y = gy * rlm;
-        double nu_ = alpha * uice + beta * vice + dte_over_mass * (alpha * (grad_x + tau_x) + beta * (grad_y + tau_y)) + alpha * delu + beta * delv;
-        nu_ *= rdenom;
-        double nv_ = alpha * vice - beta * uice + dte_over_mass * (alpha * (grad_y + tau_y) - beta * (grad_x + tau_x)) + alpha * delv - beta * delu;
-        nv_ *= rdenom;
-        uice = nu_; vice = nv_;
+        nodal_solve(p, gx, gy, uice, vice, node_mass, w.rlmass[n], w.C_bu[n], w.fcor[n], m.lat[n], w.D_tau_a[n],
+                    w.D_tau_a[n + Nn], s.ocean[n], s.ocean[n + Nn], w.VTM[n], w.VTM[n + Nn]);
         s.VT[n] = uice;
         s.VT[n + Nn] = vice;
     }
@@ -470,6 +522,142 @@ __global__ void __launch_bounds__(BLOCK) k_move(DevMesh m, DevState s, int first
     }
     s.UT[n] += dt * u;
     s.UT[n + Nn] += dt * v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// v2  ONE launch per sub-step: K3 (stress/damage) + K4 (assembly) + K5 (nodal solve) + K7 (mesh move).
+// FE.cpp:10425-10553.  Workgroup = patch.  Phase 0 stages the patch's nodal velocities in LDS,
+// phase A updates every patch element from them and leaves its six corner forces in LDS, phase B
+// lets each own node subtract the forces of its fan (ascending element order, as the serial scatter)
+// and solve.  sigma, damage and VT are ping-pong buffered: a neighbouring patch may still be reading
+// the old values of a shared element / node while this one writes the new ones.
+template <int T, bool POW4>
+__global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p,
+                                                     PingPong b, double move_dt) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *lu = lds, *lv = lds + pp.Mmax, *lF = lds + 2 * (size_t)pp.Mmax;  // lF[6][Emax]
+    // consecutive patches are neighbours in space: keep them on one XCD (blocks are dealt round-robin
+    // over the 8 XCDs) so that shared halo elements / nodes hit that XCD's L2.  Speed only.
+    int blk = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blk & 7;
+        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blk >> 3);
+    }
+    const int t = threadIdx.x, Nn = m.Nn, Ne = m.Ne, Emax = pp.Emax;
+    const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
+    const int *pn = pp.pnodes + (size_t)blk * pp.Mmax;
+    const int *pe = pp.pelem + (size_t)blk * Emax;
+    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * Emax;
+    const bool bbm = p.dynamics_type == NXS_DYN_BBM;
+
+    // The kernel is latency-bound unless every dependent load hop is overlapped, so all global loads
+    // that do not need LDS are issued up front: indices first, then (one hop later) the nodal
+    // velocities to stage and this thread's element data, all in flight together before barrier 1.
+    const int my_node = (t < nM) ? pn[t] : 0;  // patch-local slot t (an own node when t < nO)
+    int eraw = 0;
+    ushort4 tr = make_ushort4(0, 0, 0, 0);
+    if (t < nE) { eraw = pe[t]; tr = pt[t]; }
+
+    if (t < nM) { lu[t] = b.VTc[my_node]; lv[t] = b.VTc[my_node + Nn]; }
+    for (int i = t + T; i < nM; i += T) {
+        const int g = pn[i];
+        lu[i] = b.VTc[g];
+        lv[i] = b.VTc[g + Nn];
+    }
+
+    for (int base = 0; base < nE; base += T) {
+        const int l = base + t;
+        if (base > 0 && l < nE) { eraw = pe[l]; tr = pt[l]; }  // patches larger than the block: extra rounds
+        const bool active = l < nE;
+        const bool writer = eraw >= 0;
+        const int e = writer ? eraw : ~eraw;
+        double dxN[6], sig[3] = {0., 0., 0.}, damage = 0., c_expC = 0., c_pmax = 0., c_heal = 0., c_dxs = 1., c_coh = 0., volume = 0.;
+        bool skip = true;
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
+            skip = w.eskip[e];
+            sig[0] = b.s0c[e]; sig[1] = b.s1c[e]; sig[2] = b.s2c[e];
+            c_expC = w.expC[e];
+            volume = w.volume[e];
+            if (bbm) { damage = b.dc[e]; c_pmax = w.pmax[e]; c_heal = w.heal[e]; c_dxs = w.dxs[e]; c_coh = s.cohesion[e]; }
+        }
+        if (base == 0) __syncthreads();  // staged velocities visible
+        if (active) {
+            if (skip) {
+                sig[0] = sig[1] = sig[2] = 0.;
+                damage = 0.;
+            } else {
+                const double u[3] = {lu[tr.x], lu[tr.y], lu[tr.z]};
+                const double v[3] = {lv[tr.x], lv[tr.y], lv[tr.z]};
+                if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, c_expC, c_pmax, c_heal, c_dxs, c_coh);
+                else vp_stress(p, dxN, u, v, sig, c_expC);
+            }
+            if (writer) {
+                b.s0n[e] = sig[0]; b.s1n[e] = sig[1]; b.s2n[e] = sig[2];
+                if (bbm) b.dn[e] = damage;
+            }
+            double F[6];
+            corner_forces(volume, sig, dxN, F);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + l] = F[k];
+        }
+    }
+
+    // node phase: issue this node's loads before barrier 2 so that they overlap the wait
+    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.Pmax;
+    for (int base = 0; base < nO || base == 0; base += T) {
+        const int i = base + t;
+        const bool active = i < nO;
+        const int n = active ? (base == 0 ? my_node : pn[i]) : 0;
+        unsigned char nf = 0;
+        double node_mass = 0., gx = 0., gy = 0., rlm = 0., cbu = 0., fcor = 0., lat = 0., tax = 0., tay = 0., ou = 0., ov = 0.,
+               vtmu = 0., vtmv = 0., umu = 0., umv = 0., utu = 0., utv = 0.;
+        if (active) {
+            nf = m.nflags[n];
+            node_mass = w.node_mass[n];
+            gx = w.grad_ssh[n]; gy = w.grad_ssh[n + Nn];
+            rlm = w.rlmass[n]; cbu = w.C_bu[n]; fcor = w.fcor[n]; lat = m.lat[n];
+            tax = w.D_tau_a[n]; tay = w.D_tau_a[n + Nn];
+            ou = s.ocean[n]; ov = s.ocean[n + Nn];
+            if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
+            if (move_dt != 0.) { umu = s.UM[n]; umv = s.UM[n + Nn]; utu = s.UT[n]; utv = s.UT[n + Nn]; }
+        }
+        if (base == 0) __syncthreads();  // corner forces visible
+        if (!active) continue;
+        double uice = lu[i], vice = lv[i];
+        if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
+            for (int k = 0; k < pp.Wp; ++k) {
+                const unsigned ent = pf[(size_t)k * pp.Pmax + i];
+                if (ent == 0xFFFFu) break;
+                if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
+                const int l = ent >> 3, c = ent & 3u;
+                gx -= lF[(size_t)c * Emax + l];
+                gy -= lF[(size_t)(c + 3) * Emax + l];
+            }
+            nodal_solve(p, gx, gy, uice, vice, node_mass, rlm, cbu, fcor, lat, tax, tay, ou, ov, vtmu, vtmv);
+        }
+        b.VTn[n] = uice;
+        b.VTn[n + Nn] = vice;
+        if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
+            if (!(nf & NF_NEUMANN)) {
+                s.UM[n] = umu + move_dt * uice;
+                s.UM[n + Nn] = umv + move_dt * vice;
+            }
+            s.UT[n] = utu + move_dt * uice;
+            s.UT[n + Nn] = utv + move_dt * vice;
+        }
+    }
+}
+
+// odd number of sub-steps: bring the ping-pong result back to the primary buffers
+__global__ void __launch_bounds__(BLOCK) k_pingpong_copy_back(DevMesh m, DevState s, int bbm) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < 2 * m.Nn) s.VT[i] = s.VT2[i];
+    if (i < m.Ne) {
+        s.s0[i] = s.s0_b[i]; s.s1[i] = s.s1_b[i]; s.s2[i] = s.s2_b[i];
+        if (bbm) s.damage[i] = s.damage_b[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -791,6 +979,14 @@ struct nxs_dyn_handle {
     DevMesh dm{};
     DevState ds{};
     DevWork dw{};
+    DevPatches dpch{};
+    int fused = 1;          // v2 fused sub-step kernel (default) vs v1 two-kernel sub-step
+    int patch_nodes = 0;    // own nodes per patch; 0 = auto (largest patch whose elements fit one 512-thread block)
+    size_t fused_lds = 0;
+    std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
+    std::vector<unsigned char> h_ghost;
+    std::vector<double> h_x0, h_y0;
+    std::vector<void *> patch_allocs;
     std::vector<void *> mesh_allocs, state_allocs;
     // halo
     bool have_halo = false;
@@ -889,6 +1085,7 @@ void derive_params(nxs_dyn_handle *h) {
     d.compaction_param = p.compaction_param;
     d.utrs = p.undamaged_time_relaxation_sigma;
     d.ers_m1 = p.exponent_relaxation_sigma - 1.;  // FE.cpp:4186
+    d.ers_int = (d.ers_m1 >= 0. && d.ers_m1 <= 16. && d.ers_m1 == std::floor(d.ers_m1)) ? (int)d.ers_m1 : -1;
     d.compression_factor = p.compression_factor;
     d.ecf = p.exponent_compression_factor;
     d.min_h = p.min_h; d.min_c = p.min_c;
@@ -940,6 +1137,191 @@ int harvest(nxs_dyn_handle *h, int k) {
     }
     h->sum_steps++;
     h->set_pending[k] = false;
+    return NXS_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Host: node patches for the fused sub-step kernel (see DevPatches).
+struct HostPatches {
+    int nP = 0, Pmax = 0, Emax = 0, Mmax = 0, Wp = 0;
+    std::vector<int> own_cnt, elem_cnt, node_cnt, pnodes, pelem;
+    std::vector<unsigned short> ptri, pfan;
+    double avg_elems_per_own_node = 0.;
+};
+
+// order: owned nodes in the order they are cut into patches of P.
+bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int No, int P,
+                              const std::vector<int> &order, HostPatches &out) {
+    // node -> elements CSR
+    std::vector<int> off(Nn + 1, 0);
+    for (int k = 0; k < 3; ++k) for (int e = 0; e < Ne; ++e) off[t[k][e] + 1]++;
+    for (int n = 0; n < Nn; ++n) off[n + 1] += off[n];
+    std::vector<int> adj(off[Nn]), fill(off.begin(), off.end() - 1);
+    for (int e = 0; e < Ne; ++e) for (int k = 0; k < 3; ++k) adj[fill[t[k][e]]++] = e;  // ascending e per node
+
+    const int nNodePatches = (No + P - 1) / P;
+    std::vector<int> patch_of(Nn, -1);
+    for (int i = 0; i < No; ++i) patch_of[order[i]] = i / P;
+    // writer patch of an element = smallest patch id among its owned nodes; none -> orphan
+    std::vector<int> writer(Ne, -1);
+    std::vector<int> orphans;
+    for (int e = 0; e < Ne; ++e) {
+        int w = -1;
+        for (int k = 0; k < 3; ++k) {
+            const int q = patch_of[t[k][e]];
+            if (q >= 0 && (w < 0 || q < w)) w = q;
+        }
+        writer[e] = w;
+        if (w < 0) orphans.push_back(e);
+    }
+    const int EORPH = 2 * P;
+    const int nOrphPatches = ((int)orphans.size() + EORPH - 1) / EORPH;
+    const int nP = nNodePatches + nOrphPatches;
+
+    std::vector<std::vector<int>> pel(nP), pnd(nP);
+    std::vector<int> own_cnt(nP, 0);
+    std::vector<int> mark(Ne, -1), slot_of(Nn, -1);
+    size_t tot_e = 0;
+    for (int q = 0; q < nNodePatches; ++q) {
+        const int a = q * P, bnd = std::min(No, a + P);
+        own_cnt[q] = bnd - a;
+        auto &el = pel[q];
+        for (int i = a; i < bnd; ++i) {
+            const int n = order[i];
+            for (int j = off[n]; j < off[n + 1]; ++j) {
+                const int e = adj[j];
+                if (mark[e] != q) { mark[e] = q; el.push_back(e); }
+            }
+        }
+        std::sort(el.begin(), el.end());
+        tot_e += el.size();
+    }
+    for (int q = 0; q < nOrphPatches; ++q) {
+        auto &el = pel[nNodePatches + q];
+        const int a = q * EORPH, bnd = std::min((int)orphans.size(), a + EORPH);
+        el.assign(orphans.begin() + a, orphans.begin() + bnd);  // already ascending
+    }
+    int Emax = 0, Mmax = 0, Wp = 0, Pmax = 0;
+    std::vector<std::vector<unsigned short>> tri_l(nP);
+    std::vector<std::vector<std::vector<unsigned short>>> fan_l(nP);
+    for (int q = 0; q < nP; ++q) {
+        auto &nd = pnd[q];
+        if (q < nNodePatches) {
+            const int a = q * P;
+            for (int i = 0; i < own_cnt[q]; ++i) { nd.push_back(order[a + i]); slot_of[order[a + i]] = i; }
+        }
+        std::vector<int> halo;
+        for (int e : pel[q])
+            for (int k = 0; k < 3; ++k) {
+                const int n = t[k][e];
+                if (slot_of[n] < 0) { slot_of[n] = -2; halo.push_back(n); }
+            }
+        std::sort(halo.begin(), halo.end());
+        for (int n : halo) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
+        if (nd.size() > 65535 || pel[q].size() > 8191) return false;
+        auto &tl = tri_l[q];
+        tl.resize(4 * pel[q].size());
+        auto &fl = fan_l[q];
+        fl.assign(own_cnt[q], {});
+        for (size_t l = 0; l < pel[q].size(); ++l) {
+            const int e = pel[q][l];
+            for (int k = 0; k < 3; ++k) {
+                const int n = t[k][e], sl = slot_of[n];
+                tl[4 * l + k] = (unsigned short)sl;
+                if (sl < own_cnt[q]) fl[sl].push_back((unsigned short)((l << 3) | (ghost3[3 * (size_t)e + k] ? 4 : 0) | k));
+            }
+            tl[4 * l + 3] = 0;
+        }
+        for (auto &f : fl) Wp = std::max(Wp, (int)f.size());
+        for (int n : nd) slot_of[n] = -1;
+        Emax = std::max(Emax, (int)pel[q].size());
+        Mmax = std::max(Mmax, (int)nd.size());
+        Pmax = std::max(Pmax, own_cnt[q]);
+    }
+    Emax = (Emax + 1) & ~1;  // keep the ushort4 / double rows 16-byte aligned
+    Mmax = (Mmax + 1) & ~1;
+    Pmax = std::max(Pmax, 1);
+    Wp = std::max(Wp, 1);
+    out = HostPatches{};
+    out.nP = nP; out.Pmax = Pmax; out.Emax = Emax; out.Mmax = Mmax; out.Wp = Wp;
+    out.own_cnt = own_cnt;
+    out.elem_cnt.resize(nP); out.node_cnt.resize(nP);
+    out.pnodes.assign((size_t)nP * Mmax, 0);
+    out.pelem.assign((size_t)nP * Emax, 0);
+    out.ptri.assign((size_t)nP * Emax * 4, 0);
+    out.pfan.assign((size_t)nP * Wp * Pmax, 0xFFFF);
+    for (int q = 0; q < nP; ++q) {
+        out.elem_cnt[q] = (int)pel[q].size();
+        out.node_cnt[q] = (int)pnd[q].size();
+        std::copy(pnd[q].begin(), pnd[q].end(), out.pnodes.begin() + (size_t)q * Mmax);
+        for (size_t l = 0; l < pel[q].size(); ++l) {
+            const int e = pel[q][l];
+            const bool is_writer = (writer[e] == q) || (writer[e] < 0);  // orphans are written by their orphan patch
+            out.pelem[(size_t)q * Emax + l] = is_writer ? e : ~e;
+        }
+        std::copy(tri_l[q].begin(), tri_l[q].end(), out.ptri.begin() + (size_t)q * Emax * 4);
+        for (int i = 0; i < own_cnt[q]; ++i)
+            for (size_t k = 0; k < fan_l[q][i].size(); ++k)
+                out.pfan[(size_t)q * Wp * Pmax + k * Pmax + i] = fan_l[q][i][k];
+    }
+    out.avg_elems_per_own_node = No > 0 ? (double)tot_e / No : 0.;
+    return true;
+}
+
+bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
+                   int No, int P, HostPatches &out) {
+    // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
+    std::vector<int> order(No);
+    for (int i = 0; i < No; ++i) order[i] = i;
+    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out);
+    if (ok && out.avg_elems_per_own_node <= 3.0) return true;
+    // numbering without locality: cut patches along a Morton curve through the node coordinates
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int n = 0; n < No; ++n) { xmin = std::min(xmin, x0[n]); xmax = std::max(xmax, x0[n]); ymin = std::min(ymin, y0[n]); ymax = std::max(ymax, y0[n]); }
+    const double sx = xmax > xmin ? 65535. / (xmax - xmin) : 0., sy = ymax > ymin ? 65535. / (ymax - ymin) : 0.;
+    auto spread = [](unsigned v) { unsigned long long x = v & 0xFFFF; x = (x | (x << 8)) & 0x00FF00FF; x = (x | (x << 4)) & 0x0F0F0F0F; x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; };
+    std::vector<unsigned long long> key(No);
+    for (int n = 0; n < No; ++n) key[n] = spread((unsigned)((x0[n] - xmin) * sx)) | (spread((unsigned)((y0[n] - ymin) * sy)) << 1);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
+    HostPatches alt;
+    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
+        out = std::move(alt);
+        return true;
+    }
+    return ok;
+}
+
+int upload_patches(nxs_dyn_handle *h) {
+    free_pool(h->patch_allocs);
+    h->dpch = DevPatches{};
+    h->fused_lds = 0;
+    const DevMesh &m = h->dm;
+    const bool automatic = h->patch_nodes <= 0;
+    int P = automatic ? 224 : std::max(64, std::min(h->patch_nodes, 1024));
+    HostPatches hp;
+    for (;;) {
+        if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, P, hp))
+            return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
+        const size_t lds = (2 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax) * sizeof(double);
+        h->fused_lds = lds;
+        // automatic: one element per thread of a 512-thread block (all loads of a patch in flight at once)
+        // and at least 2 workgroups per CU (160 KiB LDS)
+        const bool fits = automatic ? (hp.Emax <= 512 && lds <= 80 * 1024) : (lds <= 80 * 1024);
+        if (fits || P <= 64) break;
+        P = automatic ? P - 16 : std::max(64, P * 3 / 4);
+    }
+    if (h->fused_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "patches need %zu B of LDS", h->fused_lds);
+    DevPatches &d = h->dpch;
+    d.nP = hp.nP; d.Pmax = hp.Pmax; d.Emax = hp.Emax; d.Mmax = hp.Mmax; d.Wp = hp.Wp;
+    int rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.own_cnt, hp.own_cnt))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.elem_cnt, hp.elem_cnt))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.node_cnt, hp.node_cnt))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.pnodes, hp.pnodes))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.pelem, hp.pelem))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.ptri, hp.ptri))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.pfan, hp.pfan))) return rc;
     return NXS_OK;
 }
 
@@ -1019,6 +1401,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->mesh_allocs);
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
+    free_pool(h->patch_allocs);
     if (h->h_send) (void)hipHostFree(h->h_send);
     if (h->h_recv) (void)hipHostFree(h->h_recv);
     if (h->d_partials) (void)hipFree(h->d_partials);
@@ -1043,6 +1426,14 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     if (!h || !key) return NXS_ERR_INVALID;
     if (!std::strcmp(key, "graph")) { h->use_graph = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "timing")) { h->timing_enabled = value != 0; return NXS_OK; }
+    if (!std::strcmp(key, "fused")) { h->fused = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "patch_nodes")) {
+        if (value != 0 && (value < 64 || value > 1024)) return fail(h, NXS_ERR_INVALID, "patch_nodes must be 0 (auto) or in [64,1024]");
+        h->patch_nodes = (int)value;
+        release_graph(h);
+        if (h->have_mesh) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipStreamSynchronize(h->stream)); return upload_patches(h); }
+        return NXS_OK;
+    }
     if (!std::strcmp(key, "timing_reset")) {  // drop what was accumulated so far (e.g. after warm-up)
         for (int k = 0; k < nxs_dyn_handle::NSETS; ++k) { int rc = harvest(h, k); if (rc) return rc; }
         for (double &x : h->sum_ms) x = 0.;
@@ -1077,6 +1468,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->mesh_allocs);
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
+    free_pool(h->patch_allocs);
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
     h->rank = 0; h->nranks = 1;
     h->send_procs.clear(); h->recv_procs.clear(); h->send_offsets.assign(1, 0); h->recv_offsets.assign(1, 0);
@@ -1086,8 +1478,11 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     d.Nn = Nn; d.Ne = Ne; d.No = No; d.Neo = Neo;
     int rc;
     // triangles, SoA, 0-based
-    std::vector<int> t[3];
+    std::vector<int> *t = h->h_t;
     for (int k = 0; k < 3; ++k) { t[k].resize(Ne); for (int e = 0; e < Ne; ++e) t[k][e] = m->indices[3 * e + k] - 1; }
+    h->h_ghost.assign(m->ghost_nodes, m->ghost_nodes + 3 * (size_t)Ne);
+    h->h_x0.assign(m->coord_x, m->coord_x + Nn);
+    h->h_y0.assign(m->coord_y, m->coord_y + Nn);
     if ((rc = dev_upload(h, h->mesh_allocs, &d.t0, t[0]))) return rc;
     if ((rc = dev_upload(h, h->mesh_allocs, &d.t1, t[1]))) return rc;
     if ((rc = dev_upload(h, h->mesh_allocs, &d.t2, t[2]))) return rc;
@@ -1180,6 +1575,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(s.VT, n2); A(s.VT2, n2); A(s.UM, n2); A(s.UT, n2);
     A(s.conc, ne); A(s.thick, ne); A(s.snow, ne); A(s.damage, ne); A(s.ridge, ne);
     A(s.s0, ne); A(s.s1, ne); A(s.s2, ne);
+    A(s.damage_b, ne); A(s.s0_b, ne); A(s.s1_b, ne); A(s.s2_b, ne);
     A(s.cyoung, ne); A(s.hyoung, ne); A(s.hsyoung, ne); A(s.cmyi, ne); A(s.tmyi, ne);
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
@@ -1199,6 +1595,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     h->n_partials = std::min(nblocks(Ne), 1024);
     HIPCHK(h, hipMalloc((void **)&h->d_partials, sizeof(RegridPartial) * h->n_partials));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if ((rc = upload_patches(h))) return rc;
     h->have_mesh = true;
     return NXS_OK;
 }
@@ -1451,9 +1848,35 @@ int halo_exchange(nxs_dyn_handle *h, double *vec, double move_dt) {
 
 bool multi_rank(const nxs_dyn_handle *h) { return h->nranks > 1; }
 
+PingPong pingpong(const nxs_dyn_handle *h, int parity) {
+    const DevState &s = h->ds;
+    PingPong b;
+    if (parity == 0) {
+        b.VTc = s.VT; b.s0c = s.s0; b.s1c = s.s1; b.s2c = s.s2; b.dc = s.damage;
+        b.VTn = s.VT2; b.s0n = s.s0_b; b.s1n = s.s1_b; b.s2n = s.s2_b; b.dn = s.damage_b;
+    } else {
+        b.VTc = s.VT2; b.s0c = s.s0_b; b.s1c = s.s1_b; b.s2c = s.s2_b; b.dc = s.damage_b;
+        b.VTn = s.VT; b.s0n = s.s0; b.s1n = s.s1; b.s2n = s.s2; b.dn = s.damage;
+    }
+    return b;
+}
+
+// sub-step `sidx` of the fused path: reads buffers of parity sidx%2, writes the other set
+void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt) {
+    const PingPong b = pingpong(h, sidx & 1);
+    const dim3 grid(h->dpch.nP);
+    const bool big = h->dpch.Pmax > 128 || h->dpch.Emax > 256, pow4 = h->dp.ers_int == 4;
+#define FUSED(TT, PP) hipLaunchKernelGGL((k_substep_fused<TT, PP>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt)
+    if (big) { if (pow4) FUSED(512, true); else FUSED(512, false); }
+    else { if (pow4) FUSED(256, true); else FUSED(256, false); }
+#undef FUSED
+}
+
 void launch_substep(nxs_dyn_handle *h, double move_dt) {
-    if (h->dp.dynamics_type == NXS_DYN_BBM)
-        LAUNCH(h, k_sigma_bbm, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    if (h->dp.dynamics_type == NXS_DYN_BBM) {
+        if (h->dp.ers_int == 4) LAUNCH(h, k_sigma_bbm<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+        else LAUNCH(h, k_sigma_bbm<false>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    }
     else
         LAUNCH(h, k_sigma_vp, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     LAUNCH(h, k_solve_move, h->dm.No, h->dm, h->ds, h->dw, h->dp, move_dt);
@@ -1462,25 +1885,38 @@ void launch_substep(nxs_dyn_handle *h, double move_dt) {
 int run_substeps(nxs_dyn_handle *h) {
     const int S = h->dp.substeps;
     const double move_dt = (h->dp.dynamics_type == NXS_DYN_MEVP) ? 0. : h->dp.dte;
+    const bool fused = h->fused != 0;
+    const int bbm = h->dp.dynamics_type == NXS_DYN_BBM;
+    auto one = [&](int s) {
+        if (fused) launch_fused(h, s, move_dt); else launch_substep(h, move_dt);
+    };
+    auto tail = [&]() {  // odd S on the fused path: result sits in the secondary buffers
+        if (fused && (S & 1)) LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm);
+    };
     if (multi_rank(h)) {
         for (int s = 0; s < S; ++s) {
-            launch_substep(h, move_dt);
-            int rc = halo_exchange(h, h->ds.VT, move_dt);
+            one(s);
+            // owned nodes were written to the buffer the next sub-step reads; ghosts must land there too
+            double *vec = fused ? ((s & 1) ? h->ds.VT : h->ds.VT2) : h->ds.VT;
+            int rc = halo_exchange(h, vec, move_dt);
             if (rc) return rc;
         }
-        h->timing.substep_launches = S * 4;
+        tail();
+        h->timing.substep_launches = S * (fused ? 3 : 4);
         return NXS_OK;
     }
-    h->timing.substep_launches = S * 2;
+    h->timing.substep_launches = S * (fused ? 1 : 2);
     if (!h->use_graph) {
-        for (int s = 0; s < S; ++s) launch_substep(h, move_dt);
+        for (int s = 0; s < S; ++s) one(s);
+        tail();
         return NXS_OK;
     }
     if (!h->graph_valid) {
         release_graph(h);
         hipGraph_t g = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        for (int s = 0; s < S; ++s) launch_substep(h, move_dt);
+        for (int s = 0; s < S; ++s) one(s);
+        tail();
         HIPCHK(h, hipStreamEndCapture(h->stream, &g));
         hipError_t e = hipGraphInstantiate(&h->substep_graph, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);

@@ -295,3 +295,52 @@ def test_full_size_10km_invariants_and_rigid_state():
     s = fe.get_state()
     assert np.all(s["VT"] == 0) and np.all(s["UM"] == 0) and np.all(s["sigma0"] == 0)
     fe.close()
+
+
+# ---- v2 fused sub-step kernel vs the v1 reference-loop kernels ----
+
+@pytest.mark.parametrize("dyn,substeps", [("bbm", 120), ("evp", 120), ("mevp", 120), ("bbm", 3), ("bbm", 1)])
+def test_fused_substep_kernel_is_bitwise_equal_to_the_per_loop_kernels(dyn, substeps):
+    """The fused kernel (node patches, LDS-staged assembly, ping-pong buffers) performs the same
+    operations in the same order as k_sigma_* + k_solve_move: identical bits, for even and odd numbers of
+    sub-steps (the odd case ends with a copy back from the secondary buffers)."""
+    outs = []
+    for fused in (1, 0):
+        fe, ref, lm = _pair("small", 2, options={"fused": fused}, dynamics_type=dyn, substeps=substeps,
+                            dtime_step=200. * substeps / 120.)
+        outs.append(fe.get_state())
+        fe.close()
+    for k in STATE_KEYS:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+@pytest.mark.parametrize("patch_nodes", [64, 200, 1024])
+def test_patch_size_does_not_change_a_bit(patch_nodes):
+    base, _, _ = _pair("toy", 2)
+    other, _, _ = _pair("toy", 2, options={"patch_nodes": patch_nodes})
+    a, b = base.get_state(), other.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(a[k], b[k]), k
+    base.close(); other.close()
+
+
+def test_shuffled_numbering_still_matches_the_oracle():
+    """A mesh whose node/element numbering has no locality (random permutation): patches are then cut
+    along a Morton curve through the coordinates; results must still match the oracle on that mesh."""
+    from nextsim_amd import dynamics, forcing as F, mesh as M
+    from oracle import pyoracle as O
+    gm = cases.global_mesh("small")
+    rng = np.random.default_rng(7)
+    pn = rng.permutation(gm.num_nodes); pe = rng.permutation(gm.num_elements)
+    inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
+    g2 = M.GlobalMesh(x=gm.x[pn].copy(), y=gm.y[pn].copy(), tri=np.ascontiguousarray(inv[gm.tri][pe].astype(np.int32)),
+                      dirichlet=gm.dirichlet[pn].copy(), neumann=gm.neumann[pn].copy(), lat=gm.lat[pn].copy(), name="shuffled")
+    p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), g2, alea_factor=0.33)
+    g = F.global_fields(g2, p, "arctic", C_fix, C_alea)
+    lm = M.localize(g2, 1)[0]
+    f = F.localize_fields(g, lm, g2.num_nodes)
+    fe = dynamics.FiniteElementDynamics(p); fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+    ref = O.OracleRank(lm, p, f)
+    fe.step(); ref.step(); fe.synchronize()
+    _assert_close(fe.get_state(), ref.arr, STATE_KEYS, 1e-10, "shuffled numbering")
+    fe.close()
