@@ -53,6 +53,7 @@ static constexpr int BLOCK = 256;
 // node flag bits
 #define NF_DIRICHLET 1
 #define NF_NEUMANN 2
+#define NF_LAT_NEG 4  // signbit(lat): all the solve needs of lat is copysign(sin_theta, lat)
 // element flag bits (static, per mesh)
 #define EF_ON_NEUMANN 8  // any vertex in M_neumann_flags (FE.cpp:3957-3961)
 
@@ -114,6 +115,7 @@ struct DevWork {
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
+    double *xs, *ys;  // [Nn] node coordinates on the displaced mesh at step start (frozen over the sub-steps, Q4)
     double *D_tau_a, *D_tau_w, *D_del;
 };
 
@@ -245,6 +247,9 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
             gv -= w.shape[(size_t)(j + 3) * Ne + e] * m_g_A3rd * sshj;
         }
     }
+    // same expression as load_vertices(): the fused sub-step kernel rebuilds the shape coefficients from these
+    w.xs[n] = m.x0[n] + 1. * s.UM[n];
+    w.ys[n] = m.y0[n] + 1. * s.UM[n + Nn];
     w.C_bu[n] = cb;
     w.grad_ssh[n] = gu;
     w.grad_ssh[n + Nn] = gv;
@@ -535,7 +540,8 @@ template <int T, bool POW4>
 __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p,
                                                      PingPong b, double move_dt) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lu = lds, *lv = lds + pp.Mmax, *lF = lds + 2 * (size_t)pp.Mmax;  // lF[6][Emax]
+    double *lu = lds, *lv = lds + pp.Mmax, *lx = lds + 2 * (size_t)pp.Mmax, *ly = lds + 3 * (size_t)pp.Mmax,
+           *lF = lds + 4 * (size_t)pp.Mmax;  // lF[6][Emax]
     // consecutive patches are neighbours in space: keep them on one XCD (blocks are dealt round-robin
     // over the 8 XCDs) so that shared halo elements / nodes hit that XCD's L2.  Speed only.
     int blk = blockIdx.x;
@@ -543,7 +549,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blk & 7;
         blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blk >> 3);
     }
-    const int t = threadIdx.x, Nn = m.Nn, Ne = m.Ne, Emax = pp.Emax;
+    const int t = threadIdx.x, Nn = m.Nn, Emax = pp.Emax;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
     const int *pn = pp.pnodes + (size_t)blk * pp.Mmax;
     const int *pe = pp.pelem + (size_t)blk * Emax;
@@ -558,11 +564,13 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     ushort4 tr = make_ushort4(0, 0, 0, 0);
     if (t < nE) { eraw = pe[t]; tr = pt[t]; }
 
-    if (t < nM) { lu[t] = b.VTc[my_node]; lv[t] = b.VTc[my_node + Nn]; }
+    if (t < nM) { lu[t] = b.VTc[my_node]; lv[t] = b.VTc[my_node + Nn]; lx[t] = w.xs[my_node]; ly[t] = w.ys[my_node]; }
     for (int i = t + T; i < nM; i += T) {
         const int g = pn[i];
         lu[i] = b.VTc[g];
         lv[i] = b.VTc[g + Nn];
+        lx[i] = w.xs[g];
+        ly[i] = w.ys[g];
     }
 
     for (int base = 0; base < nE; base += T) {
@@ -574,16 +582,26 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         double dxN[6], sig[3] = {0., 0., 0.}, damage = 0., c_expC = 0., c_pmax = 0., c_heal = 0., c_dxs = 1., c_coh = 0., volume = 0.;
         bool skip = true;
         if (active) {
-#pragma unroll
-            for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
             skip = w.eskip[e];
             sig[0] = b.s0c[e]; sig[1] = b.s1c[e]; sig[2] = b.s2c[e];
             c_expC = w.expC[e];
             volume = w.volume[e];
             if (bbm) { damage = b.dc[e]; c_pmax = w.pmax[e]; c_heal = w.heal[e]; c_dxs = w.dxs[e]; c_coh = s.cohesion[e]; }
         }
-        if (base == 0) __syncthreads();  // staged velocities visible
+        if (base == 0) __syncthreads();  // staged velocities / coordinates visible
         if (active) {
+            {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates: the same operations as
+                // k_prep_elements, so the same bits as M_shape_coeff -- 48 B/element less to stream
+                const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
+                const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
+                const double jac = jacobian(vx, vy);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+                    dxN[k] = (vy[kp1] - vy[kp2]) / jac;
+                    dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+                }
+            }
             if (skip) {
                 sig[0] = sig[1] = sig[2] = 0.;
                 damage = 0.;
@@ -617,7 +635,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             nf = m.nflags[n];
             node_mass = w.node_mass[n];
             gx = w.grad_ssh[n]; gy = w.grad_ssh[n + Nn];
-            rlm = w.rlmass[n]; cbu = w.C_bu[n]; fcor = w.fcor[n]; lat = m.lat[n];
+            rlm = w.rlmass[n]; cbu = w.C_bu[n]; fcor = w.fcor[n]; lat = (nf & NF_LAT_NEG) ? -1. : 1.;
             tax = w.D_tau_a[n]; tay = w.D_tau_a[n + Nn];
             ou = s.ocean[n]; ov = s.ocean[n + Nn];
             if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
@@ -981,7 +999,7 @@ struct nxs_dyn_handle {
     DevWork dw{};
     DevPatches dpch{};
     int fused = 1;          // v2 fused sub-step kernel (default) vs v1 two-kernel sub-step
-    int patch_nodes = 0;    // own nodes per patch; 0 = auto (largest patch whose elements fit one 512-thread block)
+    int patch_nodes = 0;    // own nodes per patch; 0 = auto
     size_t fused_lds = 0;
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
     std::vector<unsigned char> h_ghost;
@@ -1298,18 +1316,19 @@ int upload_patches(nxs_dyn_handle *h) {
     h->fused_lds = 0;
     const DevMesh &m = h->dm;
     const bool automatic = h->patch_nodes <= 0;
-    int P = automatic ? 224 : std::max(64, std::min(h->patch_nodes, 1024));
+    int P = automatic ? 512 : std::max(64, std::min(h->patch_nodes, 1024));
     HostPatches hp;
     for (;;) {
         if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, P, hp))
             return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
-        const size_t lds = (2 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax) * sizeof(double);
+        const size_t lds = (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax) * sizeof(double);
         h->fused_lds = lds;
-        // automatic: one element per thread of a 512-thread block (all loads of a patch in flight at once)
-        // and at least 2 workgroups per CU (160 KiB LDS)
-        const bool fits = automatic ? (hp.Emax <= 512 && lds <= 80 * 1024) : (lds <= 80 * 1024);
+        // large patches = few recomputed halo elements; the limit is 2 workgroups per CU (160 KiB LDS).
+        // Small meshes: enough patches to give every CU two workgroups.
+        bool fits = lds <= 80 * 1024;
+        if (automatic && fits && hp.nP < 512 && P > 64) fits = false;
         if (fits || P <= 64) break;
-        P = automatic ? P - 16 : std::max(64, P * 3 / 4);
+        P = automatic ? P - 32 : std::max(64, P * 3 / 4);
     }
     if (h->fused_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "patches need %zu B of LDS", h->fused_lds);
     DevPatches &d = h->dpch;
@@ -1489,6 +1508,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     // node flags
     std::vector<unsigned char> nf(Nn, 0);
     for (int n = 0; n < Nn; ++n) if (m->mask_dirichlet[n]) nf[n] |= NF_DIRICHLET;
+    for (int n = 0; n < Nn; ++n) if (std::signbit(m->lat[n])) nf[n] |= NF_LAT_NEG;
     for (int i = 0; i < m->num_neumann_flags; ++i) nf[m->neumann_flags[i]] |= NF_NEUMANN;
     if ((rc = dev_upload(h, h->mesh_allocs, &d.nflags, nf))) return rc;
     // element flags
@@ -1583,7 +1603,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne);
     A(w.force, 6 * ne);
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
-    A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
+    A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.xs, (size_t)Nn); A(w.ys, (size_t)Nn); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
 #undef A
     HIPCHK(h, hipMemsetAsync(w.surface, 0, ne * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(w.delta_x, 0, ne * sizeof(double), h->stream));
