@@ -57,8 +57,9 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn):
     gm, p, lm, f = build_case(kind, world, rank)
     fe = dynamics.FiniteElementDynamics(p, device=local_rank)
     fe.set_mesh(lm)
+    transport = "none"
     if world > 1:
-        fe.comm_init(unique_id_fn(), rank, world)
+        transport = setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn)
     fe.put_state(f)
     fe.set_forcing(f)
 
@@ -83,7 +84,42 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn):
     tm = fe.timing()
     crash = fe.checkFieldsFast()
     fe.close()
-    return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash)
+    return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash, transport=transport)
+
+
+def setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn):
+    """RCCL over xGMI (device-direct send/recv of the packed M_VT halo) unless NXS_HALO_TRANSPORT=host or
+    the communicator cannot be created on every rank; then the host-staged transport
+    (nxs_dyn_set_halo_exchange_fn) through torch.distributed/gloo -- slower, but the job still runs."""
+    from nextsim_amd import dynamics
+    want = os.environ.get("NXS_HALO_TRANSPORT", "rccl")
+    ok = 0.0
+    if want == "rccl":
+        try:
+            fe.comm_init(unique_id_fn(), rank, world)
+            ok = 1.0
+        except dynamics.NxsError as e:
+            print(f"[bench rank {rank}] RCCL communicator failed: {e}", file=sys.stderr, flush=True)
+    t = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if float(t[0]) == 1.0:
+        return "rccl"
+
+    def exchange(send, recv):
+        reqs, bufs = [], []
+        for k, q in enumerate(lm.send_procs):
+            a, b = 2 * int(lm.send_offsets[k]), 2 * int(lm.send_offsets[k + 1])
+            reqs.append(dist.isend(torch.from_numpy(send[a:b].copy()), int(q)))
+        for k, q in enumerate(lm.recv_procs):
+            a, b = 2 * int(lm.recv_offsets[k]), 2 * int(lm.recv_offsets[k + 1])
+            tt = torch.empty(b - a, dtype=torch.float64)
+            reqs.append(dist.irecv(tt, int(q))); bufs.append((a, b, tt))
+        for r_ in reqs:
+            r_.wait()
+        for a, b, tt in bufs:
+            recv[a:b] = tt.numpy()
+    fe.set_halo_exchange(exchange)
+    return "host-staged (gloo)"
 
 
 def cpu_baseline(kind, nsteps=1):
@@ -120,14 +156,25 @@ def main():
 
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the dynamics path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % max(torch.cuda.device_count(), 1))
+    local_rank = local_rank % max(torch.cuda.device_count(), 1)  # several ranks may share a GPU on a test box
 
     unique_id_fn = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (barrier, max-reduce, id broadcast) on gloo; the data path (halo exchange of
         # M_VT) is RCCL inside libnxsdyn.so
-        dist.init_process_group("gloo", rank=rank, world_size=world)
+        # gloo announces itself on stdout from C++; keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
         def unique_id_fn():
             ids = [dynamics.FiniteElementDynamics.comm_unique_id() if rank == 0 else None]
@@ -162,12 +209,12 @@ def main():
                         f"BBM rheology, dt=200 s, {S} sub-steps, 50 smoother sweeps, update(); "
                         f"domain-decomposed over {world} GPU(s)",
             "mesh": args.mesh, "elements": gm.num_elements, "nodes": gm.num_nodes, "substeps": S,
-            "rheology": "bbm", "partitions": world,
+            "rheology": "bbm", "partitions": world, "halo_transport": res["transport"],
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "sub-step loop (k_sigma_bbm + k_solve_move per sub-step)" if launches_per_substep == 2
-                      else f"sub-step loop ({launches_per_substep} launches per sub-step)",
+            "kernel": "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve + mesh move)"
+                      if launches_per_substep == 1 else f"sub-step loop ({launches_per_substep} launches per sub-step incl. halo pack/unpack)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -529,6 +529,10 @@ __global__ void __launch_bounds__(BLOCK) k_move(DevMesh m, DevState s, int first
     s.UT[n + Nn] += dt * v;
 }
 
+// streaming accesses that should not displace the reusable arrays from L2 / Infinity Cache
+template <bool NT> __device__ __forceinline__ double ldg(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ void stg(double *p, double v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
+
 // ------------------------------------------------------------------------------------------------
 // v2  ONE launch per sub-step: K3 (stress/damage) + K4 (assembly) + K5 (nodal solve) + K7 (mesh move).
 // FE.cpp:10425-10553.  Workgroup = patch.  Phase 0 stages the patch's nodal velocities in LDS,
@@ -536,7 +540,7 @@ __global__ void __launch_bounds__(BLOCK) k_move(DevMesh m, DevState s, int first
 // lets each own node subtract the forces of its fan (ascending element order, as the serial scatter)
 // and solve.  sigma, damage and VT are ping-pong buffered: a neighbouring patch may still be reading
 // the old values of a shared element / node while this one writes the new ones.
-template <int T, bool POW4>
+template <int T, bool POW4, int NTM>
 __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p,
                                                      PingPong b, double move_dt) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -555,6 +559,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     const int *pe = pp.pelem + (size_t)blk * Emax;
     const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * Emax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
+    constexpr bool NT_S = NTM & 1, NT_U = NTM & 2, NT_C = NTM & 4;  // sigma/damage, UM/UT, element constants
 
     // The kernel is latency-bound unless every dependent load hop is overlapped, so all global loads
     // that do not need LDS are issued up front: indices first, then (one hop later) the nodal
@@ -583,10 +588,13 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         bool skip = true;
         if (active) {
             skip = w.eskip[e];
-            sig[0] = b.s0c[e]; sig[1] = b.s1c[e]; sig[2] = b.s2c[e];
-            c_expC = w.expC[e];
-            volume = w.volume[e];
-            if (bbm) { damage = b.dc[e]; c_pmax = w.pmax[e]; c_heal = w.heal[e]; c_dxs = w.dxs[e]; c_coh = s.cohesion[e]; }
+            sig[0] = ldg<NT_S>(b.s0c + e); sig[1] = ldg<NT_S>(b.s1c + e); sig[2] = ldg<NT_S>(b.s2c + e);
+            c_expC = ldg<NT_C>(w.expC + e);
+            volume = ldg<NT_C>(w.volume + e);
+            if (bbm) {
+                damage = ldg<NT_S>(b.dc + e);
+                c_pmax = ldg<NT_C>(w.pmax + e); c_heal = ldg<NT_C>(w.heal + e); c_dxs = ldg<NT_C>(w.dxs + e); c_coh = ldg<NT_C>(s.cohesion + e);
+            }
         }
         if (base == 0) __syncthreads();  // staged velocities / coordinates visible
         if (active) {
@@ -612,8 +620,8 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 else vp_stress(p, dxN, u, v, sig, c_expC);
             }
             if (writer) {
-                b.s0n[e] = sig[0]; b.s1n[e] = sig[1]; b.s2n[e] = sig[2];
-                if (bbm) b.dn[e] = damage;
+                stg<NT_S>(b.s0n + e, sig[0]); stg<NT_S>(b.s1n + e, sig[1]); stg<NT_S>(b.s2n + e, sig[2]);
+                if (bbm) stg<NT_S>(b.dn + e, damage);
             }
             double F[6];
             corner_forces(volume, sig, dxN, F);
@@ -639,7 +647,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             tax = w.D_tau_a[n]; tay = w.D_tau_a[n + Nn];
             ou = s.ocean[n]; ov = s.ocean[n + Nn];
             if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
-            if (move_dt != 0.) { umu = s.UM[n]; umv = s.UM[n + Nn]; utu = s.UT[n]; utv = s.UT[n + Nn]; }
+            if (move_dt != 0.) { umu = ldg<NT_U>(s.UM + n); umv = ldg<NT_U>(s.UM + n + Nn); utu = ldg<NT_U>(s.UT + n); utv = ldg<NT_U>(s.UT + n + Nn); }
         }
         if (base == 0) __syncthreads();  // corner forces visible
         if (!active) continue;
@@ -659,11 +667,11 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         b.VTn[n + Nn] = vice;
         if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
             if (!(nf & NF_NEUMANN)) {
-                s.UM[n] = umu + move_dt * uice;
-                s.UM[n + Nn] = umv + move_dt * vice;
+                stg<NT_U>(s.UM + n, umu + move_dt * uice);
+                stg<NT_U>(s.UM + n + Nn, umv + move_dt * vice);
             }
-            s.UT[n] = utu + move_dt * uice;
-            s.UT[n + Nn] = utv + move_dt * vice;
+            stg<NT_U>(s.UT + n, utu + move_dt * uice);
+            stg<NT_U>(s.UT + n + Nn, utv + move_dt * vice);
         }
     }
 }
@@ -719,24 +727,30 @@ __global__ void __launch_bounds__(BLOCK) k_halo_unpack(double *__restrict__ vec,
 
 // ------------------------------------------------------------------------------------------------
 // K8 one Jacobi sweep of the open-water smoother, FE.cpp:10582-10608: src -> dst for every node
+// Only ice-free, non-Dirichlet OWNED nodes change (FE.cpp:10589); every other node keeps its value in
+// both ping-pong buffers (k_copy_vt makes them equal once before the 50 sweeps; ghosts are refreshed by
+// the halo exchange), so a sweep touches 9 B per node plus the open-water nodes' neighbourhoods.
 __global__ void __launch_bounds__(BLOCK) k_smooth(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst) {
     const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= m.Nn) return;
+    if (n >= m.No) return;
+    if ((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.) return;
     const int Nn = m.Nn;
-    double u = src[n], v = src[n + Nn];
-    if (n < m.No && !((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) {
-        u = 0.; v = 0.;
-        const int num_neighbours = m.n2n_cnt[n];
-        for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
-            const int nni = m.n2n[(size_t)j * Nn + n];
-            u += src[nni];
-            v += src[nni + Nn];
-        }
-        u /= num_neighbours;
-        v /= num_neighbours;
+    double u = 0., v = 0.;
+    const int num_neighbours = m.n2n_cnt[n];
+    for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
+        const int nni = m.n2n[(size_t)j * Nn + n];
+        u += src[nni];
+        v += src[nni + Nn];
     }
+    u /= num_neighbours;
+    v /= num_neighbours;
     dst[n] = u;
     dst[n + Nn] = v;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_copy_vt(int n2, const double *__restrict__ src, double *__restrict__ dst) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n2) dst[i] = src[i];
 }
 
 // K9 FE.cpp:10613-10640
@@ -1000,6 +1014,7 @@ struct nxs_dyn_handle {
     DevPatches dpch{};
     int fused = 1;          // v2 fused sub-step kernel (default) vs v1 two-kernel sub-step
     int patch_nodes = 0;    // own nodes per patch; 0 = auto
+    int nt_mask = 3;        // non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)
     size_t fused_lds = 0;
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
     std::vector<unsigned char> h_ghost;
@@ -1445,6 +1460,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     if (!h || !key) return NXS_ERR_INVALID;
     if (!std::strcmp(key, "graph")) { h->use_graph = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "timing")) { h->timing_enabled = value != 0; return NXS_OK; }
+    if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "fused")) { h->fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
         if (value != 0 && (value < 64 || value > 1024)) return fail(h, NXS_ERR_INVALID, "patch_nodes must be 0 (auto) or in [64,1024]");
@@ -1886,9 +1902,11 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt) {
     const PingPong b = pingpong(h, sidx & 1);
     const dim3 grid(h->dpch.nP);
     const bool big = h->dpch.Pmax > 128 || h->dpch.Emax > 256, pow4 = h->dp.ers_int == 4;
-#define FUSED(TT, PP) hipLaunchKernelGGL((k_substep_fused<TT, PP>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt)
-    if (big) { if (pow4) FUSED(512, true); else FUSED(512, false); }
-    else { if (pow4) FUSED(256, true); else FUSED(256, false); }
+#define FUSED(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt)
+#define FUSED_NT(TT, PP) switch (h->nt_mask) { case 0: FUSED(TT, PP, 0); break; case 1: FUSED(TT, PP, 1); break; case 3: FUSED(TT, PP, 3); break; case 4: FUSED(TT, PP, 4); break; case 5: FUSED(TT, PP, 5); break; default: FUSED(TT, PP, 7); break; }
+    if (big) { if (pow4) { FUSED_NT(512, true); } else { FUSED(512, false, 0); } }
+    else { if (pow4) { FUSED_NT(256, true); } else { FUSED(256, false, 0); } }
+#undef FUSED_NT
 #undef FUSED
 }
 
@@ -1972,8 +1990,9 @@ int explicit_solve(nxs_dyn_handle *h) {
     if (timed) HIPCHK(h, hipEventRecord(h->cur[2], h->stream));
     // Q9: 50 sweeps, hard-coded (FE.cpp:10580)
     double *a = h->ds.VT, *b = h->ds.VT2;
+    LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
     for (int nit = 0; nit < 50; ++nit) {
-        LAUNCH(h, k_smooth, m.Nn, m, h->dw, a, b);
+        LAUNCH(h, k_smooth, m.No, m, h->dw, a, b);
         if (multi_rank(h)) { rc = halo_exchange(h, b, 0.); if (rc) return rc; }
         std::swap(a, b);
     }
