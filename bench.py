@@ -92,9 +92,22 @@ def setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn):
     the communicator cannot be created on every rank; then the host-staged transport
     (nxs_dyn_set_halo_exchange_fn) through torch.distributed/gloo -- slower, but the job still runs."""
     from nextsim_amd import dynamics
-    want = os.environ.get("NXS_HALO_TRANSPORT", "rccl")
+    want = os.environ.get("NXS_HALO_TRANSPORT", "auto")
+
+    def all_gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+
+    if want in ("auto", "ipc"):
+        # device-direct peer stores over xGMI; kept only if its self-test passes on every rank
+        try:
+            if fe.ipc_setup(all_gather):
+                return "device-direct peer mailboxes (hipIpc, xGMI P2P stores)"
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench rank {rank}] ipc transport unavailable: {e}", file=sys.stderr, flush=True)
     ok = 0.0
-    if want == "rccl":
+    if want in ("auto", "rccl"):
         try:
             fe.comm_init(unique_id_fn(), rank, world)
             ok = 1.0

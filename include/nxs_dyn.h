@@ -203,6 +203,19 @@ NXS_API int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo);
 NXS_API int nxs_dyn_comm_unique_id(void *id128);
 NXS_API int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks);
 
+/* Device-direct transport: updateGhosts through peer-mapped mailboxes (stores over xGMI, flags, no RCCL
+ * launch, replayable from a hipGraph).  Collective setup driven by the host launcher:
+ *   1. every rank: nxs_dyn_ipc_export(h, blob)                 -> NXS_IPC_BLOB_BYTES bytes to publish
+ *   2. the launcher all-gathers the blobs and each rank's receive lists
+ *   3. every rank: nxs_dyn_ipc_connect(h, blobs_of_my_send_neighbours, ...)
+ *   4. every rank: nxs_dyn_ipc_selftest(h, rounds, &errors)    -> use it only if errors == 0 everywhere
+ * Takes precedence over RCCL once connected; the host-staged callback below overrides both. */
+#define NXS_IPC_BLOB_BYTES 128
+NXS_API int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob);
+NXS_API int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset,
+                                const int32_t *peer_recv_total, const int32_t *peer_flag_slot);
+NXS_API int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors);
+
 /* Alternative transport: host-staged exchange through the CALLER's communicator -- the literal
  * M_comm.send / M_comm.recv of FE.cpp:13981-13985.  send holds, per send neighbour k, 2*n_k doubles
  * [u-block | v-block] at offset 2*send_offsets[k]; recv is laid out the same way from recv_offsets.

@@ -726,6 +726,130 @@ __global__ void __launch_bounds__(BLOCK) k_halo_unpack(double *__restrict__ vec,
 }
 
 // ------------------------------------------------------------------------------------------------
+// K6, device-direct transport: updateGhosts through peer-mapped memory (xGMI P2P stores) instead of
+// RCCL launches.  Every rank owns a "mailbox" = two receive buffers (exchange parity) + one flag per
+// receive neighbour, exported with hipIpcGetMemHandle and mapped by its neighbours.
+//   k_halo_push      pack my boundary values and store them straight into each neighbour's mailbox
+//                    (write-through, system scope), then -- after ALL blocks have finished -- set my flag
+//                    in each neighbour's mailbox to the exchange's sequence number.
+//   k_halo_pull      wait until every neighbour's flag has reached the sequence number, then unpack the
+//                    mailbox (reads that bypass the caches) into the ghost slots and move the ghost nodes.
+// Sequence numbers live in device memory, so the kernels replay unchanged from a hipGraph.  Two mailbox
+// buffers suffice: a neighbour cannot start exchange x+2 before it has received my exchange x+1, which I
+// send only after my pull of exchange x.  Every spin is bounded; a timeout raises ipc->error.
+struct IpcDev {
+    unsigned long long *seq_push;   // exchanges pushed so far (this rank)
+    unsigned long long *seq_pull;   // exchanges pulled so far
+    unsigned int *done_push, *done_pull;  // block-completion counters
+    int *error;                     // != 0 after a timeout / self-test mismatch
+    double *mailbox;                // my mailbox: [2][2*tr] doubles
+    unsigned long long *flags;      // my flags: [nr], written by the neighbours
+    int tr, ns, nr;
+    double *const *peer_seg;        // [ns] neighbour k's mailbox address of MY segment (parity 0)
+    const long long *peer_parity_stride;  // [ns] doubles between that neighbour's two buffers (2*tr_k)
+    unsigned long long *const *peer_flag; // [ns] address of my flag slot in neighbour k's mailbox
+};
+
+__device__ __forceinline__ void sys_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double sys_load(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
+// selftest != 0: the payload is a code of (rank, entry, sequence) instead of vec
+__global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ vec, int Nn, int total, const int *__restrict__ index,
+                                                     const int *__restrict__ seg_of, const int *__restrict__ offsets, IpcDev ipc,
+                                                     int rank, int selftest) {
+    const unsigned long long seq = *ipc.seq_push;
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j < total) {
+        const int k = seg_of[j];
+        const int off = offsets[k], srl = offsets[k + 1] - off;
+        double *dst = ipc.peer_seg[k] + (seq & 1ull) * ipc.peer_parity_stride[k];
+        double u, v;
+        if (selftest) {
+            u = (double)rank * 1e6 + (double)(j - off) + (double)seq * 1e-3;
+            v = -u;
+        } else {
+            const int idx = index[j];
+            u = vec[idx];
+            v = vec[idx + Nn];
+        }
+        sys_store(dst + (j - off), u);
+        sys_store(dst + (j - off) + srl, v);
+    }
+    // publish: every block releases its stores, the last one to finish raises the flags
+    __threadfence_system();
+    __syncthreads();
+    __shared__ int last;
+    if (threadIdx.x == 0) last = (atomicAdd(ipc.done_push, 1u) == gridDim.x - 1);
+    __syncthreads();
+    if (last) {
+        __threadfence_system();
+        for (int k = threadIdx.x; k < ipc.ns; k += BLOCK)
+            __hip_atomic_store(ipc.peer_flag[k], seq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+            *ipc.done_push = 0u;
+            *ipc.seq_push = seq + 1ull;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_halo_pull(double *__restrict__ vec, DevMesh m, DevState s, int total,
+                                                     const int *__restrict__ index, const int *__restrict__ seg_of,
+                                                     const int *__restrict__ offsets, IpcDev ipc, double move_dt, int selftest,
+                                                     const int *__restrict__ recv_procs) {
+    const unsigned long long seq = *ipc.seq_pull;
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        const long long t0 = wall_clock64();  // 100 MHz
+        for (int k = 0; k < ipc.nr; ++k) {
+            while (__hip_atomic_load(ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq + 1ull) {
+                __builtin_amdgcn_s_sleep(8);
+                if (wall_clock64() - t0 > 1000000000ll) { ok = 0; atomicExch(ipc.error, 1); break; }  // 10 s
+            }
+            if (!ok) break;
+        }
+        __threadfence_system();
+    }
+    __syncthreads();
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (ok && j < total) {
+        const int Nn = m.Nn;
+        const int k = seg_of[j];
+        const int off = offsets[k], srl = offsets[k + 1] - off;
+        const double *src = ipc.mailbox + (seq & 1ull) * 2ull * (unsigned long long)ipc.tr + 2 * (size_t)off;
+        const double u = sys_load(src + (j - off));
+        const double v = sys_load(src + (j - off) + srl);
+        if (selftest) {
+            const double eu = (double)recv_procs[k] * 1e6 + (double)(j - off) + (double)seq * 1e-3;
+            if (u != eu || v != -eu) atomicExch(ipc.error, 2);
+        } else {
+            const int n = index[j];
+            vec[n] = u;
+            vec[n + Nn] = v;
+            if (move_dt != 0.) {
+                if (!(m.nflags[n] & NF_NEUMANN)) {
+                    s.UM[n] += move_dt * u;
+                    s.UM[n + Nn] += move_dt * v;
+                }
+                s.UT[n] += move_dt * u;
+                s.UT[n + Nn] += move_dt * v;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ipc.done_pull, 1u) == gridDim.x - 1) {
+        *ipc.done_pull = 0u;
+        *ipc.seq_pull = seq + 1ull;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // K8 one Jacobi sweep of the open-water smoother, FE.cpp:10582-10608: src -> dst for every node
 // Only ice-free, non-Dirichlet OWNED nodes change (FE.cpp:10589); every other node keeps its value in
 // both ping-pong buffers (k_copy_vt makes them equal once before the 50 sweeps; ghosts are refreshed by
@@ -1031,6 +1155,14 @@ struct nxs_dyn_handle {
     std::vector<void *> halo_allocs;
     Rccl rccl;
     void *comm = nullptr;
+    // device-direct transport (peer-mapped mailboxes)
+    bool ipc_ready = false;
+    IpcDev ipc{};
+    void *ipc_block = nullptr;             // my mailbox allocation (exported)
+    size_t ipc_block_bytes = 0;
+    std::vector<void *> ipc_peer_base;     // opened peer mailboxes (to close)
+    std::vector<void *> ipc_allocs;
+    int *d_recv_procs = nullptr;
     nxs_dyn_halo_fn halo_fn = nullptr;  // host-staged exchange through the caller's communicator
     void *halo_ctx = nullptr;
     double *h_send = nullptr, *h_recv = nullptr;  // pinned staging buffers
@@ -1359,6 +1491,14 @@ int upload_patches(nxs_dyn_handle *h) {
     return NXS_OK;
 }
 
+void ipc_release(nxs_dyn_handle *h) {
+    for (void *p : h->ipc_peer_base) if (p) (void)hipIpcCloseMemHandle(p);
+    h->ipc_peer_base.clear();
+    free_pool(h->ipc_allocs);
+    if (h->ipc_block) { (void)hipFree(h->ipc_block); h->ipc_block = nullptr; }
+    h->ipc_ready = false;
+    h->ipc = IpcDev{};
+}
 void release_graph(nxs_dyn_handle *h) {
     if (h->substep_graph) { (void)hipGraphExecDestroy(h->substep_graph); h->substep_graph = nullptr; }
     h->graph_valid = false;
@@ -1432,6 +1572,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     release_graph(h);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
+    ipc_release(h);
     free_pool(h->mesh_allocs);
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
@@ -1644,6 +1785,7 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     release_graph(h);
     free_pool(h->halo_allocs);
+    ipc_release(h);
     h->have_halo = false;
     const int Nn = h->dm.Nn, No = h->dm.No;
     if (halo->nranks < 1 || halo->rank < 0 || halo->rank >= halo->nranks) return fail(h, NXS_ERR_INVALID, "rank/nranks invalid");
@@ -1683,6 +1825,7 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
     if ((rc = dev_upload(h, h->halo_allocs, &cp, ridx))) return rc; h->d_recv_index = const_cast<int *>(cp);
     if ((rc = dev_upload(h, h->halo_allocs, &cp, rseg))) return rc; h->d_recv_seg = const_cast<int *>(cp);
     if ((rc = dev_upload(h, h->halo_allocs, &cp, h->recv_offsets))) return rc; h->d_recv_off = const_cast<int *>(cp);
+    if ((rc = dev_upload(h, h->halo_allocs, &cp, h->recv_procs))) return rc; h->d_recv_procs = const_cast<int *>(cp);
     if ((rc = dev_alloc(h, h->halo_allocs, &h->d_send_buf, 2 * (size_t)ts))) return rc;
     if ((rc = dev_alloc(h, h->halo_allocs, &h->d_recv_buf, 2 * (size_t)tr))) return rc;
     if (h->h_send) { (void)hipHostFree(h->h_send); h->h_send = nullptr; }
@@ -1735,6 +1878,97 @@ int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks
     nccl_comm_init_rank_t init = (nccl_comm_init_rank_t)h->rccl.CommInitRank;
     int e = init(&h->comm, nranks, id, rank);
     if (e != 0) return fail(h, NXS_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, h->rccl.GetErrorString(e));
+    return NXS_OK;
+}
+
+// Device-direct transport, step 1: allocate my mailbox and export it.  blob receives NXS_IPC_BLOB_BYTES.
+int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
+    if (!h || !blob) return NXS_ERR_INVALID;
+    if (!h->have_halo) return fail(h, NXS_ERR_STATE, "ipc_export before set_halo");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    release_graph(h);
+    ipc_release(h);
+    const int nr = (int)h->recv_procs.size();
+    const size_t tr = (size_t)h->recv_offsets[nr];
+    const size_t bytes = (4 * tr + (size_t)std::max(nr, 1) + 16) * sizeof(double);  // 2 buffers of 2*tr doubles + flags
+    HIPCHK(h, hipMalloc(&h->ipc_block, bytes));
+    HIPCHK(h, hipMemset(h->ipc_block, 0, bytes));
+    h->ipc_block_bytes = bytes;
+    hipIpcMemHandle_t mh;
+    HIPCHK(h, hipIpcGetMemHandle(&mh, h->ipc_block));
+    static_assert(sizeof(hipIpcMemHandle_t) <= NXS_IPC_BLOB_BYTES, "blob too small");
+    std::memset(blob, 0, NXS_IPC_BLOB_BYTES);
+    std::memcpy(blob, &mh, sizeof mh);
+    return NXS_OK;
+}
+
+// Step 2: map the neighbours' mailboxes.  For send neighbour k (order of nxs_dyn_halo.send_procs):
+// blobs + k*NXS_IPC_BLOB_BYTES is its exported blob, peer_recv_offset[k] the offset (in nodes) of MY
+// segment inside its receive lists, peer_recv_total[k] its total number of received nodes and
+// peer_flag_slot[k] my position in its recv_procs.
+int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset, const int32_t *peer_recv_total,
+                        const int32_t *peer_flag_slot) {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->ipc_block) return fail(h, NXS_ERR_STATE, "ipc_connect before ipc_export");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
+    if (ns > 0 && (!blobs || !peer_recv_offset || !peer_recv_total || !peer_flag_slot)) return fail(h, NXS_ERR_INVALID, "ipc_connect: NULL tables");
+    std::vector<double *> seg(ns);
+    std::vector<long long> stride(ns);
+    std::vector<unsigned long long *> flag(ns);
+    for (int k = 0; k < ns; ++k) {
+        hipIpcMemHandle_t mh;
+        std::memcpy(&mh, (const char *)blobs + (size_t)k * NXS_IPC_BLOB_BYTES, sizeof mh);
+        void *base = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&base, mh, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) return fail(h, NXS_ERR_COMM, "hipIpcOpenMemHandle(neighbour %d): %s", h->send_procs[k], hipGetErrorString(e));
+        h->ipc_peer_base.push_back(base);
+        double *mb = static_cast<double *>(base);
+        seg[k] = mb + 2 * (size_t)peer_recv_offset[k];
+        stride[k] = 2ll * peer_recv_total[k];
+        flag[k] = reinterpret_cast<unsigned long long *>(mb + 4 * (size_t)peer_recv_total[k]) + peer_flag_slot[k];
+    }
+    IpcDev &d = h->ipc;
+    const size_t tr = (size_t)h->recv_offsets[nr];
+    d.mailbox = static_cast<double *>(h->ipc_block);
+    d.flags = reinterpret_cast<unsigned long long *>(d.mailbox + 4 * tr);
+    d.tr = (int)tr; d.ns = ns; d.nr = nr;
+    int rc;
+    unsigned long long *ctr = nullptr;
+    if ((rc = dev_alloc(h, h->ipc_allocs, &ctr, 8))) return rc;
+    HIPCHK(h, hipMemset(ctr, 0, 8 * sizeof(unsigned long long)));
+    d.seq_push = ctr; d.seq_pull = ctr + 1;
+    d.done_push = reinterpret_cast<unsigned int *>(ctr + 2); d.done_pull = reinterpret_cast<unsigned int *>(ctr + 3);
+    d.error = reinterpret_cast<int *>(ctr + 4);
+    double *const *dseg; const long long *dstr; unsigned long long *const *dfl;
+    { const double **tmp; std::vector<const double *> v(seg.begin(), seg.end()); if ((rc = dev_upload(h, h->ipc_allocs, (const double *const **)&tmp, v))) return rc; dseg = (double *const *)tmp; }
+    if ((rc = dev_upload(h, h->ipc_allocs, &dstr, stride))) return rc;
+    { const unsigned long long **tmp; std::vector<const unsigned long long *> v(flag.begin(), flag.end()); if ((rc = dev_upload(h, h->ipc_allocs, (const unsigned long long *const **)&tmp, v))) return rc; dfl = (unsigned long long *const *)tmp; }
+    d.peer_seg = dseg; d.peer_parity_stride = dstr; d.peer_flag = dfl;
+    h->ipc_ready = true;
+    release_graph(h);
+    return NXS_OK;
+}
+
+// Step 3 (collective): `rounds` exchanges of a synthetic pattern through the mailboxes; *errors gets
+// 0 when every value arrived intact and in time on this rank.
+int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors) {
+    if (!h || !errors) return NXS_ERR_INVALID;
+    if (!h->ipc_ready) return fail(h, NXS_ERR_STATE, "ipc_selftest before ipc_connect");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
+    const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
+    for (int it = 0; it < rounds; ++it) {
+        hipLaunchKernelGGL(k_halo_push, dim3(nblocks(ts)), dim3(BLOCK), 0, h->stream, (const double *)nullptr, h->dm.Nn, ts,
+                           h->d_send_index, h->d_send_seg, h->d_send_off, h->ipc, h->rank, 1);
+        hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, (double *)nullptr, h->dm, h->ds, tr,
+                           h->d_recv_index, h->d_recv_seg, h->d_recv_off, h->ipc, 0., 1, h->d_recv_procs);
+    }
+    int err = 0;
+    HIPCHK(h, hipMemcpyAsync(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *errors = err;
     return NXS_OK;
 }
 
@@ -1853,7 +2087,15 @@ int halo_exchange(nxs_dyn_handle *h, double *vec, double move_dt) {
     // updateGhosts (FE.cpp:13963-13996): pack -> grouped send/recv -> unpack
     const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
     const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
-    if (!h->comm && !h->halo_fn) return fail(h, NXS_ERR_STATE, "halo exchange needs nxs_dyn_comm_init or nxs_dyn_set_halo_exchange_fn");
+    if (h->ipc_ready && !h->halo_fn) {
+        // device-direct: pack + peer stores + flags, then wait + unpack (+ ghost-node move); no host work
+        hipLaunchKernelGGL(k_halo_push, dim3(nblocks(ts)), dim3(BLOCK), 0, h->stream, (const double *)vec, h->dm.Nn, ts,
+                           h->d_send_index, h->d_send_seg, h->d_send_off, h->ipc, h->rank, 0);
+        hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,
+                           h->d_recv_seg, h->d_recv_off, h->ipc, move_dt, 0, h->d_recv_procs);
+        return NXS_OK;
+    }
+    if (!h->comm && !h->halo_fn) return fail(h, NXS_ERR_STATE, "halo exchange needs nxs_dyn_comm_init, nxs_dyn_ipc_connect or nxs_dyn_set_halo_exchange_fn");
     if (ts > 0) LAUNCH(h, k_halo_pack, ts, vec, h->dm.Nn, ts, h->d_send_index, h->d_send_seg, h->d_send_off, h->d_send_buf);
     if (h->halo_fn) {
         // host-staged: exactly the reference's M_comm.send / M_comm.recv of packed std::vector<double>
@@ -1931,30 +2173,29 @@ int run_substeps(nxs_dyn_handle *h) {
     auto tail = [&]() {  // odd S on the fused path: result sits in the secondary buffers
         if (fused && (S & 1)) LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm);
     };
-    if (multi_rank(h)) {
+    const bool mr = multi_rank(h);
+    const bool device_halo = mr && h->ipc_ready && !h->halo_fn;  // no host work inside the loop: graph-capturable
+    auto loop = [&]() -> int {
         for (int s = 0; s < S; ++s) {
             one(s);
-            // owned nodes were written to the buffer the next sub-step reads; ghosts must land there too
-            double *vec = fused ? ((s & 1) ? h->ds.VT : h->ds.VT2) : h->ds.VT;
-            int rc = halo_exchange(h, vec, move_dt);
-            if (rc) return rc;
+            if (mr) {
+                // owned nodes were written to the buffer the next sub-step reads; ghosts must land there too
+                double *vec = fused ? ((s & 1) ? h->ds.VT : h->ds.VT2) : h->ds.VT;
+                int rc = halo_exchange(h, vec, move_dt);
+                if (rc) return rc;
+            }
         }
         tail();
-        h->timing.substep_launches = S * (fused ? 3 : 4);
         return NXS_OK;
-    }
-    h->timing.substep_launches = S * (fused ? 1 : 2);
-    if (!h->use_graph) {
-        for (int s = 0; s < S; ++s) one(s);
-        tail();
-        return NXS_OK;
-    }
+    };
+    h->timing.substep_launches = S * ((fused ? 1 : 2) + (mr ? 2 : 0));
+    if (!h->use_graph || (mr && !device_halo)) return loop();
     if (!h->graph_valid) {
         release_graph(h);
         hipGraph_t g = nullptr;
         HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-        for (int s = 0; s < S; ++s) one(s);
-        tail();
+        int lrc = loop();
+        if (lrc) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(h->stream, &dead); if (dead) (void)hipGraphDestroy(dead); return lrc; }
         HIPCHK(h, hipStreamEndCapture(h->stream, &g));
         hipError_t e = hipGraphInstantiate(&h->substep_graph, g, nullptr, nullptr, 0);
         (void)hipGraphDestroy(g);

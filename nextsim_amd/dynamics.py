@@ -59,6 +59,9 @@ def load_library():
     L.nxs_dyn_comm_unique_id.argtypes = [C.c_void_p]
     L.nxs_dyn_comm_init.argtypes = [H, C.c_void_p, C.c_int, C.c_int]
     L.nxs_dyn_set_halo_exchange_fn.argtypes = [H, HALO_FN, C.c_void_p]
+    L.nxs_dyn_ipc_export.argtypes = [H, C.c_void_p]
+    L.nxs_dyn_ipc_connect.argtypes = [H, C.c_void_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p]
+    L.nxs_dyn_ipc_selftest.argtypes = [H, C.c_int, P(C.c_int32)]
     L.nxs_dyn_put_state.argtypes = [H, P(_abi.State)]
     L.nxs_dyn_get_state.argtypes = [H, P(_abi.State)]
     L.nxs_dyn_set_forcing.argtypes = [H, P(_abi.Forcing)]
@@ -89,8 +92,10 @@ def load_library():
 HALO_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _abi.c_double_p, _abi.c_double_p)
 
 # every symbol include/nxs_dyn.h declares
+IPC_BLOB_BYTES = 128
+
 EXPORTS = (
-    "nxs_dyn_set_halo_exchange_fn",
+    "nxs_dyn_set_halo_exchange_fn", "nxs_dyn_ipc_export", "nxs_dyn_ipc_connect", "nxs_dyn_ipc_selftest",
     "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_create", "nxs_dyn_destroy",
     "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init",
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_get_diag", "nxs_dyn_step",
@@ -180,6 +185,47 @@ class FiniteElementDynamics:
                 return 1
         self._halo_cb = HALO_FN(tramp)
         self._chk(self.L.nxs_dyn_set_halo_exchange_fn(self.h, self._halo_cb, None))
+
+    def ipc_setup(self, all_gather, selftest_rounds: int = 64) -> bool:
+        """Collective setup of the device-direct halo transport (peer-mapped mailboxes).
+        all_gather(obj) -> list of every rank's obj (the launcher's communicator, e.g.
+        torch.distributed.all_gather_object).  Returns True when the transport is connected and its
+        self-test passed on EVERY rank; otherwise the handle is left on its previous transport."""
+        lm = self.lm
+        blob = C.create_string_buffer(IPC_BLOB_BYTES)
+        ok = 1
+        try:
+            self._chk(self.L.nxs_dyn_ipc_export(self.h, blob))
+        except NxsError:
+            ok = 0
+        infos = all_gather({"ok": ok, "blob": blob.raw, "recv_procs": lm.recv_procs.tolist(),
+                            "recv_offsets": lm.recv_offsets.tolist()})
+        if not all(i["ok"] for i in infos):
+            return False
+        blobs, off, tot, slot = b"", [], [], []
+        for q in lm.send_procs.tolist():
+            inf = infos[q]
+            k = inf["recv_procs"].index(lm.rank)
+            blobs += inf["blob"]
+            off.append(inf["recv_offsets"][k]); tot.append(inf["recv_offsets"][-1]); slot.append(k)
+        a_off, a_tot, a_slot = (np.asarray(v, np.int32) for v in (off, tot, slot))
+        bbuf = C.create_string_buffer(blobs, max(len(blobs), 1))
+        ok = 1
+        try:
+            self._chk(self.L.nxs_dyn_ipc_connect(self.h, bbuf, _abi.iptr(np.ascontiguousarray(a_off)),
+                                                 _abi.iptr(np.ascontiguousarray(a_tot)), _abi.iptr(np.ascontiguousarray(a_slot))))
+        except NxsError as e:
+            self._ipc_error = str(e)
+            ok = 0
+        if not all(all_gather(ok)):
+            self.L.nxs_dyn_set_halo(self.h, C.byref(_abi.halo_struct(lm)))  # drops the half-made transport
+            return False
+        err = C.c_int32(0)
+        self._chk(self.L.nxs_dyn_ipc_selftest(self.h, selftest_rounds, C.byref(err)))
+        good = all(e == 0 for e in all_gather(int(err.value)))
+        if not good:
+            self.L.nxs_dyn_set_halo(self.h, C.byref(_abi.halo_struct(lm)))
+        return good
 
     @staticmethod
     def comm_unique_id() -> bytes:

@@ -27,6 +27,16 @@ try:
         except dynamics.NxsError as e:
             report["comm_error"] = str(e)
             raise
+    elif transport == "ipc":
+        def all_gather(obj):
+            out = [None] * world
+            dist.all_gather_object(out, obj)
+            return out
+        good = fe.ipc_setup(all_gather)
+        report["ipc_selftest"] = bool(good)
+        if not good:
+            report["comm_error"] = "ipc self-test failed: " + getattr(fe, "_ipc_error", "")
+            raise RuntimeError(report["comm_error"])
     else:
         # host-staged updateGhosts through "the caller's communicator" (here torch.distributed/gloo)
         def exchange(send, recv):
