@@ -1172,8 +1172,8 @@ struct nxs_dyn_handle {
     int n_partials = 0;
     // graph of the sub-step loop
     int use_graph = 1;
-    hipGraphExec_t substep_graph = nullptr;
-    bool graph_valid = false;
+    hipGraphExec_t substep_graph = nullptr, tail_graph = nullptr;
+    bool graph_valid = false, tail_graph_valid = false;
     // timing: a ring of event sets so that steps can be enqueued back to back; a set is harvested
     // (its elapsed times added to the sums) when it is about to be reused or when timing is read
     static constexpr int NSETS = 8;
@@ -1279,7 +1279,8 @@ void derive_params(nxs_dyn_handle *h) {
     d.D[3] = Dunit_factor * p.nu0;
     d.D[4] = Dunit_factor * 1.;
     d.D[8] = Dunit_factor * (1. - p.nu0) / 2.;
-    h->graph_valid = false;
+    h->graph_valid = false;       // kernel arguments are baked into the graphs
+    h->tail_graph_valid = false;
 }
 
 int check_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
@@ -1501,7 +1502,9 @@ void ipc_release(nxs_dyn_handle *h) {
 }
 void release_graph(nxs_dyn_handle *h) {
     if (h->substep_graph) { (void)hipGraphExecDestroy(h->substep_graph); h->substep_graph = nullptr; }
+    if (h->tail_graph) { (void)hipGraphExecDestroy(h->tail_graph); h->tail_graph = nullptr; }
     h->graph_valid = false;
+    h->tail_graph_valid = false;
 }
 
 }  // namespace
@@ -2229,16 +2232,39 @@ int explicit_solve(nxs_dyn_handle *h) {
     if (h->dp.dynamics_type == NXS_DYN_MEVP)  // FE.cpp:10559-10573
         LAUNCH(h, k_move, m.Nn, m, h->ds, 0, m.Nn, h->dp.dtime_step);
     if (timed) HIPCHK(h, hipEventRecord(h->cur[2], h->stream));
-    // Q9: 50 sweeps, hard-coded (FE.cpp:10580)
-    double *a = h->ds.VT, *b = h->ds.VT2;
-    LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
-    for (int nit = 0; nit < 50; ++nit) {
-        LAUNCH(h, k_smooth, m.No, m, h->dw, a, b);
-        if (multi_rank(h)) { rc = halo_exchange(h, b, 0.); if (rc) return rc; }
-        std::swap(a, b);
+    // Q9: 50 sweeps, hard-coded (FE.cpp:10580); + open-water mesh move.  52+ small launches: replayed from
+    // a second hipGraph whenever no host work is needed inside (single rank, or device-direct halo).
+    auto smooth_and_tail = [&]() -> int {
+        double *a = h->ds.VT, *b = h->ds.VT2;
+        LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
+        for (int nit = 0; nit < 50; ++nit) {
+            LAUNCH(h, k_smooth, m.No, m, h->dw, a, b);
+            if (multi_rank(h)) { int r2 = halo_exchange(h, b, 0.); if (r2) return r2; }
+            std::swap(a, b);
+        }
+        // 50 is even: the result is back in ds.VT
+        LAUNCH(h, k_ow_tail, m.Nn, m, h->ds, h->dw, h->dp);
+        return NXS_OK;
+    };
+    const bool tail_capturable = h->use_graph && (!multi_rank(h) || (h->ipc_ready && !h->halo_fn));
+    if (!tail_capturable) {
+        rc = smooth_and_tail();
+        if (rc) return rc;
+    } else {
+        if (!h->tail_graph_valid) {
+            if (h->tail_graph) { (void)hipGraphExecDestroy(h->tail_graph); h->tail_graph = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+            rc = smooth_and_tail();
+            if (rc) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(h->stream, &dead); if (dead) (void)hipGraphDestroy(dead); return rc; }
+            HIPCHK(h, hipStreamEndCapture(h->stream, &g));
+            hipError_t e = hipGraphInstantiate(&h->tail_graph, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) return fail(h, NXS_ERR_HIP, "hipGraphInstantiate(tail): %s", hipGetErrorString(e));
+            h->tail_graph_valid = true;
+        }
+        HIPCHK(h, hipGraphLaunch(h->tail_graph, h->stream));
     }
-    // 50 is even: the result is back in ds.VT
-    LAUNCH(h, k_ow_tail, m.Nn, m, h->ds, h->dw, h->dp);
     if (timed) HIPCHK(h, hipEventRecord(h->cur[3], h->stream));
     return NXS_OK;
 }
@@ -2292,6 +2318,11 @@ int nxs_dyn_synchronize(nxs_dyn_handle *h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    if (h->ipc_ready) {
+        int err = 0;
+        HIPCHK(h, hipMemcpy(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost));
+        if (err) return fail(h, NXS_ERR_COMM, "device-direct halo exchange failed (%s)", err == 1 ? "a neighbour's flag did not arrive within 10 s" : "self-test mismatch");
+    }
     return NXS_OK;
 }
 
