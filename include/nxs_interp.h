@@ -1,0 +1,53 @@
+/*
+ * nxs_interp.h -- C ABI of the mesh-to-mesh interpolation used at regrid (SURVEY.md section 8f, row N1;
+ * BASELINE config 5).  Replaces the root-serial call
+ *
+ *   InterpFromMeshToMesh2dx(&interp_out, &mesh_prev.indexTr()[0], &coordX[0], &coordY[0], numNodes, numTriangles,
+ *                           &interp_in[0], numNodes, nb_var, &new_coordX[0], &new_coordY[0], new_numNodes, false);
+ *
+ * of FiniteElement::interpFields (FE.cpp:3131-3139; contrib/bamg/src/InterpFromMeshToMesh2dx.cpp:17-179)
+ * with a HIP gather kernel: exact integer point location (bamg's own integer coordinates and
+ * determinants, contrib/bamg/src/Mesh.cpp:3441-3468, 3688-3690, include/det.h:8-12) through a uniform
+ * bucket grid, then the barycentric (nodal data) or piecewise-constant (element data) gather.
+ *
+ * Semantics, relative to the reference:
+ *   - a target point inside a triangle of the data mesh gets exactly the reference's value: area
+ *     coordinates are ratios of the same 64-bit integer determinants, combined in the same order;
+ *   - isdefault != 0: points outside the data mesh get defaultvalue (as the reference);
+ *   - isdefault == 0: the reference walks bamg's hull-filling triangulation and projects exterior
+ *     points on a boundary edge (CloseBoundaryEdge, Mesh.cpp:4590-4627).  Here an exterior point is
+ *     projected on the NEAREST boundary edge with the same a/b formula; *num_exterior reports how
+ *     many points took that path (they can differ from the reference near concave boundary corners).
+ */
+#ifndef NXS_INTERP_H
+#define NXS_INTERP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define NXS_INTERP_API __attribute__((visibility("default")))
+#else
+#define NXS_INTERP_API
+#endif
+
+/* Same argument meaning and layout as InterpFromMeshToMesh2dx: index_data 1-based [3*nels_data];
+ * data [M_data][N_data] row-major with M_data == nods_data (P1) or nels_data (P0);
+ * data_interp [N_interp][N_data] is CALLER-allocated here (the reference allocates it).
+ * Returns 0, or a negative NXS_ERR_* code of nxs_dyn.h (no HIP device: -2, never a CPU fallback).
+ * kernel_ms (may be NULL) receives the device time of the gather kernel alone. */
+NXS_INTERP_API int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *index_data, const double *x_data,
+                                              const double *y_data, int32_t nods_data, int32_t nels_data, const double *data,
+                                              int32_t M_data, int32_t N_data, const double *x_interp, const double *y_interp,
+                                              int32_t N_interp, int32_t isdefault, double defaultvalue, int32_t device,
+                                              int32_t *num_exterior, double *kernel_ms);
+
+NXS_INTERP_API const char *nxs_interp_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

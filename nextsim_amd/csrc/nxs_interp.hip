@@ -1,0 +1,287 @@
+// nxs_interp.hip -- mesh-to-mesh interpolation at regrid as a HIP gather kernel (include/nxs_interp.h).
+//
+// Reference: contrib/bamg/src/InterpFromMeshToMesh2dx.cpp:17-179 (called at FE.cpp:3131-3139), which
+// locates every target point by walking bamg's triangulation with EXACT integer predicates:
+//   integer coordinates  Mesh::SetIntCoor  contrib/bamg/src/Mesh.cpp:3441-3468  (bbox grown by 5 %,
+//                        coefIcoor = (2^30-1)/max extent, truncation)   and R2ToI2 Mesh.cpp:3688-3690
+//   determinants         include/det.h:8-12 (64-bit)
+//   area coordinates     det3[k]/det, InterpFromMeshToMesh2dx.cpp:113-116
+// The same integers are used here, so a point inside the data mesh gets the reference's weights bit for
+// bit whatever triangle search is used; the search itself is a uniform bucket grid over the integer plane
+// (one thread per target point, candidates tested in ascending triangle number).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nxs_dyn.h"
+#include "nxs_interp.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+struct BEdge {  // a boundary edge as seen from its (inside) triangle
+    int tri, k;  // triangle number, local edge index (vertices VOTE[k][0] -> VOTE[k][1])
+};
+
+struct InterpDev {
+    int nods, nels, N_data, N_interp, nodal;
+    const int *t0, *t1, *t2;       // 0-based vertices
+    const int *ix, *iy;            // integer coordinates of the data vertices
+    int G, shift;                  // bucket grid: G x G cells of 2^shift integer units
+    const int *cell_off, *cell_tri;
+    int nbe;
+    const BEdge *bedges;
+    double coef, pminx, pminy;     // R2ToI2
+    double xmin, xmax, ymin, ymax; // unexpanded bbox (isdefault test, InterpFromMeshToMesh2dx.cpp:93)
+    int isdefault;
+    double defaultvalue;
+};
+
+__device__ __forceinline__ long long det3(long long ax, long long ay, long long bx, long long by, long long cx, long long cy) {
+    // include/det.h:8-12
+    const long long bax = bx - ax, bay = by - ay, cax = cx - ax, cay = cy - ay;
+    return bax * cay - bay * cax;
+}
+
+__global__ void __launch_bounds__(256) k_interp(InterpDev d, const double *__restrict__ data, const double *__restrict__ xi,
+                                                const double *__restrict__ yi, double *__restrict__ out, int *num_exterior) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.N_interp) return;
+    const double x = xi[i], y = yi[i];
+    double *o = out + (size_t)i * d.N_data;
+    if (d.isdefault && (x < d.xmin || x > d.xmax || y < d.ymin || y > d.ymax)) {
+        for (int j = 0; j < d.N_data; ++j) o[j] = d.defaultvalue;
+        return;
+    }
+    // R2ToI2 (Mesh.cpp:3688-3690): truncation of coefIcoor*(P - pmin)
+    const double fx = d.coef * (x - d.pminx), fy = d.coef * (y - d.pminy);
+    const bool in_plane = fx > -1. && fx < 1073741824. && fy > -1. && fy < 1073741824.;
+    const long long Bx = in_plane ? (long long)(int)fx : (fx < 0. ? -1073741824ll : 2147483647ll);
+    const long long By = in_plane ? (long long)(int)fy : (fy < 0. ? -1073741824ll : 2147483647ll);
+
+    int it = -1;
+    long long dd[3] = {0, 0, 0};
+    if (in_plane && Bx >= 0 && By >= 0) {
+        const int cx = (int)(Bx >> d.shift), cy = (int)(By >> d.shift);
+        if (cx < d.G && cy < d.G) {
+            const int c = cy * d.G + cx;
+            for (int q = d.cell_off[c]; q < d.cell_off[c + 1]; ++q) {
+                const int t = d.cell_tri[q];
+                const int v0 = d.t0[t], v1 = d.t1[t], v2 = d.t2[t];
+                const long long x0 = d.ix[v0], y0 = d.iy[v0], x1 = d.ix[v1], y1 = d.iy[v1], x2 = d.ix[v2], y2 = d.iy[v2];
+                const long long e0 = det3(x1, y1, x2, y2, Bx, By);  // area coordinate of vertex 0
+                const long long e1 = det3(x2, y2, x0, y0, Bx, By);
+                const long long e2 = det3(x0, y0, x1, y1, Bx, By);
+                if (e0 >= 0 && e1 >= 0 && e2 >= 0 && (e0 + e1 + e2) > 0) { it = t; dd[0] = e0; dd[1] = e1; dd[2] = e2; break; }
+            }
+        }
+    }
+    double a[3];
+    if (it >= 0) {
+        const long long det = dd[0] + dd[1] + dd[2];  // == det(v0,v1,v2) exactly
+        a[0] = (double)dd[0] / det;                   // InterpFromMeshToMesh2dx.cpp:113-116
+        a[1] = (double)dd[1] / det;
+        a[2] = (double)dd[2] / det;
+    } else {
+        if (d.isdefault) {
+            for (int j = 0; j < d.N_data; ++j) o[j] = d.defaultvalue;
+            return;
+        }
+        // exterior point: nearest boundary edge, a/b as CloseBoundaryEdge (Mesh.cpp:4606-4625)
+        atomicAdd(num_exterior, 1);
+        double best = INFINITY;
+        int bk = -1;
+        double ba = 0., bb = 0.;
+        const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+        for (int e = 0; e < d.nbe; ++e) {
+            const BEdge be = d.bedges[e];
+            const int tv[3] = {d.t0[be.tri], d.t1[be.tri], d.t2[be.tri]};
+            // seen from OUTSIDE the edge runs from the triangle's VOTE[k][1] to VOTE[k][0]
+            const int vI = tv[VOTE[be.k][1]], vJ = tv[VOTE[be.k][0]];
+            const long long Ix = d.ix[vI], Iy = d.iy[vI], Jx = d.ix[vJ], Jy = d.iy[vJ];
+            const long long IJx = Jx - Ix, IJy = Jy - Iy;
+            const long long IJ_IA = IJx * (Bx - Ix) + IJy * (By - Iy);
+            const long long IJ_AJ = IJx * (Jx - Bx) + IJy * (Jy - By);
+            double aa, b2, dist;
+            if (IJ_IA < 0) { aa = 1.; b2 = 0.; dist = hypot((double)(Bx - Ix), (double)(By - Iy)); }
+            else if (IJ_AJ < 0) { aa = 0.; b2 = 1.; dist = hypot((double)(Bx - Jx), (double)(By - Jy)); }
+            else {
+                const double IJ2 = (double)(IJ_IA + IJ_AJ);
+                aa = IJ_AJ / IJ2;
+                b2 = IJ_IA / IJ2;
+                const double cr = (double)(IJx * (By - Iy) - IJy * (Bx - Ix));
+                dist = fabs(cr) / sqrt(IJ2);
+            }
+            if (dist < best) { best = dist; bk = e; ba = aa; bb = b2; }
+        }
+        if (bk < 0) { for (int j = 0; j < d.N_data; ++j) o[j] = d.defaultvalue; return; }
+        const BEdge be = d.bedges[bk];
+        it = be.tri;
+        // InterpFromMeshToMesh2dx.cpp:141-143, expressed in the inside triangle's local numbering
+        a[VOTE[be.k][1]] = ba;
+        a[VOTE[be.k][0]] = bb;
+        a[be.k] = 1 - ba - bb;
+    }
+    if (d.nodal) {
+        const int i0 = d.t0[it], i1 = d.t1[it], i2 = d.t2[it];
+        for (int j = 0; j < d.N_data; ++j)  // InterpFromMeshToMesh2dx.cpp:151-156
+            o[j] = a[0] * data[(size_t)d.N_data * i0 + j] + a[1] * data[(size_t)d.N_data * i1 + j] + a[2] * data[(size_t)d.N_data * i2 + j];
+    } else {
+        for (int j = 0; j < d.N_data; ++j) o[j] = data[(size_t)d.N_data * it + j];
+    }
+}
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t n) { return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+    int upload(const T *src, size_t n) {
+        if (alloc(n)) return -1;
+        return (n == 0 || hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
+    }
+};
+
+}  // namespace
+
+extern "C" const char *nxs_interp_last_error(void) { return g_err.c_str(); }
+
+extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *index_data, const double *x_data,
+                                          const double *y_data, int32_t nods, int32_t nels, const double *data, int32_t M_data,
+                                          int32_t N_data, const double *x_interp, const double *y_interp, int32_t N_interp,
+                                          int32_t isdefault, double defaultvalue, int32_t device, int32_t *num_exterior,
+                                          double *kernel_ms) {
+    if (!data_interp || !index_data || !x_data || !y_data || !data || !x_interp || !y_interp) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (nods <= 0 || nels <= 0 || N_data <= 0 || N_interp < 0) return fail(NXS_ERR_INVALID, "bad sizes");
+    if (M_data != nods && M_data != nels)  // InterpFromMeshToMesh2dx.cpp:39-42
+        return fail(NXS_ERR_INVALID, "data provided should have either %d or %d lines (not %d)", nods, nels, M_data);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the interpolation has no CPU path");
+    if (device < 0 || device >= ndev) return fail(NXS_ERR_INVALID, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
+    for (int64_t i = 0; i < 3ll * nels; ++i)
+        if (index_data[i] < 1 || index_data[i] > nods) return fail(NXS_ERR_INVALID, "index_data[%lld] out of range", (long long)i);
+
+    // ---- SetIntCoor (Mesh.cpp:3441-3468)
+    double pminx = x_data[0], pminy = y_data[0], pmaxx = x_data[0], pmaxy = y_data[0];
+    for (int i = 0; i < nods; ++i) {
+        pminx = std::min(pminx, x_data[i]); pminy = std::min(pminy, y_data[i]);
+        pmaxx = std::max(pmaxx, x_data[i]); pmaxy = std::max(pmaxy, y_data[i]);
+    }
+    InterpDev d{};
+    d.xmin = pminx; d.xmax = pmaxx; d.ymin = pminy; d.ymax = pmaxy;
+    const double DDx = (pmaxx - pminx) * 0.05, DDy = (pmaxy - pminy) * 0.05;
+    pminx = pminx - DDx; pminy = pminy - DDy;
+    pmaxx = pmaxx + DDx; pmaxy = pmaxy + DDy;
+    const double coef = 1073741823. / std::max(pmaxx - pminx, pmaxy - pminy);
+    if (!(coef > 0.)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive, a problem in the geometry is likely");
+    std::vector<int> ix(nods), iy(nods);
+    for (int i = 0; i < nods; ++i) {  // R2ToI2
+        ix[i] = (int)(coef * (x_data[i] - pminx));
+        iy[i] = (int)(coef * (y_data[i] - pminy));
+    }
+    std::vector<int> t0(nels), t1(nels), t2(nels);
+    for (int e = 0; e < nels; ++e) { t0[e] = index_data[3 * e] - 1; t1[e] = index_data[3 * e + 1] - 1; t2[e] = index_data[3 * e + 2] - 1; }
+
+    // ---- bucket grid over the integer plane
+    int G = 1;
+    while ((long long)G * G * 2 < nels && G < 4096) G <<= 1;
+    int shift = 30;
+    for (int g = G; g > 1; g >>= 1) --shift;  // cell = 2^shift units, G cells cover [0, 2^30)
+    std::vector<int> cnt((size_t)G * G + 1, 0);
+    auto cell_range = [&](int e, int &cx0, int &cx1, int &cy0, int &cy1) {
+        const int xs[3] = {ix[t0[e]], ix[t1[e]], ix[t2[e]]}, ys[3] = {iy[t0[e]], iy[t1[e]], iy[t2[e]]};
+        cx0 = std::min({xs[0], xs[1], xs[2]}) >> shift; cx1 = std::max({xs[0], xs[1], xs[2]}) >> shift;
+        cy0 = std::min({ys[0], ys[1], ys[2]}) >> shift; cy1 = std::max({ys[0], ys[1], ys[2]}) >> shift;
+        cx0 = std::max(cx0, 0); cy0 = std::max(cy0, 0); cx1 = std::min(cx1, G - 1); cy1 = std::min(cy1, G - 1);
+    };
+    for (int e = 0; e < nels; ++e) {
+        int a, b, c, dd2;
+        cell_range(e, a, b, c, dd2);
+        for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cnt[(size_t)cy * G + cx + 1]++;
+    }
+    for (size_t c = 0; c < (size_t)G * G; ++c) cnt[c + 1] += cnt[c];
+    std::vector<int> cell_tri(cnt[(size_t)G * G]), fill(cnt.begin(), cnt.end() - 1);
+    for (int e = 0; e < nels; ++e) {  // ascending e => ascending lists
+        int a, b, c, dd2;
+        cell_range(e, a, b, c, dd2);
+        for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cell_tri[fill[(size_t)cy * G + cx]++] = e;
+    }
+
+    // ---- boundary edges (edges held by exactly one triangle)
+    std::vector<BEdge> bedges;
+    if (!isdefault) {
+        static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+        std::vector<std::pair<long long, int>> keys;  // (sorted vertex pair, 3*tri + k)
+        keys.reserve(3 * (size_t)nels);
+        for (int e = 0; e < nels; ++e) {
+            const int tv[3] = {t0[e], t1[e], t2[e]};
+            for (int k = 0; k < 3; ++k) {
+                const int p = tv[VOTE[k][0]], q = tv[VOTE[k][1]];
+                keys.emplace_back((long long)std::min(p, q) * nods + std::max(p, q), 3 * e + k);
+            }
+        }
+        std::sort(keys.begin(), keys.end());
+        for (size_t i = 0; i < keys.size();) {
+            size_t j = i + 1;
+            while (j < keys.size() && keys[j].first == keys[i].first) ++j;
+            if (j - i == 1) bedges.push_back(BEdge{keys[i].second / 3, keys[i].second % 3});
+            i = j;
+        }
+        std::sort(bedges.begin(), bedges.end(), [](const BEdge &a, const BEdge &b) { return a.tri != b.tri ? a.tri < b.tri : a.k < b.k; });
+    }
+
+    DevBuf<int> dt0, dt1, dt2, dix, diy, doff, dtri, dnext;
+    DevBuf<BEdge> dbe;
+    DevBuf<double> ddata, dxi, dyi, dout;
+    if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || dix.upload(ix.data(), nods) ||
+        diy.upload(iy.data(), nods) || doff.upload(cnt.data(), cnt.size()) || dtri.upload(cell_tri.data(), cell_tri.size()) ||
+        dbe.upload(bedges.data(), bedges.size()) || ddata.upload(data, (size_t)M_data * N_data) || dxi.upload(x_interp, N_interp) ||
+        dyi.upload(y_interp, N_interp) || dout.alloc((size_t)N_interp * N_data) || dnext.alloc(1))
+        return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
+    if (hipMemset(dnext.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+
+    d.nods = nods; d.nels = nels; d.N_data = N_data; d.N_interp = N_interp; d.nodal = (M_data == nods);
+    d.t0 = dt0.p; d.t1 = dt1.p; d.t2 = dt2.p; d.ix = dix.p; d.iy = diy.p;
+    d.G = G; d.shift = shift; d.cell_off = doff.p; d.cell_tri = dtri.p;
+    d.nbe = (int)bedges.size(); d.bedges = dbe.p;
+    d.coef = coef; d.pminx = pminx; d.pminy = pminy;
+    d.isdefault = isdefault != 0; d.defaultvalue = defaultvalue;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    if (N_interp > 0)
+        hipLaunchKernelGGL(k_interp, dim3((N_interp + 255) / 256), dim3(256), 0, nullptr, d, (const double *)ddata.p, (const double *)dxi.p,
+                           (const double *)dyi.p, dout.p, dnext.p);
+    (void)hipEventRecord(e1, nullptr);
+    hipError_t err = hipDeviceSynchronize();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(NXS_ERR_HIP, "interpolation kernel failed: %s", hipGetErrorString(err));
+    if (kernel_ms) *kernel_ms = ms;
+    if (N_interp > 0 && hipMemcpy(data_interp, dout.p, (size_t)N_interp * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+        return fail(NXS_ERR_HIP, "copy back failed");
+    int next = 0;
+    (void)hipMemcpy(&next, dnext.p, sizeof(int), hipMemcpyDeviceToHost);
+    if (num_exterior) *num_exterior = next;
+    return NXS_OK;
+}

@@ -232,3 +232,21 @@ def multirank_step(ranks: list):
     for r in ranks:
         r.ow_tail()
         r.update()
+
+
+def bamg_interp_mesh_to_mesh(index_data, x_data, y_data, data, x_interp, y_interp, isdefault=False, defaultvalue=1e-24):
+    """The REAL InterpFromMeshToMesh2dx (contrib/bamg/src/InterpFromMeshToMesh2dx.cpp) through the shim."""
+    L = bamg_shim()
+    assert L is not None
+    idx = np.ascontiguousarray(np.asarray(index_data).ravel().astype(np.intc))
+    x_data = np.ascontiguousarray(x_data, np.float64); y_data = np.ascontiguousarray(y_data, np.float64)
+    data = np.ascontiguousarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    xi = np.ascontiguousarray(x_interp, np.float64); yi = np.ascontiguousarray(y_interp, np.float64)
+    out = np.empty((xi.size, data.shape[1]))
+    rc = L.shim_bamg_interp_mesh_to_mesh(idx.ctypes.data_as(C.POINTER(C.c_int)), _abi.dptr(x_data), _abi.dptr(y_data), x_data.size,
+                                         idx.size // 3, _abi.dptr(data), data.shape[0], data.shape[1], _abi.dptr(xi), _abi.dptr(yi),
+                                         xi.size, int(bool(isdefault)), float(defaultvalue), _abi.dptr(out))
+    assert rc == 0
+    return out

@@ -3,6 +3,9 @@
 
   bamg_connectivity.npz  REAL contrib/bamg BamgConvertMeshx output on the seeded 'tiny' mesh
                          (inputs + both tables)  -- pins nxs_mesh_connectivity and the oracle.
+  bamg_interp.npz        REAL contrib/bamg InterpFromMeshToMesh2dx (FE.cpp:3131 call shape) on the seeded 'small'
+                         mesh: 3 nodal fields + 2 element fields at interior points, mesh vertices, exterior
+                         points, with and without default value -- pins the regrid interpolation kernel.
   oracle_tiny.npz        oracle (liboracle.so) state on the 'tiny' toy case after 1 sub-step, 1 step
                          and 3 steps (beyond a few steps the algorithm amplifies 1-ulp differences to O(1), see
                          tests/test_oracle_sensitivity.py): a regression net for the oracle itself and size-0 cost
@@ -26,12 +29,45 @@ KEYS = ("VT", "UM", "UT", "sigma0", "sigma1", "sigma2", "damage", "conc", "thick
         "conc_young", "h_young", "hs_young", "conc_myi", "thick_myi")
 
 
+def interp_case():
+    """Seeded inputs of the interpolation fixture (shared with tests/test_interp.py)."""
+    gm = cases.global_mesh("small")
+    rng = np.random.default_rng(11)
+    idx = (gm.tri + 1).astype(np.int32).ravel()
+    nodal = np.stack([np.sin(gm.x / 7e5) * np.cos(gm.y / 9e5), 1e-3 * gm.x - 2e-3 * gm.y, rng.standard_normal(gm.num_nodes)], 1)
+    elemental = np.stack([rng.standard_normal(gm.num_elements), np.arange(gm.num_elements, dtype=float)], 1)
+    t = rng.integers(0, gm.num_elements, 4000)
+    w = rng.dirichlet([1, 1, 1], 4000)
+    xin = (gm.x[gm.tri[t]] * w).sum(1); yin = (gm.y[gm.tri[t]] * w).sum(1)      # strictly interior points
+    vsel = rng.integers(0, gm.num_nodes, 300)                                     # mesh vertices themselves
+    R = np.hypot(gm.x, gm.y).max()
+    th = rng.uniform(0, 2 * np.pi, 200)
+    xout = 1.3 * R * np.cos(th); yout = 1.3 * R * np.sin(th)                      # clearly outside the domain
+    xi = np.concatenate([xin, gm.x[vsel], xout]); yi = np.concatenate([yin, gm.y[vsel], yout])
+    kind = np.concatenate([np.zeros(4000, int), np.ones(300, int), np.full(200, 2)])
+    return gm, idx, nodal, elemental, xi, yi, kind
+
+
+def make_interp_fixture():
+    gm, idx, nodal, elemental, xi, yi, kind = interp_case()
+    out = dict(xi=xi, yi=yi, kind=kind)
+    out["nodal"] = O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, nodal, xi, yi, False)
+    out["nodal_default"] = O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, nodal, xi, yi, True, -999.0)
+    # element data only at points of the mesh: the reference throws on points that fall in its hull-filling
+    # triangles ("Triangle number ... not in [0 nels]", InterpFromMeshToMesh2dx.cpp:161-164)
+    ins = kind == 0  # (a boundary vertex can be located in a hull triangle too)
+    out["elemental"] = O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, elemental, xi[ins], yi[ins], False)
+    np.savez_compressed(os.path.join(HERE, "bamg_interp.npz"), **out)
+
+
 def main():
     lm = M.localize(cases.global_mesh("tiny"), 1)[0]
     assert O.bamg_shim() is not None, "build oracle/_ref first (make -C oracle ref)"
     nec, nc = O.bamg_connectivity(lm.indices, lm.coord_x, lm.coord_y)
     np.savez_compressed(os.path.join(HERE, "bamg_connectivity.npz"), indices=lm.indices, num_nodes=lm.num_nodes,
                         x=lm.coord_x, y=lm.coord_y, nec=nec, nc=nc)
+
+    make_interp_fixture()
 
     out = {}
     for tag, nsteps, over in (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step3", 3, {})):

@@ -21,6 +21,11 @@ def test_every_declared_symbol_is_exported():
     for name in declared:
         assert hasattr(L, name), name
     assert L.nxs_dyn_abi_version() == 1
+    itext = open(os.path.join(ROOT, "include", "nxs_interp.h")).read()
+    ideclared = set(re.findall(r"NXS_INTERP_API\s+(?:const\s+char\s*\*|int)\s*(nxs_\w+)\s*\(", itext))
+    assert ideclared == set(dynamics.INTERP_EXPORTS)
+    for name in ideclared:
+        assert hasattr(L, name), name
 
 
 def test_library_does_not_depend_on_the_oracle_or_torch():

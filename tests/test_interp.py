@@ -1,0 +1,120 @@
+"""Regrid interpolation (BASELINE config 5): the HIP gather kernel behind
+nxs_interp_mesh_to_mesh_2d against the REAL contrib/bamg InterpFromMeshToMesh2dx -- live when oracle/_ref
+is present, and through the committed fixture tests/golden/bamg_interp.npz generated with it.
+
+Bar: bit-exact for every target point that lies in the data mesh (the weights are ratios of the same
+64-bit integer determinants, combined in the same order); default value outside when isdefault; for
+isdefault == false exterior points are projected on the nearest boundary edge (documented deviation:
+the reference walks bamg's hull triangulation), checked to a loose tolerance and counted."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from oracle import pyoracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_golden  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "bamg_interp.npz")
+
+
+@pytest.mark.skipif(O.bamg_shim() is None, reason="oracle/_ref (real contrib/bamg) not built here")
+def test_real_bamg_reproduces_the_committed_fixture():
+    gm, idx, nodal, elemental, xi, yi, kind = make_golden.interp_case()
+    z = np.load(GOLD)
+    assert np.array_equal(z["xi"], xi) and np.array_equal(z["yi"], yi)
+    assert np.array_equal(O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, nodal, xi, yi, False), z["nodal"])
+    assert np.array_equal(O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, nodal, xi, yi, True, -999.0), z["nodal_default"])
+    ins = kind == 0
+    assert np.array_equal(O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, elemental, xi[ins], yi[ins], False), z["elemental"])
+
+
+def test_fixture_is_sane():
+    """P1 interpolation of a linear field is exact up to bamg's integer-coordinate quantisation (~5 mm)."""
+    gm, idx, nodal, elemental, xi, yi, kind = make_golden.interp_case()
+    z = np.load(GOLD)
+    inside = kind < 2
+    lin = 1e-3 * xi - 2e-3 * yi
+    assert np.abs(z["nodal"][inside, 1] - lin[inside]).max() < 1e-4
+    assert np.all(z["nodal_default"][kind == 2] == -999.0)
+    assert np.array_equal(z["nodal_default"][kind == 0], z["nodal"][kind == 0])
+    # a BOUNDARY vertex is a corner of hull-filling triangles too; when the reference's walk ends in one of
+    # those it returns the default although the point is a node of the mesh (walk-dependent tie)
+    tie = (kind == 1) & np.all(z["nodal_default"] == -999.0, axis=1)
+    assert 0 < tie.sum() < 0.2 * (kind == 1).sum()
+    assert np.array_equal(z["nodal_default"][(kind == 1) & ~tie], z["nodal"][(kind == 1) & ~tie])
+
+
+@pytest.mark.gpu
+def test_gpu_interpolation_matches_real_bamg_fixture_bit_for_bit():
+    from nextsim_amd.interp import InterpFromMeshToMesh2dx
+    gm, idx, nodal, elemental, xi, yi, kind = make_golden.interp_case()
+    z = np.load(GOLD)
+    inside = kind < 2
+    out, info = InterpFromMeshToMesh2dx(idx, gm.x, gm.y, nodal, xi, yi, False, return_info=True)
+    assert np.array_equal(out[inside], z["nodal"][inside])
+    assert info["num_exterior"] == int((kind == 2).sum())
+    # exterior points, isdefault == false: same construction (projection on a boundary edge), the edge may differ
+    scale = np.abs(z["nodal"]).max(0)
+    assert (np.abs(out[~inside] - z["nodal"][~inside]) / scale).max() < 0.2
+    outd = InterpFromMeshToMesh2dx(idx, gm.x, gm.y, nodal, xi, yi, True, -999.0)
+    tie = (kind == 1) & np.all(z["nodal_default"] == -999.0, axis=1)   # see test_fixture_is_sane
+    assert np.array_equal(outd[~tie], z["nodal_default"][~tie])
+    assert np.array_equal(outd[tie], z["nodal"][tie])                  # here: the node's own value
+    generic = kind == 0   # a vertex belongs to several triangles: the P0 value there depends on the walk
+    oute = InterpFromMeshToMesh2dx(idx, gm.x, gm.y, elemental, xi[generic], yi[generic], False)
+    assert np.array_equal(oute, z["elemental"])
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(O.bamg_shim() is None, reason="oracle/_ref (real contrib/bamg) not present on this box")
+def test_gpu_interpolation_matches_real_bamg_live_regrid_shape():
+    """The FE.cpp:3131 call shape: 6 nodal variables (M_VT, M_UM, M_UT) from a displaced old mesh onto the
+    nodes of a new, differently sized mesh of the same domain; default-value mode."""
+    from nextsim_amd.interp import InterpFromMeshToMesh2dx
+    from nextsim_amd import mesh as M
+    old = cases.global_mesh("40km")
+    new = M.make_disc_mesh(61e3, seed=5, name="new")
+    rng = np.random.default_rng(2)
+    um = 300.0 * rng.standard_normal((2, old.num_nodes))
+    xo, yo = old.x + um[0], old.y + um[1]
+    data = rng.standard_normal((old.num_nodes, 6))
+    idx = (old.tri + 1).astype(np.int32).ravel()
+    ref = O.bamg_interp_mesh_to_mesh(idx, xo, yo, data, new.x, new.y, True, 0.0)
+    got, info = InterpFromMeshToMesh2dx(idx, xo, yo, data, new.x, new.y, True, 0.0, return_info=True)
+    same = np.all(got == ref, axis=1)
+    # every point either equals the reference bit for bit ...
+    assert same.mean() > 0.97
+    # ... or sits in bamg's hull-filling triangles outside the data mesh, where the reference does not
+    # return the default although the point is outside (reft >= 0 there only inside the mesh)
+    assert np.all(got[~same] == 0.0)
+
+
+@pytest.mark.gpu
+def test_gpu_interpolation_properties_at_full_size():
+    """10 km mesh -> 1.5e5 random interior points: constants reproduced, linear fields exact to the
+    integer quantisation, weights in [0,1]."""
+    from nextsim_amd.interp import InterpFromMeshToMesh2dx
+    gm = cases.global_mesh("10km")
+    rng = np.random.default_rng(5)
+    n = 150000
+    t = rng.integers(0, gm.num_elements, n); w = rng.dirichlet([1, 1, 1], n)
+    xi = (gm.x[gm.tri[t]] * w).sum(1); yi = (gm.y[gm.tri[t]] * w).sum(1)
+    data = np.stack([np.full(gm.num_nodes, 3.25), 1e-3 * gm.x + 5e-4 * gm.y, (gm.x == gm.x).astype(float) * 0 + np.arange(gm.num_nodes) % 2], 1)
+    out, info = InterpFromMeshToMesh2dx((gm.tri + 1).ravel(), gm.x, gm.y, data, xi, yi, True, np.nan, return_info=True)
+    assert not np.isnan(out).any() and info["num_exterior"] == 0
+    assert np.abs(out[:, 0] - 3.25).max() < 1e-14
+    assert np.abs(out[:, 1] - (1e-3 * xi + 5e-4 * yi)).max() < 1e-4
+    assert out[:, 2].min() >= -1e-15 and out[:, 2].max() <= 1 + 1e-15
+
+
+def test_interp_rejects_bad_input_or_missing_gpu():
+    from nextsim_amd.interp import InterpFromMeshToMesh2dx
+    from nextsim_amd.dynamics import NxsError
+    gm = cases.global_mesh("tiny")
+    with pytest.raises(NxsError) as e:
+        InterpFromMeshToMesh2dx((gm.tri + 1).ravel(), gm.x, gm.y, np.zeros((5, 2)), gm.x[:3], gm.y[:3])
+    assert e.value.code == -1 and "lines" in str(e.value)      # InterpFromMeshToMesh2dx.cpp:39-42
