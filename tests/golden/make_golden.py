@@ -40,11 +40,23 @@ def interp_case():
     w = rng.dirichlet([1, 1, 1], 4000)
     xin = (gm.x[gm.tri[t]] * w).sum(1); yin = (gm.y[gm.tri[t]] * w).sum(1)      # strictly interior points
     vsel = rng.integers(0, gm.num_nodes, 300)                                     # mesh vertices themselves
+    # just outside: boundary-edge points pushed 50 m along the outward normal (a mesh that moved a little)
+    tri = gm.tri
+    e = np.concatenate([tri[:, [1, 2]], tri[:, [2, 0]], tri[:, [0, 1]]], 0)
+    key = np.sort(e, 1)[:, 0].astype(np.int64) * gm.num_nodes + np.sort(e, 1)[:, 1]
+    uk, first, cnt = np.unique(key, return_index=True, return_counts=True)
+    be = e[first[cnt == 1]]                                                       # oriented as in their triangle (ccw)
+    be = be[rng.permutation(be.shape[0])[:150]]
+    s_ = rng.uniform(0.2, 0.8, be.shape[0])
+    px = gm.x[be[:, 0]] * (1 - s_) + gm.x[be[:, 1]] * s_; py = gm.y[be[:, 0]] * (1 - s_) + gm.y[be[:, 1]] * s_
+    tx = gm.x[be[:, 1]] - gm.x[be[:, 0]]; ty = gm.y[be[:, 1]] - gm.y[be[:, 0]]
+    nrm = np.hypot(tx, ty)
+    xnear = px + 50.0 * ty / nrm; ynear = py - 50.0 * tx / nrm                    # outward of a ccw triangle: (ty, -tx)
     R = np.hypot(gm.x, gm.y).max()
-    th = rng.uniform(0, 2 * np.pi, 200)
-    xout = 1.3 * R * np.cos(th); yout = 1.3 * R * np.sin(th)                      # clearly outside the domain
-    xi = np.concatenate([xin, gm.x[vsel], xout]); yi = np.concatenate([yin, gm.y[vsel], yout])
-    kind = np.concatenate([np.zeros(4000, int), np.ones(300, int), np.full(200, 2)])
+    th = rng.uniform(0, 2 * np.pi, 50)
+    xfar = 1.3 * R * np.cos(th); yfar = 1.3 * R * np.sin(th)                      # far outside (default-value mode only)
+    xi = np.concatenate([xin, gm.x[vsel], xnear, xfar]); yi = np.concatenate([yin, gm.y[vsel], ynear, yfar])
+    kind = np.concatenate([np.zeros(4000, int), np.ones(300, int), np.full(150, 2), np.full(50, 3)])
     return gm, idx, nodal, elemental, xi, yi, kind
 
 

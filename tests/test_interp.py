@@ -39,7 +39,7 @@ def test_fixture_is_sane():
     inside = kind < 2
     lin = 1e-3 * xi - 2e-3 * yi
     assert np.abs(z["nodal"][inside, 1] - lin[inside]).max() < 1e-4
-    assert np.all(z["nodal_default"][kind == 2] == -999.0)
+    assert np.all(z["nodal_default"][kind >= 2] == -999.0)
     assert np.array_equal(z["nodal_default"][kind == 0], z["nodal"][kind == 0])
     # a BOUNDARY vertex is a corner of hull-filling triangles too; when the reference's walk ends in one of
     # those it returns the default although the point is a node of the mesh (walk-dependent tie)
@@ -56,10 +56,17 @@ def test_gpu_interpolation_matches_real_bamg_fixture_bit_for_bit():
     inside = kind < 2
     out, info = InterpFromMeshToMesh2dx(idx, gm.x, gm.y, nodal, xi, yi, False, return_info=True)
     assert np.array_equal(out[inside], z["nodal"][inside])
-    assert info["num_exterior"] == int((kind == 2).sum())
-    # exterior points, isdefault == false: same construction (projection on a boundary edge), the edge may differ
+    assert info["num_exterior"] == int((kind >= 2).sum())
+    # points 50 m outside the boundary (a mesh that moved a little), isdefault == false.  The reference
+    # interpolates those inside bamg's hull-filling triangles when the boundary is locally concave and
+    # projects on a boundary edge (CloseBoundaryEdge) otherwise; here: always the nearest boundary edge.
+    # Documented deviation -- only closeness is asserted: same value for most points, and always a convex
+    # combination of nodal values.
+    near = kind == 2
     scale = np.abs(z["nodal"]).max(0)
-    assert (np.abs(out[~inside] - z["nodal"][~inside]) / scale).max() < 0.2
+    rel = (np.abs(out[near] - z["nodal"][near]) / scale).max(1)
+    assert np.median(rel) < 1e-3
+    assert np.all(out[kind >= 2] >= nodal.min(0) - 1e-9) and np.all(out[kind >= 2] <= nodal.max(0) + 1e-9)
     outd = InterpFromMeshToMesh2dx(idx, gm.x, gm.y, nodal, xi, yi, True, -999.0)
     tie = (kind == 1) & np.all(z["nodal_default"] == -999.0, axis=1)   # see test_fixture_is_sane
     assert np.array_equal(outd[~tie], z["nodal_default"][~tie])
