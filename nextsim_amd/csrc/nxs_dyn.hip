@@ -676,11 +676,35 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     }
 }
 
+// Deferred mesh move of the fused path: the fused kernel leaves every sub-step's velocity in a ring of
+// VT buffers; every `count` sub-steps this kernel applies the same sequence of additions
+// M_UM += dte*M_VT, M_UT += dte*M_VT (FE.cpp:10543-10550) for all nodes, owned and ghost -- same
+// operations in the same order, but UM/UT are streamed once per `count` sub-steps instead of every one.
+#define NXS_MAX_RING 17
+struct VTRing { double *slot[NXS_MAX_RING]; int R; };
+
+__global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRing ring, int first, int count, double dt) {
+    const int n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n >= m.Nn) return;
+    const int Nn = m.Nn;
+    const bool free_node = !(m.nflags[n] & NF_NEUMANN);  // Neumann nodes keep M_UM (restore == skip)
+    double umu = s.UM[n], umv = s.UM[n + Nn], utu = s.UT[n], utv = s.UT[n + Nn];
+    int sl = first;
+    for (int j = 0; j < count; ++j) {
+        const double u = ring.slot[sl][n], v = ring.slot[sl][n + Nn];
+        if (free_node) { umu += dt * u; umv += dt * v; }
+        utu += dt * u; utv += dt * v;
+        sl = (sl + 1 == ring.R) ? 0 : sl + 1;
+    }
+    if (free_node) { s.UM[n] = umu; s.UM[n + Nn] = umv; }
+    s.UT[n] = utu; s.UT[n + Nn] = utv;
+}
+
 // odd number of sub-steps: bring the ping-pong result back to the primary buffers
-__global__ void __launch_bounds__(BLOCK) k_pingpong_copy_back(DevMesh m, DevState s, int bbm) {
+__global__ void __launch_bounds__(BLOCK) k_pingpong_copy_back(DevMesh m, DevState s, int bbm, const double *vt_src, int copy_sigma) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < 2 * m.Nn) s.VT[i] = s.VT2[i];
-    if (i < m.Ne) {
+    if (vt_src && i < 2 * m.Nn) s.VT[i] = vt_src[i];
+    if (copy_sigma && i < m.Ne) {
         s.s0[i] = s.s0_b[i]; s.s1[i] = s.s1_b[i]; s.s2[i] = s.s2_b[i];
         if (bbm) s.damage[i] = s.damage_b[i];
     }
@@ -1138,6 +1162,10 @@ struct nxs_dyn_handle {
     DevPatches dpch{};
     int fused = 1;          // v2 fused sub-step kernel (default) vs v1 two-kernel sub-step
     int patch_nodes = 0;    // own nodes per patch; 0 = auto
+    int um_ring = 0;        // fused path: apply the mesh move every um_ring sub-steps from a ring of VT buffers
+                            // (1 = every sub-step; 0 = auto: 16 on meshes that stream from HBM, 1 on cache-resident ones)
+    VTRing ring{};
+    std::vector<void *> ring_allocs;
     int nt_mask = 3;        // non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)
     size_t fused_lds = 0;
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
@@ -1580,6 +1608,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
+    free_pool(h->ring_allocs);
     if (h->h_send) (void)hipHostFree(h->h_send);
     if (h->h_recv) (void)hipHostFree(h->h_recv);
     if (h->d_partials) (void)hipFree(h->d_partials);
@@ -1604,6 +1633,11 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     if (!h || !key) return NXS_ERR_INVALID;
     if (!std::strcmp(key, "graph")) { h->use_graph = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "timing")) { h->timing_enabled = value != 0; return NXS_OK; }
+    if (!std::strcmp(key, "um_ring")) {
+        if (value < 0 || value > NXS_MAX_RING - 1) return fail(h, NXS_ERR_INVALID, "um_ring must be in [0,%d]", NXS_MAX_RING - 1);
+        h->um_ring = (int)value; release_graph(h);
+        return NXS_OK;
+    }
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "fused")) { h->fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
@@ -1648,6 +1682,8 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
+    free_pool(h->ring_allocs);
+    h->ring = VTRing{};
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
     h->rank = 0; h->nranks = 1;
     h->send_procs.clear(); h->recv_procs.clear(); h->send_offsets.assign(1, 0); h->recv_offsets.assign(1, 0);
@@ -1895,8 +1931,15 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
     const int nr = (int)h->recv_procs.size();
     const size_t tr = (size_t)h->recv_offsets[nr];
     const size_t bytes = (4 * tr + (size_t)std::max(nr, 1) + 16) * sizeof(double);  // 2 buffers of 2*tr doubles + flags
-    HIPCHK(h, hipMalloc(&h->ipc_block, bytes));
+    // uncached (MTYPE_UC) device memory: neither my L2 nor a neighbour's can hold a stale copy of a
+    // mailbox line or a flag; plain device memory as a fallback (the kernels use system-scope accesses anyway)
+    if (hipExtMallocWithFlags(&h->ipc_block, bytes, hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        h->ipc_block = nullptr;
+        HIPCHK(h, hipMalloc(&h->ipc_block, bytes));
+    }
     HIPCHK(h, hipMemset(h->ipc_block, 0, bytes));
+    HIPCHK(h, hipDeviceSynchronize());
     h->ipc_block_bytes = bytes;
     hipIpcMemHandle_t mh;
     HIPCHK(h, hipIpcGetMemHandle(&mh, h->ipc_block));
@@ -2142,9 +2185,13 @@ PingPong pingpong(const nxs_dyn_handle *h, int parity) {
     return b;
 }
 
-// sub-step `sidx` of the fused path: reads buffers of parity sidx%2, writes the other set
+// sub-step `sidx` of the fused path: sigma/damage ping-pong by parity; velocities move through the ring
+// (ring of 2 == ping-pong between VT and VT2 when the deferred mesh move is off)
 void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt) {
-    const PingPong b = pingpong(h, sidx & 1);
+    PingPong b = pingpong(h, sidx & 1);
+    const int R = h->ring.R;
+    b.VTc = h->ring.slot[sidx % R];
+    b.VTn = h->ring.slot[(sidx + 1) % R];
     const dim3 grid(h->dpch.nP);
     const bool big = h->dpch.Pmax > 128 || h->dpch.Emax > 256, pow4 = h->dp.ers_int == 4;
 #define FUSED(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt)
@@ -2153,6 +2200,23 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt) {
     else { if (pow4) { FUSED_NT(256, true); } else { FUSED(256, false, 0); } }
 #undef FUSED_NT
 #undef FUSED
+}
+
+// (re)build the ring of velocity buffers of the fused path: slot 0 is M_VT itself, slot 1 is VT2
+int setup_ring(nxs_dyn_handle *h, int K) {
+    const int R = K + 1;
+    if (h->ring.R == R) return NXS_OK;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    free_pool(h->ring_allocs);
+    h->ring = VTRing{};
+    h->ring.slot[0] = h->ds.VT;
+    h->ring.slot[1] = h->ds.VT2;
+    for (int i = 2; i < R; ++i) {
+        int rc = dev_alloc(h, h->ring_allocs, &h->ring.slot[i], 2 * (size_t)h->dm.Nn);
+        if (rc) return rc;
+    }
+    h->ring.R = R;
+    return NXS_OK;
 }
 
 void launch_substep(nxs_dyn_handle *h, double move_dt) {
@@ -2170,25 +2234,34 @@ int run_substeps(nxs_dyn_handle *h) {
     const double move_dt = (h->dp.dynamics_type == NXS_DYN_MEVP) ? 0. : h->dp.dte;
     const bool fused = h->fused != 0;
     const int bbm = h->dp.dynamics_type == NXS_DYN_BBM;
-    auto one = [&](int s) {
-        if (fused) launch_fused(h, s, move_dt); else launch_substep(h, move_dt);
-    };
-    auto tail = [&]() {  // odd S on the fused path: result sits in the secondary buffers
-        if (fused && (S & 1)) LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm);
-    };
     const bool mr = multi_rank(h);
+    // deferred mesh move (fused path, not mEVP whose single move comes after the loop)
+    const int want_ring = h->um_ring > 0 ? h->um_ring : (h->dm.Ne >= 400000 ? 16 : 1);
+    const int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
+    const bool deferred = K > 1;
+    if (fused) { int rc = setup_ring(h, K); if (rc) return rc; }
+    const int R = h->ring.R;
     const bool device_halo = mr && h->ipc_ready && !h->halo_fn;  // no host work inside the loop: graph-capturable
     auto loop = [&]() -> int {
+        int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
         for (int s = 0; s < S; ++s) {
-            one(s);
+            if (fused) launch_fused(h, s, deferred ? 0. : move_dt); else launch_substep(h, move_dt);
             if (mr) {
                 // owned nodes were written to the buffer the next sub-step reads; ghosts must land there too
-                double *vec = fused ? ((s & 1) ? h->ds.VT : h->ds.VT2) : h->ds.VT;
-                int rc = halo_exchange(h, vec, move_dt);
+                double *vec = fused ? h->ring.slot[(s + 1) % R] : h->ds.VT;
+                int rc = halo_exchange(h, vec, deferred ? 0. : move_dt);
                 if (rc) return rc;
             }
+            if (deferred && (++pending == K || s == S - 1)) {
+                LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt);
+                pending = 0;
+            }
         }
-        tail();
+        if (fused) {  // bring the result back to the primary buffers
+            const double *vt_src = (S % R) ? h->ring.slot[S % R] : nullptr;
+            if (vt_src || (S & 1))
+                LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm, vt_src, S & 1);
+        }
         return NXS_OK;
     };
     h->timing.substep_launches = S * ((fused ? 1 : 2) + (mr ? 2 : 0));
