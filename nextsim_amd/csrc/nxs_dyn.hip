@@ -1409,7 +1409,7 @@ bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *
         for (int e : pel[q])
             for (int k = 0; k < 3; ++k) {
                 const int n = t[k][e];
-                if (slot_of[n] < 0) { slot_of[n] = -2; halo.push_back(n); }
+                if (slot_of[n] == -1) { slot_of[n] = -2; halo.push_back(n); }
             }
         std::sort(halo.begin(), halo.end());
         for (int n : halo) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
@@ -1470,13 +1470,26 @@ bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, con
     for (int i = 0; i < No; ++i) order[i] = i;
     bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out);
     if (ok && out.avg_elems_per_own_node <= 3.0) return true;
-    // numbering without locality: cut patches along a Morton curve through the node coordinates
+    // numbering without locality: cut patches along a Hilbert curve through the node coordinates
+    // (consecutive runs of a Hilbert curve are compact blobs: small halos)
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     for (int n = 0; n < No; ++n) { xmin = std::min(xmin, x0[n]); xmax = std::max(xmax, x0[n]); ymin = std::min(ymin, y0[n]); ymax = std::max(ymax, y0[n]); }
-    const double sx = xmax > xmin ? 65535. / (xmax - xmin) : 0., sy = ymax > ymin ? 65535. / (ymax - ymin) : 0.;
-    auto spread = [](unsigned v) { unsigned long long x = v & 0xFFFF; x = (x | (x << 8)) & 0x00FF00FF; x = (x | (x << 4)) & 0x0F0F0F0F; x = (x | (x << 2)) & 0x33333333; x = (x | (x << 1)) & 0x55555555; return x; };
+    const double ext = std::max(xmax - xmin, ymax - ymin);
+    const double sc = ext > 0. ? 65535. / ext : 0.;
+    auto hilbert = [](unsigned x, unsigned y) {
+        unsigned long long d = 0;
+        for (unsigned s2 = 1u << 15; s2 > 0; s2 >>= 1) {
+            const unsigned rx = (x & s2) ? 1u : 0u, ry = (y & s2) ? 1u : 0u;
+            d += (unsigned long long)s2 * s2 * ((3u * rx) ^ ry);
+            if (ry == 0) {
+                if (rx == 1) { x = s2 - 1 - x; y = s2 - 1 - y; }
+                const unsigned t2 = x; x = y; y = t2;
+            }
+        }
+        return d;
+    };
     std::vector<unsigned long long> key(No);
-    for (int n = 0; n < No; ++n) key[n] = spread((unsigned)((x0[n] - xmin) * sx)) | (spread((unsigned)((y0[n] - ymin) * sy)) << 1);
+    for (int n = 0; n < No; ++n) key[n] = hilbert((unsigned)((x0[n] - xmin) * sc), (unsigned)((y0[n] - ymin) * sc));
     std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
     HostPatches alt;
     if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
@@ -1507,6 +1520,12 @@ int upload_patches(nxs_dyn_handle *h) {
         P = automatic ? P - 32 : std::max(64, P * 3 / 4);
     }
     if (h->fused_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "patches need %zu B of LDS", h->fused_lds);
+    if (getenv("NXS_DEBUG_PATCHES")) {
+        long long se = 0, sm = 0;
+        for (int q = 0; q < hp.nP; ++q) { se += hp.elem_cnt[q]; sm += hp.node_cnt[q]; }
+        fprintf(stderr, "[nxs] patches: P=%d nP=%d Pmax=%d Emax=%d Mmax=%d Wp=%d avgE=%.1f avgM=%.1f lds=%zu B elems x%.3f\n", P, hp.nP, hp.Pmax,
+                hp.Emax, hp.Mmax, hp.Wp, (double)se / hp.nP, (double)sm / hp.nP, h->fused_lds, (double)se / std::max(m.Ne, 1));
+    }
     DevPatches &d = h->dpch;
     d.nP = hp.nP; d.Pmax = hp.Pmax; d.Emax = hp.Emax; d.Mmax = hp.Mmax; d.Wp = hp.Wp;
     int rc;

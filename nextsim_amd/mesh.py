@@ -110,6 +110,24 @@ def _morton_key(ix: np.ndarray, iy: np.ndarray) -> np.ndarray:
     return spread(ix) | (spread(iy) << np.uint64(1))
 
 
+def _hilbert_key(ix: np.ndarray, iy: np.ndarray, order: int = 16) -> np.ndarray:
+    """Hilbert-curve index of integer points (vectorised xy2d): chunks of consecutive keys are compact
+    blobs, which is what the library's node patches want (smaller halos than Z-order chunks)."""
+    x = ix.astype(np.int64).copy(); y = iy.astype(np.int64).copy()
+    d = np.zeros_like(x)
+    s = 1 << (order - 1)
+    while s > 0:
+        rx = ((x & s) > 0).astype(np.int64); ry = ((y & s) > 0).astype(np.int64)
+        d += s * s * ((3 * rx) ^ ry)
+        # rotate
+        flip = (ry == 0) & (rx == 1)
+        x = np.where(flip, s - 1 - x, x); y = np.where(flip, s - 1 - y, y)
+        swap = ry == 0
+        x, y = np.where(swap, y, x), np.where(swap, x, y)
+        s >>= 1
+    return d
+
+
 def _lattice_mesh(nx: int, ny: int, h: float, x0: float, y0: float, inside, jitter: float, seed: int,
                   open_boundary, name: str, reorder: bool = True) -> GlobalMesh:
     """Triangulate the (nx+1) x (ny+1) lattice of spacing h (rows offset by h/2: near-equilateral
@@ -151,8 +169,11 @@ def _lattice_mesh(nx: int, ny: int, h: float, x0: float, y0: float, inside, jitt
     neumann = bnd & open_boundary(px, py)
     dirichlet = bnd & ~neumann
     if reorder:
-        # Morton (Z-curve) numbering of nodes and elements: neighbours in space are neighbours in memory
-        order = np.argsort(_morton_key(lat_i, lat_j), kind="stable")
+        # space-filling-curve numbering of nodes and elements: neighbours in space are neighbours in memory
+        import os as _os
+        curve = _os.environ.get("NXS_MESH_CURVE", "hilbert")
+        key = _hilbert_key(lat_i, lat_j) if curve == "hilbert" else _morton_key(lat_i, lat_j)
+        order = np.argsort(key, kind="stable")
         inv = np.empty(nn, np.int64); inv[order] = np.arange(nn)
         px, py, dirichlet, neumann = px[order], py[order], dirichlet[order], neumann[order]
         tri = inv[tri]
