@@ -45,6 +45,18 @@ NXS_INTERP_API int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t
                                               int32_t N_interp, int32_t isdefault, double defaultvalue, int32_t device,
                                               int32_t *num_exterior, double *kernel_ms);
 
+/* Mesh -> regular grid sampling of the Moorings output (model/gridoutput.cpp:467-500 calls
+ * InterpFromMeshToGridx, contrib/bamg/src/InterpFromMeshToGridx.cpp:11-193).  Same arguments: grid point
+ * (i,j), i < nrows along x, j < ncols along y (x_i = xmin + i*xposting, y_j descending from ymax when
+ * yposting > 0), griddata[N_data*(i*ncols+j)+k] CALLER-allocated.  A grid point takes the value of the LAST
+ * element (highest number) whose area coordinates are all > -1e-11, exactly as the reference's element loop
+ * overwrites; points in no element keep default_value; NaN results become default_value.  The area
+ * coordinates are the reference's double expressions, so the values are bit-identical. */
+NXS_INTERP_API int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
+                                           int32_t nods, int32_t nels, const double *data_mesh, int32_t data_length, int32_t N_data,
+                                           double xmin, double ymax, double xposting, double yposting, int32_t nrows,
+                                           int32_t ncols, double default_value, int32_t device, double *kernel_ms);
+
 NXS_INTERP_API const char *nxs_interp_last_error(void);
 
 #ifdef __cplusplus

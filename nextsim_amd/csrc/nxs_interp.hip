@@ -161,6 +161,132 @@ struct DevBuf {
 
 }  // namespace
 
+namespace {
+
+struct GridDev {
+    int nods, nels, N_data, nrows, ncols, nodal;
+    const int *t0, *t1, *t2;
+    const double *x, *y;
+    const double *xg, *yg;  // grid coordinates as the reference builds them (InterpFromMeshToGridx.cpp:73-92)
+    int G; double bx0, by0, bdx, bdy;  // bucket grid over the mesh bbox
+    const int *cell_off, *cell_tri;
+    double default_value;
+};
+
+// one thread per grid point; candidates in ascending element number, the LAST hit wins (the reference's
+// element loop overwrites, InterpFromMeshToGridx.cpp:96-181)
+__global__ void __launch_bounds__(256) k_mesh_to_grid(GridDev d, const double *__restrict__ data, double *__restrict__ out) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (long long)d.nrows * d.ncols) return;
+    const int i = (int)(gid / d.ncols), j = (int)(gid % d.ncols);
+    const double xg = d.xg[i], yg = d.yg[j];
+    double *o = out + (size_t)d.N_data * gid;
+    for (int k = 0; k < d.N_data; ++k) o[k] = d.default_value;
+    const int cx = (int)floor((xg - d.bx0) / d.bdx), cy = (int)floor((yg - d.by0) / d.bdy);
+    if (cx < 0 || cy < 0 || cx >= d.G || cy >= d.G) return;
+    const int c = cy * d.G + cx;
+    int hit = -1;
+    double h1 = 0., h2 = 0., h3 = 0.;
+    for (int q = d.cell_off[c]; q < d.cell_off[c + 1]; ++q) {
+        const int n = d.cell_tri[q];
+        const int a = d.t0[n], b = d.t1[n], c3 = d.t2[n];
+        const double x1 = d.x[a], y1 = d.y[a], x2 = d.x[b], y2 = d.y[b], x3 = d.x[c3], y3 = d.y[c3];
+        double xmin = x1, xmax = x1, ymin = y1, ymax = y1;
+        if (x2 < xmin) xmin = x2; if (x2 > xmax) xmax = x2; if (y2 < ymin) ymin = y2; if (y2 > ymax) ymax = y2;
+        if (x3 < xmin) xmin = x3; if (x3 > xmax) xmax = x3; if (y3 < ymin) ymin = y3; if (y3 > ymax) ymax = y3;
+        if ((xg > xmax) || (xg < xmin) || (yg > ymax) || (yg < ymin)) continue;  // :143, :148
+        const double area = x2 * y3 - y2 * x3 + x1 * y2 - y1 * x2 + x3 * y1 - y3 * x1;  // :135-137
+        const double area_1 = ((xg - x3) * (y2 - y3) - (yg - y3) * (x2 - x3)) / area;     // :152-153
+        const double area_2 = ((x1 - x3) * (yg - y3) - (y1 - y3) * (xg - x3)) / area;     // :155-156
+        const double area_3 = 1 - area_1 - area_2;
+        if (area_1 > -10e-12 && area_2 > -10e-12 && area_3 > -10e-12) { hit = n; h1 = area_1; h2 = area_2; h3 = area_3; }
+    }
+    if (hit < 0) return;
+    for (int k = 0; k < d.N_data; ++k) {
+        double v;
+        if (d.nodal) {
+            v = h1 * data[(size_t)d.N_data * d.t0[hit] + k];
+            v += h2 * data[(size_t)d.N_data * d.t1[hit] + k];
+            v += h3 * data[(size_t)d.N_data * d.t2[hit] + k];
+        } else {
+            v = data[(size_t)d.N_data * hit + k];
+        }
+        if (isnan(v)) v = d.default_value;
+        o[k] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
+                                       int32_t nods, int32_t nels, const double *data_mesh, int32_t data_length, int32_t N_data,
+                                       double xmin, double ymax, double xposting, double yposting, int32_t nrows, int32_t ncols,
+                                       double default_value, int32_t device, double *kernel_ms) {
+    if (!griddata || !index_mesh || !x_mesh || !y_mesh || !data_mesh) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (nels < 1 || nods < 3 || ncols < 1 || nrows < 1 || xposting == 0 || yposting == 0 || N_data < 1)  // :34-36
+        return fail(NXS_ERR_INVALID, "nothing to be done according to the mesh given in input");
+    if (data_length != nods && data_length != nels)
+        return fail(NXS_ERR_INVALID, "length of vector data not supported yet. It should be of length (number of nodes) or (number of elements)!");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the interpolation has no CPU path");
+    if (device < 0 || device >= ndev) return fail(NXS_ERR_INVALID, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
+    for (int64_t i = 0; i < 3ll * nels; ++i)
+        if (index_mesh[i] < 1 || index_mesh[i] > nods) return fail(NXS_ERR_INVALID, "index_mesh[%lld] out of range", (long long)i);
+
+    // grid coordinates exactly as the reference builds them (flips included), :66-92
+    std::vector<double> xg(nrows), yg(ncols);
+    if (xposting < 0) { for (int i = 0; i < nrows; ++i) xg[nrows - 1 - i] = xmin - xposting * i; }
+    else { for (int i = 0; i < nrows; ++i) xg[i] = xmin + xposting * i; }
+    if (yposting < 0) { for (int i = 0; i < ncols; ++i) yg[i] = ymax + yposting * i; }
+    else { for (int i = 0; i < ncols; ++i) yg[ncols - 1 - i] = ymax - yposting * i; }
+
+    std::vector<int> t0(nels), t1(nels), t2(nels);
+    double bx0 = x_mesh[0], bx1 = x_mesh[0], by0 = y_mesh[0], by1 = y_mesh[0];
+    for (int i = 0; i < nods; ++i) { bx0 = std::min(bx0, x_mesh[i]); bx1 = std::max(bx1, x_mesh[i]); by0 = std::min(by0, y_mesh[i]); by1 = std::max(by1, y_mesh[i]); }
+    for (int e = 0; e < nels; ++e) { t0[e] = index_mesh[3 * e] - 1; t1[e] = index_mesh[3 * e + 1] - 1; t2[e] = index_mesh[3 * e + 2] - 1; }
+    int G = 1;
+    while ((long long)G * G * 2 < nels && G < 4096) G <<= 1;
+    const double bdx = (bx1 - bx0) / G * (1. + 1e-12) + 1e-300, bdy = (by1 - by0) / G * (1. + 1e-12) + 1e-300;
+    auto cellr = [&](int e, int &a, int &b, int &c, int &dd2) {
+        const double xs[3] = {x_mesh[t0[e]], x_mesh[t1[e]], x_mesh[t2[e]]}, ys[3] = {y_mesh[t0[e]], y_mesh[t1[e]], y_mesh[t2[e]]};
+        a = (int)std::floor((std::min({xs[0], xs[1], xs[2]}) - bx0) / bdx) - 1; b = (int)std::floor((std::max({xs[0], xs[1], xs[2]}) - bx0) / bdx) + 1;
+        c = (int)std::floor((std::min({ys[0], ys[1], ys[2]}) - by0) / bdy) - 1; dd2 = (int)std::floor((std::max({ys[0], ys[1], ys[2]}) - by0) / bdy) + 1;
+        a = std::max(a, 0); c = std::max(c, 0); b = std::min(b, G - 1); dd2 = std::min(dd2, G - 1);
+    };
+    std::vector<int> cnt((size_t)G * G + 1, 0);
+    for (int e = 0; e < nels; ++e) { int a, b, c, dd2; cellr(e, a, b, c, dd2); for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cnt[(size_t)cy * G + cx + 1]++; }
+    for (size_t c = 0; c < (size_t)G * G; ++c) cnt[c + 1] += cnt[c];
+    std::vector<int> cell_tri(cnt[(size_t)G * G]), fill(cnt.begin(), cnt.end() - 1);
+    for (int e = 0; e < nels; ++e) { int a, b, c, dd2; cellr(e, a, b, c, dd2); for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cell_tri[fill[(size_t)cy * G + cx]++] = e; }
+
+    DevBuf<int> dt0, dt1, dt2, doff, dtri;
+    DevBuf<double> dx, dy, dxg, dyg, ddata, dout;
+    const size_t npts = (size_t)nrows * ncols;
+    if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || doff.upload(cnt.data(), cnt.size()) ||
+        dtri.upload(cell_tri.data(), cell_tri.size()) || dx.upload(x_mesh, nods) || dy.upload(y_mesh, nods) || dxg.upload(xg.data(), nrows) ||
+        dyg.upload(yg.data(), ncols) || ddata.upload(data_mesh, (size_t)data_length * N_data) || dout.alloc(npts * N_data))
+        return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
+    GridDev d{};
+    d.nods = nods; d.nels = nels; d.N_data = N_data; d.nrows = nrows; d.ncols = ncols; d.nodal = (data_length == nods);
+    d.t0 = dt0.p; d.t1 = dt1.p; d.t2 = dt2.p; d.x = dx.p; d.y = dy.p; d.xg = dxg.p; d.yg = dyg.p;
+    d.G = G; d.bx0 = bx0; d.by0 = by0; d.bdx = bdx; d.bdy = bdy; d.cell_off = doff.p; d.cell_tri = dtri.p;
+    d.default_value = default_value;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_mesh_to_grid, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, nullptr, d, (const double *)ddata.p, dout.p);
+    (void)hipEventRecord(e1, nullptr);
+    hipError_t err = hipDeviceSynchronize();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(NXS_ERR_HIP, "mesh-to-grid kernel failed: %s", hipGetErrorString(err));
+    if (kernel_ms) *kernel_ms = ms;
+    if (hipMemcpy(griddata, dout.p, npts * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    return NXS_OK;
+}
+
 extern "C" const char *nxs_interp_last_error(void) { return g_err.c_str(); }
 
 extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *index_data, const double *x_data,

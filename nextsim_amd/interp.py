@@ -52,3 +52,29 @@ def InterpFromMeshToMesh2dx(index_data, x_data, y_data, data, x_interp, y_interp
     if return_info:
         return out, {"num_exterior": next_.value, "kernel_ms": ms.value}
     return out
+
+
+def InterpFromMeshToGridx(index_mesh, x_mesh, y_mesh, data, xmin, ymax, xposting, yposting, nrows, ncols, default_value,
+                          device=0, return_info=False):
+    """Mesh -> regular grid (Moorings) sampling, argument meaning of contrib/bamg's InterpFromMeshToGridx
+    (model/gridoutput.cpp:496-505).  Returns griddata [nrows, ncols, N_data]."""
+    L = _lib()
+    if not hasattr(L, "_grid_declared"):
+        L.nxs_interp_mesh_to_grid.argtypes = [_abi.c_double_p, _abi.c_int32_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_int32,
+                                              _abi.c_double_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                              C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double)]
+        L.nxs_interp_mesh_to_grid.restype = C.c_int
+        L._grid_declared = True
+    index_mesh = np.ascontiguousarray(index_mesh, np.int32).ravel()
+    x_mesh = np.ascontiguousarray(x_mesh, np.float64); y_mesh = np.ascontiguousarray(y_mesh, np.float64)
+    data = np.ascontiguousarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    out = np.empty((nrows, ncols, data.shape[1]))
+    ms = C.c_double(0.0)
+    rc = L.nxs_interp_mesh_to_grid(_abi.dptr(out), _abi.iptr(index_mesh), _abi.dptr(x_mesh), _abi.dptr(y_mesh), x_mesh.size,
+                                   index_mesh.size // 3, _abi.dptr(data), data.shape[0], data.shape[1], float(xmin), float(ymax),
+                                   float(xposting), float(yposting), int(nrows), int(ncols), float(default_value), device, C.byref(ms))
+    if rc:
+        raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
+    return (out, {"kernel_ms": ms.value}) if return_info else out

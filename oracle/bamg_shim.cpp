@@ -57,3 +57,23 @@ int shim_bamg_interp_mesh_to_mesh(const int *index_data, const double *x_data, c
 }
 
 } /* extern "C" */
+
+#include "InterpFromMeshToGridx.h"
+
+extern "C" {
+
+/* InterpFromMeshToGridx as called by GridOutput (model/gridoutput.cpp:496-505). */
+int shim_bamg_interp_mesh_to_grid(const int *index_mesh, const double *x_mesh, const double *y_mesh, int nods, int nels,
+                                  const double *data_mesh, int data_length, int N_data, double xmin, double ymax, double xposting,
+                                  double yposting, int nrows, int ncols, double default_value, double *out) {
+    double *grid = NULL;
+    InterpFromMeshToGridx(grid, const_cast<int *>(index_mesh), const_cast<double *>(x_mesh), const_cast<double *>(y_mesh), nods, nels,
+                          const_cast<double *>(data_mesh), data_length, N_data, xmin, ymax, xposting, yposting, nrows, ncols,
+                          default_value);
+    if (!grid) return -1;
+    std::memcpy(out, grid, sizeof(double) * (size_t)N_data * nrows * ncols);
+    delete[] grid;
+    return 0;
+}
+
+} /* extern "C" */

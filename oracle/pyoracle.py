@@ -250,3 +250,23 @@ def bamg_interp_mesh_to_mesh(index_data, x_data, y_data, data, x_interp, y_inter
                                          xi.size, int(bool(isdefault)), float(defaultvalue), _abi.dptr(out))
     assert rc == 0
     return out
+
+
+def bamg_interp_mesh_to_grid(index_mesh, x_mesh, y_mesh, data, xmin, ymax, xposting, yposting, nrows, ncols, default_value):
+    """The REAL InterpFromMeshToGridx (contrib/bamg/src/InterpFromMeshToGridx.cpp) through the shim."""
+    path = os.path.join(HERE, "_ref", "libbamg_shim.so")
+    L = C.CDLL(path)
+    idx = np.ascontiguousarray(np.asarray(index_mesh).ravel().astype(np.intc))
+    x_mesh = np.ascontiguousarray(x_mesh, np.float64); y_mesh = np.ascontiguousarray(y_mesh, np.float64)
+    data = np.ascontiguousarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    out = np.empty((nrows, ncols, data.shape[1]))
+    L.shim_bamg_interp_mesh_to_grid.argtypes = [C.POINTER(C.c_int), _abi.c_double_p, _abi.c_double_p, C.c_int, C.c_int, _abi.c_double_p,
+                                                C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                                C.c_double, _abi.c_double_p]
+    rc = L.shim_bamg_interp_mesh_to_grid(idx.ctypes.data_as(C.POINTER(C.c_int)), _abi.dptr(x_mesh), _abi.dptr(y_mesh), x_mesh.size,
+                                         idx.size // 3, _abi.dptr(data), data.shape[0], data.shape[1], float(xmin), float(ymax),
+                                         float(xposting), float(yposting), int(nrows), int(ncols), float(default_value), _abi.dptr(out))
+    assert rc == 0
+    return out

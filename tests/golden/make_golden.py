@@ -6,6 +6,8 @@
   bamg_interp.npz        REAL contrib/bamg InterpFromMeshToMesh2dx (FE.cpp:3131 call shape) on the seeded 'small'
                          mesh: 3 nodal fields + 2 element fields at interior points, mesh vertices, exterior
                          points, with and without default value -- pins the regrid interpolation kernel.
+  bamg_mesh_to_grid.npz  REAL contrib/bamg InterpFromMeshToGridx (Moorings sampling, gridoutput.cpp:496) on the
+                         'small' mesh: nodal + element data, normal and flipped grids, NaN data.
   oracle_tiny.npz        oracle (liboracle.so) state on the 'tiny' toy case after 1 sub-step, 1 step
                          and 3 steps (beyond a few steps the algorithm amplifies 1-ulp differences to O(1), see
                          tests/test_oracle_sensitivity.py): a regression net for the oracle itself and size-0 cost
@@ -60,6 +62,29 @@ def interp_case():
     return gm, idx, nodal, elemental, xi, yi, kind
 
 
+def grid_case():
+    """Moorings-like regular grid over the seeded 'small' mesh (model/gridoutput.cpp:467-505 call shape)."""
+    gm = cases.global_mesh("small")
+    rng = np.random.default_rng(13)
+    idx = (gm.tri + 1).astype(np.int32).ravel()
+    nodal = np.stack([np.cos(gm.x / 6e5) + np.sin(gm.y / 8e5), rng.standard_normal(gm.num_nodes)], 1)
+    nodal[rng.integers(0, gm.num_nodes, 5), 1] = np.nan          # NaN data -> default (InterpFromMeshToGridx.cpp:172)
+    elemental = np.stack([rng.standard_normal(gm.num_elements), np.arange(gm.num_elements, dtype=float)], 1)
+    ncols = 97; nrows = 83
+    xmin = gm.x.min() - 2e5; ymax = gm.y.max() + 1.5e5
+    xpost = (gm.x.max() - gm.x.min() + 4e5) / (nrows - 1); ypost = (gm.y.max() - gm.y.min() + 3e5) / (ncols - 1)
+    return gm, idx, nodal, elemental, xmin, ymax, xpost, ypost, nrows, ncols
+
+
+def make_grid_fixture():
+    gm, idx, nodal, elemental, xmin, ymax, xp, yp, nrows, ncols = grid_case()
+    out = {}
+    out["nodal"] = O.bamg_interp_mesh_to_grid(idx, gm.x, gm.y, nodal, xmin, ymax, xp, yp, nrows, ncols, -1e14)
+    out["elemental"] = O.bamg_interp_mesh_to_grid(idx, gm.x, gm.y, elemental, xmin, ymax, xp, yp, nrows, ncols, -1e14)
+    out["nodal_flipped"] = O.bamg_interp_mesh_to_grid(idx, gm.x, gm.y, nodal, xmin, ymax, -xp, -yp, nrows, ncols, -1e14)
+    np.savez_compressed(os.path.join(HERE, "bamg_mesh_to_grid.npz"), **out)
+
+
 def make_interp_fixture():
     gm, idx, nodal, elemental, xi, yi, kind = interp_case()
     out = dict(xi=xi, yi=yi, kind=kind)
@@ -80,6 +105,7 @@ def main():
                         x=lm.coord_x, y=lm.coord_y, nec=nec, nc=nc)
 
     make_interp_fixture()
+    make_grid_fixture()
 
     out = {}
     for tag, nsteps, over in (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step3", 3, {})):
