@@ -1,0 +1,67 @@
+/*
+ * nxs_io.h -- host-side output writers: the two file formats the reference's
+ * time loop produces from the arrays of the dynamics path, so that a host that drops libnxsdyn.so in
+ * keeps its outputs.  Plain C ABI, host memory only, no GPU involved.
+ *
+ *   Exporter  core/src/exporter.cpp:32-189   field_*.bin/.dat, mesh_*.bin/.dat, restart files:
+ *             binary  = per record  int32 count, then count values (int32 | float32 | float64);
+ *             sidecar = one text line per record  "name type count min max".
+ *   Moorings  model/gridoutput.cpp:805-1035  CF-1.6 NetCDF: dims time(unlimited), nv=2, x, y;
+ *             time, time_bnds, longitude, latitude, one float variable per field with _FillValue,
+ *             optional Polar_Stereographic_Grid mapping variable.  The reference links netcdf-cxx4
+ *             (NetCDF-4/HDF5); no NetCDF library exists in this image, so the file is written by hand in
+ *             the NetCDF-3 classic format (CDF-1), which every NetCDF reader opens; schema unchanged.
+ */
+#ifndef NXS_IO_H
+#define NXS_IO_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define NXS_IO_API __attribute__((visibility("default")))
+#else
+#define NXS_IO_API
+#endif
+
+typedef struct nxs_exporter nxs_exporter;
+
+/* precision: "double" or "float" (output.exporter_precision, exporter.cpp:17-27). */
+NXS_IO_API int nxs_exporter_open(const char *bin_path, const char *dat_path, const char *precision, nxs_exporter **out);
+/* writeMesh (exporter.cpp:72-128): records Elements, id, Nodes_x, Nodes_y in that order. */
+NXS_IO_API int nxs_exporter_write_mesh(nxs_exporter *e, const double *xnod, const double *ynod, const int32_t *idnod,
+                                       int64_t num_nodes, const int32_t *elements, int64_t num_indices);
+/* writeField (exporter.cpp:130-156): floating fields follow the exporter precision, except "Time" (double). */
+NXS_IO_API int nxs_exporter_write_field(nxs_exporter *e, const char *name, const double *values, int64_t count);
+NXS_IO_API int nxs_exporter_write_field_int(nxs_exporter *e, const char *name, const int32_t *values, int64_t count);
+/* writeRecord (exporter.cpp:158-189) + close both files. */
+NXS_IO_API int nxs_exporter_close(nxs_exporter *e);
+
+typedef struct nxs_mooring_var {
+    const char *name, *standard_name, *long_name, *units, *cell_methods; /* gridoutput.hpp variable descriptors */
+} nxs_mooring_var;
+
+typedef struct nxs_mooring_proj { /* createProjectionVariable, gridoutput.cpp:943-980; NULL = none */
+    double semi_major_axis, semi_minor_axis, lat0, lat_ts, rotation;
+    int32_t false_easting;
+} nxs_mooring_proj;
+
+/* initNetCDF (gridoutput.cpp:805-940).  lon/lat: [nrows*ncols] floats, row-major (y, x).
+ * averaging_period in days (0 = snapshots: "time: point "). */
+NXS_IO_API int nxs_moorings_create(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat,
+                                   int32_t nvars, const nxs_mooring_var *vars, float miss_val, double averaging_period,
+                                   const nxs_mooring_proj *proj);
+/* appendNetCDF (gridoutput.cpp:984-1030): one more record; data[v] is [nrows*ncols] floats. timestamp in days
+ * since 1900-01-01. */
+NXS_IO_API int nxs_moorings_append(const char *path, double timestamp, double averaging_period, int32_t nvars,
+                                   const float *const *data);
+
+NXS_IO_API const char *nxs_io_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
