@@ -42,6 +42,23 @@ def parse():
     return ap.parse_args()
 
 
+def pmc_traffic(mesh, launches_per_substep, world):
+    """HBM bytes per launch of the sub-step kernel from the committed rocprofv3 --pmc passes
+    (profiles/r01_v2_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes, same kernel, same
+    mesh).  PMC counters cannot be collected from inside this process; null when the profile does not
+    apply to this run."""
+    if mesh != "2km" or launches_per_substep != 1 or world != 1:
+        return None
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_traffic.json")))
+        for k, v in prof["kernels"].items():
+            if k.startswith("k_substep_fused"):
+                return v["hbm_bytes_per_launch"]
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def build_case(kind, nparts, rank):
     from nextsim_amd import forcing as F, mesh as M
     gm = M.make_mesh(kind)
@@ -136,17 +153,40 @@ def setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn):
 
 
 def cpu_baseline(kind, nsteps=1):
-    """The restated reference CPU path (oracle/dyn_ref.c, -O3 -march=native, 1 thread) on the same mesh
-    and forcing: `nsteps` full dynamics steps.  kind 'port': the reference binary itself cannot be
-    built without Boost/Gmsh/NetCDF."""
+    """The restated reference CPU path (oracle/dyn_ref.c, -O3 -march=native) on the same mesh and forcing.
+    (i) one core, the serial loops; (ii) all host cores this process may use: one mesh partition per core
+    with shared-memory halo exchanges between the phases (the CPU analogue of the reference's MPI run).
+    kind 'port': the reference binary itself cannot be built without Boost/Gmsh/NetCDF."""
+    from concurrent.futures import ThreadPoolExecutor
+    from nextsim_amd import forcing as F, mesh as M
     from oracle import pyoracle as O
     gm, p, lm, f = build_case(kind, 1, 0)
     r = O.OracleRank(lm, p, f, fast=True)
     t0 = time.perf_counter()
     for _ in range(nsteps):
         r.step()
-    dt = time.perf_counter() - t0
-    return gm.num_elements * p.substeps * nsteps / dt, dt
+    dt1 = time.perf_counter() - t0
+    single = gm.num_elements * p.substeps * nsteps / dt1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # a one-GPU box's CPU share
+    out = {"value": single, "cores": 1, "seconds": dt1, "single_core_value": single}
+    if cores > 1:
+        p2, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
+        g = F.global_fields(gm, p2, "arctic", C_fix, C_alea)
+        lms = M.localize(gm, cores)
+        ranks = [O.OracleRank(l, p2, F.localize_fields(g, l, gm.num_nodes), fast=True) for l in lms]
+        with ThreadPoolExecutor(cores) as pool:
+            t0 = time.perf_counter()
+            for _ in range(nsteps):
+                O.multirank_step_threaded(ranks, pool)
+            dtn = time.perf_counter() - t0
+        multi = gm.num_elements * p.substeps * nsteps / dtn
+        if multi > single:
+            out.update(value=multi, cores=cores, seconds=dtn)
+    return out
 
 
 def main():
@@ -232,7 +272,7 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": pmc_traffic(args.mesh, launches_per_substep, world),
             "bytes_per_launch_group": bytes_per_substep,
             "avg_ms_per_launch_group": substep_ms,
             "note": "rank-0 partition; algorithmic bytes = 172 B/element + 217 B/node per sub-step",
@@ -241,11 +281,13 @@ def main():
         "fields_ok": res["crash"] == 0,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        v, secs = cpu_baseline(args.mesh, 1)
+        cb = cpu_baseline(args.mesh, 1)
         out["cpu_baseline"] = {
-            "value": v, "unit": "element-updates/s", "cores": 1, "kind": "port",
+            "value": cb["value"], "unit": "element-updates/s", "cores": cb["cores"], "kind": "port",
+            "single_core_value": cb["single_core_value"],
             "sample": f"1 full dynamics step ({S} sub-steps) of the same '{args.mesh}' mesh and forcing, "
-                      f"oracle/dyn_ref.c -O3 -march=native, single thread, {secs:.1f} s",
+                      f"oracle/dyn_ref.c -O3 -march=native, {cb['cores']} thread(s) = one mesh partition per core with "
+                      f"shared-memory halo exchange, {cb['seconds']:.1f} s",
         }
     if world == 1 and not args.no_aux and args.mesh != "10km":
         aux_args = argparse.Namespace(**vars(args)); aux_args.steps = max(args.steps, 20); aux_args.warmup = max(args.warmup, 3)

@@ -270,3 +270,28 @@ def bamg_interp_mesh_to_grid(index_mesh, x_mesh, y_mesh, data, xmin, ymax, xpost
                                          float(xposting), float(yposting), int(nrows), int(ncols), float(default_value), _abi.dptr(out))
     assert rc == 0
     return out
+
+
+def multirank_step_threaded(ranks: list, pool) -> None:
+    """multirank_step with the per-rank phases run concurrently on `pool` (a ThreadPoolExecutor; ctypes
+    releases the GIL): one mesh partition per host core, halos exchanged through shared memory between the
+    phases -- the CPU analogue of the reference's MPI run, used by bench.py's cpu_baseline."""
+    p = ranks[0].params
+    steps = p.substeps
+    dte = p.dtime_step / float(steps)
+
+    def run(fn):
+        list(pool.map(fn, ranks))
+
+    run(lambda r: r.prep())
+    for _ in range(steps):
+        run(lambda r: r.substep_solve())
+        exchange_ghosts(ranks)
+        if p.dynamics_type != _abi.NXS_DYN_MEVP:
+            run(lambda r: r.move_mesh(dte))
+    if p.dynamics_type == _abi.NXS_DYN_MEVP:
+        run(lambda r: r.move_mesh(p.dtime_step))
+    for _ in range(50):
+        run(lambda r: r.smoother_sweep())
+        exchange_ghosts(ranks)
+    run(lambda r: (r.ow_tail(), r.update()))
