@@ -357,3 +357,22 @@ def test_shuffled_numbering_still_matches_the_oracle():
     fe.step(); ref.step(); fe.synchronize()
     _assert_close(fe.get_state(), ref.arr, STATE_KEYS, 1e-10, "shuffled numbering")
     fe.close()
+
+
+def test_remesh_on_a_live_handle_equals_a_fresh_handle():
+    """nxs_dyn_set_mesh is called again after every regrid (FE.cpp:3071-3154 -> distributedMeshProcessing):
+    a handle that already ran on another mesh must give the same bits as a fresh one."""
+    from nextsim_amd import dynamics
+    gm1, p1, g1, lms1, f1 = cases.make_case("toy")
+    gm2, p2, g2, lms2, f2 = cases.make_case("small")
+    fe = dynamics.FiniteElementDynamics(p1)
+    fe.set_mesh(lms1[0]); fe.put_state(f1[0]); fe.set_forcing(f1[0]); fe.step(); fe.step()
+    fe.set_params(p2)
+    fe.set_mesh(lms2[0]); fe.put_state(f2[0]); fe.set_forcing(f2[0]); fe.step(); fe.synchronize()
+    a = fe.get_state()
+    fresh = dynamics.FiniteElementDynamics(p2)
+    fresh.set_mesh(lms2[0]); fresh.put_state(f2[0]); fresh.set_forcing(f2[0]); fresh.step(); fresh.synchronize()
+    b = fresh.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(a[k], b[k]), k
+    fe.close(); fresh.close()
