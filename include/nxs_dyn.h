@@ -259,6 +259,11 @@ NXS_API int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int
                           int32_t *nec_width, double *nodal_element_connectivity,
                           int32_t *nc_width, double *nodal_connectivity);
 
+/* bamgmesh->ElementConnectivity (contrib/bamg/src/Mesh.cpp:777-796): ec[3*e+j] = 1-based number of the triangle
+ * across local edge j (vertices (j+1)%3,(j+2)%3) of triangle e, NaN on the boundary.  Host only. */
+NXS_API int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
+                                  double *element_connectivity);
+
 #ifdef __cplusplus
 }
 #endif

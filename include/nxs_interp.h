@@ -57,6 +57,36 @@ NXS_INTERP_API int nxs_interp_mesh_to_grid(double *griddata, const int32_t *inde
                                            double xmin, double ymax, double xposting, double yposting, int32_t nrows,
                                            int32_t ncols, double default_value, int32_t device, double *kernel_ms);
 
+/* Conservative remapping of the element variables at regrid: replaces the root-serial
+ *
+ *   ConservativeRemappingMeshToMesh(interp_elt_out, interp_in_elements, nb_var_element, bamgmesh_previous, bamgmesh_root);
+ *
+ * of FiniteElement::interpFields (FE.cpp:3108; contrib/bamg/src/ConservativeRemapping.cpp:176-328).  One thread per
+ * triangle of the new mesh: the old triangle holding its barycentre (the reference finds it with
+ * InterpFromMeshToMesh2dx, :243-249), the "same three vertices" shortcut through PreviousNumbering (:263-289),
+ * otherwise the walk over the overlapping old triangles (checkTriangle, :330-449) with the polygon-clipping
+ * weights, then out = (sum_k in[tri_k]*w_k) * (1/area(new triangle)) in the reference's visiting order
+ * (ConservativeRemappingMeshToGrid, :97-131).  Same predicates, tolerances, sort and operand order as the
+ * reference, so the result is bit-identical (tests/test_remap.py).
+ *
+ *   interp_in  [nels_old][nb_var], interp_out [nels_new][nb_var] (caller-allocated; the reference allocates it)
+ *   index_     1-based triangles (bamgmesh->Triangles without the 4th column), x_, y_ = bamgmesh->Vertices
+ *   nec_old / nec_width / ec_old   bamgmesh_previous->NodalElementConnectivity (+Size[1]) and ->ElementConnectivity
+ *              as bamg leaves them (doubles, NaN padding); NULL = built here with nxs_mesh_connectivity /
+ *              nxs_mesh_element_connectivity, which reproduce bamg's tables
+ *   previous_numbering  bamgmesh_root->PreviousNumbering (1-based old number of every new vertex, 0 = new), may be NULL
+ *   n_geom_vertices     bamgmesh_root->VerticesOnGeomVertexSize[0]
+ *   num_failed (may be NULL)  new triangles whose barycentre is in no old triangle (the reference asserts) or
+ *              that overlap more than 96 old triangles; their rows are NaN
+ *   visits (may be NULL) [nels_new]  number of old triangles that contributed (1 = unchanged triangle)
+ */
+NXS_INTERP_API int nxs_interp_conservative_remap(double *interp_out, const double *interp_in, int32_t nb_var, const int32_t *index_old,
+                                                 const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old,
+                                                 const double *nec_old, int32_t nec_width, const double *ec_old,
+                                                 const int32_t *index_new, const double *x_new, const double *y_new, int32_t nods_new,
+                                                 int32_t nels_new, const double *previous_numbering, int32_t n_geom_vertices,
+                                                 int32_t device, int32_t *num_failed, int32_t *visits, double *kernel_ms);
+
 NXS_INTERP_API const char *nxs_interp_last_error(void);
 
 #ifdef __cplusplus

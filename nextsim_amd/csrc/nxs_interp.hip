@@ -60,24 +60,14 @@ __device__ __forceinline__ long long det3(long long ax, long long ay, long long 
     return bax * cay - bay * cax;
 }
 
-__global__ void __launch_bounds__(256) k_interp(InterpDev d, const double *__restrict__ data, const double *__restrict__ xi,
-                                                const double *__restrict__ yi, double *__restrict__ out, int *num_exterior) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= d.N_interp) return;
-    const double x = xi[i], y = yi[i];
-    double *o = out + (size_t)i * d.N_data;
-    if (d.isdefault && (x < d.xmin || x > d.xmax || y < d.ymin || y > d.ymax)) {
-        for (int j = 0; j < d.N_data; ++j) o[j] = d.defaultvalue;
-        return;
-    }
-    // R2ToI2 (Mesh.cpp:3688-3690): truncation of coefIcoor*(P - pmin)
+// Exact point location: R2ToI2 (Mesh.cpp:3688-3690: truncation of coefIcoor*(P - pmin)), then the candidates of
+// the bucket in ascending triangle number.  Returns the triangle (dd = its three integer area coordinates) or
+// -1 when the point is in no triangle of the data mesh; Bx/By = the integer point.
+__device__ __forceinline__ int locate(const InterpDev &d, double x, double y, long long dd[3], long long &Bx, long long &By) {
     const double fx = d.coef * (x - d.pminx), fy = d.coef * (y - d.pminy);
     const bool in_plane = fx > -1. && fx < 1073741824. && fy > -1. && fy < 1073741824.;
-    const long long Bx = in_plane ? (long long)(int)fx : (fx < 0. ? -1073741824ll : 2147483647ll);
-    const long long By = in_plane ? (long long)(int)fy : (fy < 0. ? -1073741824ll : 2147483647ll);
-
-    int it = -1;
-    long long dd[3] = {0, 0, 0};
+    Bx = in_plane ? (long long)(int)fx : (fx < 0. ? -1073741824ll : 2147483647ll);
+    By = in_plane ? (long long)(int)fy : (fy < 0. ? -1073741824ll : 2147483647ll);
     if (in_plane && Bx >= 0 && By >= 0) {
         const int cx = (int)(Bx >> d.shift), cy = (int)(By >> d.shift);
         if (cx < d.G && cy < d.G) {
@@ -89,10 +79,25 @@ __global__ void __launch_bounds__(256) k_interp(InterpDev d, const double *__res
                 const long long e0 = det3(x1, y1, x2, y2, Bx, By);  // area coordinate of vertex 0
                 const long long e1 = det3(x2, y2, x0, y0, Bx, By);
                 const long long e2 = det3(x0, y0, x1, y1, Bx, By);
-                if (e0 >= 0 && e1 >= 0 && e2 >= 0 && (e0 + e1 + e2) > 0) { it = t; dd[0] = e0; dd[1] = e1; dd[2] = e2; break; }
+                if (e0 >= 0 && e1 >= 0 && e2 >= 0 && (e0 + e1 + e2) > 0) { dd[0] = e0; dd[1] = e1; dd[2] = e2; return t; }
             }
         }
     }
+    return -1;
+}
+
+__global__ void __launch_bounds__(256) k_interp(InterpDev d, const double *__restrict__ data, const double *__restrict__ xi,
+                                                const double *__restrict__ yi, double *__restrict__ out, int *num_exterior) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= d.N_interp) return;
+    const double x = xi[i], y = yi[i];
+    double *o = out + (size_t)i * d.N_data;
+    if (d.isdefault && (x < d.xmin || x > d.xmax || y < d.ymin || y > d.ymax)) {
+        for (int j = 0; j < d.N_data; ++j) o[j] = d.defaultvalue;
+        return;
+    }
+    long long dd[3] = {0, 0, 0}, Bx, By;
+    int it = locate(d, x, y, dd, Bx, By);
     double a[3];
     if (it >= 0) {
         const long long det = dd[0] + dd[1] + dd[2];  // == det(v0,v1,v2) exactly
@@ -218,6 +223,98 @@ __global__ void __launch_bounds__(256) k_mesh_to_grid(GridDev d, const double *_
 
 }  // namespace
 
+namespace {
+
+// The data mesh in bamg's integer plane + the bucket grid used by locate(), resident on the device.
+struct Locator {
+    InterpDev d{};
+    DevBuf<int> dt0, dt1, dt2, dix, diy, doff, dtri;
+    DevBuf<BEdge> dbe;
+    std::vector<int> t0, t1, t2;
+
+    int build(const int32_t *index_data, const double *x_data, const double *y_data, int32_t nods, int32_t nels, bool need_boundary_edges) {
+        // ---- SetIntCoor (Mesh.cpp:3441-3468)
+        double pminx = x_data[0], pminy = y_data[0], pmaxx = x_data[0], pmaxy = y_data[0];
+        for (int i = 0; i < nods; ++i) {
+            pminx = std::min(pminx, x_data[i]); pminy = std::min(pminy, y_data[i]);
+            pmaxx = std::max(pmaxx, x_data[i]); pmaxy = std::max(pmaxy, y_data[i]);
+        }
+        d.xmin = pminx; d.xmax = pmaxx; d.ymin = pminy; d.ymax = pmaxy;
+        const double DDx = (pmaxx - pminx) * 0.05, DDy = (pmaxy - pminy) * 0.05;
+        pminx = pminx - DDx; pminy = pminy - DDy;
+        pmaxx = pmaxx + DDx; pmaxy = pmaxy + DDy;
+        const double coef = 1073741823. / std::max(pmaxx - pminx, pmaxy - pminy);
+        if (!(coef > 0.)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive, a problem in the geometry is likely");
+        std::vector<int> ix(nods), iy(nods);
+        for (int i = 0; i < nods; ++i) {  // R2ToI2
+            ix[i] = (int)(coef * (x_data[i] - pminx));
+            iy[i] = (int)(coef * (y_data[i] - pminy));
+        }
+        t0.resize(nels); t1.resize(nels); t2.resize(nels);
+        for (int e = 0; e < nels; ++e) { t0[e] = index_data[3 * e] - 1; t1[e] = index_data[3 * e + 1] - 1; t2[e] = index_data[3 * e + 2] - 1; }
+
+        // ---- bucket grid over the integer plane
+        int G = 1;
+        while ((long long)G * G * 2 < nels && G < 4096) G <<= 1;
+        int shift = 30;
+        for (int g = G; g > 1; g >>= 1) --shift;  // cell = 2^shift units, G cells cover [0, 2^30)
+        std::vector<int> cnt((size_t)G * G + 1, 0);
+        auto cell_range = [&](int e, int &cx0, int &cx1, int &cy0, int &cy1) {
+            const int xs[3] = {ix[t0[e]], ix[t1[e]], ix[t2[e]]}, ys[3] = {iy[t0[e]], iy[t1[e]], iy[t2[e]]};
+            cx0 = std::min({xs[0], xs[1], xs[2]}) >> shift; cx1 = std::max({xs[0], xs[1], xs[2]}) >> shift;
+            cy0 = std::min({ys[0], ys[1], ys[2]}) >> shift; cy1 = std::max({ys[0], ys[1], ys[2]}) >> shift;
+            cx0 = std::max(cx0, 0); cy0 = std::max(cy0, 0); cx1 = std::min(cx1, G - 1); cy1 = std::min(cy1, G - 1);
+        };
+        for (int e = 0; e < nels; ++e) {
+            int a, b, c, dd2;
+            cell_range(e, a, b, c, dd2);
+            for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cnt[(size_t)cy * G + cx + 1]++;
+        }
+        for (size_t c = 0; c < (size_t)G * G; ++c) cnt[c + 1] += cnt[c];
+        std::vector<int> cell_tri(cnt[(size_t)G * G]), fill(cnt.begin(), cnt.end() - 1);
+        for (int e = 0; e < nels; ++e) {  // ascending e => ascending lists
+            int a, b, c, dd2;
+            cell_range(e, a, b, c, dd2);
+            for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cell_tri[fill[(size_t)cy * G + cx]++] = e;
+        }
+
+        // ---- boundary edges (edges held by exactly one triangle)
+        std::vector<BEdge> bedges;
+        if (need_boundary_edges) {
+            static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+            std::vector<std::pair<long long, int>> keys;  // (sorted vertex pair, 3*tri + k)
+            keys.reserve(3 * (size_t)nels);
+            for (int e = 0; e < nels; ++e) {
+                const int tv[3] = {t0[e], t1[e], t2[e]};
+                for (int k = 0; k < 3; ++k) {
+                    const int p = tv[VOTE[k][0]], q = tv[VOTE[k][1]];
+                    keys.emplace_back((long long)std::min(p, q) * nods + std::max(p, q), 3 * e + k);
+                }
+            }
+            std::sort(keys.begin(), keys.end());
+            for (size_t i = 0; i < keys.size();) {
+                size_t j = i + 1;
+                while (j < keys.size() && keys[j].first == keys[i].first) ++j;
+                if (j - i == 1) bedges.push_back(BEdge{keys[i].second / 3, keys[i].second % 3});
+                i = j;
+            }
+            std::sort(bedges.begin(), bedges.end(), [](const BEdge &a, const BEdge &b) { return a.tri != b.tri ? a.tri < b.tri : a.k < b.k; });
+        }
+        if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || dix.upload(ix.data(), nods) ||
+            diy.upload(iy.data(), nods) || doff.upload(cnt.data(), cnt.size()) || dtri.upload(cell_tri.data(), cell_tri.size()) ||
+            dbe.upload(bedges.data(), bedges.size()))
+            return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
+        d.nods = nods; d.nels = nels;
+        d.t0 = dt0.p; d.t1 = dt1.p; d.t2 = dt2.p; d.ix = dix.p; d.iy = diy.p;
+        d.G = G; d.shift = shift; d.cell_off = doff.p; d.cell_tri = dtri.p;
+        d.nbe = (int)bedges.size(); d.bedges = dbe.p;
+        d.coef = coef; d.pminx = pminx; d.pminy = pminy;
+        return 0;
+    }
+};
+
+}  // namespace
+
 extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
                                        int32_t nods, int32_t nels, const double *data_mesh, int32_t data_length, int32_t N_data,
                                        double xmin, double ymax, double xposting, double yposting, int32_t nrows, int32_t ncols,
@@ -305,90 +402,16 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     for (int64_t i = 0; i < 3ll * nels; ++i)
         if (index_data[i] < 1 || index_data[i] > nods) return fail(NXS_ERR_INVALID, "index_data[%lld] out of range", (long long)i);
 
-    // ---- SetIntCoor (Mesh.cpp:3441-3468)
-    double pminx = x_data[0], pminy = y_data[0], pmaxx = x_data[0], pmaxy = y_data[0];
-    for (int i = 0; i < nods; ++i) {
-        pminx = std::min(pminx, x_data[i]); pminy = std::min(pminy, y_data[i]);
-        pmaxx = std::max(pmaxx, x_data[i]); pmaxy = std::max(pmaxy, y_data[i]);
-    }
-    InterpDev d{};
-    d.xmin = pminx; d.xmax = pmaxx; d.ymin = pminy; d.ymax = pmaxy;
-    const double DDx = (pmaxx - pminx) * 0.05, DDy = (pmaxy - pminy) * 0.05;
-    pminx = pminx - DDx; pminy = pminy - DDy;
-    pmaxx = pmaxx + DDx; pmaxy = pmaxy + DDy;
-    const double coef = 1073741823. / std::max(pmaxx - pminx, pmaxy - pminy);
-    if (!(coef > 0.)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive, a problem in the geometry is likely");
-    std::vector<int> ix(nods), iy(nods);
-    for (int i = 0; i < nods; ++i) {  // R2ToI2
-        ix[i] = (int)(coef * (x_data[i] - pminx));
-        iy[i] = (int)(coef * (y_data[i] - pminy));
-    }
-    std::vector<int> t0(nels), t1(nels), t2(nels);
-    for (int e = 0; e < nels; ++e) { t0[e] = index_data[3 * e] - 1; t1[e] = index_data[3 * e + 1] - 1; t2[e] = index_data[3 * e + 2] - 1; }
-
-    // ---- bucket grid over the integer plane
-    int G = 1;
-    while ((long long)G * G * 2 < nels && G < 4096) G <<= 1;
-    int shift = 30;
-    for (int g = G; g > 1; g >>= 1) --shift;  // cell = 2^shift units, G cells cover [0, 2^30)
-    std::vector<int> cnt((size_t)G * G + 1, 0);
-    auto cell_range = [&](int e, int &cx0, int &cx1, int &cy0, int &cy1) {
-        const int xs[3] = {ix[t0[e]], ix[t1[e]], ix[t2[e]]}, ys[3] = {iy[t0[e]], iy[t1[e]], iy[t2[e]]};
-        cx0 = std::min({xs[0], xs[1], xs[2]}) >> shift; cx1 = std::max({xs[0], xs[1], xs[2]}) >> shift;
-        cy0 = std::min({ys[0], ys[1], ys[2]}) >> shift; cy1 = std::max({ys[0], ys[1], ys[2]}) >> shift;
-        cx0 = std::max(cx0, 0); cy0 = std::max(cy0, 0); cx1 = std::min(cx1, G - 1); cy1 = std::min(cy1, G - 1);
-    };
-    for (int e = 0; e < nels; ++e) {
-        int a, b, c, dd2;
-        cell_range(e, a, b, c, dd2);
-        for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cnt[(size_t)cy * G + cx + 1]++;
-    }
-    for (size_t c = 0; c < (size_t)G * G; ++c) cnt[c + 1] += cnt[c];
-    std::vector<int> cell_tri(cnt[(size_t)G * G]), fill(cnt.begin(), cnt.end() - 1);
-    for (int e = 0; e < nels; ++e) {  // ascending e => ascending lists
-        int a, b, c, dd2;
-        cell_range(e, a, b, c, dd2);
-        for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cell_tri[fill[(size_t)cy * G + cx]++] = e;
-    }
-
-    // ---- boundary edges (edges held by exactly one triangle)
-    std::vector<BEdge> bedges;
-    if (!isdefault) {
-        static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
-        std::vector<std::pair<long long, int>> keys;  // (sorted vertex pair, 3*tri + k)
-        keys.reserve(3 * (size_t)nels);
-        for (int e = 0; e < nels; ++e) {
-            const int tv[3] = {t0[e], t1[e], t2[e]};
-            for (int k = 0; k < 3; ++k) {
-                const int p = tv[VOTE[k][0]], q = tv[VOTE[k][1]];
-                keys.emplace_back((long long)std::min(p, q) * nods + std::max(p, q), 3 * e + k);
-            }
-        }
-        std::sort(keys.begin(), keys.end());
-        for (size_t i = 0; i < keys.size();) {
-            size_t j = i + 1;
-            while (j < keys.size() && keys[j].first == keys[i].first) ++j;
-            if (j - i == 1) bedges.push_back(BEdge{keys[i].second / 3, keys[i].second % 3});
-            i = j;
-        }
-        std::sort(bedges.begin(), bedges.end(), [](const BEdge &a, const BEdge &b) { return a.tri != b.tri ? a.tri < b.tri : a.k < b.k; });
-    }
-
-    DevBuf<int> dt0, dt1, dt2, dix, diy, doff, dtri, dnext;
-    DevBuf<BEdge> dbe;
+    Locator loc;
+    if (int rc = loc.build(index_data, x_data, y_data, nods, nels, !isdefault)) return rc;
+    InterpDev d = loc.d;
+    DevBuf<int> dnext;
     DevBuf<double> ddata, dxi, dyi, dout;
-    if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || dix.upload(ix.data(), nods) ||
-        diy.upload(iy.data(), nods) || doff.upload(cnt.data(), cnt.size()) || dtri.upload(cell_tri.data(), cell_tri.size()) ||
-        dbe.upload(bedges.data(), bedges.size()) || ddata.upload(data, (size_t)M_data * N_data) || dxi.upload(x_interp, N_interp) ||
-        dyi.upload(y_interp, N_interp) || dout.alloc((size_t)N_interp * N_data) || dnext.alloc(1))
+    if (ddata.upload(data, (size_t)M_data * N_data) || dxi.upload(x_interp, N_interp) || dyi.upload(y_interp, N_interp) ||
+        dout.alloc((size_t)N_interp * N_data) || dnext.alloc(1))
         return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
     if (hipMemset(dnext.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
-
-    d.nods = nods; d.nels = nels; d.N_data = N_data; d.N_interp = N_interp; d.nodal = (M_data == nods);
-    d.t0 = dt0.p; d.t1 = dt1.p; d.t2 = dt2.p; d.ix = dix.p; d.iy = diy.p;
-    d.G = G; d.shift = shift; d.cell_off = doff.p; d.cell_tri = dtri.p;
-    d.nbe = (int)bedges.size(); d.bedges = dbe.p;
-    d.coef = coef; d.pminx = pminx; d.pminy = pminy;
+    d.N_data = N_data; d.N_interp = N_interp; d.nodal = (M_data == nods);
     d.isdefault = isdefault != 0; d.defaultvalue = defaultvalue;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -409,5 +432,148 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     int next = 0;
     (void)hipMemcpy(&next, dnext.p, sizeof(int), hipMemcpyDeviceToHost);
     if (num_exterior) *num_exterior = next;
+    return NXS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Conservative remapping of the element variables at regrid (ConservativeRemappingMeshToMesh, FE.cpp:3108)
+// ---------------------------------------------------------------------------------------------------------
+#undef NXS_HD
+#define NXS_HD __device__
+#include "nxs_remap_core.inl"
+
+namespace {
+
+struct RemapDev {
+    InterpDev loc;           // old mesh in bamg's integer plane (seed search = InterpFromMeshToMesh2dx with isdefault)
+    nxs_remap::OldMesh m;
+    int nels_new, nb_var, n_geom;
+    const int *tri_new;      // [3*nels_new] 0-based
+    const double *xn, *yn;
+    const double *prev;      // bamgmesh_new->PreviousNumbering or NULL
+};
+
+// one thread per new triangle: seed, identity test, replay of checkTriangle's recursion, weighted sum
+__global__ void __launch_bounds__(128) k_remap(RemapDev r, const double *__restrict__ in, double *__restrict__ out, int *failed, int *visits) {
+    const int t = blockIdx.x * 128 + threadIdx.x;
+    if (t >= r.nels_new) return;
+    double cx[3], cy[3];
+    int nt[3];
+    double gx = 0., gy = 0.;  // barycentre, ConservativeRemapping.cpp:217-231
+    for (int i = 0; i < 3; ++i) {
+        nt[i] = r.tri_new[3 * t + i];
+        cx[i] = r.xn[nt[i]];
+        cy[i] = r.yn[nt[i]];
+        gx += cx[i];
+        gy += cy[i];
+    }
+    gx /= 3.;
+    gy /= 3.;
+    double *o = out + (size_t)t * r.nb_var;
+    int seed = -1;
+    if (!(gx < r.loc.xmin || gx > r.loc.xmax || gy < r.loc.ymin || gy > r.loc.ymax)) {
+        long long dd[3], Bx, By;
+        seed = locate(r.loc, gx, gy, dd, Bx, By);
+    }
+    int n = -1;
+    int tris[nxs_remap::kMaxVisit];
+    double w[nxs_remap::kMaxVisit];
+    nxs_remap::Frame stack[nxs_remap::kMaxVisit + 1];
+    if (seed >= 0) {
+        const bool same = nxs_remap::same_triangle(r.m, seed, nt, r.prev, r.n_geom);
+        n = nxs_remap::collect(r.m, cx, cy, seed, same, tris, w, stack);
+    }
+    if (visits) visits[t] = n;
+    if (n < 0) {  // barycentre outside the old mesh (the reference asserts) or capacity exceeded: flagged, never silent
+        atomicAdd(failed, 1);
+        for (int v = 0; v < r.nb_var; ++v) o[v] = __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    nxs_remap::apply(in, r.nb_var, cx, cy, tris, w, n, o);
+}
+
+}  // namespace
+
+extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *interp_in, int32_t nb_var, const int32_t *index_old,
+                                             const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old,
+                                             const double *nec_old, int32_t nec_width, const double *ec_old, const int32_t *index_new,
+                                             const double *x_new, const double *y_new, int32_t nods_new, int32_t nels_new,
+                                             const double *previous_numbering, int32_t n_geom_vertices, int32_t device,
+                                             int32_t *num_failed, int32_t *visits, double *kernel_ms) {
+    if (!interp_out || !interp_in || !index_old || !x_old || !y_old || !index_new || !x_new || !y_new) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (nb_var < 1 || nods_old < 3 || nels_old < 1 || nods_new < 3 || nels_new < 1) return fail(NXS_ERR_INVALID, "bad sizes");
+    if (nec_old && nec_width < 1) return fail(NXS_ERR_INVALID, "nec_width must be given with the NodalElementConnectivity table");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the remapping has no CPU path");
+    if (device < 0 || device >= ndev) return fail(NXS_ERR_INVALID, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
+    for (int64_t i = 0; i < 3ll * nels_old; ++i)
+        if (index_old[i] < 1 || index_old[i] > nods_old) return fail(NXS_ERR_INVALID, "index_old[%lld] out of range", (long long)i);
+    for (int64_t i = 0; i < 3ll * nels_new; ++i)
+        if (index_new[i] < 1 || index_new[i] > nods_new) return fail(NXS_ERR_INVALID, "index_new[%lld] out of range", (long long)i);
+
+    // the two tables checkTriangle walks, as bamg leaves them (doubles, NaN padding); built here when not given
+    std::vector<double> nec_own, ec_own;
+    if (!nec_old) {
+        int32_t w1 = 0, w2 = 0;
+        if (nxs_mesh_connectivity(index_old, nods_old, nels_old, &w1, nullptr, &w2, nullptr)) return fail(NXS_ERR_INVALID, "connectivity of the old mesh failed");
+        nec_own.resize((size_t)nods_old * w1);
+        if (nxs_mesh_connectivity(index_old, nods_old, nels_old, &w1, nec_own.data(), nullptr, nullptr)) return fail(NXS_ERR_INVALID, "connectivity of the old mesh failed");
+        nec_old = nec_own.data();
+        nec_width = w1;
+    }
+    if (!ec_old) {
+        ec_own.resize(3 * (size_t)nels_old);
+        if (nxs_mesh_element_connectivity(index_old, nods_old, nels_old, ec_own.data())) return fail(NXS_ERR_INVALID, "an edge of the old mesh is shared by more than two triangles");
+        ec_old = ec_own.data();
+    }
+    if (nec_width > 255) return fail(NXS_ERR_INVALID, "NodalElementConnectivity wider than 255");
+    std::vector<int> neci((size_t)nods_old * nec_width), eci(3 * (size_t)nels_old), trio(3 * (size_t)nels_old), trin(3 * (size_t)nels_new);
+    auto to_index = [&](double v, int hi) -> int {  // "(int)(v - 1)" of the reference; NaN and junk become "no more entries"
+        if (!(v >= 1.) || !(v <= (double)hi)) return -1;
+        return (int)v - 1;
+    };
+    for (size_t i = 0; i < neci.size(); ++i) neci[i] = to_index(nec_old[i], nels_old);
+    for (size_t i = 0; i < eci.size(); ++i) eci[i] = to_index(ec_old[i], nels_old);
+    for (size_t i = 0; i < trio.size(); ++i) trio[i] = index_old[i] - 1;
+    for (size_t i = 0; i < trin.size(); ++i) trin[i] = index_new[i] - 1;
+    if (previous_numbering)
+        for (int i = 0; i < nods_new; ++i)
+            if (!(previous_numbering[i] >= 0.) || previous_numbering[i] > (double)nods_old) return fail(NXS_ERR_INVALID, "previous_numbering[%d] out of range", i);
+
+    Locator loc;
+    if (int rc = loc.build(index_old, x_old, y_old, nods_old, nels_old, false)) return rc;
+    DevBuf<int> dnec, dec, dtrio, dtrin, dfail, dvis;
+    DevBuf<double> dxo, dyo, dxn, dyn, dprev, din, dout;
+    if (dnec.upload(neci.data(), neci.size()) || dec.upload(eci.data(), eci.size()) || dtrio.upload(trio.data(), trio.size()) ||
+        dtrin.upload(trin.data(), trin.size()) || dxo.upload(x_old, nods_old) || dyo.upload(y_old, nods_old) || dxn.upload(x_new, nods_new) ||
+        dyn.upload(y_new, nods_new) || (previous_numbering && dprev.upload(previous_numbering, nods_new)) ||
+        din.upload(interp_in, (size_t)nels_old * nb_var) || dout.alloc((size_t)nels_new * nb_var) || dfail.alloc(1) || (visits && dvis.alloc(nels_new)))
+        return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
+    if (hipMemset(dfail.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+
+    RemapDev r{};
+    r.loc = loc.d;
+    r.loc.isdefault = 1;
+    r.m = nxs_remap::OldMesh{nels_old, nods_old, dtrio.p, dxo.p, dyo.p, dnec.p, nec_width, dec.p};
+    r.nels_new = nels_new; r.nb_var = nb_var; r.n_geom = n_geom_vertices;
+    r.tri_new = dtrin.p; r.xn = dxn.p; r.yn = dyn.p; r.prev = previous_numbering ? dprev.p : nullptr;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_remap, dim3((nels_new + 127) / 128), dim3(128), 0, nullptr, r, (const double *)din.p, dout.p, dfail.p, visits ? dvis.p : nullptr);
+    (void)hipEventRecord(e1, nullptr);
+    hipError_t err = hipDeviceSynchronize();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(NXS_ERR_HIP, "remapping kernel failed: %s", hipGetErrorString(err));
+    if (kernel_ms) *kernel_ms = ms;
+    if (hipMemcpy(interp_out, dout.p, (size_t)nels_new * nb_var * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    if (visits && hipMemcpy(visits, dvis.p, (size_t)nels_new * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    int nf = 0;
+    (void)hipMemcpy(&nf, dfail.p, sizeof(int), hipMemcpyDeviceToHost);
+    if (num_failed) *num_failed = nf;
     return NXS_OK;
 }

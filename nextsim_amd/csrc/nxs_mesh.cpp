@@ -98,3 +98,38 @@ extern "C" int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, 
     }
     return NXS_OK;
 }
+
+// bamgmesh->ElementConnectivity (contrib/bamg/src/Mesh.cpp:777-796): column j = 1-based number of the
+// triangle across local edge j (vertices (j+1)%3, (j+2)%3), NaN on the boundary.  The rows are what
+// ConservativeRemapping's checkTriangle walks (ConservativeRemapping.cpp:411-436), which stops at the first
+// NaN of a row -- so the column of a neighbour matters, not only the set.
+extern "C" int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements, double *ec) {
+    if (!indices || !ec || num_nodes <= 0 || num_elements <= 0) return NXS_ERR_INVALID;
+    const int64_t Ne = num_elements;
+    for (int64_t i = 0; i < 3 * Ne; ++i)
+        if (indices[i] < 1 || indices[i] > num_nodes) return NXS_ERR_INVALID;
+    static const int LE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+    const double nan = std::nan("");
+    for (int64_t i = 0; i < 3 * Ne; ++i) ec[i] = nan;
+    // half-edge chains on the smaller end
+    std::vector<int32_t> head(num_nodes, -1), nxt(3 * Ne, -1), other(3 * Ne);
+    for (int64_t t = 0; t < Ne; ++t)
+        for (int j = 0; j < 3; ++j) {
+            const int32_t p = indices[3 * t + LE[j][0]] - 1, q = indices[3 * t + LE[j][1]] - 1;
+            const int32_t a = p < q ? p : q, b = p < q ? q : p;
+            const int64_t me = 3 * t + j;
+            other[me] = b;
+            int32_t mate = -1;
+            for (int32_t h = head[a]; h >= 0; h = nxt[h])
+                if (other[h] == b) { mate = h; break; }
+            if (mate >= 0) {
+                if (!std::isnan(ec[mate])) return NXS_ERR_INVALID;  // an edge shared by three triangles
+                ec[mate] = double(t + 1);
+                ec[me] = double(mate / 3 + 1);
+            } else {
+                nxt[me] = head[a];
+                head[a] = int32_t(me);
+            }
+        }
+    return NXS_OK;
+}

@@ -78,6 +78,7 @@ def load_library():
     L.nxs_dyn_debug_array.argtypes = [H, C.c_char_p, _abi.c_double_p, C.c_int64]
     L.nxs_mesh_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, P(C.c_int32), _abi.c_double_p,
                                         P(C.c_int32), _abi.c_double_p]
+    L.nxs_mesh_element_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, _abi.c_double_p]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
         if name not in ("nxs_dyn_last_error",):
@@ -101,9 +102,9 @@ EXPORTS = (
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_get_diag", "nxs_dyn_step",
     "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
     "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
-    "nxs_dyn_debug_array", "nxs_mesh_connectivity",
+    "nxs_dyn_debug_array", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity",
 )
-INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_last_error")
+INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_conservative_remap", "nxs_interp_last_error")
 
 
 def mesh_connectivity(indices: np.ndarray, num_nodes: int):
@@ -121,6 +122,17 @@ def mesh_connectivity(indices: np.ndarray, num_nodes: int):
     if rc:
         raise NxsError(rc, "nxs_mesh_connectivity")
     return nec, nc
+
+
+def mesh_element_connectivity(indices: np.ndarray, num_nodes: int) -> np.ndarray:
+    """bamgmesh->ElementConnectivity ([Ne,3] doubles, 1-based, NaN on the boundary), bamg's column order."""
+    L = load_library()
+    indices = np.ascontiguousarray(indices, np.int32)
+    ec = np.empty((indices.size // 3, 3))
+    rc = L.nxs_mesh_element_connectivity(_abi.iptr(indices), num_nodes, indices.size // 3, _abi.dptr(ec))
+    if rc:
+        raise NxsError(rc, "nxs_mesh_element_connectivity")
+    return ec
 
 
 class FiniteElementDynamics:

@@ -78,3 +78,40 @@ def InterpFromMeshToGridx(index_mesh, x_mesh, y_mesh, data, xmin, ymax, xposting
     if rc:
         raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
     return (out, {"kernel_ms": ms.value}) if return_info else out
+
+
+def ConservativeRemappingMeshToMesh(interp_in, index_old, x_old, y_old, index_new, x_new, y_new, previous_numbering=None,
+                                    n_geom_vertices=0, nec_old=None, ec_old=None, device=0, return_info=False):
+    """Element variables old mesh -> new mesh, argument meaning of contrib/bamg's ConservativeRemappingMeshToMesh
+    (FE.cpp:3108) with the BamgMesh members spelled out: index_* 1-based [3*nels], previous_numbering 1-based
+    (0 = vertex created by the remesher).  interp_in [nels_old, nb_var] -> [nels_new, nb_var]."""
+    L = _lib()
+    if not hasattr(L, "_remap_declared"):
+        D, I = _abi.c_double_p, _abi.c_int32_p
+        L.nxs_interp_conservative_remap.argtypes = [D, D, C.c_int32, I, D, D, C.c_int32, C.c_int32, D, C.c_int32, D, I, D, D, C.c_int32,
+                                                    C.c_int32, D, C.c_int32, C.c_int32, C.POINTER(C.c_int32), I, C.POINTER(C.c_double)]
+        L.nxs_interp_conservative_remap.restype = C.c_int
+        L._remap_declared = True
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
+    index_old = np.ascontiguousarray(index_old, np.int32).ravel(); index_new = np.ascontiguousarray(index_new, np.int32).ravel()
+    x_old, y_old, x_new, y_new = f64(x_old), f64(y_old), f64(x_new), f64(y_new)
+    interp_in = f64(interp_in)
+    if interp_in.ndim == 1:
+        interp_in = interp_in[:, None]
+    ne_new = index_new.size // 3
+    out = np.empty((ne_new, interp_in.shape[1]))
+    visits = np.zeros(ne_new, np.int32)
+    prev = None if previous_numbering is None else f64(previous_numbering)
+    nec = None if nec_old is None else f64(nec_old)
+    ec = None if ec_old is None else f64(ec_old)
+    nfail, ms = C.c_int32(0), C.c_double(0.0)
+    rc = L.nxs_interp_conservative_remap(_abi.dptr(out), _abi.dptr(interp_in), interp_in.shape[1], _abi.iptr(index_old), _abi.dptr(x_old),
+                                         _abi.dptr(y_old), x_old.size, index_old.size // 3, None if nec is None else _abi.dptr(nec),
+                                         0 if nec is None else nec.shape[1], None if ec is None else _abi.dptr(ec), _abi.iptr(index_new),
+                                         _abi.dptr(x_new), _abi.dptr(y_new), x_new.size, ne_new, None if prev is None else _abi.dptr(prev),
+                                         int(n_geom_vertices), device, C.byref(nfail), _abi.iptr(visits), C.byref(ms))
+    if rc:
+        raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
+    if return_info:
+        return out, {"num_failed": nfail.value, "visits": visits, "kernel_ms": ms.value}
+    return out

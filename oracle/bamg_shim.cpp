@@ -77,3 +77,54 @@ int shim_bamg_interp_mesh_to_grid(const int *index_mesh, const double *x_mesh, c
 }
 
 } /* extern "C" */
+
+#include <vector>
+#include "ConservativeRemapping.hpp"
+
+extern "C" {
+
+/* bamgmesh->ElementConnectivity and ->Triangles of BamgConvertMeshx (Mesh.cpp:690-693, 777-796), for the
+ * adjacency rows ConservativeRemapping's checkTriangle walks. */
+int shim_bamg_element_connectivity(const int *index, const double *x, const double *y, int nods, int nels, double *ec, double *tri) {
+    BamgMesh *bamgmesh = new BamgMesh();
+    BamgGeom *bamggeom = new BamgGeom();
+    int rc = BamgConvertMeshx(bamgmesh, bamggeom, const_cast<int *>(index), const_cast<double *>(x), const_cast<double *>(y), nods, nels);
+    if (bamgmesh->ElementConnectivitySize[0] != nels || bamgmesh->TrianglesSize[0] != nels) rc = 0;
+    if (rc == 1) {
+        std::memcpy(ec, bamgmesh->ElementConnectivity, sizeof(double) * 3 * (size_t)nels);
+        for (int t = 0; t < nels; ++t)
+            for (int k = 0; k < 3; ++k) tri[3 * t + k] = bamgmesh->Triangles[4 * t + k];
+    }
+    delete bamggeom;
+    delete bamgmesh;
+    return rc == 1 ? 0 : -1;
+}
+
+/* ConservativeRemappingMeshToMesh as called at FE.cpp:3108.  Both BamgMesh objects come from BamgConvertMeshx;
+ * on the new mesh PreviousNumbering (1-based, 0 = new vertex) and VerticesOnGeomVertexSize[0] are set from the
+ * arguments, which is what Bamgx leaves there after an adaptation (Mesh.cpp:553-558, 729). */
+int shim_bamg_conservative_remap(const int *index_old, const double *x_old, const double *y_old, int nods_old, int nels_old,
+                                 const int *index_new, const double *x_new, const double *y_new, int nods_new, int nels_new,
+                                 const double *previous_numbering, int n_geom_vertices, const double *in, int nb_var, double *out) {
+    BamgMesh *mo = new BamgMesh(), *mn = new BamgMesh();
+    BamgGeom *go = new BamgGeom(), *gn = new BamgGeom();
+    int rc = BamgConvertMeshx(mo, go, const_cast<int *>(index_old), const_cast<double *>(x_old), const_cast<double *>(y_old), nods_old, nels_old);
+    if (rc == 1) rc = BamgConvertMeshx(mn, gn, const_cast<int *>(index_new), const_cast<double *>(x_new), const_cast<double *>(y_new), nods_new, nels_new);
+    if (rc == 1 && (mo->TrianglesSize[0] != nels_old || mn->TrianglesSize[0] != nels_new)) rc = 0;
+    if (rc == 1) {
+        delete[] mn->PreviousNumbering;
+        mn->PreviousNumbering = new double[nods_new];
+        std::memcpy(mn->PreviousNumbering, previous_numbering, sizeof(double) * (size_t)nods_new);
+        mn->VerticesOnGeomVertexSize[0] = n_geom_vertices;
+        std::vector<double> vin(in, in + (size_t)nb_var * nels_old);
+        double *res = NULL;
+        ConservativeRemappingMeshToMesh(res, vin, nb_var, mo, mn);
+        std::memcpy(out, res, sizeof(double) * (size_t)nb_var * nels_new);
+        delete[] res;
+        mn->VerticesOnGeomVertexSize[0] = 0; /* the destructor frees VerticesOnGeomVertex by pointer only */
+    }
+    delete go; delete gn; delete mo; delete mn;
+    return rc == 1 ? 0 : -1;
+}
+
+} /* extern "C" */

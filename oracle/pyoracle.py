@@ -295,3 +295,38 @@ def multirank_step_threaded(ranks: list, pool) -> None:
         run(lambda r: r.smoother_sweep())
         exchange_ghosts(ranks)
     run(lambda r: (r.ow_tail(), r.update()))
+
+
+def bamg_element_connectivity(indices, x, y):
+    """bamgmesh->ElementConnectivity and ->Triangles of the REAL BamgConvertMeshx (doubles, NaN on the boundary)."""
+    L = C.CDLL(os.path.join(HERE, "_ref", "libbamg_shim.so"))
+    idx = np.ascontiguousarray(np.asarray(indices).ravel().astype(np.intc))
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    ne = idx.size // 3
+    ec = np.empty((ne, 3)); tri = np.empty((ne, 3))
+    L.shim_bamg_element_connectivity.argtypes = [C.POINTER(C.c_int), _abi.c_double_p, _abi.c_double_p, C.c_int, C.c_int, _abi.c_double_p, _abi.c_double_p]
+    rc = L.shim_bamg_element_connectivity(idx.ctypes.data_as(C.POINTER(C.c_int)), _abi.dptr(x), _abi.dptr(y), x.size, ne, _abi.dptr(ec), _abi.dptr(tri))
+    assert rc == 0
+    return ec, tri
+
+
+def bamg_conservative_remap(index_old, x_old, y_old, index_new, x_new, y_new, previous_numbering, n_geom_vertices, data):
+    """The REAL ConservativeRemappingMeshToMesh (contrib/bamg/src/ConservativeRemapping.cpp:176-328), as called at
+    FE.cpp:3108.  previous_numbering: 1-based old vertex number of every new vertex (0 = created by the remesher)."""
+    L = C.CDLL(os.path.join(HERE, "_ref", "libbamg_shim.so"))
+    io = np.ascontiguousarray(np.asarray(index_old).ravel().astype(np.intc)); inw = np.ascontiguousarray(np.asarray(index_new).ravel().astype(np.intc))
+    xo = np.ascontiguousarray(x_old, np.float64); yo = np.ascontiguousarray(y_old, np.float64)
+    xn = np.ascontiguousarray(x_new, np.float64); yn = np.ascontiguousarray(y_new, np.float64)
+    pn = np.ascontiguousarray(previous_numbering, np.float64)
+    data = np.ascontiguousarray(data, np.float64)
+    if data.ndim == 1:
+        data = data[:, None]
+    out = np.empty((inw.size // 3, data.shape[1]))
+    IP = C.POINTER(C.c_int)
+    L.shim_bamg_conservative_remap.argtypes = [IP, _abi.c_double_p, _abi.c_double_p, C.c_int, C.c_int, IP, _abi.c_double_p, _abi.c_double_p,
+                                               C.c_int, C.c_int, _abi.c_double_p, C.c_int, _abi.c_double_p, C.c_int, _abi.c_double_p]
+    rc = L.shim_bamg_conservative_remap(io.ctypes.data_as(IP), _abi.dptr(xo), _abi.dptr(yo), xo.size, io.size // 3, inw.ctypes.data_as(IP),
+                                        _abi.dptr(xn), _abi.dptr(yn), xn.size, inw.size // 3, _abi.dptr(pn), int(n_geom_vertices),
+                                        _abi.dptr(data), data.shape[1], _abi.dptr(out))
+    assert rc == 0
+    return out

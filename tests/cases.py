@@ -30,3 +30,86 @@ def rel_err(a, b):
     near zero crossings)."""
     scale = max(float(np.abs(b).max()), 1e-300)
     return float(np.abs(a - b).max()) / scale
+
+
+# ---- regrid pairs for the conservative remapping (N1) ----------------------------------------------------
+
+def _delaunay(x, y):
+    from scipy.spatial import Delaunay
+    t = Delaunay(np.column_stack([x, y])).simplices.astype(np.int64)
+    jac = (x[t[:, 1]] - x[t[:, 0]]) * (y[t[:, 2]] - y[t[:, 0]]) - (x[t[:, 2]] - x[t[:, 0]]) * (y[t[:, 1]] - y[t[:, 0]])
+    t = t[np.abs(jac) > 1e-3]
+    jac = (x[t[:, 1]] - x[t[:, 0]]) * (y[t[:, 2]] - y[t[:, 0]]) - (x[t[:, 2]] - x[t[:, 0]]) * (y[t[:, 1]] - y[t[:, 0]])
+    t[jac < 0] = t[jac < 0][:, [0, 2, 1]]    # counter-clockwise, as the meshes of the model
+    return np.ascontiguousarray(t, np.int32)
+
+
+def rect_mesh(n, seed, L=400e3, H=300e3, x0=-150e3, y0=-900e3):
+    """A Delaunay mesh of a rectangle: boundary vertices first (they play bamg's geometric vertices: same
+    numbers and positions in every mesh of the same rectangle), then jittered interior vertices."""
+    rng = np.random.default_rng(seed)
+    nb = 24
+    s = np.arange(nb) / nb
+    bx = np.concatenate([x0 + L * s, np.full(nb, x0 + L), x0 + L * (1 - s), np.full(nb, x0)])
+    by = np.concatenate([np.full(nb, y0), y0 + H * s, np.full(nb, y0 + H), y0 + H * (1 - s)])
+    gx, gy = np.meshgrid((np.arange(n) + 0.5) / n, (np.arange(n) + 0.5) / n)
+    ix = x0 + L * (gx.ravel() + rng.uniform(-0.3, 0.3, n * n) / n)
+    iy = y0 + H * (gy.ravel() + rng.uniform(-0.3, 0.3, n * n) / n)
+    x = np.concatenate([bx, ix]); y = np.concatenate([by, iy])
+    return x, y, _delaunay(x, y), 4 * nb
+
+
+def adapted_mesh(x, y, tri, n_geom, seed, frac_touched=0.15):
+    """What a bamg adaptation leaves behind, built by hand: most triangles survive, some edges are flipped,
+    some triangles are split by a new vertex, some interior vertices move; vertices (beyond the geometric
+    ones) and triangles are renumbered.  Returns x, y, tri (0-based), previous_numbering (1-based, 0 = new)."""
+    rng = np.random.default_rng(seed)
+    tri = tri.copy()
+    ne = tri.shape[0]
+    # edge -> triangles
+    emap = {}
+    for e in range(ne):
+        for j in range(3):
+            p, q = int(tri[e, (j + 1) % 3]), int(tri[e, (j + 2) % 3])
+            emap.setdefault((min(p, q), max(p, q)), []).append((e, j))
+    touched = np.zeros(ne, bool)
+
+    def ccw(a, b, c):
+        return (x[b] - x[a]) * (y[c] - y[a]) - (x[c] - x[a]) * (y[b] - y[a])
+
+    edges = [k for k, v in emap.items() if len(v) == 2]
+    rng.shuffle(edges)
+    nflip = 0
+    for k in edges:
+        (e1, j1), (e2, j2) = emap[k]
+        if touched[e1] or touched[e2]:
+            continue
+        a = int(tri[e1, j1]); c = int(tri[e2, j2])           # the two apexes
+        p, q = int(tri[e1, (j1 + 1) % 3]), int(tri[e1, (j1 + 2) % 3])
+        if ccw(a, p, c) > 1e3 and ccw(a, c, q) > 1e3:        # convex quad: flip p-q into a-c
+            tri[e1] = (a, p, c); tri[e2] = (a, c, q)
+            touched[e1] = touched[e2] = True
+            nflip += 1
+            if nflip >= frac_touched * ne / 4:
+                break
+    free = np.flatnonzero(~touched)
+    split = rng.choice(free, size=max(1, int(frac_touched * ne / 6)), replace=False)
+    nx, ny, new_tri = list(x), list(y), []
+    for e in split:
+        a, b, c = (int(v) for v in tri[e])
+        m = len(nx)
+        w = rng.dirichlet([2., 2., 2.])
+        nx.append(w[0] * x[a] + w[1] * x[b] + w[2] * x[c]); ny.append(w[0] * y[a] + w[1] * y[b] + w[2] * y[c])
+        tri[e] = (a, b, m)
+        new_tri += [(b, c, m), (c, a, m)]
+        touched[e] = True
+    tri = np.vstack([tri, np.array(new_tri, np.int32)])
+    xn, yn = np.array(nx), np.array(ny)
+    prev = np.concatenate([np.arange(1, x.size + 1), np.zeros(xn.size - x.size, np.int64)]).astype(np.float64)
+    # renumber the non-geometric vertices and all the triangles
+    perm = np.concatenate([np.arange(n_geom), n_geom + rng.permutation(xn.size - n_geom)])   # new id -> old id
+    inv = np.empty_like(perm); inv[perm] = np.arange(perm.size)
+    xn, yn, prev = xn[perm], yn[perm], prev[perm]
+    tri = inv[tri].astype(np.int32)
+    tri = tri[rng.permutation(tri.shape[0])]
+    return xn, yn, np.ascontiguousarray(tri), prev

@@ -8,6 +8,9 @@
                          points, with and without default value -- pins the regrid interpolation kernel.
   bamg_mesh_to_grid.npz  REAL contrib/bamg InterpFromMeshToGridx (Moorings sampling, gridoutput.cpp:496) on the
                          'small' mesh: nodal + element data, normal and flipped grids, NaN data.
+  bamg_remap.npz         REAL contrib/bamg ConservativeRemappingMeshToMesh (FE.cpp:3108) on four seeded regrid pairs
+                         (adapted / coarser / finer / moved vertices), plus bamg's ElementConnectivity of the old
+                         mesh and the seed triangles InterpFromMeshToMesh2dx returns -- pins the remapping kernel.
   oracle_tiny.npz        oracle (liboracle.so) state on the 'tiny' toy case after 1 sub-step, 1 step
                          and 3 steps (beyond a few steps the algorithm amplifies 1-ulp differences to O(1), see
                          tests/test_oracle_sensitivity.py): a regression net for the oracle itself and size-0 cost
@@ -97,6 +100,37 @@ def make_interp_fixture():
     np.savez_compressed(os.path.join(HERE, "bamg_interp.npz"), **out)
 
 
+def remap_cases():
+    """Seeded (old mesh, new mesh) pairs of the conservative-remapping fixture (shared with tests/test_remap.py):
+    name -> (x_old, y_old, tri_old, x_new, y_new, tri_new, previous_numbering, n_geom, data)."""
+    rng = np.random.default_rng(77)
+    x, y, tri, ng = cases.rect_mesh(24, 1)
+    out = {}
+    xn, yn, trin, prev = cases.adapted_mesh(x, y, tri, ng, 2)
+    data = np.column_stack([rng.random(tri.shape[0]), rng.normal(size=tri.shape[0]) * 1e3, np.ones(tri.shape[0])])
+    out["adapted"] = (x, y, tri, xn, yn, trin, prev, ng, data)                       # what a regrid looks like
+    x2, y2, tri2, _ = cases.rect_mesh(17, 5)
+    out["coarser"] = (x, y, tri, x2, y2, tri2, np.zeros(x2.size), ng, data)          # every triangle through checkTriangle
+    x3, y3, tri3, _ = cases.rect_mesh(41, 6)
+    out["finer"] = (x, y, tri, x3, y3, tri3, np.zeros(x3.size), ng, data)
+    xm, ym = x.copy(), y.copy()
+    xm[ng:] += rng.uniform(-800, 800, x.size - ng); ym[ng:] += rng.uniform(-800, 800, x.size - ng)
+    out["moved"] = (x, y, tri, xm, ym, tri, np.arange(1, x.size + 1, dtype=np.float64), ng, data)
+    return out
+
+
+def make_remap_fixture():
+    out = {}
+    for name, (x, y, tri, xn, yn, trin, prev, ng, data) in remap_cases().items():
+        out[name] = O.bamg_conservative_remap(tri + 1, x, y, trin + 1, xn, yn, prev, ng, data)
+        ec, _ = O.bamg_element_connectivity(tri + 1, x, y)
+        out[name + "_ec"] = ec
+        bx = (((0. + xn[trin[:, 0]]) + xn[trin[:, 1]]) + xn[trin[:, 2]]) / 3.
+        by = (((0. + yn[trin[:, 0]]) + yn[trin[:, 1]]) + yn[trin[:, 2]]) / 3.
+        out[name + "_seed"] = np.round(O.bamg_interp_mesh_to_mesh(tri + 1, x, y, np.arange(tri.shape[0], dtype=np.float64), bx, by, True, -1)[:, 0]).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "bamg_remap.npz"), **out)
+
+
 def main():
     lm = M.localize(cases.global_mesh("tiny"), 1)[0]
     assert O.bamg_shim() is not None, "build oracle/_ref first (make -C oracle ref)"
@@ -106,6 +140,7 @@ def main():
 
     make_interp_fixture()
     make_grid_fixture()
+    make_remap_fixture()
 
     out = {}
     for tag, nsteps, over in (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step3", 3, {})):

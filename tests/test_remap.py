@@ -1,0 +1,166 @@
+"""Conservative remapping of the element variables at regrid: the HIP kernel behind
+nxs_interp_conservative_remap against the REAL contrib/bamg ConservativeRemappingMeshToMesh (FE.cpp:3108;
+contrib/bamg/src/ConservativeRemapping.cpp:176-328) -- live when oracle/_ref is present, and through the
+committed fixture tests/golden/bamg_remap.npz generated with it.
+
+Bar: bit-exact.  The per-triangle functions of the kernel (nextsim_amd/csrc/nxs_remap_core.inl) are also built
+for the host (oracle/libremap_host.so, test-only) so that the CPU suite checks the very code the GPU runs."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import cases
+from nextsim_amd import _abi, dynamics
+from oracle import pyoracle as O
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+import make_golden  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "bamg_remap.npz")
+NAMES = ("adapted", "coarser", "finer", "moved")
+IP = C.POINTER(C.c_int)
+
+
+def _same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def _tables(tri, n):
+    idx = np.ascontiguousarray((tri + 1).ravel(), np.int32)
+    nec, _ = dynamics.mesh_connectivity(idx, n)
+    ec = dynamics.mesh_element_connectivity(idx, n)
+    return nec, ec
+
+
+def _host_remap(case, seed):
+    """The kernel's per-triangle functions, host build."""
+    x, y, tri, xn, yn, trin, prev, ng, data = case
+    L = C.CDLL(os.path.join(os.path.dirname(O.__file__), "libremap_host.so"))
+    D = _abi.c_double_p
+    L.remap_host.argtypes = [IP, D, D, C.c_int, C.c_int, IP, C.c_int, IP, IP, D, D, C.c_int, D, C.c_int, IP, D, C.c_int, D, IP]
+    nec, ec = _tables(tri, x.size)
+    neci = np.ascontiguousarray(np.where(np.isnan(nec), 0, nec).astype(np.int32) - 1)
+    eci = np.ascontiguousarray(np.where(np.isnan(ec), 0, ec).astype(np.int32) - 1)
+    t_old = np.ascontiguousarray(tri, np.int32); t_new = np.ascontiguousarray(trin, np.int32)
+    seed = np.ascontiguousarray(seed, np.int32)
+    prev = np.ascontiguousarray(prev, np.float64)
+    data = np.ascontiguousarray(data)
+    out = np.empty((t_new.shape[0], data.shape[1])); visits = np.zeros(t_new.shape[0], np.int32)
+    i = lambda a: a.ctypes.data_as(IP)  # noqa: E731
+    nf = L.remap_host(i(t_old), _abi.dptr(x), _abi.dptr(y), x.size, t_old.shape[0], i(neci), neci.shape[1], i(eci), i(t_new),
+                      _abi.dptr(xn), _abi.dptr(yn), t_new.shape[0], _abi.dptr(prev), ng, i(seed), _abi.dptr(data), data.shape[1],
+                      _abi.dptr(out), i(visits))
+    return out, visits, nf
+
+
+@pytest.mark.skipif(O.bamg_shim() is None, reason="oracle/_ref (real contrib/bamg) not built here")
+def test_real_bamg_reproduces_the_committed_fixture():
+    z = np.load(GOLD)
+    for name, (x, y, tri, xn, yn, trin, prev, ng, data) in make_golden.remap_cases().items():
+        assert _same(O.bamg_conservative_remap(tri + 1, x, y, trin + 1, xn, yn, prev, ng, data), z[name]), name
+
+
+def test_fixture_is_sane():
+    """A constant field stays constant wherever the walk covered the whole new triangle; unchanged triangles keep
+    their value to rounding; the area integral is conserved to the reference's own accuracy (its walk stops at
+    the first NaN of an ElementConnectivity row, so coverage next to the boundary can be incomplete)."""
+    z = np.load(GOLD)
+    for name, (x, y, tri, xn, yn, trin, prev, ng, data) in make_golden.remap_cases().items():
+        ref = z[name]
+        assert ref.shape == (trin.shape[0], 3) and not np.isnan(ref).any()
+        dev = np.abs(ref[:, 2] - 1.)
+        assert np.median(dev) < 1e-12 and dev.max() < 0.9 and (dev > 1e-9).mean() < 0.05
+
+        def area(x, y, t):
+            return 0.5 * ((x[t[:, 1]] - x[t[:, 0]]) * (y[t[:, 2]] - y[t[:, 0]]) - (x[t[:, 2]] - x[t[:, 0]]) * (y[t[:, 1]] - y[t[:, 0]]))
+        a_old, a_new = area(x, y, tri), area(xn, yn, trin)
+        if name != "moved":
+            assert abs((ref[:, 0] * a_new).sum() / (data[:, 0] * a_old).sum() - 1.) < 2e-2
+
+
+def test_element_connectivity_equals_bamg():
+    z = np.load(GOLD)
+    x, y, tri = make_golden.remap_cases()["adapted"][:3]
+    _, ec = _tables(tri, x.size)
+    assert _same(ec, z["adapted_ec"])
+    assert np.isnan(ec).any() and np.isnan(ec[:, 0]).any()   # boundary triangles exist, NaN also in column 0
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_kernel_functions_on_the_host_match_real_bamg_bit_for_bit(name):
+    z = np.load(GOLD)
+    case = make_golden.remap_cases()[name]
+    out, visits, nf = _host_remap(case, z[name + "_seed"])
+    assert nf == 0
+    assert _same(out, z[name])
+    if name in ("adapted", "moved"):
+        assert (visits == 1).mean() > 0.8          # the PreviousNumbering shortcut carries a real regrid
+    if name in ("coarser", "finer"):
+        assert visits.max() >= 8                   # the recursion replay is exercised
+
+
+def test_capacity_overflow_is_reported_not_hidden():
+    """One huge new triangle over a fine old mesh overlaps more old triangles than the kernel's stack holds."""
+    x, y, tri, ng = cases.rect_mesh(24, 1)
+    xn = np.array([x.min(), x.max(), x.max(), x.min()]); yn = np.array([y.min(), y.min(), y.max(), y.max()])
+    trin = np.array([[0, 1, 2], [0, 2, 3]], np.int32)
+    data = np.ones((tri.shape[0], 1))
+    bx = xn[trin].sum(1) / 3; by = yn[trin].sum(1) / 3
+    # seeds by brute force (no bamg needed)
+    seed = []
+    for px, py in zip(bx, by):
+        a = (x[tri[:, 1]] - x[tri[:, 0]]) * (py - y[tri[:, 0]]) - (y[tri[:, 1]] - y[tri[:, 0]]) * (px - x[tri[:, 0]])
+        b = (x[tri[:, 2]] - x[tri[:, 1]]) * (py - y[tri[:, 1]]) - (y[tri[:, 2]] - y[tri[:, 1]]) * (px - x[tri[:, 1]])
+        c = (x[tri[:, 0]] - x[tri[:, 2]]) * (py - y[tri[:, 2]]) - (y[tri[:, 0]] - y[tri[:, 2]]) * (px - x[tri[:, 2]])
+        seed.append(int(np.flatnonzero((a >= 0) & (b >= 0) & (c >= 0))[0]))
+    out, visits, nf = _host_remap((x, y, tri, xn, yn, trin, np.zeros(4), 0, data), np.array(seed))
+    assert nf == 2 and np.isnan(out).all() and (visits < 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_gpu_remapping_matches_real_bamg_fixture_bit_for_bit(name):
+    from nextsim_amd.interp import ConservativeRemappingMeshToMesh
+    z = np.load(GOLD)
+    x, y, tri, xn, yn, trin, prev, ng, data = make_golden.remap_cases()[name]
+    out, info = ConservativeRemappingMeshToMesh(data, tri + 1, x, y, trin + 1, xn, yn, prev, ng, return_info=True)
+    assert info["num_failed"] == 0
+    assert _same(out, z[name])
+    # same answer with the caller's own bamg tables
+    nec, ec = _tables(tri, x.size)
+    out2 = ConservativeRemappingMeshToMesh(data, tri + 1, x, y, trin + 1, xn, yn, prev, ng, nec_old=nec, ec_old=ec)
+    assert _same(out2, out)
+
+
+@pytest.mark.gpu
+def test_gpu_remapping_reports_what_it_cannot_do():
+    from nextsim_amd.interp import ConservativeRemappingMeshToMesh
+    x, y, tri, ng = cases.rect_mesh(24, 1)
+    xn = np.array([x.min(), x.max(), x.max(), x.min(), x.max() + 5e4]); yn = np.array([y.min(), y.min(), y.max(), y.max(), y.max() + 5e4])
+    trin = np.array([[0, 1, 2], [0, 2, 3], [1, 4, 2]], np.int32)   # two too large, one with its barycentre outside
+    out, info = ConservativeRemappingMeshToMesh(np.ones((tri.shape[0], 2)), tri + 1, x, y, trin + 1, xn, yn, None, 0, return_info=True)
+    assert info["num_failed"] == 3 and np.isnan(out).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(O.bamg_shim() is None, reason="oracle/_ref (real contrib/bamg) not present on this box")
+def test_gpu_remapping_matches_live_bamg_on_a_larger_regrid():
+    from nextsim_amd.interp import ConservativeRemappingMeshToMesh
+    x, y, tri, ng = cases.rect_mesh(120, 7)
+    rng = np.random.default_rng(5)
+    data = rng.random((tri.shape[0], 30))                      # ~30 element variables at a regrid
+    xn, yn, trin, prev = cases.adapted_mesh(x, y, tri, ng, 9, frac_touched=0.1)
+    ref = O.bamg_conservative_remap(tri + 1, x, y, trin + 1, xn, yn, prev, ng, data)
+    out, info = ConservativeRemappingMeshToMesh(data, tri + 1, x, y, trin + 1, xn, yn, prev, ng, return_info=True)
+    assert info["num_failed"] == 0 and _same(out, ref)
+    x2, y2, tri2, _ = cases.rect_mesh(100, 8)
+    ref = O.bamg_conservative_remap(tri + 1, x, y, tri2 + 1, x2, y2, np.zeros(x2.size), ng, data)
+    out, info = ConservativeRemappingMeshToMesh(data, tri + 1, x, y, tri2 + 1, x2, y2, np.zeros(x2.size), ng, return_info=True)
+    assert info["num_failed"] == 0
+    same = np.all(out == ref, axis=1)
+    # a barycentre that falls exactly on an old edge in bamg's integer plane may be seeded in the other triangle
+    # (walk-dependent tie): same set of contributions, another summation order
+    assert same.mean() > 0.999 and np.abs(out - ref).max() < 1e-12
