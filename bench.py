@@ -79,6 +79,9 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn):
         transport = setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn)
     fe.put_state(f)
     fe.set_forcing(f)
+    if transport.startswith("device-direct"):
+        transport += choose_halo_kernels(fe, f, rank, world, dist, torch)
+        fe.put_state(f)
 
     def barrier():
         if world > 1:
@@ -102,6 +105,53 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn):
     crash = fe.checkFieldsFast()
     fe.close()
     return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash, transport=transport)
+
+
+def choose_halo_kernels(fe, f, rank, world, dist, torch):
+    """The device-direct exchange can run inside the fused sub-step kernel (one launch per sub-step) or as separate
+    push / pull kernels.  The in-kernel variant is kept only if, on this machine and this partition, one full step
+    gives the bits of the separate kernels on every rank (NXS_HALO_FUSED=0/1 forces a choice)."""
+    import numpy as np
+    from nextsim_amd import dynamics
+    force = os.environ.get("NXS_HALO_FUSED")
+    if force is not None:
+        fe.set_option("halo_fused", int(force))
+        return " + exchange inside the sub-step kernel (forced)" if int(force) else ", separate push/pull kernels (forced)"
+    ok, states, secs = 1.0, [], [0.0, 0.0]
+    for i, mode in enumerate((1, 0)):
+        try:
+            fe.set_option("halo_fused", mode)
+            fe.put_state(f)
+            fe.step(); fe.synchronize()           # (graph capture happens here)
+            states.append(fe.get_state())
+            dist.barrier()
+            t0 = time.perf_counter()
+            fe.step(); fe.step(); fe.synchronize()
+            secs[i] = time.perf_counter() - t0
+        except dynamics.NxsError as e:
+            print(f"[bench rank {rank}] halo_fused={mode}: {e}", file=sys.stderr, flush=True)
+            ok = 0.0
+            break
+    if ok and not all(np.array_equal(states[0][k], states[1][k]) for k in states[0]):
+        ok = 0.0
+    t = torch.tensor([ok], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if float(t[0]) == 1.0:
+        tt = torch.tensor(secs, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        inside = float(tt[0]) <= float(tt[1])
+        fe.set_option("halo_fused", 1 if inside else 0)
+        note = f"both variants bit-identical; {float(tt[0])*500:.2f} vs {float(tt[1])*500:.2f} ms/step in-kernel vs separate"
+        return (" + exchange inside the sub-step kernel (" if inside else ", separate push/pull kernels (") + note + ")"
+    # a rank that timed out is out of step with its neighbours: fresh mailboxes, then the separate kernels
+
+    def all_gather(obj):
+        out = [None] * world
+        dist.all_gather_object(out, obj)
+        return out
+    fe.ipc_setup(all_gather)
+    fe.set_option("halo_fused", 0)
+    return ", separate push/pull kernels (in-kernel exchange failed its check)"
 
 
 def setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn):

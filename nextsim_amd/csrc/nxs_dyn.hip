@@ -529,6 +529,64 @@ __global__ void __launch_bounds__(BLOCK) k_move(DevMesh m, DevState s, int first
     s.UT[n + Nn] += dt * v;
 }
 
+struct IpcDev {
+    unsigned long long *seq_push;   // exchanges pushed so far (this rank)
+    unsigned long long *seq_pull;   // exchanges pulled so far
+    unsigned int *done_push, *done_pull;  // block-completion counters
+    int *error;                     // != 0 after a timeout / self-test mismatch
+    double *mailbox;                // my mailbox: [2][2*tr] doubles
+    unsigned long long *flags;      // my flags: [nr], written by the neighbours
+    int tr, ns, nr;
+    double *const *peer_seg;        // [ns] neighbour k's mailbox address of MY segment (parity 0)
+    const long long *peer_parity_stride;  // [ns] doubles between that neighbour's two buffers (2*tr_k)
+    unsigned long long *const *peer_flag; // [ns] address of my flag slot in neighbour k's mailbox
+};
+
+__device__ __forceinline__ void sys_store(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ double sys_load(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
+// Halo exchange fused into the sub-step kernel (device-direct transport only).  Exchange x = the x-th
+// updateGhosts since the mailboxes were connected; *ipc.seq_push counts the exchanges this rank has
+// published, a neighbour's flag in my mailbox the exchanges IT has published.
+//   kernel of sub-step s (x = *seq_push on entry):
+//     boundary patches (own nodes that are sent, or ghost nodes among the staged ones) first wait until every
+//     neighbour's flag has reached x, i.e. exchange x-1 -- the velocities this sub-step starts from -- has
+//     landed, stage their ghost nodes straight from the mailbox (parity (x-1)&1) and copy them through to the
+//     VT buffer (the deferred mesh move and the end of the step read them there);
+//     in the node phase every sent node is stored into the neighbours' mailboxes (parity x&1); the last
+//     boundary patch to finish raises my flag at the neighbours to x+1; the last patch of the grid advances
+//     *seq_push.  Boundary patches come first in the grid, so the data travels while the interior is computed.
+//   Why two mailbox halves suffice: a patch that stages ghosts also has sent nodes (if own node n shares an
+//   element with a ghost owned by B, then n is a ghost of B), so it is a boundary patch, and my flag x+1 is
+//   raised only after all of them have finished reading exchange x-1; a neighbour overwrites that half
+//   (exchange x+1) only after it has seen my flag x+1.
+struct HaloFused {
+    IpcDev ipc;
+    const unsigned char *pflag;        // [nP] 1 = boundary patch
+    const int *pmap;                   // [nP] grid position -> patch (boundary patches first)
+    int n_boundary;
+    const int *send_ptr;               // [No+1] CSR over own nodes
+    const int *send_k, *send_pos;      // neighbour (index into send_procs) and position inside its segment
+    const int *send_off;               // [ns+1] segment offsets (segment length = v offset)
+    const int *ghost_off, *ghost_srl;  // [Nn-No] u offset inside a mailbox half, and the v offset from it
+    int No;
+    int from_mailbox;                  // 0: first sub-step of a step, the ghosts are in the VT buffer
+    unsigned int *done_all;
+};
+
+#ifndef NXS_PF
+#define NXS_PF 1
+#endif
+#ifndef NXS_T256_MAXP
+#define NXS_T256_MAXP 128
+#endif
+
 // streaming accesses that should not displace the reusable arrays from L2 / Infinity Cache
 template <bool NT> __device__ __forceinline__ double ldg(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
 template <bool NT> __device__ __forceinline__ void stg(double *p, double v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
@@ -540,9 +598,9 @@ template <bool NT> __device__ __forceinline__ void stg(double *p, double v) { if
 // lets each own node subtract the forces of its fan (ascending element order, as the serial scatter)
 // and solve.  sigma, damage and VT are ping-pong buffered: a neighbouring patch may still be reading
 // the old values of a shared element / node while this one writes the new ones.
-template <int T, bool POW4, int NTM>
+template <int T, bool POW4, int NTM, bool HALO>
 __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p,
-                                                     PingPong b, double move_dt) {
+                                                     PingPong b, double move_dt, HaloFused hf) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lu = lds, *lv = lds + pp.Mmax, *lx = lds + 2 * (size_t)pp.Mmax, *ly = lds + 3 * (size_t)pp.Mmax,
            *lF = lds + 4 * (size_t)pp.Mmax;  // lF[6][Emax]
@@ -552,6 +610,13 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     {
         const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blk & 7;
         blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blk >> 3);
+    }
+    unsigned long long xseq = 0ull;
+    bool boundary = false;
+    if (HALO) {
+        blk = hf.pmap[blk];
+        boundary = hf.pflag[blk] != 0;
+        xseq = *hf.ipc.seq_push;
     }
     const int t = threadIdx.x, Nn = m.Nn, Emax = pp.Emax;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
@@ -568,19 +633,53 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     int eraw = 0;
     ushort4 tr = make_ushort4(0, 0, 0, 0);
     if (t < nE) { eraw = pe[t]; tr = pt[t]; }
+#if NXS_PF >= 1
+    // element rounds 1 and 2 (a patch holds ~2.2 elements per own node): their indices are fetched now, so
+    // that a later round starts with its data loads instead of an index hop
+    int eraw1 = 0, eraw2 = 0;
+    ushort4 tr1 = tr, tr2 = tr;
+    if (t + T < nE) { eraw1 = pe[t + T]; tr1 = pt[t + T]; }
+    if (t + 2 * T < nE) { eraw2 = pe[t + 2 * T]; tr2 = pt[t + 2 * T]; }
+#endif
 
-    if (t < nM) { lu[t] = b.VTc[my_node]; lv[t] = b.VTc[my_node + Nn]; lx[t] = w.xs[my_node]; ly[t] = w.ys[my_node]; }
-    for (int i = t + T; i < nM; i += T) {
-        const int g = pn[i];
-        lu[i] = b.VTc[g];
-        lv[i] = b.VTc[g + Nn];
+    const bool mailbox_ghosts = HALO && boundary && hf.from_mailbox;
+    if (mailbox_ghosts) {  // exchange xseq-1 must have landed before a ghost node is staged
+        if (t == 0) {
+            const long long t0 = wall_clock64();  // 100 MHz
+            bool ok = true;
+            for (int k = 0; k < hf.ipc.nr && ok; ++k)
+                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 3); break; }  // 10 s
+                }
+            __threadfence_system();
+        }
+        __syncthreads();
+    }
+    auto stage = [&](int i, int g) {
+        if (mailbox_ghosts && g >= hf.No) {
+            const double *src = hf.ipc.mailbox + ((xseq - 1ull) & 1ull) * 2ull * (unsigned long long)hf.ipc.tr + hf.ghost_off[g - hf.No];
+            const double u = sys_load(src), v = sys_load(src + hf.ghost_srl[g - hf.No]);
+            lu[i] = u; lv[i] = v;
+            const_cast<double *>(b.VTc)[g] = u;  // every patch that stages g writes the same two values
+            const_cast<double *>(b.VTc)[g + Nn] = v;
+        } else {
+            lu[i] = b.VTc[g];
+            lv[i] = b.VTc[g + Nn];
+        }
         lx[i] = w.xs[g];
         ly[i] = w.ys[g];
-    }
+    };
+    if (t < nM) stage(t, my_node);
+    for (int i = t + T; i < nM; i += T) stage(i, pn[i]);
 
     for (int base = 0; base < nE; base += T) {
         const int l = base + t;
+#if NXS_PF >= 1
+        if (base >= 3 * T && l < nE) { eraw = pe[l]; tr = pt[l]; }  // very large patches: rounds beyond the prefetched ones
+#else
         if (base > 0 && l < nE) { eraw = pe[l]; tr = pt[l]; }  // patches larger than the block: extra rounds
+#endif
         const bool active = l < nE;
         const bool writer = eraw >= 0;
         const int e = writer ? eraw : ~eraw;
@@ -589,10 +688,10 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         if (active) {
             skip = w.eskip[e];
             sig[0] = ldg<NT_S>(b.s0c + e); sig[1] = ldg<NT_S>(b.s1c + e); sig[2] = ldg<NT_S>(b.s2c + e);
+            if (bbm) damage = ldg<NT_S>(b.dc + e);
             c_expC = ldg<NT_C>(w.expC + e);
             volume = ldg<NT_C>(w.volume + e);
             if (bbm) {
-                damage = ldg<NT_S>(b.dc + e);
                 c_pmax = ldg<NT_C>(w.pmax + e); c_heal = ldg<NT_C>(w.heal + e); c_dxs = ldg<NT_C>(w.dxs + e); c_coh = ldg<NT_C>(s.cohesion + e);
             }
         }
@@ -628,6 +727,9 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
 #pragma unroll
             for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + l] = F[k];
         }
+#if NXS_PF >= 1
+        eraw = eraw1; tr = tr1; eraw1 = eraw2; tr1 = tr2;
+#endif
     }
 
     // node phase: issue this node's loads before barrier 2 so that they overlap the wait
@@ -639,6 +741,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         unsigned char nf = 0;
         double node_mass = 0., gx = 0., gy = 0., rlm = 0., cbu = 0., fcor = 0., lat = 0., tax = 0., tay = 0., ou = 0., ov = 0.,
                vtmu = 0., vtmv = 0., umu = 0., umv = 0., utu = 0., utv = 0.;
+        int sq0 = 0, sq1 = 0;
         if (active) {
             nf = m.nflags[n];
             node_mass = w.node_mass[n];
@@ -648,6 +751,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             ou = s.ocean[n]; ov = s.ocean[n + Nn];
             if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
             if (move_dt != 0.) { umu = ldg<NT_U>(s.UM + n); umv = ldg<NT_U>(s.UM + n + Nn); utu = ldg<NT_U>(s.UT + n); utv = ldg<NT_U>(s.UT + n + Nn); }
+            if (HALO && boundary) { sq0 = hf.send_ptr[n]; sq1 = hf.send_ptr[n + 1]; }
         }
         if (base == 0) __syncthreads();  // corner forces visible
         if (!active) continue;
@@ -665,6 +769,14 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         }
         b.VTn[n] = uice;
         b.VTn[n + Nn] = vice;
+        if (HALO) {  // updateGhosts, sending side: straight into the neighbours' mailboxes
+            for (int q = sq0; q < sq1; ++q) {
+                const int k = hf.send_k[q];
+                double *dst = hf.ipc.peer_seg[k] + (xseq & 1ull) * hf.ipc.peer_parity_stride[k] + hf.send_pos[q];
+                sys_store(dst, uice);
+                sys_store(dst + (hf.send_off[k + 1] - hf.send_off[k]), vice);
+            }
+        }
         if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
             if (!(nf & NF_NEUMANN)) {
                 stg<NT_U>(s.UM + n, umu + move_dt * uice);
@@ -672,6 +784,22 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             }
             stg<NT_U>(s.UT + n, utu + move_dt * uice);
             stg<NT_U>(s.UT + n + Nn, utv + move_dt * vice);
+        }
+    }
+    if (HALO) {
+        if (boundary) {  // publish: the last boundary patch to finish raises my flag at every neighbour
+            __threadfence_system();
+            __syncthreads();
+            if (t == 0 && atomicAdd(hf.ipc.done_push, 1u) == (unsigned)hf.n_boundary - 1u) {
+                __threadfence_system();
+                for (int k = 0; k < hf.ipc.ns; ++k)
+                    __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                *hf.ipc.done_push = 0u;
+            }
+        }
+        if (t == 0 && atomicAdd(hf.done_all, 1u) == gridDim.x - 1u) {
+            *hf.done_all = 0u;
+            *hf.ipc.seq_push = xseq + 1ull;
         }
     }
 }
@@ -761,28 +889,6 @@ __global__ void __launch_bounds__(BLOCK) k_halo_unpack(double *__restrict__ vec,
 // Sequence numbers live in device memory, so the kernels replay unchanged from a hipGraph.  Two mailbox
 // buffers suffice: a neighbour cannot start exchange x+2 before it has received my exchange x+1, which I
 // send only after my pull of exchange x.  Every spin is bounded; a timeout raises ipc->error.
-struct IpcDev {
-    unsigned long long *seq_push;   // exchanges pushed so far (this rank)
-    unsigned long long *seq_pull;   // exchanges pulled so far
-    unsigned int *done_push, *done_pull;  // block-completion counters
-    int *error;                     // != 0 after a timeout / self-test mismatch
-    double *mailbox;                // my mailbox: [2][2*tr] doubles
-    unsigned long long *flags;      // my flags: [nr], written by the neighbours
-    int tr, ns, nr;
-    double *const *peer_seg;        // [ns] neighbour k's mailbox address of MY segment (parity 0)
-    const long long *peer_parity_stride;  // [ns] doubles between that neighbour's two buffers (2*tr_k)
-    unsigned long long *const *peer_flag; // [ns] address of my flag slot in neighbour k's mailbox
-};
-
-__device__ __forceinline__ void sys_store(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ double sys_load(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_SYSTEM));
-}
-
 // selftest != 0: the payload is a code of (rank, entry, sequence) instead of vec
 __global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ vec, int Nn, int total, const int *__restrict__ index,
                                                      const int *__restrict__ seg_of, const int *__restrict__ offsets, IpcDev ipc,
@@ -825,8 +931,10 @@ __global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ 
 __global__ void __launch_bounds__(BLOCK) k_halo_pull(double *__restrict__ vec, DevMesh m, DevState s, int total,
                                                      const int *__restrict__ index, const int *__restrict__ seg_of,
                                                      const int *__restrict__ offsets, IpcDev ipc, double move_dt, int selftest,
-                                                     const int *__restrict__ recv_procs) {
-    const unsigned long long seq = *ipc.seq_pull;
+                                                     const int *__restrict__ recv_procs, int latest_pushed) {
+    // latest_pushed: pull the exchange this rank published last (the fused kernel pushes by itself and keeps no
+    // pull counter); afterwards both counters agree again
+    const unsigned long long seq = latest_pushed ? *ipc.seq_push - 1ull : *ipc.seq_pull;
     __shared__ int ok;
     if (threadIdx.x == 0) {
         ok = 1;
@@ -1191,6 +1299,14 @@ struct nxs_dyn_handle {
     std::vector<void *> ipc_peer_base;     // opened peer mailboxes (to close)
     std::vector<void *> ipc_allocs;
     int *d_recv_procs = nullptr;
+    // halo exchange fused into the sub-step kernel (device-direct transport + fused path)
+    int halo_fused = 1;                    // option "halo_fused"
+    bool hf_ready = false;
+    HaloFused hf{};
+    std::vector<void *> hf_allocs;
+    std::vector<int> h_send_index, h_recv_index;   // host copies of the halo lists
+    std::vector<int> hp_pnodes, hp_own_cnt, hp_node_cnt;  // host copies of the patch node lists
+    int hp_Mmax = 0;
     nxs_dyn_halo_fn halo_fn = nullptr;  // host-staged exchange through the caller's communicator
     void *halo_ctx = nullptr;
     double *h_send = nullptr, *h_recv = nullptr;  // pinned staging buffers
@@ -1519,6 +1635,24 @@ int upload_patches(nxs_dyn_handle *h) {
         if (fits || P <= 64) break;
         P = automatic ? P - 32 : std::max(64, P * 3 / 4);
     }
+    if (automatic && hp.nP > 512 && P > 64) {
+        // Whole rounds: two workgroups fit a CU, so the grid runs in rounds of 2*CUs patches and a last round
+        // that is partly empty costs as much as a full one.  Shrink P just enough to fill the last round
+        // (2 km mesh: 1427 patches of 512 = 2.79 rounds -> 1535 patches of 476 = 3.00 rounds, -1.2 % time).
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        const int slots = 2 * std::max(cus, 1);
+        const int rounds = (hp.nP + slots - 1) / slots;
+        int Pb = (m.No + rounds * slots - 1) / (rounds * slots);
+        Pb = (Pb + 3) & ~3;
+        if (Pb < P && Pb >= P * 17 / 20) {
+            HostPatches hb;
+            if (build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, Pb, hb) && hb.nP <= rounds * slots) {
+                const size_t lds = (4 * (size_t)hb.Mmax + 6 * (size_t)hb.Emax) * sizeof(double);
+                if (lds <= 80 * 1024) { hp = std::move(hb); P = Pb; h->fused_lds = lds; }
+            }
+        }
+    }
     if (h->fused_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "patches need %zu B of LDS", h->fused_lds);
     if (getenv("NXS_DEBUG_PATCHES")) {
         long long se = 0, sm = 0;
@@ -1526,6 +1660,8 @@ int upload_patches(nxs_dyn_handle *h) {
         fprintf(stderr, "[nxs] patches: P=%d nP=%d Pmax=%d Emax=%d Mmax=%d Wp=%d avgE=%.1f avgM=%.1f lds=%zu B elems x%.3f\n", P, hp.nP, hp.Pmax,
                 hp.Emax, hp.Mmax, hp.Wp, (double)se / hp.nP, (double)sm / hp.nP, h->fused_lds, (double)se / std::max(m.Ne, 1));
     }
+    h->hp_pnodes = hp.pnodes; h->hp_own_cnt = hp.own_cnt; h->hp_node_cnt = hp.node_cnt; h->hp_Mmax = hp.Mmax;
+    h->hf_ready = false;
     DevPatches &d = h->dpch;
     d.nP = hp.nP; d.Pmax = hp.Pmax; d.Emax = hp.Emax; d.Mmax = hp.Mmax; d.Wp = hp.Wp;
     int rc;
@@ -1628,6 +1764,8 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
     free_pool(h->ring_allocs);
+    free_pool(h->hf_allocs);
+    h->hf_ready = false;
     if (h->h_send) (void)hipHostFree(h->h_send);
     if (h->h_recv) (void)hipHostFree(h->h_recv);
     if (h->d_partials) (void)hipFree(h->d_partials);
@@ -1659,6 +1797,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     }
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "fused")) { h->fused = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "halo_fused")) { h->halo_fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
         if (value != 0 && (value < 64 || value > 1024)) return fail(h, NXS_ERR_INVALID, "patch_nodes must be 0 (auto) or in [64,1024]");
         h->patch_nodes = (int)value;
@@ -1702,6 +1841,8 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
     free_pool(h->ring_allocs);
+    free_pool(h->hf_allocs);
+    h->hf_ready = false;
     h->ring = VTRing{};
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
     h->rank = 0; h->nranks = 1;
@@ -1856,6 +1997,8 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
     h->recv_offsets.assign(halo->recv_offsets, halo->recv_offsets + nr + 1);
     const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
     std::vector<int> sidx(halo->send_index, halo->send_index + ts), ridx(halo->recv_index, halo->recv_index + tr);
+    h->h_send_index = sidx; h->h_recv_index = ridx;
+    h->hf_ready = false;
     std::vector<int> sseg(ts), rseg(tr);
     for (int k = 0; k < ns; ++k) {
         if (h->send_procs[k] < 0 || h->send_procs[k] >= halo->nranks || h->send_procs[k] == halo->rank) return fail(h, NXS_ERR_INVALID, "send_procs[%d] invalid", k);
@@ -2028,7 +2171,7 @@ int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors) {
         hipLaunchKernelGGL(k_halo_push, dim3(nblocks(ts)), dim3(BLOCK), 0, h->stream, (const double *)nullptr, h->dm.Nn, ts,
                            h->d_send_index, h->d_send_seg, h->d_send_off, h->ipc, h->rank, 1);
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, (double *)nullptr, h->dm, h->ds, tr,
-                           h->d_recv_index, h->d_recv_seg, h->d_recv_off, h->ipc, 0., 1, h->d_recv_procs);
+                           h->d_recv_index, h->d_recv_seg, h->d_recv_off, h->ipc, 0., 1, h->d_recv_procs, 0);
     }
     int err = 0;
     HIPCHK(h, hipMemcpyAsync(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
@@ -2157,7 +2300,7 @@ int halo_exchange(nxs_dyn_handle *h, double *vec, double move_dt) {
         hipLaunchKernelGGL(k_halo_push, dim3(nblocks(ts)), dim3(BLOCK), 0, h->stream, (const double *)vec, h->dm.Nn, ts,
                            h->d_send_index, h->d_send_seg, h->d_send_off, h->ipc, h->rank, 0);
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,
-                           h->d_recv_seg, h->d_recv_off, h->ipc, move_dt, 0, h->d_recv_procs);
+                           h->d_recv_seg, h->d_recv_off, h->ipc, move_dt, 0, h->d_recv_procs, 0);
         return NXS_OK;
     }
     if (!h->comm && !h->halo_fn) return fail(h, NXS_ERR_STATE, "halo exchange needs nxs_dyn_comm_init, nxs_dyn_ipc_connect or nxs_dyn_set_halo_exchange_fn");
@@ -2206,14 +2349,26 @@ PingPong pingpong(const nxs_dyn_handle *h, int parity) {
 
 // sub-step `sidx` of the fused path: sigma/damage ping-pong by parity; velocities move through the ring
 // (ring of 2 == ping-pong between VT and VT2 when the deferred mesh move is off)
-void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt) {
+// halo != 0: the sub-step also performs updateGhosts (HaloFused); from_mailbox = ghosts come from exchange x-1
+void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int from_mailbox = 0) {
     PingPong b = pingpong(h, sidx & 1);
     const int R = h->ring.R;
     b.VTc = h->ring.slot[sidx % R];
     b.VTn = h->ring.slot[(sidx + 1) % R];
     const dim3 grid(h->dpch.nP);
-    const bool big = h->dpch.Pmax > 128 || h->dpch.Emax > 256, pow4 = h->dp.ers_int == 4;
-#define FUSED(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt)
+    const bool big = h->dpch.Pmax > NXS_T256_MAXP || h->dpch.Emax > 3 * 256, pow4 = h->dp.ers_int == 4;
+    if (halo) {
+        HaloFused hf = h->hf;
+        hf.ipc = h->ipc;
+        hf.from_mailbox = from_mailbox;
+#define FUSED_H(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, true>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, hf)
+        if (big) { if (pow4) { if (h->nt_mask) FUSED_H(512, true, 3); else FUSED_H(512, true, 0); } else { FUSED_H(512, false, 0); } }
+        else { if (pow4) { if (h->nt_mask) FUSED_H(256, true, 3); else FUSED_H(256, true, 0); } else { FUSED_H(256, false, 0); } }
+#undef FUSED_H
+        return;
+    }
+    const HaloFused none{};
+#define FUSED(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, false>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, none)
 #define FUSED_NT(TT, PP) switch (h->nt_mask) { case 0: FUSED(TT, PP, 0); break; case 1: FUSED(TT, PP, 1); break; case 3: FUSED(TT, PP, 3); break; case 4: FUSED(TT, PP, 4); break; case 5: FUSED(TT, PP, 5); break; default: FUSED(TT, PP, 7); break; }
     if (big) { if (pow4) { FUSED_NT(512, true); } else { FUSED(512, false, 0); } }
     else { if (pow4) { FUSED_NT(256, true); } else { FUSED(256, false, 0); } }
@@ -2238,6 +2393,73 @@ int setup_ring(nxs_dyn_handle *h, int K) {
     return NXS_OK;
 }
 
+// tables of the halo exchange fused into the sub-step kernel (see HaloFused)
+int build_halo_fused(nxs_dyn_handle *h) {
+    free_pool(h->hf_allocs);
+    h->hf = HaloFused{};
+    h->hf_ready = false;
+    const int Nn = h->dm.Nn, No = h->dm.No, nP = h->dpch.nP;
+    const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
+    if ((int)h->hp_own_cnt.size() != nP || (int)h->h_recv_index.size() != Nn - No) return fail(h, NXS_ERR_STATE, "fused halo tables: patches / halo lists missing");
+    // sending side: CSR over own nodes
+    std::vector<int> sptr(No + 1, 0);
+    for (int k = 0; k < ns; ++k)
+        for (int j = h->send_offsets[k]; j < h->send_offsets[k + 1]; ++j) sptr[h->h_send_index[j] + 1]++;
+    for (int n = 0; n < No; ++n) sptr[n + 1] += sptr[n];
+    std::vector<int> sk(std::max(sptr[No], 1)), spos(std::max(sptr[No], 1)), fill(sptr.begin(), sptr.end() - 1);
+    for (int k = 0; k < ns; ++k)
+        for (int j = h->send_offsets[k]; j < h->send_offsets[k + 1]; ++j) {
+            const int q = fill[h->h_send_index[j]]++;
+            sk[q] = k;
+            spos[q] = j - h->send_offsets[k];
+        }
+    // receiving side: where each ghost node sits inside a mailbox half (layout of k_halo_pull)
+    std::vector<int> goff(std::max(Nn - No, 1), 0), gsrl(std::max(Nn - No, 1), 0);
+    for (int k = 0; k < nr; ++k) {
+        const int off = h->recv_offsets[k], srl = h->recv_offsets[k + 1] - off;
+        for (int j = off; j < h->recv_offsets[k + 1]; ++j) {
+            goff[h->h_recv_index[j] - No] = 2 * off + (j - off);
+            gsrl[h->h_recv_index[j] - No] = srl;
+        }
+    }
+    // boundary patches: send something or stage a ghost node; they come first in the grid
+    std::vector<unsigned char> pflag(nP, 0);
+    int nb = 0;
+    for (int q = 0; q < nP; ++q) {
+        const int *nd = h->hp_pnodes.data() + (size_t)q * h->hp_Mmax;
+        bool bnd = false;
+        for (int i = 0; i < h->hp_node_cnt[q] && !bnd; ++i) {
+            const int n = nd[i];
+            bnd = (n >= No) || (i < h->hp_own_cnt[q] && sptr[n + 1] > sptr[n]);
+        }
+        pflag[q] = bnd;
+        nb += bnd;
+    }
+    std::vector<int> pmap;
+    pmap.reserve(nP);
+    for (int q = 0; q < nP; ++q) if (pflag[q]) pmap.push_back(q);
+    for (int q = 0; q < nP; ++q) if (!pflag[q]) pmap.push_back(q);
+    HaloFused &f = h->hf;
+    int rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.pflag, pflag))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.pmap, pmap))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.send_ptr, sptr))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.send_k, sk))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.send_pos, spos))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_off, goff))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_srl, gsrl))) return rc;
+    unsigned int *ctr = nullptr;
+    if ((rc = dev_alloc(h, h->hf_allocs, &ctr, 4))) return rc;
+    HIPCHK(h, hipMemsetAsync(ctr, 0, 4 * sizeof(unsigned int), h->stream));
+    f.done_all = ctr;
+    f.send_off = h->d_send_off;
+    f.n_boundary = nb;
+    f.No = No;
+    h->hf_ready = true;
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d fused halo: %d of %d patches on the boundary, %d sent nodes, %d ghosts\n", h->rank, nb, nP, sptr[No], Nn - No);
+    return NXS_OK;
+}
+
 void launch_substep(nxs_dyn_handle *h, double move_dt) {
     if (h->dp.dynamics_type == NXS_DYN_BBM) {
         if (h->dp.ers_int == 4) LAUNCH(h, k_sigma_bbm<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
@@ -2255,15 +2477,36 @@ int run_substeps(nxs_dyn_handle *h) {
     const int bbm = h->dp.dynamics_type == NXS_DYN_BBM;
     const bool mr = multi_rank(h);
     // deferred mesh move (fused path, not mEVP whose single move comes after the loop)
-    const int want_ring = h->um_ring > 0 ? h->um_ring : (h->dm.Ne >= 400000 ? 16 : 1);
+    const bool device_halo = mr && h->ipc_ready && !h->halo_fn;  // no host work inside the loop: graph-capturable
+    // auto ring: 16 on meshes that stream from HBM; also whenever the halo exchange runs inside the sub-step kernel
+    const int want_ring = h->um_ring > 0 ? h->um_ring : ((h->dm.Ne >= 400000 || (device_halo && h->halo_fused)) ? 16 : 1);
     const int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
     const bool deferred = K > 1;
     if (fused) { int rc = setup_ring(h, K); if (rc) return rc; }
     const int R = h->ring.R;
-    const bool device_halo = mr && h->ipc_ready && !h->halo_fn;  // no host work inside the loop: graph-capturable
+    // the exchange inside the sub-step kernel: needs the deferred mesh move (ghost nodes are moved from the ring)
+    // or no move at all (mEVP)
+    const bool halo_in_kernel = device_halo && fused && h->halo_fused && (deferred || move_dt == 0.);
+    if (halo_in_kernel && !h->hf_ready) { int rc = build_halo_fused(h); if (rc) return rc; }
+    auto pull_latest = [&](double *vec) {
+        const int tr = h->recv_offsets[h->recv_procs.size()];
+        hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,
+                           h->d_recv_seg, h->d_recv_off, h->ipc, 0., 0, h->d_recv_procs, 1);
+    };
     auto loop = [&]() -> int {
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
         for (int s = 0; s < S; ++s) {
+            if (halo_in_kernel) {
+                launch_fused(h, s, 0., 1, s > 0);
+                const bool flush = deferred && (pending + 1 == K || s == S - 1);
+                if (flush || s == S - 1) pull_latest(h->ring.slot[(s + 1) % R]);  // the newest ghosts, for the move / the end of the step
+                if (flush) {
+                    ++pending;
+                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt);
+                    pending = 0;
+                } else if (deferred) ++pending;
+                continue;
+            }
             if (fused) launch_fused(h, s, deferred ? 0. : move_dt); else launch_substep(h, move_dt);
             if (mr) {
                 // owned nodes were written to the buffer the next sub-step reads; ghosts must land there too
@@ -2283,7 +2526,7 @@ int run_substeps(nxs_dyn_handle *h) {
         }
         return NXS_OK;
     };
-    h->timing.substep_launches = S * ((fused ? 1 : 2) + (mr ? 2 : 0));
+    h->timing.substep_launches = halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
     if (!h->use_graph || (mr && !device_halo)) return loop();
     if (!h->graph_valid) {
         release_graph(h);

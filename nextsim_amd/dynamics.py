@@ -17,7 +17,8 @@ import numpy as np
 from . import _abi
 
 _LIB = None
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnxsdyn.so")
+# NXS_DYN_LIBRARY: another build of the same library (kernel experiments); never a different implementation
+_LIB_PATH = os.environ.get("NXS_DYN_LIBRARY") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libnxsdyn.so")
 
 
 class NxsError(RuntimeError):

@@ -27,7 +27,7 @@ try:
         except dynamics.NxsError as e:
             report["comm_error"] = str(e)
             raise
-    elif transport == "ipc":
+    elif transport in ("ipc", "ipc_sep"):
         def all_gather(obj):
             out = [None] * world
             dist.all_gather_object(out, obj)
@@ -54,11 +54,24 @@ try:
             for a, b, t in bufs:
                 recv[a:b] = t.numpy()
         fe.set_halo_exchange(exchange)
+    if transport == "ipc_sep":
+        fe.set_option("halo_fused", 0)      # k_halo_push / k_halo_pull as separate kernels
     fe.put_state(fields[rank]); fe.set_forcing(fields[rank])
     for _ in range(nsteps):
         fe.step()
     fe.synchronize()
     got = fe.get_state()
+    if transport == "ipc":
+        # the exchange inside the sub-step kernel (default) must give the bits of the separate kernels
+        report["launches_fused"] = fe.timing()["substep_launches"]
+        fe.set_option("halo_fused", 0)
+        fe.put_state(fields[rank]); fe.set_forcing(fields[rank])
+        for _ in range(nsteps):
+            fe.step()
+        fe.synchronize()
+        sep = fe.get_state()
+        report["launches_separate"] = fe.timing()["substep_launches"]
+        report["fused_equals_separate"] = bool(all(np.array_equal(got[k], sep[k]) for k in got))
     ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
     for _ in range(nsteps):
         O.multirank_step(ranks)

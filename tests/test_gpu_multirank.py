@@ -48,14 +48,18 @@ def test_partitioned_gpu_run_host_staged_halo_matches_multirank_oracle(world, tm
 
 @pytest.mark.parametrize("world,kind,nsteps", [(2, "small", 2), (4, "small", 1), (3, "toy", 2)])
 def test_partitioned_gpu_run_device_direct_halo_matches_multirank_oracle(world, kind, nsteps, tmp_path):
-    """Ranks share GPU 0; updateGhosts through peer-mapped mailboxes (hipIpc): k_halo_push stores into the
-    neighbours' mailboxes and raises flags, k_halo_pull waits and unpacks; the whole sub-step loop replays
-    from a hipGraph.  On one GPU this validates the protocol (lists, sequence numbers, double buffering,
+    """Ranks share GPU 0; updateGhosts through peer-mapped mailboxes (hipIpc).  Default: the exchange runs INSIDE
+    the fused sub-step kernel (boundary patches wait for the neighbours' flags, stage ghosts from the mailbox, store
+    their sent nodes into the neighbours' mailboxes; one launch per sub-step); it must reproduce, bit for bit, the
+    run with separate kernels (k_halo_push stores and raises flags, k_halo_pull waits and unpacks), and both must
+    match the multi-rank oracle.  The whole sub-step loop replays from a hipGraph.  On one GPU this validates the protocol (lists, sequence numbers, double buffering,
     graph replay); xGMI coherence itself is probed at run time by the transport's self-test."""
     reps = _run(world, kind, nsteps, tmp_path, "ipc")
     for r in reps:
         assert r["ok"], r
         assert r.get("ipc_selftest") is True
+        assert r["fused_equals_separate"] is True, r
+        assert r["launches_fused"] < r["launches_separate"]
         assert r["crash"] == 0
         for k, e in r["errs"].items():
             assert e <= 1e-10, (r["rank"], k, e)
