@@ -1621,36 +1621,47 @@ int upload_patches(nxs_dyn_handle *h) {
     h->fused_lds = 0;
     const DevMesh &m = h->dm;
     const bool automatic = h->patch_nodes <= 0;
-    int P = automatic ? 512 : std::max(64, std::min(h->patch_nodes, 1024));
     HostPatches hp;
-    for (;;) {
-        if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, P, hp))
-            return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
-        const size_t lds = (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax) * sizeof(double);
-        h->fused_lds = lds;
-        // large patches = few recomputed halo elements; the limit is 2 workgroups per CU (160 KiB LDS).
-        // Small meshes: enough patches to give every CU two workgroups.
-        bool fits = lds <= 80 * 1024;
-        if (automatic && fits && hp.nP < 512 && P > 64) fits = false;
-        if (fits || P <= 64) break;
-        P = automatic ? P - 32 : std::max(64, P * 3 / 4);
-    }
-    if (automatic && hp.nP > 512 && P > 64) {
-        // Whole rounds: two workgroups fit a CU, so the grid runs in rounds of 2*CUs patches and a last round
-        // that is partly empty costs as much as a full one.  Shrink P just enough to fill the last round
-        // (2 km mesh: 1427 patches of 512 = 2.79 rounds -> 1535 patches of 476 = 3.00 rounds, -1.2 % time).
+    int P = 0;
+    auto build = [&](int PP) -> bool {
+        if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, PP, hp)) return false;
+        h->fused_lds = (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax) * sizeof(double);
+        return true;
+    };
+    if (!automatic) {
+        P = std::max(64, std::min(h->patch_nodes, 1024));
+        for (;;) {
+            if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
+            if (h->fused_lds <= 80 * 1024 || P <= 64) break;
+            P = std::max(64, P * 3 / 4);
+        }
+    } else {
+        // Large patches recompute few halo elements; the limits are the LDS of two resident workgroups per CU
+        // (160 KiB / 2) and, above all, WHOLE ROUNDS: the grid runs in rounds of `slots` resident workgroups and a
+        // last round that is partly empty costs as much as a full one.  So: the smallest number of rounds k whose
+        // patch size ceil(No / (k*slots)) fits, e.g. 730 k nodes -> 3 rounds of 512 patches of 476 nodes (not 2.79
+        // rounds of 512-node patches); 92 k nodes (one rank of eight) -> one round of 511 patches of 180 nodes.
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-        const int slots = 2 * std::max(cus, 1);
-        const int rounds = (hp.nP + slots - 1) / slots;
-        int Pb = (m.No + rounds * slots - 1) / (rounds * slots);
-        Pb = (Pb + 3) & ~3;
-        if (Pb < P && Pb >= P * 17 / 20) {
-            HostPatches hb;
-            if (build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, Pb, hb) && hb.nP <= rounds * slots) {
-                const size_t lds = (4 * (size_t)hb.Mmax + 6 * (size_t)hb.Emax) * sizeof(double);
-                if (lds <= 80 * 1024) { hp = std::move(hb); P = Pb; h->fused_lds = lds; }
+        cus = std::max(cus, 1);
+        const int slots512 = 2 * cus, slots256 = 4 * cus;  // 16 waves per CU (112 VGPRs): 2 x 512 or 4 x 256 threads
+        bool done = false;
+        for (int k = 1; k <= 64 && !done; ++k) {
+            P = (int)(((long long)m.No + (long long)k * slots512 - 1) / ((long long)k * slots512));
+            P = (P + 3) & ~3;
+            if (P > 512) continue;
+            if (P <= NXS_T256_MAXP) break;  // small mesh: the 256-thread kernel below
+            for (int it = 0; it < 4 && !done; ++it) {  // orphan patches (multi-rank) may add a few workgroups
+                if (it > 0) P += 4;
+                if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
+                if (h->fused_lds > 80 * 1024) break;            // does not fit twice: more rounds of smaller patches
+                done = hp.nP <= k * slots512;
             }
+        }
+        if (!done) {
+            P = (int)(((long long)m.No + slots256 - 1) / slots256);
+            P = std::max(64, std::min((P + 3) & ~3, NXS_T256_MAXP));
+            if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
         }
     }
     if (h->fused_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "patches need %zu B of LDS", h->fused_lds);

@@ -3,11 +3,13 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--mesh", default="2km"); ap.add_argument("--steps", type=int, default=10)
+ap.add_argument("--h", type=float, default=0.0, help="disc mesh of this resolution (m) instead of --mesh")
 ap.add_argument("P", nargs="+", type=int)
 a = ap.parse_args()
 import torch  # noqa: F401  (its HIP runtime must be the one in the process)
 from nextsim_amd import dynamics, forcing as F, mesh as M
-gm = M.make_mesh(a.mesh)
+gm = M.make_disc_mesh(a.h, seed=M.SEED, name="custom") if a.h > 0 else M.make_mesh(a.mesh)
+print(f"mesh: {gm.num_elements} triangles, {gm.num_nodes} nodes", flush=True)
 p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
 g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
 lm = M.localize(gm, 1)[0]; f = F.localize_fields(g, lm, gm.num_nodes)
