@@ -11,11 +11,12 @@ from oracle import pyoracle as O
 
 rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"]); out = sys.argv[1]; kind = sys.argv[2]; nsteps = int(sys.argv[3])
 transport = sys.argv[4] if len(sys.argv) > 4 else "rccl"
+over = json.loads(sys.argv[5]) if len(sys.argv) > 5 else {}
 dev = int(os.environ.get("NXS_TEST_DEVICE", "0"))
 dist.init_process_group("gloo", rank=rank, world_size=world)
 report = {"rank": rank, "ok": False}
 try:
-    gm, p, g, lms, fields = cases.make_case(kind, nparts=world)
+    gm, p, g, lms, fields = cases.make_case(kind, nparts=world, **over)
     fe = dynamics.FiniteElementDynamics(p, device=dev)
     fe.set_mesh(lms[rank])
     lm = lms[rank]

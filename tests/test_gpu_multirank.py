@@ -16,13 +16,14 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(world, kind, nsteps, tmp_path, transport="rccl"):
+def _run(world, kind, nsteps, tmp_path, transport="rccl", over=None):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mr_worker.py"), str(tmp_path), kind, str(nsteps), transport], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mr_worker.py"), str(tmp_path), kind, str(nsteps), transport,
+                                       json.dumps(over or {})], env=env))
     for p in procs:
         try:
             p.wait(timeout=300)
@@ -63,6 +64,21 @@ def test_partitioned_gpu_run_device_direct_halo_matches_multirank_oracle(world, 
         assert r["crash"] == 0
         for k, e in r["errs"].items():
             assert e <= 1e-10, (r["rank"], k, e)
+
+
+@pytest.mark.parametrize("dyn", ["mevp", "evp"])
+def test_in_kernel_halo_exchange_with_the_vp_rheologies(dyn, tmp_path):
+    """mEVP moves the mesh once after the sub-step loop (no ring of velocity buffers: the ghosts are copied through
+    to the two ping-pong buffers and pulled once at the end); EVP moves every sub-step like BBM."""
+    from nextsim_amd import _abi
+    code = {"mevp": _abi.NXS_DYN_MEVP, "evp": _abi.NXS_DYN_EVP}[dyn]
+    reps = _run(3, "small", 1, tmp_path, "ipc", over={"dynamics_type": code})
+    for r in reps:
+        assert r["ok"], r
+        assert r["fused_equals_separate"] is True, r
+        assert r["crash"] == 0
+        for k, e in r["errs"].items():
+            assert e <= 1e-9, (r["rank"], k, e)
 
 
 @pytest.mark.parametrize("world", [2, 3])
