@@ -40,6 +40,31 @@ NXS_IO_API int nxs_exporter_write_field_int(nxs_exporter *e, const char *name, c
 /* writeRecord (exporter.cpp:158-189) + close both files. */
 NXS_IO_API int nxs_exporter_close(nxs_exporter *e);
 
+/* Reading the files back: Exporter::readRecord + loadFile (core/src/exporter.cpp:183-222).  Records of type "double"
+ * and "int" as the reference; "float" records (which the reference's loadFile rejects) are widened to double. */
+typedef struct nxs_exporter_file nxs_exporter_file;
+NXS_IO_API int nxs_exporter_load(const char *bin_path, const char *dat_path, nxs_exporter_file **out);
+NXS_IO_API int nxs_exporter_file_num_records(const nxs_exporter_file *f);
+NXS_IO_API int nxs_exporter_file_record(const nxs_exporter_file *f, int index, const char **name, const char **type, int64_t *count);
+/* By name, as field_map_dbl[name] / field_map_int[name] in readRestart (the first record of that name). */
+NXS_IO_API int nxs_exporter_file_get_double(const nxs_exporter_file *f, const char *name, double *out, int64_t count);
+NXS_IO_API int nxs_exporter_file_get_int(const nxs_exporter_file *f, const char *name, int32_t *out, int64_t count);
+NXS_IO_API int nxs_exporter_file_close(nxs_exporter_file *f);
+
+/* FiniteElement::writeRestart (FE.cpp:9518-9695): <directory>/mesh_<name>.bin/.dat (writeMesh) and
+ * <directory>/field_<name>.bin/.dat with the records, in this order: Misc_int {pcpt, M_flag_fix, mesh_adapt_step,
+ * M_nb_regrid}, M_dirichlet_flags, Time, the element variables under their M_restart_names_elt names
+ * (e.g. M_conc, M_thick, M_sigma_0..2, M_damage, ...), M_VT, M_UM, M_UT ([u | v], 2*num_nodes), PreviousNumbering.
+ * Always double precision, as the reference (Exporter exporter("double"), FE.cpp:9590).  The directory must exist. */
+NXS_IO_API int nxs_restart_write(const char *directory, const char *name_str, const double *xnod, const double *ynod,
+                                 const int32_t *idnod, int64_t num_nodes, const int32_t *elements, int64_t num_indices,
+                                 const int32_t misc_int[4], const int32_t *dirichlet_flags, int64_t num_dirichlet,
+                                 double current_time, int32_t num_elt_vars, const char *const *elt_names,
+                                 const double *const *elt_values, const double *VT, const double *UM, const double *UT,
+                                 const double *previous_numbering);
+/* FiniteElement::readRestart's file part (FE.cpp:9699-9790): loads the pair and checks that the records it needs exist. */
+NXS_IO_API int nxs_restart_read(const char *directory, const char *name_str, nxs_exporter_file **mesh, nxs_exporter_file **field);
+
 typedef struct nxs_mooring_var {
     const char *name, *standard_name, *long_name, *units, *cell_methods; /* gridoutput.hpp variable descriptors */
 } nxs_mooring_var;

@@ -136,6 +136,135 @@ int nxs_exporter_close(nxs_exporter *e) {
 }  // extern "C"
 
 // ------------------------------------------------------------------------------------------------
+// Reading the Exporter's files back (Exporter::readRecord / loadFile, core/src/exporter.cpp:183-222) and the
+// restart file set built from them (FiniteElement::writeRestart / readRestart, FE.cpp:9518-9695, 9699-9925)
+struct nxs_exporter_file {
+    struct Rec { std::string name, type; std::vector<double> d; std::vector<int32_t> i; };
+    std::vector<Rec> recs;
+};
+
+extern "C" {
+
+int nxs_exporter_load(const char *bin_path, const char *dat_path, nxs_exporter_file **out) {
+    if (!bin_path || !dat_path || !out) return fail(NXS_ERR_INVALID, "NULL argument");
+    FILE *dat = fopen(dat_path, "r");
+    if (!dat) return fail(NXS_ERR_INVALID, "File not found: %s", dat_path);
+    nxs_exporter_file *f = new nxs_exporter_file();
+    char name[256], type[64], size[64], mn[64], mx[64];
+    while (fscanf(dat, "%255s %63s %63s %63s %63s", name, type, size, mn, mx) == 5) {  // readRecord: five tokens per record
+        nxs_exporter_file::Rec r;
+        r.name = name; r.type = type;
+        f->recs.push_back(std::move(r));
+    }
+    fclose(dat);
+    FILE *bin = fopen(bin_path, "rb");
+    if (!bin) { delete f; return fail(NXS_ERR_INVALID, "File not found: %s", bin_path); }
+    int rc = NXS_OK;
+    for (auto &r : f->recs) {  // loadFile: int32 length, then the payload in the type the record names
+        int32_t reclen = 0;
+        if (fread(&reclen, sizeof reclen, 1, bin) != 1 || reclen < 0) { rc = fail(NXS_ERR_INVALID, "%s: truncated before record %s", bin_path, r.name.c_str()); break; }
+        size_t got = 0;
+        if (r.type == "double") { r.d.resize(reclen); got = fread(r.d.data(), sizeof(double), reclen, bin); }
+        else if (r.type == "int") { r.i.resize(reclen); got = fread(r.i.data(), sizeof(int32_t), reclen, bin); }
+        else if (r.type == "float") {  // the reference's loadFile stops here ("unknown type in file"); fields exported in
+            std::vector<float> t(reclen);  // single precision are widened instead
+            got = fread(t.data(), sizeof(float), reclen, bin);
+            r.d.assign(t.begin(), t.end());
+        } else { rc = fail(NXS_ERR_INVALID, "unknown type in file"); break; }
+        if (got != (size_t)reclen) { rc = fail(NXS_ERR_INVALID, "%s: record %s is truncated", bin_path, r.name.c_str()); break; }
+    }
+    fclose(bin);
+    if (rc) { delete f; return rc; }
+    *out = f;
+    return NXS_OK;
+}
+
+int nxs_exporter_file_num_records(const nxs_exporter_file *f) { return f ? (int)f->recs.size() : 0; }
+
+int nxs_exporter_file_record(const nxs_exporter_file *f, int index, const char **name, const char **type, int64_t *count) {
+    if (!f || index < 0 || index >= (int)f->recs.size()) return fail(NXS_ERR_INVALID, "record index out of range");
+    const auto &r = f->recs[index];
+    if (name) *name = r.name.c_str();
+    if (type) *type = r.type.c_str();
+    if (count) *count = (int64_t)(r.type == "int" ? r.i.size() : r.d.size());
+    return NXS_OK;
+}
+
+static const nxs_exporter_file::Rec *find_rec(const nxs_exporter_file *f, const char *name) {
+    if (!f || !name) return nullptr;
+    for (const auto &r : f->recs) if (r.name == name) return &r;  // field_map.emplace keeps the FIRST record of a name
+    return nullptr;
+}
+
+int nxs_exporter_file_get_double(const nxs_exporter_file *f, const char *name, double *out, int64_t count) {
+    const auto *r = find_rec(f, name);
+    if (!r) return fail(NXS_ERR_INVALID, "no record named %s", name ? name : "(null)");
+    if (r->type == "int") return fail(NXS_ERR_INVALID, "record %s holds integers", name);
+    if ((int64_t)r->d.size() != count || (count > 0 && !out)) return fail(NXS_ERR_INVALID, "record %s has %zu values, not %lld", name, r->d.size(), (long long)count);
+    std::copy(r->d.begin(), r->d.end(), out);
+    return NXS_OK;
+}
+
+int nxs_exporter_file_get_int(const nxs_exporter_file *f, const char *name, int32_t *out, int64_t count) {
+    const auto *r = find_rec(f, name);
+    if (!r) return fail(NXS_ERR_INVALID, "no record named %s", name ? name : "(null)");
+    if (r->type != "int") return fail(NXS_ERR_INVALID, "record %s holds reals", name);
+    if ((int64_t)r->i.size() != count || (count > 0 && !out)) return fail(NXS_ERR_INVALID, "record %s has %zu values, not %lld", name, r->i.size(), (long long)count);
+    std::copy(r->i.begin(), r->i.end(), out);
+    return NXS_OK;
+}
+
+int nxs_exporter_file_close(nxs_exporter_file *f) { delete f; return NXS_OK; }
+
+int nxs_restart_write(const char *directory, const char *name_str, const double *xnod, const double *ynod, const int32_t *idnod,
+                      int64_t num_nodes, const int32_t *elements, int64_t num_indices, const int32_t misc_int[4],
+                      const int32_t *dirichlet_flags, int64_t num_dirichlet, double current_time, int32_t num_elt_vars,
+                      const char *const *elt_names, const double *const *elt_values, const double *VT, const double *UM,
+                      const double *UT, const double *previous_numbering) {
+    if (!directory || !name_str || !misc_int || !VT || !UM || !UT || !previous_numbering || (num_elt_vars > 0 && (!elt_names || !elt_values)))
+        return fail(NXS_ERR_INVALID, "NULL argument");
+    const std::string base = std::string(directory) + "/";
+    const int64_t ne = num_indices / 3;
+    nxs_exporter *e = nullptr;
+    int rc;
+    // mesh_<name>.bin/.dat: writeMesh, FE.cpp:9601-9620.  Restart files are always double precision (:9590)
+    if ((rc = nxs_exporter_open((base + "mesh_" + name_str + ".bin").c_str(), (base + "mesh_" + name_str + ".dat").c_str(), "double", &e))) return rc;
+    rc = nxs_exporter_write_mesh(e, xnod, ynod, idnod, num_nodes, elements, num_indices);
+    int rc2 = nxs_exporter_close(e);
+    if (rc || rc2) return rc ? rc : rc2;
+    // field_<name>.bin/.dat in the reference's record order, FE.cpp:9633-9690
+    if ((rc = nxs_exporter_open((base + "field_" + name_str + ".bin").c_str(), (base + "field_" + name_str + ".dat").c_str(), "double", &e))) return rc;
+    rc = nxs_exporter_write_field_int(e, "Misc_int", misc_int, 4);
+    if (!rc) rc = nxs_exporter_write_field_int(e, "M_dirichlet_flags", dirichlet_flags, num_dirichlet);
+    if (!rc) rc = nxs_exporter_write_field(e, "Time", &current_time, 1);
+    for (int j = 0; j < num_elt_vars && !rc; ++j) rc = nxs_exporter_write_field(e, elt_names[j], elt_values[j], ne);
+    if (!rc) rc = nxs_exporter_write_field(e, "M_VT", VT, 2 * num_nodes);
+    if (!rc) rc = nxs_exporter_write_field(e, "M_UM", UM, 2 * num_nodes);
+    if (!rc) rc = nxs_exporter_write_field(e, "M_UT", UT, 2 * num_nodes);
+    if (!rc) rc = nxs_exporter_write_field(e, "PreviousNumbering", previous_numbering, num_nodes);
+    rc2 = nxs_exporter_close(e);
+    return rc ? rc : rc2;
+}
+
+int nxs_restart_read(const char *directory, const char *name_str, nxs_exporter_file **mesh, nxs_exporter_file **field) {
+    if (!directory || !name_str || !mesh || !field) return fail(NXS_ERR_INVALID, "NULL argument");
+    const std::string base = std::string(directory) + "/";
+    int rc = nxs_exporter_load((base + "mesh_" + name_str + ".bin").c_str(), (base + "mesh_" + name_str + ".dat").c_str(), mesh);
+    if (rc) return rc;
+    rc = nxs_exporter_load((base + "field_" + name_str + ".bin").c_str(), (base + "field_" + name_str + ".dat").c_str(), field);
+    if (rc) { nxs_exporter_file_close(*mesh); *mesh = nullptr; return rc; }
+    // what readRestart requires of the pair (FE.cpp:9744-9747, 9781-9787, 9813)
+    for (const char *need : {"Elements", "Nodes_x", "Nodes_y", "id"})
+        if (!find_rec(*mesh, need)) rc = fail(NXS_ERR_INVALID, "restart mesh file lacks %s", need);
+    for (const char *need : {"Time", "Misc_int", "M_dirichlet_flags", "M_VT", "M_UM", "M_UT", "PreviousNumbering"})
+        if (!find_rec(*field, need)) rc = fail(NXS_ERR_INVALID, "restart field file lacks %s", need);
+    if (rc) { nxs_exporter_file_close(*mesh); nxs_exporter_file_close(*field); *mesh = *field = nullptr; }
+    return rc;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
 // NetCDF-3 classic writer (just what the Moorings schema needs)
 namespace {
 

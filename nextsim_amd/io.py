@@ -21,7 +21,9 @@ class MooringProj(C.Structure):
 
 
 IO_EXPORTS = ("nxs_exporter_open", "nxs_exporter_write_mesh", "nxs_exporter_write_field", "nxs_exporter_write_field_int",
-              "nxs_exporter_close", "nxs_moorings_create", "nxs_moorings_append", "nxs_io_last_error")
+              "nxs_exporter_close", "nxs_exporter_load", "nxs_exporter_file_num_records", "nxs_exporter_file_record",
+              "nxs_exporter_file_get_double", "nxs_exporter_file_get_int", "nxs_exporter_file_close", "nxs_restart_write",
+              "nxs_restart_read", "nxs_moorings_create", "nxs_moorings_append", "nxs_io_last_error")
 _decl = False
 
 
@@ -39,6 +41,17 @@ def _lib():
                                           C.c_double, P(MooringProj)]
         L.nxs_moorings_append.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_int32, P(P(C.c_float))]
         L.nxs_io_last_error.restype = C.c_char_p
+        V = C.c_void_p
+        L.nxs_exporter_load.argtypes = [C.c_char_p, C.c_char_p, P(V)]
+        L.nxs_exporter_file_num_records.argtypes = [V]
+        L.nxs_exporter_file_record.argtypes = [V, C.c_int, P(C.c_char_p), P(C.c_char_p), P(C.c_int64)]
+        L.nxs_exporter_file_get_double.argtypes = [V, C.c_char_p, _abi.c_double_p, C.c_int64]
+        L.nxs_exporter_file_get_int.argtypes = [V, C.c_char_p, _abi.c_int32_p, C.c_int64]
+        L.nxs_exporter_file_close.argtypes = [V]
+        L.nxs_restart_write.argtypes = [C.c_char_p, C.c_char_p, _abi.c_double_p, _abi.c_double_p, _abi.c_int32_p, C.c_int64, _abi.c_int32_p,
+                                        C.c_int64, _abi.c_int32_p, _abi.c_int32_p, C.c_int64, C.c_double, C.c_int32, P(C.c_char_p),
+                                        P(_abi.c_double_p), _abi.c_double_p, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p]
+        L.nxs_restart_read.argtypes = [C.c_char_p, C.c_char_p, P(V), P(V)]
         _decl = True
     return L
 
@@ -90,6 +103,64 @@ def read_exported(bin_path: str, dat_path: str) -> dict:
         out[name] = np.frombuffer(raw, dt, n, pos).copy(); pos += n * np.dtype(dt).itemsize
     assert pos == len(raw)
     return out
+
+
+def _file_to_dict(L, fh) -> dict:
+    out = {}
+    for i in range(L.nxs_exporter_file_num_records(fh)):
+        name, typ, cnt = C.c_char_p(), C.c_char_p(), C.c_int64()
+        _chk(L, L.nxs_exporter_file_record(fh, i, C.byref(name), C.byref(typ), C.byref(cnt)))
+        key = name.value.decode()
+        if key in out:
+            continue                       # field_map.emplace keeps the first record of a name
+        if typ.value == b"int":
+            a = np.empty(cnt.value, np.int32)
+            _chk(L, L.nxs_exporter_file_get_int(fh, name.value, _abi.iptr(a) if a.size else None, a.size))
+        else:
+            a = np.empty(cnt.value, np.float64)
+            _chk(L, L.nxs_exporter_file_get_double(fh, name.value, _abi.dptr(a) if a.size else None, a.size))
+        out[key] = a
+    return out
+
+
+def load_exported(bin_path: str, dat_path: str) -> dict:
+    """Exporter::readRecord + loadFile through the library (nxs_exporter_load): name -> array, record order kept."""
+    L = _lib()
+    fh = C.c_void_p()
+    _chk(L, L.nxs_exporter_load(bin_path.encode(), dat_path.encode(), C.byref(fh)))
+    try:
+        return _file_to_dict(L, fh)
+    finally:
+        L.nxs_exporter_file_close(fh)
+
+
+def write_restart(directory, name_str, xnod, ynod, idnod, elements, misc_int, dirichlet_flags, current_time, elt_vars: dict,
+                  VT, UM, UT, previous_numbering):
+    """FiniteElement::writeRestart (FE.cpp:9518-9695).  elt_vars: ordered {restart name: [Ne] values}."""
+    L = _lib()
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
+    x, y = f64(xnod), f64(ynod)
+    ids = np.ascontiguousarray(idnod, np.int32); el = np.ascontiguousarray(elements, np.int32).ravel()
+    mi = np.ascontiguousarray(misc_int, np.int32); df = np.ascontiguousarray(dirichlet_flags, np.int32)
+    assert mi.size == 4
+    names = (C.c_char_p * max(len(elt_vars), 1))(*[k.encode() for k in elt_vars])
+    vals = [f64(v) for v in elt_vars.values()]
+    ptrs = (_abi.c_double_p * max(len(vals), 1))(*[_abi.dptr(v) for v in vals])
+    VT, UM, UT, pn = f64(VT), f64(UM), f64(UT), f64(previous_numbering)
+    _chk(L, L.nxs_restart_write(str(directory).encode(), name_str.encode(), _abi.dptr(x), _abi.dptr(y), _abi.iptr(ids), x.size, _abi.iptr(el),
+                                el.size, _abi.iptr(mi), _abi.iptr(df) if df.size else None, df.size, float(current_time), len(vals), names, ptrs,
+                                _abi.dptr(VT), _abi.dptr(UM), _abi.dptr(UT), _abi.dptr(pn)))
+
+
+def read_restart(directory, name_str):
+    """The file part of FiniteElement::readRestart (FE.cpp:9699-9790): (mesh records, field records) as dicts."""
+    L = _lib()
+    mh, fh = C.c_void_p(), C.c_void_p()
+    _chk(L, L.nxs_restart_read(str(directory).encode(), name_str.encode(), C.byref(mh), C.byref(fh)))
+    try:
+        return _file_to_dict(L, mh), _file_to_dict(L, fh)
+    finally:
+        L.nxs_exporter_file_close(mh); L.nxs_exporter_file_close(fh)
 
 
 def moorings_create(path, lon, lat, variables, miss_val=-1e14, averaging_period=0.0, proj=None):

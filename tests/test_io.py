@@ -92,6 +92,68 @@ def test_moorings_netcdf_schema_and_records(tmp_path):
         nio.moorings_append(path2, 2.0, [recs[0][0], recs[0][1]])   # wrong number of fields
 
 
+def test_library_loader_equals_the_independent_reader(tmp_path):
+    """nxs_exporter_load (readRecord + loadFile, exporter.cpp:183-222) against the pure-numpy reader."""
+    rng = np.random.default_rng(1)
+    b, d = str(tmp_path / "field_7.bin"), str(tmp_path / "field_7.dat")
+    e = nio.Exporter(b, d, "float")
+    e.writeField(np.array([1.5]), "Time"); e.writeField(rng.random(33), "M_thick"); e.writeField(np.arange(5, dtype=np.int32), "Misc_int")
+    e.writeField(rng.random(4), "M_thick")          # a second record of the same name: the first one wins (emplace)
+    e.close()
+    ind = nio.read_exported(b, d)
+    got = nio.load_exported(b, d)
+    assert list(got) == ["Time", "M_thick", "Misc_int"]
+    assert got["M_thick"].size == 33 and got["M_thick"].dtype == np.float64   # float records are widened
+    assert np.array_equal(got["Misc_int"], ind["Misc_int"]) and got["Time"][0] == 1.5
+    with pytest.raises(Exception):
+        nio.load_exported(str(tmp_path / "missing.bin"), d)
+    open(b, "r+b").truncate(20)                      # a truncated payload is an error, not garbage
+    with pytest.raises(Exception):
+        nio.load_exported(b, d)
+
+
+def test_restart_files_round_trip_in_the_reference_layout(tmp_path):
+    """writeRestart (FE.cpp:9518-9695): file names, record names and ORDER, double precision; then the pair is
+    read back (readRestart's file part) and every array must come back bit for bit."""
+    import cases
+    gm, p, g, lms, fields = cases.make_case("tiny")
+    lm, f = lms[0], fields[0]
+    nn, ne = lm.num_nodes, lm.num_elements
+    ids = np.arange(1, nn + 1, dtype=np.int32)
+    names = ["M_conc", "M_thick", "M_snow_thick", "M_sigma_0", "M_sigma_1", "M_sigma_2", "M_damage", "M_ridge_ratio"]
+    keys = ["conc", "thick", "snow_thick", "sigma0", "sigma1", "sigma2", "damage", "ridge_ratio"]
+    elt = {n: f[k] for n, k in zip(names, keys)}
+    dirichlet = np.flatnonzero(lm.mask_dirichlet[:nn]).astype(np.int32) + 1
+    prev = np.arange(1, nn + 1, dtype=np.float64)
+    misc = [17, 10000, 3, 2]
+    nio.write_restart(tmp_path, "final", lm.coord_x, lm.coord_y, ids, lm.indices, misc, dirichlet, 42005.125, elt, f["VT"], f["UM"], f["UT"], prev)
+    for fn in ("mesh_final.bin", "mesh_final.dat", "field_final.bin", "field_final.dat"):
+        assert (tmp_path / fn).exists()
+    order = [ln.split()[0] for ln in open(tmp_path / "field_final.dat")]
+    assert order == ["Misc_int", "M_dirichlet_flags", "Time"] + names + ["M_VT", "M_UM", "M_UT", "PreviousNumbering"]
+    types = [ln.split()[1] for ln in open(tmp_path / "field_final.dat")]
+    assert types[:3] == ["int", "int", "double"] and set(types[3:]) == {"double"}
+    assert [ln.split()[0] for ln in open(tmp_path / "mesh_final.dat")] == ["Elements", "id", "Nodes_x", "Nodes_y"]
+    mesh, field = nio.read_restart(tmp_path, "final")
+    assert np.array_equal(mesh["Elements"], lm.indices.ravel()) and np.array_equal(mesh["id"], ids)
+    assert np.array_equal(mesh["Nodes_x"], lm.coord_x) and np.array_equal(mesh["Nodes_y"], lm.coord_y)
+    assert list(field["Misc_int"]) == misc and field["Time"][0] == 42005.125
+    assert np.array_equal(field["M_dirichlet_flags"], dirichlet)
+    for n, k in zip(names, keys):
+        assert np.array_equal(field[n], f[k]), n
+    for n, k in (("M_VT", "VT"), ("M_UM", "UM"), ("M_UT", "UT")):
+        assert field[n].size == 2 * nn and np.array_equal(field[n], f[k])
+    assert np.array_equal(field["PreviousNumbering"], prev)
+    # the independent reader sees the same bytes
+    ind = nio.read_exported(str(tmp_path / "field_final.bin"), str(tmp_path / "field_final.dat"))
+    assert all(np.array_equal(ind[k], field[k]) for k in field)
+    # a pair that lacks what readRestart needs is refused
+    e = nio.Exporter(str(tmp_path / "field_bad.bin"), str(tmp_path / "field_bad.dat"), "double"); e.writeField(np.zeros(3), "Time"); e.close()
+    e = nio.Exporter(str(tmp_path / "mesh_bad.bin"), str(tmp_path / "mesh_bad.dat"), "double"); e.writeMesh(lm.coord_x, lm.coord_y, ids, lm.indices); e.close()
+    with pytest.raises(Exception, match="lacks"):
+        nio.read_restart(tmp_path, "bad")
+
+
 def test_io_symbols_are_declared():
     import os, re
     from nextsim_amd import dynamics
