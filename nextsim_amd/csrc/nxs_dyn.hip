@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -568,9 +569,7 @@ __device__ __forceinline__ double sys_load(const double *p) {
 //   (exchange x+1) only after it has seen my flag x+1.
 struct HaloFused {
     IpcDev ipc;
-    const unsigned char *pflag;        // [nP] 1 = boundary patch
-    const int *pmap;                   // [nP] grid position -> patch (boundary patches first)
-    int n_boundary;
+    int n_boundary;                    // patches [0, n_boundary) are the boundary patches (re-uploaded in that order)
     const int *send_ptr;               // [No+1] CSR over own nodes
     const int *send_k, *send_pos;      // neighbour (index into send_procs) and position inside its segment
     const int *send_off;               // [ns+1] segment offsets (segment length = v offset)
@@ -579,6 +578,13 @@ struct HaloFused {
     int from_mailbox;                  // 0: first sub-step of a step, the ghosts are in the VT buffer
     unsigned int *done_all;
 };
+
+#ifdef NXS_PHASE_TIMING  // kernel microscope (scripts/phase_timing.py builds a variant of the library with it)
+__device__ long long g_phase_t[8 * 8192];
+#define NXS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_t[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define NXS_STAMP(k) do { } while (0)
+#endif
 
 #ifndef NXS_PF
 #define NXS_PF 1
@@ -606,17 +612,20 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
            *lF = lds + 4 * (size_t)pp.Mmax;  // lF[6][Emax]
     // consecutive patches are neighbours in space: keep them on one XCD (blocks are dealt round-robin
     // over the 8 XCDs) so that shared halo elements / nodes hit that XCD's L2.  Speed only.
+    auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index, classes pos%8 -> contiguous index ranges
+        const int q = n >> 3, r = n & 7, x = pos & 7;
+        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
+    };
     int blk = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = blk & 7;
-        blk = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blk >> 3);
-    }
+    NXS_STAMP(0);
     unsigned long long xseq = 0ull;
     bool boundary = false;
-    if (HALO) {
-        blk = hf.pmap[blk];
-        boundary = hf.pflag[blk] != 0;
+    if (HALO) {  // boundary patches [0, n_boundary) lead the grid in dispatch order; the remap acts inside each group
+        boundary = blk < hf.n_boundary;
+        blk = boundary ? xcd_remap(blk, hf.n_boundary) : hf.n_boundary + xcd_remap(blk - hf.n_boundary, (int)gridDim.x - hf.n_boundary);
         xseq = *hf.ipc.seq_push;
+    } else {
+        blk = xcd_remap(blk, (int)gridDim.x);
     }
     const int t = threadIdx.x, Nn = m.Nn, Emax = pp.Emax;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
@@ -629,17 +638,19 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     // The kernel is latency-bound unless every dependent load hop is overlapped, so all global loads
     // that do not need LDS are issued up front: indices first, then (one hop later) the nodal
     // velocities to stage and this thread's element data, all in flight together before barrier 1.
-    const int my_node = (t < nM) ? pn[t] : 0;  // patch-local slot t (an own node when t < nO)
+    // The index rows are padded to Mmax / Emax, so these loads depend on the launch arguments only -- not on the
+    // patch's counts (one more dependent hop; the counts arrive meanwhile and mask the uses).
+    const int my_node = (t < pp.Mmax) ? pn[t] : 0;  // patch-local slot t (an own node when t < nO)
     int eraw = 0;
     ushort4 tr = make_ushort4(0, 0, 0, 0);
-    if (t < nE) { eraw = pe[t]; tr = pt[t]; }
+    if (t < Emax) { eraw = pe[t]; tr = pt[t]; }
 #if NXS_PF >= 1
     // element rounds 1 and 2 (a patch holds ~2.2 elements per own node): their indices are fetched now, so
     // that a later round starts with its data loads instead of an index hop
     int eraw1 = 0, eraw2 = 0;
     ushort4 tr1 = tr, tr2 = tr;
-    if (t + T < nE) { eraw1 = pe[t + T]; tr1 = pt[t + T]; }
-    if (t + 2 * T < nE) { eraw2 = pe[t + 2 * T]; tr2 = pt[t + 2 * T]; }
+    if (t + T < Emax) { eraw1 = pe[t + T]; tr1 = pt[t + T]; }
+    if (t + 2 * T < Emax) { eraw2 = pe[t + 2 * T]; tr2 = pt[t + 2 * T]; }
 #endif
 
     const bool mailbox_ghosts = HALO && boundary && hf.from_mailbox;
@@ -695,7 +706,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 c_pmax = ldg<NT_C>(w.pmax + e); c_heal = ldg<NT_C>(w.heal + e); c_dxs = ldg<NT_C>(w.dxs + e); c_coh = ldg<NT_C>(s.cohesion + e);
             }
         }
-        if (base == 0) __syncthreads();  // staged velocities / coordinates visible
+        if (base == 0) { __syncthreads(); NXS_STAMP(1); }  // staged velocities / coordinates visible
         if (active) {
             {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates: the same operations as
                 // k_prep_elements, so the same bits as M_shape_coeff -- 48 B/element less to stream
@@ -732,6 +743,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
 #endif
     }
 
+    NXS_STAMP(2);
     // node phase: issue this node's loads before barrier 2 so that they overlap the wait
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.Pmax;
     for (int base = 0; base < nO || base == 0; base += T) {
@@ -753,11 +765,25 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             if (move_dt != 0.) { umu = ldg<NT_U>(s.UM + n); umv = ldg<NT_U>(s.UM + n + Nn); utu = ldg<NT_U>(s.UT + n); utv = ldg<NT_U>(s.UT + n + Nn); }
             if (HALO && boundary) { sq0 = hf.send_ptr[n]; sq1 = hf.send_ptr[n + 1]; }
         }
-        if (base == 0) __syncthreads();  // corner forces visible
+        // the node's fan (element slot, corner) too: 8 entries cover all but the most irregular vertices
+        unsigned short fan[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) fan[k] = (active && k < pp.Wp) ? pf[(size_t)k * pp.Pmax + i] : (unsigned short)0xFFFFu;
+        if (base == 0) { __syncthreads(); NXS_STAMP(3); }  // corner forces visible
         if (!active) continue;
         double uice = lu[i], vice = lv[i];
         if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
-            for (int k = 0; k < pp.Wp; ++k) {
+            bool more = true;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned ent = fan[k];
+                if (!more || ent == 0xFFFFu) { more = false; continue; }
+                if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
+                const int l = ent >> 3, c = ent & 3u;
+                gx -= lF[(size_t)c * Emax + l];
+                gy -= lF[(size_t)(c + 3) * Emax + l];
+            }
+            for (int k = 8; more && k < pp.Wp; ++k) {
                 const unsigned ent = pf[(size_t)k * pp.Pmax + i];
                 if (ent == 0xFFFFu) break;
                 if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
@@ -786,6 +812,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             stg<NT_U>(s.UT + n + Nn, utv + move_dt * vice);
         }
     }
+    NXS_STAMP(4);
     if (HALO) {
         if (boundary) {  // publish: the last boundary patch to finish raises my flag at every neighbour
             __threadfence_system();
@@ -1258,6 +1285,13 @@ struct Rccl {  // RCCL entry points, resolved at comm_init (no link-time depende
 struct NcclId { char internal[128]; };
 typedef int (*nccl_comm_init_rank_t)(void **, int, NcclId, int);
 
+struct HostPatches {
+    int nP = 0, Pmax = 0, Emax = 0, Mmax = 0, Wp = 0;
+    std::vector<int> own_cnt, elem_cnt, node_cnt, pnodes, pelem;
+    std::vector<unsigned short> ptri, pfan;
+    double avg_elems_per_own_node = 0.;
+};
+
 struct nxs_dyn_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1305,8 +1339,7 @@ struct nxs_dyn_handle {
     HaloFused hf{};
     std::vector<void *> hf_allocs;
     std::vector<int> h_send_index, h_recv_index;   // host copies of the halo lists
-    std::vector<int> hp_pnodes, hp_own_cnt, hp_node_cnt;  // host copies of the patch node lists
-    int hp_Mmax = 0;
+    std::shared_ptr<HostPatches> hp;  // host copy of the patches (re-uploaded boundary-first for the fused halo)
     nxs_dyn_halo_fn halo_fn = nullptr;  // host-staged exchange through the caller's communicator
     void *halo_ctx = nullptr;
     double *h_send = nullptr, *h_recv = nullptr;  // pinned staging buffers
@@ -1453,12 +1486,6 @@ int harvest(nxs_dyn_handle *h, int k) {
 
 // ------------------------------------------------------------------------------------------------
 // Host: node patches for the fused sub-step kernel (see DevPatches).
-struct HostPatches {
-    int nP = 0, Pmax = 0, Emax = 0, Mmax = 0, Wp = 0;
-    std::vector<int> own_cnt, elem_cnt, node_cnt, pnodes, pelem;
-    std::vector<unsigned short> ptri, pfan;
-    double avg_elems_per_own_node = 0.;
-};
 
 // order: owned nodes in the order they are cut into patches of P.
 bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int No, int P,
@@ -1615,6 +1642,22 @@ bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, con
     return ok;
 }
 
+int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
+    free_pool(h->patch_allocs);
+    DevPatches &d = h->dpch;
+    d = DevPatches{};
+    d.nP = hp.nP; d.Pmax = hp.Pmax; d.Emax = hp.Emax; d.Mmax = hp.Mmax; d.Wp = hp.Wp;
+    int rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.own_cnt, hp.own_cnt))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.elem_cnt, hp.elem_cnt))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.node_cnt, hp.node_cnt))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.pnodes, hp.pnodes))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.pelem, hp.pelem))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.ptri, hp.ptri))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &d.pfan, hp.pfan))) return rc;
+    return NXS_OK;
+}
+
 int upload_patches(nxs_dyn_handle *h) {
     free_pool(h->patch_allocs);
     h->dpch = DevPatches{};
@@ -1671,19 +1714,9 @@ int upload_patches(nxs_dyn_handle *h) {
         fprintf(stderr, "[nxs] patches: P=%d nP=%d Pmax=%d Emax=%d Mmax=%d Wp=%d avgE=%.1f avgM=%.1f lds=%zu B elems x%.3f\n", P, hp.nP, hp.Pmax,
                 hp.Emax, hp.Mmax, hp.Wp, (double)se / hp.nP, (double)sm / hp.nP, h->fused_lds, (double)se / std::max(m.Ne, 1));
     }
-    h->hp_pnodes = hp.pnodes; h->hp_own_cnt = hp.own_cnt; h->hp_node_cnt = hp.node_cnt; h->hp_Mmax = hp.Mmax;
     h->hf_ready = false;
-    DevPatches &d = h->dpch;
-    d.nP = hp.nP; d.Pmax = hp.Pmax; d.Emax = hp.Emax; d.Mmax = hp.Mmax; d.Wp = hp.Wp;
-    int rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.own_cnt, hp.own_cnt))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.elem_cnt, hp.elem_cnt))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.node_cnt, hp.node_cnt))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.pnodes, hp.pnodes))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.pelem, hp.pelem))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.ptri, hp.ptri))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.pfan, hp.pfan))) return rc;
-    return NXS_OK;
+    h->hp = std::make_shared<HostPatches>(std::move(hp));
+    return upload_host_patches(h, *h->hp);
 }
 
 void ipc_release(nxs_dyn_handle *h) {
@@ -2289,6 +2322,15 @@ int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_
             HIPCHK(h, hipStreamSynchronize(h->stream));
             return NXS_OK;
         }
+#ifdef NXS_PHASE_TIMING
+    if (!std::strcmp(name, "phase_times")) {  // [8192][8] timestamps (100 MHz) of the last fused launch, as doubles
+        std::vector<long long> t(8 * 8192);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_phase_t), t.size() * sizeof(long long)));
+        for (int64_t i = 0; i < n && i < (int64_t)t.size(); ++i) out[i] = (double)t[i];
+        return NXS_OK;
+    }
+#endif
     return fail(h, NXS_ERR_INVALID, "unknown debug array '%s'", name);
 }
 
@@ -2411,7 +2453,7 @@ int build_halo_fused(nxs_dyn_handle *h) {
     h->hf_ready = false;
     const int Nn = h->dm.Nn, No = h->dm.No, nP = h->dpch.nP;
     const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
-    if ((int)h->hp_own_cnt.size() != nP || (int)h->h_recv_index.size() != Nn - No) return fail(h, NXS_ERR_STATE, "fused halo tables: patches / halo lists missing");
+    if (!h->hp || h->hp->nP != nP || (int)h->h_recv_index.size() != Nn - No) return fail(h, NXS_ERR_STATE, "fused halo tables: patches / halo lists missing");
     // sending side: CSR over own nodes
     std::vector<int> sptr(No + 1, 0);
     for (int k = 0; k < ns; ++k)
@@ -2433,27 +2475,42 @@ int build_halo_fused(nxs_dyn_handle *h) {
             gsrl[h->h_recv_index[j] - No] = srl;
         }
     }
-    // boundary patches: send something or stage a ghost node; they come first in the grid
-    std::vector<unsigned char> pflag(nP, 0);
-    int nb = 0;
+    // boundary patches: send something or stage a ghost node.  The patch arrays are re-uploaded with those patches
+    // FIRST, so that the grid starts with them and "boundary" is blk < n_boundary (no lookup on the critical path)
+    HostPatches &hp = *h->hp;
+    std::vector<int> order_b, order_i;
     for (int q = 0; q < nP; ++q) {
-        const int *nd = h->hp_pnodes.data() + (size_t)q * h->hp_Mmax;
+        const int *nd = hp.pnodes.data() + (size_t)q * hp.Mmax;
         bool bnd = false;
-        for (int i = 0; i < h->hp_node_cnt[q] && !bnd; ++i) {
+        for (int i = 0; i < hp.node_cnt[q] && !bnd; ++i) {
             const int n = nd[i];
-            bnd = (n >= No) || (i < h->hp_own_cnt[q] && sptr[n + 1] > sptr[n]);
+            bnd = (n >= No) || (i < hp.own_cnt[q] && sptr[n + 1] > sptr[n]);
         }
-        pflag[q] = bnd;
-        nb += bnd;
+        (bnd ? order_b : order_i).push_back(q);
     }
-    std::vector<int> pmap;
-    pmap.reserve(nP);
-    for (int q = 0; q < nP; ++q) if (pflag[q]) pmap.push_back(q);
-    for (int q = 0; q < nP; ++q) if (!pflag[q]) pmap.push_back(q);
+    const int nb = (int)order_b.size();
+    bool sorted = true;
+    for (int q = 0; q < nb; ++q) sorted = sorted && order_b[q] == q;
+    if (!sorted) {
+        std::vector<int> order(order_b);
+        order.insert(order.end(), order_i.begin(), order_i.end());
+        HostPatches r = hp;
+        for (int q = 0; q < nP; ++q) {
+            const int o = order[q];
+            r.own_cnt[q] = hp.own_cnt[o]; r.elem_cnt[q] = hp.elem_cnt[o]; r.node_cnt[q] = hp.node_cnt[o];
+            std::copy_n(hp.pnodes.begin() + (size_t)o * hp.Mmax, hp.Mmax, r.pnodes.begin() + (size_t)q * hp.Mmax);
+            std::copy_n(hp.pelem.begin() + (size_t)o * hp.Emax, hp.Emax, r.pelem.begin() + (size_t)q * hp.Emax);
+            std::copy_n(hp.ptri.begin() + (size_t)o * hp.Emax * 4, (size_t)hp.Emax * 4, r.ptri.begin() + (size_t)q * hp.Emax * 4);
+            std::copy_n(hp.pfan.begin() + (size_t)o * hp.Wp * hp.Pmax, (size_t)hp.Wp * hp.Pmax, r.pfan.begin() + (size_t)q * hp.Wp * hp.Pmax);
+        }
+        hp = std::move(r);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        release_graph(h);
+        int rcu = upload_host_patches(h, hp);
+        if (rcu) return rcu;
+    }
     HaloFused &f = h->hf;
     int rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.pflag, pflag))) return rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.pmap, pmap))) return rc;
     if ((rc = dev_upload(h, h->hf_allocs, &f.send_ptr, sptr))) return rc;
     if ((rc = dev_upload(h, h->hf_allocs, &f.send_k, sk))) return rc;
     if ((rc = dev_upload(h, h->hf_allocs, &f.send_pos, spos))) return rc;

@@ -290,7 +290,8 @@ class FiniteElementDynamics:
     def debug_array(self, name: str) -> np.ndarray:
         Nn, Ne = self.lm.num_nodes, self.lm.num_elements
         n = {"rlmass": Nn, "node_mass": Nn, "C_bu": Nn, "grad_ssh": 2 * Nn, "fcor": Nn, "VTM": 2 * Nn,
-             "shape": 6 * Ne, "emass": Ne, "ecbu": Ne, "force": 6 * Ne, "volume": Ne, "expC": Ne}[name]
+             "shape": 6 * Ne, "emass": Ne, "ecbu": Ne, "force": 6 * Ne, "volume": Ne, "expC": Ne,
+             "phase_times": 8 * 8192}[name]
         out = np.empty(n)
         self._chk(self.L.nxs_dyn_debug_array(self.h, name.encode(), _abi.dptr(out), n))
         return out

@@ -1,0 +1,35 @@
+"""Where a workgroup of the fused sub-step kernel spends its time: builds a variant of the library with
+-DNXS_PHASE_TIMING (timestamps at the phase boundaries), runs one step and prints the statistics.
+    python3 scripts/phase_timing.py --build        (in the build container: writes nextsim_amd/csrc/libnxsdyn_phase.so)
+    NXS_DYN_LIBRARY=$PWD/nextsim_amd/csrc/libnxsdyn_phase.so python3 scripts/phase_timing.py --mesh 2km   (on the GPU box)"""
+import argparse, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.)
+a = ap.parse_args()
+csrc = os.path.join(ROOT, "nextsim_amd", "csrc")
+if a.build:
+    subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
+                           "-I" + os.path.join(ROOT, "include"), "-DNXS_PHASE_TIMING", "-shared", "-o", os.path.join(csrc, "libnxsdyn_phase.so")] +
+                          [os.path.join(csrc, f) for f in ("nxs_dyn.hip", "nxs_interp.hip", "nxs_krylov.hip", "nxs_mesh.cpp", "nxs_io.cpp")] + ["-ldl"])
+    sys.exit(0)
+import numpy as np
+import torch  # noqa: F401
+from nextsim_amd import dynamics, forcing as F, mesh as M
+gm = M.make_disc_mesh(a.h, seed=M.SEED, name="custom") if a.h > 0 else M.make_mesh(a.mesh)
+p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
+g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
+lm = M.localize(gm, 1)[0]; f = F.localize_fields(g, lm, gm.num_nodes)
+fe = dynamics.FiniteElementDynamics(p); fe.set_option("graph", 0)
+fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+fe.step(); fe.step(); fe.synchronize()
+t = fe.debug_array("phase_times")
+t = t.reshape(8192, 8)[:, :5]
+t = t[t[:, 0] > 0]
+k0 = t[:, 0].min()
+d = np.diff(t, axis=1) * 10e-3  # 100 MHz ticks -> us
+print(f"{gm.num_elements} triangles, {t.shape[0]} workgroups; kernel span {(t[:, 4].max() - k0) * 10e-3:.2f} us")
+for nm, col in zip(("index hop + staging (to barrier 1)", "element rounds", "wait at barrier 2 (+ node loads)", "fan gather + solve + stores"), d.T):
+    print(f"  {nm:38s} mean {col.mean():6.2f} us   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
+print(f"  workgroup total                        mean {(t[:, 4] - t[:, 0]).mean():6.2f} us; start of the last workgroup {(t[:, 0].max() - k0) * 10e-3:.2f} us after the first")
+fe.close()
