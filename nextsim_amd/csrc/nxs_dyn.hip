@@ -112,6 +112,7 @@ struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
 
 struct DevWork {
     double *delta_x, *surface, *shape /*[6][Ne]*/, *emass, *ecbu;
+    double *prec /*[Ne][10]: what k_prep_nodes gathers per fan entry, one record per element (see k_prep_elements)*/;
     double *expC, *pmax, *heal, *dxs, *volume;  // per-step element constants of the sub-step loop
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
@@ -143,8 +144,8 @@ __device__ __forceinline__ double jacobian(const double vx[3], const double vy[3
 // ------------------------------------------------------------------------------------------------
 // K1a  prep elements, FE.cpp:10235-10308
 __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, DevWork w, DevParams p) {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= m.Ne) return;
+    // threads past the end redo the last element (identical values to identical places): every thread reaches the barrier
+    const int e = min(blockIdx.x * BLOCK + (int)threadIdx.x, m.Ne - 1);
     double vx[3], vy[3];
     load_vertices(m, s.UM, e, vx, vy);
 
@@ -198,7 +199,37 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
         critical_h = conc * depth_eff / p.k1;
         critical_h_mod = mean_keel_depth / p.k1;
     }
-    w.ecbu[e] = p.k2 * STD_MAX(0., critical_h_mod - critical_h) * exp(-p.Cb * (1. - conc));
+    const double ecbu = p.k2 * STD_MAX(0., critical_h_mod - critical_h) * exp(-p.Cb * (1. - conc));
+    w.ecbu[e] = ecbu;
+
+    // The record k_prep_nodes gathers for every fan entry -- everything the nodal loops of FE.cpp:10309-10340 and
+    // 10578-10602 take from this element, contiguous (80 B) instead of nine arrays: the products are formed with the
+    // reference's operand order, so the node side performs the same additions on the same values.
+    __shared__ double rec[BLOCK * 10];  // staged so that the 80-byte records leave the block as one contiguous stream
+    {
+        double *r = rec + threadIdx.x * 10;
+        const double meA = element_mass * surface;           // node_mass += element_mass*surface, FE.cpp:10314
+        const double m_g_A3rd = meA * (NXS_GRAVITY / 3.);    // FE.cpp:10321
+        double dragp = s.drag_ui[e];                          // FE.cpp:10585-10596
+        if (p.young_cat) {
+            const double cy = s.cyoung[e];
+            if (conc + cy > 0.) dragp = (s.drag_ui[e] * conc + s.drag_ui_young[e] * cy) / (conc + cy);
+        }
+        const double sshn[3] = {s.ssh[m.t0[e]], s.ssh[m.t1[e]], s.ssh[m.t2[e]]};
+        r[0] = surface; r[1] = meA; r[2] = ecbu; r[3] = dragp * surface;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {                         // FE.cpp:10334-10339
+            const int kp1 = (j + 1) % 3, kp2 = (j + 2) % 3;
+            r[4 + j] = (vy[kp1] - vy[kp2]) / jac * m_g_A3rd * sshn[j];
+            r[7 + j] = (vx[kp2] - vx[kp1]) / jac * m_g_A3rd * sshn[j];
+        }
+    }
+    __syncthreads();
+    {
+        const size_t base = (size_t)blockIdx.x * BLOCK * 10;
+        const int count = min(BLOCK, m.Ne - (int)blockIdx.x * BLOCK) * 10;
+        for (int i = threadIdx.x; i < count; i += BLOCK) w.prec[base + i] = rec[i];
+    }
 
     // Per-step constants of the sub-step loop.  M_conc, M_thick, M_delta_x, M_surface do not change
     // while sub-cycling (Q4), so exp/pow of them are evaluated once here instead of S times; the
@@ -222,30 +253,24 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
 __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, DevWork w, DevParams p) {
     const int n = blockIdx.x * BLOCK + threadIdx.x;
     if (n >= m.Nn) return;
-    const int Nn = m.Nn, Ne = m.Ne;
+    const int Nn = m.Nn;
     const bool dirichlet = m.nflags[n] & NF_DIRICHLET;
-    const double g3rd = NXS_GRAVITY / 3.;
 
     double rl = 0., nm = 0., cb = 0., gu = 0., gv = 0.;
     for (int slot = 0; slot < m.W; ++slot) {
         const int ent = m.fan[(size_t)slot * Nn + n];
         if (ent < 0) break;
-        const int e = ent >> 3;
+        const double *r = w.prec + (size_t)(ent >> 3) * 10;
         const bool ghost_corner = ent & 4;
-        const double A = w.surface[e], me = w.emass[e];
-        rl += A;                                       // FE.cpp:10313
-        nm += me * A;                                  // FE.cpp:10314
-        const double ecbu = w.ecbu[e];
-        cb = STD_MAX(cb, ecbu);                        // FE.cpp:10317
+        rl += r[0];                                    // FE.cpp:10313
+        nm += r[1];                                    // FE.cpp:10314
+        cb = STD_MAX(cb, r[2]);                        // FE.cpp:10317
         // Q7: the skip test sees node_mass as accumulated so far (elements <= e)
         if (dirichlet || nm == 0. || ghost_corner) continue;
-        const double m_g_A3rd = me * A * g3rd;         // FE.cpp:10321
-        const int nj[3] = {m.t0[e], m.t1[e], m.t2[e]};
 #pragma unroll
         for (int j = 0; j < 3; ++j) {                  // FE.cpp:10334-10339
-            const double sshj = s.ssh[nj[j]];
-            gu -= w.shape[(size_t)j * Ne + e] * m_g_A3rd * sshj;
-            gv -= w.shape[(size_t)(j + 3) * Ne + e] * m_g_A3rd * sshj;
+            gu -= r[4 + j];
+            gv -= r[7 + j];
         }
     }
     // same expression as load_vertices(): the fused sub-step kernel rebuilds the shape coefficients from these
@@ -263,14 +288,9 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     for (int j = 0; j < m.W1; ++j) {                  // bamg row order (summation order!)
         const int e = m.n2e[(size_t)j * Nn + n];
         if (e < 0) continue;                           // Q2
-        double dragp = s.drag_ui[e];
-        if (p.young_cat) {
-            const double c = s.conc[e], cy = s.cyoung[e];
-            if (c + cy > 0.) dragp = (s.drag_ui[e] * c + s.drag_ui_young[e] * cy) / (c + cy);
-        }
-        const double A = w.surface[e];
-        drag += dragp * A;
-        surface += A;
+        const double *r = w.prec + (size_t)e * 10;
+        drag += r[3];                                  // dragp * surface
+        surface += r[0];
     }
     const double wu = s.wind[n], wv = s.wind[n + Nn];
     drag *= NXS_RHOA * hypot(wu, wv) / surface;        // Q6
@@ -835,7 +855,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
 // VT buffers; every `count` sub-steps this kernel applies the same sequence of additions
 // M_UM += dte*M_VT, M_UT += dte*M_VT (FE.cpp:10543-10550) for all nodes, owned and ghost -- same
 // operations in the same order, but UM/UT are streamed once per `count` sub-steps instead of every one.
-#define NXS_MAX_RING 17
+#define NXS_MAX_RING 129
 struct VTRing { double *slot[NXS_MAX_RING]; int R; };
 
 __global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRing ring, int first, int count, double dt) {
@@ -1305,7 +1325,7 @@ struct nxs_dyn_handle {
     int fused = 1;          // v2 fused sub-step kernel (default) vs v1 two-kernel sub-step
     int patch_nodes = 0;    // own nodes per patch; 0 = auto
     int um_ring = 0;        // fused path: apply the mesh move every um_ring sub-steps from a ring of VT buffers
-                            // (1 = every sub-step; 0 = auto: 16 on meshes that stream from HBM, 1 on cache-resident ones)
+                            // (1 = every sub-step; 0 = auto: once per step on meshes that stream from HBM, 1 on cache-resident ones)
     VTRing ring{};
     std::vector<void *> ring_allocs;
     int nt_mask = 3;        // non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)
@@ -1999,7 +2019,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(s.cyoung, ne); A(s.hyoung, ne); A(s.hsyoung, ne); A(s.cmyi, ne); A(s.tmyi, ne);
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
-    A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne);
+    A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 10 * ne);
     A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne);
     A(w.force, 6 * ne);
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
@@ -2546,8 +2566,10 @@ int run_substeps(nxs_dyn_handle *h) {
     const bool mr = multi_rank(h);
     // deferred mesh move (fused path, not mEVP whose single move comes after the loop)
     const bool device_halo = mr && h->ipc_ready && !h->halo_fn;  // no host work inside the loop: graph-capturable
-    // auto ring: 16 on meshes that stream from HBM; also whenever the halo exchange runs inside the sub-step kernel
-    const int want_ring = h->um_ring > 0 ? h->um_ring : ((h->dm.Ne >= 400000 || (device_halo && h->halo_fused)) ? 16 : 1);
+    // auto ring: one flush per step (up to 120 sub-steps) on meshes that stream from HBM -- the flush reads every slot once
+    // whatever its period, so a longer ring only saves UM/UT passes (2 km: 7.60 -> 7.49 ms/step from 16 to 120, 1.4 GB of
+    // slots); also whenever the halo exchange runs inside the sub-step kernel
+    const int want_ring = h->um_ring > 0 ? h->um_ring : ((h->dm.Ne >= 400000 || (device_halo && h->halo_fused)) ? 120 : 1);
     const int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
     const bool deferred = K > 1;
     if (fused) { int rc = setup_ring(h, K); if (rc) return rc; }

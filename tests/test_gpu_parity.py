@@ -350,7 +350,7 @@ def test_fused_substep_kernel_is_bitwise_equal_to_the_per_loop_kernels(dyn, subs
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
-@pytest.mark.parametrize("um_ring,substeps", [(1, 120), (5, 120), (16, 120), (8, 13), (7, 7)])
+@pytest.mark.parametrize("um_ring,substeps", [(1, 120), (5, 120), (16, 120), (120, 120), (8, 13), (7, 7)])
 def test_deferred_mesh_move_ring_does_not_change_a_bit(um_ring, substeps):
     """UM/UT are advanced every um_ring sub-steps from a ring of velocity buffers: the same additions in the
     same order as moving the mesh every sub-step (v1 path), for ring sizes that do and do not divide S."""
