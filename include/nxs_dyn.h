@@ -244,8 +244,16 @@ NXS_API int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32
 NXS_API int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local);
 
 NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
-/* Options: "graph" (1 = sub-step loop replayed from a hipGraph, default; 0 = plain launches),
- * "timing" (1 = record the per-phase events, default), "timing_reset" (any value: zero the averages). */
+/* Options (none changes a bit of the results; the tests assert that):
+ *   "graph"        1 = sub-step loop replayed from a hipGraph (default); 0 = plain launches
+ *   "timing"       1 = record the per-phase events (default); "timing_reset": zero the averages
+ *   "fused"        1 = one patch kernel per sub-step (default); 0 = one kernel per reference loop
+ *   "patch_nodes"  own nodes per patch of the fused kernel, 64..1024; 0 = automatic (whole rounds of resident workgroups)
+ *   "um_ring"      apply M_UM/M_UT += dt*M_VT every n sub-steps from a ring of velocity buffers, 1..128;
+ *                  0 = automatic (once per step on meshes that stream from HBM, every sub-step on cache-resident ones)
+ *   "nt_mask"      non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)
+ *   "halo_fused"   device-direct transport only: 1 = updateGhosts inside the fused sub-step kernel (default),
+ *                  0 = separate push / pull kernels */
 NXS_API int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);
 
 /* Test door: copies a named internal work array (rlmass, node_mass, C_bu, grad_ssh, fcor, VTM, shape,
