@@ -28,6 +28,8 @@ GHOST_FN = C.CFUNCTYPE(None, C.c_void_p, _abi.c_double_p)
 
 
 def build(fast: bool = False) -> str:
+    if os.environ.get("NXS_ORACLE_LIBRARY"):   # another build of the same source (tests/test_sanitizers.py: ASan/UBSan)
+        return os.environ["NXS_ORACLE_LIBRARY"]
     name = "liboracle_fast.so" if fast else "liboracle.so"
     path = os.path.join(HERE, name)
     src = os.path.join(HERE, "dyn_ref.c")
