@@ -43,6 +43,15 @@ NXS_KRYLOV_API int nxs_fem_poisson_solve(const int32_t *indices, const double *x
                                          double rtol, int32_t max_iter, int32_t device, int32_t *iterations,
                                          double *rel_residual, double *ms_assembly, double *ms_solve);
 
+/* A x = b for a general CSR matrix (columns in any order, a non-zero diagonal in every row), x0 = 0, Jacobi
+ * preconditioner: NXS_KRYLOV_CG for symmetric positive definite A, NXS_KRYLOV_BICGSTAB for non-symmetric A (a momentum
+ * matrix with Coriolis terms is).  SpMV / fused vector updates / deterministic dots, scalars kept on the device, the
+ * residual read back every 10 iterations.  Stops at ||r|| <= rtol*||b|| or max_iter. */
+enum { NXS_KRYLOV_CG = 0, NXS_KRYLOV_BICGSTAB = 1 };
+NXS_KRYLOV_API int nxs_krylov_solve(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *val, const double *b,
+                                    double *x, int32_t method, double rtol, int32_t max_iter, int32_t device, int32_t *iterations,
+                                    double *rel_residual, double *ms_solve);
+
 NXS_KRYLOV_API const char *nxs_krylov_last_error(void);
 
 #ifdef __cplusplus

@@ -138,6 +138,47 @@ __global__ void __launch_bounds__(BS) k_init_cg(int n, const double *__restrict_
     x[i] = 0.; r[i] = b[i]; z[i] = dinv[i] * b[i]; p[i] = z[i];
 }
 
+
+// ---- BiCGStab (right Jacobi preconditioner); scalars stay on the device: scal[0] rho, [1] alpha, [2] omega,
+//      [3] rho_new, [4] (rhat,v), [5] (t,s), [6] (t,t), [7] (r,r)
+__global__ void __launch_bounds__(BS) k_bicg_p(int n, const double *__restrict__ scal, const double *__restrict__ r, const double *__restrict__ v,
+                                               const double *__restrict__ dinv, double *__restrict__ p, double *__restrict__ y) {
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= n) return;
+    const double beta = (scal[3] / scal[0]) * (scal[1] / scal[2]);
+    const double pi = r[i] + beta * (p[i] - scal[2] * v[i]);
+    p[i] = pi;
+    y[i] = dinv[i] * pi;
+}
+__global__ void __launch_bounds__(BS) k_bicg_s(int n, const double *__restrict__ scal, const double *__restrict__ r, const double *__restrict__ v,
+                                               const double *__restrict__ dinv, double *__restrict__ sv, double *__restrict__ z) {
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= n) return;
+    const double alpha = scal[3] / scal[4];
+    const double si = r[i] - alpha * v[i];
+    sv[i] = si;
+    z[i] = dinv[i] * si;
+}
+__global__ void __launch_bounds__(BS) k_bicg_x(int n, const double *__restrict__ scal, const double *__restrict__ y, const double *__restrict__ z,
+                                               const double *__restrict__ sv, const double *__restrict__ t, double *__restrict__ x, double *__restrict__ r) {
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i >= n) return;
+    const double alpha = scal[3] / scal[4];
+    const double omega = scal[6] != 0. ? scal[5] / scal[6] : 0.;
+    x[i] += alpha * y[i] + omega * z[i];
+    r[i] = sv[i] - omega * t[i];
+}
+__global__ void k_bicg_shift(double *scal) {  // after an iteration: rho <- rho_new, alpha, omega kept for the next beta
+    scal[1] = scal[3] / scal[4];
+    scal[2] = scal[6] != 0. ? scal[5] / scal[6] : 0.;
+    scal[0] = scal[3];
+}
+__global__ void __launch_bounds__(BS) k_copy2(int n, const double *__restrict__ b, double *__restrict__ r, double *__restrict__ rhat) {
+    const int i = blockIdx.x * BS + threadIdx.x;
+    if (i < n) { r[i] = b[i]; rhat[i] = b[i]; }
+}
+__global__ void k_set_ones(double *scal) { scal[0] = scal[1] = scal[2] = 1.; }
+
 template <typename T>
 struct DBuf {
     T *p = nullptr;
@@ -307,6 +348,110 @@ int nxs_fem_poisson_solve(const int32_t *indices, const double *x, const double 
     if (rel_residual) *rel_residual = std::sqrt(rr / bb);
     if (ms_assembly) *ms_assembly = msa;
     if (ms_solve) *ms_solve = mss;
+    return NXS_OK;
+}
+
+int nxs_krylov_solve(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *val, const double *b, double *x, int32_t method,
+                     double rtol, int32_t max_iter, int32_t device, int32_t *iterations, double *rel_residual, double *ms_solve) {
+    if (n < 1 || !rowptr || !colidx || !val || !b || !x) return fail(NXS_ERR_INVALID, "NULL argument / empty system");
+    if (method != NXS_KRYLOV_CG && method != NXS_KRYLOV_BICGSTAB) return fail(NXS_ERR_INVALID, "method must be NXS_KRYLOV_CG or NXS_KRYLOV_BICGSTAB");
+    if (rowptr[0] != 0) return fail(NXS_ERR_INVALID, "rowptr[0] must be 0");
+    for (int i = 0; i < n; ++i) {
+        if (rowptr[i + 1] < rowptr[i]) return fail(NXS_ERR_INVALID, "rowptr not monotone at row %d", i);
+        bool diag = false;
+        for (int q = rowptr[i]; q < rowptr[i + 1]; ++q) {
+            if (colidx[q] < 0 || colidx[q] >= n) return fail(NXS_ERR_INVALID, "column index out of range in row %d", i);
+            diag = diag || (colidx[q] == i && val[q] != 0.);
+        }
+        if (!diag) return fail(NXS_ERR_INVALID, "row %d has no diagonal entry (Jacobi preconditioner)", i);
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the solver has no CPU path");
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_INVALID, "bad device %d", device);
+    const size_t nnz = (size_t)rowptr[n];
+    DBuf<int> drp, dci;
+    DBuf<double> dval, db, dx, dr, drh, dp, dv, dy, ds, dz, dt, ddinv, dpart, dscal;
+    const int nparts = 512;
+    if (!drp.up(rowptr, (size_t)n + 1) || !dci.up(colidx, nnz) || !dval.up(val, nnz) || !db.up(b, n) || !dx.zero(n) || !dr.zero(n) || !drh.zero(n) ||
+        !dp.zero(n) || !dv.zero(n) || !dy.zero(n) || !ds.zero(n) || !dz.zero(n) || !dt.zero(n) || !ddinv.zero(n) || !dpart.zero(nparts) || !dscal.zero(8))
+        return fail(NXS_ERR_HIP, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+    const dim3 gN((n + BS - 1) / BS), blk(BS);
+    auto dot = [&](const double *a, const double *c, int slot) {
+        hipLaunchKernelGGL(k_dot_partial, dim3(nparts), blk, 0, nullptr, n, a, c, dpart.p);
+        hipLaunchKernelGGL(k_dot_final, dim3(1), blk, 0, nullptr, nparts, (const double *)dpart.p, dscal.p, slot);
+    };
+    auto spmv = [&](const double *in, double *out) {
+        hipLaunchKernelGGL(k_spmv, gN, blk, 0, nullptr, n, (const int *)drp.p, (const int *)dci.p, (const double *)dval.p, in, out);
+    };
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_diag_inv, gN, blk, 0, nullptr, n, (const int *)drp.p, (const int *)dci.p, (const double *)dval.p, ddinv.p);
+    double h[8] = {0};
+    int it = 0;
+    double rr = 0., bb = 1.;
+    const int check_every = 10;
+    if (method == NXS_KRYLOV_CG) {
+        // r = b, z = M^-1 r, p = z (x0 = 0); buffers: dz = z, dv = A p
+        hipLaunchKernelGGL(k_init_cg, gN, blk, 0, nullptr, n, (const double *)db.p, (const double *)ddinv.p, dx.p, dr.p, dz.p, dp.p);
+        dot(dr.p, dz.p, 0);
+        dot(db.p, db.p, 4);
+        (void)hipMemcpy(h, dscal.p, sizeof h, hipMemcpyDeviceToHost);
+        bb = h[4] > 0. ? h[4] : 1.;
+        rr = bb;
+        while (it < max_iter && h[4] > 0.) {
+            spmv(dp.p, dv.p);
+            dot(dp.p, dv.p, 1);
+            hipLaunchKernelGGL(k_update_xr, gN, blk, 0, nullptr, n, (const double *)dscal.p, (const double *)dp.p, (const double *)dv.p, (const double *)ddinv.p, dx.p, dr.p, dz.p);
+            dot(dr.p, dz.p, 2);
+            hipLaunchKernelGGL(k_update_p, gN, blk, 0, nullptr, n, dscal.p, (const double *)dz.p, dp.p);
+            hipLaunchKernelGGL(k_shift_rz, dim3(1), dim3(1), 0, nullptr, dscal.p);
+            ++it;
+            if (it % check_every == 0 || it == max_iter) {
+                dot(dr.p, dr.p, 3);
+                (void)hipMemcpy(h, dscal.p, sizeof h, hipMemcpyDeviceToHost);
+                rr = h[3];
+                if (!(rr == rr) || std::sqrt(rr / bb) <= rtol) break;
+            }
+        }
+    } else {
+        hipLaunchKernelGGL(k_copy2, gN, blk, 0, nullptr, n, (const double *)db.p, dr.p, drh.p);
+        hipLaunchKernelGGL(k_set_ones, dim3(1), dim3(1), 0, nullptr, dscal.p);
+        dot(db.p, db.p, 7);
+        (void)hipMemcpy(h, dscal.p, sizeof h, hipMemcpyDeviceToHost);
+        bb = h[7] > 0. ? h[7] : 1.;
+        rr = bb;
+        while (it < max_iter && h[7] > 0.) {
+            dot(drh.p, dr.p, 3);                                                  // rho_new
+            hipLaunchKernelGGL(k_bicg_p, gN, blk, 0, nullptr, n, (const double *)dscal.p, (const double *)dr.p, (const double *)dv.p, (const double *)ddinv.p, dp.p, dy.p);
+            spmv(dy.p, dv.p);                                                     // v = A M^-1 p
+            dot(drh.p, dv.p, 4);
+            hipLaunchKernelGGL(k_bicg_s, gN, blk, 0, nullptr, n, (const double *)dscal.p, (const double *)dr.p, (const double *)dv.p, (const double *)ddinv.p, ds.p, dz.p);
+            spmv(dz.p, dt.p);                                                     // t = A M^-1 s
+            dot(dt.p, ds.p, 5);
+            dot(dt.p, dt.p, 6);
+            hipLaunchKernelGGL(k_bicg_x, gN, blk, 0, nullptr, n, (const double *)dscal.p, (const double *)dy.p, (const double *)dz.p, (const double *)ds.p, (const double *)dt.p, dx.p, dr.p);
+            hipLaunchKernelGGL(k_bicg_shift, dim3(1), dim3(1), 0, nullptr, dscal.p);
+            ++it;
+            if (it % check_every == 0 || it == max_iter) {
+                dot(dr.p, dr.p, 7);
+                (void)hipMemcpy(h, dscal.p, sizeof h, hipMemcpyDeviceToHost);
+                rr = h[7];
+                if (!(rr == rr) || std::sqrt(rr / bb) <= rtol) break;
+                if (h[0] == 0.) break;  // breakdown (rho = 0)
+            }
+        }
+    }
+    (void)hipEventRecord(e1, nullptr);
+    hipError_t err = hipDeviceSynchronize();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(NXS_ERR_HIP, "solver kernels failed: %s", hipGetErrorString(err));
+    if (hipMemcpy(x, dx.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    if (iterations) *iterations = it;
+    if (rel_residual) *rel_residual = std::sqrt(rr / bb);
+    if (ms_solve) *ms_solve = ms;
     return NXS_OK;
 }
 
