@@ -1051,6 +1051,66 @@ __global__ void __launch_bounds__(BLOCK) k_smooth(DevMesh m, DevWork w, const do
     dst[n + Nn] = v;
 }
 
+// The same sweep with updateGhosts inside (device-direct transport, see HaloFused): ghost neighbours are read from
+// the mailbox (exchange x-1), every sent node -- smoothed or not -- is stored into the neighbours' mailboxes
+// (exchange x), and the last block raises the flags.  One launch per sweep instead of three.
+__global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst, HaloFused hf) {
+    const unsigned long long xseq = *hf.ipc.seq_push;
+    const int Nn = m.Nn, No = m.No;
+    if (hf.from_mailbox) {
+        if (threadIdx.x == 0) {
+            const long long t0 = wall_clock64();
+            bool ok = true;
+            for (int k = 0; k < hf.ipc.nr && ok; ++k)
+                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 4); break; }  // 10 s
+                }
+            __threadfence_system();
+        }
+        __syncthreads();
+    }
+    const int n = blockIdx.x * BLOCK + threadIdx.x;
+    if (n < No) {
+        double u = src[n], v = src[n + Nn];
+        if (!((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) {
+            const double *mb = hf.ipc.mailbox + ((xseq - 1ull) & 1ull) * 2ull * (unsigned long long)hf.ipc.tr;
+            u = 0.; v = 0.;
+            const int num_neighbours = m.n2n_cnt[n];
+            for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
+                const int nni = m.n2n[(size_t)j * Nn + n];
+                if (hf.from_mailbox && nni >= No) {
+                    const double *g = mb + hf.ghost_off[nni - No];
+                    u += sys_load(g);
+                    v += sys_load(g + hf.ghost_srl[nni - No]);
+                } else {
+                    u += src[nni];
+                    v += src[nni + Nn];
+                }
+            }
+            u /= num_neighbours;
+            v /= num_neighbours;
+            dst[n] = u;
+            dst[n + Nn] = v;
+        }
+        for (int q = hf.send_ptr[n]; q < hf.send_ptr[n + 1]; ++q) {
+            const int k = hf.send_k[q];
+            double *d = hf.ipc.peer_seg[k] + (xseq & 1ull) * hf.ipc.peer_parity_stride[k] + hf.send_pos[q];
+            sys_store(d, u);
+            sys_store(d + (hf.send_off[k + 1] - hf.send_off[k]), v);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(hf.done_all, 1u) == gridDim.x - 1u) {
+        __threadfence_system();
+        for (int k = 0; k < hf.ipc.ns; ++k)
+            __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        *hf.done_all = 0u;
+        *hf.ipc.seq_push = xseq + 1ull;
+    }
+}
+
 __global__ void __launch_bounds__(BLOCK) k_copy_vt(int n2, const double *__restrict__ src, double *__restrict__ dst) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < n2) dst[i] = src[i];
@@ -2662,9 +2722,22 @@ int explicit_solve(nxs_dyn_handle *h) {
     auto smooth_and_tail = [&]() -> int {
         double *a = h->ds.VT, *b = h->ds.VT2;
         LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
+        const bool halo_in_kernel = multi_rank(h) && h->ipc_ready && !h->halo_fn && h->halo_fused && h->hf_ready && m.No > 0;
         for (int nit = 0; nit < 50; ++nit) {
-            LAUNCH(h, k_smooth, m.No, m, h->dw, a, b);
-            if (multi_rank(h)) { int r2 = halo_exchange(h, b, 0.); if (r2) return r2; }
+            if (halo_in_kernel) {  // updateGhosts inside the sweep; the ghosts land in the array once, after the last sweep
+                HaloFused hf = h->hf;
+                hf.ipc = h->ipc;
+                hf.from_mailbox = nit > 0;
+                LAUNCH(h, k_smooth_halo, m.No, m, h->dw, (const double *)a, b, hf);
+                if (nit == 49) {
+                    const int tr = h->recv_offsets[h->recv_procs.size()];
+                    hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, b, h->dm, h->ds, tr, h->d_recv_index,
+                                       h->d_recv_seg, h->d_recv_off, h->ipc, 0., 0, h->d_recv_procs, 1);
+                }
+            } else {
+                LAUNCH(h, k_smooth, m.No, m, h->dw, a, b);
+                if (multi_rank(h)) { int r2 = halo_exchange(h, b, 0.); if (r2) return r2; }
+            }
             std::swap(a, b);
         }
         // 50 is even: the result is back in ds.VT
