@@ -661,6 +661,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     // The index rows are padded to Mmax / Emax, so these loads depend on the launch arguments only -- not on the
     // patch's counts (one more dependent hop; the counts arrive meanwhile and mask the uses).
     const int my_node = (t < pp.Mmax) ? pn[t] : 0;  // patch-local slot t (an own node when t < nO)
+    const int my_node2 = (t + T < pp.Mmax) ? pn[t + T] : 0;  // a patch stages ~1.25 nodes per own node: second staging slot
     int eraw = 0;
     ushort4 tr = make_ushort4(0, 0, 0, 0);
     if (t < Emax) { eraw = pe[t]; tr = pt[t]; }
@@ -702,7 +703,8 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         ly[i] = w.ys[g];
     };
     if (t < nM) stage(t, my_node);
-    for (int i = t + T; i < nM; i += T) stage(i, pn[i]);
+    if (t + T < nM) stage(t + T, my_node2);
+    for (int i = t + 2 * T; i < nM; i += T) stage(i, pn[i]);
 
     for (int base = 0; base < nE; base += T) {
         const int l = base + t;
