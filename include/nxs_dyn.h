@@ -269,6 +269,12 @@ NXS_API int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int
 
 /* bamgmesh->ElementConnectivity (contrib/bamg/src/Mesh.cpp:777-796): ec[3*e+j] = 1-based number of the triangle
  * across local edge j (vertices (j+1)%3,(j+2)%3) of triangle e, NaN on the boundary.  Host only. */
+/* M_Cohesion of calcCohesion() (FE.cpp:3909-3914) from initIce's random field (FE.cpp:11459-11475): C_fix + C_alea * r(id),
+ * r = boost::uniform_01<boost::minstd_rand>, one draw per global element in id order.  global_element_id: 1-based
+ * (M_mesh.trianglesIdWithGhost()).  Host only. */
+NXS_API int nxs_calc_cohesion(double C_fix, double C_alea, const int32_t *global_element_id, int64_t num_elements,
+                              int64_t num_global_elements, double *cohesion);
+
 NXS_API int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
                                   double *element_connectivity);
 

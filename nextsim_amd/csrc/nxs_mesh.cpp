@@ -133,3 +133,23 @@ extern "C" int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num
         }
     return NXS_OK;
 }
+
+// calcCohesion (FE.cpp:3909-3914) on top of initIce's random field (FE.cpp:11459-11475): one draw of
+// boost::uniform_01<boost::minstd_rand> (default seed 1; x_{k+1} = 48271 x_k mod 2^31-1; r = (x - 1)/(2^31 - 2)) per GLOBAL
+// element, indexed by the element's global id, so every rank sees the same value for the same triangle.
+extern "C" int nxs_calc_cohesion(double C_fix, double C_alea, const int32_t *global_element_id, int64_t num_elements,
+                                 int64_t num_global_elements, double *cohesion) {
+    if (!global_element_id || !cohesion || num_elements < 0 || num_global_elements < 1) return NXS_ERR_INVALID;
+    std::vector<double> random_number_root((size_t)num_global_elements);
+    unsigned long long x = 1ull;
+    for (int64_t i = 0; i < num_global_elements; ++i) {
+        x = (x * 48271ull) % 2147483647ull;
+        random_number_root[(size_t)i] = (double)(x - 1ull) / 2147483646.0;
+    }
+    for (int64_t i = 0; i < num_elements; ++i) {
+        const int32_t id = global_element_id[i];
+        if (id < 1 || id > num_global_elements) return NXS_ERR_INVALID;
+        cohesion[i] = C_fix + C_alea * (random_number_root[(size_t)id - 1]);
+    }
+    return NXS_OK;
+}

@@ -80,6 +80,7 @@ def load_library():
     L.nxs_mesh_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, P(C.c_int32), _abi.c_double_p,
                                         P(C.c_int32), _abi.c_double_p]
     L.nxs_mesh_element_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, _abi.c_double_p]
+    L.nxs_calc_cohesion.argtypes = [C.c_double, C.c_double, _abi.c_int32_p, C.c_int64, C.c_int64, _abi.c_double_p]
     for name in EXPORTS:
         getattr(L, name)  # raises AttributeError if a declared symbol is not exported
         if name not in ("nxs_dyn_last_error",):
@@ -103,7 +104,7 @@ EXPORTS = (
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_get_diag", "nxs_dyn_step",
     "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
     "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
-    "nxs_dyn_debug_array", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity",
+    "nxs_dyn_debug_array", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
 )
 INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_conservative_remap", "nxs_interp_last_error")
 
@@ -123,6 +124,17 @@ def mesh_connectivity(indices: np.ndarray, num_nodes: int):
     if rc:
         raise NxsError(rc, "nxs_mesh_connectivity")
     return nec, nc
+
+
+def calc_cohesion(C_fix: float, C_alea: float, global_element_id: np.ndarray, num_global_elements: int) -> np.ndarray:
+    """calcCohesion() (FE.cpp:3909-3914): C_fix + C_alea * (the reference's minstd/uniform_01 draw of each global element)."""
+    L = load_library()
+    ids = np.ascontiguousarray(global_element_id, np.int32)
+    out = np.empty(ids.size)
+    rc = L.nxs_calc_cohesion(float(C_fix), float(C_alea), _abi.iptr(ids), ids.size, int(num_global_elements), _abi.dptr(out))
+    if rc:
+        raise NxsError(rc, "nxs_calc_cohesion")
+    return out
 
 
 def mesh_element_connectivity(indices: np.ndarray, num_nodes: int) -> np.ndarray:

@@ -68,3 +68,15 @@ def test_minstd_uniform01_matches_the_lcg():
         ref.append((x - 1) / 2147483646.0)
     assert np.array_equal(minstd_uniform01(1000), np.array(ref))
     assert minstd_uniform01(1)[0] == 48270 / 2147483646.0  # boost::minstd_rand, seed 1, first draw 48271
+
+
+def test_c_abi_cohesion_equals_the_python_mirror():
+    """nxs_calc_cohesion (C ABI, host) = C_fix + C_alea * minstd/uniform_01 draw by GLOBAL element id: ranks agree."""
+    from nextsim_amd import dynamics
+    from nextsim_amd.forcing import minstd_uniform01
+    r = minstd_uniform01(5000)
+    ids = np.array([1, 2, 3, 5000, 77, 77], np.int32)
+    got = dynamics.calc_cohesion(1.5e4, 3.0e3, ids, 5000)
+    assert np.array_equal(got, 1.5e4 + 3.0e3 * r[ids - 1])
+    with pytest.raises(Exception):
+        dynamics.calc_cohesion(1., 1., np.array([0], np.int32), 10)
