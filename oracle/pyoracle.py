@@ -332,3 +332,20 @@ def bamg_conservative_remap(index_old, x_old, y_old, index_new, x_new, y_new, pr
                                         _abi.dptr(data), data.shape[1], _abi.dptr(out))
     assert rc == 0
     return out
+
+
+def mapx_lat(x, y, mppfile="/root/reference/mesh/NpsNextsim.mpp"):
+    """GmshMesh::lat() (core/src/gmshmesh.cpp:1798-1824) with the REAL contrib/mapx: inverse_mapx of every (x, y).
+    Needs oracle/_ref/libmapx_ref.so AND the reference's .mpp parameter file (build container only)."""
+    L = C.CDLL(os.path.join(HERE, "_ref", "libmapx_ref.so"))
+    L.init_mapx.restype = C.c_void_p; L.init_mapx.argtypes = [C.c_char_p]
+    L.inverse_mapx.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.close_mapx.argtypes = [C.c_void_p]
+    m = L.init_mapx(mppfile.encode())
+    assert m, "init_mapx failed"
+    lat = np.empty(len(x)); a, b = C.c_double(), C.c_double()
+    for i, (xi, yi) in enumerate(zip(x, y)):
+        L.inverse_mapx(m, float(xi), float(yi), C.byref(a), C.byref(b))
+        lat[i] = a.value
+    L.close_mapx(m)
+    return lat

@@ -11,6 +11,8 @@
   bamg_remap.npz         REAL contrib/bamg ConservativeRemappingMeshToMesh (FE.cpp:3108) on four seeded regrid pairs
                          (adapted / coarser / finer / moved vertices), plus bamg's ElementConnectivity of the old
                          mesh and the seed triangles InterpFromMeshToMesh2dx returns -- pins the remapping kernel.
+  mapx_lat.npz           REAL contrib/mapx inverse_mapx with mesh/NpsNextsim.mpp (GmshMesh::lat(), gmshmesh.cpp:1798-1824) at
+                         600 points -- pins the latitude (Coriolis, sign of the turning angle) of the synthetic meshes.
   oracle_tiny.npz        oracle (liboracle.so) state on the 'tiny' toy case after 1 sub-step, 1 step
                          and 3 steps (beyond a few steps the algorithm amplifies 1-ulp differences to O(1), see
                          tests/test_oracle_sensitivity.py): a regression net for the oracle itself and size-0 cost
@@ -131,6 +133,18 @@ def make_remap_fixture():
     np.savez_compressed(os.path.join(HERE, "bamg_remap.npz"), **out)
 
 
+def mapx_case():
+    rng = np.random.default_rng(11)
+    x = rng.uniform(-2.6e6, 2.6e6, 600); y = rng.uniform(-2.6e6, 2.6e6, 600)
+    x[:3] = [0.0, 1.0, -2.5e6]; y[:3] = [0.0, 0.0, 2.5e6]          # the pole itself and a far corner
+    return x, y
+
+
+def make_mapx_fixture():
+    x, y = mapx_case()
+    np.savez_compressed(os.path.join(HERE, "mapx_lat.npz"), x=x, y=y, lat=O.mapx_lat(x, y))
+
+
 def main():
     lm = M.localize(cases.global_mesh("tiny"), 1)[0]
     assert O.bamg_shim() is not None, "build oracle/_ref first (make -C oracle ref)"
@@ -141,6 +155,7 @@ def main():
     make_interp_fixture()
     make_grid_fixture()
     make_remap_fixture()
+    make_mapx_fixture()
 
     out = {}
     for tag, nsteps, over in (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step3", 3, {})):

@@ -80,3 +80,16 @@ def test_c_abi_cohesion_equals_the_python_mirror():
     assert np.array_equal(got, 1.5e4 + 3.0e3 * r[ids - 1])
     with pytest.raises(Exception):
         dynamics.calc_cohesion(1., 1., np.array([0], np.int32), 10)
+
+
+def test_latitude_formula_equals_real_mapx():
+    """mesh.polar_stereographic_lat against the REAL contrib/mapx (inverse_mapx with mesh/NpsNextsim.mpp, what
+    GmshMesh::lat() calls): committed fixture, and live when oracle/_ref and the reference's .mpp file are present."""
+    import os, sys
+    from nextsim_amd.mesh import polar_stereographic_lat
+    from oracle import pyoracle as O
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mapx_lat.npz"))
+    assert np.abs(polar_stereographic_lat(z["x"], z["y"]) - z["lat"]).max() < 1e-10      # degrees
+    assert z["lat"][0] == 90.0 and z["lat"].min() > 50.0
+    if os.path.exists(os.path.join(os.path.dirname(O.__file__), "_ref", "libmapx_ref.so")) and os.path.exists("/root/reference/mesh/NpsNextsim.mpp"):
+        assert np.array_equal(O.mapx_lat(z["x"], z["y"]), z["lat"])
