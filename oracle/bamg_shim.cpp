@@ -128,3 +128,53 @@ int shim_bamg_conservative_remap(const int *index_old, const double *x_old, cons
 }
 
 } /* extern "C" */
+
+#include "BamgOpts.h"
+#include "Bamgx.h"
+
+extern "C" {
+
+/* One regrid of the reference on the root (FE.cpp:3606-3700 regrid + :3760-3801 adaptMesh), with the REAL remesher:
+ *   BamgConvertMeshx of the mesh at rest (as rootMeshProcessing, FE.cpp:300-340) -> bamgopt as initBamg (FE.cpp:992-1038)
+ *   with hmin / hmax from the caller (minMaxSide, FE.cpp:343-355) -> Vertices overwritten with the moved coordinates
+ *   (FE.cpp:3674-3678) -> Dirichlet edge flags (:3775-3789) -> Bamgx(root, previous).
+ * Outputs (caller-allocated with capacities; sizes returned): the adapted mesh, bamgmesh_root->PreviousNumbering and
+ * VerticesOnGeomVertexSize[0].  Objects are leaked on purpose (the reference shares pointers between root and previous). */
+int shim_bamg_adapt(const int *index, const double *x0, const double *y0, int nods, int nels, const int *dirichlet_flags, int ndir,
+                    const double *x_moved, const double *y_moved, double hmin, double hmax, int cap_nods, int cap_nels, int *out_nods,
+                    int *out_nels, int *out_index, double *out_x, double *out_y, double *out_prev, int *out_ngeom) {
+    BamgOpts *bamgopt = new BamgOpts();
+    bamgopt->Crack = 0; bamgopt->anisomax = 1e30; bamgopt->coeff = 1; bamgopt->cutoff = 1e-5; bamgopt->errg = 0.1; bamgopt->field = NULL;
+    bamgopt->gradation = 1.5; bamgopt->Hessiantype = 0; bamgopt->hmin = 1e-100; bamgopt->hmax = 1e100; bamgopt->hminVertices = NULL;
+    bamgopt->hmaxVertices = NULL; bamgopt->hVertices = NULL; bamgopt->KeepVertices = 1; bamgopt->MaxCornerAngle = 10; bamgopt->maxnbv = 1e7;
+    bamgopt->maxsubdiv = 10; bamgopt->metric = NULL; bamgopt->Metrictype = 0; bamgopt->nbjacobi = 1; bamgopt->nbsmooth = 3; bamgopt->omega = 1.8;
+    bamgopt->power = 1.; bamgopt->splitcorners = 1; bamgopt->geometricalmetric = 0; bamgopt->random = true; bamgopt->verbose = 0;
+    bamgopt->Check();
+    bamgopt->hmin = hmin; bamgopt->hmax = hmax;               /* FROM_UNREF meshes, FE.cpp:352-355 */
+    bamgopt->KeepVertices = 1; bamgopt->splitcorners = 0;     /* state after the first time step, FE.cpp:391-392 */
+
+    BamgMesh *root = new BamgMesh(); BamgGeom *groot = new BamgGeom();
+    if (BamgConvertMeshx(root, groot, const_cast<int *>(index), const_cast<double *>(x0), const_cast<double *>(y0), nods, nels) != 1) return -1;
+    for (int id = 0; id < root->VerticesSize[0]; ++id) { root->Vertices[3 * id] = x_moved[id]; root->Vertices[3 * id + 1] = y_moved[id]; }
+    BamgMesh *prev = new BamgMesh(); BamgGeom *gprev = new BamgGeom(); BamgOpts *oprev = new BamgOpts();
+    *prev = *root; *gprev = *groot; *oprev = *bamgopt;        /* FE.cpp:3770-3772 */
+    const int M_flag_fix = 10000;
+    for (int edg = 0; edg < prev->EdgesSize[0]; ++edg) {
+        const int fnd = (int)prev->Edges[3 * edg];
+        bool dir = false;
+        for (int k = 0; k < ndir && !dir; ++k) dir = dirichlet_flags[k] == fnd;
+        gprev->Edges[3 * edg + 2] = dir ? M_flag_fix : M_flag_fix + 1;
+        prev->Edges[3 * edg + 2] = dir ? M_flag_fix : M_flag_fix + 1;
+    }
+    BamgMesh *out = new BamgMesh(); BamgGeom *gout = new BamgGeom();
+    if (Bamgx(out, gout, prev, gprev, oprev) != 1) return -2;
+    const int nn = out->VerticesSize[0], ne = out->TrianglesSize[0];
+    *out_nods = nn; *out_nels = ne;
+    if (nn > cap_nods || ne > cap_nels) return -3;
+    for (int i = 0; i < nn; ++i) { out_x[i] = out->Vertices[3 * i]; out_y[i] = out->Vertices[3 * i + 1]; out_prev[i] = out->PreviousNumbering ? out->PreviousNumbering[i] : 0.; }
+    for (int t = 0; t < ne; ++t) for (int k = 0; k < 3; ++k) out_index[3 * t + k] = (int)out->Triangles[4 * t + k];
+    *out_ngeom = out->VerticesOnGeomVertexSize[0];
+    return 0;
+}
+
+} /* extern "C" */

@@ -349,3 +349,24 @@ def mapx_lat(x, y, mppfile="/root/reference/mesh/NpsNextsim.mpp"):
         lat[i] = a.value
     L.close_mapx(m)
     return lat
+
+
+def bamg_adapt(index, x0, y0, dirichlet_flags, x_moved, y_moved, hmin, hmax):
+    """One regrid with the REAL remesher (Bamgx as FiniteElement::adaptMesh calls it, FE.cpp:3760-3801, options of
+    initBamg FE.cpp:992-1038) on the mesh (index 1-based, x0, y0) whose vertices have moved to (x_moved, y_moved).
+    Returns x, y, tri (0-based), PreviousNumbering (1-based, 0 = new), VerticesOnGeomVertexSize[0]."""
+    L = C.CDLL(os.path.join(HERE, "_ref", "libbamg_shim.so"))
+    IP, D = C.POINTER(C.c_int), _abi.c_double_p
+    L.shim_bamg_adapt.argtypes = [IP, D, D, C.c_int, C.c_int, IP, C.c_int, D, D, C.c_double, C.c_double, C.c_int, C.c_int, IP, IP, IP, D, D, D, IP]
+    idx = np.ascontiguousarray(np.asarray(index).ravel().astype(np.intc)); dirf = np.ascontiguousarray(np.asarray(dirichlet_flags).astype(np.intc))
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
+    x0, y0, xm, ym = f64(x0), f64(y0), f64(x_moved), f64(y_moved)
+    cap_n, cap_e = 4 * x0.size + 1000, 4 * (idx.size // 3) + 1000
+    on, oe, og = C.c_int(), C.c_int(), C.c_int()
+    oi = np.zeros(3 * cap_e, np.intc); ox = np.zeros(cap_n); oy = np.zeros(cap_n); op = np.zeros(cap_n)
+    rc = L.shim_bamg_adapt(idx.ctypes.data_as(IP), _abi.dptr(x0), _abi.dptr(y0), x0.size, idx.size // 3, dirf.ctypes.data_as(IP), dirf.size,
+                           _abi.dptr(xm), _abi.dptr(ym), float(hmin), float(hmax), cap_n, cap_e, C.byref(on), C.byref(oe),
+                           oi.ctypes.data_as(IP), _abi.dptr(ox), _abi.dptr(oy), _abi.dptr(op), C.byref(og))
+    assert rc == 0, rc
+    nn, ne = on.value, oe.value
+    return ox[:nn].copy(), oy[:nn].copy(), (oi[:3 * ne].reshape(-1, 3) - 1).astype(np.int32), op[:nn].copy(), og.value

@@ -11,6 +11,9 @@
   bamg_remap.npz         REAL contrib/bamg ConservativeRemappingMeshToMesh (FE.cpp:3108) on four seeded regrid pairs
                          (adapted / coarser / finer / moved vertices), plus bamg's ElementConnectivity of the old
                          mesh and the seed triangles InterpFromMeshToMesh2dx returns -- pins the remapping kernel.
+  bamg_regrid.npz        a regrid made by the REAL remesher (Bamgx as adaptMesh calls it): both meshes, PreviousNumbering, and the
+                         reference's interpFields results on them (conservative remap of 5 element variables, P1 interpolation of 6
+                         nodal variables) -- pins both regrid kernels on what bamg really produces.
   mapx_lat.npz           REAL contrib/mapx inverse_mapx with mesh/NpsNextsim.mpp (GmshMesh::lat(), gmshmesh.cpp:1798-1824) at
                          600 points -- pins the latitude (Coriolis, sign of the turning angle) of the synthetic meshes.
   oracle_tiny.npz        oracle (liboracle.so) state on the 'tiny' toy case after 1 sub-step, 1 step
@@ -133,6 +136,38 @@ def make_remap_fixture():
     np.savez_compressed(os.path.join(HERE, "bamg_remap.npz"), **out)
 
 
+def make_regrid_fixture():
+    """A regrid as the reference performs it, with the REAL remesher: bamg cleans a seeded mesh (first adaptation,
+    FE.cpp:384-392), the vertices move (shear band, no flipped triangle), Bamgx adapts (FE.cpp:3760-3801).  Stored: both
+    meshes, PreviousNumbering, and what the reference's interpFields computes on them -- ConservativeRemappingMeshToMesh of
+    5 element variables (FE.cpp:3108) and InterpFromMeshToMesh2dx of 6 nodal variables (FE.cpp:3131-3139)."""
+    x, y, tri, ng = cases.rect_mesh(24, 1)
+
+    def sides_mm(x, y, t):
+        s = np.stack([np.hypot(x[t[:, 1]] - x[t[:, 0]], y[t[:, 1]] - y[t[:, 0]]), np.hypot(x[t[:, 2]] - x[t[:, 1]], y[t[:, 2]] - y[t[:, 1]]),
+                      np.hypot(x[t[:, 2]] - x[t[:, 0]], y[t[:, 2]] - y[t[:, 0]])], 1)
+        return s.min(1).mean(), s.max(1).mean()                    # minMaxSide, FE.cpp:343
+    hmin, hmax = sides_mm(x, y, tri)
+    dirf = np.arange(1, ng + 1)
+    xb, yb, trib, _, ngb = O.bamg_adapt(tri + 1, x, y, dirf, x, y, hmin, hmax)
+    rng = np.random.default_rng(4)
+    um = np.zeros((2, xb.size))
+    um[0] = 5e3 * np.tanh((yb - yb.mean()) / 25e3); um[1] = rng.normal(0, 150, xb.size)
+    d = np.minimum.reduce([xb - xb.min(), xb.max() - xb, yb - yb.min(), yb.max() - yb])
+    um *= np.clip(d / 40e3, 0, 1)
+    xm, ym = xb + um[0], yb + um[1]
+    jac = (xm[trib[:, 1]] - xm[trib[:, 0]]) * (ym[trib[:, 2]] - ym[trib[:, 0]]) - (xm[trib[:, 2]] - xm[trib[:, 0]]) * (ym[trib[:, 1]] - ym[trib[:, 0]])
+    assert (jac > 0).all()
+    xc, yc, tric, prev, ngc = O.bamg_adapt(trib + 1, xb, yb, np.arange(1, ngb + 1), xm, ym, hmin, hmax)
+    elt = np.column_stack([rng.random(trib.shape[0]), rng.normal(size=trib.shape[0]) * 1e3, np.ones(trib.shape[0]), rng.random(trib.shape[0]) ** 3,
+                           rng.uniform(0, 4, trib.shape[0])])
+    nod = np.column_stack([rng.normal(0, 0.2, xb.size) for _ in range(6)])
+    out = dict(x_old=xm, y_old=ym, tri_old=trib, x_new=xc, y_new=yc, tri_new=tric, prev=prev, ngeom=np.int32(ngc), elt_in=elt, nod_in=nod)
+    out["elt_out"] = O.bamg_conservative_remap(trib + 1, xm, ym, tric + 1, xc, yc, prev, ngc, elt)
+    out["nod_out"] = O.bamg_interp_mesh_to_mesh(trib + 1, xm, ym, nod, xc, yc, False)
+    np.savez_compressed(os.path.join(HERE, "bamg_regrid.npz"), **out)
+
+
 def mapx_case():
     rng = np.random.default_rng(11)
     x = rng.uniform(-2.6e6, 2.6e6, 600); y = rng.uniform(-2.6e6, 2.6e6, 600)
@@ -156,6 +191,7 @@ def main():
     make_grid_fixture()
     make_remap_fixture()
     make_mapx_fixture()
+    make_regrid_fixture()
 
     out = {}
     for tag, nsteps, over in (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step3", 3, {})):

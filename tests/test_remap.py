@@ -164,3 +164,73 @@ def test_gpu_remapping_matches_live_bamg_on_a_larger_regrid():
     # a barycentre that falls exactly on an old edge in bamg's integer plane may be seeded in the other triangle
     # (walk-dependent tie): same set of contributions, another summation order
     assert same.mean() > 0.999 and np.abs(out - ref).max() < 1e-12
+
+
+# ---- a regrid made by the REAL remesher (Bamgx), tests/golden/bamg_regrid.npz ----
+
+REGRID = os.path.join(os.path.dirname(__file__), "golden", "bamg_regrid.npz")
+
+
+def _seeds_brute(x, y, tri, px, py):
+    out = []
+    for qx, qy in zip(px, py):
+        a = (x[tri[:, 1]] - x[tri[:, 0]]) * (qy - y[tri[:, 0]]) - (y[tri[:, 1]] - y[tri[:, 0]]) * (qx - x[tri[:, 0]])
+        b = (x[tri[:, 2]] - x[tri[:, 1]]) * (qy - y[tri[:, 1]]) - (y[tri[:, 2]] - y[tri[:, 1]]) * (qx - x[tri[:, 1]])
+        c = (x[tri[:, 0]] - x[tri[:, 2]]) * (qy - y[tri[:, 2]]) - (y[tri[:, 0]] - y[tri[:, 2]]) * (qx - x[tri[:, 2]])
+        out.append(int(np.flatnonzero((a >= 0) & (b >= 0) & (c >= 0))[0]))
+    return np.array(out, np.int32)
+
+
+@pytest.mark.skipif(O.bamg_shim() is None, reason="oracle/_ref (real contrib/bamg) not built here")
+def test_real_remesher_reproduces_the_regrid_fixture():
+    import shutil, tempfile
+    keep = tempfile.mkdtemp()
+    shutil.copy(REGRID, os.path.join(keep, "a.npz"))
+    try:
+        make_golden.make_regrid_fixture()
+        a, b = np.load(os.path.join(keep, "a.npz")), np.load(REGRID)
+        assert all(np.array_equal(a[k], b[k]) for k in a.files)
+    finally:
+        shutil.copy(os.path.join(keep, "a.npz"), REGRID)
+
+
+def test_regrid_fixture_is_what_a_regrid_looks_like():
+    z = np.load(REGRID)
+    prev, ng, tn, to = z["prev"], int(z["ngeom"]), z["tri_new"], z["tri_old"]
+    assert ng == 96 and (prev[ng + 1:] >= 0).all() and prev.max() <= z["x_old"].size
+    kept = prev > 0
+    assert 0.5 < kept.mean() < 1.0                                     # KeepVertices = 1: most vertices survive ...
+    d = np.hypot(z["x_new"][kept] - z["x_old"][prev[kept].astype(int) - 1], z["y_new"][kept] - z["y_old"][prev[kept].astype(int) - 1])
+    assert d.max() < 1e-2                                               # ... where they were, up to bamg's integer grid
+    old_sets = {tuple(sorted(r)) for r in to.tolist()}
+    pn = np.where(np.arange(prev.size) > ng, prev.astype(int) - 1, np.arange(prev.size))
+    same = sum(1 for r in tn.tolist() if tuple(sorted(pn[r].tolist())) in old_sets)
+    assert 0.6 < same / tn.shape[0] < 1.0                              # most triangles survive, the sheared band is remeshed
+    assert np.abs(z["elt_out"][:, 2] - 1.).max() < 0.5 and np.median(np.abs(z["elt_out"][:, 2] - 1.)) < 1e-9
+
+
+def test_kernel_functions_on_the_host_match_the_reference_on_a_real_regrid():
+    z = np.load(REGRID)
+    bx = (((0. + z["x_new"][z["tri_new"][:, 0]]) + z["x_new"][z["tri_new"][:, 1]]) + z["x_new"][z["tri_new"][:, 2]]) / 3.
+    by = (((0. + z["y_new"][z["tri_new"][:, 0]]) + z["y_new"][z["tri_new"][:, 1]]) + z["y_new"][z["tri_new"][:, 2]]) / 3.
+    seed = _seeds_brute(z["x_old"], z["y_old"], z["tri_old"], bx, by)
+    case = (z["x_old"], z["y_old"], z["tri_old"], z["x_new"], z["y_new"], z["tri_new"], z["prev"], int(z["ngeom"]), z["elt_in"])
+    out, visits, nf = _host_remap(case, seed)
+    assert nf == 0 and _same(out, z["elt_out"])
+    assert 0.6 < (visits == 1).mean() < 1.0 and visits.max() >= 6
+
+
+@pytest.mark.gpu
+def test_gpu_regrid_kernels_match_the_reference_on_a_real_regrid():
+    """Both regrid kernels on what bamg really produces: element variables (conservative) and nodal variables (P1)."""
+    from nextsim_amd.interp import ConservativeRemappingMeshToMesh, InterpFromMeshToMesh2dx
+    z = np.load(REGRID)
+    out, info = ConservativeRemappingMeshToMesh(z["elt_in"], z["tri_old"] + 1, z["x_old"], z["y_old"], z["tri_new"] + 1, z["x_new"], z["y_new"],
+                                                z["prev"], int(z["ngeom"]), return_info=True)
+    assert info["num_failed"] == 0 and _same(out, z["elt_out"])
+    nod, ninfo = InterpFromMeshToMesh2dx(z["tri_old"] + 1, z["x_old"], z["y_old"], z["nod_in"], z["x_new"], z["y_new"], False, return_info=True)
+    inside = np.ones(z["x_new"].size, bool)
+    inside[:int(z["ngeom"])] = False          # boundary vertices: the reference's walk may end in a hull triangle (documented tie)
+    assert np.array_equal(nod[inside], z["nod_out"][inside])
+    scale = np.abs(z["nod_out"]).max()
+    assert np.abs(nod[~inside] - z["nod_out"][~inside]).max() < 1e-6 * scale
