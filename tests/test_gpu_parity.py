@@ -412,3 +412,38 @@ def test_remesh_on_a_live_handle_equals_a_fresh_handle():
     for k in STATE_KEYS:
         assert np.array_equal(a[k], b[k]), k
     fe.close(); fresh.close()
+
+
+def test_checkpoint_resume_through_restart_files_is_bitwise(tmp_path):
+    """Checkpoint / resume (writeRestart / readRestart, FE.cpp:9518-9925): state -> restart files in
+    the reference's layout -> a NEW handle -> the run continues with the bits of the uninterrupted run."""
+    from nextsim_amd import dynamics, io as nio
+    gm, p, g, lms, fields = cases.make_case("small")
+    lm, f = lms[0], fields[0]
+    fe = dynamics.FiniteElementDynamics(p)
+    fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+    fe.step(); fe.step(); fe.synchronize()
+    st = fe.get_state()
+    names = {"M_conc": "conc", "M_thick": "thick", "M_snow_thick": "snow_thick", "M_sigma_0": "sigma0", "M_sigma_1": "sigma1", "M_sigma_2": "sigma2",
+             "M_damage": "damage", "M_ridge_ratio": "ridge_ratio", "M_conc_young": "conc_young", "M_h_young": "h_young", "M_hs_young": "hs_young",
+             "M_conc_myi": "conc_myi", "M_thick_myi": "thick_myi"}
+    nn = lm.num_nodes
+    nio.write_restart(tmp_path, "step2", lm.coord_x, lm.coord_y, np.arange(1, nn + 1, dtype=np.int32), lm.indices, [2, 10000, 0, 0],
+                      np.flatnonzero(lm.mask_dirichlet[:nn]).astype(np.int32) + 1, 42000.0 + 2 * 200. / 86400., {k: st[v] for k, v in names.items()},
+                      st["VT"], st["UM"], st["UT"], np.arange(1, nn + 1, dtype=np.float64))
+    fe.step(); fe.step(); fe.synchronize()
+    cont = fe.get_state()
+    fe.close()
+    mesh, field = nio.read_restart(tmp_path, "step2")
+    assert np.array_equal(mesh["Elements"], lm.indices.ravel()) and field["Misc_int"][0] == 2
+    f2 = dict(f)
+    for k, v in names.items():
+        f2[v] = field[k]
+    f2["VT"], f2["UM"], f2["UT"] = field["M_VT"], field["M_UM"], field["M_UT"]
+    fe2 = dynamics.FiniteElementDynamics(p)
+    fe2.set_mesh(lm); fe2.put_state(f2); fe2.set_forcing(f2)
+    fe2.step(); fe2.step(); fe2.synchronize()
+    res = fe2.get_state()
+    fe2.close()
+    for k in STATE_KEYS:
+        assert np.array_equal(res[k], cont[k]), k
