@@ -76,8 +76,9 @@ NXS_INTERP_API int nxs_interp_mesh_to_grid(double *griddata, const int32_t *inde
  *              nxs_mesh_element_connectivity, which reproduce bamg's tables
  *   previous_numbering  bamgmesh_root->PreviousNumbering (1-based old number of every new vertex, 0 = new), may be NULL
  *   n_geom_vertices     bamgmesh_root->VerticesOnGeomVertexSize[0]
- *   num_failed (may be NULL)  new triangles whose barycentre is in no old triangle (the reference asserts) or
- *              that overlap more than 96 old triangles; their rows are NaN
+ *   num_failed (may be NULL)  new triangles whose barycentre is in no old triangle (the reference asserts) or that overlap
+ *              more than 4096 old triangles (up to 96: lists in registers/scratch; beyond: a second pass with lists in
+ *              global memory); their rows are NaN
  *   visits (may be NULL) [nels_new]  number of old triangles that contributed (1 = unchanged triangle)
  */
 NXS_INTERP_API int nxs_interp_conservative_remap(double *interp_out, const double *interp_in, int32_t nb_var, const int32_t *index_old,

@@ -454,7 +454,8 @@ struct RemapDev {
 };
 
 // one thread per new triangle: seed, identity test, replay of checkTriangle's recursion, weighted sum
-__global__ void __launch_bounds__(128) k_remap(RemapDev r, const double *__restrict__ in, double *__restrict__ out, int *failed, int *visits) {
+__global__ void __launch_bounds__(128) k_remap(RemapDev r, const double *__restrict__ in, double *__restrict__ out, int *failed, int *visits,
+                                               int *failed_list, int failed_cap) {
     const int t = blockIdx.x * 128 + threadIdx.x;
     if (t >= r.nels_new) return;
     double cx[3], cy[3];
@@ -485,11 +486,34 @@ __global__ void __launch_bounds__(128) k_remap(RemapDev r, const double *__restr
     }
     if (visits) visits[t] = n;
     if (n < 0) {  // barycentre outside the old mesh (the reference asserts) or capacity exceeded: flagged, never silent
-        atomicAdd(failed, 1);
+        const int slot = atomicAdd(failed, 1);
+        if (failed_list && slot < failed_cap) failed_list[slot] = seed >= 0 ? t : ~t;  // ~t: no seed, nothing a second pass can do
         for (int v = 0; v < r.nb_var; ++v) o[v] = __longlong_as_double(0x7ff8000000000000ll);
         return;
     }
     nxs_remap::apply(in, r.nb_var, cx, cy, tris, w, n, o);
+}
+
+// second pass for the new triangles that overlap more than kMaxVisit old ones (a much coarser new mesh): the same
+// walk with lists of kMaxVisitBig entries in global memory, one thread per such triangle
+__global__ void __launch_bounds__(64) k_remap_big(RemapDev r, const double *__restrict__ in, double *__restrict__ out, const int *__restrict__ list, int nlist,
+                                                  int *tris_all, double *w_all, nxs_remap::Frame *stack_all, int *still_failed, int *visits) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nlist) return;
+    const int t = list[i];
+    double cx[3], cy[3], gx = 0., gy = 0.;
+    int nt[3];
+    for (int k = 0; k < 3; ++k) { nt[k] = r.tri_new[3 * t + k]; cx[k] = r.xn[nt[k]]; cy[k] = r.yn[nt[k]]; gx += cx[k]; gy += cy[k]; }
+    gx /= 3.; gy /= 3.;
+    long long dd[3], Bx, By;
+    const int seed = locate(r.loc, gx, gy, dd, Bx, By);
+    int *tris = tris_all + (size_t)i * nxs_remap::kMaxVisitBig;
+    double *w = w_all + (size_t)i * nxs_remap::kMaxVisitBig;
+    nxs_remap::Frame *stack = stack_all + (size_t)i * (nxs_remap::kMaxVisitBig + 1);
+    const int n = seed >= 0 ? nxs_remap::collect(r.m, cx, cy, seed, false, tris, w, stack, nxs_remap::kMaxVisitBig) : -1;
+    if (visits) visits[t] = n;
+    if (n < 0) { atomicAdd(still_failed, 1); return; }
+    nxs_remap::apply(in, r.nb_var, cx, cy, tris, w, n, out + (size_t)t * r.nb_var);
 }
 
 }  // namespace
@@ -562,7 +586,33 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, nullptr);
-    hipLaunchKernelGGL(k_remap, dim3((nels_new + 127) / 128), dim3(128), 0, nullptr, r, (const double *)din.p, dout.p, dfail.p, visits ? dvis.p : nullptr);
+    const int failed_cap = 1 << 16;
+    DevBuf<int> dflist, dstill, dbt;
+    DevBuf<double> dbw;
+    DevBuf<nxs_remap::Frame> dbs;
+    if (dflist.alloc(failed_cap) || dstill.alloc(1) || hipMemset(dstill.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "device allocation failed");
+    hipLaunchKernelGGL(k_remap, dim3((nels_new + 127) / 128), dim3(128), 0, nullptr, r, (const double *)din.p, dout.p, dfail.p, visits ? dvis.p : nullptr,
+                       dflist.p, failed_cap);
+    int nf1 = 0;
+    if (hipMemcpy(&nf1, dfail.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    int unrecoverable = 0, nbig = 0;
+    if (nf1 > 0) {  // the few that exceeded the fast path's capacity: second pass with large lists in global memory
+        std::vector<int> fl(std::min(nf1, failed_cap));
+        if (hipMemcpy(fl.data(), dflist.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+        std::vector<int> big;
+        for (int v : fl) { if (v >= 0) big.push_back(v); else ++unrecoverable; }
+        unrecoverable += nf1 - (int)fl.size();  // more failures than the list holds: left as failures
+        std::sort(big.begin(), big.end());
+        nbig = (int)big.size();
+        const size_t per = (size_t)nxs_remap::kMaxVisitBig;
+        if (nbig > 0) {
+            if (dflist.p && hipMemcpy(dflist.p, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(NXS_ERR_HIP, "upload failed");
+            if (dbt.alloc(nbig * per) || dbw.alloc(nbig * per) || dbs.alloc(nbig * (per + 1)))
+                return fail(NXS_ERR_HIP, "second remapping pass: %d triangles need %zu MB of lists", nbig, nbig * per * 28 >> 20);
+            hipLaunchKernelGGL(k_remap_big, dim3((nbig + 63) / 64), dim3(64), 0, nullptr, r, (const double *)din.p, dout.p, (const int *)dflist.p, nbig, dbt.p, dbw.p,
+                               dbs.p, dstill.p, visits ? dvis.p : nullptr);
+        }
+    }
     (void)hipEventRecord(e1, nullptr);
     hipError_t err = hipDeviceSynchronize();
     float ms = 0.f;
@@ -572,8 +622,8 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
     if (kernel_ms) *kernel_ms = ms;
     if (hipMemcpy(interp_out, dout.p, (size_t)nels_new * nb_var * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     if (visits && hipMemcpy(visits, dvis.p, (size_t)nels_new * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
-    int nf = 0;
-    (void)hipMemcpy(&nf, dfail.p, sizeof(int), hipMemcpyDeviceToHost);
-    if (num_failed) *num_failed = nf;
+    int still = 0;
+    (void)hipMemcpy(&still, dstill.p, sizeof(int), hipMemcpyDeviceToHost);
+    if (num_failed) *num_failed = unrecoverable + still;
     return NXS_OK;
 }

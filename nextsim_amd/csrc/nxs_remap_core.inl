@@ -21,7 +21,8 @@
 
 namespace nxs_remap {
 
-constexpr int kMaxVisit = 96;   // old triangles one new triangle may overlap (reference: unbounded)
+constexpr int kMaxVisit = 96;   // old triangles one new triangle may overlap, fast path (lists in per-thread scratch);
+constexpr int kMaxVisitBig = 4096;  // second pass for the few that exceed it (lists in global memory); reference: unbounded
 constexpr int kMaxPoints = 16;  // 3 nodes + 3 corners + 6 intersections <= 12
 
 struct OldMesh {
@@ -153,8 +154,9 @@ struct Frame {
 
 // One new triangle: corners (cx, cy), the old triangle `seed` that holds its barycentre, `same` = the three
 // vertices are those of the seed (ConservativeRemapping.cpp:263-289).  Fills tris/w in the reference's
-// push order and returns their number, or -1 on capacity overflow.
-NXS_HD inline int collect(const OldMesh &m, const double *cx, const double *cy, int seed, bool same, int *tris, double *w, Frame *stack) {
+// push order and returns their number, or -1 on capacity overflow (cap entries in tris / w, cap + 1 frames).
+NXS_HD inline int collect(const OldMesh &m, const double *cx, const double *cy, int seed, bool same, int *tris, double *w, Frame *stack,
+                          int cap = kMaxVisit) {
     if (same) {
         Pt p[3] = {{cx[0], cy[0]}, {cx[1], cy[1]}, {cx[2], cy[2]}};
         tris[0] = seed;
@@ -221,7 +223,7 @@ NXS_HD inline int collect(const OldMesh &m, const double *cx, const double *cy, 
             if (child < 0) { --sp; continue; }
         }
         if (child >= 0) {
-            if (n >= kMaxVisit) return -1;
+            if (n >= cap) return -1;
             enter(child);
         }
     }

@@ -136,13 +136,23 @@ def test_gpu_remapping_matches_real_bamg_fixture_bit_for_bit(name):
 
 
 @pytest.mark.gpu
-def test_gpu_remapping_reports_what_it_cannot_do():
+def test_gpu_remapping_second_pass_and_what_it_cannot_do():
+    """New triangles that overlap more old ones than the fast path's 96-entry lists are redone by a second pass with
+    4096-entry lists in global memory (a much coarser new mesh); a barycentre outside the old mesh stays a reported
+    failure with a NaN row (the reference asserts there)."""
     from nextsim_amd.interp import ConservativeRemappingMeshToMesh
     x, y, tri, ng = cases.rect_mesh(24, 1)
     xn = np.array([x.min(), x.max(), x.max(), x.min(), x.max() + 5e4]); yn = np.array([y.min(), y.min(), y.max(), y.max(), y.max() + 5e4])
-    trin = np.array([[0, 1, 2], [0, 2, 3], [1, 4, 2]], np.int32)   # two too large, one with its barycentre outside
-    out, info = ConservativeRemappingMeshToMesh(np.ones((tri.shape[0], 2)), tri + 1, x, y, trin + 1, xn, yn, None, 0, return_info=True)
-    assert info["num_failed"] == 3 and np.isnan(out).all()
+    trin = np.array([[0, 1, 2], [0, 2, 3], [1, 4, 2]], np.int32)   # two that cover half the domain each, one with its barycentre outside
+    rng = np.random.default_rng(2)
+    data = np.column_stack([np.ones(tri.shape[0]), rng.random(tri.shape[0])])
+    out, info = ConservativeRemappingMeshToMesh(data, tri + 1, x, y, trin + 1, xn, yn, None, 0, return_info=True)
+    assert info["num_failed"] == 1 and np.isnan(out[2]).all() and not np.isnan(out[:2]).any()
+    assert (info["visits"][:2] > 96).all() and info["visits"][2] < 0
+    assert np.abs(out[:2, 0] - 1.).max() < 0.2                     # a constant stays roughly constant (the reference loses coverage at the boundary)
+    if O.bamg_shim() is not None:                                  # the reference has no capacity: same bits from the second pass
+        ref = O.bamg_conservative_remap(tri + 1, x, y, trin[:2] + 1, xn[:4], yn[:4], np.zeros(4), 0, data)
+        assert np.array_equal(out[:2], ref)
 
 
 @pytest.mark.gpu
