@@ -88,6 +88,25 @@ NXS_INTERP_API int nxs_interp_conservative_remap(double *interp_out, const doubl
                                                  int32_t nels_new, const double *previous_numbering, int32_t n_geom_vertices,
                                                  int32_t device, int32_t *num_failed, int32_t *visits, double *kernel_ms);
 
+/* Structured grid -> mesh: the forcing ingest.  Replaces
+ *
+ *   InterpFromGridToMeshx(data_out, &gridX[0], gridX.size(), &gridY[0], gridY.size(), &data_in[0], gridY.size(), gridX.size(),
+ *                         nb_var*nb_forcing_step, &RX[0], &RY[0], M_target_size, 100000000., interp_type);
+ *
+ * of ExternalData::loadDataset (model/externaldata.cpp:1436; contrib/bamg/src/InterpFromGridToMeshx.cpp:14-485), which
+ * fills M_wind / M_ocean / M_ssh, the forcing inputs of the dynamics.  Same arguments: x_in / y_in are the pixel centres
+ * (x_rows == N, y_rows == M) or their contours (one more entry each: centres are taken); data [M][N][N_data]
+ * (row_major == 0, the call above) or [N][M][N_data]; data_mesh [nods][N_data] CALLER-allocated.  A node takes the
+ * first grid interval that brackets it in x and in y (either orientation of the axes; the last coordinate belongs to the
+ * last interval), then the triangle / bilinear / nearest formula with the reference's operand order -- including its
+ * nearest-neighbour rule, which compares the node with the HALF EXTENT of the cell rather than its centre; NaN and
+ * nodes outside the grid get default_value.  Bit-identical to the reference (tests/test_grid_to_mesh.py). */
+enum { NXS_INTERP_TRIANGLE = 0, NXS_INTERP_BILINEAR = 1, NXS_INTERP_NEAREST = 2 };
+NXS_INTERP_API int nxs_interp_grid_to_mesh(double *data_mesh, const double *x_in, int32_t x_rows, const double *y_in, int32_t y_rows,
+                                           const double *data, int32_t M, int32_t N, int32_t N_data, const double *x_mesh,
+                                           const double *y_mesh, int32_t nods, double default_value, int32_t interp, int32_t row_major,
+                                           int32_t device, double *kernel_ms);
+
 NXS_INTERP_API const char *nxs_interp_last_error(void);
 
 #ifdef __cplusplus

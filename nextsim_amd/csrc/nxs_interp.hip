@@ -627,3 +627,136 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
     if (num_failed) *num_failed = unrecoverable + still;
     return NXS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Structured grid -> mesh nodes: the forcing ingest (InterpFromGridToMeshx, called at externaldata.cpp:1436)
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+struct G2M {
+    const double *x, *y;  // pixel centres, x_rows / y_rows entries
+    int x_rows, y_rows, M, N, N_data, nods, interp, row_major, mono_x, mono_y;
+    double default_value;
+};
+
+// findindices (InterpFromGridToMeshx.cpp:361-395): the FIRST interval that brackets v, either orientation; the last
+// coordinate itself belongs to the last interval.  On a strictly monotone axis that interval is unique: bisection.
+__device__ __forceinline__ bool find_interval(const double *a, int rows, int mono, double v, int &idx) {
+    bool found = false;
+    idx = -1;
+    if (mono != 0) {
+        const bool asc = mono > 0;
+        int lo = 0, hi = rows - 1;  // invariant: the bracketing interval, if any, lies in [lo, hi]
+        if (asc ? (v >= a[0] && v < a[rows - 1]) : (v <= a[0] && v > a[rows - 1])) {
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (asc ? (a[mid] <= v) : (a[mid] >= v)) lo = mid; else hi = mid;
+            }
+            idx = lo;
+            found = true;
+        }
+    } else {
+        for (int i = 0; i < rows - 1; ++i)
+            if (((a[i] <= v) && (v < a[i + 1])) || ((a[i] >= v) && (v > a[i + 1]))) { idx = i; found = true; break; }
+    }
+    if (v == a[rows - 1]) { idx = rows - 2; found = true; }
+    return found;
+}
+
+__global__ void __launch_bounds__(256) k_grid_to_mesh(G2M g, const double *__restrict__ data, const double *__restrict__ xm, const double *__restrict__ ym,
+                                                      double *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.nods) return;
+    const double xg = xm[i], yg = ym[i];
+    double *o = out + (size_t)i * g.N_data;
+    int n, m;
+    const bool fx = find_interval(g.x, g.x_rows, g.mono_x, xg, n), fy = find_interval(g.y, g.y_rows, g.mono_y, yg, m);
+    if (!(fx && fy)) {
+        for (int j = 0; j < g.N_data; ++j) o[j] = g.default_value;
+        return;
+    }
+    int n_min, n_max, m_min, m_max;
+    if (g.x[n] < g.x[n + 1]) { n_min = n; n_max = n + 1; } else { n_min = n + 1; n_max = n; }
+    if (g.y[m] < g.y[m + 1]) { m_min = m; m_max = m + 1; } else { m_min = m + 1; m_max = m; }
+    const double x1 = g.x[n_min], x2 = g.x[n_max], y1 = g.y[m_min], y2 = g.y[m_max];
+    const size_t ND = (size_t)g.N_data;
+    for (int j = 0; j < g.N_data; ++j) {
+        double Q11, Q12, Q21, Q22;
+        if (g.row_major) {
+            Q11 = data[ND * ((size_t)n_min * g.M + m_min) + j]; Q12 = data[ND * ((size_t)n_min * g.M + m_max) + j];
+            Q21 = data[ND * ((size_t)n_max * g.M + m_min) + j]; Q22 = data[ND * ((size_t)n_max * g.M + m_max) + j];
+        } else {
+            Q11 = data[ND * ((size_t)m_min * g.N + n_min) + j]; Q12 = data[ND * ((size_t)m_max * g.N + n_min) + j];
+            Q21 = data[ND * ((size_t)m_min * g.N + n_max) + j]; Q22 = data[ND * ((size_t)m_max * g.N + n_max) + j];
+        }
+        double v;
+        if (g.interp == NXS_INTERP_TRIANGLE) {  // triangleinterp, :397-430
+            const double area = (x2 - x1) * (y2 - y1);
+            if ((xg - x1) / (x2 - x1) < (yg - y1) / (y2 - y1)) {
+                const double area_1 = ((y2 - yg) * (x2 - x1)) / area, area_2 = ((xg - x1) * (y2 - y1)) / area, area_3 = 1 - area_1 - area_2;
+                v = area_1 * Q11 + area_2 * Q22 + area_3 * Q12;
+            } else {
+                const double area_1 = ((yg - y1) * (x2 - x1)) / area, area_2 = ((x2 - xg) * (y2 - y1)) / area, area_3 = 1 - area_1 - area_2;
+                v = area_1 * Q22 + area_2 * Q11 + area_3 * Q21;
+            }
+        } else if (g.interp == NXS_INTERP_BILINEAR) {  // bilinearinterp, :432-455
+            v = +Q11 * (x2 - xg) * (y2 - yg) / ((x2 - x1) * (y2 - y1)) + Q21 * (xg - x1) * (y2 - yg) / ((x2 - x1) * (y2 - y1)) +
+                Q12 * (x2 - xg) * (yg - y1) / ((x2 - x1) * (y2 - y1)) + Q22 * (xg - x1) * (yg - y1) / ((x2 - x1) * (y2 - y1));
+        } else {  // nearestinterp, :457-485 -- xm, ym are HALF EXTENTS compared with absolute coordinates, as the reference does
+            const double xmid = (x2 - x1) / 2, ymid = (y2 - y1) / 2;
+            if (xg <= xmid && yg <= ymid) v = Q11;
+            else if (xg <= xmid && yg > ymid) v = Q12;
+            else if (xg > xmid && yg <= ymid) v = Q21;
+            else v = Q22;
+        }
+        if (isnan(v)) v = g.default_value;
+        o[j] = v;
+    }
+}
+
+int monotone(const double *a, int n) {
+    bool asc = true, desc = true;
+    for (int i = 0; i + 1 < n; ++i) { asc = asc && a[i] < a[i + 1]; desc = desc && a[i] > a[i + 1]; }
+    return asc ? 1 : desc ? -1 : 0;
+}
+
+}  // namespace
+
+extern "C" int nxs_interp_grid_to_mesh(double *data_mesh, const double *x_in, int32_t x_rows, const double *y_in, int32_t y_rows, const double *data,
+                                       int32_t M, int32_t N, int32_t N_data, const double *x_mesh, const double *y_mesh, int32_t nods,
+                                       double default_value, int32_t interp, int32_t row_major, int32_t device, double *kernel_ms) {
+    if (!data_mesh || !x_in || !y_in || !data || !x_mesh || !y_mesh) return fail(NXS_ERR_INVALID, "NULL argument");
+    if ((M < 2) || (N < 2) || (nods <= 0) || N_data < 1) return fail(NXS_ERR_INVALID, "nothing to be done according to the dimensions of input matrices and vectors.");
+    if (interp != NXS_INTERP_TRIANGLE && interp != NXS_INTERP_BILINEAR && interp != NXS_INTERP_NEAREST) return fail(NXS_ERR_INVALID, "Interpolation %d not supported yet", interp);
+    std::vector<double> x(N), y(M);
+    if (N == (x_rows - 1) && M == (y_rows - 1)) {  // contours of the pixels given: take the centres (:44-53)
+        for (int i = 0; i < N; ++i) x[i] = (x_in[i] + x_in[i + 1]) / 2.;
+        for (int i = 0; i < M; ++i) y[i] = (y_in[i] + y_in[i + 1]) / 2.;
+    } else if (N == x_rows && M == y_rows) {
+        for (int i = 0; i < N; ++i) x[i] = x_in[i];
+        for (int i = 0; i < M; ++i) y[i] = y_in[i];
+    } else {
+        return fail(NXS_ERR_INVALID, "x and y vectors length should be 1 or 0 more than data number of rows.");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the interpolation has no CPU path");
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_INVALID, "bad device %d", device);
+    DevBuf<double> dx, dy, dd, dxm, dym, dout;
+    if (dx.upload(x.data(), N) || dy.upload(y.data(), M) || dd.upload(data, (size_t)M * N * N_data) || dxm.upload(x_mesh, nods) || dym.upload(y_mesh, nods) ||
+        dout.alloc((size_t)nods * N_data))
+        return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
+    G2M g{dx.p, dy.p, N, M, M, N, N_data, nods, interp, row_major != 0, monotone(x.data(), N), monotone(y.data(), M), default_value};
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, nullptr);
+    hipLaunchKernelGGL(k_grid_to_mesh, dim3((nods + 255) / 256), dim3(256), 0, nullptr, g, (const double *)dd.p, (const double *)dxm.p, (const double *)dym.p, dout.p);
+    (void)hipEventRecord(e1, nullptr);
+    hipError_t err = hipDeviceSynchronize();
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(NXS_ERR_HIP, "grid-to-mesh kernel failed: %s", hipGetErrorString(err));
+    if (kernel_ms) *kernel_ms = ms;
+    if (hipMemcpy(data_mesh, dout.p, (size_t)nods * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    return NXS_OK;
+}

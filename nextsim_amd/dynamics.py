@@ -106,7 +106,8 @@ EXPORTS = (
     "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
     "nxs_dyn_debug_array", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
 )
-INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_conservative_remap", "nxs_interp_last_error")
+INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
+                  "nxs_interp_last_error")
 
 
 def mesh_connectivity(indices: np.ndarray, num_nodes: int):

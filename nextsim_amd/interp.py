@@ -115,3 +115,30 @@ def ConservativeRemappingMeshToMesh(interp_in, index_old, x_old, y_old, index_ne
     if return_info:
         return out, {"num_failed": nfail.value, "visits": visits, "kernel_ms": ms.value}
     return out
+
+
+TRIANGLE, BILINEAR, NEAREST = 0, 1, 2
+
+
+def InterpFromGridToMeshx(x_in, y_in, data, x_mesh, y_mesh, default_value=1e8, interp=BILINEAR, row_major=False, device=0, return_info=False):
+    """Structured grid -> mesh nodes (forcing ingest), argument meaning of contrib/bamg's InterpFromGridToMeshx
+    (model/externaldata.cpp:1436): data [M, N, N_data] ([N, M, N_data] when row_major), x_in / y_in centres or contours."""
+    L = _lib()
+    if not hasattr(L, "_g2m_declared"):
+        D = _abi.c_double_p
+        L.nxs_interp_grid_to_mesh.argtypes = [D, D, C.c_int32, D, C.c_int32, D, C.c_int32, C.c_int32, C.c_int32, D, D, C.c_int32, C.c_double, C.c_int32,
+                                              C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+        L.nxs_interp_grid_to_mesh.restype = C.c_int
+        L._g2m_declared = True
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
+    x_in, y_in, data, xm, ym = f64(x_in), f64(y_in), f64(data), f64(x_mesh), f64(y_mesh)
+    if data.ndim == 2:
+        data = data[:, :, None]
+    M, N = (data.shape[1], data.shape[0]) if row_major else (data.shape[0], data.shape[1])
+    out = np.empty((xm.size, data.shape[2]))
+    ms = C.c_double(0.0)
+    rc = L.nxs_interp_grid_to_mesh(_abi.dptr(out), _abi.dptr(x_in), x_in.size, _abi.dptr(y_in), y_in.size, _abi.dptr(data), M, N, data.shape[2],
+                                   _abi.dptr(xm), _abi.dptr(ym), xm.size, float(default_value), int(interp), int(bool(row_major)), device, C.byref(ms))
+    if rc:
+        raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
+    return (out, {"kernel_ms": ms.value}) if return_info else out

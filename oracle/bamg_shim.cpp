@@ -178,3 +178,22 @@ int shim_bamg_adapt(const int *index, const double *x0, const double *y0, int no
 }
 
 } /* extern "C" */
+
+#include "InterpFromGridToMeshx.h"
+
+extern "C" {
+
+/* InterpFromGridToMeshx as called by ExternalData::loadDataset (model/externaldata.cpp:1436).  interp: 0 triangle, 1 bilinear, 2 nearest. */
+int shim_bamg_interp_grid_to_mesh(const double *x_in, int x_rows, const double *y_in, int y_rows, const double *data, int M, int N, int N_data,
+                                  const double *x_mesh, const double *y_mesh, int nods, double default_value, int interp, int row_major, double *out) {
+    const int e = interp == 0 ? TriangleInterpEnum : interp == 1 ? BilinearInterpEnum : NearestInterpEnum;
+    double *res = NULL;
+    InterpFromGridToMeshx(res, const_cast<double *>(x_in), x_rows, const_cast<double *>(y_in), y_rows, const_cast<double *>(data), M, N, N_data,
+                          const_cast<double *>(x_mesh), const_cast<double *>(y_mesh), nods, default_value, e, row_major != 0);
+    if (!res) return -1;
+    std::memcpy(out, res, sizeof(double) * (size_t)nods * N_data);
+    delete[] res;
+    return 0;
+}
+
+} /* extern "C" */

@@ -370,3 +370,19 @@ def bamg_adapt(index, x0, y0, dirichlet_flags, x_moved, y_moved, hmin, hmax):
     assert rc == 0, rc
     nn, ne = on.value, oe.value
     return ox[:nn].copy(), oy[:nn].copy(), (oi[:3 * ne].reshape(-1, 3) - 1).astype(np.int32), op[:nn].copy(), og.value
+
+
+def bamg_interp_grid_to_mesh(x_in, y_in, data, x_mesh, y_mesh, default_value=1e8, interp=1, row_major=False):
+    """The REAL InterpFromGridToMeshx (forcing ingest, model/externaldata.cpp:1436).  data [M, N, N_data] (or [N, M, N_data]
+    when row_major); prints a line per node outside the grid, as the reference does."""
+    L = C.CDLL(os.path.join(HERE, "_ref", "libbamg_shim.so"))
+    D = _abi.c_double_p
+    L.shim_bamg_interp_grid_to_mesh.argtypes = [D, C.c_int, D, C.c_int, D, C.c_int, C.c_int, C.c_int, D, D, C.c_int, C.c_double, C.c_int, C.c_int, D]
+    f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
+    x_in, y_in, data, xm, ym = f64(x_in), f64(y_in), f64(data), f64(x_mesh), f64(y_mesh)
+    M, N = (data.shape[1], data.shape[0]) if row_major else (data.shape[0], data.shape[1])
+    out = np.empty((xm.size, data.shape[2]))
+    rc = L.shim_bamg_interp_grid_to_mesh(_abi.dptr(x_in), x_in.size, _abi.dptr(y_in), y_in.size, _abi.dptr(data), M, N, data.shape[2], _abi.dptr(xm),
+                                         _abi.dptr(ym), xm.size, float(default_value), int(interp), int(bool(row_major)), _abi.dptr(out))
+    assert rc == 0
+    return out

@@ -14,6 +14,8 @@
   bamg_regrid.npz        a regrid made by the REAL remesher (Bamgx as adaptMesh calls it): both meshes, PreviousNumbering, and the
                          reference's interpFields results on them (conservative remap of 5 element variables, P1 interpolation of 6
                          nodal variables) -- pins both regrid kernels on what bamg really produces.
+  bamg_grid_to_mesh.npz  REAL contrib/bamg InterpFromGridToMeshx (forcing ingest, externaldata.cpp:1436): bilinear / triangle /
+                         nearest, descending axes, pixel contours, NaN data, row-major data, nodes on grid lines and outside.
   mapx_lat.npz           REAL contrib/mapx inverse_mapx with mesh/NpsNextsim.mpp (GmshMesh::lat(), gmshmesh.cpp:1798-1824) at
                          600 points -- pins the latitude (Coriolis, sign of the turning angle) of the synthetic meshes.
   oracle_tiny.npz        oracle (liboracle.so) state on the 'tiny' toy case after 1 sub-step, 1 step
@@ -168,6 +170,31 @@ def make_regrid_fixture():
     np.savez_compressed(os.path.join(HERE, "bamg_regrid.npz"), **out)
 
 
+def grid_to_mesh_cases():
+    """Seeded forcing-ingest cases (shared with tests/test_grid_to_mesh.py): name -> (x_in, y_in, data, x_mesh, y_mesh, interp, row_major)."""
+    rng = np.random.default_rng(21)
+    gm = cases.global_mesh("small")
+    xs = np.linspace(gm.x.min() - 30e3, gm.x.max() + 30e3, 41); ys = np.linspace(gm.y.max() + 30e3, gm.y.min() - 30e3, 33)   # y descending, as many datasets
+    X, Y = np.meshgrid(xs, ys)
+    data = np.stack([1e-5 * X - 2e-5 * Y, np.sin(X / 2e5) * np.cos(Y / 3e5), rng.normal(size=X.shape)], 2)    # [M=33, N=41, 3]
+    xm, ym = gm.x.copy(), gm.y.copy()
+    xm[:4] = [xs[0], xs[-1], xs[5], xs[0] - 1e3]; ym[:4] = [ys[0], ys[-1], ys[7], ys[3]]     # corners, a grid line, one node outside
+    out = {"bilinear": (xs, ys, data, xm, ym, 1, False), "triangle": (xs, ys, data, xm, ym, 0, False), "nearest": (xs, ys, data, xm, ym, 2, False)}
+    # pixel contours (one more coordinate than data columns / rows) and NaN data
+    xc = np.linspace(xs[0], xs[-1], 42); yc = np.linspace(ys[0], ys[-1], 34)
+    d2 = data.copy(); d2[10:12, 20:22, 1] = np.nan
+    out["contours_nan"] = (xc, yc, d2, xm, ym, 1, False)
+    out["row_major"] = (xs, ys[::-1].copy(), np.ascontiguousarray(np.transpose(data[::-1], (1, 0, 2))), xm, ym, 1, True)
+    return out
+
+
+def make_grid_to_mesh_fixture():
+    out = {}
+    for name, (xs, ys, data, xm, ym, interp, rm) in grid_to_mesh_cases().items():
+        out[name] = O.bamg_interp_grid_to_mesh(xs, ys, data, xm, ym, 1e8, interp, rm)
+    np.savez_compressed(os.path.join(HERE, "bamg_grid_to_mesh.npz"), **out)
+
+
 def mapx_case():
     rng = np.random.default_rng(11)
     x = rng.uniform(-2.6e6, 2.6e6, 600); y = rng.uniform(-2.6e6, 2.6e6, 600)
@@ -191,6 +218,7 @@ def main():
     make_grid_fixture()
     make_remap_fixture()
     make_mapx_fixture()
+    make_grid_to_mesh_fixture()
     make_regrid_fixture()
 
     out = {}
