@@ -2221,11 +2221,14 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
     const size_t bytes = (4 * tr + (size_t)std::max(nr, 1) + 16) * sizeof(double);  // 2 buffers of 2*tr doubles + flags
     // uncached (MTYPE_UC) device memory: neither my L2 nor a neighbour's can hold a stale copy of a
     // mailbox line or a flag; plain device memory as a fallback (the kernels use system-scope accesses anyway)
+    bool uncached = true;
     if (hipExtMallocWithFlags(&h->ipc_block, bytes, hipDeviceMallocUncached) != hipSuccess) {
         (void)hipGetLastError();
         h->ipc_block = nullptr;
+        uncached = false;
         HIPCHK(h, hipMalloc(&h->ipc_block, bytes));
     }
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d mailbox: %zu bytes, %s\n", h->rank, bytes, uncached ? "uncached (MTYPE_UC)" : "plain hipMalloc (uncached allocation refused)");
     HIPCHK(h, hipMemset(h->ipc_block, 0, bytes));
     HIPCHK(h, hipDeviceSynchronize());
     h->ipc_block_bytes = bytes;
