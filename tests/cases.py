@@ -14,13 +14,27 @@ def global_mesh(kind):
     return _cache[kind]
 
 
-def make_case(kind="small", forcing_kind=None, nparts=1, alea=0.33, **param_over):
+def ragged_partition(gm, nparts, seed):
+    """An element partition nobody would choose: a coarse random mosaic (blocks of ~40 elements thrown at random ranks), so
+    that every rank has every other rank as a neighbour, several disconnected pieces, ghost elements without any owned node
+    and boundary nodes shared by three or more ranks -- the corner cases of the halo lists."""
+    rng = np.random.default_rng(seed)
+    cx = gm.x[gm.tri].mean(1); cy = gm.y[gm.tri].mean(1)
+    nb = max(4, int(np.sqrt(gm.num_elements / 40.)))
+    ix = np.minimum(((cx - cx.min()) / (np.ptp(cx) + 1e-9) * nb).astype(int), nb - 1)
+    iy = np.minimum(((cy - cy.min()) / (np.ptp(cy) + 1e-9) * nb).astype(int), nb - 1)
+    owner = rng.integers(0, nparts, (nb, nb))
+    owner.flat[:nparts] = np.arange(nparts)          # nobody is empty
+    return owner[ix, iy].astype(np.int32)
+
+
+def make_case(kind="small", forcing_kind=None, nparts=1, alea=0.33, ragged_seed=None, **param_over):
     gm = global_mesh(kind)
     forcing_kind = forcing_kind or ("toy" if kind in ("toy", "tiny") else "arctic")
     p = F.default_params(**param_over)
     p, C_fix, C_alea = F.scale_params_to_mesh(p, gm, alea_factor=alea)
     g = F.global_fields(gm, p, forcing_kind, C_fix, C_alea)
-    lms = M.localize(gm, nparts)
+    lms = M.localize(gm, nparts, elem_part=ragged_partition(gm, nparts, ragged_seed) if ragged_seed is not None else None)
     fields = [F.localize_fields(g, lm, gm.num_nodes) for lm in lms]
     return gm, p, g, lms, fields
 

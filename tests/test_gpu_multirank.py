@@ -66,6 +66,19 @@ def test_partitioned_gpu_run_device_direct_halo_matches_multirank_oracle(world, 
             assert e <= 1e-10, (r["rank"], k, e)
 
 
+@pytest.mark.parametrize("world,seed", [(3, 1), (4, 2)])
+def test_device_direct_halo_on_a_ragged_partition(world, seed, tmp_path):
+    """A random mosaic partition: every rank neighbours every other, disconnected pieces, ghost elements without owned
+    nodes (orphan patches), nodes shared by 3+ ranks.  In-kernel exchange == separate kernels == multi-rank oracle."""
+    reps = _run(world, "small", 1, tmp_path, "ipc", over={"ragged_seed": seed})
+    for r in reps:
+        assert r["ok"], r
+        assert r["fused_equals_separate"] is True, r
+        assert r["crash"] == 0
+        for k, e in r["errs"].items():
+            assert e <= 1e-10, (r["rank"], k, e)
+
+
 @pytest.mark.parametrize("dyn", ["mevp", "evp"])
 def test_in_kernel_halo_exchange_with_the_vp_rheologies(dyn, tmp_path):
     """mEVP moves the mesh once after the sub-step loop (no ring of velocity buffers: the ghosts are copied through
