@@ -115,6 +115,7 @@ struct DevWork {
     double *prec /*[Ne][10]: what k_prep_nodes gathers per fan entry, one record per element (see k_prep_elements)*/;
     double *expC, *pmax, *heal, *dxs, *volume;  // per-step element constants of the sub-step loop
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
+    int *dxi;                                    // BBM, fused kernel: M_delta_x as the integer it is (Q1), ~M_delta_x when the element is skipped
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
     double *xs, *ys;  // [Nn] node coordinates on the displaced mesh at step start (frozen over the sub-steps, Q4)
@@ -157,6 +158,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
     acc = (int)(acc + side0);
     acc = (int)(acc + side1);
     acc = (int)(acc + side2);
+    const int acc_div3 = (int)((unsigned long)acc / 3ul);
     const double delta_x = (double)((unsigned long)acc / 3ul);
     w.delta_x[e] = delta_x;
 
@@ -241,6 +243,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
         w.heal[e] = p.dte / s.theal[e] * expC;                                 // FE.cpp:4257
         w.dxs[e] = delta_x * p.sqrt_nu_rhoi;                                   // FE.cpp:4232
         w.eskip[e] = (conc <= 0.1) ? 1 : 0;                                    // Q5, FE.cpp:4146-4151
+        w.dxi[e] = (conc <= 0.1) ? ~acc_div3 : acc_div3;                       // 4 bytes instead of 9 for the fused kernel
     } else {
         w.expC[e] = p.evp_Pstar * exp(-p.evp_C * (1. - conc));                 // FE.cpp:10684 (P)
         w.eskip[e] = (thick == 0.) ? 1 : 0;                                    // FE.cpp:10656
@@ -718,17 +721,22 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         const int e = writer ? eraw : ~eraw;
         double dxN[6], sig[3] = {0., 0., 0.}, damage = 0., c_expC = 0., c_pmax = 0., c_heal = 0., c_dxs = 1., c_coh = 0., volume = 0.;
         bool skip = true;
+        int dxi = 0;
         if (active) {
-            skip = w.eskip[e];
+            if (!bbm) skip = w.eskip[e];
             sig[0] = ldg<NT_S>(b.s0c + e); sig[1] = ldg<NT_S>(b.s1c + e); sig[2] = ldg<NT_S>(b.s2c + e);
             if (bbm) damage = ldg<NT_S>(b.dc + e);
             c_expC = ldg<NT_C>(w.expC + e);
             volume = ldg<NT_C>(w.volume + e);
             if (bbm) {
-                c_pmax = ldg<NT_C>(w.pmax + e); c_heal = ldg<NT_C>(w.heal + e); c_dxs = ldg<NT_C>(w.dxs + e); c_coh = ldg<NT_C>(s.cohesion + e);
+                c_pmax = ldg<NT_C>(w.pmax + e); c_heal = ldg<NT_C>(w.heal + e); dxi = w.dxi[e]; c_coh = ldg<NT_C>(s.cohesion + e);
             }
         }
         if (base == 0) { __syncthreads(); NXS_STAMP(1); }  // staged velocities / coordinates visible
+        if (active && bbm) {  // M_delta_x is an integer number of metres (Q1) and travels as one, with the skip flag in its sign
+            skip = dxi < 0;
+            c_dxs = (double)(skip ? ~dxi : dxi) * p.sqrt_nu_rhoi;  // == w.dxs[e], FE.cpp:4232
+        }
         if (active) {
             {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates: the same operations as
                 // k_prep_elements, so the same bits as M_shape_coeff -- 48 B/element less to stream
@@ -2082,7 +2090,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
     A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 10 * ne);
-    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne);
+    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne);
     A(w.force, 6 * ne);
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
     A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.xs, (size_t)Nn); A(w.ys, (size_t)Nn); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
