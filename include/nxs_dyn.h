@@ -226,6 +226,14 @@ NXS_API int nxs_dyn_set_halo_exchange_fn(nxs_dyn_handle *h, nxs_dyn_halo_fn fn, 
 NXS_API int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s);
 NXS_API int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s);
 NXS_API int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f);
+/* Forcing that is interpolated linearly in time (ExternalData::get, model/externaldata.cpp:360-401) without a host->device
+ * copy per step: the two snapshots of a forcing interval (dataset->variables[].interpolated_data[0] and [1] of M_wind,
+ * M_ocean, M_ssh; element_depth of f0, a constant dataset) become resident once per interval, and every step only passes
+ *   fcoeff[0] = |t - ftime_range[1]| / fdt,  fcoeff[1] = |t - ftime_range[0]| / fdt,
+ * M_factor (spin-up ramp, Q10) and M_bias_correction of {wind, ocean, ssh} (NULL = 1 and 0); the device evaluates
+ *   M_factor*(fcoeff[0]*d0[i] + fcoeff[1]*d1[i]) + M_bias_correction      -- the reference's expression, same bits. */
+NXS_API int nxs_dyn_set_forcing_pair(nxs_dyn_handle *h, const nxs_dyn_forcing *f0, const nxs_dyn_forcing *f1);
+NXS_API int nxs_dyn_set_forcing_time(nxs_dyn_handle *h, double fcoeff0, double fcoeff1, const double factor[3], const double bias[3]);
 NXS_API int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *d);
 
 /* One dynamics step on the device-resident state: FE.cpp:8197-8214.  Asynchronous on the

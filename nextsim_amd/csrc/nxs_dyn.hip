@@ -1351,6 +1351,20 @@ __global__ void __launch_bounds__(BLOCK) k_check_fields(DevMesh m, DevState s, D
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(crash, 1);
 }
 
+
+// ExternalData::get for a dataset that is interpolated linearly in time (model/externaldata.cpp:360-401):
+//   value = M_factor*(fcoeff[0]*interpolated_data[0][i] + fcoeff[1]*interpolated_data[1][i]) + M_bias_correction
+// for M_wind, M_ocean (2Nn) and M_ssh (Nn), evaluated on the device from two resident snapshots.
+struct ForcingBlend { const double *w0, *w1, *o0, *o1, *s0, *s1; double c0, c1, factor[3], bias[3]; };
+__global__ void __launch_bounds__(BLOCK) k_blend_forcing(int Nn, ForcingBlend b, double *__restrict__ wind, double *__restrict__ ocean, double *__restrict__ ssh) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < 2 * Nn) {
+        wind[i] = b.factor[0] * (b.c0 * b.w0[i] + b.c1 * b.w1[i]) + b.bias[0];
+        ocean[i] = b.factor[1] * (b.c0 * b.o0[i] + b.c1 * b.o1[i]) + b.bias[1];
+    }
+    if (i < Nn) ssh[i] = b.factor[2] * (b.c0 * b.s0[i] + b.c1 * b.s1[i]) + b.bias[2];
+}
+
 // ================================================================================================
 // host side
 
@@ -1424,6 +1438,9 @@ struct nxs_dyn_handle {
     std::vector<void *> ipc_allocs;
     int *d_recv_procs = nullptr;
     // halo exchange fused into the sub-step kernel (device-direct transport + fused path)
+    double *f_snap[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // wind0, wind1, ocean0, ocean1, ssh0, ssh1 (forcing pair)
+    bool have_pair = false;
+    std::vector<void *> forcing_allocs;
     int halo_fused = 1;                    // option "halo_fused"
     bool hf_ready = false;
     HaloFused hf{};
@@ -1900,6 +1917,9 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
+    free_pool(h->forcing_allocs);
+    for (auto &q : h->f_snap) q = nullptr;
+    h->have_pair = false;
     if (h->h_send) (void)hipHostFree(h->h_send);
     if (h->h_recv) (void)hipHostFree(h->h_recv);
     if (h->d_partials) (void)hipFree(h->d_partials);
@@ -1977,6 +1997,9 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
+    free_pool(h->forcing_allocs);
+    for (auto &q : h->f_snap) q = nullptr;
+    h->have_pair = false;
     h->ring = VTRing{};
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
     h->rank = 0; h->nranks = 1;
@@ -2378,6 +2401,34 @@ int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f) {
     HIPCHK(h, hipMemcpyAsync(h->ds.ssh, f->ssh, Nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->ds.depth, f->element_depth, Ne * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_forcing = true;
+    return NXS_OK;
+}
+
+int nxs_dyn_set_forcing_pair(nxs_dyn_handle *h, const nxs_dyn_forcing *f0, const nxs_dyn_forcing *f1) {
+    if (!h || !f0 || !f1) return NXS_ERR_INVALID;
+    if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "set_forcing_pair before set_mesh");
+    if (!f0->wind || !f0->ocean || !f0->ssh || !f0->element_depth || !f1->wind || !f1->ocean || !f1->ssh) return fail(h, NXS_ERR_INVALID, "forcing has NULL arrays");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t Nn = h->dm.Nn, Ne = h->dm.Ne;
+    const size_t len[6] = {2 * Nn, 2 * Nn, 2 * Nn, 2 * Nn, Nn, Nn};
+    const double *src[6] = {f0->wind, f1->wind, f0->ocean, f1->ocean, f0->ssh, f1->ssh};
+    if (!h->f_snap[0])
+        for (int k = 0; k < 6; ++k) { int rc = dev_alloc(h, h->forcing_allocs, &h->f_snap[k], len[k]); if (rc) return rc; }
+    for (int k = 0; k < 6; ++k) HIPCHK(h, hipMemcpyAsync(h->f_snap[k], src[k], len[k] * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(h->ds.depth, f0->element_depth, Ne * sizeof(double), hipMemcpyHostToDevice, h->stream));  // a "constant" dataset
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->have_pair = true;
+    return NXS_OK;
+}
+
+int nxs_dyn_set_forcing_time(nxs_dyn_handle *h, double fcoeff0, double fcoeff1, const double factor[3], const double bias[3]) {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->have_pair) return fail(h, NXS_ERR_STATE, "set_forcing_time before set_forcing_pair");
+    HIPCHK(h, hipSetDevice(h->device));
+    ForcingBlend b{h->f_snap[0], h->f_snap[1], h->f_snap[2], h->f_snap[3], h->f_snap[4], h->f_snap[5], fcoeff0, fcoeff1, {1., 1., 1.}, {0., 0., 0.}};
+    for (int k = 0; k < 3; ++k) { if (factor) b.factor[k] = factor[k]; if (bias) b.bias[k] = bias[k]; }
+    hipLaunchKernelGGL(k_blend_forcing, dim3(nblocks(2 * h->dm.Nn)), dim3(BLOCK), 0, h->stream, h->dm.Nn, b, h->ds.wind, h->ds.ocean, h->ds.ssh);
     h->have_forcing = true;
     return NXS_OK;
 }

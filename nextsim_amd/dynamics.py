@@ -72,6 +72,8 @@ def load_library():
     L.nxs_dyn_update.argtypes = [H]
     L.nxs_dyn_synchronize.argtypes = [H]
     L.nxs_dyn_step_host.argtypes = [H, P(_abi.State), P(_abi.Forcing)]
+    L.nxs_dyn_set_forcing_pair.argtypes = [H, P(_abi.Forcing), P(_abi.Forcing)]
+    L.nxs_dyn_set_forcing_time.argtypes = [H, C.c_double, C.c_double, P(C.c_double), P(C.c_double)]
     L.nxs_dyn_check_regridding.argtypes = [H, P(C.c_double), P(C.c_int32), P(C.c_int32)]
     L.nxs_dyn_check_fields_fast.argtypes = [H, P(C.c_int32)]
     L.nxs_dyn_get_timing.argtypes = [H, P(_abi.Timing)]
@@ -101,7 +103,8 @@ EXPORTS = (
     "nxs_dyn_set_halo_exchange_fn", "nxs_dyn_ipc_export", "nxs_dyn_ipc_connect", "nxs_dyn_ipc_selftest",
     "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_create", "nxs_dyn_destroy",
     "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init",
-    "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_get_diag", "nxs_dyn_step",
+    "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_set_forcing_pair", "nxs_dyn_set_forcing_time",
+    "nxs_dyn_get_diag", "nxs_dyn_step",
     "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
     "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
     "nxs_dyn_debug_array", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
@@ -274,6 +277,18 @@ class FiniteElementDynamics:
     def set_forcing(self, arrays: dict):
         f = _abi.forcing_struct(arrays)
         self._chk(self.L.nxs_dyn_set_forcing(self.h, C.byref(f)))
+
+    def set_forcing_pair(self, arrays0: dict, arrays1: dict):
+        """The two snapshots of a forcing interval become resident (ExternalData's interpolated_data[0], [1])."""
+        f0, f1 = _abi.forcing_struct(arrays0), _abi.forcing_struct(arrays1)
+        self._keep_forcing = (arrays0, arrays1)
+        self._chk(self.L.nxs_dyn_set_forcing_pair(self.h, C.byref(f0), C.byref(f1)))
+
+    def set_forcing_time(self, fcoeff0: float, fcoeff1: float, factor=None, bias=None):
+        """Per step: M_factor*(fcoeff0*d0 + fcoeff1*d1) + M_bias_correction on the device (externaldata.cpp:360-401)."""
+        fa = (C.c_double * 3)(*factor) if factor is not None else None
+        bi = (C.c_double * 3)(*bias) if bias is not None else None
+        self._chk(self.L.nxs_dyn_set_forcing_time(self.h, float(fcoeff0), float(fcoeff1), fa, bi))
 
     def get_state(self) -> dict:
         Nn, Ne = self.lm.num_nodes, self.lm.num_elements

@@ -447,3 +447,35 @@ def test_checkpoint_resume_through_restart_files_is_bitwise(tmp_path):
     fe2.close()
     for k in STATE_KEYS:
         assert np.array_equal(res[k], cont[k]), k
+
+
+def test_time_interpolated_forcing_on_the_device_equals_host_evaluation():
+    """nxs_dyn_set_forcing_pair + nxs_dyn_set_forcing_time (two resident snapshots, blended per step on the device with
+    ExternalData::get's expression, externaldata.cpp:360-401) against uploading the host-evaluated arrays every step."""
+    from nextsim_amd import dynamics
+    gm, p, g, lms, fields = cases.make_case("small")
+    lm, f0 = lms[0], fields[0]
+    rng = np.random.default_rng(3)
+    f1 = dict(f0)
+    f1["wind"] = f0["wind"] * 1.3 + rng.normal(0, 1.0, f0["wind"].size); f1["ocean"] = f0["ocean"] * 0.7; f1["ssh"] = f0["ssh"] + rng.normal(0, 0.01, f0["ssh"].size)
+    factor, bias = (0.625, 1.0, 1.0), (0.0, 0.0, 0.003)         # a spin-up ramp on the wind, a bias on ssh
+    t0, t1, times = 100.0, 100.25, (100.03125, 100.0625, 100.2)
+    a = dynamics.FiniteElementDynamics(p); b = dynamics.FiniteElementDynamics(p)
+    for fe in (a, b):
+        fe.set_mesh(lm); fe.put_state(f0)
+    b.set_forcing_pair(f0, f1)
+    for t in times:
+        fdt = abs(t1 - t0)
+        c0, c1 = abs(t - t1) / fdt, abs(t - t0) / fdt
+        host = dict(f0)
+        for k, (fa, bi) in zip(("wind", "ocean", "ssh"), zip(factor, bias)):
+            host[k] = fa * (c0 * f0[k] + c1 * f1[k]) + bi
+        a.set_forcing(host); a.step()
+        b.set_forcing_time(c0, c1, factor, bias); b.step()
+    a.synchronize(); b.synchronize()
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(sa[k], sb[k]), k
+    with pytest.raises(Exception, match="set_forcing_pair"):
+        c = dynamics.FiniteElementDynamics(p); c.set_mesh(lm); c.set_forcing_time(0.5, 0.5)
+    a.close(); b.close()
