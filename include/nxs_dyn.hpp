@@ -26,6 +26,12 @@ public:
     void putState(const nxs_dyn_state &s) { check(nxs_dyn_put_state(h_, &s), "put_state"); }
     void getState(nxs_dyn_state &s) { check(nxs_dyn_get_state(h_, &s), "get_state"); }
     void setForcing(const nxs_dyn_forcing &f) { check(nxs_dyn_set_forcing(h_, &f), "set_forcing"); }
+    // ExternalData's two snapshots resident + the per-step time coefficients (externaldata.cpp:360-401)
+    void setForcingPair(const nxs_dyn_forcing &f0, const nxs_dyn_forcing &f1) { check(nxs_dyn_set_forcing_pair(h_, &f0, &f1), "set_forcing_pair"); }
+    void setForcingTime(double fcoeff0, double fcoeff1, const double *factor = nullptr, const double *bias = nullptr) {
+        check(nxs_dyn_set_forcing_time(h_, fcoeff0, fcoeff1, factor, bias), "set_forcing_time");
+    }
+    void setOption(const char *key, long long value) { check(nxs_dyn_set_option(h_, key, value), "set_option"); }
     void getDiag(nxs_dyn_diag &d) { check(nxs_dyn_get_diag(h_, &d), "get_diag"); }
 
     void explicitSolve() { check(nxs_dyn_explicit_solve(h_), "explicitSolve"); }               // FE.cpp:10182-10643
