@@ -479,3 +479,34 @@ def test_time_interpolated_forcing_on_the_device_equals_host_evaluation():
     with pytest.raises(Exception, match="set_forcing_pair"):
         c = dynamics.FiniteElementDynamics(p); c.set_mesh(lm); c.set_forcing_time(0.5, 0.5)
     a.close(); b.close()
+
+
+def test_handles_give_their_device_memory_back():
+    """create -> set_mesh (twice: a regrid) -> halo-less step -> regrid interpolation -> destroy, 15 times: the free device
+    memory afterwards is what it was (every pool of the handle is released; the one-shot entry points free what they take)."""
+    import ctypes as C
+    from nextsim_amd import dynamics
+    from nextsim_amd.interp import InterpFromMeshToMesh2dx
+    L = dynamics.load_library()
+    L.hipMemGetInfo.argtypes = [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+
+    def free_bytes():
+        a, b = C.c_size_t(), C.c_size_t()
+        assert L.hipMemGetInfo(C.byref(a), C.byref(b)) == 0
+        return a.value
+    gm, p, g, lms, fields = cases.make_case("small")
+    gm2, p2, g2, lms2, f2 = cases.make_case("toy")
+
+    def cycle():
+        fe = dynamics.FiniteElementDynamics(p)
+        fe.set_mesh(lms[0]); fe.put_state(fields[0]); fe.set_forcing(fields[0]); fe.step()
+        fe.set_forcing_pair(fields[0], fields[0]); fe.set_forcing_time(0.5, 0.5); fe.step()
+        fe.set_params(p2); fe.set_mesh(lms2[0]); fe.put_state(f2[0]); fe.set_forcing(f2[0]); fe.step(); fe.synchronize()
+        fe.close()
+        InterpFromMeshToMesh2dx(gm.tri + 1, gm.x, gm.y, np.ones((gm.num_nodes, 2)), gm.x[:100], gm.y[:100], False)
+    cycle()                      # first use: runtime-internal allocations (code objects, graph pools) settle
+    before = free_bytes()
+    for _ in range(15):
+        cycle()
+    after = free_bytes()
+    assert before - after < 8 << 20, (before, after)
