@@ -27,5 +27,9 @@ def write_case(path: str, lm, params: _abi.Params, fields: dict) -> None:
         rec("indices", lm.indices); rec("ghost_nodes", lm.ghost_nodes)
         rec("coord_x", lm.coord_x); rec("coord_y", lm.coord_y); rec("lat", lm.lat)
         rec("mask_dirichlet", lm.mask_dirichlet); rec("neumann_flags", lm.neumann_flags)
+        # halo lists of initUpdateGhosts() (FE.hpp:615-618), for multi-rank hosts (examples/nextsim_mpi.cpp)
+        rec("halo_rank", np.array([lm.rank, lm.nranks], np.int32))
+        for k in ("send_procs", "send_offsets", "send_index", "recv_procs", "recv_offsets", "recv_index"):
+            rec(k, np.ascontiguousarray(getattr(lm, k), np.int32))
         for k, v in fields.items():
             rec(k, np.asarray(v, np.float64))

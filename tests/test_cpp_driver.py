@@ -60,3 +60,68 @@ def test_cpp_driver_runs_config1_and_matches_python_path(tmp_path):
     ref = O.OracleRank(lm, p, f); ref.step()
     for k in ("VT", "sigma0", "damage", "conc"):
         assert cases.rel_err(rec1["M_" + k], ref.arr[k]) <= 1e-10, k
+
+
+# ---- the multi-rank host: C++ + MPI (the reference's Boost.MPI sits on the same MPI) ----
+
+MPI_LIB = "/opt/conda/lib/libmpi.so.12"
+MPIEXEC = "/opt/conda/bin/mpiexec"
+needs_mpi = pytest.mark.skipif(not (os.path.exists(MPI_LIB) and os.path.exists(MPIEXEC) and os.path.exists("/opt/conda/include/mpi.h")),
+                               reason="no MPICH in this image")
+
+
+def _build_mpi(tmp_path):
+    """g++ against MPICH's headers and library by full path: the image's mpicxx wrapper wants a conda compiler that is not
+    there, and -L/opt/conda/lib would put conda's old libstdc++ in front of the system's.  The run-time search path gets a
+    directory that holds nothing but links to libmpi and its Fortran run-time."""
+    exe = str(tmp_path / "nextsim_mpi")
+    lib = os.path.join(ROOT, "nextsim_amd", "csrc")
+    only = tmp_path / "mpilib"
+    only.mkdir(exist_ok=True)
+    for name in ("libmpi.so.12", "libgfortran.so.4", "libquadmath.so.0"):      # libmpi and the two Fortran run-time libraries it drags in
+        if not (only / name).exists() and os.path.exists("/opt/conda/lib/" + name):
+            os.symlink("/opt/conda/lib/" + name, only / name)
+    subprocess.check_call(["g++", "-std=c++14", "-O2", "-I", os.path.join(ROOT, "include"), "-I", "/opt/conda/include",
+                           os.path.join(ROOT, "examples", "nextsim_mpi.cpp"), "-L", lib, "-lnxsdyn", MPI_LIB, f"-Wl,-rpath,{lib}", f"-Wl,-rpath,{only}", "-o", exe])
+    return exe
+
+
+@needs_mpi
+def test_mpi_host_builds_and_refuses_a_foreign_case_file(tmp_path):
+    """No GPU needed: one MPI rank, a case file written for rank 1 of 2 -> refused before anything touches a device."""
+    from nextsim_amd import casefile
+    exe = _build_mpi(tmp_path)
+    gm, p, g, lms, fields = cases.make_case("tiny", nparts=2)
+    casefile.write_case(str(tmp_path / "case_0.bin"), lms[1], p, fields[1])
+    r = subprocess.run([MPIEXEC, "-n", "1", exe, str(tmp_path / "case_%d.bin"), "1", str(tmp_path / "out_%d.bin")], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "another rank" in r.stderr
+
+
+@needs_mpi
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 3])
+def test_mpi_host_runs_a_partitioned_case_and_matches_the_multirank_oracle(world, tmp_path):
+    """mpiexec -n N ./nextsim_mpi: every rank creates its handle, exchanges mailbox handles and receive lists with
+    MPI_Allgather(v), runs the mailbox self-test and two steps with the halo exchange inside the sub-step kernel."""
+    from nextsim_amd import casefile
+    from oracle import pyoracle as O
+    exe = _build_mpi(tmp_path)
+    gm, p, g, lms, fields = cases.make_case("small", nparts=world)
+    for r in range(world):
+        casefile.write_case(str(tmp_path / f"case_{r}.bin"), lms[r], p, fields[r])
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([MPIEXEC, "-n", str(world), exe, str(tmp_path / "case_%d.bin"), "2", str(tmp_path / "out_%d.bin")], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert res.returncode == 0, (res.stdout[-1000:], res.stderr[-3000:])
+    ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    for _ in range(2):
+        O.multirank_step(ranks)
+    keys = ("VT", "UM", "UT", "sigma0", "sigma1", "sigma2", "damage", "conc", "thick")
+    for r in range(world):
+        raw = np.fromfile(str(tmp_path / f"out_{r}.bin"))
+        pos = 0
+        for k in keys:
+            n = ranks[r].arr[k].size
+            got = raw[pos:pos + n]; pos += n
+            assert cases.rel_err(got, ranks[r].arr[k]) <= 1e-10, (r, k)
+        assert pos == raw.size
