@@ -333,3 +333,77 @@ def test_reference_invariants_after_ten_toy_steps():
     assert np.hypot(a["VT"][:Nn], a["VT"][Nn:]).max() < 5
     ang, flip, rg = r.check_regridding()
     assert ang > 10 and not flip and not rg
+
+
+def test_the_equations_do_not_know_where_x_points():
+    """Frame invariance: the momentum equation, the Coriolis and turning-angle terms (their signs!) and the rheology are
+    written in components; rotating the whole problem by 90 degrees (coordinates, winds, currents, initial velocities)
+    must rotate the answer.  A sign or index slip in any vector term breaks this at O(1); round-off breaks it at 1e-13.
+    One BBM step of 5 sub-steps on a multi-element mesh with land, open water, wind, current, tilt and basal stress."""
+    import cases
+    from nextsim_amd import mesh as M
+    gm, p, g, lms, fields = cases.make_case("tiny", substeps=5, dtime_step=200. * 5 / 120, basal_stress_type=1)
+    lm, f = lms[0], fields[0]
+    rng = np.random.default_rng(0)
+    Nn = lm.num_nodes
+    f = {k: v.copy() for k, v in f.items()}
+    f["wind"] = np.concatenate([rng.normal(8, 3, Nn), rng.normal(-5, 3, Nn)]); f["ocean"] = np.concatenate([rng.normal(0, .1, Nn), rng.normal(0, .1, Nn)])
+    f["ssh"] = 1e-6 * lm.coord_x - 2e-6 * lm.coord_y; f["element_depth"] = rng.uniform(2., 30., lm.num_elements)
+    free = ~lm.mask_dirichlet[:Nn].astype(bool)
+    f["VT"] = np.concatenate([rng.normal(0, .1, Nn) * free, rng.normal(0, .1, Nn) * free])
+    f["sigma0"] = rng.normal(0, 1e3, lm.num_elements); f["sigma1"] = rng.normal(0, 1e3, lm.num_elements); f["sigma2"] = rng.normal(0, 5e2, lm.num_elements)
+    a = O.OracleRank(lm, p, f); a.step()
+
+    def rot_vec(v):                       # (u, v) -> (-v, u)
+        return np.concatenate([-v[Nn:], v[:Nn]])
+    import dataclasses
+    lmr = dataclasses.replace(lm, coord_x=-lm.coord_y.copy(), coord_y=lm.coord_x.copy())
+    fr = {k: v.copy() for k, v in f.items()}
+    for k in ("wind", "ocean", "VT", "UM", "UT"):
+        fr[k] = rot_vec(f[k])
+    fr["sigma0"], fr["sigma1"], fr["sigma2"] = f["sigma1"].copy(), f["sigma0"].copy(), -f["sigma2"]      # R sigma R^T
+    b = O.OracleRank(lmr, p, fr); b.step()
+    scale = np.abs(a.arr["VT"]).max()
+    assert scale > 1e-3
+    for k in ("VT", "UM", "UT"):
+        assert np.abs(b.arr[k] - rot_vec(a.arr[k])).max() <= 1e-11 * max(np.abs(a.arr[k]).max(), 1e-30), k
+    s = max(np.abs(a.arr["sigma0"]).max(), 1.)
+    assert np.abs(b.arr["sigma0"] - a.arr["sigma1"]).max() <= 1e-10 * s and np.abs(b.arr["sigma1"] - a.arr["sigma0"]).max() <= 1e-10 * s
+    assert np.abs(b.arr["sigma2"] + a.arr["sigma2"]).max() <= 1e-10 * s
+    for k in ("damage", "conc", "thick", "ridge_ratio"):
+        assert np.abs(b.arr[k] - a.arr[k]).max() <= 1e-11, k
+
+
+def test_mirror_image_is_the_other_hemisphere():
+    """Reflecting the problem (x -> -x, u -> -u, sigma12 -> -sigma12, triangles re-oriented) turns every rotation sense
+    around; with the latitudes negated as well (Coriolis parameter and the sign of the ocean turning angle follow the
+    hemisphere, FE.cpp:10351, 10503) the reflected run must be the mirror image of the original one."""
+    import cases, dataclasses
+    gm, p, g, lms, fields = cases.make_case("tiny", substeps=5, dtime_step=200. * 5 / 120)
+    lm, f = lms[0], fields[0]
+    rng = np.random.default_rng(1)
+    Nn, Ne = lm.num_nodes, lm.num_elements
+    f = {k: v.copy() for k, v in f.items()}
+    f["wind"] = np.concatenate([rng.normal(6, 3, Nn), rng.normal(4, 3, Nn)]); f["ocean"] = np.concatenate([rng.normal(0, .1, Nn), rng.normal(0, .1, Nn)])
+    f["sigma2"] = rng.normal(0, 5e2, Ne)
+    a = O.OracleRank(lm, p, f); a.step()
+
+    def mir(v):
+        return np.concatenate([-v[:Nn], v[Nn:]])
+    idx = lm.indices.reshape(-1, 3)[:, [0, 2, 1]].copy()                 # keep the triangles counter-clockwise
+    gh = lm.ghost_nodes.reshape(-1, 3)[:, [0, 2, 1]].copy()
+    lmm = dataclasses.replace(lm, coord_x=-lm.coord_x, lat=-lm.lat, indices=np.ascontiguousarray(idx.ravel()), ghost_nodes=np.ascontiguousarray(gh.ravel()))
+    fm = {k: v.copy() for k, v in f.items()}
+    for k in ("wind", "ocean", "VT", "UM", "UT"):
+        fm[k] = mir(f[k])
+    fm["sigma2"] = -f["sigma2"]
+    b = O.OracleRank(lmm, p, fm); b.step()
+    assert np.abs(a.arr["VT"]).max() > 1e-3
+    for k in ("VT", "UM"):
+        assert np.abs(b.arr[k] - mir(a.arr[k])).max() <= 1e-10 * np.abs(a.arr[k]).max(), k
+    assert np.abs(b.arr["sigma2"] + a.arr["sigma2"]).max() <= 1e-9 * max(np.abs(a.arr["sigma2"]).max(), 1.)
+    assert np.abs(b.arr["damage"] - a.arr["damage"]).max() <= 1e-11
+    # and WITHOUT flipping the hemisphere the mirror image is NOT reproduced: the Coriolis / turning terms are really there
+    lmw = dataclasses.replace(lmm, lat=lm.lat)
+    c = O.OracleRank(lmw, p, fm); c.step()
+    assert np.abs(c.arr["VT"] - mir(a.arr["VT"])).max() > 1e-6 * np.abs(a.arr["VT"]).max()
