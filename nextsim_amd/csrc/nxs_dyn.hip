@@ -685,6 +685,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             for (int k = 0; k < hf.ipc.nr && ok; ++k)
                 while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
                     __builtin_amdgcn_s_sleep(4);
+                    if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost, do not wait again
                     if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 3); break; }  // 10 s
                 }
             __threadfence_system();
@@ -999,6 +1000,7 @@ __global__ void __launch_bounds__(BLOCK) k_halo_pull(double *__restrict__ vec, D
         for (int k = 0; k < ipc.nr; ++k) {
             while (__hip_atomic_load(ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq + 1ull) {
                 __builtin_amdgcn_s_sleep(8);
+                if (__hip_atomic_load(ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }  // a wait already timed out: do not wait again
                 if (wall_clock64() - t0 > 1000000000ll) { ok = 0; atomicExch(ipc.error, 1); break; }  // 10 s
             }
             if (!ok) break;
@@ -1074,6 +1076,7 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
             for (int k = 0; k < hf.ipc.nr && ok; ++k)
                 while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
                     __builtin_amdgcn_s_sleep(4);
+                    if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
                     if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 4); break; }  // 10 s
                 }
             __threadfence_system();
@@ -2883,7 +2886,7 @@ int nxs_dyn_synchronize(nxs_dyn_handle *h) {
     if (h->ipc_ready) {
         int err = 0;
         HIPCHK(h, hipMemcpy(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost));
-        if (err) return fail(h, NXS_ERR_COMM, "device-direct halo exchange failed (%s)", err == 1 ? "a neighbour's flag did not arrive within 10 s" : "self-test mismatch");
+        if (err) return fail(h, NXS_ERR_COMM, "device-direct halo exchange failed (%s)", err == 2 ? "self-test mismatch" : "a neighbour's flag did not arrive within 10 s");
     }
     return NXS_OK;
 }
