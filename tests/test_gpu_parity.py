@@ -510,3 +510,28 @@ def test_handles_give_their_device_memory_back():
         cycle()
     after = free_bytes()
     assert before - after < 8 << 20, (before, after)
+
+
+def test_arctic_free_running_sixty_steps_is_statistically_the_oracle():
+    """The long horizon, where point-wise comparison is meaningless (1-ulp differences grow to O(1), see
+    tests/test_oracle_sensitivity.py): 60 free-running steps (3.3 hours of model time, 7200 sub-steps) on the 21 k-triangle
+    Arctic-like mesh.  Both runs must stay physical and agree in everything that is not chaotic: ice volume and area
+    (conserved quantities), mean drift speed, the damage distribution and the stress statistics."""
+    fe, ref, lm = _pair("40km", 60)
+    got = fe.get_state()
+    assert fe.checkFieldsFast() == 0 == ref.check_fields_fast()
+    Nn = lm.num_nodes
+    surf_g = fe.get_diag()["surface"]; surf_r = ref.work_array("surface", lm.num_elements)
+    for k in ("thick", "conc"):
+        vg, vr = (got[k] * surf_g).sum(), (ref.arr[k] * surf_r).sum()
+        assert abs(vg - vr) <= 1e-5 * vr, k                                  # volume / area
+    sp_g = np.hypot(got["VT"][:Nn], got["VT"][Nn:]); sp_r = np.hypot(ref.arr["VT"][:Nn], ref.arr["VT"][Nn:])
+    assert abs(sp_g.mean() - sp_r.mean()) <= 0.02 * sp_r.mean()
+    assert abs(np.hypot(got["UM"][:Nn], got["UM"][Nn:]).mean() - np.hypot(ref.arr["UM"][:Nn], ref.arr["UM"][Nn:]).mean()) <= 0.02 * np.hypot(ref.arr["UM"][:Nn], ref.arr["UM"][Nn:]).mean()
+    q = [0.5, 0.9, 0.99]
+    assert np.abs(np.quantile(got["damage"], q) - np.quantile(ref.arr["damage"], q)).max() <= 0.03
+    assert abs(got["damage"].mean() - ref.arr["damage"].mean()) <= 0.01
+    sn_g, sn_r = 0.5 * (got["sigma0"] + got["sigma1"]), 0.5 * (ref.arr["sigma0"] + ref.arr["sigma1"])
+    assert abs(sn_g.mean() - sn_r.mean()) <= 0.05 * abs(sn_r.mean()) + 1.0
+    assert abs(np.abs(got["sigma2"]).mean() - np.abs(ref.arr["sigma2"]).mean()) <= 0.05 * np.abs(ref.arr["sigma2"]).mean() + 1.0
+    fe.close()
