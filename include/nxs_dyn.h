@@ -223,6 +223,9 @@ NXS_API int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors)
 typedef int (*nxs_dyn_halo_fn)(void *ctx, const double *send, double *recv);
 NXS_API int nxs_dyn_set_halo_exchange_fn(nxs_dyn_handle *h, nxs_dyn_halo_fn fn, void *ctx);
 
+/* Host <-> device copies of the prognostic arrays.  The first put after nxs_dyn_set_mesh must bring every member; afterwards a
+ * NULL member means "the device copy is current" (put) / "not wanted" (get), so a host whose thermodynamics only touched
+ * concentration, thickness and snow moves only those across PCIe instead of the whole state every step. */
 NXS_API int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s);
 NXS_API int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s);
 NXS_API int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f);

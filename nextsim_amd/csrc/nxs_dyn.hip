@@ -2367,8 +2367,11 @@ int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s) {
         {d.cohesion, s->cohesion, ne, "cohesion"}, {d.theal, s->time_relaxation_damage, ne, "time_relaxation_damage"},
         {d.drag_ui, s->drag_ui, ne, "drag_ui"}, {d.drag_ui_young, s->drag_ui_young, ne, "drag_ui_young"},
     };
-    for (auto &c : cp) if (!c.src) return fail(h, NXS_ERR_INVALID, "put_state: %s is NULL", c.name);
-    for (auto &c : cp) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, h->stream));
+    // the first put after set_mesh must bring every array; later ones may leave members NULL = "the device copy is current"
+    // (a host whose thermodynamics only touched concentration and thickness uploads only those)
+    if (!h->have_state)
+        for (auto &c : cp) if (!c.src) return fail(h, NXS_ERR_INVALID, "put_state: %s is NULL", c.name);
+    for (auto &c : cp) if (c.src) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_state = true;
     return NXS_OK;

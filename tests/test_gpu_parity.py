@@ -538,3 +538,31 @@ def test_arctic_free_running_sixty_steps_is_statistically_the_oracle():
     assert abs(sn_g.mean() - sn_r.mean()) <= 0.05 * abs(sn_r.mean()) + 1.0
     assert abs(np.abs(got["sigma2"]).mean() - np.abs(ref.arr["sigma2"]).mean()) <= 0.05 * np.abs(ref.arr["sigma2"]).mean() + 1.0
     fe.close()
+
+
+def test_partial_state_transfers():
+    """put_state / get_state with NULL members: only the arrays a host-side thermodynamics touched cross PCIe."""
+    import ctypes as C
+    from nextsim_amd import _abi, dynamics
+    gm, p, g, lms, fields = cases.make_case("small")
+    lm, f = lms[0], fields[0]
+    a = dynamics.FiniteElementDynamics(p); b = dynamics.FiniteElementDynamics(p)
+    for fe in (a, b):
+        fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f); fe.step(); fe.synchronize()
+    # "thermodynamics": thicker ice everywhere.  a: full round trip; b: only thick goes up, nothing else moves
+    sa = a.get_state(); sa2 = dict(f); sa2.update(sa); sa2["thick"] = sa["thick"] * 1.01
+    a.put_state(sa2)
+    thick = np.empty(lm.num_elements)
+    s = _abi.State(); s.thick = _abi.dptr(thick)
+    assert b.L.nxs_dyn_get_state(b.h, C.byref(s)) == 0
+    thick *= 1.01
+    s = _abi.State(); s.thick = _abi.dptr(thick)
+    assert b.L.nxs_dyn_put_state(b.h, C.byref(s)) == 0
+    a.step(); b.step(); a.synchronize(); b.synchronize()
+    ga, gb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(ga[k], gb[k]), k
+    # the first put of a mesh must be complete
+    c = dynamics.FiniteElementDynamics(p); c.set_mesh(lm)
+    assert c.L.nxs_dyn_put_state(c.h, C.byref(s)) != 0
+    a.close(); b.close(); c.close()
