@@ -265,8 +265,8 @@ def main():
     unique_id_fn = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # control plane (barrier, max-reduce, id broadcast) on gloo; the data path (halo exchange of
-        # M_VT) is RCCL inside libnxsdyn.so
+        # control plane (barrier, max-reduce, handle / id exchange at set-up) on gloo; the data path (halo exchange of M_VT)
+        # is inside libnxsdyn.so: device-direct peer mailboxes over xGMI, RCCL or host-staged as fallbacks
         # gloo announces itself on stdout from C++; keep stdout for the one JSON line
         sys.stdout.flush()
         saved = os.dup(1)
