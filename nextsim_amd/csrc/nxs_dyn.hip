@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstring>
 #include <dlfcn.h>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -1444,6 +1445,8 @@ struct nxs_dyn_handle {
     double *f_snap[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // wind0, wind1, ocean0, ocean1, ssh0, ssh1 (forcing pair)
     bool have_pair = false;
     std::vector<void *> forcing_allocs;
+    int pin_host = 0;                      // option "pin_host": page-lock the caller's state / forcing vectors on first use
+    std::map<const void *, size_t> pinned; // what this handle has registered with hipHostRegister
     int halo_fused = 1;                    // option "halo_fused"
     bool hf_ready = false;
     HaloFused hf{};
@@ -1837,6 +1840,23 @@ void ipc_release(nxs_dyn_handle *h) {
     h->ipc_ready = false;
     h->ipc = IpcDev{};
 }
+// option "pin_host": the caller's vectors (FiniteElement's M_VT, M_conc, ... live as long as the mesh) are page-locked the first
+// time they are seen, so that the per-step copies of a host-side thermodynamics run at PCIe speed and overlap; a vector that was
+// reallocated simply registers anew, stale registrations are dropped at set_mesh / destroy.  Failure to register is not an error.
+void pin_host_buffer(nxs_dyn_handle *h, const void *p, size_t bytes) {
+    if (!h->pin_host || !p || bytes == 0) return;
+    auto it = h->pinned.find(p);
+    if (it != h->pinned.end() && it->second >= bytes) return;
+    if (it != h->pinned.end()) { (void)hipHostUnregister(const_cast<void *>(p)); h->pinned.erase(it); }
+    if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterDefault) == hipSuccess) h->pinned[p] = bytes;
+    else (void)hipGetLastError();
+}
+void unpin_all(nxs_dyn_handle *h) {
+    for (auto &kv : h->pinned) (void)hipHostUnregister(const_cast<void *>(kv.first));
+    (void)hipGetLastError();
+    h->pinned.clear();
+}
+
 void release_graph(nxs_dyn_handle *h) {
     if (h->substep_graph) { (void)hipGraphExecDestroy(h->substep_graph); h->substep_graph = nullptr; }
     if (h->tail_graph) { (void)hipGraphExecDestroy(h->tail_graph); h->tail_graph = nullptr; }
@@ -1923,6 +1943,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->forcing_allocs);
     for (auto &q : h->f_snap) q = nullptr;
     h->have_pair = false;
+    unpin_all(h);
     if (h->h_send) (void)hipHostFree(h->h_send);
     if (h->h_recv) (void)hipHostFree(h->h_recv);
     if (h->d_partials) (void)hipFree(h->d_partials);
@@ -1954,6 +1975,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     }
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "fused")) { h->fused = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "pin_host")) { h->pin_host = value != 0; if (!h->pin_host) unpin_all(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_fused")) { h->halo_fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
         if (value != 0 && (value < 64 || value > 1024)) return fail(h, NXS_ERR_INVALID, "patch_nodes must be 0 (auto) or in [64,1024]");
@@ -2003,6 +2025,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->forcing_allocs);
     for (auto &q : h->f_snap) q = nullptr;
     h->have_pair = false;
+    unpin_all(h);
     h->ring = VTRing{};
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
     h->rank = 0; h->nranks = 1;
@@ -2371,6 +2394,7 @@ int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s) {
     // (a host whose thermodynamics only touched concentration and thickness uploads only those)
     if (!h->have_state)
         for (auto &c : cp) if (!c.src) return fail(h, NXS_ERR_INVALID, "put_state: %s is NULL", c.name);
+    for (auto &c : cp) if (c.src) pin_host_buffer(h, c.src, c.bytes);
     for (auto &c : cp) if (c.src) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_state = true;
@@ -2391,6 +2415,7 @@ int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s) {
         {s->conc_young, d.cyoung, ne}, {s->h_young, d.hyoung, ne}, {s->hs_young, d.hsyoung, ne},
         {s->conc_myi, d.cmyi, ne}, {s->thick_myi, d.tmyi, ne},
     };
+    for (auto &c : cp) if (c.dst) pin_host_buffer(h, c.dst, c.bytes);
     for (auto &c : cp) if (c.dst) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return NXS_OK;
@@ -2402,6 +2427,8 @@ int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f) {
     if (!f->wind || !f->ocean || !f->ssh || !f->element_depth) return fail(h, NXS_ERR_INVALID, "forcing has NULL arrays");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t Nn = h->dm.Nn, Ne = h->dm.Ne;
+    pin_host_buffer(h, f->wind, 2 * Nn * sizeof(double)); pin_host_buffer(h, f->ocean, 2 * Nn * sizeof(double));
+    pin_host_buffer(h, f->ssh, Nn * sizeof(double)); pin_host_buffer(h, f->element_depth, Ne * sizeof(double));
     HIPCHK(h, hipMemcpyAsync(h->ds.wind, f->wind, 2 * Nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->ds.ocean, f->ocean, 2 * Nn * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipMemcpyAsync(h->ds.ssh, f->ssh, Nn * sizeof(double), hipMemcpyHostToDevice, h->stream));

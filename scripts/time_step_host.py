@@ -22,6 +22,11 @@ ss, fo = _abi.state_struct(st), _abi.forcing_struct(f)
 t = time.perf_counter()
 for _ in range(n): assert fe.L.nxs_dyn_step_host(fe.h, C.byref(ss), C.byref(fo)) == 0
 host = (time.perf_counter() - t) / n
+fe.set_option("pin_host", 1)
+assert fe.L.nxs_dyn_step_host(fe.h, C.byref(ss), C.byref(fo)) == 0      # registers the vectors
+t = time.perf_counter()
+for _ in range(n): assert fe.L.nxs_dyn_step_host(fe.h, C.byref(ss), C.byref(fo)) == 0
+host_pinned = (time.perf_counter() - t) / n
 fe.set_forcing_pair(f, f)
 arr = {k: np.empty(lm.num_elements) for k in ("conc", "thick", "snow_thick")}
 s = _abi.State()
@@ -33,5 +38,5 @@ for _ in range(n):
     fe.step()
     fe.L.nxs_dyn_get_state(fe.h, C.byref(s))
 part = (time.perf_counter() - t) / n
-print(f"{lm.num_elements} triangles: resident {res*1e3:.2f} ms/step; step_host (whole state + forcing over PCIe every step) {host*1e3:.2f} ms/step; "
+print(f"{lm.num_elements} triangles: resident {res*1e3:.2f} ms/step; step_host (whole state + forcing over PCIe every step) {host*1e3:.2f} ms/step, {host_pinned*1e3:.2f} with option pin_host; "
       f"resident state + device-blended forcing + 3 thermodynamic arrays down and up {part*1e3:.2f} ms/step")

@@ -566,3 +566,25 @@ def test_partial_state_transfers():
     c = dynamics.FiniteElementDynamics(p); c.set_mesh(lm)
     assert c.L.nxs_dyn_put_state(c.h, C.byref(s)) != 0
     a.close(); b.close(); c.close()
+
+
+def test_pin_host_option_changes_nothing_but_the_copies():
+    import ctypes as C
+    from nextsim_amd import _abi, dynamics
+    gm, p, g, lms, fields = cases.make_case("small")
+    lm = lms[0]
+    out = []
+    for pin in (0, 1):
+        f = {k: v.copy() for k, v in fields[0].items()}
+        fe = dynamics.FiniteElementDynamics(p)
+        fe.set_option("pin_host", pin)
+        fe.set_mesh(lm)
+        s = _abi.state_struct(f); fo = _abi.forcing_struct(f)
+        for _ in range(3):
+            assert fe.L.nxs_dyn_step_host(fe.h, C.byref(s), C.byref(fo)) == 0
+        fe.set_mesh(lm)                         # a regrid drops the registrations; the vectors register anew
+        assert fe.L.nxs_dyn_step_host(fe.h, C.byref(s), C.byref(fo)) == 0
+        fe.close()
+        out.append(f)
+    for k in STATE_KEYS:
+        assert np.array_equal(out[0][k], out[1][k]), k
