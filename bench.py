@@ -117,26 +117,38 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch):
     if force is not None:
         fe.set_option("halo_fused", int(force))
         return " + exchange inside the sub-step kernel (forced)" if int(force) else ", separate push/pull kernels (forced)"
-    ok, states, secs = 1.0, [], [0.0, 0.0]
+    def agree(flag):   # every rank calls this the same number of times, whatever happened to it
+        t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t[0]) == 1.0
+
+    states, secs, good = [], [0.0, 0.0], True
     for i, mode in enumerate((1, 0)):
+        mine = True
         try:
             fe.set_option("halo_fused", mode)
             fe.put_state(f)
             fe.step(); fe.synchronize()           # (graph capture happens here)
             states.append(fe.get_state())
-            dist.barrier()
-            t0 = time.perf_counter()
-            fe.step(); fe.step(); fe.synchronize()
-            secs[i] = time.perf_counter() - t0
         except dynamics.NxsError as e:
             print(f"[bench rank {rank}] halo_fused={mode}: {e}", file=sys.stderr, flush=True)
-            ok = 0.0
+            mine = False
+        if not agree(mine):
+            good = False
             break
-    if ok and not all(np.array_equal(states[0][k], states[1][k]) for k in states[0]):
-        ok = 0.0
-    t = torch.tensor([ok], dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    if float(t[0]) == 1.0:
+        t0 = time.perf_counter()
+        try:
+            fe.step(); fe.step(); fe.synchronize()
+        except dynamics.NxsError as e:
+            print(f"[bench rank {rank}] halo_fused={mode}: {e}", file=sys.stderr, flush=True)
+            mine = False
+        secs[i] = time.perf_counter() - t0
+        if not agree(mine):
+            good = False
+            break
+    if good:
+        good = agree(all(np.array_equal(states[0][k], states[1][k]) for k in states[0]))
+    if good:
         tt = torch.tensor(secs, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         inside = float(tt[0]) <= float(tt[1])

@@ -684,12 +684,13 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             const long long t0 = wall_clock64();  // 100 MHz
             bool ok = true;
             for (int k = 0; k < hf.ipc.nr && ok; ++k)
-                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
+                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
                     __builtin_amdgcn_s_sleep(4);
                     if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost, do not wait again
                     if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 3); break; }  // 10 s
                 }
-            __threadfence_system();
+            // no acquire fence: the mailbox is uncached memory and every read of it below is a system-scope load that
+            // bypasses the caches; a fence here would invalidate this XCD's caches once per boundary patch and sub-step
         }
         __syncthreads();
     }
@@ -847,10 +848,14 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     NXS_STAMP(4);
     if (HALO) {
         if (boundary) {  // publish: the last boundary patch to finish raises my flag at every neighbour
-            __threadfence_system();
+            // The mailbox stores are write-through system-scope stores into uncached memory: nothing of them lives in a cache, so
+            // no release fence (= writing this XCD's whole L2 back, per workgroup and sub-step) is needed to make them visible --
+            // every wave drains its own stores, the barrier collects the waves, one lane counts the workgroup in, and the last
+            // one raises the flags with release stores (one fence per launch).  The separate k_halo_push keeps the fences; bench.py
+            // checks both variants against each other on the machine it runs on.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0 && atomicAdd(hf.ipc.done_push, 1u) == (unsigned)hf.n_boundary - 1u) {
-                __threadfence_system();
                 for (int k = 0; k < hf.ipc.ns; ++k)
                     __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 *hf.ipc.done_push = 0u;
@@ -970,11 +975,11 @@ __global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ 
         sys_store(dst + (j - off), u);
         sys_store(dst + (j - off) + srl, v);
     }
-    // publish: every block releases its stores, the last one to finish raises the flags
-    __threadfence_system();
+    // publish: every wave drains its stores, one lane releases for the block, the last block to finish raises the flags
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int last;
-    if (threadIdx.x == 0) last = (atomicAdd(ipc.done_push, 1u) == gridDim.x - 1);
+    if (threadIdx.x == 0) { __threadfence_system(); last = (atomicAdd(ipc.done_push, 1u) == gridDim.x - 1); }
     __syncthreads();
     if (last) {
         __threadfence_system();
@@ -999,14 +1004,13 @@ __global__ void __launch_bounds__(BLOCK) k_halo_pull(double *__restrict__ vec, D
         ok = 1;
         const long long t0 = wall_clock64();  // 100 MHz
         for (int k = 0; k < ipc.nr; ++k) {
-            while (__hip_atomic_load(ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq + 1ull) {
+            while (__hip_atomic_load(ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq + 1ull) {
                 __builtin_amdgcn_s_sleep(8);
                 if (__hip_atomic_load(ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }  // a wait already timed out: do not wait again
                 if (wall_clock64() - t0 > 1000000000ll) { ok = 0; atomicExch(ipc.error, 1); break; }  // 10 s
             }
             if (!ok) break;
         }
-        __threadfence_system();
     }
     __syncthreads();
     const int j = blockIdx.x * BLOCK + threadIdx.x;
@@ -1075,12 +1079,11 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
             const long long t0 = wall_clock64();
             bool ok = true;
             for (int k = 0; k < hf.ipc.nr && ok; ++k)
-                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
+                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
                     __builtin_amdgcn_s_sleep(4);
                     if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
                     if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 4); break; }  // 10 s
                 }
-            __threadfence_system();
         }
         __syncthreads();
     }
@@ -1114,10 +1117,9 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
             sys_store(d + (hf.send_off[k + 1] - hf.send_off[k]), v);
         }
     }
-    __threadfence_system();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // as in the sub-step kernel: drain per wave, count the block in, release once
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(hf.done_all, 1u) == gridDim.x - 1u) {
-        __threadfence_system();
         for (int k = 0; k < hf.ipc.ns; ++k)
             __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         *hf.done_all = 0u;
