@@ -251,7 +251,11 @@ class FiniteElementDynamics:
             self.L.nxs_dyn_set_halo(self.h, C.byref(_abi.halo_struct(lm)))  # drops the half-made transport
             return False
         err = C.c_int32(0)
-        self._chk(self.L.nxs_dyn_ipc_selftest(self.h, selftest_rounds, C.byref(err)))
+        try:
+            self._chk(self.L.nxs_dyn_ipc_selftest(self.h, selftest_rounds, C.byref(err)))
+        except NxsError as e:   # still take part in the gather below: the other ranks are waiting in it
+            self._ipc_error = str(e)
+            err.value = err.value or -1
         good = all(e == 0 for e in all_gather(int(err.value)))
         if not good:
             self.L.nxs_dyn_set_halo(self.h, C.byref(_abi.halo_struct(lm)))

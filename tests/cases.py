@@ -127,3 +127,30 @@ def adapted_mesh(x, y, tri, n_geom, seed, frac_touched=0.15):
     tri = inv[tri].astype(np.int32)
     tri = tri[rng.permutation(tri.shape[0])]
     return xn, yn, np.ascontiguousarray(tri), prev
+
+
+def mesh_operator(gm, nonsymmetric=False, shift=0.05):
+    """A node-numbered sparse operator on the mesh for the Krylov tests (scipy CSR, sorted columns), its right-hand side
+    for a known solution, and that solution: the P1 stiffness matrix (element matrix of research/laplacian.cpp:163-224)
+    plus `shift` times the lumped mass -- symmetric positive definite; nonsymmetric=True adds a skew edge term of
+    the size of half the stiffness entries (what a Coriolis / advection term does to a momentum matrix)."""
+    import scipy.sparse as sp
+    L = max(np.ptp(gm.x), np.ptp(gm.y))
+    x, y = gm.x / L, gm.y / L
+    t = gm.tri
+    xs, ys = x[t], y[t]
+    area = 0.5 * np.abs((xs[:, 1] - xs[:, 0]) * (ys[:, 2] - ys[:, 0]) - (xs[:, 2] - xs[:, 0]) * (ys[:, 1] - ys[:, 0]))
+    rows, cols, vals = [], [], []
+    for j in range(3):
+        jp1, jp2 = (j + 1) % 3, (j + 2) % 3
+        for k in range(3):
+            kp1, kp2 = (k + 1) % 3, (k + 2) % 3
+            m = ((ys[:, jp1] - ys[:, jp2]) * (ys[:, kp1] - ys[:, kp2]) + (xs[:, jp1] - xs[:, jp2]) * (xs[:, kp1] - xs[:, kp2])) / (4.0 * area)
+            if nonsymmetric and j != k:
+                m = m + (0.5 if (k - j) % 3 == 1 else -0.5) * np.abs(m)      # skew: +w on (j,k), -w on (k,j)
+            rows.append(t[:, j]); cols.append(t[:, k]); vals.append(m)
+        rows.append(t[:, j]); cols.append(t[:, j]); vals.append(shift * area / 3.0 * gm.num_nodes)
+    A = sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(gm.num_nodes, gm.num_nodes))
+    A.sum_duplicates(); A.sort_indices()
+    sol = np.sin(3.0 * x) * np.cos(2.0 * y) + 0.3
+    return A, A @ sol, sol
