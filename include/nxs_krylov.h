@@ -34,10 +34,13 @@ NXS_KRYLOV_API int nxs_fem_csr_pattern(const int32_t *indices, int32_t num_nodes
 NXS_KRYLOV_API int nxs_fem_colour_elements(const int32_t *indices, int32_t num_nodes, int32_t num_elements, int32_t *colour,
                                            int32_t *ncolours);
 
-/* -div grad u = f on the mesh, u = 0 on `dirichlet` nodes: colour-by-colour scatter of the 3x3 element
- * matrices into CSR (no atomics), then Jacobi-preconditioned CG (SpMV / axpy / dot kernels, dot by wave
- * shuffles + a deterministic two-stage reduction).  f_elem[e] = source at the barycentre of element e.
- * Stops at ||r|| <= rtol*||b|| or max_iter.  Returns 0 / negative NXS_ERR_* (no HIP device: -2). */
+/* -div grad u = f on the mesh, u = 0 on `dirichlet` nodes: graph-coloured scatter of the 3x3 element matrices
+ * into the (sliced-ELLPACK) matrix without atomics -- one launch, a workgroup per patch of 128 rows builds its
+ * contiguous piece of the matrix in LDS, the element colours taking turns -- then Jacobi-preconditioned CG
+ * (SpMV with the dot (p, Ap) fused, one fused x/r/z update carrying (r, z) and (r, r), one p update; dots by
+ * wave shuffles + a fixed-order sum of per-block partials).  f_elem[e] = source at the barycentre of element e.
+ * Stops at ||r|| <= rtol*||b|| or max_iter.  *ms_assembly: assembly + Dirichlet rows, second of two passes.
+ * Returns 0 / negative NXS_ERR_* (no HIP device: -2). */
 NXS_KRYLOV_API int nxs_fem_poisson_solve(const int32_t *indices, const double *x, const double *y, int32_t num_nodes,
                                          int32_t num_elements, const uint8_t *dirichlet, const double *f_elem, double *u,
                                          double rtol, int32_t max_iter, int32_t device, int32_t *iterations,
