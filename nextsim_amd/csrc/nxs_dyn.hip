@@ -600,7 +600,9 @@ struct HaloFused {
     const int *ghost_off, *ghost_srl;  // [Nn-No] u offset inside a mailbox half, and the v offset from it
     int No;
     int from_mailbox;                  // 0: first sub-step of a step, the ghosts are in the VT buffer
-    unsigned int *done_all;
+    unsigned int *done_all;            // k_smooth_halo: two-level ticket counters, [0] global, [32 (g+1)] group g
+    const int *send_block_rank;        // k_smooth_halo: rank of block b among the blocks that send something, -1: sends nothing
+    int n_send_blocks;
 };
 
 #ifdef NXS_PHASE_TIMING  // kernel microscope (scripts/phase_timing.py builds a variant of the library with it)
@@ -646,8 +648,8 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     bool boundary = false;
     if (HALO) {  // boundary patches [0, n_boundary) lead the grid in dispatch order; the remap acts inside each group
         boundary = blk < hf.n_boundary;
+        if (boundary || hf.n_boundary == 0) xseq = *hf.ipc.seq_push;  // interior patches never look at it: the last boundary patch may advance it while they run
         blk = boundary ? xcd_remap(blk, hf.n_boundary) : hf.n_boundary + xcd_remap(blk - hf.n_boundary, (int)gridDim.x - hf.n_boundary);
-        xseq = *hf.ipc.seq_push;
     } else {
         blk = xcd_remap(blk, (int)gridDim.x);
     }
@@ -860,10 +862,9 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 for (int k = 0; k < hf.ipc.ns; ++k)
                     __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
                 *hf.ipc.done_push = 0u;
+                *hf.ipc.seq_push = xseq + 1ull;  // every boundary patch has read it; no counter over the whole grid (same-address atomics are served ~10 ns apart)
             }
-        }
-        if (t == 0 && atomicAdd(hf.done_all, 1u) == gridDim.x - 1u) {
-            *hf.done_all = 0u;
+        } else if (hf.n_boundary == 0 && blockIdx.x == 0 && t == 0) {
             *hf.ipc.seq_push = xseq + 1ull;
         }
     }
@@ -1118,13 +1119,28 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
             sys_store(d + (hf.send_off[k + 1] - hf.send_off[k]), v);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // as in the sub-step kernel: drain per wave, count the block in, release once
+    // as in the sub-step kernel: drain per wave, count the block in, release once.  Only blocks that sent something take a
+    // ticket, and the tickets are two-level (16 group counters, then one): atomics on one address are served ~10 ns apart,
+    // a counter over all blocks of a 2-rank 2 km partition (1 400) would cost more than the sweep itself.
+    const int sr = hf.send_block_rank[blockIdx.x];
+    if (sr < 0 && !(hf.n_send_blocks == 0 && blockIdx.x == 0)) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(hf.done_all, 1u) == gridDim.x - 1u) {
+    if (threadIdx.x != 0) return;
+    bool last = hf.n_send_blocks == 0;
+    if (!last) {
+        const unsigned int total = (unsigned)hf.n_send_blocks, g = (unsigned)sr % 16u, members = (total - g + 15u) / 16u;
+        if (__hip_atomic_fetch_add(hf.done_all + 32u * (g + 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+            __hip_atomic_store(hf.done_all + 32u * (g + 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned int groups = total < 16u ? total : 16u;
+            last = __hip_atomic_fetch_add(hf.done_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
+        }
+    }
+    if (last) {
         __threadfence_system();  // the one release of the launch
         for (int k = 0; k < hf.ipc.ns; ++k)
             __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
-        *hf.done_all = 0u;
+        __hip_atomic_store(hf.done_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *hf.ipc.seq_push = xseq + 1ull;
     }
 }
@@ -2698,9 +2714,18 @@ int build_halo_fused(nxs_dyn_handle *h) {
     if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_off, goff))) return rc;
     if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_srl, gsrl))) return rc;
     unsigned int *ctr = nullptr;
-    if ((rc = dev_alloc(h, h->hf_allocs, &ctr, 4))) return rc;
-    HIPCHK(h, hipMemsetAsync(ctr, 0, 4 * sizeof(unsigned int), h->stream));
+    if ((rc = dev_alloc(h, h->hf_allocs, &ctr, 32 * 17))) return rc;
+    HIPCHK(h, hipMemsetAsync(ctr, 0, 32 * 17 * sizeof(unsigned int), h->stream));
     f.done_all = ctr;
+    {   // k_smooth_halo runs BLOCK own nodes per block: which blocks store into a mailbox
+        const int nblk = std::max(1, (No + BLOCK - 1) / BLOCK);
+        std::vector<int> rank_of(nblk, -1);
+        int cnt = 0;
+        for (int b = 0; b < nblk; ++b)
+            if (sptr[std::min(No, (b + 1) * BLOCK)] > sptr[std::min(No, b * BLOCK)]) rank_of[b] = cnt++;
+        if ((rc = dev_upload(h, h->hf_allocs, &f.send_block_rank, rank_of))) return rc;
+        f.n_send_blocks = cnt;
+    }
     f.send_off = h->d_send_off;
     f.n_boundary = nb;
     f.No = No;
