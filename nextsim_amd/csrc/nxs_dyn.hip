@@ -106,6 +106,19 @@ struct DevPatches {
     const unsigned short *pfan;   // [nP][Wp][Pmax] (element slot << 3 | ghost << 2 | corner), 0xFFFF pad
 };
 
+// Patches of the two-sub-steps-per-launch kernel (k_substep_pair): two rings of halo around the own nodes.
+//   nodes    [0, own) own | [own, n1) the other nodes of the elements touching an own node | [n1, n2) the other nodes of the
+//            elements touching an N1 node
+//   elements [0, e1) every element touching an own node (ascending id) | [e1, e2) the other elements touching an N1 node
+struct DevPatches2 {
+    int nP, Pmax, N1max, N2max, E1max, E2max, Wp;
+    const int *own_cnt, *n1_cnt, *n2_cnt, *e1_cnt, *e2_cnt;  // [nP]
+    const int *pnodes;            // [nP][N2max] global node ids
+    const int *pelem;             // [nP][E2max] global element id; ~id when another patch writes it (or nobody from here: ring 2)
+    const unsigned short *ptri;   // [nP][E2max][4] patch-local node slots of the 3 corners (+ pad)
+    const unsigned short *pfan;   // [nP][Wp][N1max] fan of every N1 node, ascending element id: (element slot << 3 | ghost << 2 | corner)
+};
+
 struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
     const double *VTc, *s0c, *s1c, *s2c, *dc;
     double *VTn, *s0n, *s1n, *s2n, *dn;
@@ -870,6 +883,197 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v3  TWO sub-steps per launch (single rank, deferred mesh move).  The sub-step loop is bound by HBM traffic, most of it
+// the element state (sigma, damage) and the per-step element constants that every sub-step streams once.  Here a patch
+// carries two rings of halo (DevPatches2): sub-step s is computed for every element touching an N1 node and every N1
+// node, sub-step s+1 for the elements touching an own node and the own nodes -- the ring is recomputed redundantly by the
+// neighbouring patches (same inputs, same operations, same bits) -- so the element state is read once and written
+// once per TWO sub-steps, and so are the nodal inputs.  The intermediate stresses stay in LDS, the intermediate
+// velocities (s+1) of the own nodes still go to their ring slot: the deferred mesh move needs every sub-step's velocity.
+template <int T, bool POW4, int NTM>
+__global__ void __launch_bounds__(T) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, double *__restrict__ VTn2) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int N2m = pp.N2max, E2m = pp.E2max, E1m = pp.E1max;
+    double *lu = lds, *lv = lu + N2m, *lx = lv + N2m, *ly = lx + N2m, *lF = ly + N2m /*[6][E2m]*/, *lS = lF + 6 * (size_t)E2m /*[4][E1m]*/;
+    int blk;
+    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
+        const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, r = n & 7, x = pos & 7;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
+    }
+    const int t = threadIdx.x, Nn = m.Nn;
+    const int nO = pp.own_cnt[blk], n1 = pp.n1_cnt[blk], n2 = pp.n2_cnt[blk], e1 = pp.e1_cnt[blk], e2 = pp.e2_cnt[blk];
+    const int *pn = pp.pnodes + (size_t)blk * N2m;
+    const int *pe = pp.pelem + (size_t)blk * E2m;
+    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * E2m;
+    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.N1max;
+    const bool bbm = p.dynamics_type == NXS_DYN_BBM;
+    constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
+
+    // index rows are padded: the first loads depend on the launch arguments only
+    const int my_node = (t < N2m) ? pn[t] : 0;
+    int eraw0 = 0;
+    ushort4 tr0 = make_ushort4(0, 0, 0, 0);
+    if (t < E2m) { eraw0 = pe[t]; tr0 = pt[t]; }
+    for (int i = t; i < n2; i += T) {
+        const int g = (i == t) ? my_node : pn[i];
+        lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
+        lx[i] = w.xs[g]; ly[i] = w.ys[g];
+    }
+
+    // one element of one sub-step (FE.cpp:10425-10467), split into its global loads and the rest so that the barrier
+    // between them sits in uniform control flow.  first: state from HBM, result to LDS (if the element is needed again);
+    // second: state from LDS, result to HBM (if this patch writes the element)
+    struct ElemIn { int e; bool writer, skip; int dxi; double sig[3], damage, expC, volume, pmax, heal, coh; };
+    auto load_element = [&](const int eraw, const bool first) {
+        ElemIn in;
+        in.writer = eraw >= 0;
+        in.e = in.writer ? eraw : ~eraw;
+        const int e = in.e;
+        in.skip = true; in.dxi = 0; in.damage = 0.; in.pmax = 0.; in.heal = 0.; in.coh = 0.; in.sig[0] = in.sig[1] = in.sig[2] = 0.;
+        if (!bbm) in.skip = w.eskip[e];
+        if (first) {
+            in.sig[0] = ldg<NT_S>(b.s0c + e); in.sig[1] = ldg<NT_S>(b.s1c + e); in.sig[2] = ldg<NT_S>(b.s2c + e);
+            if (bbm) in.damage = ldg<NT_S>(b.dc + e);
+        }
+        // the element constants are read by both sub-steps: the second read hits the L2 and is the streaming one
+        in.expC = first ? w.expC[e] : ldg<NT_C>(w.expC + e);
+        in.volume = first ? w.volume[e] : ldg<NT_C>(w.volume + e);
+        if (bbm) {
+            in.pmax = first ? w.pmax[e] : ldg<NT_C>(w.pmax + e); in.heal = first ? w.heal[e] : ldg<NT_C>(w.heal + e);
+            in.dxi = w.dxi[e]; in.coh = first ? s.cohesion[e] : ldg<NT_C>(s.cohesion + e);
+        }
+        return in;
+    };
+    auto compute_element = [&](const int l, const ushort4 tr, ElemIn &in, const bool first) {
+        double dxN[6], sig[3] = {in.sig[0], in.sig[1], in.sig[2]}, damage = in.damage, c_dxs = 1.;
+        bool skip = in.skip;
+        if (!first) { sig[0] = lS[l]; sig[1] = lS[E1m + l]; sig[2] = lS[2 * (size_t)E1m + l]; damage = lS[3 * (size_t)E1m + l]; }
+        if (bbm) {  // M_delta_x is an integer number of metres (Q1) and travels as one, with the skip flag in its sign
+            skip = in.dxi < 0;
+            c_dxs = (double)(skip ? ~in.dxi : in.dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
+        }
+        {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates, as k_substep_fused
+            const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
+            const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
+            const double jac = jacobian(vx, vy);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+                dxN[k] = (vy[kp1] - vy[kp2]) / jac;
+                dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+            }
+        }
+        if (skip) {
+            sig[0] = sig[1] = sig[2] = 0.;
+            damage = 0.;
+        } else {
+            const double u[3] = {lu[tr.x], lu[tr.y], lu[tr.z]};
+            const double v[3] = {lv[tr.x], lv[tr.y], lv[tr.z]};
+            if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, in.expC, in.pmax, in.heal, c_dxs, in.coh);
+            else vp_stress(p, dxN, u, v, sig, in.expC);
+        }
+        if (first) {
+            if (l < e1) { lS[l] = sig[0]; lS[E1m + l] = sig[1]; lS[2 * (size_t)E1m + l] = sig[2]; lS[3 * (size_t)E1m + l] = damage; }
+        } else if (in.writer) {
+            stg<NT_S>(b.s0n + in.e, sig[0]); stg<NT_S>(b.s1n + in.e, sig[1]); stg<NT_S>(b.s2n + in.e, sig[2]);
+            if (bbm) stg<NT_S>(b.dn + in.e, damage);
+        }
+        double F[6];
+        corner_forces(in.volume, sig, dxN, F);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) lF[(size_t)k * E2m + l] = F[k];
+    };
+    // one node of one sub-step (FE.cpp:10472-10529), loads and solve apart for the same reason
+    struct NodeIn { unsigned char nf; double node_mass, gx, gy, rlm, cbu, fcor, tax, tay, ou, ov; unsigned short fan[8]; };
+    auto load_node = [&](const int i, const int n) {
+        NodeIn in;
+        in.nf = m.nflags[n];
+        in.node_mass = w.node_mass[n];
+        in.gx = w.grad_ssh[n]; in.gy = w.grad_ssh[n + Nn];
+        in.rlm = w.rlmass[n]; in.cbu = w.C_bu[n]; in.fcor = w.fcor[n];
+        in.tax = w.D_tau_a[n]; in.tay = w.D_tau_a[n + Nn];
+        in.ou = s.ocean[n]; in.ov = s.ocean[n + Nn];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) in.fan[k] = (k < pp.Wp) ? pf[(size_t)k * pp.N1max + i] : (unsigned short)0xFFFFu;
+        return in;
+    };
+    auto solve_node = [&](const int i, NodeIn &in, double &uice, double &vice) {
+        uice = lu[i]; vice = lv[i];
+        if ((in.nf & NF_DIRICHLET) || in.node_mass == 0.) return;
+        double gx = in.gx, gy = in.gy;
+        bool more = true;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const unsigned ent = in.fan[k];
+            if (!more || ent == 0xFFFFu) { more = false; continue; }
+            if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
+            const int l = ent >> 3, c = ent & 3u;
+            gx -= lF[(size_t)c * E2m + l];
+            gy -= lF[(size_t)(c + 3) * E2m + l];
+        }
+        for (int k = 8; more && k < pp.Wp; ++k) {
+            const unsigned ent = pf[(size_t)k * pp.N1max + i];
+            if (ent == 0xFFFFu) break;
+            if (ent & 4u) continue;
+            const int l = ent >> 3, c = ent & 3u;
+            gx -= lF[(size_t)c * E2m + l];
+            gy -= lF[(size_t)(c + 3) * E2m + l];
+        }
+        nodal_solve(p, gx, gy, uice, vice, in.node_mass, in.rlm, in.cbu, in.fcor, (in.nf & NF_LAT_NEG) ? -1. : 1., in.tax, in.tay, in.ou, in.ov, 0., 0.);
+    };
+
+    // ---- sub-step s: every element touching an N1 node, every N1 node
+    for (int base = 0; base < e2 || base == 0; base += T) {
+        const int l = base + t;
+        const bool active = l < e2;
+        int eraw = eraw0; ushort4 tr = tr0;
+        if (base > 0 && active) { eraw = pe[l]; tr = pt[l]; }
+        ElemIn in{};
+        if (active) in = load_element(eraw, true);
+        if (base == 0) __syncthreads();  // staged velocities / coordinates visible
+        if (active) compute_element(l, tr, in, true);
+    }
+    for (int base = 0; base < n1 || base == 0; base += T) {
+        const int i = base + t;
+        const bool active = i < n1;
+        const int n = active ? ((base == 0) ? my_node : pn[i]) : 0;
+        NodeIn in{};
+        if (active) in = load_node(i, n);
+        if (base == 0) __syncthreads();  // corner forces of sub-step s visible
+        if (active) {
+            double u1, v1;
+            solve_node(i, in, u1, v1);
+            if (i < nO) { b.VTn[n] = u1; b.VTn[n + Nn] = v1; }
+            lu[i] = u1; lv[i] = v1;  // a node's solve reads only its own staged velocity: in place
+        }
+    }
+    __syncthreads();  // velocities of sub-step s+1 on every N1 node; the corner forces of sub-step s are consumed
+    // ---- sub-step s+1: the elements touching an own node, the own nodes
+    for (int base = 0; base < e1; base += T) {
+        const int l = base + t;
+        if (l < e1) {
+            int eraw = eraw0; ushort4 tr = tr0;
+            if (base > 0) { eraw = pe[l]; tr = pt[l]; }
+            ElemIn in = load_element(eraw, false);
+            compute_element(l, tr, in, false);
+        }
+    }
+    for (int base = 0; base < nO || base == 0; base += T) {
+        const int i = base + t;
+        const bool active = i < nO;
+        const int n = active ? ((base == 0) ? my_node : pn[i]) : 0;
+        NodeIn in{};
+        if (active) in = load_node(i, n);
+        if (base == 0) __syncthreads();  // corner forces of sub-step s+1 visible
+        if (active) {
+            double u2, v2;
+            solve_node(i, in, u2, v2);
+            VTn2[n] = u2; VTn2[n + Nn] = v2;
+        }
+    }
+}
+
 // Deferred mesh move of the fused path: the fused kernel leaves every sub-step's velocity in a ring of
 // VT buffers; every `count` sub-steps this kernel applies the same sequence of additions
 // M_UM += dte*M_VT, M_UT += dte*M_VT (FE.cpp:10543-10550) for all nodes, owned and ghost -- same
@@ -1420,6 +1624,12 @@ struct HostPatches {
     double avg_elems_per_own_node = 0.;
 };
 
+struct HostPatches2 {
+    int nP = 0, Pmax = 0, N1max = 0, N2max = 0, E1max = 0, E2max = 0, Wp = 0;
+    std::vector<int> own_cnt, n1_cnt, n2_cnt, e1_cnt, e2_cnt, pnodes, pelem;
+    std::vector<unsigned short> ptri, pfan;
+};
+
 struct nxs_dyn_handle {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -1430,7 +1640,14 @@ struct nxs_dyn_handle {
     DevState ds{};
     DevWork dw{};
     DevPatches dpch{};
-    int fused = 1;          // v2 fused sub-step kernel (default) vs v1 two-kernel sub-step
+    int fused = 3;          // 3 (default): v3 (two sub-steps per launch) on single-rank meshes that live in the caches, else v2;
+                            // 2: v3 wherever it is possible; 1: v2 fused sub-step kernel; 0: v1 two-kernel sub-step
+    int pair_nodes = 0;     // v3: own nodes per patch; 0 = auto
+    DevPatches2 dpch2{};
+    size_t pair_lds = 0;
+    int pair_threads = 512;
+    bool pair_ready = false;
+    std::vector<void *> pair_allocs;
     int patch_nodes = 0;    // own nodes per patch; 0 = auto
     int um_ring = 0;        // fused path: apply the mesh move every um_ring sub-steps from a ring of VT buffers
                             // (1 = every sub-step; 0 = auto: once per step on meshes that stream from HBM, 1 on cache-resident ones)
@@ -1775,6 +1992,162 @@ bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, con
     return ok;
 }
 
+// Host: two-ring patches of k_substep_pair (DevPatches2); single rank (every node owned, no orphan elements).
+bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int P, const std::vector<int> &order, HostPatches2 &out) {
+    std::vector<int> off(Nn + 1, 0);
+    for (int k = 0; k < 3; ++k) for (int e = 0; e < Ne; ++e) off[t[k][e] + 1]++;
+    for (int n = 0; n < Nn; ++n) off[n + 1] += off[n];
+    std::vector<int> adj(off[Nn]), fill(off.begin(), off.end() - 1);
+    for (int e = 0; e < Ne; ++e) for (int k = 0; k < 3; ++k) adj[fill[t[k][e]]++] = e;  // ascending e per node
+    const int nP = (Nn + P - 1) / P;
+    std::vector<int> patch_of(Nn, -1);
+    for (int i = 0; i < Nn; ++i) patch_of[order[i]] = i / P;
+    std::vector<int> writer(Ne);
+    for (int e = 0; e < Ne; ++e) writer[e] = std::min({patch_of[t[0][e]], patch_of[t[1][e]], patch_of[t[2][e]]});
+
+    out = HostPatches2{};
+    out.nP = nP;
+    out.own_cnt.resize(nP); out.n1_cnt.resize(nP); out.n2_cnt.resize(nP); out.e1_cnt.resize(nP); out.e2_cnt.resize(nP);
+    std::vector<std::vector<int>> pel(nP), pnd(nP);
+    std::vector<std::vector<unsigned short>> tri_l(nP);
+    std::vector<std::vector<std::vector<unsigned short>>> fan_l(nP);
+    std::vector<int> emark(Ne, -1), eslot(Ne, -1), slot_of(Nn, -1);
+    for (int q = 0; q < nP; ++q) {
+        const int a = q * P, bnd = std::min(Nn, a + P);
+        auto &nd = pnd[q];
+        auto &el = pel[q];
+        for (int i = a; i < bnd; ++i) { slot_of[order[i]] = (int)nd.size(); nd.push_back(order[i]); }
+        out.own_cnt[q] = bnd - a;
+        auto add_elements_of = [&](int n0, int n1e) {  // elements touching nodes nd[n0..n1e) not yet listed, ascending
+            std::vector<int> add;
+            for (int i = n0; i < n1e; ++i)
+                for (int j = off[nd[i]]; j < off[nd[i] + 1]; ++j) {
+                    const int e = adj[j];
+                    if (emark[e] != q) { emark[e] = q; add.push_back(e); }
+                }
+            std::sort(add.begin(), add.end());
+            el.insert(el.end(), add.begin(), add.end());
+        };
+        auto add_nodes_of = [&](int e0, int e1e) {  // nodes of elements el[e0..e1e) not yet listed, ascending
+            std::vector<int> add;
+            for (int l = e0; l < e1e; ++l)
+                for (int k = 0; k < 3; ++k) {
+                    const int n = t[k][el[l]];
+                    if (slot_of[n] == -1) { slot_of[n] = -2; add.push_back(n); }
+                }
+            std::sort(add.begin(), add.end());
+            for (int n : add) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
+        };
+        add_elements_of(0, out.own_cnt[q]);
+        out.e1_cnt[q] = (int)el.size();
+        add_nodes_of(0, out.e1_cnt[q]);
+        out.n1_cnt[q] = (int)nd.size();
+        add_elements_of(out.own_cnt[q], out.n1_cnt[q]);
+        out.e2_cnt[q] = (int)el.size();
+        add_nodes_of(out.e1_cnt[q], out.e2_cnt[q]);
+        out.n2_cnt[q] = (int)nd.size();
+        if (nd.size() > 65535 || el.size() > 8191) return false;
+        for (size_t l = 0; l < el.size(); ++l) eslot[el[l]] = (int)l;
+        auto &tl = tri_l[q];
+        tl.assign(4 * el.size(), 0);
+        for (size_t l = 0; l < el.size(); ++l)
+            for (int k = 0; k < 3; ++k) tl[4 * l + k] = (unsigned short)slot_of[t[k][el[l]]];
+        auto &fl = fan_l[q];
+        fl.assign(out.n1_cnt[q], {});
+        for (int i = 0; i < out.n1_cnt[q]; ++i) {
+            const int n = nd[i];
+            for (int j = off[n]; j < off[n + 1]; ++j) {  // ascending element id = the order of the serial scatter
+                const int e = adj[j];
+                int k = 0;
+                while (t[k][e] != n) ++k;
+                fl[i].push_back((unsigned short)((eslot[e] << 3) | (ghost3[3 * (size_t)e + k] ? 4 : 0) | k));
+            }
+            out.Wp = std::max(out.Wp, (int)fl[i].size());
+        }
+        for (int n : nd) slot_of[n] = -1;
+        out.Pmax = std::max(out.Pmax, out.own_cnt[q]);
+        out.N1max = std::max(out.N1max, out.n1_cnt[q]); out.N2max = std::max(out.N2max, out.n2_cnt[q]);
+        out.E1max = std::max(out.E1max, out.e1_cnt[q]); out.E2max = std::max(out.E2max, out.e2_cnt[q]);
+    }
+    out.N1max = (out.N1max + 1) & ~1; out.N2max = (out.N2max + 1) & ~1; out.E1max = (out.E1max + 1) & ~1; out.E2max = (out.E2max + 1) & ~1;
+    out.Wp = std::max(out.Wp, 1);
+    out.pnodes.assign((size_t)nP * out.N2max, 0);
+    out.pelem.assign((size_t)nP * out.E2max, 0);
+    out.ptri.assign((size_t)nP * out.E2max * 4, 0);
+    out.pfan.assign((size_t)nP * out.Wp * out.N1max, 0xFFFF);
+    for (int q = 0; q < nP; ++q) {
+        std::copy(pnd[q].begin(), pnd[q].end(), out.pnodes.begin() + (size_t)q * out.N2max);
+        for (size_t l = 0; l < pel[q].size(); ++l) {
+            const int e = pel[q][l];
+            out.pelem[(size_t)q * out.E2max + l] = (writer[e] == q) ? e : ~e;
+        }
+        std::copy(tri_l[q].begin(), tri_l[q].end(), out.ptri.begin() + (size_t)q * out.E2max * 4);
+        for (int i = 0; i < out.n1_cnt[q]; ++i)
+            for (size_t k = 0; k < fan_l[q][i].size(); ++k)
+                out.pfan[(size_t)q * out.Wp * out.N1max + k * out.N1max + i] = fan_l[q][i][k];
+    }
+    return true;
+}
+
+int upload_patches2(nxs_dyn_handle *h) {
+    free_pool(h->pair_allocs);
+    h->dpch2 = DevPatches2{};
+    h->pair_ready = false;
+    const DevMesh &m = h->dm;
+    if (m.No != m.Nn) return fail(h, NXS_ERR_STATE, "two-sub-step patches need a single-rank mesh");
+    std::vector<int> order(m.Nn);
+    for (int i = 0; i < m.Nn; ++i) order[i] = i;
+    HostPatches2 hp;
+    auto lds_of = [](const HostPatches2 &x) { return (4 * (size_t)x.N2max + 6 * (size_t)x.E2max + 4 * (size_t)x.E1max) * sizeof(double); };
+    int P = 0, threads = 512;
+    if (h->pair_nodes > 0) {
+        P = h->pair_nodes;
+        if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, order, hp)) return fail(h, NXS_ERR_INVALID, "two-sub-step patch construction failed (pair_nodes=%d)", P);
+    } else {
+        // as upload_patches: whole rounds of resident workgroups -- j workgroups per CU at a time, j = 1 first (a small mesh
+        // is fastest with ONE workgroup on every CU: 10 km, 247 patches of 120 nodes 1.06 ms/step, 265 patches of 112 nodes
+        // 1.30); the second sub-step's elements and the first sub-step's nodes in one round of the block
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        cus = std::max(cus, 1);
+        bool done = false;
+        for (int j = 1; j <= 512 && !done; ++j) {
+            P = (int)(((long long)m.Nn + (long long)j * cus - 1) / ((long long)j * cus));
+            P = std::max(32, (P + 3) & ~3);
+            if (P > 256) continue;
+            if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, order, hp)) continue;
+            const size_t lds_cap = (j == 1 ? 160 : 80) * 1024;  // one workgroup per CU may take it all; otherwise two must fit
+            done = hp.E1max <= 512 && hp.N1max <= 512 && lds_of(hp) <= lds_cap && (hp.nP <= j * cus || P == 32);
+        }
+        if (!done) return fail(h, NXS_ERR_INVALID, "no two-sub-step patch size fits (node numbering without locality?)");
+    }
+    h->pair_lds = lds_of(hp);
+    if (h->pair_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "two-sub-step patches need %zu B of LDS", h->pair_lds);
+    if (hp.E1max <= 256 && hp.N1max <= 256 && hp.E2max <= 512) threads = 256;
+    h->pair_threads = threads;
+    if (getenv("NXS_DEBUG_PATCHES")) {
+        long long s1 = 0, s2 = 0, m1 = 0, m2 = 0;
+        for (int q = 0; q < hp.nP; ++q) { s1 += hp.e1_cnt[q]; s2 += hp.e2_cnt[q]; m1 += hp.n1_cnt[q]; m2 += hp.n2_cnt[q]; }
+        fprintf(stderr, "[nxs] pair patches: P=%d nP=%d E1max=%d E2max=%d N1max=%d N2max=%d Wp=%d avg E1 %.1f E2 %.1f N1 %.1f N2 %.1f lds=%zu B threads=%d elems A x%.3f B x%.3f\n", P,
+                hp.nP, hp.E1max, hp.E2max, hp.N1max, hp.N2max, hp.Wp, (double)s1 / hp.nP, (double)s2 / hp.nP, (double)m1 / hp.nP, (double)m2 / hp.nP, h->pair_lds, threads,
+                (double)s2 / std::max(m.Ne, 1), (double)s1 / std::max(m.Ne, 1));
+    }
+    DevPatches2 &d = h->dpch2;
+    d.nP = hp.nP; d.Pmax = hp.Pmax; d.N1max = hp.N1max; d.N2max = hp.N2max; d.E1max = hp.E1max; d.E2max = hp.E2max; d.Wp = hp.Wp;
+    int rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.own_cnt, hp.own_cnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.n1_cnt, hp.n1_cnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.n2_cnt, hp.n2_cnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.e1_cnt, hp.e1_cnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.e2_cnt, hp.e2_cnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.pnodes, hp.pnodes))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.pelem, hp.pelem))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.ptri, hp.ptri))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.pfan, hp.pfan))) return rc;
+    h->pair_ready = true;
+    return NXS_OK;
+}
+
 int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
     free_pool(h->patch_allocs);
     DevPatches &d = h->dpch;
@@ -1957,6 +2330,8 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
+    free_pool(h->pair_allocs);
+    h->pair_ready = false;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -1994,7 +2369,14 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         return NXS_OK;
     }
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }
-    if (!std::strcmp(key, "fused")) { h->fused = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "fused")) {
+        if (value < 0 || value > 3) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2 or 3");
+        h->fused = (int)value; release_graph(h); return NXS_OK;
+    }
+    if (!std::strcmp(key, "pair_nodes")) {
+        if (value != 0 && (value < 16 || value > 512)) return fail(h, NXS_ERR_INVALID, "pair_nodes must be 0 (auto) or in [16,512]");
+        h->pair_nodes = (int)value; h->pair_ready = false; release_graph(h); return NXS_OK;
+    }
     if (!std::strcmp(key, "pin_host")) { h->pin_host = value != 0; if (!h->pin_host) unpin_all(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_fused")) { h->halo_fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
@@ -2039,6 +2421,8 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
+    free_pool(h->pair_allocs);
+    h->pair_ready = false;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -2626,6 +3010,21 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int
 #undef FUSED
 }
 
+// sub-steps sidx and sidx+1 in one launch (k_substep_pair): sigma/damage ping-pong per PAIR, velocities through the ring
+void launch_pair(nxs_dyn_handle *h, int sidx) {
+    PingPong b = pingpong(h, (sidx >> 1) & 1);
+    const int R = h->ring.R;
+    b.VTc = h->ring.slot[sidx % R];
+    b.VTn = h->ring.slot[(sidx + 1) % R];
+    double *vt2 = h->ring.slot[(sidx + 2) % R];
+    const dim3 grid(h->dpch2.nP);
+    const bool pow4 = h->dp.ers_int == 4;
+#define PAIR(TT, PP, NN) hipLaunchKernelGGL((k_substep_pair<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vt2)
+    if (h->pair_threads == 512) { if (pow4) { if (h->nt_mask) PAIR(512, true, 5); else PAIR(512, true, 0); } else PAIR(512, false, 0); }
+    else { if (pow4) { if (h->nt_mask) PAIR(256, true, 5); else PAIR(256, true, 0); } else PAIR(256, false, 0); }
+#undef PAIR
+}
+
 // (re)build the ring of velocity buffers of the fused path: slot 0 is M_VT itself, slot 1 is VT2
 int setup_ring(nxs_dyn_handle *h, int K) {
     const int R = K + 1;
@@ -2756,8 +3155,14 @@ int run_substeps(nxs_dyn_handle *h) {
     // whatever its period, so a longer ring only saves UM/UT passes (2 km: 7.60 -> 7.49 ms/step from 16 to 120, 1.4 GB of
     // slots); also whenever the halo exchange runs inside the sub-step kernel
     const int want_ring = h->um_ring > 0 ? h->um_ring : ((h->dm.Ne >= 400000 || (device_halo && h->halo_fused)) ? 120 : 1);
-    const int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
+    // v3: two sub-steps per launch -- single rank, an even number of sub-steps, the deferred mesh move (ring of >= 3 buffers)
+    // (it trades 20-60 % more arithmetic for less HBM traffic and half the launches: a gain where the sub-step is latency-bound,
+    // 10 km: 1.23 -> 1.06 ms/step; a loss where the v2 kernel already runs at 5.5 TB/s with its VALUs half busy, 2 km: 7.4 -> 8.0)
+    const bool pair = (h->fused == 2 || (h->fused == 3 && h->dm.Ne < 400000)) && !mr && move_dt != 0. && S >= 2 && (S & 1) == 0;
+    int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
+    if (pair) K = std::max(2, K & ~1);
     const bool deferred = K > 1;
+    if (pair && !h->pair_ready) { int rc = upload_patches2(h); if (rc) return rc; }
     if (fused) { int rc = setup_ring(h, K); if (rc) return rc; }
     const int R = h->ring.R;
     // the exchange inside the sub-step kernel: needs the deferred mesh move (ghost nodes are moved from the ring)
@@ -2772,6 +3177,16 @@ int run_substeps(nxs_dyn_handle *h) {
     auto loop = [&]() -> int {
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
         for (int s = 0; s < S; ++s) {
+            if (pair) {
+                launch_pair(h, s);
+                ++s;
+                pending += 2;
+                if (pending == K || s == S - 1) {
+                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt);
+                    pending = 0;
+                }
+                continue;
+            }
             if (halo_in_kernel) {
                 launch_fused(h, s, 0., 1, s > 0);
                 const bool flush = deferred && (pending + 1 == K || s == S - 1);
@@ -2797,12 +3212,13 @@ int run_substeps(nxs_dyn_handle *h) {
         }
         if (fused) {  // bring the result back to the primary buffers
             const double *vt_src = (S % R) ? h->ring.slot[S % R] : nullptr;
-            if (vt_src || (S & 1))
-                LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm, vt_src, S & 1);
+            const int odd = pair ? ((S >> 1) & 1) : (S & 1);  // sigma/damage ended in the secondary buffers
+            if (vt_src || odd)
+                LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm, vt_src, odd);
         }
         return NXS_OK;
     };
-    h->timing.substep_launches = halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
+    h->timing.substep_launches = pair ? S / 2 : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
     if (!h->use_graph || (mr && !device_halo)) return loop();
     if (!h->graph_valid) {
         release_graph(h);

@@ -363,6 +363,42 @@ def test_deferred_mesh_move_ring_does_not_change_a_bit(um_ring, substeps):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("dyn,substeps,opts", [("bbm", 120, {}), ("evp", 120, {}), ("bbm", 120, {"um_ring": 16}), ("bbm", 120, {"um_ring": 2}),
+                                               ("bbm", 6, {"pair_nodes": 16}), ("bbm", 120, {"pair_nodes": 300}), ("bbm", 2, {}),
+                                               ("bbm", 7, {}), ("mevp", 120, {})])
+def test_two_sub_steps_per_launch_do_not_change_a_bit(dyn, substeps, opts):
+    """fused=2 (k_substep_pair): sub-steps s and s+1 in one launch on patches with two rings of halo -- the ring is
+    recomputed by the neighbouring patches with the same operations, so every array has the bits of the per-loop
+    kernels; odd sub-step counts and mEVP (no deferred mesh move) fall back to one sub-step per launch."""
+    outs, launches = [], []
+    for options in (dict(opts, fused=2), {"fused": 0}):
+        fe, ref, lm = _pair("small", 2, options=options, dynamics_type=dyn, substeps=substeps, dtime_step=200. * substeps / 120.)
+        outs.append(fe.get_state())
+        launches.append(fe.timing()["substep_launches"])
+        fe.close()
+    for k in STATE_KEYS:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+    if dyn != "mevp" and substeps % 2 == 0:
+        assert launches[0] == substeps // 2
+
+
+def test_full_size_2km_two_sub_steps_per_launch_agree_bit_for_bit():
+    from nextsim_amd import dynamics
+    gm, p, g, lms, fields = cases.make_case("2km")
+    lm, f = lms[0], fields[0]
+    out = []
+    for fused in (2, 1):
+        fe = dynamics.FiniteElementDynamics(p)
+        fe.set_option("fused", fused)
+        fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+        fe.step(); fe.step(); fe.synchronize()
+        assert fe.checkFieldsFast() == 0
+        out.append(fe.get_state())
+        fe.close()
+    for k in STATE_KEYS:
+        assert np.array_equal(out[0][k], out[1][k]), k
+
+
 @pytest.mark.parametrize("patch_nodes", [64, 200, 1024])
 def test_patch_size_does_not_change_a_bit(patch_nodes):
     base, _, _ = _pair("toy", 2)
