@@ -382,6 +382,21 @@ def test_two_sub_steps_per_launch_do_not_change_a_bit(dyn, substeps, opts):
         assert launches[0] == substeps // 2
 
 
+def test_automatic_choice_of_the_sub_step_kernel():
+    """Default (fused = 3): two sub-steps per launch on a single-rank mesh that lives in the caches, one per launch when the
+    pairing is impossible (odd count) -- and the same bits either way."""
+    a, _, _ = _pair("small", 1)
+    assert a.timing()["substep_launches"] == 60
+    b, _, _ = _pair("small", 1, options={"fused": 1})
+    assert b.timing()["substep_launches"] == 120
+    x, y = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(x[k], y[k]), k
+    c, _, _ = _pair("small", 1, substeps=7, dtime_step=200. * 7 / 120.)
+    assert c.timing()["substep_launches"] == 7
+    a.close(); b.close(); c.close()
+
+
 def test_full_size_2km_two_sub_steps_per_launch_agree_bit_for_bit():
     from nextsim_amd import dynamics
     gm, p, g, lms, fields = cases.make_case("2km")
