@@ -129,6 +129,7 @@ struct DevWork {
     double *prec /*[Ne][10]: what k_prep_nodes gathers per fan entry, one record per element (see k_prep_elements)*/;
     double *expC, *pmax, *heal, *dxs, *volume;  // per-step element constants of the sub-step loop
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
+    unsigned char *open_blk;                     // [ceil(Nn/BLOCK)] != 0: the block of BLOCK nodes holds a node the open-water smoother changes (zeroed by k_prep_elements, set by k_prep_nodes)
     int *dxi;                                    // BBM, fused kernel: M_delta_x as the integer it is (Q1), ~M_delta_x when the element is skipped
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
@@ -161,6 +162,7 @@ __device__ __forceinline__ double jacobian(const double vx[3], const double vy[3
 __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, DevWork w, DevParams p) {
     // threads past the end redo the last element (identical values to identical places): every thread reaches the barrier
     const int e = min(blockIdx.x * BLOCK + (int)threadIdx.x, m.Ne - 1);
+    for (int i = blockIdx.x * BLOCK + (int)threadIdx.x; i < (m.Nn + BLOCK - 1) / BLOCK; i += gridDim.x * BLOCK) w.open_blk[i] = 0;  // k_prep_nodes raises them
     double vx[3], vy[3];
     load_vertices(m, s.UM, e, vx, vy);
 
@@ -321,6 +323,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     rl *= 3.;
     w.rlmass[n] = rl;
     w.node_mass[n] = nm;
+    if (n < m.No && !dirichlet && nm == 0.) w.open_blk[n / BLOCK] = 1;  // k_smooth's own test (FE.cpp:10589): its other blocks have nothing to do
 
     w.VTM[n] = vu;
     w.VTM[n + Nn] = vv;
@@ -1257,6 +1260,7 @@ __global__ void __launch_bounds__(BLOCK) k_halo_pull(double *__restrict__ vec, D
 // both ping-pong buffers (k_copy_vt makes them equal once before the 50 sweeps; ghosts are refreshed by
 // the halo exchange), so a sweep touches 9 B per node plus the open-water nodes' neighbourhoods.
 __global__ void __launch_bounds__(BLOCK) k_smooth(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst) {
+    if (!w.open_blk[blockIdx.x]) return;  // no ice-free node among these BLOCK nodes: 9 B per node not read, 50 times per step
     const int n = blockIdx.x * BLOCK + threadIdx.x;
     if (n >= m.No) return;
     if ((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.) return;
@@ -2543,7 +2547,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
     A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 10 * ne);
-    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne);
+    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn));
     A(w.force, 6 * ne);
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
     A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.xs, (size_t)Nn); A(w.ys, (size_t)Nn); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
