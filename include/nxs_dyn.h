@@ -258,12 +258,13 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
 /* Options (none changes a bit of the results; the tests assert that):
  *   "graph"        1 = sub-step loop replayed from a hipGraph (default); 0 = plain launches
  *   "timing"       1 = record the per-phase events (default); "timing_reset": zero the averages
- *   "fused"        3 = automatic (default): two sub-steps per launch on single-rank meshes that live in the caches
- *                  (< 400 k triangles; patches with two rings of halo), one patch kernel per sub-step otherwise;
- *                  2 = two sub-steps per launch wherever possible (single rank, even number of sub-steps, not mEVP);
- *                  1 = one patch kernel per sub-step; 0 = one kernel per reference loop
+ *   "fused"        3 = automatic (default): several sub-steps per launch on single-rank meshes that live in the caches
+ *                  (< 400 k triangles; patches with that many rings of halo), one patch kernel per sub-step otherwise;
+ *                  2 = several sub-steps per launch wherever possible (single rank, not mEVP, a depth that divides the
+ *                  number of sub-steps); 1 = one patch kernel per sub-step; 0 = one kernel per reference loop
+ *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)
  *   "patch_nodes"  own nodes per patch of the fused kernel, 64..1024; 0 = automatic (whole rounds of resident workgroups)
- *   "pair_nodes"   the same for the two-sub-step kernel, 16..512; 0 = automatic
+ *   "pair_nodes"   the same for the several-sub-steps kernel, 16..512; 0 = automatic
  *   "um_ring"      apply M_UM/M_UT += dt*M_VT every n sub-steps from a ring of velocity buffers, 1..128;
  *                  0 = automatic (once per step on meshes that stream from HBM, every sub-step on cache-resident ones)
  *   "nt_mask"      non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)

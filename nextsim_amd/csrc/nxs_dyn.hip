@@ -106,18 +106,21 @@ struct DevPatches {
     const unsigned short *pfan;   // [nP][Wp][Pmax] (element slot << 3 | ghost << 2 | corner), 0xFFFF pad
 };
 
-// Patches of the two-sub-steps-per-launch kernel (k_substep_pair): two rings of halo around the own nodes.
-//   nodes    [0, own) own | [own, n1) the other nodes of the elements touching an own node | [n1, n2) the other nodes of the
-//            elements touching an N1 node
-//   elements [0, e1) every element touching an own node (ascending id) | [e1, e2) the other elements touching an N1 node
+// Patches of the several-sub-steps-per-launch kernel (k_substep_multi): D rings of halo around the own nodes.
+//   nodes    N_0 = own | N_1 \ N_0 | ... | N_D \ N_(D-1)     N_i = the nodes of the elements E_i
+//   elements E_1 | E_2 \ E_1 | ... | E_D \ E_(D-1)           E_i = every element touching a node of N_(i-1), ascending id inside a level
+// sub-step k of a launch (k = 0 .. D-1) updates the elements E_(D-k) and solves the nodes N_(D-k-1).
+#define NXS_MAX_DEPTH 8
 struct DevPatches2 {
-    int nP, Pmax, N1max, N2max, E1max, E2max, Wp;
-    const int *own_cnt, *n1_cnt, *n2_cnt, *e1_cnt, *e2_cnt;  // [nP]
-    const int *pnodes;            // [nP][N2max] global node ids
-    const int *pelem;             // [nP][E2max] global element id; ~id when another patch writes it (or nobody from here: ring 2)
-    const unsigned short *ptri;   // [nP][E2max][4] patch-local node slots of the 3 corners (+ pad)
-    const unsigned short *pfan;   // [nP][Wp][N1max] fan of every N1 node, ascending element id: (element slot << 3 | ghost << 2 | corner)
+    int nP, D, NDmax /*nodes staged*/, NSmax /*nodes ever solved = N_(D-1)*/, EDmax /*elements of sub-step 0*/, ESmax /*elements needed again = E_(D-1)*/, Wp;
+    const int *ncnt;              // [nP][D+1] |N_0| .. |N_D|
+    const int *ecnt;              // [nP][D]   |E_1| .. |E_D|
+    const int *pnodes;            // [nP][NDmax] global node ids
+    const int *pelem;             // [nP][EDmax] global element id; ~id when this patch does not write it
+    const unsigned short *ptri;   // [nP][EDmax][4] patch-local node slots of the 3 corners (+ pad)
+    const unsigned short *pfan;   // [nP][Wp][NSmax] fan of every solved node, ascending element id: (element slot << 3 | ghost << 2 | corner)
 };
+struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
 
 struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
     const double *VTc, *s0c, *s1c, *s2c, *dc;
@@ -887,48 +890,48 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
 }
 
 // ------------------------------------------------------------------------------------------------
-// v3  TWO sub-steps per launch (single rank, deferred mesh move).  The sub-step loop is bound by HBM traffic, most of it
-// the element state (sigma, damage) and the per-step element constants that every sub-step streams once.  Here a patch
-// carries two rings of halo (DevPatches2): sub-step s is computed for every element touching an N1 node and every N1
-// node, sub-step s+1 for the elements touching an own node and the own nodes -- the ring is recomputed redundantly by the
-// neighbouring patches (same inputs, same operations, same bits) -- so the element state is read once and written
-// once per TWO sub-steps, and so are the nodal inputs.  The intermediate stresses stay in LDS, the intermediate
-// velocities (s+1) of the own nodes still go to their ring slot: the deferred mesh move needs every sub-step's velocity.
+// v3  D sub-steps per launch (single rank, deferred mesh move): temporal blocking of the sub-step loop.
+// A patch carries D rings of halo (DevPatches2).  Sub-step k of the launch updates the elements E_(D-k) and solves the nodes
+// N_(D-k-1): what lies outside the own nodes is recomputed redundantly by the neighbouring patches -- same inputs, same
+// operations, same bits -- so the element state and the nodal inputs are read once and written once per D sub-steps and
+// the loop needs S/D launches.  The intermediate stresses stay in LDS, the intermediate velocities of the own nodes still go
+// to their ring slots: the deferred mesh move needs every sub-step's velocity.
 template <int T, bool POW4, int NTM>
-__global__ void __launch_bounds__(T) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, double *__restrict__ VTn2) {
+__global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int N2m = pp.N2max, E2m = pp.E2max, E1m = pp.E1max;
-    double *lu = lds, *lv = lu + N2m, *lx = lv + N2m, *ly = lx + N2m, *lF = ly + N2m /*[6][E2m]*/, *lS = lF + 6 * (size_t)E2m /*[4][E1m]*/;
+    const int NDm = pp.NDmax, EDm = pp.EDmax, ESm = pp.ESmax, D = pp.D;
+    double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm, *lF = ly + NDm /*[6][EDm]*/, *lS = lF + 6 * (size_t)EDm /*[4][ESm]*/;
     int blk;
     {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
         const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, r = n & 7, x = pos & 7;
         blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
     }
     const int t = threadIdx.x, Nn = m.Nn;
-    const int nO = pp.own_cnt[blk], n1 = pp.n1_cnt[blk], n2 = pp.n2_cnt[blk], e1 = pp.e1_cnt[blk], e2 = pp.e2_cnt[blk];
-    const int *pn = pp.pnodes + (size_t)blk * N2m;
-    const int *pe = pp.pelem + (size_t)blk * E2m;
-    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * E2m;
-    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.N1max;
+    const int *ncnt = pp.ncnt + (size_t)blk * (D + 1), *ecnt = pp.ecnt + (size_t)blk * D;
+    const int nO = ncnt[0], nD = ncnt[D];
+    const int *pn = pp.pnodes + (size_t)blk * NDm;
+    const int *pe = pp.pelem + (size_t)blk * EDm;
+    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * EDm;
+    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
     constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
 
     // index rows are padded: the first loads depend on the launch arguments only
-    const int my_node = (t < N2m) ? pn[t] : 0;
+    const int my_node = (t < NDm) ? pn[t] : 0;
     int eraw0 = 0;
     ushort4 tr0 = make_ushort4(0, 0, 0, 0);
-    if (t < E2m) { eraw0 = pe[t]; tr0 = pt[t]; }
-    for (int i = t; i < n2; i += T) {
+    if (t < EDm) { eraw0 = pe[t]; tr0 = pt[t]; }
+    for (int i = t; i < nD; i += T) {
         const int g = (i == t) ? my_node : pn[i];
         lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
         lx[i] = w.xs[g]; ly[i] = w.ys[g];
     }
 
     // one element of one sub-step (FE.cpp:10425-10467), split into its global loads and the rest so that the barrier
-    // between them sits in uniform control flow.  first: state from HBM, result to LDS (if the element is needed again);
-    // second: state from LDS, result to HBM (if this patch writes the element)
+    // between them sits in uniform control flow.  first sub-step of the launch: state from HBM; last: result to HBM (if this
+    // patch writes the element); in between the state lives in LDS
     struct ElemIn { int e; bool writer, skip; int dxi; double sig[3], damage, expC, volume, pmax, heal, coh; };
-    auto load_element = [&](const int eraw, const bool first) {
+    auto load_element = [&](const int eraw, const bool first, const bool last) {
         ElemIn in;
         in.writer = eraw >= 0;
         in.e = in.writer ? eraw : ~eraw;
@@ -939,19 +942,19 @@ __global__ void __launch_bounds__(T) k_substep_pair(DevMesh m, DevPatches2 pp, D
             in.sig[0] = ldg<NT_S>(b.s0c + e); in.sig[1] = ldg<NT_S>(b.s1c + e); in.sig[2] = ldg<NT_S>(b.s2c + e);
             if (bbm) in.damage = ldg<NT_S>(b.dc + e);
         }
-        // the element constants are read by both sub-steps: the second read hits the L2 and is the streaming one
-        in.expC = first ? w.expC[e] : ldg<NT_C>(w.expC + e);
-        in.volume = first ? w.volume[e] : ldg<NT_C>(w.volume + e);
+        // the element constants are read by every sub-step of the launch: the later reads hit the L2
+        in.expC = last ? ldg<NT_C>(w.expC + e) : w.expC[e];
+        in.volume = last ? ldg<NT_C>(w.volume + e) : w.volume[e];
         if (bbm) {
-            in.pmax = first ? w.pmax[e] : ldg<NT_C>(w.pmax + e); in.heal = first ? w.heal[e] : ldg<NT_C>(w.heal + e);
-            in.dxi = w.dxi[e]; in.coh = first ? s.cohesion[e] : ldg<NT_C>(s.cohesion + e);
+            in.pmax = last ? ldg<NT_C>(w.pmax + e) : w.pmax[e]; in.heal = last ? ldg<NT_C>(w.heal + e) : w.heal[e];
+            in.dxi = w.dxi[e]; in.coh = last ? ldg<NT_C>(s.cohesion + e) : s.cohesion[e];
         }
         return in;
     };
-    auto compute_element = [&](const int l, const ushort4 tr, ElemIn &in, const bool first) {
+    auto compute_element = [&](const int l, const ushort4 tr, ElemIn &in, const bool first, const bool last, const int keep) {
         double dxN[6], sig[3] = {in.sig[0], in.sig[1], in.sig[2]}, damage = in.damage, c_dxs = 1.;
         bool skip = in.skip;
-        if (!first) { sig[0] = lS[l]; sig[1] = lS[E1m + l]; sig[2] = lS[2 * (size_t)E1m + l]; damage = lS[3 * (size_t)E1m + l]; }
+        if (!first) { sig[0] = lS[l]; sig[1] = lS[ESm + l]; sig[2] = lS[2 * (size_t)ESm + l]; damage = lS[3 * (size_t)ESm + l]; }
         if (bbm) {  // M_delta_x is an integer number of metres (Q1) and travels as one, with the skip flag in its sign
             skip = in.dxi < 0;
             c_dxs = (double)(skip ? ~in.dxi : in.dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
@@ -976,8 +979,8 @@ __global__ void __launch_bounds__(T) k_substep_pair(DevMesh m, DevPatches2 pp, D
             if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, in.expC, in.pmax, in.heal, c_dxs, in.coh);
             else vp_stress(p, dxN, u, v, sig, in.expC);
         }
-        if (first) {
-            if (l < e1) { lS[l] = sig[0]; lS[E1m + l] = sig[1]; lS[2 * (size_t)E1m + l] = sig[2]; lS[3 * (size_t)E1m + l] = damage; }
+        if (!last) {
+            if (l < keep) { lS[l] = sig[0]; lS[ESm + l] = sig[1]; lS[2 * (size_t)ESm + l] = sig[2]; lS[3 * (size_t)ESm + l] = damage; }  // needed by the next sub-step
         } else if (in.writer) {
             stg<NT_S>(b.s0n + in.e, sig[0]); stg<NT_S>(b.s1n + in.e, sig[1]); stg<NT_S>(b.s2n + in.e, sig[2]);
             if (bbm) stg<NT_S>(b.dn + in.e, damage);
@@ -985,7 +988,7 @@ __global__ void __launch_bounds__(T) k_substep_pair(DevMesh m, DevPatches2 pp, D
         double F[6];
         corner_forces(in.volume, sig, dxN, F);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) lF[(size_t)k * E2m + l] = F[k];
+        for (int k = 0; k < 6; ++k) lF[(size_t)k * EDm + l] = F[k];
     };
     // one node of one sub-step (FE.cpp:10472-10529), loads and solve apart for the same reason
     struct NodeIn { unsigned char nf; double node_mass, gx, gy, rlm, cbu, fcor, tax, tay, ou, ov; unsigned short fan[8]; };
@@ -998,7 +1001,7 @@ __global__ void __launch_bounds__(T) k_substep_pair(DevMesh m, DevPatches2 pp, D
         in.tax = w.D_tau_a[n]; in.tay = w.D_tau_a[n + Nn];
         in.ou = s.ocean[n]; in.ov = s.ocean[n + Nn];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) in.fan[k] = (k < pp.Wp) ? pf[(size_t)k * pp.N1max + i] : (unsigned short)0xFFFFu;
+        for (int k = 0; k < 8; ++k) in.fan[k] = (k < pp.Wp) ? pf[(size_t)k * pp.NSmax + i] : (unsigned short)0xFFFFu;
         return in;
     };
     auto solve_node = [&](const int i, NodeIn &in, double &uice, double &vice) {
@@ -1012,67 +1015,49 @@ __global__ void __launch_bounds__(T) k_substep_pair(DevMesh m, DevPatches2 pp, D
             if (!more || ent == 0xFFFFu) { more = false; continue; }
             if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
             const int l = ent >> 3, c = ent & 3u;
-            gx -= lF[(size_t)c * E2m + l];
-            gy -= lF[(size_t)(c + 3) * E2m + l];
+            gx -= lF[(size_t)c * EDm + l];
+            gy -= lF[(size_t)(c + 3) * EDm + l];
         }
         for (int k = 8; more && k < pp.Wp; ++k) {
-            const unsigned ent = pf[(size_t)k * pp.N1max + i];
+            const unsigned ent = pf[(size_t)k * pp.NSmax + i];
             if (ent == 0xFFFFu) break;
             if (ent & 4u) continue;
             const int l = ent >> 3, c = ent & 3u;
-            gx -= lF[(size_t)c * E2m + l];
-            gy -= lF[(size_t)(c + 3) * E2m + l];
+            gx -= lF[(size_t)c * EDm + l];
+            gy -= lF[(size_t)(c + 3) * EDm + l];
         }
         nodal_solve(p, gx, gy, uice, vice, in.node_mass, in.rlm, in.cbu, in.fcor, (in.nf & NF_LAT_NEG) ? -1. : 1., in.tax, in.tay, in.ou, in.ov, 0., 0.);
     };
 
-    // ---- sub-step s: every element touching an N1 node, every N1 node
-    for (int base = 0; base < e2 || base == 0; base += T) {
-        const int l = base + t;
-        const bool active = l < e2;
-        int eraw = eraw0; ushort4 tr = tr0;
-        if (base > 0 && active) { eraw = pe[l]; tr = pt[l]; }
-        ElemIn in{};
-        if (active) in = load_element(eraw, true);
-        if (base == 0) __syncthreads();  // staged velocities / coordinates visible
-        if (active) compute_element(l, tr, in, true);
-    }
-    for (int base = 0; base < n1 || base == 0; base += T) {
-        const int i = base + t;
-        const bool active = i < n1;
-        const int n = active ? ((base == 0) ? my_node : pn[i]) : 0;
-        NodeIn in{};
-        if (active) in = load_node(i, n);
-        if (base == 0) __syncthreads();  // corner forces of sub-step s visible
-        if (active) {
-            double u1, v1;
-            solve_node(i, in, u1, v1);
-            if (i < nO) { b.VTn[n] = u1; b.VTn[n + Nn] = v1; }
-            lu[i] = u1; lv[i] = v1;  // a node's solve reads only its own staged velocity: in place
-        }
-    }
-    __syncthreads();  // velocities of sub-step s+1 on every N1 node; the corner forces of sub-step s are consumed
-    // ---- sub-step s+1: the elements touching an own node, the own nodes
-    for (int base = 0; base < e1; base += T) {
-        const int l = base + t;
-        if (l < e1) {
+    for (int k = 0; k < D; ++k) {
+        const int ne = ecnt[D - 1 - k], nn = ncnt[D - 1 - k], keep = (k + 1 < D) ? ecnt[D - 2 - k] : 0;
+        const bool first = k == 0, last = k == D - 1;
+        // ---- elements E_(D-k)
+        for (int base = 0; base < ne || base == 0; base += T) {
+            const int l = base + t;
+            const bool active = l < ne;
             int eraw = eraw0; ushort4 tr = tr0;
-            if (base > 0) { eraw = pe[l]; tr = pt[l]; }
-            ElemIn in = load_element(eraw, false);
-            compute_element(l, tr, in, false);
+            if (base > 0 && active) { eraw = pe[l]; tr = pt[l]; }
+            ElemIn in{};
+            if (active) in = load_element(eraw, first, last);
+            if (base == 0) __syncthreads();  // k == 0: staged velocities / coordinates; k > 0: the velocities of sub-step k on N_(D-k), forces consumed
+            if (active) compute_element(l, tr, in, first, last, keep);
         }
-    }
-    for (int base = 0; base < nO || base == 0; base += T) {
-        const int i = base + t;
-        const bool active = i < nO;
-        const int n = active ? ((base == 0) ? my_node : pn[i]) : 0;
-        NodeIn in{};
-        if (active) in = load_node(i, n);
-        if (base == 0) __syncthreads();  // corner forces of sub-step s+1 visible
-        if (active) {
-            double u2, v2;
-            solve_node(i, in, u2, v2);
-            VTn2[n] = u2; VTn2[n + Nn] = v2;
+        // ---- nodes N_(D-k-1)
+        double *vt = vout.slot[k];
+        for (int base = 0; base < nn || base == 0; base += T) {
+            const int i = base + t;
+            const bool active = i < nn;
+            const int n = active ? ((base == 0) ? my_node : pn[i]) : 0;
+            NodeIn in{};
+            if (active) in = load_node(i, n);
+            if (base == 0) __syncthreads();  // corner forces of this sub-step visible
+            if (active) {
+                double u1, v1;
+                solve_node(i, in, u1, v1);
+                if (i < nO) { vt[n] = u1; vt[n + Nn] = v1; }
+                lu[i] = u1; lv[i] = v1;  // a node's solve reads only its own staged velocity: in place
+            }
         }
     }
 }
@@ -1626,11 +1611,12 @@ struct HostPatches {
     std::vector<int> own_cnt, elem_cnt, node_cnt, pnodes, pelem;
     std::vector<unsigned short> ptri, pfan;
     double avg_elems_per_own_node = 0.;
+    bool used_hilbert = false;  // the caller's numbering had no locality: patches cut along a Hilbert curve
 };
 
 struct HostPatches2 {
-    int nP = 0, Pmax = 0, N1max = 0, N2max = 0, E1max = 0, E2max = 0, Wp = 0;
-    std::vector<int> own_cnt, n1_cnt, n2_cnt, e1_cnt, e2_cnt, pnodes, pelem;
+    int nP = 0, D = 0, NDmax = 0, NSmax = 0, EDmax = 0, ESmax = 0, Wp = 0;
+    std::vector<int> ncnt, ecnt, pnodes, pelem;
     std::vector<unsigned short> ptri, pfan;
 };
 
@@ -1647,6 +1633,9 @@ struct nxs_dyn_handle {
     int fused = 3;          // 3 (default): v3 (two sub-steps per launch) on single-rank meshes that live in the caches, else v2;
                             // 2: v3 wherever it is possible; 1: v2 fused sub-step kernel; 0: v1 two-kernel sub-step
     int pair_nodes = 0;     // v3: own nodes per patch; 0 = auto
+    int pair_depth = 0;     // v3: sub-steps per launch, 2..NXS_MAX_DEPTH; 0 = auto
+    int pair_depth_built = 0;
+    bool pair_failed = false;   // the D-ring patches could not be built for this mesh: v2 instead
     DevPatches2 dpch2{};
     size_t pair_lds = 0;
     int pair_threads = 512;
@@ -1960,15 +1949,10 @@ bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *
     return true;
 }
 
-bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
-                   int No, int P, HostPatches &out) {
-    // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
-    std::vector<int> order(No);
+// owned nodes sorted along a Hilbert curve through their coordinates
+void hilbert_order(const double *x0, const double *y0, int No, std::vector<int> &order) {
+    order.resize(No);
     for (int i = 0; i < No; ++i) order[i] = i;
-    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out);
-    if (ok && out.avg_elems_per_own_node <= 3.0) return true;
-    // numbering without locality: cut patches along a Hilbert curve through the node coordinates
-    // (consecutive runs of a Hilbert curve are compact blobs: small halos)
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     for (int n = 0; n < No; ++n) { xmin = std::min(xmin, x0[n]); xmax = std::max(xmax, x0[n]); ymin = std::min(ymin, y0[n]); ymax = std::max(ymax, y0[n]); }
     const double ext = std::max(xmax - xmin, ymax - ymin);
@@ -1988,16 +1972,29 @@ bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, con
     std::vector<unsigned long long> key(No);
     for (int n = 0; n < No; ++n) key[n] = hilbert((unsigned)((x0[n] - xmin) * sc), (unsigned)((y0[n] - ymin) * sc));
     std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
+}
+
+bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
+                   int No, int P, HostPatches &out) {
+    // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
+    std::vector<int> order(No);
+    for (int i = 0; i < No; ++i) order[i] = i;
+    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out);
+    if (ok && out.avg_elems_per_own_node <= 3.0) return true;
+    // numbering without locality: cut patches along a Hilbert curve through the node coordinates
+    // (consecutive runs of a Hilbert curve are compact blobs: small halos)
+    hilbert_order(x0, y0, No, order);
     HostPatches alt;
     if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
         out = std::move(alt);
+        out.used_hilbert = true;
         return true;
     }
     return ok;
 }
 
-// Host: two-ring patches of k_substep_pair (DevPatches2); single rank (every node owned, no orphan elements).
-bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int P, const std::vector<int> &order, HostPatches2 &out) {
+// Host: D-ring patches of k_substep_multi (DevPatches2); single rank (every node owned, no orphan elements).
+bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int P, int D, const std::vector<int> &order, HostPatches2 &out) {
     std::vector<int> off(Nn + 1, 0);
     for (int k = 0; k < 3; ++k) for (int e = 0; e < Ne; ++e) off[t[k][e] + 1]++;
     for (int n = 0; n < Nn; ++n) off[n + 1] += off[n];
@@ -2010,8 +2007,8 @@ bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, in
     for (int e = 0; e < Ne; ++e) writer[e] = std::min({patch_of[t[0][e]], patch_of[t[1][e]], patch_of[t[2][e]]});
 
     out = HostPatches2{};
-    out.nP = nP;
-    out.own_cnt.resize(nP); out.n1_cnt.resize(nP); out.n2_cnt.resize(nP); out.e1_cnt.resize(nP); out.e2_cnt.resize(nP);
+    out.nP = nP; out.D = D;
+    out.ncnt.assign((size_t)nP * (D + 1), 0); out.ecnt.assign((size_t)nP * D, 0);
     std::vector<std::vector<int>> pel(nP), pnd(nP);
     std::vector<std::vector<unsigned short>> tri_l(nP);
     std::vector<std::vector<std::vector<unsigned short>>> fan_l(nP);
@@ -2020,45 +2017,43 @@ bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, in
         const int a = q * P, bnd = std::min(Nn, a + P);
         auto &nd = pnd[q];
         auto &el = pel[q];
+        int *nc = out.ncnt.data() + (size_t)q * (D + 1), *ec = out.ecnt.data() + (size_t)q * D;
         for (int i = a; i < bnd; ++i) { slot_of[order[i]] = (int)nd.size(); nd.push_back(order[i]); }
-        out.own_cnt[q] = bnd - a;
-        auto add_elements_of = [&](int n0, int n1e) {  // elements touching nodes nd[n0..n1e) not yet listed, ascending
+        nc[0] = bnd - a;
+        int n_prev = 0, e_prev = 0;
+        for (int lev = 1; lev <= D; ++lev) {
+            // E_lev: the elements touching N_(lev-1) that are not listed yet, ascending
             std::vector<int> add;
-            for (int i = n0; i < n1e; ++i)
+            for (int i = n_prev; i < nc[lev - 1]; ++i)
                 for (int j = off[nd[i]]; j < off[nd[i] + 1]; ++j) {
                     const int e = adj[j];
                     if (emark[e] != q) { emark[e] = q; add.push_back(e); }
                 }
             std::sort(add.begin(), add.end());
             el.insert(el.end(), add.begin(), add.end());
-        };
-        auto add_nodes_of = [&](int e0, int e1e) {  // nodes of elements el[e0..e1e) not yet listed, ascending
-            std::vector<int> add;
-            for (int l = e0; l < e1e; ++l)
+            ec[lev - 1] = (int)el.size();
+            // N_lev: their nodes that are not listed yet, ascending
+            std::vector<int> addn;
+            for (int l = e_prev; l < ec[lev - 1]; ++l)
                 for (int k = 0; k < 3; ++k) {
                     const int n = t[k][el[l]];
-                    if (slot_of[n] == -1) { slot_of[n] = -2; add.push_back(n); }
+                    if (slot_of[n] == -1) { slot_of[n] = -2; addn.push_back(n); }
                 }
-            std::sort(add.begin(), add.end());
-            for (int n : add) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
-        };
-        add_elements_of(0, out.own_cnt[q]);
-        out.e1_cnt[q] = (int)el.size();
-        add_nodes_of(0, out.e1_cnt[q]);
-        out.n1_cnt[q] = (int)nd.size();
-        add_elements_of(out.own_cnt[q], out.n1_cnt[q]);
-        out.e2_cnt[q] = (int)el.size();
-        add_nodes_of(out.e1_cnt[q], out.e2_cnt[q]);
-        out.n2_cnt[q] = (int)nd.size();
+            std::sort(addn.begin(), addn.end());
+            for (int n : addn) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
+            nc[lev] = (int)nd.size();
+            n_prev = nc[lev - 1]; e_prev = ec[lev - 1];
+        }
         if (nd.size() > 65535 || el.size() > 8191) return false;
         for (size_t l = 0; l < el.size(); ++l) eslot[el[l]] = (int)l;
         auto &tl = tri_l[q];
         tl.assign(4 * el.size(), 0);
         for (size_t l = 0; l < el.size(); ++l)
             for (int k = 0; k < 3; ++k) tl[4 * l + k] = (unsigned short)slot_of[t[k][el[l]]];
+        const int nsolved = nc[D - 1];
         auto &fl = fan_l[q];
-        fl.assign(out.n1_cnt[q], {});
-        for (int i = 0; i < out.n1_cnt[q]; ++i) {
+        fl.assign(nsolved, {});
+        for (int i = 0; i < nsolved; ++i) {
             const int n = nd[i];
             for (int j = off[n]; j < off[n + 1]; ++j) {  // ascending element id = the order of the serial scatter
                 const int e = adj[j];
@@ -2069,48 +2064,49 @@ bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, in
             out.Wp = std::max(out.Wp, (int)fl[i].size());
         }
         for (int n : nd) slot_of[n] = -1;
-        out.Pmax = std::max(out.Pmax, out.own_cnt[q]);
-        out.N1max = std::max(out.N1max, out.n1_cnt[q]); out.N2max = std::max(out.N2max, out.n2_cnt[q]);
-        out.E1max = std::max(out.E1max, out.e1_cnt[q]); out.E2max = std::max(out.E2max, out.e2_cnt[q]);
+        out.NDmax = std::max(out.NDmax, nc[D]); out.NSmax = std::max(out.NSmax, nc[D - 1]);
+        out.EDmax = std::max(out.EDmax, ec[D - 1]); out.ESmax = std::max(out.ESmax, D >= 2 ? ec[D - 2] : 0);
     }
-    out.N1max = (out.N1max + 1) & ~1; out.N2max = (out.N2max + 1) & ~1; out.E1max = (out.E1max + 1) & ~1; out.E2max = (out.E2max + 1) & ~1;
+    out.NDmax = (out.NDmax + 1) & ~1; out.NSmax = (out.NSmax + 1) & ~1; out.EDmax = (out.EDmax + 1) & ~1; out.ESmax = std::max(2, (out.ESmax + 1) & ~1);
     out.Wp = std::max(out.Wp, 1);
-    out.pnodes.assign((size_t)nP * out.N2max, 0);
-    out.pelem.assign((size_t)nP * out.E2max, 0);
-    out.ptri.assign((size_t)nP * out.E2max * 4, 0);
-    out.pfan.assign((size_t)nP * out.Wp * out.N1max, 0xFFFF);
+    out.pnodes.assign((size_t)nP * out.NDmax, 0);
+    out.pelem.assign((size_t)nP * out.EDmax, 0);
+    out.ptri.assign((size_t)nP * out.EDmax * 4, 0);
+    out.pfan.assign((size_t)nP * out.Wp * out.NSmax, 0xFFFF);
     for (int q = 0; q < nP; ++q) {
-        std::copy(pnd[q].begin(), pnd[q].end(), out.pnodes.begin() + (size_t)q * out.N2max);
+        std::copy(pnd[q].begin(), pnd[q].end(), out.pnodes.begin() + (size_t)q * out.NDmax);
         for (size_t l = 0; l < pel[q].size(); ++l) {
             const int e = pel[q][l];
-            out.pelem[(size_t)q * out.E2max + l] = (writer[e] == q) ? e : ~e;
+            out.pelem[(size_t)q * out.EDmax + l] = (writer[e] == q) ? e : ~e;
         }
-        std::copy(tri_l[q].begin(), tri_l[q].end(), out.ptri.begin() + (size_t)q * out.E2max * 4);
-        for (int i = 0; i < out.n1_cnt[q]; ++i)
+        std::copy(tri_l[q].begin(), tri_l[q].end(), out.ptri.begin() + (size_t)q * out.EDmax * 4);
+        for (size_t i = 0; i < fan_l[q].size(); ++i)
             for (size_t k = 0; k < fan_l[q][i].size(); ++k)
-                out.pfan[(size_t)q * out.Wp * out.N1max + k * out.N1max + i] = fan_l[q][i][k];
+                out.pfan[(size_t)q * out.Wp * out.NSmax + k * out.NSmax + i] = fan_l[q][i][k];
     }
     return true;
 }
 
-int upload_patches2(nxs_dyn_handle *h) {
+int upload_patches2(nxs_dyn_handle *h, int D) {
     free_pool(h->pair_allocs);
     h->dpch2 = DevPatches2{};
     h->pair_ready = false;
     const DevMesh &m = h->dm;
-    if (m.No != m.Nn) return fail(h, NXS_ERR_STATE, "two-sub-step patches need a single-rank mesh");
+    if (m.No != m.Nn) return fail(h, NXS_ERR_STATE, "multi-sub-step patches need a single-rank mesh");
     std::vector<int> order(m.Nn);
     for (int i = 0; i < m.Nn; ++i) order[i] = i;
+    // the caller's numbering if it has locality, else the Hilbert curve the single-ring patches were cut along
+    if (h->hp && h->hp->used_hilbert) hilbert_order(h->h_x0.data(), h->h_y0.data(), m.Nn, order);
     HostPatches2 hp;
-    auto lds_of = [](const HostPatches2 &x) { return (4 * (size_t)x.N2max + 6 * (size_t)x.E2max + 4 * (size_t)x.E1max) * sizeof(double); };
+    auto lds_of = [](const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 4 * (size_t)x.ESmax) * sizeof(double); };
     int P = 0, threads = 512;
     if (h->pair_nodes > 0) {
         P = h->pair_nodes;
-        if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, order, hp)) return fail(h, NXS_ERR_INVALID, "two-sub-step patch construction failed (pair_nodes=%d)", P);
+        if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, D, order, hp)) return fail(h, NXS_ERR_INVALID, "multi-sub-step patch construction failed (pair_nodes=%d)", P);
     } else {
         // as upload_patches: whole rounds of resident workgroups -- j workgroups per CU at a time, j = 1 first (a small mesh
         // is fastest with ONE workgroup on every CU: 10 km, 247 patches of 120 nodes 1.06 ms/step, 265 patches of 112 nodes
-        // 1.30); the second sub-step's elements and the first sub-step's nodes in one round of the block
+        // 1.30)
         int cus = 256;
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
         cus = std::max(cus, 1);
@@ -2119,36 +2115,39 @@ int upload_patches2(nxs_dyn_handle *h) {
             P = (int)(((long long)m.Nn + (long long)j * cus - 1) / ((long long)j * cus));
             P = std::max(32, (P + 3) & ~3);
             if (P > 256) continue;
-            if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, order, hp)) continue;
+            if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, D, order, hp)) continue;
             const size_t lds_cap = (j == 1 ? 160 : 80) * 1024;  // one workgroup per CU may take it all; otherwise two must fit
-            done = hp.E1max <= 512 && hp.N1max <= 512 && lds_of(hp) <= lds_cap && (hp.nP <= j * cus || P == 32);
+            done = lds_of(hp) <= lds_cap && (hp.nP <= j * cus || P == 32);
         }
-        if (!done) return fail(h, NXS_ERR_INVALID, "no two-sub-step patch size fits (node numbering without locality?)");
+        if (!done) return fail(h, NXS_ERR_INVALID, "no multi-sub-step patch size fits (node numbering without locality?)");
     }
     h->pair_lds = lds_of(hp);
-    if (h->pair_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "two-sub-step patches need %zu B of LDS", h->pair_lds);
-    if (hp.E1max <= 256 && hp.N1max <= 256 && hp.E2max <= 512) threads = 256;
+    if (h->pair_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "multi-sub-step patches need %zu B of LDS", h->pair_lds);
+    // 512 threads at most: a 1 024-thread workgroup runs this kernel at half the speed (10 km, D = 2: 1.98 vs 1.11 ms/step); the
+    // outer levels of a deep patch take a second round of the block instead
+    threads = hp.EDmax <= 256 ? 256 : 512;
     h->pair_threads = threads;
     if (getenv("NXS_DEBUG_PATCHES")) {
-        long long s1 = 0, s2 = 0, m1 = 0, m2 = 0;
-        for (int q = 0; q < hp.nP; ++q) { s1 += hp.e1_cnt[q]; s2 += hp.e2_cnt[q]; m1 += hp.n1_cnt[q]; m2 += hp.n2_cnt[q]; }
-        fprintf(stderr, "[nxs] pair patches: P=%d nP=%d E1max=%d E2max=%d N1max=%d N2max=%d Wp=%d avg E1 %.1f E2 %.1f N1 %.1f N2 %.1f lds=%zu B threads=%d elems A x%.3f B x%.3f\n", P,
-                hp.nP, hp.E1max, hp.E2max, hp.N1max, hp.N2max, hp.Wp, (double)s1 / hp.nP, (double)s2 / hp.nP, (double)m1 / hp.nP, (double)m2 / hp.nP, h->pair_lds, threads,
-                (double)s2 / std::max(m.Ne, 1), (double)s1 / std::max(m.Ne, 1));
+        std::vector<double> se(D, 0.), sn(D + 1, 0.);
+        for (int q = 0; q < hp.nP; ++q) { for (int i = 0; i < D; ++i) se[i] += hp.ecnt[(size_t)q * D + i]; for (int i = 0; i <= D; ++i) sn[i] += hp.ncnt[(size_t)q * (D + 1) + i]; }
+        fprintf(stderr, "[nxs] multi patches: D=%d P=%d nP=%d EDmax=%d ESmax=%d NDmax=%d NSmax=%d Wp=%d lds=%zu B threads=%d; elements per level x", D, P, hp.nP, hp.EDmax, hp.ESmax,
+                hp.NDmax, hp.NSmax, hp.Wp, h->pair_lds, threads);
+        for (int i = 0; i < D; ++i) fprintf(stderr, " %.3f", se[i] / std::max(m.Ne, 1));
+        fprintf(stderr, "; nodes per level x");
+        for (int i = 0; i <= D; ++i) fprintf(stderr, " %.3f", sn[i] / std::max(m.Nn, 1));
+        fprintf(stderr, "\n");
     }
     DevPatches2 &d = h->dpch2;
-    d.nP = hp.nP; d.Pmax = hp.Pmax; d.N1max = hp.N1max; d.N2max = hp.N2max; d.E1max = hp.E1max; d.E2max = hp.E2max; d.Wp = hp.Wp;
+    d.nP = hp.nP; d.D = D; d.NDmax = hp.NDmax; d.NSmax = hp.NSmax; d.EDmax = hp.EDmax; d.ESmax = hp.ESmax; d.Wp = hp.Wp;
     int rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.own_cnt, hp.own_cnt))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.n1_cnt, hp.n1_cnt))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.n2_cnt, hp.n2_cnt))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.e1_cnt, hp.e1_cnt))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.e2_cnt, hp.e2_cnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.ncnt, hp.ncnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.ecnt, hp.ecnt))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.pnodes, hp.pnodes))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.pelem, hp.pelem))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.ptri, hp.ptri))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.pfan, hp.pfan))) return rc;
     h->pair_ready = true;
+    h->pair_depth_built = D;
     return NXS_OK;
 }
 
@@ -2336,6 +2335,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->patch_allocs);
     free_pool(h->pair_allocs);
     h->pair_ready = false;
+    h->pair_failed = false;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -2377,9 +2377,13 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         if (value < 0 || value > 3) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2 or 3");
         h->fused = (int)value; release_graph(h); return NXS_OK;
     }
+    if (!std::strcmp(key, "substeps_per_launch")) {
+        if (value != 0 && (value < 2 || value > NXS_MAX_DEPTH)) return fail(h, NXS_ERR_INVALID, "substeps_per_launch must be 0 (auto) or in [2,%d]", NXS_MAX_DEPTH);
+        h->pair_depth = (int)value; h->pair_failed = false; release_graph(h); return NXS_OK;
+    }
     if (!std::strcmp(key, "pair_nodes")) {
         if (value != 0 && (value < 16 || value > 512)) return fail(h, NXS_ERR_INVALID, "pair_nodes must be 0 (auto) or in [16,512]");
-        h->pair_nodes = (int)value; h->pair_ready = false; release_graph(h); return NXS_OK;
+        h->pair_nodes = (int)value; h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "pin_host")) { h->pin_host = value != 0; if (!h->pin_host) unpin_all(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_fused")) { h->halo_fused = value != 0; release_graph(h); return NXS_OK; }
@@ -2427,6 +2431,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->patch_allocs);
     free_pool(h->pair_allocs);
     h->pair_ready = false;
+    h->pair_failed = false;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -3014,19 +3019,21 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int
 #undef FUSED
 }
 
-// sub-steps sidx and sidx+1 in one launch (k_substep_pair): sigma/damage ping-pong per PAIR, velocities through the ring
-void launch_pair(nxs_dyn_handle *h, int sidx) {
-    PingPong b = pingpong(h, (sidx >> 1) & 1);
+// sub-steps sidx .. sidx+D-1 in one launch (k_substep_multi): sigma/damage ping-pong per LAUNCH, velocities through the ring
+void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
+    PingPong b = pingpong(h, (sidx / D) & 1);
     const int R = h->ring.R;
     b.VTc = h->ring.slot[sidx % R];
-    b.VTn = h->ring.slot[(sidx + 1) % R];
-    double *vt2 = h->ring.slot[(sidx + 2) % R];
+    b.VTn = nullptr;
+    VTOut vo{};
+    for (int k = 0; k < D; ++k) vo.slot[k] = h->ring.slot[(sidx + 1 + k) % R];
     const dim3 grid(h->dpch2.nP);
     const bool pow4 = h->dp.ers_int == 4;
-#define PAIR(TT, PP, NN) hipLaunchKernelGGL((k_substep_pair<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vt2)
-    if (h->pair_threads == 512) { if (pow4) { if (h->nt_mask) PAIR(512, true, 5); else PAIR(512, true, 0); } else PAIR(512, false, 0); }
-    else { if (pow4) { if (h->nt_mask) PAIR(256, true, 5); else PAIR(256, true, 0); } else PAIR(256, false, 0); }
-#undef PAIR
+#define MULTI(TT, PP, NN) hipLaunchKernelGGL((k_substep_multi<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo)
+#define MULTI_T(TT) do { if (pow4) { if (h->nt_mask) MULTI(TT, true, 5); else MULTI(TT, true, 0); } else MULTI(TT, false, 0); } while (0)
+    if (h->pair_threads == 512) MULTI_T(512); else MULTI_T(256);
+#undef MULTI_T
+#undef MULTI
 }
 
 // (re)build the ring of velocity buffers of the fused path: slot 0 is M_VT itself, slot 1 is VT2
@@ -3159,14 +3166,24 @@ int run_substeps(nxs_dyn_handle *h) {
     // whatever its period, so a longer ring only saves UM/UT passes (2 km: 7.60 -> 7.49 ms/step from 16 to 120, 1.4 GB of
     // slots); also whenever the halo exchange runs inside the sub-step kernel
     const int want_ring = h->um_ring > 0 ? h->um_ring : ((h->dm.Ne >= 400000 || (device_halo && h->halo_fused)) ? 120 : 1);
-    // v3: two sub-steps per launch -- single rank, an even number of sub-steps, the deferred mesh move (ring of >= 3 buffers)
-    // (it trades 20-60 % more arithmetic for less HBM traffic and half the launches: a gain where the sub-step is latency-bound,
-    // 10 km: 1.23 -> 1.06 ms/step; a loss where the v2 kernel already runs at 5.5 TB/s with its VALUs half busy, 2 km: 7.4 -> 8.0)
-    const bool pair = (h->fused == 2 || (h->fused == 3 && h->dm.Ne < 400000)) && !mr && move_dt != 0. && S >= 2 && (S & 1) == 0;
+    // v3: D sub-steps per launch -- single rank, the deferred mesh move (ring of >= D+1 buffers).  It trades redundant arithmetic
+    // on the halo rings for less HBM traffic and fewer launches: a gain where the sub-step is latency-bound (10 km: 1.23 -> 0.97
+    // ms/step), a loss where the v2 kernel already runs at 5.5 TB/s with its VALUs half busy (2 km, D = 2: 7.4 -> 8.0).
+    // D sub-steps per launch: the requested depth, else (auto) 4 (10 km: D = 2 / 3 / 4 / 5 / 6 / 8: 1.11 / 1.01 / 0.97 / 0.96 / 0.98 / 1.08 ms/step; the
+    // rings grow the arithmetic by x2.0 per sub-step at D = 4) -- lowered until it divides the number of sub-steps
+    int D = 1;
+    if ((h->fused == 2 || (h->fused == 3 && h->dm.Ne < 400000)) && !mr && move_dt != 0. && S >= 2 && !h->pair_failed) {
+        D = std::min(h->pair_depth > 0 ? h->pair_depth : 4, std::min(S, NXS_MAX_DEPTH));
+        while (D > 1 && S % D != 0) --D;
+        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D) != NXS_OK) {
+            h->pair_failed = true;  // no patch size fits (a numbering without any locality, huge fans): one sub-step per launch
+            D = 1;
+        }
+    }
+    const bool pair = D >= 2;
     int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
-    if (pair) K = std::max(2, K & ~1);
+    if (pair) K = std::max(D, K - K % D);  // the ring is flushed between launches
     const bool deferred = K > 1;
-    if (pair && !h->pair_ready) { int rc = upload_patches2(h); if (rc) return rc; }
     if (fused) { int rc = setup_ring(h, K); if (rc) return rc; }
     const int R = h->ring.R;
     // the exchange inside the sub-step kernel: needs the deferred mesh move (ghost nodes are moved from the ring)
@@ -3182,9 +3199,9 @@ int run_substeps(nxs_dyn_handle *h) {
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
         for (int s = 0; s < S; ++s) {
             if (pair) {
-                launch_pair(h, s);
-                ++s;
-                pending += 2;
+                launch_multi(h, s, D);
+                s += D - 1;
+                pending += D;
                 if (pending == K || s == S - 1) {
                     LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt);
                     pending = 0;
@@ -3216,13 +3233,13 @@ int run_substeps(nxs_dyn_handle *h) {
         }
         if (fused) {  // bring the result back to the primary buffers
             const double *vt_src = (S % R) ? h->ring.slot[S % R] : nullptr;
-            const int odd = pair ? ((S >> 1) & 1) : (S & 1);  // sigma/damage ended in the secondary buffers
+            const int odd = pair ? ((S / D) & 1) : (S & 1);  // sigma/damage ended in the secondary buffers
             if (vt_src || odd)
                 LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm, vt_src, odd);
         }
         return NXS_OK;
     };
-    h->timing.substep_launches = pair ? S / 2 : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
+    h->timing.substep_launches = pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
     if (!h->use_graph || (mr && !device_halo)) return loop();
     if (!h->graph_valid) {
         release_graph(h);

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--mesh", default="2km"); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--torch-first", action="store_true"); ap.add_argument("--graph", type=int, default=1)
-ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=3); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0)
+ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=3); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0)
 a = ap.parse_args()
 if a.torch_first:
     import torch
@@ -17,6 +17,7 @@ lm = M.localize(gm, 1)[0]; f = F.localize_fields(g, lm, gm.num_nodes)
 fe = dynamics.FiniteElementDynamics(p); fe.set_option("graph", a.graph); fe.set_option("fused", a.fused); fe.set_option("nt_mask", a.nt); fe.set_option("um_ring", a.ring)
 if a.patch_nodes: fe.set_option("patch_nodes", a.patch_nodes)
 if a.pair_nodes: fe.set_option("pair_nodes", a.pair_nodes)
+if a.depth: fe.set_option("substeps_per_launch", a.depth)
 fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
 fe.step(); fe.synchronize(); fe.set_option("timing_reset", 1)
 t = time.perf_counter()

@@ -363,13 +363,22 @@ def test_deferred_mesh_move_ring_does_not_change_a_bit(um_ring, substeps):
     a.close(); b.close()
 
 
+def _depth(substeps, want=4):
+    d = min(want, substeps, 8)
+    while d > 1 and substeps % d:
+        d -= 1
+    return d
+
+
 @pytest.mark.parametrize("dyn,substeps,opts", [("bbm", 120, {}), ("evp", 120, {}), ("bbm", 120, {"um_ring": 16}), ("bbm", 120, {"um_ring": 2}),
                                                ("bbm", 6, {"pair_nodes": 16}), ("bbm", 120, {"pair_nodes": 300}), ("bbm", 2, {}),
-                                               ("bbm", 7, {}), ("mevp", 120, {})])
-def test_two_sub_steps_per_launch_do_not_change_a_bit(dyn, substeps, opts):
-    """fused=2 (k_substep_pair): sub-steps s and s+1 in one launch on patches with two rings of halo -- the ring is
+                                               ("bbm", 7, {}), ("mevp", 120, {}), ("bbm", 120, {"substeps_per_launch": 2}),
+                                               ("bbm", 120, {"substeps_per_launch": 3}), ("bbm", 120, {"substeps_per_launch": 8}),
+                                               ("evp", 120, {"substeps_per_launch": 6, "pair_nodes": 40}), ("bbm", 10, {"substeps_per_launch": 5})])
+def test_several_sub_steps_per_launch_do_not_change_a_bit(dyn, substeps, opts):
+    """fused=2 (k_substep_multi): D sub-steps in one launch on patches with D rings of halo -- the rings are
     recomputed by the neighbouring patches with the same operations, so every array has the bits of the per-loop
-    kernels; odd sub-step counts and mEVP (no deferred mesh move) fall back to one sub-step per launch."""
+    kernels; sub-step counts no depth divides and mEVP (no deferred mesh move) fall back to one sub-step per launch."""
     outs, launches = [], []
     for options in (dict(opts, fused=2), {"fused": 0}):
         fe, ref, lm = _pair("small", 2, options=options, dynamics_type=dyn, substeps=substeps, dtime_step=200. * substeps / 120.)
@@ -378,15 +387,15 @@ def test_two_sub_steps_per_launch_do_not_change_a_bit(dyn, substeps, opts):
         fe.close()
     for k in STATE_KEYS:
         assert np.array_equal(outs[0][k], outs[1][k]), k
-    if dyn != "mevp" and substeps % 2 == 0:
-        assert launches[0] == substeps // 2
+    if dyn != "mevp":
+        assert launches[0] == substeps // _depth(substeps, opts.get("substeps_per_launch", 4))
 
 
 def test_automatic_choice_of_the_sub_step_kernel():
-    """Default (fused = 3): two sub-steps per launch on a single-rank mesh that lives in the caches, one per launch when the
+    """Default (fused = 3): four sub-steps per launch on a single-rank mesh that lives in the caches, one per launch when the
     pairing is impossible (odd count) -- and the same bits either way."""
     a, _, _ = _pair("small", 1)
-    assert a.timing()["substep_launches"] == 60
+    assert a.timing()["substep_launches"] == 30
     b, _, _ = _pair("small", 1, options={"fused": 1})
     assert b.timing()["substep_launches"] == 120
     x, y = a.get_state(), b.get_state()
@@ -397,7 +406,7 @@ def test_automatic_choice_of_the_sub_step_kernel():
     a.close(); b.close(); c.close()
 
 
-def test_full_size_2km_two_sub_steps_per_launch_agree_bit_for_bit():
+def test_full_size_2km_several_sub_steps_per_launch_agree_bit_for_bit():
     from nextsim_amd import dynamics
     gm, p, g, lms, fields = cases.make_case("2km")
     lm, f = lms[0], fields[0]
