@@ -258,8 +258,8 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
 /* Options (none changes a bit of the results; the tests assert that):
  *   "graph"        1 = sub-step loop replayed from a hipGraph (default); 0 = plain launches
  *   "timing"       1 = record the per-phase events (default); "timing_reset": zero the averages
- *   "fused"        3 = automatic (default): several sub-steps per launch on single-rank meshes that live in the caches
- *                  (< 400 k triangles; patches with that many rings of halo), one patch kernel per sub-step otherwise;
+ *   "fused"        3 = automatic (default): several sub-steps per launch on single-rank meshes small enough for one patch
+ *                  per CU (<= 256 nodes each, patches with that many rings of halo), one patch kernel per sub-step otherwise;
  *                  2 = several sub-steps per launch wherever possible (single rank, not mEVP, a depth that divides the
  *                  number of sub-steps); 1 = one patch kernel per sub-step; 0 = one kernel per reference loop
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)

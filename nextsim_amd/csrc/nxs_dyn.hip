@@ -2087,7 +2087,7 @@ bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, in
     return true;
 }
 
-int upload_patches2(nxs_dyn_handle *h, int D) {
+int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
     free_pool(h->pair_allocs);
     h->dpch2 = DevPatches2{};
     h->pair_ready = false;
@@ -2111,7 +2111,7 @@ int upload_patches2(nxs_dyn_handle *h, int D) {
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
         cus = std::max(cus, 1);
         bool done = false;
-        for (int j = 1; j <= 512 && !done; ++j) {
+        for (int j = 1; j <= (single_round_only ? 1 : 512) && !done; ++j) {
             P = (int)(((long long)m.Nn + (long long)j * cus - 1) / ((long long)j * cus));
             P = std::max(32, (P + 3) & ~3);
             if (P > 256) continue;
@@ -2119,7 +2119,7 @@ int upload_patches2(nxs_dyn_handle *h, int D) {
             const size_t lds_cap = (j == 1 ? 160 : 80) * 1024;  // one workgroup per CU may take it all; otherwise two must fit
             done = lds_of(hp) <= lds_cap && (hp.nP <= j * cus || P == 32);
         }
-        if (!done) return fail(h, NXS_ERR_INVALID, "no multi-sub-step patch size fits (node numbering without locality?)");
+        if (!done) return fail(h, NXS_ERR_INVALID, single_round_only ? "the mesh does not fit one multi-sub-step patch per CU" : "no multi-sub-step patch size fits (node numbering without locality?)");
     }
     h->pair_lds = lds_of(hp);
     if (h->pair_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "multi-sub-step patches need %zu B of LDS", h->pair_lds);
@@ -3168,14 +3168,17 @@ int run_substeps(nxs_dyn_handle *h) {
     const int want_ring = h->um_ring > 0 ? h->um_ring : ((h->dm.Ne >= 400000 || (device_halo && h->halo_fused)) ? 120 : 1);
     // v3: D sub-steps per launch -- single rank, the deferred mesh move (ring of >= D+1 buffers).  It trades redundant arithmetic
     // on the halo rings for less HBM traffic and fewer launches: a gain where the sub-step is latency-bound (10 km: 1.23 -> 0.97
-    // ms/step), a loss where the v2 kernel already runs at 5.5 TB/s with its VALUs half busy (2 km, D = 2: 7.4 -> 8.0).
+    // ms/step), a loss as soon as a CU hosts more than one patch (182 k triangles: 1.65 -> 1.90) and where the v2 kernel already
+    // runs at 5.5 TB/s with its VALUs half busy (2 km, D = 2: 7.4 -> 8.0).
     // D sub-steps per launch: the requested depth, else (auto) 4 (10 km: D = 2 / 3 / 4 / 5 / 6 / 8: 1.11 / 1.01 / 0.97 / 0.96 / 0.98 / 1.08 ms/step; the
     // rings grow the arithmetic by x2.0 per sub-step at D = 4) -- lowered until it divides the number of sub-steps
     int D = 1;
-    if ((h->fused == 2 || (h->fused == 3 && h->dm.Ne < 400000)) && !mr && move_dt != 0. && S >= 2 && !h->pair_failed) {
+    // Automatic (fused == 3): only where ONE round of one patch per CU covers the mesh (<= 256 own nodes per patch: 65 k nodes, 130 k
+    // triangles on 256 CUs) -- 111 k triangles: 1.47 (v2) -> 1.21 ms/step; 182 k triangles, two patches per CU: 1.65 -> 1.90-2.31.
+    if ((h->fused == 2 || (h->fused == 3 && (long long)h->dm.Nn <= 256ll * 1024)) && !mr && move_dt != 0. && S >= 2 && !h->pair_failed) {
         D = std::min(h->pair_depth > 0 ? h->pair_depth : 4, std::min(S, NXS_MAX_DEPTH));
         while (D > 1 && S % D != 0) --D;
-        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D) != NXS_OK) {
+        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D, h->fused == 3) != NXS_OK) {
             h->pair_failed = true;  // no patch size fits (a numbering without any locality, huge fans): one sub-step per launch
             D = 1;
         }

@@ -241,6 +241,8 @@ def make_mesh(kind: str, seed: int = SEED) -> GlobalMesh:
         return make_disc_mesh(27.6e3, seed=seed, name="10km")     # ~60k triangles (config-10km)
     if kind == "2km":
         return make_disc_mesh(5.52e3, seed=seed, name="2km")      # ~1.5M triangles (config-2km)
+    if kind.startswith("h") and kind[1:].replace(".", "", 1).isdigit():
+        return make_disc_mesh(float(kind[1:]), seed=seed, name=kind)  # "h15600": edge length in metres (sweeps between the named sizes)
     raise ValueError(f"unknown mesh kind {kind!r}")
 
 
