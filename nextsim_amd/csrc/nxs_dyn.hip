@@ -36,1551 +36,7 @@
 
 #include "nxs_dyn.h"
 
-// ------------------------------------------------------------------------------------------------
-// constants (model/constants.hpp:56-87, model/finiteelement.hpp:549)
-#define NXS_RHOI 917.
-#define NXS_RHOW 1025.
-#define NXS_RHOS 330.
-#define NXS_RHOA 1.22
-#define NXS_GRAVITY 9.80616
-#define NXS_OMEGA 7.292e-5
-#define NXS_PI 3.141592653589793238462643383279502884197169399375105820974944592308
-#define NXS_DAYS_IN_SEC 86400.
-
-#define STD_MAX(a, b) (((a) < (b)) ? (b) : (a))  // std::max
-#define STD_MIN(a, b) (((b) < (a)) ? (b) : (a))  // std::min
-
-static constexpr int BLOCK = 256;
-
-// node flag bits
-#define NF_DIRICHLET 1
-#define NF_NEUMANN 2
-#define NF_LAT_NEG 4  // signbit(lat): all the solve needs of lat is copysign(sin_theta, lat)
-// element flag bits (static, per mesh)
-#define EF_ON_NEUMANN 8  // any vertex in M_neumann_flags (FE.cpp:3957-3961)
-
-// everything the kernels need from nxs_dyn_params, plus host-precomputed scalars
-struct DevParams {
-    double dtime_step, dte;
-    int substeps, dynamics_type, basal_stress_type, young_cat, newice_type, equal_ridging, use_young_myi;
-    double young, nu0, tan_phi, compr_strength, compaction_param, utrs, ers_m1, compression_factor, ecf;
-    double min_h, min_c, min_m, qdw, ldw, qda, lda;
-    double cos_ota, sin_ota;
-    double k1, k2, Cb, u0;
-    double evp_e, evp_Pstar, evp_C, evp_dmin, ralpha1, ralpha2, mevp_beta;
-    double sqrt_nu_rhoi;
-    double D[9];
-    int ers_int;  // exponent_relaxation_sigma - 1 when it is an integer in [0,16], else -1
-};
-
-struct DevMesh {
-    int Nn, Ne, No, Neo;
-    const int *t0, *t1, *t2;     // [Ne] 0-based node ids
-    const unsigned char *eflags; // [Ne] bits 0-2 ghostNodes[k], bit 3 on-neumann
-    const double *x0, *y0, *lat; // [Nn]
-    const unsigned char *nflags; // [Nn]
-    int W;  const int *fan;      // [W][Nn] ascending fan: (e<<3)|(ghost<<2)|corner, -1 pad
-    int W1; const int *n2e;      // [W1][Nn] bamg row order, 0-based element, -1 pad
-    int W2; const int *n2n;      // [W2][Nn] bamg row order, 0-based node
-    const int *n2n_cnt;          // [Nn]
-};
-
-struct DevState {
-    double *VT, *VT2, *UM, *UT;  // VT2: second buffer (Jacobi smoother; ping-pong of the fused sub-step)
-    double *conc, *thick, *snow, *damage, *ridge, *s0, *s1, *s2;
-    double *damage_b, *s0_b, *s1_b, *s2_b;  // ping-pong partners of damage, sigma (fused sub-step)
-    double *cyoung, *hyoung, *hsyoung, *cmyi, *tmyi;
-    double *cohesion, *theal, *drag_ui, *drag_ui_young;
-    double *wind, *ocean, *ssh, *depth;
-};
-
-// v2: node patches.  One workgroup owns up to Pmax nodes ("own" nodes) and processes every element
-// that touches one of them; elements shared with a neighbouring patch are recomputed by both (like the
-// MPI ghost layer, one level down) and written by exactly one.  Element->node traffic stays in LDS.
-struct DevPatches {
-    int nP, Pmax, Emax, Mmax, Wp;
-    const int *own_cnt, *elem_cnt, *node_cnt;  // [nP]
-    const int *pnodes;            // [nP][Mmax] global node id of each patch-local node slot (own nodes first)
-    const int *pelem;             // [nP][Emax] global element id, ascending; ~id when another patch writes it
-    const unsigned short *ptri;   // [nP][Emax][4] patch-local node slots of the 3 corners (+ pad)
-    const unsigned short *pfan;   // [nP][Wp][Pmax] (element slot << 3 | ghost << 2 | corner), 0xFFFF pad
-};
-
-// Patches of the several-sub-steps-per-launch kernel (k_substep_multi): D rings of halo around the own nodes.
-//   nodes    N_0 = own | N_1 \ N_0 | ... | N_D \ N_(D-1)     N_i = the nodes of the elements E_i
-//   elements E_1 | E_2 \ E_1 | ... | E_D \ E_(D-1)           E_i = every element touching a node of N_(i-1), ascending id inside a level
-// sub-step k of a launch (k = 0 .. D-1) updates the elements E_(D-k) and solves the nodes N_(D-k-1).
-#define NXS_MAX_DEPTH 8
-struct DevPatches2 {
-    int nP, D, NDmax /*nodes staged*/, NSmax /*nodes ever solved = N_(D-1)*/, EDmax /*elements of sub-step 0*/, ESmax /*elements needed again = E_(D-1)*/, Wp;
-    const int *ncnt;              // [nP][D+1] |N_0| .. |N_D|
-    const int *ecnt;              // [nP][D]   |E_1| .. |E_D|
-    const int *pnodes;            // [nP][NDmax] global node ids
-    const int *pelem;             // [nP][EDmax] global element id; ~id when this patch does not write it
-    const unsigned short *ptri;   // [nP][EDmax][4] patch-local node slots of the 3 corners (+ pad)
-    const unsigned short *pfan;   // [nP][Wp][NSmax] fan of every solved node, ascending element id: (element slot << 3 | ghost << 2 | corner)
-};
-struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
-
-struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
-    const double *VTc, *s0c, *s1c, *s2c, *dc;
-    double *VTn, *s0n, *s1n, *s2n, *dn;
-};
-
-struct DevWork {
-    double *delta_x, *surface, *shape /*[6][Ne]*/, *emass, *ecbu;
-    double *prec /*[Ne][10]: what k_prep_nodes gathers per fan entry, one record per element (see k_prep_elements)*/;
-    double *expC, *pmax, *heal, *dxs, *volume;  // per-step element constants of the sub-step loop
-    unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
-    unsigned char *open_blk;                     // [ceil(Nn/BLOCK)] != 0: the block of BLOCK nodes holds a node the open-water smoother changes (zeroed by k_prep_elements, set by k_prep_nodes)
-    int *dxi;                                    // BBM, fused kernel: M_delta_x as the integer it is (Q1), ~M_delta_x when the element is skipped
-    double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
-    double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
-    double *xs, *ys;  // [Nn] node coordinates on the displaced mesh at step start (frozen over the sub-steps, Q4)
-    double *D_tau_a, *D_tau_w, *D_del;
-};
-
-// ------------------------------------------------------------------------------------------------
-// device helpers
-
-__device__ __forceinline__ void load_vertices(const DevMesh &m, const double *__restrict__ UM, int e,
-                                              double vx[3], double vy[3]) {
-    // GmshMesh::vertices(indices, um, 1.), gmshmesh.cpp:1929-1939
-    const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        vx[i] = m.x0[n[i]] + 1. * UM[n[i]];
-        vy[i] = m.y0[n[i]] + 1. * UM[n[i] + m.Nn];
-    }
-}
-
-__device__ __forceinline__ double jacobian(const double vx[3], const double vy[3]) {  // FE.cpp:1613-1618
-    double jac = (vx[1] - vx[0]) * (vy[2] - vy[0]);
-    jac -= (vx[2] - vx[0]) * (vy[1] - vy[0]);
-    return jac;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1a  prep elements, FE.cpp:10235-10308
-__global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, DevWork w, DevParams p) {
-    // threads past the end redo the last element (identical values to identical places): every thread reaches the barrier
-    const int e = min(blockIdx.x * BLOCK + (int)threadIdx.x, m.Ne - 1);
-    for (int i = blockIdx.x * BLOCK + (int)threadIdx.x; i < (m.Nn + BLOCK - 1) / BLOCK; i += gridDim.x * BLOCK) w.open_blk[i] = 0;  // k_prep_nodes raises them
-    double vx[3], vy[3];
-    load_vertices(m, s.UM, e, vx, vy);
-
-    // Q1 (FE.cpp:10239): int accumulator, then unsigned integer division by 3
-    const double side0 = hypot(vx[1] - vx[0], vy[1] - vy[0]);
-    const double side1 = hypot(vx[2] - vx[1], vy[2] - vy[1]);
-    const double side2 = hypot(vx[2] - vx[0], vy[2] - vy[0]);
-    int acc = 0;
-    acc = (int)(acc + side0);
-    acc = (int)(acc + side1);
-    acc = (int)(acc + side2);
-    const int acc_div3 = (int)((unsigned long)acc / 3ul);
-    const double delta_x = (double)((unsigned long)acc / 3ul);
-    w.delta_x[e] = delta_x;
-
-    const double jac = jacobian(vx, vy);
-    const double surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
-    w.surface[e] = surface;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {  // FE.cpp:1956-1962
-        const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-        w.shape[(size_t)k * m.Ne + e] = (vy[kp1] - vy[kp2]) / jac;
-        w.shape[(size_t)(k + 3) * m.Ne + e] = (vx[kp2] - vx[kp1]) / jac;
-    }
-
-    // slab mass, FE.cpp:10255-10269
-    const double conc = s.conc[e], thick = s.thick[e];
-    double total_concentration = conc, total_thickness = thick, total_snow = s.snow[e];
-    if (p.young_cat) {
-        total_concentration += s.cyoung[e];
-        total_thickness += s.hyoung[e];
-        total_snow += s.hsyoung[e];
-    }
-    double element_mass = 0.;
-    if (total_concentration > 0.)
-        element_mass = (NXS_RHOI * total_thickness + NXS_RHOS * total_snow) / total_concentration;
-    w.emass[e] = element_mass;
-
-    // basal stress numerator, FE.cpp:10273-10308
-    double element_ssh = 0;
-    element_ssh += s.ssh[m.t0[e]];
-    element_ssh += s.ssh[m.t1[e]];
-    element_ssh += s.ssh[m.t2[e]];
-    element_ssh /= 3.;
-    const double max_keel_depth = 28;
-    const double min_water_depth = 2.;
-    const double depth_eff = STD_MAX(0., element_ssh + STD_MAX(min_water_depth, s.depth[e]));
-    double critical_h = 0., critical_h_mod = 0.;
-    if (p.basal_stress_type == NXS_BASAL_LEMIEUX) {
-        double mean_keel_depth = p.k1 * thick;
-        mean_keel_depth = STD_MIN(mean_keel_depth, conc * max_keel_depth);
-        critical_h = conc * depth_eff / p.k1;
-        critical_h_mod = mean_keel_depth / p.k1;
-    }
-    const double ecbu = p.k2 * STD_MAX(0., critical_h_mod - critical_h) * exp(-p.Cb * (1. - conc));
-    w.ecbu[e] = ecbu;
-
-    // The record k_prep_nodes gathers for every fan entry -- everything the nodal loops of FE.cpp:10309-10340 and
-    // 10578-10602 take from this element, contiguous (80 B) instead of nine arrays: the products are formed with the
-    // reference's operand order, so the node side performs the same additions on the same values.
-    __shared__ double rec[BLOCK * 10];  // staged so that the 80-byte records leave the block as one contiguous stream
-    {
-        double *r = rec + threadIdx.x * 10;
-        const double meA = element_mass * surface;           // node_mass += element_mass*surface, FE.cpp:10314
-        const double m_g_A3rd = meA * (NXS_GRAVITY / 3.);    // FE.cpp:10321
-        double dragp = s.drag_ui[e];                          // FE.cpp:10585-10596
-        if (p.young_cat) {
-            const double cy = s.cyoung[e];
-            if (conc + cy > 0.) dragp = (s.drag_ui[e] * conc + s.drag_ui_young[e] * cy) / (conc + cy);
-        }
-        const double sshn[3] = {s.ssh[m.t0[e]], s.ssh[m.t1[e]], s.ssh[m.t2[e]]};
-        r[0] = surface; r[1] = meA; r[2] = ecbu; r[3] = dragp * surface;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {                         // FE.cpp:10334-10339
-            const int kp1 = (j + 1) % 3, kp2 = (j + 2) % 3;
-            r[4 + j] = (vy[kp1] - vy[kp2]) / jac * m_g_A3rd * sshn[j];
-            r[7 + j] = (vx[kp2] - vx[kp1]) / jac * m_g_A3rd * sshn[j];
-        }
-    }
-    __syncthreads();
-    {
-        const size_t base = (size_t)blockIdx.x * BLOCK * 10;
-        const int count = min(BLOCK, m.Ne - (int)blockIdx.x * BLOCK) * 10;
-        for (int i = threadIdx.x; i < count; i += BLOCK) w.prec[base + i] = rec[i];
-    }
-
-    // Per-step constants of the sub-step loop.  M_conc, M_thick, M_delta_x, M_surface do not change
-    // while sub-cycling (Q4), so exp/pow of them are evaluated once here instead of S times; the
-    // expressions are the reference's, operand for operand.
-    if (p.dynamics_type == NXS_DYN_BBM) {
-        const double expC = exp(p.compaction_param * (1. - conc));             // FE.cpp:4185
-        w.expC[e] = expC;
-        w.pmax[e] = pow(thick, p.ecf) * p.compression_factor * expC;          // FE.cpp:4192
-        w.heal[e] = p.dte / s.theal[e] * expC;                                 // FE.cpp:4257
-        w.dxs[e] = delta_x * p.sqrt_nu_rhoi;                                   // FE.cpp:4232
-        w.eskip[e] = (conc <= 0.1) ? 1 : 0;                                    // Q5, FE.cpp:4146-4151
-        w.dxi[e] = (conc <= 0.1) ? ~acc_div3 : acc_div3;                       // 4 bytes instead of 9 for the fused kernel
-    } else {
-        w.expC[e] = p.evp_Pstar * exp(-p.evp_C * (1. - conc));                 // FE.cpp:10684 (P)
-        w.eskip[e] = (thick == 0.) ? 1 : 0;                                    // FE.cpp:10656
-    }
-    w.volume[e] = thick * surface;                                             // FE.cpp:10450
-}
-
-// ------------------------------------------------------------------------------------------------
-// K1b + K2  the nodal side of prep elements (as a gather) and prep nodes, FE.cpp:10309-10416
-__global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, DevWork w, DevParams p) {
-    const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= m.Nn) return;
-    const int Nn = m.Nn;
-    const bool dirichlet = m.nflags[n] & NF_DIRICHLET;
-
-    double rl = 0., nm = 0., cb = 0., gu = 0., gv = 0.;
-    for (int slot = 0; slot < m.W; ++slot) {
-        const int ent = m.fan[(size_t)slot * Nn + n];
-        if (ent < 0) break;
-        const double *r = w.prec + (size_t)(ent >> 3) * 10;
-        const bool ghost_corner = ent & 4;
-        rl += r[0];                                    // FE.cpp:10313
-        nm += r[1];                                    // FE.cpp:10314
-        cb = STD_MAX(cb, r[2]);                        // FE.cpp:10317
-        // Q7: the skip test sees node_mass as accumulated so far (elements <= e)
-        if (dirichlet || nm == 0. || ghost_corner) continue;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {                  // FE.cpp:10334-10339
-            gu -= r[4 + j];
-            gv -= r[7 + j];
-        }
-    }
-    // same expression as load_vertices(): the fused sub-step kernel rebuilds the shape coefficients from these
-    w.xs[n] = m.x0[n] + 1. * s.UM[n];
-    w.ys[n] = m.y0[n] + 1. * s.UM[n + Nn];
-    w.C_bu[n] = cb;
-    w.grad_ssh[n] = gu;
-    w.grad_ssh[n + Nn] = gv;
-
-    // prep nodes, FE.cpp:10356-10416
-    double vu = s.VT[n], vv = s.VT[n + Nn];
-    if (nm == 0.) { vu = 0.; vv = 0.; s.VT[n] = 0.; s.VT[n + Nn] = 0.; }
-
-    double drag = 0., surface = 0;
-    for (int j = 0; j < m.W1; ++j) {                  // bamg row order (summation order!)
-        const int e = m.n2e[(size_t)j * Nn + n];
-        if (e < 0) continue;                           // Q2
-        const double *r = w.prec + (size_t)e * 10;
-        drag += r[3];                                  // dragp * surface
-        surface += r[0];
-    }
-    const double wu = s.wind[n], wv = s.wind[n + Nn];
-    drag *= NXS_RHOA * hypot(wu, wv) / surface;        // Q6
-    w.D_tau_a[n] = drag * wu;
-    w.D_tau_a[n + Nn] = drag * wv;
-
-    w.fcor[n] = 2 * NXS_OMEGA * sin(m.lat[n] * NXS_PI / 180.);
-
-    rl = 1. / rl;                                      // FE.cpp:10400-10402
-    nm *= rl;
-    rl *= 3.;
-    w.rlmass[n] = rl;
-    w.node_mass[n] = nm;
-    if (n < m.No && !dirichlet && nm == 0.) w.open_blk[n / BLOCK] = 1;  // k_smooth's own test (FE.cpp:10589): its other blocks have nothing to do
-
-    w.VTM[n] = vu;
-    w.VTM[n + Nn] = vv;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Arithmetic shared by the v1 kernels (one per reference loop) and the v2 fused sub-step kernel, so
-// that both perform literally the same operations in the same order.
-
-// updateSigmaDamage body for one element, FE.cpp:4161-4257 (the conc <= 0.1 early-out is the caller's)
-template <bool POW4>
-__device__ __forceinline__ void bbm_stress(const DevParams &p, const double dxN[6], const double u[3], const double v[3],
-                                           double sig[3], double &damage, const double expC, const double Pmax,
-                                           const double heal, const double dxs, const double cohesion) {
-    const double dt = p.dte;
-    // M_B0T (FE.cpp:10242-10249) rebuilt in registers, zeros included so that the sums below are the
-    // reference's term for term (FE.cpp:4167-4176)
-    double B0T[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) B0T[i] = 0.;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        B0T[2 * i] = dxN[i];
-        B0T[2 * i + 13] = dxN[i];
-        B0T[2 * i + 7] = dxN[i + 3];
-        B0T[2 * i + 12] = dxN[i + 3];
-    }
-    double eps[3] = {0., 0., 0.};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            eps[i] += B0T[i * 6 + 2 * j] * u[j];
-            eps[i] += B0T[i * 6 + 2 * j + 1] * v[j];
-        }
-    double sigma_n = (sig[0] + sig[1]) * 0.5;                                    // FE.cpp:4184
-    // FE.cpp:4186: std::pow(x, exponent_relaxation_sigma - 1.).  For the default exponent (5 - 1 = 4) the
-    // power is formed by two squarings: <= 1.5 ulp from the correctly rounded value, i.e. inside the error
-    // band of any libm pow, and it removes ~400 instructions and ~50 VGPRs from the hot loop.  Any other
-    // exponent takes the general pow (POW4 == false).
-    const double pw_x = (1. - damage) * expC;
-    double pw;
-    if (POW4) { const double x2 = pw_x * pw_x; pw = x2 * x2; }
-    else pw = pow(pw_x, p.ers_m1);
-    const double time_viscous = p.utrs * pw;
-    double tildeP;
-    if (sigma_n < 0.) {
-        tildeP = STD_MIN(1., -Pmax / sigma_n);                                   // FE.cpp:4194
-    } else {
-        tildeP = 0.;
-    }
-    const double multiplicator = STD_MIN(1. - 1e-12, time_viscous / (time_viscous + dt * (1. - tildeP)));  // Q3
-    const double elasticity = p.young * (1. - damage) * expC;                    // FE.cpp:4202
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {                                                // FE.cpp:4204-4210
-#pragma unroll
-        for (int j = 0; j < 3; ++j) sig[i] += dt * elasticity * p.D[3 * i + j] * eps[j];
-        sig[i] *= multiplicator;
-    }
-    const double sigma_s = hypot((sig[0] - sig[1]) / 2., sig[2]);                // FE.cpp:4218
-    sigma_n = (sig[0] + sig[1]) * 0.5;
-    double dcrit;
-    if (sigma_n < -p.compr_strength)
-        dcrit = -p.compr_strength / sigma_n;
-    else
-        dcrit = cohesion / (sigma_s + p.tan_phi * sigma_n);
-    if ((0. < dcrit) && (dcrit < 1.)) {                                          // FE.cpp:4229-4243
-        const double rtd = sqrt(elasticity) / dxs;
-        const double del_damage = (1.0 - damage) * (1.0 - dcrit) * dt * rtd;
-        damage += del_damage;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) sig[i] -= sig[i] * (1. - dcrit) * dt * rtd;
-    }
-    damage = STD_MAX(0., damage - heal);                                         // FE.cpp:4256
-}
-
-// updateSigmaVP body for one element, FE.cpp:10664-10696 (P = Pstar*exp(-C(1-A)) precomputed)
-__device__ __forceinline__ void vp_stress(const DevParams &p, const double dxN[6], const double u[3], const double v[3],
-                                          double sig[3], const double P) {
-    const double re2 = 1. / (p.evp_e * p.evp_e);
-    double eps11 = 0., eps22 = 0., eps12 = 0.;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        eps11 += dxN[i] * u[i];
-        eps22 += dxN[i + 3] * v[i];
-        eps12 += 0.5 * (dxN[i] * v[i] + dxN[i + 3] * u[i]);
-    }
-    const double eps1 = eps11 + eps22, eps2 = eps11 - eps22;
-    const double delta = sqrt(eps1 * eps1 + (eps2 * eps2 + 4 * eps12 * eps12) * re2);
-    const double zeta = P / (delta + p.evp_dmin);
-    double sigma1 = sig[0] + sig[1], sigma2 = sig[0] - sig[1];
-    sigma1 += p.ralpha1 * (zeta * (eps1 - delta) - sigma1);
-    sigma2 += p.ralpha2 * (zeta * eps2 * re2 - sigma2);
-    sig[2] += p.ralpha2 * (zeta * eps12 * re2 - sig[2]);
-    sig[0] = 0.5 * (sigma1 + sigma2);
-    sig[1] = 0.5 * (sigma1 - sigma2);
-}
-
-// element half of "gradient sigma" (FE.cpp:10449-10465): the term corner i subtracts from its node
-__device__ __forceinline__ void corner_forces(const double volume, const double sig[3], const double dxN[6], double F[6]) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        F[i] = volume * (sig[0] * dxN[i] + sig[2] * dxN[i + 3]);
-        F[i + 3] = volume * (sig[2] * dxN[i] + sig[1] * dxN[i + 3]);
-    }
-}
-
-// "sub-solve" for one node, FE.cpp:10481-10528: (uice, vice) in -> new velocity out
-__device__ __forceinline__ void nodal_solve(const DevParams &p, const double gx, const double gy, double &uice, double &vice,
-                                            const double node_mass, const double rlm, const double C_bu, const double fcor,
-                                            const double lat, const double tau_ax, const double tau_ay, const double ou,
-                                            const double ov, const double vtm_u, const double vtm_v) {
-    double dtep, delu, delv;
-    if (p.dynamics_type == NXS_DYN_MEVP) {  // FE.cpp:10483-10493
-        const double b_mevp = p.mevp_beta + 1.;
-        delu = (vtm_u - uice) / b_mevp;
-        delv = (vtm_v - vice) / b_mevp;
-        dtep = p.dte / b_mevp;
-    } else {
-        delu = 0.; delv = 0.; dtep = p.dte;
-    }
-    const double dte_over_mass = dtep / STD_MAX(p.min_m, node_mass);
-    const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
-    const double tau_b = C_bu / (hypot(uice, vice) + p.u0);
-    const double alpha = 1. + dte_over_mass * (c_prime * p.cos_ota + tau_b);
-    const double beta = dtep * fcor + dte_over_mass * c_prime * copysign(p.sin_ota, lat);
-    const double rdenom = 1. / (alpha * alpha + beta * beta);
-    const double tau_x = tau_ax + c_prime * (ou * p.cos_ota - ov * copysign(p.sin_ota, lat));
-    const double tau_y = tau_ay + c_prime * (ov * p.cos_ota + ou * copysign(p.sin_ota, lat));
-    const double grad_x = gx * rlm, grad_y = gy * rlm;
-    double nu_ = alpha * uice + beta * vice + dte_over_mass * (alpha * (grad_x + tau_x) + beta * (grad_y + tau_y)) + alpha * delu + beta * delv;
-    nu_ *= rdenom;
-    double nv_ = alpha * vice - beta * uice + dte_over_mass * (alpha * (grad_y + tau_y) - beta * (grad_x + tau_x)) + alpha * delv - beta * delu;
-    nv_ *= rdenom;
-    uice = nu_;
-    vice = nv_;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3a  updateSigmaDamage, FE.cpp:4137-4260, + the element half of K4 (corner forces)
-template <bool POW4>
-__global__ void __launch_bounds__(BLOCK) k_sigma_bbm(DevMesh m, DevState s, DevWork w, DevParams p) {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= m.Ne) return;
-    const int Ne = m.Ne, Nn = m.Nn;
-    double dxN[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
-    double sig[3];
-    if (w.eskip[e]) {  // FE.cpp:4151-4159
-        s.damage[e] = 0.;
-        sig[0] = sig[1] = sig[2] = 0.;
-    } else {
-        const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
-        double u[3], v[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { u[j] = s.VT[n[j]]; v[j] = s.VT[n[j] + Nn]; }
-        sig[0] = s.s0[e]; sig[1] = s.s1[e]; sig[2] = s.s2[e];
-        double damage = s.damage[e];
-        bbm_stress<POW4>(p, dxN, u, v, sig, damage, w.expC[e], w.pmax[e], w.heal[e], w.dxs[e], s.cohesion[e]);
-        s.damage[e] = damage;
-    }
-    s.s0[e] = sig[0]; s.s1[e] = sig[1]; s.s2[e] = sig[2];
-    double F[6];
-    corner_forces(w.volume[e], sig, dxN, F);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) w.force[(size_t)i * Ne + e] = F[i];
-}
-
-// K3b  updateSigmaVP, FE.cpp:10649-10699
-__global__ void __launch_bounds__(BLOCK) k_sigma_vp(DevMesh m, DevState s, DevWork w, DevParams p) {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= m.Ne) return;
-    const int Ne = m.Ne, Nn = m.Nn;
-    double dxN[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dxN[k] = w.shape[(size_t)k * Ne + e];
-    double sig[3];
-    if (w.eskip[e]) {
-        sig[0] = sig[1] = sig[2] = 0.;
-    } else {
-        const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
-        double u[3], v[3];
-#pragma unroll
-        for (int j = 0; j < 3; ++j) { u[j] = s.VT[n[j]]; v[j] = s.VT[n[j] + Nn]; }
-        sig[0] = s.s0[e]; sig[1] = s.s1[e]; sig[2] = s.s2[e];
-        vp_stress(p, dxN, u, v, sig, w.expC[e]);
-    }
-    s.s0[e] = sig[0]; s.s1[e] = sig[1]; s.s2[e] = sig[2];
-    double F[6];
-    corner_forces(w.volume[e], sig, dxN, F);
-#pragma unroll
-    for (int i = 0; i < 6; ++i) w.force[(size_t)i * Ne + e] = F[i];
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4 (node half) + K5 + K7 for owned nodes, FE.cpp:10445-10553
-// move_dt == 0 -> no mesh move here (mEVP moves once after the loop, FE.cpp:10559-10573)
-__global__ void __launch_bounds__(BLOCK) k_solve_move(DevMesh m, DevState s, DevWork w, DevParams p, double move_dt) {
-    const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= m.No) return;
-    const int Nn = m.Nn, Ne = m.Ne;
-    const unsigned char nf = m.nflags[n];
-    const double node_mass = w.node_mass[n];
-    double uice = s.VT[n], vice = s.VT[n + Nn];
-
-    if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
-        // grad_terms = grad_ssh, then minus the corner forces of the fan in ascending element order
-        double gx = w.grad_ssh[n], gy = w.grad_ssh[n + Nn];
-        for (int slot = 0; slot < m.W; ++slot) {
-            const int ent = m.fan[(size_t)slot * Nn + n];
-            if (ent < 0) break;
-            if (ent & 4) continue;  // ghostNodes[i] (FE.cpp:10456)
-            const int e = ent >> 3, c = ent & 3;
-            gx -= w.force[(size_t)c * Ne + e];
-            gy -= w.force[(size_t)(c + 3) * Ne + e];
-        }
-        nodal_solve(p, gx, gy, uice, vice, node_mass, w.rlmass[n], w.C_bu[n], w.fcor[n], m.lat[n], w.D_tau_a[n],
-                    w.D_tau_a[n + Nn], s.ocean[n], s.ocean[n + Nn], w.VTM[n], w.VTM[n + Nn]);
-        s.VT[n] = uice;
-        s.VT[n + Nn] = vice;
-    }
-    if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
-        if (!(nf & NF_NEUMANN)) {
-            s.UM[n] += move_dt * uice;
-            s.UM[n + Nn] += move_dt * vice;
-        }
-        s.UT[n] += move_dt * uice;
-        s.UT[n + Nn] += move_dt * vice;
-    }
-}
-
-// mesh move for a node range (mEVP end-of-loop move; ghosts when there is no halo kernel)
-__global__ void __launch_bounds__(BLOCK) k_move(DevMesh m, DevState s, int first, int last, double dt) {
-    const int n = first + blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= last) return;
-    const int Nn = m.Nn;
-    const double u = s.VT[n], v = s.VT[n + Nn];
-    if (!(m.nflags[n] & NF_NEUMANN)) {
-        s.UM[n] += dt * u;
-        s.UM[n + Nn] += dt * v;
-    }
-    s.UT[n] += dt * u;
-    s.UT[n + Nn] += dt * v;
-}
-
-struct IpcDev {
-    unsigned long long *seq_push;   // exchanges pushed so far (this rank)
-    unsigned long long *seq_pull;   // exchanges pulled so far
-    unsigned int *done_push, *done_pull;  // block-completion counters
-    int *error;                     // != 0 after a timeout / self-test mismatch
-    double *mailbox;                // my mailbox: [2][2*tr] doubles
-    unsigned long long *flags;      // my flags: [nr], written by the neighbours
-    int tr, ns, nr;
-    double *const *peer_seg;        // [ns] neighbour k's mailbox address of MY segment (parity 0)
-    const long long *peer_parity_stride;  // [ns] doubles between that neighbour's two buffers (2*tr_k)
-    unsigned long long *const *peer_flag; // [ns] address of my flag slot in neighbour k's mailbox
-};
-
-__device__ __forceinline__ void sys_store(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ double sys_load(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_SYSTEM));
-}
-
-// Halo exchange fused into the sub-step kernel (device-direct transport only).  Exchange x = the x-th
-// updateGhosts since the mailboxes were connected; *ipc.seq_push counts the exchanges this rank has
-// published, a neighbour's flag in my mailbox the exchanges IT has published.
-//   kernel of sub-step s (x = *seq_push on entry):
-//     boundary patches (own nodes that are sent, or ghost nodes among the staged ones) first wait until every
-//     neighbour's flag has reached x, i.e. exchange x-1 -- the velocities this sub-step starts from -- has
-//     landed, stage their ghost nodes straight from the mailbox (parity (x-1)&1) and copy them through to the
-//     VT buffer (the deferred mesh move and the end of the step read them there);
-//     in the node phase every sent node is stored into the neighbours' mailboxes (parity x&1); the last
-//     boundary patch to finish raises my flag at the neighbours to x+1; the last patch of the grid advances
-//     *seq_push.  Boundary patches come first in the grid, so the data travels while the interior is computed.
-//   Why two mailbox halves suffice: a patch that stages ghosts also has sent nodes (if own node n shares an
-//   element with a ghost owned by B, then n is a ghost of B), so it is a boundary patch, and my flag x+1 is
-//   raised only after all of them have finished reading exchange x-1; a neighbour overwrites that half
-//   (exchange x+1) only after it has seen my flag x+1.
-struct HaloFused {
-    IpcDev ipc;
-    int n_boundary;                    // patches [0, n_boundary) are the boundary patches (re-uploaded in that order)
-    const int *send_ptr;               // [No+1] CSR over own nodes
-    const int *send_k, *send_pos;      // neighbour (index into send_procs) and position inside its segment
-    const int *send_off;               // [ns+1] segment offsets (segment length = v offset)
-    const int *ghost_off, *ghost_srl;  // [Nn-No] u offset inside a mailbox half, and the v offset from it
-    int No;
-    int from_mailbox;                  // 0: first sub-step of a step, the ghosts are in the VT buffer
-    unsigned int *done_all;            // k_smooth_halo: two-level ticket counters, [0] global, [32 (g+1)] group g
-    const int *send_block_rank;        // k_smooth_halo: rank of block b among the blocks that send something, -1: sends nothing
-    int n_send_blocks;
-};
-
-#ifdef NXS_PHASE_TIMING  // kernel microscope (scripts/phase_timing.py builds a variant of the library with it)
-__device__ long long g_phase_t[8 * 8192];
-#define NXS_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_t[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
-#else
-#define NXS_STAMP(k) do { } while (0)
-#endif
-
-#ifndef NXS_PF
-#define NXS_PF 1
-#endif
-#ifndef NXS_T256_MAXP
-#define NXS_T256_MAXP 128
-#endif
-
-// streaming accesses that should not displace the reusable arrays from L2 / Infinity Cache
-template <bool NT> __device__ __forceinline__ double ldg(const double *p) { return NT ? __builtin_nontemporal_load(p) : *p; }
-template <bool NT> __device__ __forceinline__ void stg(double *p, double v) { if (NT) __builtin_nontemporal_store(v, p); else *p = v; }
-
-// ------------------------------------------------------------------------------------------------
-// v2  ONE launch per sub-step: K3 (stress/damage) + K4 (assembly) + K5 (nodal solve) + K7 (mesh move).
-// FE.cpp:10425-10553.  Workgroup = patch.  Phase 0 stages the patch's nodal velocities in LDS,
-// phase A updates every patch element from them and leaves its six corner forces in LDS, phase B
-// lets each own node subtract the forces of its fan (ascending element order, as the serial scatter)
-// and solve.  sigma, damage and VT are ping-pong buffered: a neighbouring patch may still be reading
-// the old values of a shared element / node while this one writes the new ones.
-template <int T, bool POW4, int NTM, bool HALO>
-__global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p,
-                                                     PingPong b, double move_dt, HaloFused hf) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *lu = lds, *lv = lds + pp.Mmax, *lx = lds + 2 * (size_t)pp.Mmax, *ly = lds + 3 * (size_t)pp.Mmax,
-           *lF = lds + 4 * (size_t)pp.Mmax;  // lF[6][Emax]
-    // consecutive patches are neighbours in space: keep them on one XCD (blocks are dealt round-robin
-    // over the 8 XCDs) so that shared halo elements / nodes hit that XCD's L2.  Speed only.
-    auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index, classes pos%8 -> contiguous index ranges
-        const int q = n >> 3, r = n & 7, x = pos & 7;
-        return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
-    };
-    int blk = blockIdx.x;
-    NXS_STAMP(0);
-    unsigned long long xseq = 0ull;
-    bool boundary = false;
-    if (HALO) {  // boundary patches [0, n_boundary) lead the grid in dispatch order; the remap acts inside each group
-        boundary = blk < hf.n_boundary;
-        if (boundary || hf.n_boundary == 0) xseq = *hf.ipc.seq_push;  // interior patches never look at it: the last boundary patch may advance it while they run
-        blk = boundary ? xcd_remap(blk, hf.n_boundary) : hf.n_boundary + xcd_remap(blk - hf.n_boundary, (int)gridDim.x - hf.n_boundary);
-    } else {
-        blk = xcd_remap(blk, (int)gridDim.x);
-    }
-    const int t = threadIdx.x, Nn = m.Nn, Emax = pp.Emax;
-    const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
-    const int *pn = pp.pnodes + (size_t)blk * pp.Mmax;
-    const int *pe = pp.pelem + (size_t)blk * Emax;
-    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * Emax;
-    const bool bbm = p.dynamics_type == NXS_DYN_BBM;
-    constexpr bool NT_S = NTM & 1, NT_U = NTM & 2, NT_C = NTM & 4;  // sigma/damage, UM/UT, element constants
-
-    // The kernel is latency-bound unless every dependent load hop is overlapped, so all global loads
-    // that do not need LDS are issued up front: indices first, then (one hop later) the nodal
-    // velocities to stage and this thread's element data, all in flight together before barrier 1.
-    // The index rows are padded to Mmax / Emax, so these loads depend on the launch arguments only -- not on the
-    // patch's counts (one more dependent hop; the counts arrive meanwhile and mask the uses).
-    const int my_node = (t < pp.Mmax) ? pn[t] : 0;  // patch-local slot t (an own node when t < nO)
-    const int my_node2 = (t + T < pp.Mmax) ? pn[t + T] : 0;  // a patch stages ~1.25 nodes per own node: second staging slot
-    int eraw = 0;
-    ushort4 tr = make_ushort4(0, 0, 0, 0);
-    if (t < Emax) { eraw = pe[t]; tr = pt[t]; }
-#if NXS_PF >= 1
-    // element rounds 1 and 2 (a patch holds ~2.2 elements per own node): their indices are fetched now, so
-    // that a later round starts with its data loads instead of an index hop
-    int eraw1 = 0, eraw2 = 0;
-    ushort4 tr1 = tr, tr2 = tr;
-    if (t + T < Emax) { eraw1 = pe[t + T]; tr1 = pt[t + T]; }
-    if (t + 2 * T < Emax) { eraw2 = pe[t + 2 * T]; tr2 = pt[t + 2 * T]; }
-#endif
-
-    const bool mailbox_ghosts = HALO && boundary && hf.from_mailbox;
-    if (mailbox_ghosts) {  // exchange xseq-1 must have landed before a ghost node is staged
-        if (t == 0) {
-            const long long t0 = wall_clock64();  // 100 MHz
-            bool ok = true;
-            for (int k = 0; k < hf.ipc.nr && ok; ++k)
-                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost, do not wait again
-                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 3); break; }  // 10 s
-                }
-            // no acquire fence: the mailbox is uncached memory and every read of it below is a system-scope load that
-            // bypasses the caches; a fence here would invalidate this XCD's caches once per boundary patch and sub-step
-        }
-        __syncthreads();
-    }
-    auto stage = [&](int i, int g) {
-        if (mailbox_ghosts && g >= hf.No) {
-            const double *src = hf.ipc.mailbox + ((xseq - 1ull) & 1ull) * 2ull * (unsigned long long)hf.ipc.tr + hf.ghost_off[g - hf.No];
-            const double u = sys_load(src), v = sys_load(src + hf.ghost_srl[g - hf.No]);
-            lu[i] = u; lv[i] = v;
-            const_cast<double *>(b.VTc)[g] = u;  // every patch that stages g writes the same two values
-            const_cast<double *>(b.VTc)[g + Nn] = v;
-        } else {
-            lu[i] = b.VTc[g];
-            lv[i] = b.VTc[g + Nn];
-        }
-        lx[i] = w.xs[g];
-        ly[i] = w.ys[g];
-    };
-    if (t < nM) stage(t, my_node);
-    if (t + T < nM) stage(t + T, my_node2);
-    for (int i = t + 2 * T; i < nM; i += T) stage(i, pn[i]);
-
-    for (int base = 0; base < nE; base += T) {
-        const int l = base + t;
-#if NXS_PF >= 1
-        if (base >= 3 * T && l < nE) { eraw = pe[l]; tr = pt[l]; }  // very large patches: rounds beyond the prefetched ones
-#else
-        if (base > 0 && l < nE) { eraw = pe[l]; tr = pt[l]; }  // patches larger than the block: extra rounds
-#endif
-        const bool active = l < nE;
-        const bool writer = eraw >= 0;
-        const int e = writer ? eraw : ~eraw;
-        double dxN[6], sig[3] = {0., 0., 0.}, damage = 0., c_expC = 0., c_pmax = 0., c_heal = 0., c_dxs = 1., c_coh = 0., volume = 0.;
-        bool skip = true;
-        int dxi = 0;
-        if (active) {
-            if (!bbm) skip = w.eskip[e];
-            sig[0] = ldg<NT_S>(b.s0c + e); sig[1] = ldg<NT_S>(b.s1c + e); sig[2] = ldg<NT_S>(b.s2c + e);
-            if (bbm) damage = ldg<NT_S>(b.dc + e);
-            c_expC = ldg<NT_C>(w.expC + e);
-            volume = ldg<NT_C>(w.volume + e);
-            if (bbm) {
-                c_pmax = ldg<NT_C>(w.pmax + e); c_heal = ldg<NT_C>(w.heal + e); dxi = w.dxi[e]; c_coh = ldg<NT_C>(s.cohesion + e);
-            }
-        }
-        if (base == 0) { __syncthreads(); NXS_STAMP(1); }  // staged velocities / coordinates visible
-        if (active && bbm) {  // M_delta_x is an integer number of metres (Q1) and travels as one, with the skip flag in its sign
-            skip = dxi < 0;
-            c_dxs = (double)(skip ? ~dxi : dxi) * p.sqrt_nu_rhoi;  // == w.dxs[e], FE.cpp:4232
-        }
-        if (active) {
-            {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates: the same operations as
-                // k_prep_elements, so the same bits as M_shape_coeff -- 48 B/element less to stream
-                const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
-                const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
-                const double jac = jacobian(vx, vy);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-                    dxN[k] = (vy[kp1] - vy[kp2]) / jac;
-                    dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
-                }
-            }
-            if (skip) {
-                sig[0] = sig[1] = sig[2] = 0.;
-                damage = 0.;
-            } else {
-                const double u[3] = {lu[tr.x], lu[tr.y], lu[tr.z]};
-                const double v[3] = {lv[tr.x], lv[tr.y], lv[tr.z]};
-                if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, c_expC, c_pmax, c_heal, c_dxs, c_coh);
-                else vp_stress(p, dxN, u, v, sig, c_expC);
-            }
-            if (writer) {
-                stg<NT_S>(b.s0n + e, sig[0]); stg<NT_S>(b.s1n + e, sig[1]); stg<NT_S>(b.s2n + e, sig[2]);
-                if (bbm) stg<NT_S>(b.dn + e, damage);
-            }
-            double F[6];
-            corner_forces(volume, sig, dxN, F);
-#pragma unroll
-            for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + l] = F[k];
-        }
-#if NXS_PF >= 1
-        eraw = eraw1; tr = tr1; eraw1 = eraw2; tr1 = tr2;
-#endif
-    }
-
-    NXS_STAMP(2);
-    // node phase: issue this node's loads before barrier 2 so that they overlap the wait
-    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.Pmax;
-    for (int base = 0; base < nO || base == 0; base += T) {
-        const int i = base + t;
-        const bool active = i < nO;
-        const int n = active ? (base == 0 ? my_node : pn[i]) : 0;
-        unsigned char nf = 0;
-        double node_mass = 0., gx = 0., gy = 0., rlm = 0., cbu = 0., fcor = 0., lat = 0., tax = 0., tay = 0., ou = 0., ov = 0.,
-               vtmu = 0., vtmv = 0., umu = 0., umv = 0., utu = 0., utv = 0.;
-        int sq0 = 0, sq1 = 0;
-        if (active) {
-            nf = m.nflags[n];
-            node_mass = w.node_mass[n];
-            gx = w.grad_ssh[n]; gy = w.grad_ssh[n + Nn];
-            rlm = w.rlmass[n]; cbu = w.C_bu[n]; fcor = w.fcor[n]; lat = (nf & NF_LAT_NEG) ? -1. : 1.;
-            tax = w.D_tau_a[n]; tay = w.D_tau_a[n + Nn];
-            ou = s.ocean[n]; ov = s.ocean[n + Nn];
-            if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
-            if (move_dt != 0.) { umu = ldg<NT_U>(s.UM + n); umv = ldg<NT_U>(s.UM + n + Nn); utu = ldg<NT_U>(s.UT + n); utv = ldg<NT_U>(s.UT + n + Nn); }
-            if (HALO && boundary) { sq0 = hf.send_ptr[n]; sq1 = hf.send_ptr[n + 1]; }
-        }
-        // the node's fan (element slot, corner) too: 8 entries cover all but the most irregular vertices
-        unsigned short fan[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) fan[k] = (active && k < pp.Wp) ? pf[(size_t)k * pp.Pmax + i] : (unsigned short)0xFFFFu;
-        if (base == 0) { __syncthreads(); NXS_STAMP(3); }  // corner forces visible
-        if (!active) continue;
-        double uice = lu[i], vice = lv[i];
-        if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
-            bool more = true;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned ent = fan[k];
-                if (!more || ent == 0xFFFFu) { more = false; continue; }
-                if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
-                const int l = ent >> 3, c = ent & 3u;
-                gx -= lF[(size_t)c * Emax + l];
-                gy -= lF[(size_t)(c + 3) * Emax + l];
-            }
-            for (int k = 8; more && k < pp.Wp; ++k) {
-                const unsigned ent = pf[(size_t)k * pp.Pmax + i];
-                if (ent == 0xFFFFu) break;
-                if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
-                const int l = ent >> 3, c = ent & 3u;
-                gx -= lF[(size_t)c * Emax + l];
-                gy -= lF[(size_t)(c + 3) * Emax + l];
-            }
-            nodal_solve(p, gx, gy, uice, vice, node_mass, rlm, cbu, fcor, lat, tax, tay, ou, ov, vtmu, vtmv);
-        }
-        b.VTn[n] = uice;
-        b.VTn[n + Nn] = vice;
-        if (HALO) {  // updateGhosts, sending side: straight into the neighbours' mailboxes
-            for (int q = sq0; q < sq1; ++q) {
-                const int k = hf.send_k[q];
-                double *dst = hf.ipc.peer_seg[k] + (xseq & 1ull) * hf.ipc.peer_parity_stride[k] + hf.send_pos[q];
-                sys_store(dst, uice);
-                sys_store(dst + (hf.send_off[k + 1] - hf.send_off[k]), vice);
-            }
-        }
-        if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
-            if (!(nf & NF_NEUMANN)) {
-                stg<NT_U>(s.UM + n, umu + move_dt * uice);
-                stg<NT_U>(s.UM + n + Nn, umv + move_dt * vice);
-            }
-            stg<NT_U>(s.UT + n, utu + move_dt * uice);
-            stg<NT_U>(s.UT + n + Nn, utv + move_dt * vice);
-        }
-    }
-    NXS_STAMP(4);
-    if (HALO) {
-        if (boundary) {  // publish: the last boundary patch to finish raises my flag at every neighbour
-            // The mailbox stores are write-through system-scope stores into uncached memory: nothing of them lives in a cache, so
-            // no release fence (= writing this XCD's whole L2 back, per workgroup and sub-step) is needed to make them visible --
-            // every wave drains its own stores, the barrier collects the waves, one lane counts the workgroup in, and the last
-            // one raises the flags behind ONE release fence per launch.  The separate k_halo_push keeps the fences; bench.py
-            // checks both variants against each other on the machine it runs on.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (t == 0 && atomicAdd(hf.ipc.done_push, 1u) == (unsigned)hf.n_boundary - 1u) {
-                __threadfence_system();  // the one release of the launch
-                for (int k = 0; k < hf.ipc.ns; ++k)
-                    __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
-                *hf.ipc.done_push = 0u;
-                *hf.ipc.seq_push = xseq + 1ull;  // every boundary patch has read it; no counter over the whole grid (same-address atomics are served ~10 ns apart)
-            }
-        } else if (hf.n_boundary == 0 && blockIdx.x == 0 && t == 0) {
-            *hf.ipc.seq_push = xseq + 1ull;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// v3  D sub-steps per launch (single rank, deferred mesh move): temporal blocking of the sub-step loop.
-// A patch carries D rings of halo (DevPatches2).  Sub-step k of the launch updates the elements E_(D-k) and solves the nodes
-// N_(D-k-1): what lies outside the own nodes is recomputed redundantly by the neighbouring patches -- same inputs, same
-// operations, same bits -- so the element state and the nodal inputs are read once and written once per D sub-steps and
-// the loop needs S/D launches.  The intermediate stresses stay in LDS, the intermediate velocities of the own nodes still go
-// to their ring slots: the deferred mesh move needs every sub-step's velocity.
-template <int T, bool POW4, int NTM>
-__global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int NDm = pp.NDmax, EDm = pp.EDmax, ESm = pp.ESmax, D = pp.D;
-    double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm, *lF = ly + NDm /*[6][EDm]*/, *lS = lF + 6 * (size_t)EDm /*[4][ESm]*/;
-    int blk;
-    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
-        const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, r = n & 7, x = pos & 7;
-        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
-    }
-    const int t = threadIdx.x, Nn = m.Nn;
-    const int *ncnt = pp.ncnt + (size_t)blk * (D + 1), *ecnt = pp.ecnt + (size_t)blk * D;
-    const int nO = ncnt[0], nD = ncnt[D];
-    const int *pn = pp.pnodes + (size_t)blk * NDm;
-    const int *pe = pp.pelem + (size_t)blk * EDm;
-    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * EDm;
-    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
-    const bool bbm = p.dynamics_type == NXS_DYN_BBM;
-    constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
-
-    // index rows are padded: the first loads depend on the launch arguments only
-    const int my_node = (t < NDm) ? pn[t] : 0;
-    int eraw0 = 0;
-    ushort4 tr0 = make_ushort4(0, 0, 0, 0);
-    if (t < EDm) { eraw0 = pe[t]; tr0 = pt[t]; }
-    for (int i = t; i < nD; i += T) {
-        const int g = (i == t) ? my_node : pn[i];
-        lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
-        lx[i] = w.xs[g]; ly[i] = w.ys[g];
-    }
-
-    // one element of one sub-step (FE.cpp:10425-10467), split into its global loads and the rest so that the barrier
-    // between them sits in uniform control flow.  first sub-step of the launch: state from HBM; last: result to HBM (if this
-    // patch writes the element); in between the state lives in LDS
-    struct ElemIn { int e; bool writer, skip; int dxi; double sig[3], damage, expC, volume, pmax, heal, coh; };
-    auto load_element = [&](const int eraw, const bool first, const bool last) {
-        ElemIn in;
-        in.writer = eraw >= 0;
-        in.e = in.writer ? eraw : ~eraw;
-        const int e = in.e;
-        in.skip = true; in.dxi = 0; in.damage = 0.; in.pmax = 0.; in.heal = 0.; in.coh = 0.; in.sig[0] = in.sig[1] = in.sig[2] = 0.;
-        if (!bbm) in.skip = w.eskip[e];
-        if (first) {
-            in.sig[0] = ldg<NT_S>(b.s0c + e); in.sig[1] = ldg<NT_S>(b.s1c + e); in.sig[2] = ldg<NT_S>(b.s2c + e);
-            if (bbm) in.damage = ldg<NT_S>(b.dc + e);
-        }
-        // the element constants are read by every sub-step of the launch: the later reads hit the L2
-        in.expC = last ? ldg<NT_C>(w.expC + e) : w.expC[e];
-        in.volume = last ? ldg<NT_C>(w.volume + e) : w.volume[e];
-        if (bbm) {
-            in.pmax = last ? ldg<NT_C>(w.pmax + e) : w.pmax[e]; in.heal = last ? ldg<NT_C>(w.heal + e) : w.heal[e];
-            in.dxi = w.dxi[e]; in.coh = last ? ldg<NT_C>(s.cohesion + e) : s.cohesion[e];
-        }
-        return in;
-    };
-    auto compute_element = [&](const int l, const ushort4 tr, ElemIn &in, const bool first, const bool last, const int keep) {
-        double dxN[6], sig[3] = {in.sig[0], in.sig[1], in.sig[2]}, damage = in.damage, c_dxs = 1.;
-        bool skip = in.skip;
-        if (!first) { sig[0] = lS[l]; sig[1] = lS[ESm + l]; sig[2] = lS[2 * (size_t)ESm + l]; damage = lS[3 * (size_t)ESm + l]; }
-        if (bbm) {  // M_delta_x is an integer number of metres (Q1) and travels as one, with the skip flag in its sign
-            skip = in.dxi < 0;
-            c_dxs = (double)(skip ? ~in.dxi : in.dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
-        }
-        {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates, as k_substep_fused
-            const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
-            const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
-            const double jac = jacobian(vx, vy);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-                dxN[k] = (vy[kp1] - vy[kp2]) / jac;
-                dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
-            }
-        }
-        if (skip) {
-            sig[0] = sig[1] = sig[2] = 0.;
-            damage = 0.;
-        } else {
-            const double u[3] = {lu[tr.x], lu[tr.y], lu[tr.z]};
-            const double v[3] = {lv[tr.x], lv[tr.y], lv[tr.z]};
-            if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, in.expC, in.pmax, in.heal, c_dxs, in.coh);
-            else vp_stress(p, dxN, u, v, sig, in.expC);
-        }
-        if (!last) {
-            if (l < keep) { lS[l] = sig[0]; lS[ESm + l] = sig[1]; lS[2 * (size_t)ESm + l] = sig[2]; lS[3 * (size_t)ESm + l] = damage; }  // needed by the next sub-step
-        } else if (in.writer) {
-            stg<NT_S>(b.s0n + in.e, sig[0]); stg<NT_S>(b.s1n + in.e, sig[1]); stg<NT_S>(b.s2n + in.e, sig[2]);
-            if (bbm) stg<NT_S>(b.dn + in.e, damage);
-        }
-        double F[6];
-        corner_forces(in.volume, sig, dxN, F);
-#pragma unroll
-        for (int k = 0; k < 6; ++k) lF[(size_t)k * EDm + l] = F[k];
-    };
-    // one node of one sub-step (FE.cpp:10472-10529), loads and solve apart for the same reason
-    struct NodeIn { unsigned char nf; double node_mass, gx, gy, rlm, cbu, fcor, tax, tay, ou, ov; unsigned short fan[8]; };
-    auto load_node = [&](const int i, const int n) {
-        NodeIn in;
-        in.nf = m.nflags[n];
-        in.node_mass = w.node_mass[n];
-        in.gx = w.grad_ssh[n]; in.gy = w.grad_ssh[n + Nn];
-        in.rlm = w.rlmass[n]; in.cbu = w.C_bu[n]; in.fcor = w.fcor[n];
-        in.tax = w.D_tau_a[n]; in.tay = w.D_tau_a[n + Nn];
-        in.ou = s.ocean[n]; in.ov = s.ocean[n + Nn];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) in.fan[k] = (k < pp.Wp) ? pf[(size_t)k * pp.NSmax + i] : (unsigned short)0xFFFFu;
-        return in;
-    };
-    auto solve_node = [&](const int i, NodeIn &in, double &uice, double &vice) {
-        uice = lu[i]; vice = lv[i];
-        if ((in.nf & NF_DIRICHLET) || in.node_mass == 0.) return;
-        double gx = in.gx, gy = in.gy;
-        bool more = true;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned ent = in.fan[k];
-            if (!more || ent == 0xFFFFu) { more = false; continue; }
-            if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
-            const int l = ent >> 3, c = ent & 3u;
-            gx -= lF[(size_t)c * EDm + l];
-            gy -= lF[(size_t)(c + 3) * EDm + l];
-        }
-        for (int k = 8; more && k < pp.Wp; ++k) {
-            const unsigned ent = pf[(size_t)k * pp.NSmax + i];
-            if (ent == 0xFFFFu) break;
-            if (ent & 4u) continue;
-            const int l = ent >> 3, c = ent & 3u;
-            gx -= lF[(size_t)c * EDm + l];
-            gy -= lF[(size_t)(c + 3) * EDm + l];
-        }
-        nodal_solve(p, gx, gy, uice, vice, in.node_mass, in.rlm, in.cbu, in.fcor, (in.nf & NF_LAT_NEG) ? -1. : 1., in.tax, in.tay, in.ou, in.ov, 0., 0.);
-    };
-
-    for (int k = 0; k < D; ++k) {
-        const int ne = ecnt[D - 1 - k], nn = ncnt[D - 1 - k], keep = (k + 1 < D) ? ecnt[D - 2 - k] : 0;
-        const bool first = k == 0, last = k == D - 1;
-        // ---- elements E_(D-k)
-        for (int base = 0; base < ne || base == 0; base += T) {
-            const int l = base + t;
-            const bool active = l < ne;
-            int eraw = eraw0; ushort4 tr = tr0;
-            if (base > 0 && active) { eraw = pe[l]; tr = pt[l]; }
-            ElemIn in{};
-            if (active) in = load_element(eraw, first, last);
-            if (base == 0) __syncthreads();  // k == 0: staged velocities / coordinates; k > 0: the velocities of sub-step k on N_(D-k), forces consumed
-            if (active) compute_element(l, tr, in, first, last, keep);
-        }
-        // ---- nodes N_(D-k-1)
-        double *vt = vout.slot[k];
-        for (int base = 0; base < nn || base == 0; base += T) {
-            const int i = base + t;
-            const bool active = i < nn;
-            const int n = active ? ((base == 0) ? my_node : pn[i]) : 0;
-            NodeIn in{};
-            if (active) in = load_node(i, n);
-            if (base == 0) __syncthreads();  // corner forces of this sub-step visible
-            if (active) {
-                double u1, v1;
-                solve_node(i, in, u1, v1);
-                if (i < nO) { vt[n] = u1; vt[n + Nn] = v1; }
-                lu[i] = u1; lv[i] = v1;  // a node's solve reads only its own staged velocity: in place
-            }
-        }
-    }
-}
-
-// Deferred mesh move of the fused path: the fused kernel leaves every sub-step's velocity in a ring of
-// VT buffers; every `count` sub-steps this kernel applies the same sequence of additions
-// M_UM += dte*M_VT, M_UT += dte*M_VT (FE.cpp:10543-10550) for all nodes, owned and ghost -- same
-// operations in the same order, but UM/UT are streamed once per `count` sub-steps instead of every one.
-#define NXS_MAX_RING 129
-struct VTRing { double *slot[NXS_MAX_RING]; int R; };
-
-__global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRing ring, int first, int count, double dt) {
-    const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= m.Nn) return;
-    const int Nn = m.Nn;
-    const bool free_node = !(m.nflags[n] & NF_NEUMANN);  // Neumann nodes keep M_UM (restore == skip)
-    double umu = s.UM[n], umv = s.UM[n + Nn], utu = s.UT[n], utv = s.UT[n + Nn];
-    int sl = first;
-    for (int j = 0; j < count; ++j) {
-        const double u = ring.slot[sl][n], v = ring.slot[sl][n + Nn];
-        if (free_node) { umu += dt * u; umv += dt * v; }
-        utu += dt * u; utv += dt * v;
-        sl = (sl + 1 == ring.R) ? 0 : sl + 1;
-    }
-    if (free_node) { s.UM[n] = umu; s.UM[n + Nn] = umv; }
-    s.UT[n] = utu; s.UT[n + Nn] = utv;
-}
-
-// odd number of sub-steps: bring the ping-pong result back to the primary buffers
-__global__ void __launch_bounds__(BLOCK) k_pingpong_copy_back(DevMesh m, DevState s, int bbm, const double *vt_src, int copy_sigma) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (vt_src && i < 2 * m.Nn) s.VT[i] = vt_src[i];
-    if (copy_sigma && i < m.Ne) {
-        s.s0[i] = s.s0_b[i]; s.s1[i] = s.s1_b[i]; s.s2[i] = s.s2_b[i];
-        if (bbm) s.damage[i] = s.damage_b[i];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K6 updateGhosts, FE.cpp:13963-13996.  buf holds, per neighbour k, [u-block | v-block] at 2*off[k].
-__global__ void __launch_bounds__(BLOCK) k_halo_pack(const double *__restrict__ vec, int Nn, int total,
-                                                     const int *__restrict__ index, const int *__restrict__ seg_of,
-                                                     const int *__restrict__ offsets, double *__restrict__ buf) {
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= total) return;
-    const int k = seg_of[j];
-    const int off = offsets[k], srl = offsets[k + 1] - off;
-    const int idx = index[j];
-    buf[2 * (size_t)off + (j - off)] = vec[idx];
-    buf[2 * (size_t)off + (j - off) + srl] = vec[idx + Nn];
-}
-
-// unpack + (optionally) move the ghost nodes: every ghost node is in exactly one recv list
-__global__ void __launch_bounds__(BLOCK) k_halo_unpack(double *__restrict__ vec, DevMesh m, DevState s, int total,
-                                                       const int *__restrict__ index, const int *__restrict__ seg_of,
-                                                       const int *__restrict__ offsets, const double *__restrict__ buf,
-                                                       double move_dt) {
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j >= total) return;
-    const int Nn = m.Nn;
-    const int k = seg_of[j];
-    const int off = offsets[k], srl = offsets[k + 1] - off;
-    const int n = index[j];
-    const double u = buf[2 * (size_t)off + (j - off)];
-    const double v = buf[2 * (size_t)off + (j - off) + srl];
-    vec[n] = u;
-    vec[n + Nn] = v;
-    if (move_dt != 0.) {
-        if (!(m.nflags[n] & NF_NEUMANN)) {
-            s.UM[n] += move_dt * u;
-            s.UM[n + Nn] += move_dt * v;
-        }
-        s.UT[n] += move_dt * u;
-        s.UT[n + Nn] += move_dt * v;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K6, device-direct transport: updateGhosts through peer-mapped memory (xGMI P2P stores) instead of
-// RCCL launches.  Every rank owns a "mailbox" = two receive buffers (exchange parity) + one flag per
-// receive neighbour, exported with hipIpcGetMemHandle and mapped by its neighbours.
-//   k_halo_push      pack my boundary values and store them straight into each neighbour's mailbox
-//                    (write-through, system scope), then -- after ALL blocks have finished -- set my flag
-//                    in each neighbour's mailbox to the exchange's sequence number.
-//   k_halo_pull      wait until every neighbour's flag has reached the sequence number, then unpack the
-//                    mailbox (reads that bypass the caches) into the ghost slots and move the ghost nodes.
-// Sequence numbers live in device memory, so the kernels replay unchanged from a hipGraph.  Two mailbox
-// buffers suffice: a neighbour cannot start exchange x+2 before it has received my exchange x+1, which I
-// send only after my pull of exchange x.  Every spin is bounded; a timeout raises ipc->error.
-// selftest != 0: the payload is a code of (rank, entry, sequence) instead of vec
-__global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ vec, int Nn, int total, const int *__restrict__ index,
-                                                     const int *__restrict__ seg_of, const int *__restrict__ offsets, IpcDev ipc,
-                                                     int rank, int selftest) {
-    const unsigned long long seq = *ipc.seq_push;
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (j < total) {
-        const int k = seg_of[j];
-        const int off = offsets[k], srl = offsets[k + 1] - off;
-        double *dst = ipc.peer_seg[k] + (seq & 1ull) * ipc.peer_parity_stride[k];
-        double u, v;
-        if (selftest) {
-            u = (double)rank * 1e6 + (double)(j - off) + (double)seq * 1e-3;
-            v = -u;
-        } else {
-            const int idx = index[j];
-            u = vec[idx];
-            v = vec[idx + Nn];
-        }
-        sys_store(dst + (j - off), u);
-        sys_store(dst + (j - off) + srl, v);
-    }
-    // publish: every wave drains its stores, one lane releases for the block, the last block to finish raises the flags
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    __shared__ int last;
-    if (threadIdx.x == 0) { __threadfence_system(); last = (atomicAdd(ipc.done_push, 1u) == gridDim.x - 1); }
-    __syncthreads();
-    if (last) {
-        __threadfence_system();
-        for (int k = threadIdx.x; k < ipc.ns; k += BLOCK)
-            __hip_atomic_store(ipc.peer_flag[k], seq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above
-        if (threadIdx.x == 0) {
-            *ipc.done_push = 0u;
-            *ipc.seq_push = seq + 1ull;
-        }
-    }
-}
-
-__global__ void __launch_bounds__(BLOCK) k_halo_pull(double *__restrict__ vec, DevMesh m, DevState s, int total,
-                                                     const int *__restrict__ index, const int *__restrict__ seg_of,
-                                                     const int *__restrict__ offsets, IpcDev ipc, double move_dt, int selftest,
-                                                     const int *__restrict__ recv_procs, int latest_pushed) {
-    // latest_pushed: pull the exchange this rank published last (the fused kernel pushes by itself and keeps no
-    // pull counter); afterwards both counters agree again
-    const unsigned long long seq = latest_pushed ? *ipc.seq_push - 1ull : *ipc.seq_pull;
-    __shared__ int ok;
-    if (threadIdx.x == 0) {
-        ok = 1;
-        const long long t0 = wall_clock64();  // 100 MHz
-        for (int k = 0; k < ipc.nr; ++k) {
-            while (__hip_atomic_load(ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < seq + 1ull) {
-                __builtin_amdgcn_s_sleep(8);
-                if (__hip_atomic_load(ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }  // a wait already timed out: do not wait again
-                if (wall_clock64() - t0 > 1000000000ll) { ok = 0; atomicExch(ipc.error, 1); break; }  // 10 s
-            }
-            if (!ok) break;
-        }
-    }
-    __syncthreads();
-    const int j = blockIdx.x * BLOCK + threadIdx.x;
-    if (ok && j < total) {
-        const int Nn = m.Nn;
-        const int k = seg_of[j];
-        const int off = offsets[k], srl = offsets[k + 1] - off;
-        const double *src = ipc.mailbox + (seq & 1ull) * 2ull * (unsigned long long)ipc.tr + 2 * (size_t)off;
-        const double u = sys_load(src + (j - off));
-        const double v = sys_load(src + (j - off) + srl);
-        if (selftest) {
-            const double eu = (double)recv_procs[k] * 1e6 + (double)(j - off) + (double)seq * 1e-3;
-            if (u != eu || v != -eu) atomicExch(ipc.error, 2);
-        } else {
-            const int n = index[j];
-            vec[n] = u;
-            vec[n + Nn] = v;
-            if (move_dt != 0.) {
-                if (!(m.nflags[n] & NF_NEUMANN)) {
-                    s.UM[n] += move_dt * u;
-                    s.UM[n + Nn] += move_dt * v;
-                }
-                s.UT[n] += move_dt * u;
-                s.UT[n + Nn] += move_dt * v;
-            }
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(ipc.done_pull, 1u) == gridDim.x - 1) {
-        *ipc.done_pull = 0u;
-        *ipc.seq_pull = seq + 1ull;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// K8 one Jacobi sweep of the open-water smoother, FE.cpp:10582-10608: src -> dst for every node
-// Only ice-free, non-Dirichlet OWNED nodes change (FE.cpp:10589); every other node keeps its value in
-// both ping-pong buffers (k_copy_vt makes them equal once before the 50 sweeps; ghosts are refreshed by
-// the halo exchange), so a sweep touches 9 B per node plus the open-water nodes' neighbourhoods.
-__global__ void __launch_bounds__(BLOCK) k_smooth(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst) {
-    if (!w.open_blk[blockIdx.x]) return;  // no ice-free node among these BLOCK nodes: 9 B per node not read, 50 times per step
-    const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= m.No) return;
-    if ((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.) return;
-    const int Nn = m.Nn;
-    double u = 0., v = 0.;
-    const int num_neighbours = m.n2n_cnt[n];
-    for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
-        const int nni = m.n2n[(size_t)j * Nn + n];
-        u += src[nni];
-        v += src[nni + Nn];
-    }
-    u /= num_neighbours;
-    v /= num_neighbours;
-    dst[n] = u;
-    dst[n + Nn] = v;
-}
-
-// The same sweep with updateGhosts inside (device-direct transport, see HaloFused): ghost neighbours are read from
-// the mailbox (exchange x-1), every sent node -- smoothed or not -- is stored into the neighbours' mailboxes
-// (exchange x), and the last block raises the flags.  One launch per sweep instead of three.
-__global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst, HaloFused hf) {
-    const unsigned long long xseq = *hf.ipc.seq_push;
-    const int Nn = m.Nn, No = m.No;
-    if (hf.from_mailbox) {
-        if (threadIdx.x == 0) {
-            const long long t0 = wall_clock64();
-            bool ok = true;
-            for (int k = 0; k < hf.ipc.nr && ok; ++k)
-                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
-                    __builtin_amdgcn_s_sleep(4);
-                    if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 4); break; }  // 10 s
-                }
-        }
-        __syncthreads();
-    }
-    const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n < No) {
-        double u = src[n], v = src[n + Nn];
-        if (!((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) {
-            const double *mb = hf.ipc.mailbox + ((xseq - 1ull) & 1ull) * 2ull * (unsigned long long)hf.ipc.tr;
-            u = 0.; v = 0.;
-            const int num_neighbours = m.n2n_cnt[n];
-            for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
-                const int nni = m.n2n[(size_t)j * Nn + n];
-                if (hf.from_mailbox && nni >= No) {
-                    const double *g = mb + hf.ghost_off[nni - No];
-                    u += sys_load(g);
-                    v += sys_load(g + hf.ghost_srl[nni - No]);
-                } else {
-                    u += src[nni];
-                    v += src[nni + Nn];
-                }
-            }
-            u /= num_neighbours;
-            v /= num_neighbours;
-            dst[n] = u;
-            dst[n + Nn] = v;
-        }
-        for (int q = hf.send_ptr[n]; q < hf.send_ptr[n + 1]; ++q) {
-            const int k = hf.send_k[q];
-            double *d = hf.ipc.peer_seg[k] + (xseq & 1ull) * hf.ipc.peer_parity_stride[k] + hf.send_pos[q];
-            sys_store(d, u);
-            sys_store(d + (hf.send_off[k + 1] - hf.send_off[k]), v);
-        }
-    }
-    // as in the sub-step kernel: drain per wave, count the block in, release once.  Only blocks that sent something take a
-    // ticket, and the tickets are two-level (16 group counters, then one): atomics on one address are served ~10 ns apart,
-    // a counter over all blocks of a 2-rank 2 km partition (1 400) would cost more than the sweep itself.
-    const int sr = hf.send_block_rank[blockIdx.x];
-    if (sr < 0 && !(hf.n_send_blocks == 0 && blockIdx.x == 0)) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    bool last = hf.n_send_blocks == 0;
-    if (!last) {
-        const unsigned int total = (unsigned)hf.n_send_blocks, g = (unsigned)sr % 16u, members = (total - g + 15u) / 16u;
-        if (__hip_atomic_fetch_add(hf.done_all + 32u * (g + 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
-            __hip_atomic_store(hf.done_all + 32u * (g + 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned int groups = total < 16u ? total : 16u;
-            last = __hip_atomic_fetch_add(hf.done_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
-        }
-    }
-    if (last) {
-        __threadfence_system();  // the one release of the launch
-        for (int k = 0; k < hf.ipc.ns; ++k)
-            __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
-        __hip_atomic_store(hf.done_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *hf.ipc.seq_push = xseq + 1ull;
-    }
-}
-
-__global__ void __launch_bounds__(BLOCK) k_copy_vt(int n2, const double *__restrict__ src, double *__restrict__ dst) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n2) dst[i] = src[i];
-}
-
-// K9 FE.cpp:10613-10640
-__global__ void __launch_bounds__(BLOCK) k_ow_tail(DevMesh m, DevState s, DevWork w, DevParams p) {
-    const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= m.Nn) return;
-    const int Nn = m.Nn;
-    const double vu = s.VT[n], vv = s.VT[n + Nn];
-    const double uice = 0.5 * (vu + w.VTM[n]);
-    const double vice = 0.5 * (vv + w.VTM[n + Nn]);
-    const double ou = s.ocean[n], ov = s.ocean[n + Nn];
-    const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
-    w.D_tau_w[n] = c_prime * (uice - ou);
-    w.D_tau_w[n + Nn] = c_prime * (vice - ov);
-    const unsigned char nf = m.nflags[n];
-    if ((nf & NF_DIRICHLET) || w.node_mass[n] != 0.) return;
-    if (!(nf & NF_NEUMANN)) {
-        s.UM[n] += p.dtime_step * vu;
-        s.UM[n + Nn] += p.dtime_step * vv;
-    }
-    s.UT[n] += p.dtime_step * vu;
-    s.UT[n + Nn] += p.dtime_step * vv;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K10 update(), FE.cpp:3946-4131
-__global__ void __launch_bounds__(BLOCK) k_update(DevMesh m, DevState s, DevWork w, DevParams p) {
-    const int e = blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= m.Ne) return;
-    const bool to_be_updated = !(m.eflags[e] & EF_ON_NEUMANN);
-    double D_del = 0.;
-    const double surface_old = w.surface[e];
-    double conc = s.conc[e], thick = s.thick[e], snow = s.snow[e], tmyi = s.tmyi[e], cmyi = s.cmyi[e];
-    double ridge = s.ridge[e];
-    double cy = 0., hy = 0., hsy = 0.;
-    if (p.young_cat) { cy = s.cyoung[e]; hy = s.hyoung[e]; hsy = s.hsyoung[e]; }
-    const double old_conc = conc;
-    double vx[3], vy[3];
-    load_vertices(m, s.UM, e, vx, vy);
-    const double surface = (1. / 2) * fabs(jacobian(vx, vy));
-    w.surface[e] = surface;
-    if ((conc > 0.) && to_be_updated) {
-        const double surf_ratio = surface_old / surface;
-        conc *= surf_ratio; thick *= surf_ratio; snow *= surf_ratio; tmyi *= surf_ratio;
-        s.s0[e] *= surf_ratio; s.s1[e] *= surf_ratio; s.s2[e] *= surf_ratio;
-        ridge = 1. - (1. - ridge) * STD_MIN(1., conc) / (old_conc * surf_ratio);
-        if (p.young_cat) { hy *= surf_ratio; cy *= surf_ratio; hsy *= surf_ratio; }
-        if (p.equal_ridging) {
-            const double conc_ratio = STD_MIN(1., conc) / old_conc;
-            cmyi *= conc_ratio;
-            D_del = 0.;
-        } else {
-            cmyi *= surf_ratio;
-            D_del = -cmyi;
-            cmyi = STD_MIN(cmyi, 1.);
-            D_del += cmyi;
-        }
-        D_del *= NXS_DAYS_IN_SEC / p.dtime_step;
-    }
-    double open_water_concentration = 1. - conc;
-    if (p.young_cat) open_water_concentration -= cy;
-    open_water_concentration = (open_water_concentration < 0.) ? 0. : open_water_concentration;
-    open_water_concentration = (open_water_concentration > 1.) ? 1. : open_water_concentration;
-    double new_conc_young = 0., new_h_young = 0., new_hs_young = 0., newice = 0., del_c = 0., newsnow = 0.;
-    const double ridge_young_ice_aspect_ratio = 10.;
-    if (p.young_cat) {
-        if (cy > 0.) {
-            new_conc_young = STD_MIN(1., STD_MAX(0., 1. - conc - open_water_concentration));
-            if ((conc > p.min_c) && (thick > p.min_h) && (new_conc_young < cy)) {
-                new_h_young = new_conc_young * hy / cy;
-                new_hs_young = new_conc_young * hsy / cy;
-                newice = hy - new_h_young;
-                del_c = (cy - new_conc_young) / ridge_young_ice_aspect_ratio;
-                newsnow = hsy - new_hs_young;
-                hy = new_h_young;
-                hsy = new_hs_young;
-                ridge = 1. - (1. - ridge) * thick / (thick + newice);
-                thick += newice;
-                snow += newsnow;
-            }
-        } else {
-            hy = 0.;
-            hsy = 0.;
-        }
-    }
-    conc = STD_MIN(1., STD_MAX(0., 1. - new_conc_young - open_water_concentration + del_c));
-    if (p.young_cat) {
-        new_conc_young = STD_MAX(0., STD_MIN(new_conc_young, 1. - conc));
-        cy = new_conc_young;
-    }
-    const double max_true_thickness = 50.;
-    if (conc > 0.) {
-        double test_h_thick = thick / conc;
-        test_h_thick = (test_h_thick > max_true_thickness) ? max_true_thickness : test_h_thick;
-        conc = STD_MIN(1. - new_conc_young, thick / test_h_thick);
-    } else {
-        ridge = 0.; thick = 0.; snow = 0.;
-    }
-    conc = ((conc > 0.) ? conc : 0.);
-    thick = ((thick > 0.) ? thick : 0.);
-    tmyi = ((tmyi > 0.) ? tmyi : 0.);
-    snow = ((snow > 0.) ? snow : 0.);
-    D_del = -cmyi;
-    if (p.newice_type == 4 && p.use_young_myi)
-        cmyi = STD_MAX(0., STD_MIN(cmyi, conc + cy));
-    else
-        cmyi = STD_MAX(0., STD_MIN(cmyi, conc));
-    D_del += cmyi;
-    s.conc[e] = conc; s.thick[e] = thick; s.snow[e] = snow; s.tmyi[e] = tmyi; s.cmyi[e] = cmyi;
-    s.ridge[e] = ridge;
-    if (p.young_cat) { s.cyoung[e] = cy; s.hyoung[e] = hy; s.hsyoung[e] = hsy; }
-    w.D_del[e] = D_del;
-}
-
-// K13 updateFreeDriftVelocity, FE.cpp:10140-10176
-__global__ void __launch_bounds__(BLOCK) k_free_drift(DevMesh m, DevState s, DevParams p) {
-    const int nd = blockIdx.x * BLOCK + threadIdx.x;
-    if (nd >= m.Nn) return;
-    if (m.nflags[nd] & NF_DIRICHLET) return;
-    const int Nn = m.Nn;
-    const double u = s.VT[nd], v = s.VT[nd + Nn];
-    const double ou = s.ocean[nd], ov = s.ocean[nd + Nn], wu = s.wind[nd], wv = s.wind[nd + Nn];
-    double norm_Voce_ice = hypot(u - ou, v - ov);
-    norm_Voce_ice = (norm_Voce_ice > 0.01) ? norm_Voce_ice : 0.01;
-    double coef_Voce = p.ldw + p.qdw * norm_Voce_ice;
-    coef_Voce *= NXS_RHOW;
-    double norm_Vair_ice = hypot(u - wu, v - wv);
-    norm_Vair_ice = (norm_Vair_ice > 0.01) ? norm_Vair_ice : 0.01;
-    double coef_Vair = p.lda + p.qda * norm_Vair_ice;
-    coef_Vair *= NXS_RHOA;
-    const double nu_ = (coef_Vair * wu + coef_Voce * ou) / (coef_Vair + coef_Voce);
-    const double nv_ = (coef_Vair * wv + coef_Voce * ov) / (coef_Vair + coef_Voce);
-    s.VT[nd] = nu_;
-    s.VT[nd + Nn] = nv_;
-    s.UT[nd] += p.dtime_step * nu_;
-    s.UT[nd + Nn] += p.dtime_step * nv_;
-}
-
-// ------------------------------------------------------------------------------------------------
-// reductions: wave (64 lanes) shuffle -> LDS across the 4 waves of a block -> one partial per block
-struct RegridPartial { double min_angle, min_jac, max_jac; };
-
-__device__ __forceinline__ double wave_min(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = (y < x) ? y : x; }
-    return x;
-}
-__device__ __forceinline__ double wave_max(double x) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = (x < y) ? y : x; }
-    return x;
-}
-
-// K11 minAngles (FE.cpp:1758-1768) + flip's jacobians (FE.cpp:1824-1839)
-__global__ void __launch_bounds__(BLOCK) k_regrid_partials(DevMesh m, DevState s, RegridPartial *out) {
-    __shared__ double sh[3][BLOCK / 64];
-    double ang = INFINITY, jmin = INFINITY, jmax = -INFINITY;
-    for (int e = blockIdx.x * BLOCK + threadIdx.x; e < m.Ne; e += gridDim.x * BLOCK) {
-        double vx[3], vy[3];
-        load_vertices(m, s.UM, e, vx, vy);
-        double a = hypot(vx[1] - vx[0], vy[1] - vy[0]);
-        double b = hypot(vx[2] - vx[1], vy[2] - vy[1]);
-        double c = hypot(vx[2] - vx[0], vy[2] - vy[0]);
-        double t;  // std::sort of 3
-        if (b < a) { t = a; a = b; b = t; }
-        if (c < b) { t = b; b = c; c = t; }
-        if (b < a) { t = a; a = b; b = t; }
-        double minang = acos((pow(b, 2.) + pow(c, 2.) - pow(a, 2.)) / (2 * b * c));
-        minang = minang * 45.0 / atan(1.0);
-        ang = (minang < ang) ? minang : ang;
-        const double jac = jacobian(vx, vy);
-        jmin = (jac < jmin) ? jac : jmin;
-        jmax = (jmax < jac) ? jac : jmax;
-    }
-    ang = wave_min(ang); jmin = wave_min(jmin); jmax = wave_max(jmax);
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { sh[0][wv] = ang; sh[1][wv] = jmin; sh[2][wv] = jmax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int i = 1; i < BLOCK / 64; ++i) {
-            ang = (sh[0][i] < ang) ? sh[0][i] : ang;
-            jmin = (sh[1][i] < jmin) ? sh[1][i] : jmin;
-            jmax = (jmax < sh[2][i]) ? sh[2][i] : jmax;
-        }
-        out[blockIdx.x] = RegridPartial{ang, jmin, jmax};
-    }
-}
-
-__global__ void k_regrid_final(const RegridPartial *in, int n, RegridPartial *out) {
-    double ang = INFINITY, jmin = INFINITY, jmax = -INFINITY;
-    for (int i = threadIdx.x; i < n; i += 64) {
-        ang = (in[i].min_angle < ang) ? in[i].min_angle : ang;
-        jmin = (in[i].min_jac < jmin) ? in[i].min_jac : jmin;
-        jmax = (jmax < in[i].max_jac) ? in[i].max_jac : jmax;
-    }
-    ang = wave_min(ang); jmin = wave_min(jmin); jmax = wave_max(jmax);
-    if (threadIdx.x == 0) *out = RegridPartial{ang, jmin, jmax};
-}
-
-// K12 checkFieldsFast (FE.cpp:14536-14655) restricted to this path's fields
-__device__ __forceinline__ bool bad_range(double val, double lo, double hi) {
-    return (val > hi) || (val < lo) || isnan(val);
-}
-
-__global__ void __launch_bounds__(BLOCK) k_check_fields(DevMesh m, DevState s, DevParams p, int *crash) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    bool bad = false;
-    if (i < m.Ne) {
-        bad |= bad_range(s.thick[i], 0., 50.);
-        bad |= bad_range(s.snow[i], 0., 10.);
-        bad |= bad_range(s.conc[i], 0., 1.);
-        bad |= bad_range(s.damage[i], 0., 1.);
-        bad |= bad_range(s.ridge[i], 0., 1.);
-        if (p.young_cat) {
-            bad |= bad_range(s.hyoung[i], 0., 2.);
-            bad |= bad_range(s.hsyoung[i], 0., 2.);
-            bad |= bad_range(s.cyoung[i], 0., 1.);
-        }
-    }
-    if (i < m.Nn) {
-        const double u = s.VT[i], v = s.VT[i + m.Nn];
-        bad |= hypot(u, v) > 5.;
-        bad |= isnan(u + v);
-    }
-    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(crash, 1);
-}
-
-
-// ExternalData::get for a dataset that is interpolated linearly in time (model/externaldata.cpp:360-401):
-//   value = M_factor*(fcoeff[0]*interpolated_data[0][i] + fcoeff[1]*interpolated_data[1][i]) + M_bias_correction
-// for M_wind, M_ocean (2Nn) and M_ssh (Nn), evaluated on the device from two resident snapshots.
-struct ForcingBlend { const double *w0, *w1, *o0, *o1, *s0, *s1; double c0, c1, factor[3], bias[3]; };
-__global__ void __launch_bounds__(BLOCK) k_blend_forcing(int Nn, ForcingBlend b, double *__restrict__ wind, double *__restrict__ ocean, double *__restrict__ ssh) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < 2 * Nn) {
-        wind[i] = b.factor[0] * (b.c0 * b.w0[i] + b.c1 * b.w1[i]) + b.bias[0];
-        ocean[i] = b.factor[1] * (b.c0 * b.o0[i] + b.c1 * b.o1[i]) + b.bias[1];
-    }
-    if (i < Nn) ssh[i] = b.factor[2] * (b.c0 * b.s0[i] + b.c1 * b.s1[i]) + b.bias[2];
-}
+#include "nxs_dyn_kernels.inl"
 
 // ================================================================================================
 // host side
@@ -1827,406 +283,7 @@ int harvest(nxs_dyn_handle *h, int k) {
 }
 
 
-// ------------------------------------------------------------------------------------------------
-// Host: node patches for the fused sub-step kernel (see DevPatches).
-
-// order: owned nodes in the order they are cut into patches of P.
-bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int No, int P,
-                              const std::vector<int> &order, HostPatches &out) {
-    // node -> elements CSR
-    std::vector<int> off(Nn + 1, 0);
-    for (int k = 0; k < 3; ++k) for (int e = 0; e < Ne; ++e) off[t[k][e] + 1]++;
-    for (int n = 0; n < Nn; ++n) off[n + 1] += off[n];
-    std::vector<int> adj(off[Nn]), fill(off.begin(), off.end() - 1);
-    for (int e = 0; e < Ne; ++e) for (int k = 0; k < 3; ++k) adj[fill[t[k][e]]++] = e;  // ascending e per node
-
-    const int nNodePatches = (No + P - 1) / P;
-    std::vector<int> patch_of(Nn, -1);
-    for (int i = 0; i < No; ++i) patch_of[order[i]] = i / P;
-    // writer patch of an element = smallest patch id among its owned nodes; none -> orphan
-    std::vector<int> writer(Ne, -1);
-    std::vector<int> orphans;
-    for (int e = 0; e < Ne; ++e) {
-        int w = -1;
-        for (int k = 0; k < 3; ++k) {
-            const int q = patch_of[t[k][e]];
-            if (q >= 0 && (w < 0 || q < w)) w = q;
-        }
-        writer[e] = w;
-        if (w < 0) orphans.push_back(e);
-    }
-    const int EORPH = 2 * P;
-    const int nOrphPatches = ((int)orphans.size() + EORPH - 1) / EORPH;
-    const int nP = nNodePatches + nOrphPatches;
-
-    std::vector<std::vector<int>> pel(nP), pnd(nP);
-    std::vector<int> own_cnt(nP, 0);
-    std::vector<int> mark(Ne, -1), slot_of(Nn, -1);
-    size_t tot_e = 0;
-    for (int q = 0; q < nNodePatches; ++q) {
-        const int a = q * P, bnd = std::min(No, a + P);
-        own_cnt[q] = bnd - a;
-        auto &el = pel[q];
-        for (int i = a; i < bnd; ++i) {
-            const int n = order[i];
-            for (int j = off[n]; j < off[n + 1]; ++j) {
-                const int e = adj[j];
-                if (mark[e] != q) { mark[e] = q; el.push_back(e); }
-            }
-        }
-        std::sort(el.begin(), el.end());
-        tot_e += el.size();
-    }
-    for (int q = 0; q < nOrphPatches; ++q) {
-        auto &el = pel[nNodePatches + q];
-        const int a = q * EORPH, bnd = std::min((int)orphans.size(), a + EORPH);
-        el.assign(orphans.begin() + a, orphans.begin() + bnd);  // already ascending
-    }
-    int Emax = 0, Mmax = 0, Wp = 0, Pmax = 0;
-    std::vector<std::vector<unsigned short>> tri_l(nP);
-    std::vector<std::vector<std::vector<unsigned short>>> fan_l(nP);
-    for (int q = 0; q < nP; ++q) {
-        auto &nd = pnd[q];
-        if (q < nNodePatches) {
-            const int a = q * P;
-            for (int i = 0; i < own_cnt[q]; ++i) { nd.push_back(order[a + i]); slot_of[order[a + i]] = i; }
-        }
-        std::vector<int> halo;
-        for (int e : pel[q])
-            for (int k = 0; k < 3; ++k) {
-                const int n = t[k][e];
-                if (slot_of[n] == -1) { slot_of[n] = -2; halo.push_back(n); }
-            }
-        std::sort(halo.begin(), halo.end());
-        for (int n : halo) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
-        if (nd.size() > 65535 || pel[q].size() > 8191) return false;
-        auto &tl = tri_l[q];
-        tl.resize(4 * pel[q].size());
-        auto &fl = fan_l[q];
-        fl.assign(own_cnt[q], {});
-        for (size_t l = 0; l < pel[q].size(); ++l) {
-            const int e = pel[q][l];
-            for (int k = 0; k < 3; ++k) {
-                const int n = t[k][e], sl = slot_of[n];
-                tl[4 * l + k] = (unsigned short)sl;
-                if (sl < own_cnt[q]) fl[sl].push_back((unsigned short)((l << 3) | (ghost3[3 * (size_t)e + k] ? 4 : 0) | k));
-            }
-            tl[4 * l + 3] = 0;
-        }
-        for (auto &f : fl) Wp = std::max(Wp, (int)f.size());
-        for (int n : nd) slot_of[n] = -1;
-        Emax = std::max(Emax, (int)pel[q].size());
-        Mmax = std::max(Mmax, (int)nd.size());
-        Pmax = std::max(Pmax, own_cnt[q]);
-    }
-    Emax = (Emax + 1) & ~1;  // keep the ushort4 / double rows 16-byte aligned
-    Mmax = (Mmax + 1) & ~1;
-    Pmax = std::max(Pmax, 1);
-    Wp = std::max(Wp, 1);
-    out = HostPatches{};
-    out.nP = nP; out.Pmax = Pmax; out.Emax = Emax; out.Mmax = Mmax; out.Wp = Wp;
-    out.own_cnt = own_cnt;
-    out.elem_cnt.resize(nP); out.node_cnt.resize(nP);
-    out.pnodes.assign((size_t)nP * Mmax, 0);
-    out.pelem.assign((size_t)nP * Emax, 0);
-    out.ptri.assign((size_t)nP * Emax * 4, 0);
-    out.pfan.assign((size_t)nP * Wp * Pmax, 0xFFFF);
-    for (int q = 0; q < nP; ++q) {
-        out.elem_cnt[q] = (int)pel[q].size();
-        out.node_cnt[q] = (int)pnd[q].size();
-        std::copy(pnd[q].begin(), pnd[q].end(), out.pnodes.begin() + (size_t)q * Mmax);
-        for (size_t l = 0; l < pel[q].size(); ++l) {
-            const int e = pel[q][l];
-            const bool is_writer = (writer[e] == q) || (writer[e] < 0);  // orphans are written by their orphan patch
-            out.pelem[(size_t)q * Emax + l] = is_writer ? e : ~e;
-        }
-        std::copy(tri_l[q].begin(), tri_l[q].end(), out.ptri.begin() + (size_t)q * Emax * 4);
-        for (int i = 0; i < own_cnt[q]; ++i)
-            for (size_t k = 0; k < fan_l[q][i].size(); ++k)
-                out.pfan[(size_t)q * Wp * Pmax + k * Pmax + i] = fan_l[q][i][k];
-    }
-    out.avg_elems_per_own_node = No > 0 ? (double)tot_e / No : 0.;
-    return true;
-}
-
-// owned nodes sorted along a Hilbert curve through their coordinates
-void hilbert_order(const double *x0, const double *y0, int No, std::vector<int> &order) {
-    order.resize(No);
-    for (int i = 0; i < No; ++i) order[i] = i;
-    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
-    for (int n = 0; n < No; ++n) { xmin = std::min(xmin, x0[n]); xmax = std::max(xmax, x0[n]); ymin = std::min(ymin, y0[n]); ymax = std::max(ymax, y0[n]); }
-    const double ext = std::max(xmax - xmin, ymax - ymin);
-    const double sc = ext > 0. ? 65535. / ext : 0.;
-    auto hilbert = [](unsigned x, unsigned y) {
-        unsigned long long d = 0;
-        for (unsigned s2 = 1u << 15; s2 > 0; s2 >>= 1) {
-            const unsigned rx = (x & s2) ? 1u : 0u, ry = (y & s2) ? 1u : 0u;
-            d += (unsigned long long)s2 * s2 * ((3u * rx) ^ ry);
-            if (ry == 0) {
-                if (rx == 1) { x = s2 - 1 - x; y = s2 - 1 - y; }
-                const unsigned t2 = x; x = y; y = t2;
-            }
-        }
-        return d;
-    };
-    std::vector<unsigned long long> key(No);
-    for (int n = 0; n < No; ++n) key[n] = hilbert((unsigned)((x0[n] - xmin) * sc), (unsigned)((y0[n] - ymin) * sc));
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
-}
-
-bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
-                   int No, int P, HostPatches &out) {
-    // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
-    std::vector<int> order(No);
-    for (int i = 0; i < No; ++i) order[i] = i;
-    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out);
-    if (ok && out.avg_elems_per_own_node <= 3.0) return true;
-    // numbering without locality: cut patches along a Hilbert curve through the node coordinates
-    // (consecutive runs of a Hilbert curve are compact blobs: small halos)
-    hilbert_order(x0, y0, No, order);
-    HostPatches alt;
-    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
-        out = std::move(alt);
-        out.used_hilbert = true;
-        return true;
-    }
-    return ok;
-}
-
-// Host: D-ring patches of k_substep_multi (DevPatches2); single rank (every node owned, no orphan elements).
-bool build_patches2(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int P, int D, const std::vector<int> &order, HostPatches2 &out) {
-    std::vector<int> off(Nn + 1, 0);
-    for (int k = 0; k < 3; ++k) for (int e = 0; e < Ne; ++e) off[t[k][e] + 1]++;
-    for (int n = 0; n < Nn; ++n) off[n + 1] += off[n];
-    std::vector<int> adj(off[Nn]), fill(off.begin(), off.end() - 1);
-    for (int e = 0; e < Ne; ++e) for (int k = 0; k < 3; ++k) adj[fill[t[k][e]]++] = e;  // ascending e per node
-    const int nP = (Nn + P - 1) / P;
-    std::vector<int> patch_of(Nn, -1);
-    for (int i = 0; i < Nn; ++i) patch_of[order[i]] = i / P;
-    std::vector<int> writer(Ne);
-    for (int e = 0; e < Ne; ++e) writer[e] = std::min({patch_of[t[0][e]], patch_of[t[1][e]], patch_of[t[2][e]]});
-
-    out = HostPatches2{};
-    out.nP = nP; out.D = D;
-    out.ncnt.assign((size_t)nP * (D + 1), 0); out.ecnt.assign((size_t)nP * D, 0);
-    std::vector<std::vector<int>> pel(nP), pnd(nP);
-    std::vector<std::vector<unsigned short>> tri_l(nP);
-    std::vector<std::vector<std::vector<unsigned short>>> fan_l(nP);
-    std::vector<int> emark(Ne, -1), eslot(Ne, -1), slot_of(Nn, -1);
-    for (int q = 0; q < nP; ++q) {
-        const int a = q * P, bnd = std::min(Nn, a + P);
-        auto &nd = pnd[q];
-        auto &el = pel[q];
-        int *nc = out.ncnt.data() + (size_t)q * (D + 1), *ec = out.ecnt.data() + (size_t)q * D;
-        for (int i = a; i < bnd; ++i) { slot_of[order[i]] = (int)nd.size(); nd.push_back(order[i]); }
-        nc[0] = bnd - a;
-        int n_prev = 0, e_prev = 0;
-        for (int lev = 1; lev <= D; ++lev) {
-            // E_lev: the elements touching N_(lev-1) that are not listed yet, ascending
-            std::vector<int> add;
-            for (int i = n_prev; i < nc[lev - 1]; ++i)
-                for (int j = off[nd[i]]; j < off[nd[i] + 1]; ++j) {
-                    const int e = adj[j];
-                    if (emark[e] != q) { emark[e] = q; add.push_back(e); }
-                }
-            std::sort(add.begin(), add.end());
-            el.insert(el.end(), add.begin(), add.end());
-            ec[lev - 1] = (int)el.size();
-            // N_lev: their nodes that are not listed yet, ascending
-            std::vector<int> addn;
-            for (int l = e_prev; l < ec[lev - 1]; ++l)
-                for (int k = 0; k < 3; ++k) {
-                    const int n = t[k][el[l]];
-                    if (slot_of[n] == -1) { slot_of[n] = -2; addn.push_back(n); }
-                }
-            std::sort(addn.begin(), addn.end());
-            for (int n : addn) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
-            nc[lev] = (int)nd.size();
-            n_prev = nc[lev - 1]; e_prev = ec[lev - 1];
-        }
-        if (nd.size() > 65535 || el.size() > 8191) return false;
-        for (size_t l = 0; l < el.size(); ++l) eslot[el[l]] = (int)l;
-        auto &tl = tri_l[q];
-        tl.assign(4 * el.size(), 0);
-        for (size_t l = 0; l < el.size(); ++l)
-            for (int k = 0; k < 3; ++k) tl[4 * l + k] = (unsigned short)slot_of[t[k][el[l]]];
-        const int nsolved = nc[D - 1];
-        auto &fl = fan_l[q];
-        fl.assign(nsolved, {});
-        for (int i = 0; i < nsolved; ++i) {
-            const int n = nd[i];
-            for (int j = off[n]; j < off[n + 1]; ++j) {  // ascending element id = the order of the serial scatter
-                const int e = adj[j];
-                int k = 0;
-                while (t[k][e] != n) ++k;
-                fl[i].push_back((unsigned short)((eslot[e] << 3) | (ghost3[3 * (size_t)e + k] ? 4 : 0) | k));
-            }
-            out.Wp = std::max(out.Wp, (int)fl[i].size());
-        }
-        for (int n : nd) slot_of[n] = -1;
-        out.NDmax = std::max(out.NDmax, nc[D]); out.NSmax = std::max(out.NSmax, nc[D - 1]);
-        out.EDmax = std::max(out.EDmax, ec[D - 1]); out.ESmax = std::max(out.ESmax, D >= 2 ? ec[D - 2] : 0);
-    }
-    out.NDmax = (out.NDmax + 1) & ~1; out.NSmax = (out.NSmax + 1) & ~1; out.EDmax = (out.EDmax + 1) & ~1; out.ESmax = std::max(2, (out.ESmax + 1) & ~1);
-    out.Wp = std::max(out.Wp, 1);
-    out.pnodes.assign((size_t)nP * out.NDmax, 0);
-    out.pelem.assign((size_t)nP * out.EDmax, 0);
-    out.ptri.assign((size_t)nP * out.EDmax * 4, 0);
-    out.pfan.assign((size_t)nP * out.Wp * out.NSmax, 0xFFFF);
-    for (int q = 0; q < nP; ++q) {
-        std::copy(pnd[q].begin(), pnd[q].end(), out.pnodes.begin() + (size_t)q * out.NDmax);
-        for (size_t l = 0; l < pel[q].size(); ++l) {
-            const int e = pel[q][l];
-            out.pelem[(size_t)q * out.EDmax + l] = (writer[e] == q) ? e : ~e;
-        }
-        std::copy(tri_l[q].begin(), tri_l[q].end(), out.ptri.begin() + (size_t)q * out.EDmax * 4);
-        for (size_t i = 0; i < fan_l[q].size(); ++i)
-            for (size_t k = 0; k < fan_l[q][i].size(); ++k)
-                out.pfan[(size_t)q * out.Wp * out.NSmax + k * out.NSmax + i] = fan_l[q][i][k];
-    }
-    return true;
-}
-
-int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
-    free_pool(h->pair_allocs);
-    h->dpch2 = DevPatches2{};
-    h->pair_ready = false;
-    const DevMesh &m = h->dm;
-    if (m.No != m.Nn) return fail(h, NXS_ERR_STATE, "multi-sub-step patches need a single-rank mesh");
-    std::vector<int> order(m.Nn);
-    for (int i = 0; i < m.Nn; ++i) order[i] = i;
-    // the caller's numbering if it has locality, else the Hilbert curve the single-ring patches were cut along
-    if (h->hp && h->hp->used_hilbert) hilbert_order(h->h_x0.data(), h->h_y0.data(), m.Nn, order);
-    HostPatches2 hp;
-    auto lds_of = [](const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 4 * (size_t)x.ESmax) * sizeof(double); };
-    int P = 0, threads = 512;
-    if (h->pair_nodes > 0) {
-        P = h->pair_nodes;
-        if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, D, order, hp)) return fail(h, NXS_ERR_INVALID, "multi-sub-step patch construction failed (pair_nodes=%d)", P);
-    } else {
-        // as upload_patches: whole rounds of resident workgroups -- j workgroups per CU at a time, j = 1 first (a small mesh
-        // is fastest with ONE workgroup on every CU: 10 km, 247 patches of 120 nodes 1.06 ms/step, 265 patches of 112 nodes
-        // 1.30)
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-        cus = std::max(cus, 1);
-        bool done = false;
-        for (int j = 1; j <= (single_round_only ? 1 : 512) && !done; ++j) {
-            P = (int)(((long long)m.Nn + (long long)j * cus - 1) / ((long long)j * cus));
-            P = std::max(32, (P + 3) & ~3);
-            if (P > 256) continue;
-            if (!build_patches2(h->h_t, h->h_ghost.data(), m.Nn, m.Ne, P, D, order, hp)) continue;
-            const size_t lds_cap = (j == 1 ? 160 : 80) * 1024;  // one workgroup per CU may take it all; otherwise two must fit
-            done = lds_of(hp) <= lds_cap && (hp.nP <= j * cus || P == 32);
-        }
-        if (!done) return fail(h, NXS_ERR_INVALID, single_round_only ? "the mesh does not fit one multi-sub-step patch per CU" : "no multi-sub-step patch size fits (node numbering without locality?)");
-    }
-    h->pair_lds = lds_of(hp);
-    if (h->pair_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "multi-sub-step patches need %zu B of LDS", h->pair_lds);
-    // 512 threads at most: a 1 024-thread workgroup runs this kernel at half the speed (10 km, D = 2: 1.98 vs 1.11 ms/step); the
-    // outer levels of a deep patch take a second round of the block instead
-    threads = hp.EDmax <= 256 ? 256 : 512;
-    h->pair_threads = threads;
-    if (getenv("NXS_DEBUG_PATCHES")) {
-        std::vector<double> se(D, 0.), sn(D + 1, 0.);
-        for (int q = 0; q < hp.nP; ++q) { for (int i = 0; i < D; ++i) se[i] += hp.ecnt[(size_t)q * D + i]; for (int i = 0; i <= D; ++i) sn[i] += hp.ncnt[(size_t)q * (D + 1) + i]; }
-        fprintf(stderr, "[nxs] multi patches: D=%d P=%d nP=%d EDmax=%d ESmax=%d NDmax=%d NSmax=%d Wp=%d lds=%zu B threads=%d; elements per level x", D, P, hp.nP, hp.EDmax, hp.ESmax,
-                hp.NDmax, hp.NSmax, hp.Wp, h->pair_lds, threads);
-        for (int i = 0; i < D; ++i) fprintf(stderr, " %.3f", se[i] / std::max(m.Ne, 1));
-        fprintf(stderr, "; nodes per level x");
-        for (int i = 0; i <= D; ++i) fprintf(stderr, " %.3f", sn[i] / std::max(m.Nn, 1));
-        fprintf(stderr, "\n");
-    }
-    DevPatches2 &d = h->dpch2;
-    d.nP = hp.nP; d.D = D; d.NDmax = hp.NDmax; d.NSmax = hp.NSmax; d.EDmax = hp.EDmax; d.ESmax = hp.ESmax; d.Wp = hp.Wp;
-    int rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.ncnt, hp.ncnt))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.ecnt, hp.ecnt))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.pnodes, hp.pnodes))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.pelem, hp.pelem))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.ptri, hp.ptri))) return rc;
-    if ((rc = dev_upload(h, h->pair_allocs, &d.pfan, hp.pfan))) return rc;
-    h->pair_ready = true;
-    h->pair_depth_built = D;
-    return NXS_OK;
-}
-
-int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
-    free_pool(h->patch_allocs);
-    DevPatches &d = h->dpch;
-    d = DevPatches{};
-    d.nP = hp.nP; d.Pmax = hp.Pmax; d.Emax = hp.Emax; d.Mmax = hp.Mmax; d.Wp = hp.Wp;
-    int rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.own_cnt, hp.own_cnt))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.elem_cnt, hp.elem_cnt))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.node_cnt, hp.node_cnt))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.pnodes, hp.pnodes))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.pelem, hp.pelem))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.ptri, hp.ptri))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &d.pfan, hp.pfan))) return rc;
-    return NXS_OK;
-}
-
-int upload_patches(nxs_dyn_handle *h) {
-    free_pool(h->patch_allocs);
-    h->dpch = DevPatches{};
-    h->fused_lds = 0;
-    const DevMesh &m = h->dm;
-    const bool automatic = h->patch_nodes <= 0;
-    HostPatches hp;
-    int P = 0;
-    auto build = [&](int PP) -> bool {
-        if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, PP, hp)) return false;
-        h->fused_lds = (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax) * sizeof(double);
-        return true;
-    };
-    if (!automatic) {
-        P = std::max(64, std::min(h->patch_nodes, 1024));
-        for (;;) {
-            if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
-            if (h->fused_lds <= 80 * 1024 || P <= 64) break;
-            P = std::max(64, P * 3 / 4);
-        }
-    } else {
-        // Large patches recompute few halo elements; the limits are the LDS of two resident workgroups per CU
-        // (160 KiB / 2) and, above all, WHOLE ROUNDS: the grid runs in rounds of `slots` resident workgroups and a
-        // last round that is partly empty costs as much as a full one.  So: the smallest number of rounds k whose
-        // patch size ceil(No / (k*slots)) fits, e.g. 730 k nodes -> 3 rounds of 512 patches of 476 nodes (not 2.79
-        // rounds of 512-node patches); 92 k nodes (one rank of eight) -> one round of 511 patches of 180 nodes.
-        int cus = 256;
-        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
-        cus = std::max(cus, 1);
-        const int slots512 = 2 * cus, slots256 = 4 * cus;  // 16 waves per CU (112 VGPRs): 2 x 512 or 4 x 256 threads
-        bool done = false;
-        for (int k = 1; k <= 64 && !done; ++k) {
-            P = (int)(((long long)m.No + (long long)k * slots512 - 1) / ((long long)k * slots512));
-            P = (P + 3) & ~3;
-            if (P > 512) continue;
-            if (P <= NXS_T256_MAXP) break;  // small mesh: the 256-thread kernel below
-            for (int it = 0; it < 4 && !done; ++it) {  // orphan patches (multi-rank) may add a few workgroups
-                if (it > 0) P += 4;
-                if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
-                if (h->fused_lds > 80 * 1024) break;            // does not fit twice: more rounds of smaller patches
-                done = hp.nP <= k * slots512;
-            }
-        }
-        if (!done) {
-            P = (int)(((long long)m.No + slots256 - 1) / slots256);
-            P = std::max(64, std::min((P + 3) & ~3, NXS_T256_MAXP));
-            if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
-        }
-    }
-    if (h->fused_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "patches need %zu B of LDS", h->fused_lds);
-    if (getenv("NXS_DEBUG_PATCHES")) {
-        long long se = 0, sm = 0;
-        for (int q = 0; q < hp.nP; ++q) { se += hp.elem_cnt[q]; sm += hp.node_cnt[q]; }
-        fprintf(stderr, "[nxs] patches: P=%d nP=%d Pmax=%d Emax=%d Mmax=%d Wp=%d avgE=%.1f avgM=%.1f lds=%zu B elems x%.3f\n", P, hp.nP, hp.Pmax,
-                hp.Emax, hp.Mmax, hp.Wp, (double)se / hp.nP, (double)sm / hp.nP, h->fused_lds, (double)se / std::max(m.Ne, 1));
-    }
-    h->hf_ready = false;
-    h->hp = std::make_shared<HostPatches>(std::move(hp));
-    return upload_host_patches(h, *h->hp);
-}
+#include "nxs_dyn_patches.inl"
 
 void ipc_release(nxs_dyn_handle *h) {
     for (void *p : h->ipc_peer_base) if (p) (void)hipIpcCloseMemHandle(p);
