@@ -1088,7 +1088,7 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
     const bool pow4 = h->dp.ers_int == 4;
 #define MULTI(TT, PP, NN) hipLaunchKernelGGL((k_substep_multi<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo)
 #define MULTI_T(TT) do { if (pow4) { if (h->nt_mask) MULTI(TT, true, 5); else MULTI(TT, true, 0); } else MULTI(TT, false, 0); } while (0)
-    if (h->pair_threads == 512) MULTI_T(512); else MULTI_T(256);
+    if (h->pair_threads == 768) MULTI_T(768); else if (h->pair_threads == 512) MULTI_T(512); else MULTI_T(256);
 #undef MULTI_T
 #undef MULTI
 }

@@ -860,6 +860,8 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
 // operations, same bits -- so the element state and the nodal inputs are read once and written once per D sub-steps and
 // the loop needs S/D launches.  The intermediate stresses stay in LDS, the intermediate velocities of the own nodes still go
 // to their ring slots: the deferred mesh move needs every sub-step's velocity.
+// The kernel takes ~170 VGPRs: a 512-thread workgroup has its CU to itself, which is the regime it is used in automatically (one
+// patch per CU); capped at 128 (two workgroups per CU, or 1 024 threads) it spills 40 of them and loses more than it gains.
 template <int T, bool POW4, int NTM>
 __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout) {
     extern __shared__ __attribute__((aligned(16))) double lds[];

@@ -296,9 +296,12 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
     }
     h->pair_lds = lds_of(hp);
     if (h->pair_lds > 160 * 1024) return fail(h, NXS_ERR_INVALID, "multi-sub-step patches need %zu B of LDS", h->pair_lds);
-    // 512 threads at most: a 1 024-thread workgroup runs this kernel at half the speed (10 km, D = 2: 1.98 vs 1.11 ms/step); the
-    // outer levels of a deep patch take a second round of the block instead
-    threads = hp.EDmax <= 256 ? 256 : 512;
+    {   // one patch per CU: 768 threads when a level does not fit 512 (10 km, D = 4: 0.98 -> 0.93 ms/step; 1 024 threads would force
+        // 128 VGPRs + 40 spilled: 1.53); several patches per CU: 512, the outer levels take a second round of the block
+        int cus = 256;
+        (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+        threads = hp.EDmax <= 256 ? 256 : (hp.EDmax <= 512 || hp.nP > cus) ? 512 : 768;
+    }
     h->pair_threads = threads;
     if (getenv("NXS_DEBUG_PATCHES")) {
         std::vector<double> se(D, 0.), sn(D + 1, 0.);
