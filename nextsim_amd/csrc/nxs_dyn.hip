@@ -105,6 +105,8 @@ struct nxs_dyn_handle {
     int nt_mask = 3;        // non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)
     size_t fused_lds = 0;
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
+    std::vector<int> h_n2n, h_n2n_cnt;     // NodalConnectivity rows [W2][Nn] + counts (for the blocked smoother's tables)
+    size_t smooth_lds = 0;
     std::vector<unsigned char> h_ghost;
     std::vector<double> h_x0, h_y0;
     std::vector<void *> patch_allocs;
@@ -592,6 +594,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
         if ((rc = dev_upload(h, h->mesh_allocs, &d.n2e, n2e))) return rc;
         if ((rc = dev_upload(h, h->mesh_allocs, &d.n2n, n2n))) return rc;
         if ((rc = dev_upload(h, h->mesh_allocs, &d.n2n_cnt, cnt))) return rc;
+        h->h_n2n = std::move(n2n); h->h_n2n_cnt = std::move(cnt);
     }
 
     // state + work arrays
@@ -1345,6 +1348,19 @@ int explicit_solve(nxs_dyn_handle *h) {
     auto smooth_and_tail = [&]() -> int {
         double *a = h->ds.VT, *b = h->ds.VT2;
         LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
+        if (!multi_rank(h) && h->pair_ready && !h->pair_failed && h->dpch2.pnbr && h->fused >= 2) {
+            // the patches of k_substep_multi carry D rings: D sweeps per launch (see k_smooth_multi)
+            const int D = h->dpch2.D, L = (50 + D - 1) / D;
+            if (L & 1) std::swap(a, b);  // the buffers are equal now; end in ds.VT after L swaps
+            for (int nit = 0; nit < 50; nit += D) {
+                const int ks = std::min(D, 50 - nit);
+                if (h->pair_threads >= 512) hipLaunchKernelGGL((k_smooth_multi<512>), dim3(h->dpch2.nP), dim3(512), h->smooth_lds, h->stream, m, h->dpch2, h->dw, (const double *)a, b, ks);
+                else hipLaunchKernelGGL((k_smooth_multi<256>), dim3(h->dpch2.nP), dim3(256), h->smooth_lds, h->stream, m, h->dpch2, h->dw, (const double *)a, b, ks);
+                std::swap(a, b);
+            }
+            LAUNCH(h, k_ow_tail, m.Nn, m, h->ds, h->dw, h->dp);
+            return NXS_OK;
+        }
         const bool halo_in_kernel = multi_rank(h) && h->ipc_ready && !h->halo_fn && h->halo_fused && h->hf_ready && m.No > 0;
         for (int nit = 0; nit < 50; ++nit) {
             if (halo_in_kernel) {  // updateGhosts inside the sweep; the ghosts land in the array once, after the last sweep

@@ -83,6 +83,8 @@ struct DevPatches2 {
     const int *pelem;             // [nP][EDmax] global element id; ~id when this patch does not write it
     const unsigned short *ptri;   // [nP][EDmax][4] patch-local node slots of the 3 corners (+ pad)
     const unsigned short *pfan;   // [nP][Wp][NSmax] fan of every solved node, ascending element id: (element slot << 3 | ghost << 2 | corner)
+    const unsigned short *pnbr;   // [nP][W2][NSmax] NodalConnectivity row of every node of N_(D-1) in patch-local slots, bamg order (Q8), 0xFFFF pad;
+    int W2;                       //                 NULL when a row leaves its patch (then the smoother runs sweep by sweep)
 };
 struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
 
@@ -1302,6 +1304,55 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
         __hip_atomic_store(hf.done_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *hf.ipc.seq_push = xseq + 1ull;
     }
+}
+
+// KS Jacobi sweeps of the open-water smoother in one launch, on the patches of k_substep_multi: sweep j recomputes the ice-free
+// nodes of N_(KS-j-1) from their neighbours in N_(KS-j) -- the rings redo what the neighbouring patches do, same operations in
+// the same (bamg row) order, same bits as KS launches of k_smooth -- and only the own nodes are written back.  A patch without an
+// ice-free own node has nothing to write and returns at once: with no open water the 50 sweeps cost 13 empty launches instead of 50.
+template <int T>
+__global__ void __launch_bounds__(T) k_smooth_multi(DevMesh m, DevPatches2 pp, DevWork w, const double *__restrict__ src, double *__restrict__ dst, int KS) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int NDm = pp.NDmax, D = pp.D, Nn = m.Nn, t = threadIdx.x, blk = blockIdx.x;
+    double *au = lds, *av = au + NDm, *bu = av + NDm, *bv = bu + NDm;
+    unsigned char *open = reinterpret_cast<unsigned char *>(bv + NDm);  // [NSmax]
+    const int *ncnt = pp.ncnt + (size_t)blk * (D + 1);
+    const int *pn = pp.pnodes + (size_t)blk * NDm;
+    const unsigned short *nb = pp.pnbr + (size_t)blk * pp.W2 * pp.NSmax;
+    const int nO = ncnt[0], nS = ncnt[KS - 1], nK = ncnt[KS];
+    int any = 0;
+    for (int i = t; i < nS; i += T) {
+        const int g = pn[i];
+        const unsigned char o = !((m.nflags[g] & NF_DIRICHLET) || w.node_mass[g] != 0.);  // k_smooth's test, FE.cpp:10589
+        open[i] = o;
+        any |= (o && i < nO);
+    }
+    if (!__syncthreads_or(any)) return;  // (also publishes open[])
+    for (int i = t; i < nK; i += T) { const int g = pn[i]; au[i] = src[g]; av[i] = src[g + Nn]; }
+    __syncthreads();
+    for (int j = 0; j < KS; ++j) {
+        const int nn = ncnt[KS - 1 - j];
+        for (int i = t; i < nn; i += T) {
+            double u = au[i], v = av[i];
+            if (open[i]) {
+                const int num_neighbours = m.n2n_cnt[pn[i]];
+                u = 0.; v = 0.;
+                for (int k = 0; k < num_neighbours; ++k) {  // Q8: bamg row order
+                    const int sl = nb[(size_t)k * pp.NSmax + i];
+                    u += au[sl];
+                    v += av[sl];
+                }
+                u /= num_neighbours;
+                v /= num_neighbours;
+            }
+            bu[i] = u; bv[i] = v;
+        }
+        __syncthreads();
+        double *x = au; au = bu; bu = x;
+        x = av; av = bv; bv = x;
+    }
+    for (int i = t; i < nO; i += T)
+        if (open[i]) { const int g = pn[i]; dst[g] = au[i]; dst[g + Nn] = av[i]; }
 }
 
 __global__ void __launch_bounds__(BLOCK) k_copy_vt(int n2, const double *__restrict__ src, double *__restrict__ dst) {

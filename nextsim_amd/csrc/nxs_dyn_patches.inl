@@ -322,6 +322,28 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
     if ((rc = dev_upload(h, h->pair_allocs, &d.pelem, hp.pelem))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.ptri, hp.ptri))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.pfan, hp.pfan))) return rc;
+    {   // NodalConnectivity rows in patch-local slots, for D smoother sweeps per launch (k_smooth_multi)
+        const int W2 = m.W2, Nn = m.Nn;
+        std::vector<unsigned short> pnbr((size_t)hp.nP * W2 * hp.NSmax, 0xFFFF);
+        std::vector<int> slot_of(Nn, -1);
+        bool closed = (int)h->h_n2n_cnt.size() == Nn && h->h_n2n.size() == (size_t)W2 * Nn;
+        for (int q = 0; q < hp.nP && closed; ++q) {
+            const int *nd = hp.pnodes.data() + (size_t)q * hp.NDmax;
+            const int nS = hp.ncnt[(size_t)q * (D + 1) + D - 1], nD = hp.ncnt[(size_t)q * (D + 1) + D];
+            for (int i = 0; i < nD; ++i) slot_of[nd[i]] = i;
+            for (int i = 0; i < nS && closed; ++i)
+                for (int k = 0; k < h->h_n2n_cnt[nd[i]]; ++k) {
+                    const int sl = slot_of[h->h_n2n[(size_t)k * Nn + nd[i]]];
+                    if (sl < 0) { closed = false; break; }  // a caller-supplied row that reaches beyond the node's elements
+                    pnbr[((size_t)q * W2 + k) * hp.NSmax + i] = (unsigned short)sl;
+                }
+            for (int i = 0; i < nD; ++i) slot_of[nd[i]] = -1;
+        }
+        d.W2 = W2;
+        d.pnbr = nullptr;
+        if (closed && (rc = dev_upload(h, h->pair_allocs, &d.pnbr, pnbr))) return rc;
+        h->smooth_lds = 4 * (size_t)hp.NDmax * sizeof(double) + (size_t)hp.NSmax;
+    }
     h->pair_ready = true;
     h->pair_depth_built = D;
     return NXS_OK;
