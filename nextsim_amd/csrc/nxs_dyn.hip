@@ -1245,7 +1245,10 @@ int run_substeps(nxs_dyn_handle *h) {
     }
     const bool pair = D >= 2;
     int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
-    if (pair) K = std::max(D, K - K % D);  // the ring is flushed between launches
+    if (pair) {  // the ring is flushed between launches; by default once per step (a flush per launch costs 30 small launches at 10 km: 66 us of 0.88 ms)
+        if (h->um_ring <= 0) K = std::min(S, NXS_MAX_RING - 1);
+        K = std::max(D, K - K % D);
+    }
     const bool deferred = K > 1;
     if (fused) { int rc = setup_ring(h, K); if (rc) return rc; }
     const int R = h->ring.R;
