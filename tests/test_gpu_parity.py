@@ -406,6 +406,30 @@ def test_automatic_choice_of_the_sub_step_kernel():
     a.close(); b.close(); c.close()
 
 
+@pytest.mark.parametrize("kind,nsteps", [("toy", 100), ("10km", 60)])
+def test_long_free_run_default_kernels_equal_one_sub_step_per_launch_bit_for_bit(kind, nsteps):
+    """A long free run (the mesh moves, damage localises, the toy case has an open-water strip for the smoother): the default
+    kernels of a small single-rank mesh (four sub-steps and four smoother sweeps per launch, one ring flush per step) against the
+    one-sub-step-per-launch kernels -- every prognostic array bit for bit after the last step."""
+    from nextsim_amd import dynamics
+    gm, p, g, lms, fields = cases.make_case(kind)
+    lm, f = lms[0], fields[0]
+    out = []
+    for fused in (3, 1):
+        fe = dynamics.FiniteElementDynamics(p)
+        fe.set_option("fused", fused)
+        fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+        for _ in range(nsteps):
+            fe.step()
+        fe.synchronize()
+        assert fe.timing()["substep_launches"] == (30 if fused == 3 else 120)
+        out.append(fe.get_state())
+        fe.close()
+    for k in STATE_KEYS:
+        assert np.array_equal(out[0][k], out[1][k]), k
+    assert np.abs(out[0]["UM"]).max() > 0 and out[0]["damage"].max() > 0
+
+
 def test_full_size_2km_several_sub_steps_per_launch_agree_bit_for_bit():
     from nextsim_amd import dynamics
     gm, p, g, lms, fields = cases.make_case("2km")
