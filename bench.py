@@ -214,6 +214,29 @@ def setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn):
     return "host-staged (gloo)"
 
 
+def aux_spmv(gm, reps=100):
+    """include/nxs_krylov.h on the bench mesh: sliced-ELLPACK SpMV, algorithmic bytes 12 B per non-zero + 16 B per row."""
+    import numpy as np
+    import scipy.sparse as sp
+    from nextsim_amd import krylov
+    rp, ci = krylov.csr_pattern((gm.tri + 1).astype(np.int32), gm.num_nodes)
+    rng = np.random.default_rng(0)
+    va = rng.normal(size=ci.size)
+    va[ci == np.repeat(np.arange(gm.num_nodes), np.diff(rp))] = 10.0
+    A = sp.kron(sp.csr_matrix((va, ci, rp), shape=(gm.num_nodes,) * 2), sp.csr_matrix(np.array([[1.0, 0.3], [-0.3, 1.0]])), format="csr")
+    A.sort_indices()
+    s = krylov.Solver()
+    s.set_matrix(A.indptr, A.indices, A.data)
+    x = rng.normal(size=A.shape[0])
+    y, ms = s.spmv(x, reps=reps)
+    inf = s.info()
+    s.close()
+    ok = bool(np.abs(y - A @ x).max() <= 1e-11 * np.abs(y).max())
+    return {"workload": f"SpMV, 2-dof (u, v) block pattern of the mesh: {A.shape[0]} rows, {inf['nnz']} non-zeros (extension, no live reference)",
+            "us_per_spmv": ms * 1e3, "achieved": inf["spmv_bytes"] / ms / 1e6, "unit": "GB/s", "peak": 8000.0,
+            "frac": inf["spmv_bytes"] / ms / 1e6 / 8000.0, "matches_scipy": ok}
+
+
 def cpu_baseline(kind, nsteps=1):
     """The restated reference CPU path (oracle/dyn_ref.c, -O3 -march=native) on the same mesh and forcing.
     (i) one core, the serial loops; (ii) all host cores this process may use: one mesh partition per core
@@ -359,6 +382,11 @@ def main():
             "value": r2["gm"].num_elements * S * aux_args.steps / r2["dt"], "unit": "element-updates/s",
             "ms_per_step": r2["dt"] / aux_args.steps * 1e3,
         }
+    if world == 1 and not args.no_aux and args.mesh == "2km":
+        try:   # the N4 extension (no live reference): SpMV of the 2-dof block pattern a momentum matrix would have on this mesh
+            out["aux_spmv"] = aux_spmv(res["gm"])
+        except Exception as e:  # noqa: BLE001 -- never lose the main line over the extension
+            out["aux_spmv"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
