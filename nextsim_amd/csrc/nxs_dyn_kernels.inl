@@ -346,10 +346,15 @@ __device__ __forceinline__ void bbm_stress(const DevParams &p, const double dxN[
     }
     const double multiplicator = STD_MIN(1. - 1e-12, time_viscous / (time_viscous + dt * (1. - tildeP)));  // Q3
     const double elasticity = p.young * (1. - damage) * expC;                    // FE.cpp:4202
+    // M_Dunit (FE.cpp:1491-1507) is [[a, b, 0], [b, a, 0], [0, 0, c]] by construction (nxs_dyn.hip fills p.D the same way): three
+    // uniform values instead of nine keep 12 SGPRs out of the hot loop, whose scalar registers spill into VGPR lanes; the zero
+    // entries stay in the sums as literal zeros, so every product and addition of the reference's triple loop is still performed
+    const double Da = p.D[0], Db = p.D[1], Dc = p.D[8];
+    const double Dm[9] = {Da, Db, 0., Db, Da, 0., 0., 0., Dc};
 #pragma unroll
     for (int i = 0; i < 3; ++i) {                                                // FE.cpp:4204-4210
 #pragma unroll
-        for (int j = 0; j < 3; ++j) sig[i] += dt * elasticity * p.D[3 * i + j] * eps[j];
+        for (int j = 0; j < 3; ++j) sig[i] += dt * elasticity * Dm[3 * i + j] * eps[j];
         sig[i] *= multiplicator;
     }
     const double sigma_s = hypot((sig[0] - sig[1]) / 2., sig[2]);                // FE.cpp:4218
