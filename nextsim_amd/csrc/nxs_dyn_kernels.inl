@@ -880,6 +880,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
         blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
     }
     const int t = threadIdx.x, Nn = m.Nn;
+    NXS_STAMP(0);
     const int *ncnt = pp.ncnt + (size_t)blk * (D + 1), *ecnt = pp.ecnt + (size_t)blk * D;
     const int nO = ncnt[0], nD = ncnt[D];
     const int *pn = pp.pnodes + (size_t)blk * NDm;
@@ -1013,7 +1014,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
             if (base > 0 && active) { eraw = pe[l]; tr = pt[l]; }
             ElemIn in{};
             if (active) in = load_element(eraw, first, last);
-            if (base == 0) __syncthreads();  // k == 0: staged velocities / coordinates; k > 0: the velocities of sub-step k on N_(D-k), forces consumed
+            if (base == 0) { __syncthreads(); if (k == 0) NXS_STAMP(1); }  // k == 0: staged velocities / coordinates; k > 0: the velocities of sub-step k on N_(D-k), forces consumed
             if (active) compute_element(l, tr, in, first, last, keep);
         }
         // ---- nodes N_(D-k-1)
@@ -1024,7 +1025,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
             const int n = active ? ((base == 0) ? my_node : pn[i]) : 0;
             NodeIn in{};
             if (active) in = load_node(i, n);
-            if (base == 0) __syncthreads();  // corner forces of this sub-step visible
+            if (base == 0) { __syncthreads(); if (k == 0) NXS_STAMP(2); }  // corner forces of this sub-step visible
             if (active) {
                 double u1, v1;
                 solve_node(i, in, u1, v1);
@@ -1032,6 +1033,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
                 lu[i] = u1; lv[i] = v1;  // a node's solve reads only its own staged velocity: in place
             }
         }
+        if (k < 4) NXS_STAMP(3 + k);
     }
 }
 

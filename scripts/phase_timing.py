@@ -5,7 +5,7 @@
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.)
+ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true")
 a = ap.parse_args()
 csrc = os.path.join(ROOT, "nextsim_amd", "csrc")
 if a.build:
@@ -24,6 +24,14 @@ fe = dynamics.FiniteElementDynamics(p); fe.set_option("graph", 0)
 fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
 fe.step(); fe.step(); fe.synchronize()
 t = fe.debug_array("phase_times")
+if a.multi:  # k_substep_multi (small single-rank meshes), D = 4: start, barrier 1, forces of sub-step 0, end of sub-steps 0..3
+    t = t.reshape(8192, 8)[:, :7]
+    t = t[t[:, 0] > 0]
+    d = np.diff(t, axis=1) * 10e-3
+    print(f"{gm.num_elements} triangles, {t.shape[0]} workgroups; kernel span {(t[:, 6].max() - t[:, 0].min()) * 10e-3:.2f} us")
+    for nm, col in zip(("staging (to barrier 1)", "elements of sub-step 0 (to barrier 2)", "nodes of sub-step 0", "sub-step 1", "sub-step 2", "sub-step 3"), d.T):
+        print(f"  {nm:38s} mean {col.mean():6.2f} us   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
+    fe.close(); sys.exit(0)
 t = t.reshape(8192, 8)[:, :5]
 t = t[t[:, 0] > 0]
 k0 = t[:, 0].min()
