@@ -91,6 +91,7 @@ struct nxs_dyn_handle {
     int pair_nodes = 0;     // v3: own nodes per patch; 0 = auto
     int pair_depth = 0;     // v3: sub-steps per launch, 2..NXS_MAX_DEPTH; 0 = auto
     int pair_depth_built = 0;
+    int depth_now = 1;      // sub-steps per launch of the current step (choose_depth)
     bool pair_failed = false;   // the D-ring patches could not be built for this mesh: v2 instead
     DevPatches2 dpch2{};
     size_t pair_lds = 0;
@@ -395,6 +396,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
+    h->dw.erec = nullptr; h->dw.nrec = nullptr;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -491,6 +493,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
+    h->dw.erec = nullptr; h->dw.nrec = nullptr;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -1214,6 +1217,25 @@ void launch_substep(nxs_dyn_handle *h, double move_dt) {
     LAUNCH(h, k_solve_move, h->dm.No, h->dm, h->ds, h->dw, h->dp, move_dt);
 }
 
+// sub-steps per launch of this step (1 = the v2 / v1 kernels); builds the D-ring patches when they are needed
+int choose_depth(nxs_dyn_handle *h) {
+    const int S = h->dp.substeps;
+    const double move_dt = (h->dp.dynamics_type == NXS_DYN_MEVP) ? 0. : h->dp.dte;
+    int D = 1;
+    // Automatic (fused == 3): only where ONE round of one patch per CU covers the mesh (<= 256 own nodes per patch: 65 k nodes, 130 k
+    // triangles on 256 CUs) -- 111 k triangles: 1.47 (v2) -> 0.97 ms/step; 182 k triangles, two patches per CU: 1.65 -> 1.90-2.31.
+    if ((h->fused == 2 || (h->fused == 3 && (long long)h->dm.Nn <= 256ll * 1024)) && !multi_rank(h) && move_dt != 0. && S >= 2 && !h->pair_failed) {
+        D = std::min(h->pair_depth > 0 ? h->pair_depth : 4, std::min(S, NXS_MAX_DEPTH));
+        while (D > 1 && S % D != 0) --D;
+        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D, h->fused == 3) != NXS_OK) {
+            h->pair_failed = true;  // no patch size fits (a numbering without any locality, huge fans): one sub-step per launch
+            D = 1;
+        }
+    }
+    h->depth_now = D;
+    return D;
+}
+
 int run_substeps(nxs_dyn_handle *h) {
     const int S = h->dp.substeps;
     const double move_dt = (h->dp.dynamics_type == NXS_DYN_MEVP) ? 0. : h->dp.dte;
@@ -1232,17 +1254,7 @@ int run_substeps(nxs_dyn_handle *h) {
     // runs at 5.5 TB/s with its VALUs half busy (2 km, D = 2: 7.4 -> 8.0).
     // D sub-steps per launch: the requested depth, else (auto) 4 (10 km: D = 2 / 3 / 4 / 5 / 6 / 8: 1.11 / 1.01 / 0.97 / 0.96 / 0.98 / 1.08 ms/step; the
     // rings grow the arithmetic by x2.0 per sub-step at D = 4) -- lowered until it divides the number of sub-steps
-    int D = 1;
-    // Automatic (fused == 3): only where ONE round of one patch per CU covers the mesh (<= 256 own nodes per patch: 65 k nodes, 130 k
-    // triangles on 256 CUs) -- 111 k triangles: 1.47 (v2) -> 1.21 ms/step; 182 k triangles, two patches per CU: 1.65 -> 1.90-2.31.
-    if ((h->fused == 2 || (h->fused == 3 && (long long)h->dm.Nn <= 256ll * 1024)) && !mr && move_dt != 0. && S >= 2 && !h->pair_failed) {
-        D = std::min(h->pair_depth > 0 ? h->pair_depth : 4, std::min(S, NXS_MAX_DEPTH));
-        while (D > 1 && S % D != 0) --D;
-        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D, h->fused == 3) != NXS_OK) {
-            h->pair_failed = true;  // no patch size fits (a numbering without any locality, huge fans): one sub-step per launch
-            D = 1;
-        }
-    }
+    const int D = h->depth_now;  // decided by choose_depth() before the prep kernels (they fill the records the multi kernel reads)
     const bool pair = D >= 2;
     int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
     if (pair) {  // the ring is flushed between launches; by default once per step (a flush per launch costs 30 small launches at 10 km: 66 us of 0.88 ms)
@@ -1338,6 +1350,7 @@ int explicit_solve(nxs_dyn_handle *h) {
     // FE.cpp:10182-10643
     const DevMesh &m = h->dm;
     if (timed) HIPCHK(h, hipEventRecord(h->cur[0], h->stream));
+    (void)choose_depth(h);
     LAUNCH(h, k_prep_elements, m.Ne, m, h->ds, h->dw, h->dp);
     LAUNCH(h, k_prep_nodes, m.Nn, m, h->ds, h->dw, h->dp);
     if (timed) HIPCHK(h, hipEventRecord(h->cur[1], h->stream));

@@ -100,6 +100,8 @@ struct DevWork {
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
     unsigned char *open_blk;                     // [ceil(Nn/BLOCK)] != 0: the block of BLOCK nodes holds a node the open-water smoother changes (zeroed by k_prep_elements, set by k_prep_nodes)
     int *dxi;                                    // BBM, fused kernel: M_delta_x as the integer it is (Q1), ~M_delta_x when the element is skipped
+    double *erec;                                // [Ne][6] or NULL: (expC, volume, pmax, heal, cohesion, {dxi, eskip}) -- the multi kernel's element constants as one record
+    double *nrec;                                // [Nn][10] or NULL: (node_mass, grad_ssh u, v, rlmass, C_bu, fcor, D_tau_a u, v, ocean u, v)
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
     double *xs, *ys;  // [Nn] node coordinates on the displaced mesh at step start (frozen over the sub-steps, Q4)
@@ -234,6 +236,13 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
         w.eskip[e] = (thick == 0.) ? 1 : 0;                                    // FE.cpp:10656
     }
     w.volume[e] = thick * surface;                                             // FE.cpp:10450
+    if (w.erec) {  // the same values once more, as one record (k_substep_multi)
+        const bool bbm = p.dynamics_type == NXS_DYN_BBM;
+        double *r = w.erec + 6 * (size_t)e;
+        r[0] = w.expC[e]; r[1] = thick * surface; r[2] = bbm ? w.pmax[e] : 0.; r[3] = bbm ? w.heal[e] : 0.; r[4] = s.cohesion[e];
+        int *ri = reinterpret_cast<int *>(r + 5);
+        ri[0] = bbm ? w.dxi[e] : 0; ri[1] = w.eskip[e];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -296,6 +305,11 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
 
     w.VTM[n] = vu;
     w.VTM[n + Nn] = vv;
+    if (w.nrec) {  // the nodal inputs of the sub-step solve once more, as one record (k_substep_multi)
+        double *r = w.nrec + 10 * (size_t)n;
+        r[0] = nm; r[1] = gu; r[2] = gv; r[3] = rl; r[4] = cb; r[5] = w.fcor[n]; r[6] = w.D_tau_a[n]; r[7] = w.D_tau_a[n + Nn];
+        r[8] = s.ocean[n]; r[9] = s.ocean[n + Nn];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -905,24 +919,27 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     // between them sits in uniform control flow.  first sub-step of the launch: state from HBM; last: result to HBM (if this
     // patch writes the element); in between the state lives in LDS
     struct ElemIn { int e; bool writer, skip; int dxi; double sig[3], damage, expC, volume, pmax, heal, coh; };
+    typedef double d2 __attribute__((ext_vector_type(2)));
     auto load_element = [&](const int eraw, const bool first, const bool last) {
         ElemIn in;
         in.writer = eraw >= 0;
         in.e = in.writer ? eraw : ~eraw;
         const int e = in.e;
-        in.skip = true; in.dxi = 0; in.damage = 0.; in.pmax = 0.; in.heal = 0.; in.coh = 0.; in.sig[0] = in.sig[1] = in.sig[2] = 0.;
-        if (!bbm) in.skip = w.eskip[e];
+        in.damage = 0.; in.sig[0] = in.sig[1] = in.sig[2] = 0.;
         if (first) {
             in.sig[0] = ldg<NT_S>(b.s0c + e); in.sig[1] = ldg<NT_S>(b.s1c + e); in.sig[2] = ldg<NT_S>(b.s2c + e);
             if (bbm) in.damage = ldg<NT_S>(b.dc + e);
         }
-        // the element constants are read by every sub-step of the launch: the later reads hit the L2
-        in.expC = last ? ldg<NT_C>(w.expC + e) : w.expC[e];
-        in.volume = last ? ldg<NT_C>(w.volume + e) : w.volume[e];
-        if (bbm) {
-            in.pmax = last ? ldg<NT_C>(w.pmax + e) : w.pmax[e]; in.heal = last ? ldg<NT_C>(w.heal + e) : w.heal[e];
-            in.dxi = w.dxi[e]; in.coh = last ? ldg<NT_C>(s.cohesion + e) : s.cohesion[e];
-        }
+        // the element constants: one 48-byte record (k_prep_elements), read by every sub-step of the launch -- the later reads hit
+        // the L2, the last one is the streaming one
+        const d2 *r = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
+        d2 r0, r1, r2;
+        if (last && NT_C) { r0 = __builtin_nontemporal_load(r); r1 = __builtin_nontemporal_load(r + 1); r2 = __builtin_nontemporal_load(r + 2); }
+        else { r0 = r[0]; r1 = r[1]; r2 = r[2]; }
+        in.expC = r0.x; in.volume = r0.y; in.pmax = r1.x; in.heal = r1.y; in.coh = r2.x;
+        const long long pk = __double_as_longlong(r2.y);
+        in.dxi = (int)(pk & 0xffffffffll);
+        in.skip = bbm ? true : (int)(pk >> 32) != 0;
         return in;
     };
     auto compute_element = [&](const int l, const ushort4 tr, ElemIn &in, const bool first, const bool last, const int keep) {
@@ -969,11 +986,10 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     auto load_node = [&](const int i, const int n) {
         NodeIn in;
         in.nf = m.nflags[n];
-        in.node_mass = w.node_mass[n];
-        in.gx = w.grad_ssh[n]; in.gy = w.grad_ssh[n + Nn];
-        in.rlm = w.rlmass[n]; in.cbu = w.C_bu[n]; in.fcor = w.fcor[n];
-        in.tax = w.D_tau_a[n]; in.tay = w.D_tau_a[n + Nn];
-        in.ou = s.ocean[n]; in.ov = s.ocean[n + Nn];
+        const d2 *r = reinterpret_cast<const d2 *>(w.nrec) + 5 * (size_t)n;  // one 80-byte record (k_prep_nodes)
+        const d2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+        in.node_mass = r0.x; in.gx = r0.y; in.gy = r1.x; in.rlm = r1.y; in.cbu = r2.x; in.fcor = r2.y;
+        in.tax = r3.x; in.tay = r3.y; in.ou = r4.x; in.ov = r4.y;
 #pragma unroll
         for (int k = 0; k < 8; ++k) in.fan[k] = (k < pp.Wp) ? pf[(size_t)k * pp.NSmax + i] : (unsigned short)0xFFFFu;
         return in;
