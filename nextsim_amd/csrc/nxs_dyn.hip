@@ -396,7 +396,6 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
-    h->dw.erec = nullptr; h->dw.nrec = nullptr;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -493,7 +492,6 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
-    h->dw.erec = nullptr; h->dw.nrec = nullptr;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -615,7 +613,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
     A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 10 * ne);
-    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn));
+    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn)); A(w.erec, 6 * ne); A(w.nrec, 10 * (size_t)Nn);
     A(w.force, 6 * ne);
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
     A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.xs, (size_t)Nn); A(w.ys, (size_t)Nn); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);

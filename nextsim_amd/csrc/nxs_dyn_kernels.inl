@@ -100,8 +100,8 @@ struct DevWork {
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
     unsigned char *open_blk;                     // [ceil(Nn/BLOCK)] != 0: the block of BLOCK nodes holds a node the open-water smoother changes (zeroed by k_prep_elements, set by k_prep_nodes)
     int *dxi;                                    // BBM, fused kernel: M_delta_x as the integer it is (Q1), ~M_delta_x when the element is skipped
-    double *erec;                                // [Ne][6] or NULL: (expC, volume, pmax, heal, cohesion, {dxi, eskip}) -- the multi kernel's element constants as one record
-    double *nrec;                                // [Nn][10] or NULL: (node_mass, grad_ssh u, v, rlmass, C_bu, fcor, D_tau_a u, v, ocean u, v)
+    double *erec;                                // [Ne][6]: (expC, volume, pmax, heal, cohesion, {dxi, eskip}) -- the fused kernels' per-step element constants as one record
+    double *nrec;                                // [Nn][10]: (node_mass, grad_ssh u, v, rlmass, C_bu, fcor, D_tau_a u, v, ocean u, v) -- their nodal inputs
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
     double *xs, *ys;  // [Nn] node coordinates on the displaced mesh at step start (frozen over the sub-steps, Q4)
@@ -223,25 +223,39 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
     // Per-step constants of the sub-step loop.  M_conc, M_thick, M_delta_x, M_surface do not change
     // while sub-cycling (Q4), so exp/pow of them are evaluated once here instead of S times; the
     // expressions are the reference's, operand for operand.
+    double c_expC, c_pmax = 0., c_heal = 0.;
+    int c_dxi = 0, c_skip;
     if (p.dynamics_type == NXS_DYN_BBM) {
-        const double expC = exp(p.compaction_param * (1. - conc));             // FE.cpp:4185
-        w.expC[e] = expC;
-        w.pmax[e] = pow(thick, p.ecf) * p.compression_factor * expC;          // FE.cpp:4192
-        w.heal[e] = p.dte / s.theal[e] * expC;                                 // FE.cpp:4257
+        c_expC = exp(p.compaction_param * (1. - conc));                        // FE.cpp:4185
+        c_pmax = pow(thick, p.ecf) * p.compression_factor * c_expC;            // FE.cpp:4192
+        c_heal = p.dte / s.theal[e] * c_expC;                                  // FE.cpp:4257
+        c_skip = (conc <= 0.1) ? 1 : 0;                                        // Q5, FE.cpp:4146-4151
+        c_dxi = (conc <= 0.1) ? ~acc_div3 : acc_div3;                          // M_delta_x as the integer it is (Q1), 4 bytes instead of 9
+        w.expC[e] = c_expC; w.pmax[e] = c_pmax; w.heal[e] = c_heal;
         w.dxs[e] = delta_x * p.sqrt_nu_rhoi;                                   // FE.cpp:4232
-        w.eskip[e] = (conc <= 0.1) ? 1 : 0;                                    // Q5, FE.cpp:4146-4151
-        w.dxi[e] = (conc <= 0.1) ? ~acc_div3 : acc_div3;                       // 4 bytes instead of 9 for the fused kernel
+        w.eskip[e] = (unsigned char)c_skip;
+        w.dxi[e] = c_dxi;
     } else {
-        w.expC[e] = p.evp_Pstar * exp(-p.evp_C * (1. - conc));                 // FE.cpp:10684 (P)
-        w.eskip[e] = (thick == 0.) ? 1 : 0;                                    // FE.cpp:10656
+        c_expC = p.evp_Pstar * exp(-p.evp_C * (1. - conc));                    // FE.cpp:10684 (P)
+        c_skip = (thick == 0.) ? 1 : 0;                                        // FE.cpp:10656
+        w.expC[e] = c_expC;
+        w.eskip[e] = (unsigned char)c_skip;
     }
-    w.volume[e] = thick * surface;                                             // FE.cpp:10450
-    if (w.erec) {  // the same values once more, as one record (k_substep_multi)
-        const bool bbm = p.dynamics_type == NXS_DYN_BBM;
-        double *r = w.erec + 6 * (size_t)e;
-        r[0] = w.expC[e]; r[1] = thick * surface; r[2] = bbm ? w.pmax[e] : 0.; r[3] = bbm ? w.heal[e] : 0.; r[4] = s.cohesion[e];
-        int *ri = reinterpret_cast<int *>(r + 5);
-        ri[0] = bbm ? w.dxi[e] : 0; ri[1] = w.eskip[e];
+    const double c_vol = thick * surface;                                      // FE.cpp:10450
+    w.volume[e] = c_vol;
+    // the same constants once more as one 48-byte record per element -- what the fused sub-step kernels read (one base pointer and
+    // three 16-byte loads instead of six arrays) -- staged through LDS like the records above, so that they leave as one stream
+    __syncthreads();
+    {
+        double *r = rec + 6 * threadIdx.x;
+        r[0] = c_expC; r[1] = c_vol; r[2] = c_pmax; r[3] = c_heal; r[4] = s.cohesion[e];
+        r[5] = __longlong_as_double(((long long)c_skip << 32) | (long long)(unsigned int)c_dxi);
+    }
+    __syncthreads();
+    {
+        const size_t base = (size_t)blockIdx.x * BLOCK * 6;
+        const int count = min(BLOCK, m.Ne - (int)blockIdx.x * BLOCK) * 6;
+        for (int i = threadIdx.x; i < count; i += BLOCK) w.erec[base + i] = rec[i];
     }
 }
 
@@ -305,10 +319,11 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
 
     w.VTM[n] = vu;
     w.VTM[n + Nn] = vv;
-    if (w.nrec) {  // the nodal inputs of the sub-step solve once more, as one record (k_substep_multi)
-        double *r = w.nrec + 10 * (size_t)n;
-        r[0] = nm; r[1] = gu; r[2] = gv; r[3] = rl; r[4] = cb; r[5] = w.fcor[n]; r[6] = w.D_tau_a[n]; r[7] = w.D_tau_a[n + Nn];
-        r[8] = s.ocean[n]; r[9] = s.ocean[n + Nn];
+    {   // the nodal inputs of the sub-step solve once more, as one 80-byte record per node (what the fused sub-step kernels read)
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2 *r = reinterpret_cast<d2 *>(w.nrec) + 5 * (size_t)n;
+        r[0] = d2{nm, gu}; r[1] = d2{gv, rl}; r[2] = d2{cb, w.fcor[n]}; r[3] = d2{w.D_tau_a[n], w.D_tau_a[n + Nn]};
+        r[4] = d2{s.ocean[n], s.ocean[n + Nn]};
     }
 }
 
@@ -735,10 +750,14 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             if (!bbm) skip = w.eskip[e];
             sig[0] = ldg<NT_S>(b.s0c + e); sig[1] = ldg<NT_S>(b.s1c + e); sig[2] = ldg<NT_S>(b.s2c + e);
             if (bbm) damage = ldg<NT_S>(b.dc + e);
-            c_expC = ldg<NT_C>(w.expC + e);
-            volume = ldg<NT_C>(w.volume + e);
-            if (bbm) {
-                c_pmax = ldg<NT_C>(w.pmax + e); c_heal = ldg<NT_C>(w.heal + e); dxi = w.dxi[e]; c_coh = ldg<NT_C>(s.cohesion + e);
+            {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                const d2 *r = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
+                d2 r0, r1, r2;
+                if (NT_C) { r0 = __builtin_nontemporal_load(r); r1 = __builtin_nontemporal_load(r + 1); r2 = __builtin_nontemporal_load(r + 2); }
+                else { r0 = r[0]; r1 = r[1]; r2 = r[2]; }
+                c_expC = r0.x; volume = r0.y; c_pmax = r1.x; c_heal = r1.y; c_coh = r2.x;
+                dxi = (int)(__double_as_longlong(r2.y) & 0xffffffffll);
             }
         }
         if (base == 0) { __syncthreads(); NXS_STAMP(1); }  // staged velocities / coordinates visible
@@ -795,11 +814,13 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         int sq0 = 0, sq1 = 0;
         if (active) {
             nf = m.nflags[n];
-            node_mass = w.node_mass[n];
-            gx = w.grad_ssh[n]; gy = w.grad_ssh[n + Nn];
-            rlm = w.rlmass[n]; cbu = w.C_bu[n]; fcor = w.fcor[n]; lat = (nf & NF_LAT_NEG) ? -1. : 1.;
-            tax = w.D_tau_a[n]; tay = w.D_tau_a[n + Nn];
-            ou = s.ocean[n]; ov = s.ocean[n + Nn];
+            {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                const d2 *r = reinterpret_cast<const d2 *>(w.nrec) + 5 * (size_t)n;
+                const d2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
+                node_mass = r0.x; gx = r0.y; gy = r1.x; rlm = r1.y; cbu = r2.x; fcor = r2.y; tax = r3.x; tay = r3.y; ou = r4.x; ov = r4.y;
+            }
+            lat = (nf & NF_LAT_NEG) ? -1. : 1.;
             if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
             if (move_dt != 0.) { umu = ldg<NT_U>(s.UM + n); umv = ldg<NT_U>(s.UM + n + Nn); utu = ldg<NT_U>(s.UT + n); utv = ldg<NT_U>(s.UT + n + Nn); }
             if (HALO && boundary) { sq0 = hf.send_ptr[n]; sq1 = hf.send_ptr[n + 1]; }

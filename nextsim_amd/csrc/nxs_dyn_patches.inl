@@ -264,7 +264,6 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
     free_pool(h->pair_allocs);
     h->dpch2 = DevPatches2{};
     h->pair_ready = false;
-    h->dw.erec = nullptr; h->dw.nrec = nullptr;
     const DevMesh &m = h->dm;
     if (m.No != m.Nn) return fail(h, NXS_ERR_STATE, "multi-sub-step patches need a single-rank mesh");
     std::vector<int> order(m.Nn);
@@ -347,8 +346,6 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
     }
     // per-step constants of the multi kernel as one record per element / node (written by the prep kernels while these exist):
     // two base pointers instead of fourteen, half the load instructions
-    if ((rc = dev_alloc(h, h->pair_allocs, &h->dw.erec, 6 * (size_t)m.Ne))) return rc;
-    if ((rc = dev_alloc(h, h->pair_allocs, &h->dw.nrec, 10 * (size_t)m.Nn))) return rc;
     h->pair_ready = true;
     h->pair_depth_built = D;
     return NXS_OK;
