@@ -608,7 +608,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(s.VT, n2); A(s.VT2, n2); A(s.UM, n2); A(s.UT, n2);
     A(s.conc, ne); A(s.thick, ne); A(s.snow, ne); A(s.damage, ne); A(s.ridge, ne);
     A(s.s0, ne); A(s.s1, ne); A(s.s2, ne);
-    A(s.damage_b, ne); A(s.s0_b, ne); A(s.s1_b, ne); A(s.s2_b, ne);
+    A(s.S4a, 4 * ne); A(s.S4b, 4 * ne);
     A(s.cyoung, ne); A(s.hyoung, ne); A(s.hsyoung, ne); A(s.cmyi, ne); A(s.tmyi, ne);
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
@@ -1041,13 +1041,8 @@ bool multi_rank(const nxs_dyn_handle *h) { return h->nranks > 1; }
 PingPong pingpong(const nxs_dyn_handle *h, int parity) {
     const DevState &s = h->ds;
     PingPong b;
-    if (parity == 0) {
-        b.VTc = s.VT; b.s0c = s.s0; b.s1c = s.s1; b.s2c = s.s2; b.dc = s.damage;
-        b.VTn = s.VT2; b.s0n = s.s0_b; b.s1n = s.s1_b; b.s2n = s.s2_b; b.dn = s.damage_b;
-    } else {
-        b.VTc = s.VT2; b.s0c = s.s0_b; b.s1c = s.s1_b; b.s2c = s.s2_b; b.dc = s.damage_b;
-        b.VTn = s.VT; b.s0n = s.s0; b.s1n = s.s1; b.s2n = s.s2; b.dn = s.damage;
-    }
+    if (parity == 0) { b.VTc = s.VT; b.Sc = s.S4a; b.VTn = s.VT2; b.Sn = s.S4b; }
+    else { b.VTc = s.VT2; b.Sc = s.S4b; b.VTn = s.VT; b.Sn = s.S4a; }
     return b;
 }
 
@@ -1273,6 +1268,7 @@ int run_substeps(nxs_dyn_handle *h) {
     };
     auto loop = [&]() -> int {
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
+        if (fused) LAUNCH(h, k_pack_state, h->dm.Ne, h->dm, h->ds, bbm, h->ds.S4a);
         for (int s = 0; s < S; ++s) {
             if (pair) {
                 launch_multi(h, s, D);
@@ -1309,9 +1305,9 @@ int run_substeps(nxs_dyn_handle *h) {
         }
         if (fused) {  // bring the result back to the primary buffers
             const double *vt_src = (S % R) ? h->ring.slot[S % R] : nullptr;
-            const int odd = pair ? ((S / D) & 1) : (S & 1);  // sigma/damage ended in the secondary buffers
-            if (vt_src || odd)
-                LAUNCH(h, k_pingpong_copy_back, std::max(2 * h->dm.Nn, h->dm.Ne), h->dm, h->ds, bbm, vt_src, odd);
+            if (vt_src) LAUNCH(h, k_pingpong_copy_back, 2 * h->dm.Nn, h->dm, h->ds, vt_src);
+            const int odd = pair ? ((S / D) & 1) : (S & 1);  // the element state ended in the second record buffer
+            LAUNCH(h, k_unpack_state, h->dm.Ne, h->dm, h->ds, bbm, (const double *)(odd ? h->ds.S4b : h->ds.S4a));
         }
         return NXS_OK;
     };

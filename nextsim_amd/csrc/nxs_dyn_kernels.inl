@@ -52,7 +52,7 @@ struct DevMesh {
 struct DevState {
     double *VT, *VT2, *UM, *UT;  // VT2: second buffer (Jacobi smoother; ping-pong of the fused sub-step)
     double *conc, *thick, *snow, *damage, *ridge, *s0, *s1, *s2;
-    double *damage_b, *s0_b, *s1_b, *s2_b;  // ping-pong partners of damage, sigma (fused sub-step)
+    double *S4a, *S4b;  // [Ne][4] (sigma0, sigma1, sigma2, damage): the element state as the fused sub-step kernels keep it inside the sub-step loop (ping-pong pair)
     double *cyoung, *hyoung, *hsyoung, *cmyi, *tmyi;
     double *cohesion, *theal, *drag_ui, *drag_ui_young;
     double *wind, *ocean, *ssh, *depth;
@@ -89,8 +89,8 @@ struct DevPatches2 {
 struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
 
 struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
-    const double *VTc, *s0c, *s1c, *s2c, *dc;
-    double *VTn, *s0n, *s1n, *s2n, *dn;
+    const double *VTc, *Sc;  // Sc, Sn: [Ne][4] records (sigma0, sigma1, sigma2, damage), see k_pack_state
+    double *VTn, *Sn;
 };
 
 struct DevWork {
@@ -748,8 +748,13 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         int dxi = 0;
         if (active) {
             if (!bbm) skip = w.eskip[e];
-            sig[0] = ldg<NT_S>(b.s0c + e); sig[1] = ldg<NT_S>(b.s1c + e); sig[2] = ldg<NT_S>(b.s2c + e);
-            if (bbm) damage = ldg<NT_S>(b.dc + e);
+            {
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                const d2 *S = reinterpret_cast<const d2 *>(b.Sc) + 2 * (size_t)e;
+                d2 a, c2;
+                if (NT_S) { a = __builtin_nontemporal_load(S); c2 = __builtin_nontemporal_load(S + 1); } else { a = S[0]; c2 = S[1]; }
+                sig[0] = a.x; sig[1] = a.y; sig[2] = c2.x; damage = c2.y;
+            }
             {
                 typedef double d2 __attribute__((ext_vector_type(2)));
                 const d2 *r = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
@@ -788,8 +793,10 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 else vp_stress(p, dxN, u, v, sig, c_expC);
             }
             if (writer) {
-                stg<NT_S>(b.s0n + e, sig[0]); stg<NT_S>(b.s1n + e, sig[1]); stg<NT_S>(b.s2n + e, sig[2]);
-                if (bbm) stg<NT_S>(b.dn + e, damage);
+                typedef double d2 __attribute__((ext_vector_type(2)));
+                d2 *S = reinterpret_cast<d2 *>(b.Sn) + 2 * (size_t)e;
+                const d2 a = {sig[0], sig[1]}, c2 = {sig[2], damage};
+                if (NT_S) { __builtin_nontemporal_store(a, S); __builtin_nontemporal_store(c2, S + 1); } else { S[0] = a; S[1] = c2; }
             }
             double F[6];
             corner_forces(volume, sig, dxN, F);
@@ -948,8 +955,10 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
         const int e = in.e;
         in.damage = 0.; in.sig[0] = in.sig[1] = in.sig[2] = 0.;
         if (first) {
-            in.sig[0] = ldg<NT_S>(b.s0c + e); in.sig[1] = ldg<NT_S>(b.s1c + e); in.sig[2] = ldg<NT_S>(b.s2c + e);
-            if (bbm) in.damage = ldg<NT_S>(b.dc + e);
+            const d2 *S = reinterpret_cast<const d2 *>(b.Sc) + 2 * (size_t)e;
+            d2 a, c2;
+            if (NT_S) { a = __builtin_nontemporal_load(S); c2 = __builtin_nontemporal_load(S + 1); } else { a = S[0]; c2 = S[1]; }
+            in.sig[0] = a.x; in.sig[1] = a.y; in.sig[2] = c2.x; in.damage = c2.y;
         }
         // the element constants: one 48-byte record (k_prep_elements), read by every sub-step of the launch -- the later reads hit
         // the L2, the last one is the streaming one
@@ -994,8 +1003,9 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
         if (!last) {
             if (l < keep) { lS[l] = sig[0]; lS[ESm + l] = sig[1]; lS[2 * (size_t)ESm + l] = sig[2]; lS[3 * (size_t)ESm + l] = damage; }  // needed by the next sub-step
         } else if (in.writer) {
-            stg<NT_S>(b.s0n + in.e, sig[0]); stg<NT_S>(b.s1n + in.e, sig[1]); stg<NT_S>(b.s2n + in.e, sig[2]);
-            if (bbm) stg<NT_S>(b.dn + in.e, damage);
+            d2 *S = reinterpret_cast<d2 *>(b.Sn) + 2 * (size_t)in.e;
+            const d2 a = {sig[0], sig[1]}, c2 = {sig[2], damage};
+            if (NT_S) { __builtin_nontemporal_store(a, S); __builtin_nontemporal_store(c2, S + 1); } else { S[0] = a; S[1] = c2; }
         }
         double F[6];
         corner_forces(in.volume, sig, dxN, F);
@@ -1098,14 +1108,31 @@ __global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRi
     s.UT[n] = utu; s.UT[n + Nn] = utv;
 }
 
-// odd number of sub-steps: bring the ping-pong result back to the primary buffers
-__global__ void __launch_bounds__(BLOCK) k_pingpong_copy_back(DevMesh m, DevState s, int bbm, const double *vt_src, int copy_sigma) {
+// the velocity of the last sub-step back into M_VT when the ring ended elsewhere
+__global__ void __launch_bounds__(BLOCK) k_pingpong_copy_back(DevMesh m, DevState s, const double *vt_src) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (vt_src && i < 2 * m.Nn) s.VT[i] = vt_src[i];
-    if (copy_sigma && i < m.Ne) {
-        s.s0[i] = s.s0_b[i]; s.s1[i] = s.s1_b[i]; s.s2[i] = s.s2_b[i];
-        if (bbm) s.damage[i] = s.damage_b[i];
-    }
+    if (i < 2 * m.Nn) s.VT[i] = vt_src[i];
+}
+
+// The fused sub-step kernels keep (sigma0, sigma1, sigma2, damage) of an element as one 32-byte record: two 16-byte loads and two
+// stores per element and sub-step instead of four and four, one base pointer instead of four.  Everything outside the sub-step loop
+// (and the C ABI) sees the four arrays M_sigma[0..2], M_damage: packed before the loop, unpacked after it.
+__global__ void __launch_bounds__(BLOCK) k_pack_state(DevMesh m, DevState s, int bbm, double *__restrict__ S4) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= m.Ne) return;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 *S = reinterpret_cast<d2 *>(S4) + 2 * (size_t)e;
+    S[0] = d2{s.s0[e], s.s1[e]};
+    S[1] = d2{s.s2[e], bbm ? s.damage[e] : 0.};
+}
+__global__ void __launch_bounds__(BLOCK) k_unpack_state(DevMesh m, DevState s, int bbm, const double *__restrict__ S4) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= m.Ne) return;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2 *S = reinterpret_cast<const d2 *>(S4) + 2 * (size_t)e;
+    const d2 a = S[0], c2 = S[1];
+    s.s0[e] = a.x; s.s1[e] = a.y; s.s2[e] = c2.x;
+    if (bbm) s.damage[e] = c2.y;
 }
 
 // ------------------------------------------------------------------------------------------------
