@@ -262,9 +262,10 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
 // ------------------------------------------------------------------------------------------------
 // K1b + K2  the nodal side of prep elements (as a gather) and prep nodes, FE.cpp:10309-10416
 __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, DevWork w, DevParams p) {
-    const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n >= m.Nn) return;
+    // threads past the end redo the last node (identical values to identical places): every thread reaches the barrier below
+    const int n = min(blockIdx.x * BLOCK + (int)threadIdx.x, m.Nn - 1);
     const int Nn = m.Nn;
+    __shared__ double rec[BLOCK * 10];
     const bool dirichlet = m.nflags[n] & NF_DIRICHLET;
 
     double rl = 0., nm = 0., cb = 0., gu = 0., gv = 0.;
@@ -305,10 +306,12 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     }
     const double wu = s.wind[n], wv = s.wind[n + Nn];
     drag *= NXS_RHOA * hypot(wu, wv) / surface;        // Q6
-    w.D_tau_a[n] = drag * wu;
-    w.D_tau_a[n + Nn] = drag * wv;
+    const double tax = drag * wu, tay = drag * wv;
+    w.D_tau_a[n] = tax;
+    w.D_tau_a[n + Nn] = tay;
 
-    w.fcor[n] = 2 * NXS_OMEGA * sin(m.lat[n] * NXS_PI / 180.);
+    const double fc = 2 * NXS_OMEGA * sin(m.lat[n] * NXS_PI / 180.);
+    w.fcor[n] = fc;
 
     rl = 1. / rl;                                      // FE.cpp:10400-10402
     nm *= rl;
@@ -319,11 +322,16 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
 
     w.VTM[n] = vu;
     w.VTM[n + Nn] = vv;
-    {   // the nodal inputs of the sub-step solve once more, as one 80-byte record per node (what the fused sub-step kernels read)
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        d2 *r = reinterpret_cast<d2 *>(w.nrec) + 5 * (size_t)n;
-        r[0] = d2{nm, gu}; r[1] = d2{gv, rl}; r[2] = d2{cb, w.fcor[n]}; r[3] = d2{w.D_tau_a[n], w.D_tau_a[n + Nn]};
-        r[4] = d2{s.ocean[n], s.ocean[n + Nn]};
+    {   // the nodal inputs of the sub-step solve once more, as one 80-byte record per node (what the fused sub-step kernels read: one
+        // base pointer, five 16-byte loads), staged through LDS so that the records leave the block as one contiguous stream
+        double *r = rec + 10 * threadIdx.x;
+        r[0] = nm; r[1] = gu; r[2] = gv; r[3] = rl; r[4] = cb; r[5] = fc; r[6] = tax; r[7] = tay; r[8] = s.ocean[n]; r[9] = s.ocean[n + Nn];
+    }
+    __syncthreads();
+    {
+        const size_t base = (size_t)blockIdx.x * BLOCK * 10;
+        const int count = min(BLOCK, Nn - (int)blockIdx.x * BLOCK) * 10;
+        for (int i = threadIdx.x; i < count; i += BLOCK) w.nrec[base + i] = rec[i];
     }
 }
 
