@@ -616,7 +616,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn)); A(w.erec, 6 * ne); A(w.nrec, 10 * (size_t)Nn);
     A(w.force, 6 * ne);
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
-    A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.xs, (size_t)Nn); A(w.ys, (size_t)Nn); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
+    A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.xy, n2); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
 #undef A
     HIPCHK(h, hipMemsetAsync(w.surface, 0, ne * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(w.delta_x, 0, ne * sizeof(double), h->stream));

@@ -104,7 +104,7 @@ struct DevWork {
     double *nrec;                                // [Nn][10]: (node_mass, grad_ssh u, v, rlmass, C_bu, fcor, D_tau_a u, v, ocean u, v) -- their nodal inputs
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
-    double *xs, *ys;  // [Nn] node coordinates on the displaced mesh at step start (frozen over the sub-steps, Q4)
+    double *xy;       // [Nn][2] node coordinates (x, y) on the displaced mesh at step start (frozen over the sub-steps, Q4)
     double *D_tau_a, *D_tau_w, *D_del;
 };
 
@@ -286,8 +286,10 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
         }
     }
     // same expression as load_vertices(): the fused sub-step kernel rebuilds the shape coefficients from these
-    w.xs[n] = m.x0[n] + 1. * s.UM[n];
-    w.ys[n] = m.y0[n] + 1. * s.UM[n + Nn];
+    {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        reinterpret_cast<d2 *>(w.xy)[n] = d2{m.x0[n] + 1. * s.UM[n], m.y0[n] + 1. * s.UM[n + Nn]};
+    }
     w.C_bu[n] = cb;
     w.grad_ssh[n] = gu;
     w.grad_ssh[n + Nn] = gv;
@@ -734,8 +736,11 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             lu[i] = b.VTc[g];
             lv[i] = b.VTc[g + Nn];
         }
-        lx[i] = w.xs[g];
-        ly[i] = w.ys[g];
+        {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2 c = reinterpret_cast<const d2 *>(w.xy)[g];
+            lx[i] = c.x; ly[i] = c.y;
+        }
     };
     if (t < nM) stage(t, my_node);
     if (t + T < nM) stage(t + T, my_node2);
@@ -948,7 +953,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     for (int i = t; i < nD; i += T) {
         const int g = (i == t) ? my_node : pn[i];
         lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
-        lx[i] = w.xs[g]; ly[i] = w.ys[g];
+        { typedef double d2 __attribute__((ext_vector_type(2))); const d2 c = reinterpret_cast<const d2 *>(w.xy)[g]; lx[i] = c.x; ly[i] = c.y; }
     }
 
     // one element of one sub-step (FE.cpp:10425-10467), split into its global loads and the rest so that the barrier
