@@ -138,6 +138,8 @@ struct nxs_dyn_handle {
     std::map<const void *, size_t> pinned; // what this handle has registered with hipHostRegister
     int halo_fused = 1;                    // option "halo_fused"
     bool hf_ready = false;
+    HaloFused *d_hf = nullptr;  // device copy of hf with the mailbox addresses filled in (what k_substep_fused<.., HALO> reads)
+    bool d_hf_dirty = true;
     HaloFused hf{};
     std::vector<void *> hf_allocs;
     std::vector<int> h_send_index, h_recv_index;   // host copies of the halo lists
@@ -815,6 +817,7 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     { const unsigned long long **tmp; std::vector<const unsigned long long *> v(flag.begin(), flag.end()); if ((rc = dev_upload(h, h->ipc_allocs, (const unsigned long long *const **)&tmp, v))) return rc; dfl = (unsigned long long *const *)tmp; }
     d.peer_seg = dseg; d.peer_parity_stride = dstr; d.peer_flag = dfl;
     h->ipc_ready = true;
+    h->d_hf_dirty = true;
     release_graph(h);
     return NXS_OK;
 }
@@ -1057,17 +1060,13 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int
     const dim3 grid(h->dpch.nP);
     const bool big = h->dpch.Pmax > NXS_T256_MAXP || h->dpch.Emax > 3 * 256, pow4 = h->dp.ers_int == 4;
     if (halo) {
-        HaloFused hf = h->hf;
-        hf.ipc = h->ipc;
-        hf.from_mailbox = from_mailbox;
-#define FUSED_H(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, true>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, hf)
+#define FUSED_H(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, true>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, (const HaloFused *)h->d_hf, h->hf.n_boundary, from_mailbox)
         if (big) { if (pow4) { if (h->nt_mask) FUSED_H(512, true, 3); else FUSED_H(512, true, 0); } else { FUSED_H(512, false, 0); } }
         else { if (pow4) { if (h->nt_mask) FUSED_H(256, true, 3); else FUSED_H(256, true, 0); } else { FUSED_H(256, false, 0); } }
 #undef FUSED_H
         return;
     }
-    const HaloFused none{};
-#define FUSED(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, false>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, none)
+#define FUSED(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, false>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, (const HaloFused *)nullptr, 0, 0)
 #define FUSED_NT(TT, PP) switch (h->nt_mask) { case 0: FUSED(TT, PP, 0); break; case 1: FUSED(TT, PP, 1); break; case 3: FUSED(TT, PP, 3); break; case 4: FUSED(TT, PP, 4); break; case 5: FUSED(TT, PP, 5); break; default: FUSED(TT, PP, 7); break; }
     if (big) { if (pow4) { FUSED_NT(512, true); } else { FUSED(512, false, 0); } }
     else { if (pow4) { FUSED_NT(256, true); } else { FUSED(256, false, 0); } }
@@ -1195,6 +1194,12 @@ int build_halo_fused(nxs_dyn_handle *h) {
     f.send_off = h->d_send_off;
     f.n_boundary = nb;
     f.No = No;
+    {
+        unsigned long long *raw = nullptr;  // device copy of the struct itself (filled in by run_substeps once the mailboxes are connected)
+        if ((rc = dev_alloc(h, h->hf_allocs, &raw, (sizeof(HaloFused) + 7) / 8))) return rc;
+        h->d_hf = reinterpret_cast<HaloFused *>(raw);
+        h->d_hf_dirty = true;
+    }
     h->hf_ready = true;
     if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d fused halo: %d of %d patches on the boundary, %d sent nodes, %d ghosts\n", h->rank, nb, nP, sptr[No], Nn - No);
     return NXS_OK;
@@ -1261,6 +1266,13 @@ int run_substeps(nxs_dyn_handle *h) {
     // or no move at all (mEVP)
     const bool halo_in_kernel = device_halo && fused && h->halo_fused && (deferred || move_dt == 0.);
     if (halo_in_kernel && !h->hf_ready) { int rc = build_halo_fused(h); if (rc) return rc; }
+    if (halo_in_kernel && h->d_hf_dirty) {  // (outside any stream capture)
+        HaloFused tmp = h->hf;
+        tmp.ipc = h->ipc;
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(h->d_hf, &tmp, sizeof tmp, hipMemcpyHostToDevice));
+        h->d_hf_dirty = false;
+    }
     auto pull_latest = [&](double *vec) {
         const int tr = h->recv_offsets[h->recv_procs.size()];
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,

@@ -620,6 +620,8 @@ __device__ __forceinline__ double sys_load(const double *p) {
 //   element with a ghost owned by B, then n is a ghost of B), so it is a boundary patch, and my flag x+1 is
 //   raised only after all of them have finished reading exchange x-1; a neighbour overwrites that half
 //   (exchange x+1) only after it has seen my flag x+1.
+// (the sub-step kernel receives a POINTER to a device copy of this struct: only its boundary patches touch the tables, and held by
+// value their fifteen pointers sat in the scalar registers of every patch's hot loop -- 61 spilled SGPRs against 4 without the halo)
 struct HaloFused {
     IpcDev ipc;
     int n_boundary;                    // patches [0, n_boundary) are the boundary patches (re-uploaded in that order)
@@ -661,7 +663,7 @@ template <bool NT> __device__ __forceinline__ void stg(double *p, double v) { if
 // the old values of a shared element / node while this one writes the new ones.
 template <int T, bool POW4, int NTM, bool HALO>
 __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p,
-                                                     PingPong b, double move_dt, HaloFused hf) {
+                                                     PingPong b, double move_dt, const HaloFused *__restrict__ hfp, int n_boundary, int from_mailbox) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lu = lds, *lv = lds + pp.Mmax, *lx = lds + 2 * (size_t)pp.Mmax, *ly = lds + 3 * (size_t)pp.Mmax,
            *lF = lds + 4 * (size_t)pp.Mmax;  // lF[6][Emax]
@@ -676,9 +678,9 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     unsigned long long xseq = 0ull;
     bool boundary = false;
     if (HALO) {  // boundary patches [0, n_boundary) lead the grid in dispatch order; the remap acts inside each group
-        boundary = blk < hf.n_boundary;
-        if (boundary || hf.n_boundary == 0) xseq = *hf.ipc.seq_push;  // interior patches never look at it: the last boundary patch may advance it while they run
-        blk = boundary ? xcd_remap(blk, hf.n_boundary) : hf.n_boundary + xcd_remap(blk - hf.n_boundary, (int)gridDim.x - hf.n_boundary);
+        boundary = blk < n_boundary;
+        if (boundary || n_boundary == 0) xseq = *hfp->ipc.seq_push;  // interior patches never look at it: the last boundary patch may advance it while they run
+        blk = boundary ? xcd_remap(blk, n_boundary) : n_boundary + xcd_remap(blk - n_boundary, (int)gridDim.x - n_boundary);
     } else {
         blk = xcd_remap(blk, (int)gridDim.x);
     }
@@ -709,16 +711,16 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     if (t + 2 * T < Emax) { eraw2 = pe[t + 2 * T]; tr2 = pt[t + 2 * T]; }
 #endif
 
-    const bool mailbox_ghosts = HALO && boundary && hf.from_mailbox;
+    const bool mailbox_ghosts = HALO && boundary && from_mailbox;
     if (mailbox_ghosts) {  // exchange xseq-1 must have landed before a ghost node is staged
         if (t == 0) {
             const long long t0 = wall_clock64();  // 100 MHz
             bool ok = true;
-            for (int k = 0; k < hf.ipc.nr && ok; ++k)
-                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
+            for (int k = 0; k < hfp->ipc.nr && ok; ++k)
+                while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost, do not wait again
-                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 3); break; }  // 10 s
+                    if (__hip_atomic_load(hfp->ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost, do not wait again
+                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hfp->ipc.error, 3); break; }  // 10 s
                 }
             // no acquire fence: the mailbox is uncached memory and every read of it below is a system-scope load that
             // bypasses the caches; a fence here would invalidate this XCD's caches once per boundary patch and sub-step
@@ -726,9 +728,9 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         __syncthreads();
     }
     auto stage = [&](int i, int g) {
-        if (mailbox_ghosts && g >= hf.No) {
-            const double *src = hf.ipc.mailbox + ((xseq - 1ull) & 1ull) * 2ull * (unsigned long long)hf.ipc.tr + hf.ghost_off[g - hf.No];
-            const double u = sys_load(src), v = sys_load(src + hf.ghost_srl[g - hf.No]);
+        if (mailbox_ghosts && g >= hfp->No) {
+            const double *src = hfp->ipc.mailbox + ((xseq - 1ull) & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr + hfp->ghost_off[g - hfp->No];
+            const double u = sys_load(src), v = sys_load(src + hfp->ghost_srl[g - hfp->No]);
             lu[i] = u; lv[i] = v;
             const_cast<double *>(b.VTc)[g] = u;  // every patch that stages g writes the same two values
             const_cast<double *>(b.VTc)[g + Nn] = v;
@@ -843,7 +845,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             lat = (nf & NF_LAT_NEG) ? -1. : 1.;
             if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
             if (move_dt != 0.) { umu = ldg<NT_U>(s.UM + n); umv = ldg<NT_U>(s.UM + n + Nn); utu = ldg<NT_U>(s.UT + n); utv = ldg<NT_U>(s.UT + n + Nn); }
-            if (HALO && boundary) { sq0 = hf.send_ptr[n]; sq1 = hf.send_ptr[n + 1]; }
+            if (HALO && boundary) { sq0 = hfp->send_ptr[n]; sq1 = hfp->send_ptr[n + 1]; }
         }
         // the node's fan (element slot, corner) too: 8 entries cover all but the most irregular vertices
         unsigned short fan[8];
@@ -877,10 +879,10 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         b.VTn[n + Nn] = vice;
         if (HALO) {  // updateGhosts, sending side: straight into the neighbours' mailboxes
             for (int q = sq0; q < sq1; ++q) {
-                const int k = hf.send_k[q];
-                double *dst = hf.ipc.peer_seg[k] + (xseq & 1ull) * hf.ipc.peer_parity_stride[k] + hf.send_pos[q];
+                const int k = hfp->send_k[q];
+                double *dst = hfp->ipc.peer_seg[k] + (xseq & 1ull) * hfp->ipc.peer_parity_stride[k] + hfp->send_pos[q];
                 sys_store(dst, uice);
-                sys_store(dst + (hf.send_off[k + 1] - hf.send_off[k]), vice);
+                sys_store(dst + (hfp->send_off[k + 1] - hfp->send_off[k]), vice);
             }
         }
         if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
@@ -902,15 +904,15 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             // checks both variants against each other on the machine it runs on.
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (t == 0 && atomicAdd(hf.ipc.done_push, 1u) == (unsigned)hf.n_boundary - 1u) {
+            if (t == 0 && atomicAdd(hfp->ipc.done_push, 1u) == (unsigned)n_boundary - 1u) {
                 __threadfence_system();  // the one release of the launch
-                for (int k = 0; k < hf.ipc.ns; ++k)
-                    __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
-                *hf.ipc.done_push = 0u;
-                *hf.ipc.seq_push = xseq + 1ull;  // every boundary patch has read it; no counter over the whole grid (same-address atomics are served ~10 ns apart)
+                for (int k = 0; k < hfp->ipc.ns; ++k)
+                    __hip_atomic_store(hfp->ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
+                *hfp->ipc.done_push = 0u;
+                *hfp->ipc.seq_push = xseq + 1ull;  // every boundary patch has read it; no counter over the whole grid (same-address atomics are served ~10 ns apart)
             }
-        } else if (hf.n_boundary == 0 && blockIdx.x == 0 && t == 0) {
-            *hf.ipc.seq_push = xseq + 1ull;
+        } else if (n_boundary == 0 && blockIdx.x == 0 && t == 0) {
+            *hfp->ipc.seq_push = xseq + 1ull;
         }
     }
 }
