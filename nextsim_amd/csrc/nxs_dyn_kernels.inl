@@ -824,6 +824,12 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     }
 
     NXS_STAMP(2);
+    if (HALO) {
+        // The element loop above uses nothing of the exchange tables; laundering the pointer makes the compiler re-read the few
+        // fields the node phase needs instead of keeping every field it loaded for the staging phase alive -- and spilled into
+        // VGPR lanes -- across the hot loop (166 v_readlane/v_writelane in that loop before, 12 in the kernel without the exchange)
+        asm volatile("" : "+s"(hfp));
+    }
     // node phase: issue this node's loads before barrier 2 so that they overlap the wait
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.Pmax;
     for (int base = 0; base < nO || base == 0; base += T) {
