@@ -81,6 +81,8 @@ struct nxs_dyn_handle {
     hipStream_t stream = nullptr;
     nxs_dyn_params params{};
     DevParams dp{};
+    DevParams *d_dp = nullptr;   // device copy (the fused sub-step kernels read their parameters from memory)
+    bool dp_dirty = true;
     bool have_mesh = false, have_state = false, have_forcing = false;
     DevMesh dm{};
     DevState ds{};
@@ -262,6 +264,7 @@ void derive_params(nxs_dyn_handle *h) {
     d.D[8] = Dunit_factor * (1. - p.nu0) / 2.;
     h->graph_valid = false;       // kernel arguments are baked into the graphs
     h->tail_graph_valid = false;
+    h->dp_dirty = true;
 }
 
 int check_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
@@ -410,6 +413,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     if (h->d_partials) (void)hipFree(h->d_partials);
     if (h->d_regrid) (void)hipFree(h->d_regrid);
     if (h->d_crash) (void)hipFree(h->d_crash);
+    if (h->d_dp) (void)hipFree(h->d_dp);
     for (auto &set : h->ev) for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -1059,19 +1063,25 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int
     b.VTn = h->ring.slot[(sidx + 1) % R];
     const dim3 grid(h->dpch.nP);
     const bool big = h->dpch.Pmax > NXS_T256_MAXP || h->dpch.Emax > 3 * 256, pow4 = h->dp.ers_int == 4;
+    // parameters from memory (PMEM) where one round of resident workgroups covers the partition, by value where several rounds stream
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    const bool pmem = h->dpch.nP <= 5 * cus / 2;  // 511 patches (182 k triangles): 1.375 -> 1.344 ms/step; 752 patches (263 k): 1.83 -> 1.91
+#define FUSED_K(TT, PP, NN, HH, MM, HFP, NB, FM) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, HH, MM>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, (const DevParams *)h->d_dp, b, move_dt, HFP, NB, FM)
     if (halo) {
-#define FUSED_H(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, true>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, (const HaloFused *)h->d_hf, h->hf.n_boundary, from_mailbox)
+#define FUSED_H(TT, PP, NN) do { if (pmem) FUSED_K(TT, PP, NN, true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary, from_mailbox); else FUSED_K(TT, PP, NN, true, false, (const HaloFused *)h->d_hf, h->hf.n_boundary, from_mailbox); } while (0)
         if (big) { if (pow4) { if (h->nt_mask) FUSED_H(512, true, 3); else FUSED_H(512, true, 0); } else { FUSED_H(512, false, 0); } }
         else { if (pow4) { if (h->nt_mask) FUSED_H(256, true, 3); else FUSED_H(256, true, 0); } else { FUSED_H(256, false, 0); } }
 #undef FUSED_H
         return;
     }
-#define FUSED(TT, PP, NN) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, false>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, b, move_dt, (const HaloFused *)nullptr, 0, 0)
+#define FUSED(TT, PP, NN) do { if (pmem) FUSED_K(TT, PP, NN, false, true, (const HaloFused *)nullptr, 0, 0); else FUSED_K(TT, PP, NN, false, false, (const HaloFused *)nullptr, 0, 0); } while (0)
 #define FUSED_NT(TT, PP) switch (h->nt_mask) { case 0: FUSED(TT, PP, 0); break; case 1: FUSED(TT, PP, 1); break; case 3: FUSED(TT, PP, 3); break; case 4: FUSED(TT, PP, 4); break; case 5: FUSED(TT, PP, 5); break; default: FUSED(TT, PP, 7); break; }
     if (big) { if (pow4) { FUSED_NT(512, true); } else { FUSED(512, false, 0); } }
     else { if (pow4) { FUSED_NT(256, true); } else { FUSED(256, false, 0); } }
 #undef FUSED_NT
 #undef FUSED
+#undef FUSED_K
 }
 
 // sub-steps sidx .. sidx+D-1 in one launch (k_substep_multi): sigma/damage ping-pong per LAUNCH, velocities through the ring
@@ -1084,7 +1094,7 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
     for (int k = 0; k < D; ++k) vo.slot[k] = h->ring.slot[(sidx + 1 + k) % R];
     const dim3 grid(h->dpch2.nP);
     const bool pow4 = h->dp.ers_int == 4;
-#define MULTI(TT, PP, NN) hipLaunchKernelGGL((k_substep_multi<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo)
+#define MULTI(TT, PP, NN) hipLaunchKernelGGL((k_substep_multi<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, (const DevParams *)h->d_dp, b, vo)
 #define MULTI_T(TT) do { if (pow4) { if (h->nt_mask) MULTI(TT, true, 5); else MULTI(TT, true, 0); } else MULTI(TT, false, 0); } while (0)
     if (h->pair_threads == 768) MULTI_T(768); else if (h->pair_threads == 512) MULTI_T(512); else MULTI_T(256);
 #undef MULTI_T
@@ -1357,6 +1367,12 @@ int explicit_solve(nxs_dyn_handle *h) {
     const DevMesh &m = h->dm;
     if (timed) HIPCHK(h, hipEventRecord(h->cur[0], h->stream));
     (void)choose_depth(h);
+    if (h->dp_dirty) {  // (outside any stream capture)
+        if (!h->d_dp) HIPCHK(h, hipMalloc((void **)&h->d_dp, sizeof(DevParams)));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(h->d_dp, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice));
+        h->dp_dirty = false;
+    }
     LAUNCH(h, k_prep_elements, m.Ne, m, h->ds, h->dw, h->dp);
     LAUNCH(h, k_prep_nodes, m.Nn, m, h->ds, h->dw, h->dp);
     if (timed) HIPCHK(h, hipEventRecord(h->cur[1], h->stream));

@@ -661,9 +661,14 @@ template <bool NT> __device__ __forceinline__ void stg(double *p, double v) { if
 // lets each own node subtract the forces of its fan (ascending element order, as the serial scatter)
 // and solve.  sigma, damage and VT are ping-pong buffered: a neighbouring patch may still be reading
 // the old values of a shared element / node while this one writes the new ones.
-template <int T, bool POW4, int NTM, bool HALO>
-__global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p,
+template <int T, bool POW4, int NTM, bool HALO, bool PMEM>
+__global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams pval, const DevParams *__restrict__ pdev,
                                                      PingPong b, double move_dt, const HaloFused *__restrict__ hfp, int n_boundary, int from_mailbox) {
+    // PMEM: the parameters are read from device memory, per phase (the element phase and the node phase need disjoint halves of them);
+    // as a by-value argument all of them sit in scalar registers through the whole kernel and push other values into VGPR lanes
+    // (0 spilled SGPRs instead of 4, and of 35 with the exchange).  That wins where a workgroup's latency binds (one round of
+    // patches: 182 k triangles 1.375 -> 1.344 ms/step) and loses where several rounds stream (2 km: 7.07 -> 7.36), hence both.
+    const DevParams &p = PMEM ? *pdev : pval;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lu = lds, *lv = lds + pp.Mmax, *lx = lds + 2 * (size_t)pp.Mmax, *ly = lds + 3 * (size_t)pp.Mmax,
            *lF = lds + 4 * (size_t)pp.Mmax;  // lF[6][Emax]
@@ -824,6 +829,9 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     }
 
     NXS_STAMP(2);
+    const DevParams *pn_ = pdev;
+    if (PMEM) asm volatile("" : "+s"(pn_));  // the node phase re-reads its parameters (see the top of the kernel)
+    const DevParams &q = PMEM ? *pn_ : pval;
     if (HALO) {
         // The element loop above uses nothing of the exchange tables; laundering the pointer makes the compiler re-read the few
         // fields the node phase needs instead of keeping every field it loaded for the staging phase alive -- and spilled into
@@ -849,7 +857,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 node_mass = r0.x; gx = r0.y; gy = r1.x; rlm = r1.y; cbu = r2.x; fcor = r2.y; tax = r3.x; tay = r3.y; ou = r4.x; ov = r4.y;
             }
             lat = (nf & NF_LAT_NEG) ? -1. : 1.;
-            if (p.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
+            if (q.dynamics_type == NXS_DYN_MEVP) { vtmu = w.VTM[n]; vtmv = w.VTM[n + Nn]; }
             if (move_dt != 0.) { umu = ldg<NT_U>(s.UM + n); umv = ldg<NT_U>(s.UM + n + Nn); utu = ldg<NT_U>(s.UT + n); utv = ldg<NT_U>(s.UT + n + Nn); }
             if (HALO && boundary) { sq0 = hfp->send_ptr[n]; sq1 = hfp->send_ptr[n + 1]; }
         }
@@ -879,7 +887,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 gx -= lF[(size_t)c * Emax + l];
                 gy -= lF[(size_t)(c + 3) * Emax + l];
             }
-            nodal_solve(p, gx, gy, uice, vice, node_mass, rlm, cbu, fcor, lat, tax, tay, ou, ov, vtmu, vtmv);
+            nodal_solve(q, gx, gy, uice, vice, node_mass, rlm, cbu, fcor, lat, tax, tay, ou, ov, vtmu, vtmv);
         }
         b.VTn[n] = uice;
         b.VTn[n + Nn] = vice;
@@ -933,7 +941,8 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
 // The kernel takes ~170 VGPRs: a 512-thread workgroup has its CU to itself, which is the regime it is used in automatically (one
 // patch per CU); capped at 128 (two workgroups per CU, or 1 024 threads) it spills 40 of them and loses more than it gains.
 template <int T, bool POW4, int NTM>
-__global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout) {
+__global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, PingPong b, VTOut vout) {
+    const DevParams &p = *pdev;  // read from device memory where they are used (see k_substep_fused)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int NDm = pp.NDmax, EDm = pp.EDmax, ESm = pp.ESmax, D = pp.D;
     double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm, *lF = ly + NDm /*[6][EDm]*/, *lS = lF + 6 * (size_t)EDm /*[4][ESm]*/;
