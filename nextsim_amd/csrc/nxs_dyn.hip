@@ -110,6 +110,11 @@ struct nxs_dyn_handle {
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
     std::vector<int> h_n2n, h_n2n_cnt;     // NodalConnectivity rows [W2][Nn] + counts (for the blocked smoother's tables)
     size_t smooth_lds = 0;
+    // node-ring patches for the smoother alone (single rank, meshes on the one-sub-step-per-launch kernels): D sweeps per launch
+    DevPatches2 dsm{};
+    std::vector<void *> sm_allocs;
+    bool sm_ready = false, sm_failed = false;
+    size_t sm_lds = 0;
     std::vector<unsigned char> h_ghost;
     std::vector<double> h_x0, h_y0;
     std::vector<void *> patch_allocs;
@@ -401,6 +406,9 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
+    free_pool(h->sm_allocs);
+    h->sm_ready = false;
+    h->sm_failed = false;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -498,6 +506,9 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
+    free_pool(h->sm_allocs);
+    h->sm_ready = false;
+    h->sm_failed = false;
     free_pool(h->ring_allocs);
     free_pool(h->hf_allocs);
     h->hf_ready = false;
@@ -1378,6 +1389,10 @@ int explicit_solve(nxs_dyn_handle *h) {
     if (timed) HIPCHK(h, hipEventRecord(h->cur[1], h->stream));
     int rc = run_substeps(h);
     if (rc) return rc;
+    if (!multi_rank(h) && h->depth_now < 2 && !h->sm_ready && !h->sm_failed && h->fused != 0) {
+        if (build_smooth_patches(h, 5) != NXS_OK) h->sm_failed = true;  // the smoother then runs sweep by sweep
+        h->tail_graph_valid = false;
+    }
     if (h->dp.dynamics_type == NXS_DYN_MEVP)  // FE.cpp:10559-10573
         LAUNCH(h, k_move, m.Nn, m, h->ds, 0, m.Nn, h->dp.dtime_step);
     if (timed) HIPCHK(h, hipEventRecord(h->cur[2], h->stream));
@@ -1386,14 +1401,18 @@ int explicit_solve(nxs_dyn_handle *h) {
     auto smooth_and_tail = [&]() -> int {
         double *a = h->ds.VT, *b = h->ds.VT2;
         LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
-        if (!multi_rank(h) && h->pair_ready && !h->pair_failed && h->dpch2.pnbr && h->fused >= 2) {
-            // the patches of k_substep_multi carry D rings: D sweeps per launch (see k_smooth_multi)
-            const int D = h->dpch2.D, L = (50 + D - 1) / D;
+        // single rank: D sweeps per launch on patches with D rings of nodes (k_smooth_multi) -- those of k_substep_multi where that
+        // kernel runs, else node-ring patches built for the smoother alone
+        const bool v3_patches = h->pair_ready && !h->pair_failed && h->dpch2.pnbr && h->fused >= 2 && h->depth_now >= 2;
+        if (!multi_rank(h) && (v3_patches || h->sm_ready)) {
+            const DevPatches2 &pp = v3_patches ? h->dpch2 : h->dsm;
+            const size_t lds = v3_patches ? h->smooth_lds : h->sm_lds;
+            const int D = pp.D, L = (50 + D - 1) / D;
             if (L & 1) std::swap(a, b);  // the buffers are equal now; end in ds.VT after L swaps
             for (int nit = 0; nit < 50; nit += D) {
                 const int ks = std::min(D, 50 - nit);
-                if (h->pair_threads >= 512) hipLaunchKernelGGL((k_smooth_multi<512>), dim3(h->dpch2.nP), dim3(512), h->smooth_lds, h->stream, m, h->dpch2, h->dw, (const double *)a, b, ks);
-                else hipLaunchKernelGGL((k_smooth_multi<256>), dim3(h->dpch2.nP), dim3(256), h->smooth_lds, h->stream, m, h->dpch2, h->dw, (const double *)a, b, ks);
+                if (pp.NSmax > 256) hipLaunchKernelGGL((k_smooth_multi<512>), dim3(pp.nP), dim3(512), lds, h->stream, m, pp, h->dw, (const double *)a, b, ks);
+                else hipLaunchKernelGGL((k_smooth_multi<256>), dim3(pp.nP), dim3(256), lds, h->stream, m, pp, h->dw, (const double *)a, b, ks);
                 std::swap(a, b);
             }
             LAUNCH(h, k_ow_tail, m.Nn, m, h->ds, h->dw, h->dp);

@@ -85,6 +85,7 @@ struct DevPatches2 {
     const unsigned short *pfan;   // [nP][Wp][NSmax] fan of every solved node, ascending element id: (element slot << 3 | ghost << 2 | corner)
     const unsigned short *pnbr;   // [nP][W2][NSmax] NodalConnectivity row of every node of N_(D-1) in patch-local slots, bamg order (Q8), 0xFFFF pad;
     int W2;                       //                 NULL when a row leaves its patch (then the smoother runs sweep by sweep)
+    int own_is_block;             // the own nodes of patch q are the nodes [256 q, 256 q + 256): k_prep_nodes' open-water flag of that block applies
 };
 struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
 
@@ -1420,15 +1421,21 @@ __global__ void __launch_bounds__(T) k_smooth_multi(DevMesh m, DevPatches2 pp, D
     const int *ncnt = pp.ncnt + (size_t)blk * (D + 1);
     const int *pn = pp.pnodes + (size_t)blk * NDm;
     const unsigned short *nb = pp.pnbr + (size_t)blk * pp.W2 * pp.NSmax;
+    if (pp.own_is_block && !w.open_blk[blk]) return;  // no ice-free own node (flag raised by k_prep_nodes): nothing to write
     const int nO = ncnt[0], nS = ncnt[KS - 1], nK = ncnt[KS];
     int any = 0;
-    for (int i = t; i < nS; i += T) {
+    for (int i = t; i < nO; i += T) {  // the own nodes first: most patches stop here
         const int g = pn[i];
         const unsigned char o = !((m.nflags[g] & NF_DIRICHLET) || w.node_mass[g] != 0.);  // k_smooth's test, FE.cpp:10589
         open[i] = o;
-        any |= (o && i < nO);
+        any |= o;
     }
-    if (!__syncthreads_or(any)) return;  // (also publishes open[])
+    if (!__syncthreads_or(any)) return;
+    for (int i = nO + t; i < nS; i += T) {
+        const int g = pn[i];
+        open[i] = !((m.nflags[g] & NF_DIRICHLET) || w.node_mass[g] != 0.);
+    }
+    __syncthreads();
     for (int i = t; i < nK; i += T) { const int g = pn[i]; au[i] = src[g]; av[i] = src[g + Nn]; }
     __syncthreads();
     for (int j = 0; j < KS; ++j) {

@@ -428,3 +428,72 @@ int upload_patches(nxs_dyn_handle *h) {
     return upload_host_patches(h, *h->hp);
 }
 
+
+// Host: node-ring patches for the open-water smoother alone (k_smooth_multi on meshes that do not use k_substep_multi): patches of 256
+// consecutive own nodes (or consecutive along the Hilbert curve the sub-step patches were cut along), D rings of neighbours through
+// the NodalConnectivity rows.  Only the node levels and the rows in patch-local slots are filled in.
+int build_smooth_patches(nxs_dyn_handle *h, int D) {
+    free_pool(h->sm_allocs);
+    h->dsm = DevPatches2{};
+    h->sm_ready = false;
+    const DevMesh &m = h->dm;
+    const int Nn = m.Nn, W2 = m.W2, P = 256;
+    if (m.No != Nn || (int)h->h_n2n_cnt.size() != Nn || h->h_n2n.size() != (size_t)W2 * Nn) return fail(h, NXS_ERR_STATE, "smoother patches need a single-rank mesh");
+    std::vector<int> order(Nn);
+    for (int i = 0; i < Nn; ++i) order[i] = i;
+    if (h->hp && h->hp->used_hilbert) hilbert_order(h->h_x0.data(), h->h_y0.data(), Nn, order);
+    const int nP = (Nn + P - 1) / P;
+    std::vector<int> ncnt((size_t)nP * (D + 1), 0), slot_of(Nn, -1);
+    std::vector<std::vector<int>> pnd(nP);
+    int NDmax = 0, NSmax = 0;
+    for (int q = 0; q < nP; ++q) {
+        auto &nd = pnd[q];
+        const int a = q * P, bnd = std::min(Nn, a + P);
+        for (int i = a; i < bnd; ++i) { slot_of[order[i]] = (int)nd.size(); nd.push_back(order[i]); }
+        int *nc = ncnt.data() + (size_t)q * (D + 1);
+        nc[0] = bnd - a;
+        int prev = 0;
+        for (int lev = 1; lev <= D; ++lev) {
+            std::vector<int> add;
+            for (int i = prev; i < nc[lev - 1]; ++i) {
+                const int n = nd[i];
+                for (int k = 0; k < h->h_n2n_cnt[n]; ++k) {
+                    const int nb = h->h_n2n[(size_t)k * Nn + n];
+                    if (slot_of[nb] == -1) { slot_of[nb] = -2; add.push_back(nb); }
+                }
+            }
+            std::sort(add.begin(), add.end());
+            for (int n : add) { slot_of[n] = (int)nd.size(); nd.push_back(n); }
+            prev = nc[lev - 1];
+            nc[lev] = (int)nd.size();
+        }
+        for (int n : nd) slot_of[n] = -1;
+        if (nd.size() > 65535) return fail(h, NXS_ERR_INVALID, "smoother patch too large");
+        NDmax = std::max(NDmax, nc[D]); NSmax = std::max(NSmax, nc[D - 1]);
+    }
+    NDmax = (NDmax + 1) & ~1; NSmax = (NSmax + 1) & ~1;
+    const size_t lds = 4 * (size_t)NDmax * sizeof(double) + (size_t)NSmax;
+    if (lds > 64 * 1024) return fail(h, NXS_ERR_INVALID, "smoother patches need %zu B of LDS (numbering without locality?)", lds);
+    std::vector<int> pnodes((size_t)nP * NDmax, 0);
+    std::vector<unsigned short> pnbr((size_t)nP * W2 * NSmax, 0xFFFF);
+    for (int q = 0; q < nP; ++q) {
+        const auto &nd = pnd[q];
+        std::copy(nd.begin(), nd.end(), pnodes.begin() + (size_t)q * NDmax);
+        for (size_t i = 0; i < nd.size(); ++i) slot_of[nd[i]] = (int)i;
+        const int nS = ncnt[(size_t)q * (D + 1) + D - 1];
+        for (int i = 0; i < nS; ++i)
+            for (int k = 0; k < h->h_n2n_cnt[nd[i]]; ++k) pnbr[((size_t)q * W2 + k) * NSmax + i] = (unsigned short)slot_of[h->h_n2n[(size_t)k * Nn + nd[i]]];
+        for (int n : nd) slot_of[n] = -1;
+    }
+    DevPatches2 &d = h->dsm;
+    d.nP = nP; d.D = D; d.NDmax = NDmax; d.NSmax = NSmax; d.W2 = W2;
+    d.own_is_block = (P == BLOCK && !(h->hp && h->hp->used_hilbert)) ? 1 : 0;
+    int rc;
+    if ((rc = dev_upload(h, h->sm_allocs, &d.ncnt, ncnt))) return rc;
+    if ((rc = dev_upload(h, h->sm_allocs, &d.pnodes, pnodes))) return rc;
+    if ((rc = dev_upload(h, h->sm_allocs, &d.pnbr, pnbr))) return rc;
+    h->sm_lds = lds;
+    h->sm_ready = true;
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] smoother patches: D=%d nP=%d NDmax=%d NSmax=%d lds=%zu B\n", D, nP, NDmax, NSmax, lds);
+    return NXS_OK;
+}

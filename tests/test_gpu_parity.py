@@ -350,6 +350,18 @@ def test_fused_substep_kernel_is_bitwise_equal_to_the_per_loop_kernels(dyn, subs
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
+def test_smoother_with_open_water_five_sweeps_per_launch_equals_sweep_by_sweep():
+    """The toy case has an ice-free strip: the open-water smoother really changes velocities there.  fused=1 runs it five sweeps
+    per launch on node-ring patches (k_smooth_multi), fused=0 one sweep per launch (k_smooth): the same bits after three steps."""
+    outs = []
+    for fused in (1, 0):
+        fe, ref, lm = _pair("toy", 3, options={"fused": fused})
+        outs.append(fe.get_state())
+        fe.close()
+    for k in STATE_KEYS:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
 @pytest.mark.parametrize("um_ring,substeps", [(1, 120), (5, 120), (16, 120), (120, 120), (8, 13), (7, 7)])
 def test_deferred_mesh_move_ring_does_not_change_a_bit(um_ring, substeps):
     """UM/UT are advanced every um_ring sub-steps from a ring of velocity buffers: the same additions in the
