@@ -263,8 +263,15 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
 // ------------------------------------------------------------------------------------------------
 // K1b + K2  the nodal side of prep elements (as a gather) and prep nodes, FE.cpp:10309-10416
 __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, DevWork w, DevParams p) {
+    // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous range of nodes, so that the element records two rows of
+    // nodes share are found in that XCD's L2 (each record is gathered by its three corner nodes)
+    int blk;
+    {
+        const int nb = (int)gridDim.x, pos = (int)blockIdx.x, q = nb >> 3, r = nb & 7, x = pos & 7;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
+    }
     // threads past the end redo the last node (identical values to identical places): every thread reaches the barrier below
-    const int n = min(blockIdx.x * BLOCK + (int)threadIdx.x, m.Nn - 1);
+    const int n = min(blk * BLOCK + (int)threadIdx.x, m.Nn - 1);
     const int Nn = m.Nn;
     __shared__ double rec[BLOCK * 10];
     const bool dirichlet = m.nflags[n] & NF_DIRICHLET;
@@ -332,8 +339,8 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     }
     __syncthreads();
     {
-        const size_t base = (size_t)blockIdx.x * BLOCK * 10;
-        const int count = min(BLOCK, Nn - (int)blockIdx.x * BLOCK) * 10;
+        const size_t base = (size_t)blk * BLOCK * 10;
+        const int count = min(BLOCK, Nn - blk * BLOCK) * 10;
         for (int i = threadIdx.x; i < count; i += BLOCK) w.nrec[base + i] = rec[i];
     }
 }
