@@ -1106,7 +1106,8 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
     const dim3 grid(h->dpch2.nP);
     const bool pow4 = h->dp.ers_int == 4;
 #define MULTI(TT, PP, NN) hipLaunchKernelGGL((k_substep_multi<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, (const DevParams *)h->d_dp, b, vo)
-#define MULTI_T(TT) do { if (pow4) { if (h->nt_mask) MULTI(TT, true, 5); else MULTI(TT, true, 0); } else MULTI(TT, false, 0); } while (0)
+// no non-temporal hints: this kernel runs where the mesh lives in the caches (58 k triangles: 0.768 ms/step with them, 0.750 without; 111 k: 0.927 / 0.90)
+#define MULTI_T(TT) do { if (pow4) MULTI(TT, true, 0); else MULTI(TT, false, 0); } while (0)
     if (h->pair_threads == 768) MULTI_T(768); else if (h->pair_threads == 512) MULTI_T(512); else MULTI_T(256);
 #undef MULTI_T
 #undef MULTI
