@@ -267,7 +267,8 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *   "pair_nodes"   the same for the several-sub-steps kernel, 16..512; 0 = automatic
  *   "um_ring"      apply M_UM/M_UT += dt*M_VT every n sub-steps from a ring of velocity buffers, 1..128;
  *                  0 = automatic (once per step on meshes that stream from HBM, every sub-step on cache-resident ones)
- *   "nt_mask"      non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)
+ *   "nt_mask"      non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants); -1 = automatic
+ *                  (default): 3 from 1 M local triangles on, where a sub-step streams more than the Infinity Cache holds, 0 below
  *   "pin_host"     1 = page-lock the caller's state / forcing vectors the first time they are seen (hipHostRegister), so the
  *                  per-step copies of a host that keeps its thermodynamics on the CPU run at PCIe speed; registrations are
  *                  dropped at set_mesh / destroy / pin_host 0.  Default 0: the library does not touch the caller's pages.

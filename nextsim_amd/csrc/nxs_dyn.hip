@@ -105,7 +105,8 @@ struct nxs_dyn_handle {
                             // (1 = every sub-step; 0 = auto: once per step on meshes that stream from HBM, 1 on cache-resident ones)
     VTRing ring{};
     std::vector<void *> ring_allocs;
-    int nt_mask = 3;        // non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants)
+    int nt_mask = -1;       // non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants); -1 = automatic:
+                            // 3 where a sub-step streams more than the Infinity Cache holds (>= 1 M local triangles), 0 below
     size_t fused_lds = 0;
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
     std::vector<int> h_n2n, h_n2n_cnt;     // NodalConnectivity rows [W2][Nn] + counts (for the blocked smoother's tables)
@@ -446,7 +447,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         h->um_ring = (int)value; release_graph(h);
         return NXS_OK;
     }
-    if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }  // -1 = automatic
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 3) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2 or 3");
         h->fused = (int)value; release_graph(h); return NXS_OK;
@@ -1074,6 +1075,9 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int
     b.VTn = h->ring.slot[(sidx + 1) % R];
     const dim3 grid(h->dpch.nP);
     const bool big = h->dpch.Pmax > NXS_T256_MAXP || h->dpch.Emax > 3 * 256, pow4 = h->dp.ers_int == 4;
+    // streaming hints keep the state from displacing the reusable arrays -- a gain only when a sub-step's ~210 B/triangle do not fit
+    // the 256 MiB Infinity Cache anyway: 1.46 M triangles 7.08 -> 6.96 ms/step with them, 730 k 3.75 -> 3.98, 367 k 2.20 -> 2.33, 182 k 1.27 -> 1.31
+    const int nt_mask = h->nt_mask >= 0 ? h->nt_mask : (h->dm.Ne >= 1000000 ? 3 : 0);
     // parameters from memory (PMEM) where one round of resident workgroups covers the partition, by value where several rounds stream
     int cus = 256;
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
@@ -1081,13 +1085,13 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int
 #define FUSED_K(TT, PP, NN, HH, MM, HFP, NB, FM) hipLaunchKernelGGL((k_substep_fused<TT, PP, NN, HH, MM>), grid, dim3(TT), h->fused_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, h->dp, (const DevParams *)h->d_dp, b, move_dt, HFP, NB, FM)
     if (halo) {
 #define FUSED_H(TT, PP, NN) do { if (pmem) FUSED_K(TT, PP, NN, true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary, from_mailbox); else FUSED_K(TT, PP, NN, true, false, (const HaloFused *)h->d_hf, h->hf.n_boundary, from_mailbox); } while (0)
-        if (big) { if (pow4) { if (h->nt_mask) FUSED_H(512, true, 3); else FUSED_H(512, true, 0); } else { FUSED_H(512, false, 0); } }
-        else { if (pow4) { if (h->nt_mask) FUSED_H(256, true, 3); else FUSED_H(256, true, 0); } else { FUSED_H(256, false, 0); } }
+        if (big) { if (pow4) { if (nt_mask) FUSED_H(512, true, 3); else FUSED_H(512, true, 0); } else { FUSED_H(512, false, 0); } }
+        else { if (pow4) { if (nt_mask) FUSED_H(256, true, 3); else FUSED_H(256, true, 0); } else { FUSED_H(256, false, 0); } }
 #undef FUSED_H
         return;
     }
 #define FUSED(TT, PP, NN) do { if (pmem) FUSED_K(TT, PP, NN, false, true, (const HaloFused *)nullptr, 0, 0); else FUSED_K(TT, PP, NN, false, false, (const HaloFused *)nullptr, 0, 0); } while (0)
-#define FUSED_NT(TT, PP) switch (h->nt_mask) { case 0: FUSED(TT, PP, 0); break; case 1: FUSED(TT, PP, 1); break; case 3: FUSED(TT, PP, 3); break; case 4: FUSED(TT, PP, 4); break; case 5: FUSED(TT, PP, 5); break; default: FUSED(TT, PP, 7); break; }
+#define FUSED_NT(TT, PP) switch (nt_mask) { case 0: FUSED(TT, PP, 0); break; case 1: FUSED(TT, PP, 1); break; case 3: FUSED(TT, PP, 3); break; case 4: FUSED(TT, PP, 4); break; case 5: FUSED(TT, PP, 5); break; default: FUSED(TT, PP, 7); break; }
     if (big) { if (pow4) { FUSED_NT(512, true); } else { FUSED(512, false, 0); } }
     else { if (pow4) { FUSED_NT(256, true); } else { FUSED(256, false, 0); } }
 #undef FUSED_NT

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--mesh", default="2km"); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--torch-first", action="store_true"); ap.add_argument("--graph", type=int, default=1)
-ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=3); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0)
+ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=-1); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0)
 a = ap.parse_args()
 if a.torch_first:
     import torch
