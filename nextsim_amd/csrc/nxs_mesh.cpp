@@ -135,16 +135,25 @@ extern "C" int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num
 }
 
 // calcCohesion (FE.cpp:3909-3914) on top of initIce's random field (FE.cpp:11459-11475): one draw of
-// boost::uniform_01<boost::minstd_rand> (default seed 1; x_{k+1} = 48271 x_k mod 2^31-1; r = (x - 1)/(2^31 - 2)) per GLOBAL
-// element, indexed by the element's global id, so every rank sees the same value for the same triangle.
+// boost::uniform_01<boost::minstd_rand> (default seed 1; x_{k+1} = 48271 x_k mod 2^31-1) per GLOBAL element, indexed by the
+// element's global id, so every rank sees the same value for the same triangle.  With an engine as first template argument
+// Boost 1.67 (the version pinned in scripts/env_compile_gnu_linux.bash:19) takes uniform_01's backward-compatible class
+// (boost/random/uniform_01.hpp, backward_compatible_uniform_01): it stores _factor = 1 / (double(max - min) + 1) =
+// 1 / 2147483646.0 once and returns double(x - min) * _factor, drawing again while the result is >= 1.  A MULTIPLICATION by the
+// rounded reciprocal, not a division: the two differ in the last bit for about one draw in a hundred, first at draw 142 (tests/test_mesh_partition.py).
 extern "C" int nxs_calc_cohesion(double C_fix, double C_alea, const int32_t *global_element_id, int64_t num_elements,
                                  int64_t num_global_elements, double *cohesion) {
     if (!global_element_id || !cohesion || num_elements < 0 || num_global_elements < 1) return NXS_ERR_INVALID;
     std::vector<double> random_number_root((size_t)num_global_elements);
     unsigned long long x = 1ull;
+    const double factor = 1.0 / (double(2147483646ull - 1ull) + 1.0);
     for (int64_t i = 0; i < num_global_elements; ++i) {
-        x = (x * 48271ull) % 2147483647ull;
-        random_number_root[(size_t)i] = (double)(x - 1ull) / 2147483646.0;
+        double r;
+        do {
+            x = (x * 48271ull) % 2147483647ull;
+            r = double(x - 1ull) * factor;
+        } while (!(r < 1.0));
+        random_number_root[(size_t)i] = r;
     }
     for (int64_t i = 0; i < num_elements; ++i) {
         const int32_t id = global_element_id[i];

@@ -67,7 +67,9 @@ def scale_params_to_mesh(p: _abi.Params, mesh: GlobalMesh, C_lab: float = 2.0e6,
 
 def minstd_uniform01(n: int) -> np.ndarray:
     """boost::minstd_rand (a = 48271, m = 2^31-1, default seed 1) through uniform_01, one draw per
-    global element id (FE.cpp:11459-11475): r_k = (x_k - 1) / (m - 1)."""
+    global element id (FE.cpp:11459-11475).  Boost 1.67's backward_compatible_uniform_01 (the class an engine as first
+    template argument selects) multiplies by a stored reciprocal: r_k = double(x_k - 1) * (1 / 2147483646.0), and draws
+    again while r_k >= 1 -- which cannot happen here: x_k <= m - 1 gives at most 2147483645 * fl(1/2147483646) < 1."""
     m = np.uint64(2147483647)
     a = 48271
     seq = np.array([a % 2147483647], np.uint64)  # x_1
@@ -77,7 +79,7 @@ def minstd_uniform01(n: int) -> np.ndarray:
         mult_len = pow(a, int(seq.size), 2147483647)
         seq = np.concatenate([seq, (seq * np.uint64(mult_len)) % m])
     x = seq[:n].astype(np.float64)
-    return (x - 1.0) / 2147483646.0
+    return (x - 1.0) * (1.0 / 2147483646.0)
 
 
 def global_fields(mesh: GlobalMesh, p: _abi.Params, kind: str, C_fix: float, C_alea: float,

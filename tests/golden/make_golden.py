@@ -207,20 +207,25 @@ def make_mapx_fixture():
     np.savez_compressed(os.path.join(HERE, "mapx_lat.npz"), x=x, y=y, lat=O.mapx_lat(x, y))
 
 
-def main():
+def make_connectivity_fixture():
     lm = M.localize(cases.global_mesh("tiny"), 1)[0]
-    assert O.bamg_shim() is not None, "build oracle/_ref first (make -C oracle ref)"
     nec, nc = O.bamg_connectivity(lm.indices, lm.coord_x, lm.coord_y)
     np.savez_compressed(os.path.join(HERE, "bamg_connectivity.npz"), indices=lm.indices, num_nodes=lm.num_nodes,
                         x=lm.coord_x, y=lm.coord_y, nec=nec, nc=nc)
 
-    make_interp_fixture()
-    make_grid_fixture()
-    make_remap_fixture()
-    make_mapx_fixture()
-    make_grid_to_mesh_fixture()
-    make_regrid_fixture()
 
+def main():
+    """No argument: every fixture.  Otherwise the named ones: connectivity interp grid remap mapx grid_to_mesh regrid oracle."""
+    assert O.bamg_shim() is not None, "build oracle/_ref first (make -C oracle ref)"
+    makers = {"connectivity": make_connectivity_fixture, "interp": make_interp_fixture, "grid": make_grid_fixture,
+              "remap": make_remap_fixture, "mapx": make_mapx_fixture, "grid_to_mesh": make_grid_to_mesh_fixture,
+              "regrid": make_regrid_fixture, "oracle": make_oracle_fixture}
+    for name in (sys.argv[1:] or list(makers)):
+        makers[name]()
+        print("wrote", name)
+
+
+def make_oracle_fixture():
     out = {}
     for tag, nsteps, over in (("sub1", 1, dict(substeps=1, dtime_step=200. / 120.)), ("step1", 1, {}), ("step3", 3, {})):
         gm, p, g, lms, fields = cases.make_case("tiny", **over)
@@ -230,7 +235,6 @@ def main():
         for k in KEYS:
             out[f"{tag}_{k}"] = r.arr[k]
     np.savez_compressed(os.path.join(HERE, "oracle_tiny.npz"), **out)
-    print("wrote fixtures to", HERE)
 
 
 if __name__ == "__main__":

@@ -62,12 +62,19 @@ def test_generators_are_seeded_and_sane():
 
 def test_minstd_uniform01_matches_the_lcg():
     from nextsim_amd.forcing import minstd_uniform01
-    x, ref = 1, []
+    x, ref, div = 1, [], []
+    factor = 1.0 / 2147483646.0     # backward_compatible_uniform_01::_factor = 1 / (double(max - min) + 1), Boost 1.67
     for _ in range(1000):
         x = (48271 * x) % 2147483647
-        ref.append((x - 1) / 2147483646.0)
-    assert np.array_equal(minstd_uniform01(1000), np.array(ref))
-    assert minstd_uniform01(1)[0] == 48270 / 2147483646.0  # boost::minstd_rand, seed 1, first draw 48271
+        ref.append(float(x - 1) * factor)
+        div.append((x - 1) / 2147483646.0)
+    got = minstd_uniform01(1000)
+    assert np.array_equal(got, np.array(ref))
+    assert got[0] == 48270 * factor  # boost::minstd_rand, seed 1, first draw 48271
+    # known answer on a draw where "multiply by the stored reciprocal" (what Boost does) and "divide" differ: draw 142 is
+    # x = 20204387; the product is 0x1.344b6204d12d8p-7, the quotient 0x1.344b6204d12d9p-7
+    assert got[141] == float.fromhex("0x1.344b6204d12d8p-7") != div[141]
+    assert 0 < (got != np.array(div)).sum() < 30 and got.max() < 1.0
 
 
 def test_c_abi_cohesion_equals_the_python_mirror():
@@ -78,6 +85,9 @@ def test_c_abi_cohesion_equals_the_python_mirror():
     ids = np.array([1, 2, 3, 5000, 77, 77], np.int32)
     got = dynamics.calc_cohesion(1.5e4, 3.0e3, ids, 5000)
     assert np.array_equal(got, 1.5e4 + 3.0e3 * r[ids - 1])
+    # the C side multiplies by the reciprocal too: element 142 is the first draw where a division would give another bit
+    one = dynamics.calc_cohesion(0.0, 1.0, np.array([142], np.int32), 5000)
+    assert one[0] == float.fromhex("0x1.344b6204d12d8p-7")
     with pytest.raises(Exception):
         dynamics.calc_cohesion(1., 1., np.array([0], np.int32), 10)
 
