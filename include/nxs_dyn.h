@@ -202,6 +202,9 @@ NXS_API int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo);
  * (nxs_dyn_comm_unique_id on rank 0, broadcast by the host launcher). */
 NXS_API int nxs_dyn_comm_unique_id(void *id128);
 NXS_API int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks);
+/* One exchange of coded payloads through that communicator (collective): a grouped ncclSend/ncclRecv of the rank to itself and,
+ * when halo lists are set, updateGhosts' grouped send/recv with checked contents.  *errors = wrong values received. */
+NXS_API int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors);
 
 /* Device-direct transport: updateGhosts through peer-mapped mailboxes (stores over xGMI, flags, no RCCL
  * launch, replayable from a hipGraph).  Collective setup driven by the host launcher:
@@ -210,6 +213,11 @@ NXS_API int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, in
  *   3. every rank: nxs_dyn_ipc_connect(h, blobs_of_my_send_neighbours, ...)
  *   4. every rank: nxs_dyn_ipc_selftest(h, rounds, &errors)    -> use it only if errors == 0 everywhere
  * Takes precedence over RCCL once connected; the host-staged callback below overrides both. */
+/* The mailbox must be uncached device memory (the in-kernel exchange takes no acquire after its flag wait): ipc_export fails when
+ * the runtime refuses it, and the caller stays on RCCL or its own communicator.  Neighbour handles may live in other processes
+ * (hipIpc) or in this one (a host that drives several GPUs from one process); ipc_connect checks the tables it is given against
+ * what each neighbour published, and a second connect replaces the first.  The self-test pushes checked payloads through every
+ * link with both publishing protocols the step can use (one release per block / one per launch). */
 #define NXS_IPC_BLOB_BYTES 128
 NXS_API int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob);
 NXS_API int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset,

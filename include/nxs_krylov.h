@@ -75,6 +75,8 @@ NXS_KRYLOV_API int nxs_krylov_set_matrix(nxs_krylov_handle *h, int32_t n_rows, i
 NXS_KRYLOV_API int nxs_krylov_set_halo(nxs_krylov_handle *h, const nxs_dyn_halo *halo);
 /* RCCL communicator from the 128-byte ncclUniqueId of nxs_dyn_comm_unique_id (same on every rank) */
 NXS_KRYLOV_API int nxs_krylov_comm_init(nxs_krylov_handle *h, const void *id128, int32_t rank, int32_t nranks);
+/* how many ncclAllReduce calls and grouped send/recv exchanges the handle has issued (a communicator of one rank still reduces) */
+NXS_KRYLOV_API int nxs_krylov_comm_stats(const nxs_krylov_handle *h, int64_t *rccl_allreduces, int64_t *rccl_exchanges);
 /* the caller's communicator instead: exchange(send, recv) moves the packed operand values (layout of the halo lists,
  * one double per entry), allreduce(vals, n) sums n doubles over the ranks in place; both return 0 on success */
 typedef int (*nxs_krylov_exchange_fn)(void *user, const double *send, double *recv);

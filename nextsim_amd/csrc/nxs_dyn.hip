@@ -32,6 +32,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <unistd.h>
 #include <vector>
 
 #include "nxs_dyn.h"
@@ -135,6 +136,7 @@ struct nxs_dyn_handle {
     IpcDev ipc{};
     void *ipc_block = nullptr;             // my mailbox allocation (exported)
     size_t ipc_block_bytes = 0;
+    bool ipc_uncached = false;             // the mailbox is MTYPE_UC memory (what the fence-less in-kernel exchange relies on)
     std::vector<void *> ipc_peer_base;     // opened peer mailboxes (to close)
     std::vector<void *> ipc_allocs;
     int *d_recv_procs = nullptr;
@@ -299,13 +301,32 @@ int harvest(nxs_dyn_handle *h, int k) {
 
 #include "nxs_dyn_patches.inl"
 
-void ipc_release(nxs_dyn_handle *h) {
+// What nxs_dyn_ipc_export publishes (NXS_IPC_BLOB_BYTES bytes): the hipIpc handle of the mailbox, and enough about it for the
+// neighbour to check the tables it was given before any kernel stores through them.  A neighbour that lives in the SAME process
+// (a host that drives several GPUs from one process, one thread and one handle per GPU) cannot open its own process's hipIpc
+// handle; it takes the device pointer itself.
+struct IpcBlob {
+    hipIpcMemHandle_t mem;      // 64 bytes
+    unsigned long long magic;   // 'NXSIPC01'
+    long long pid;
+    unsigned long long ptr;     // the mailbox in the exporting process
+    int device, uncached;
+    int tr, nr;                 // received nodes in total, receive neighbours
+};
+static_assert(sizeof(IpcBlob) <= NXS_IPC_BLOB_BYTES, "blob too small");
+constexpr unsigned long long IPC_MAGIC = 0x4e58534950433031ull;
+
+void ipc_disconnect(nxs_dyn_handle *h) {  // the peer mappings and the tables of one nxs_dyn_ipc_connect
     for (void *p : h->ipc_peer_base) if (p) (void)hipIpcCloseMemHandle(p);
     h->ipc_peer_base.clear();
     free_pool(h->ipc_allocs);
-    if (h->ipc_block) { (void)hipFree(h->ipc_block); h->ipc_block = nullptr; }
     h->ipc_ready = false;
     h->ipc = IpcDev{};
+}
+void ipc_release(nxs_dyn_handle *h) {
+    ipc_disconnect(h);
+    if (h->ipc_block) { (void)hipFree(h->ipc_block); h->ipc_block = nullptr; }
+    h->ipc_uncached = false;
 }
 // option "pin_host": the caller's vectors (FiniteElement's M_VT, M_conc, ... live as long as the mesh) are page-locked the first
 // time they are seen, so that the per-step copies of a host-side thermodynamics run at PCIe speed and overlap; a vector that was
@@ -378,7 +399,7 @@ int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) {
         hipError_t _e = (call);                                                                 \
         if (_e != hipSuccess) {                                                                 \
             fail(nullptr, NXS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e));           \
-            delete h;                                                                           \
+            (void)nxs_dyn_destroy(h); /* the stream, events and buffers made so far */           \
             return NXS_ERR_HIP;                                                                 \
         }                                                                                       \
     } while (0)
@@ -665,11 +686,22 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
     if (halo->nranks < 1 || halo->rank < 0 || halo->rank >= halo->nranks) return fail(h, NXS_ERR_INVALID, "rank/nranks invalid");
     const int ns = halo->num_send_procs, nr = halo->num_recv_procs;
     if (ns < 0 || nr < 0) return fail(h, NXS_ERR_INVALID, "negative neighbour count");
+    if ((ns > 0 && (!halo->send_procs || !halo->send_offsets)) || (nr > 0 && (!halo->recv_procs || !halo->recv_offsets)))
+        return fail(h, NXS_ERR_INVALID, "halo lists are NULL");
+    for (int side = 0; side < 2; ++side) {  // offsets: start at 0, never decrease (the segment loops and every buffer size rely on it)
+        const int32_t *off = side ? halo->recv_offsets : halo->send_offsets;
+        const int n = side ? nr : ns;
+        if (n == 0) continue;
+        if (off[0] != 0) return fail(h, NXS_ERR_INVALID, "%s_offsets[0] = %d, expected 0", side ? "recv" : "send", off[0]);
+        for (int k = 0; k < n; ++k)
+            if (off[k + 1] < off[k]) return fail(h, NXS_ERR_INVALID, "%s_offsets decrease at %d (%d -> %d)", side ? "recv" : "send", k, off[k], off[k + 1]);
+        if (off[n] > 0 && !(side ? halo->recv_index : halo->send_index)) return fail(h, NXS_ERR_INVALID, "%s_index is NULL", side ? "recv" : "send");
+    }
     h->rank = halo->rank; h->nranks = halo->nranks;
     h->send_procs.assign(halo->send_procs, halo->send_procs + ns);
     h->recv_procs.assign(halo->recv_procs, halo->recv_procs + nr);
-    h->send_offsets.assign(halo->send_offsets, halo->send_offsets + ns + 1);
-    h->recv_offsets.assign(halo->recv_offsets, halo->recv_offsets + nr + 1);
+    if (ns > 0) h->send_offsets.assign(halo->send_offsets, halo->send_offsets + ns + 1); else h->send_offsets.assign(1, 0);
+    if (nr > 0) h->recv_offsets.assign(halo->recv_offsets, halo->recv_offsets + nr + 1); else h->recv_offsets.assign(1, 0);
     const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
     std::vector<int> sidx(halo->send_index, halo->send_index + ts), ridx(halo->recv_index, halo->recv_index + tr);
     h->h_send_index = sidx; h->h_recv_index = ridx;
@@ -757,6 +789,53 @@ int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks
     return NXS_OK;
 }
 
+// One exchange of coded payloads through the RCCL communicator (collective when nranks > 1): a grouped ncclSend/ncclRecv of the
+// rank to ITSELF, and -- when halo lists are set -- the grouped send/recv of updateGhosts with every segment carrying
+// (sending rank, position).  *errors = number of wrong values received.  With nranks == 1 this runs the dlopen'ed entry points,
+// the by-value ncclUniqueId, the stream use and the error mapping on one GPU.
+int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors) {
+    if (!h || !errors) return NXS_ERR_INVALID;
+    if (!h->comm) return fail(h, NXS_ERR_STATE, "comm_selftest before comm_init");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int ncclDouble = 8, N = 256;
+    const int ns = h->have_halo ? (int)h->send_procs.size() : 0, nr = h->have_halo ? (int)h->recv_procs.size() : 0;
+    const int ts = ns ? h->send_offsets[ns] : 0, tr = nr ? h->recv_offsets[nr] : 0;
+    std::vector<double> hs(N), hr(N, -1.), hsend(2 * (size_t)ts), hrecv(2 * (size_t)tr, -1.);
+    for (int i = 0; i < N; ++i) hs[i] = 1e6 * h->rank + i + 0.25;
+    for (int k = 0; k < ns; ++k)
+        for (int i = 2 * h->send_offsets[k]; i < 2 * h->send_offsets[k + 1]; ++i) hsend[i] = 1e6 * h->rank + (i - 2 * h->send_offsets[k]) + 0.5;
+    double *ds = nullptr, *dr = nullptr;
+    std::vector<void *> pool;
+    int rc;
+    if ((rc = dev_alloc(h, pool, &ds, N)) || (rc = dev_alloc(h, pool, &dr, N))) { free_pool(pool); return rc; }
+    auto done = [&](int code) { free_pool(pool); return code; };
+#define ST_CHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return done(fail(h, NXS_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(_e))); } while (0)
+    ST_CHK(hipMemcpyAsync(ds, hs.data(), N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    ST_CHK(hipMemsetAsync(dr, 0xff, N * sizeof(double), h->stream));
+    if (ts > 0) ST_CHK(hipMemcpyAsync(h->d_send_buf, hsend.data(), hsend.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (tr > 0) ST_CHK(hipMemsetAsync(h->d_recv_buf, 0xff, hrecv.size() * sizeof(double), h->stream));
+    int e = h->rccl.GroupStart();
+    if (e == 0) e = h->rccl.Send(ds, (size_t)N, ncclDouble, h->rank, h->comm, h->stream);
+    if (e == 0) e = h->rccl.Recv(dr, (size_t)N, ncclDouble, h->rank, h->comm, h->stream);
+    for (int k = 0; k < ns && e == 0; ++k)
+        e = h->rccl.Send(h->d_send_buf + 2 * (size_t)h->send_offsets[k], 2 * (size_t)(h->send_offsets[k + 1] - h->send_offsets[k]), ncclDouble, h->send_procs[k], h->comm, h->stream);
+    for (int k = 0; k < nr && e == 0; ++k)
+        e = h->rccl.Recv(h->d_recv_buf + 2 * (size_t)h->recv_offsets[k], 2 * (size_t)(h->recv_offsets[k + 1] - h->recv_offsets[k]), ncclDouble, h->recv_procs[k], h->comm, h->stream);
+    const int e2 = h->rccl.GroupEnd();
+    if (e == 0) e = e2;
+    if (e != 0) return done(fail(h, NXS_ERR_COMM, "comm_selftest send/recv: %s", h->rccl.GetErrorString(e)));
+    ST_CHK(hipMemcpyAsync(hr.data(), dr, N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    if (tr > 0) ST_CHK(hipMemcpyAsync(hrecv.data(), h->d_recv_buf, hrecv.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    ST_CHK(hipStreamSynchronize(h->stream));
+#undef ST_CHK
+    int bad = 0;
+    for (int i = 0; i < N; ++i) bad += hr[i] != hs[i];
+    for (int k = 0; k < nr; ++k)
+        for (int i = 2 * h->recv_offsets[k]; i < 2 * h->recv_offsets[k + 1]; ++i) bad += hrecv[i] != 1e6 * h->recv_procs[k] + (i - 2 * h->recv_offsets[k]) + 0.5;
+    *errors = bad;
+    return done(NXS_OK);
+}
+
 // Device-direct transport, step 1: allocate my mailbox and export it.  blob receives NXS_IPC_BLOB_BYTES.
 int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
     if (!h || !blob) return NXS_ERR_INVALID;
@@ -768,24 +847,36 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
     const int nr = (int)h->recv_procs.size();
     const size_t tr = (size_t)h->recv_offsets[nr];
     const size_t bytes = (4 * tr + (size_t)std::max(nr, 1) + 16) * sizeof(double);  // 2 buffers of 2*tr doubles + flags
-    // uncached (MTYPE_UC) device memory: neither my L2 nor a neighbour's can hold a stale copy of a
-    // mailbox line or a flag; plain device memory as a fallback (the kernels use system-scope accesses anyway)
-    bool uncached = true;
-    if (hipExtMallocWithFlags(&h->ipc_block, bytes, hipDeviceMallocUncached) != hipSuccess) {
-        (void)hipGetLastError();
-        h->ipc_block = nullptr;
-        uncached = false;
-        HIPCHK(h, hipMalloc(&h->ipc_block, bytes));
+    // uncached (MTYPE_UC) device memory: neither my L2 nor a neighbour's can hold a stale copy of a mailbox line or a flag.
+    // The kernels rely on that: a receiver takes no acquire after its flag wait and a sender releases once per launch.  With
+    // ordinary (cached) device memory a receiver's L2 could serve a stale line, because peer stores do not pass through the home
+    // GPU's L2 -- so when the runtime refuses an uncached allocation the transport is refused too, and the caller stays on RCCL
+    // or its own communicator.
+    {
+        const hipError_t ue = hipExtMallocWithFlags(&h->ipc_block, bytes, hipDeviceMallocUncached);
+        if (ue != hipSuccess) {
+            (void)hipGetLastError();
+            h->ipc_block = nullptr;
+            return fail(h, NXS_ERR_HIP, "device-direct halo transport unavailable: uncached device memory refused (%s)", hipGetErrorString(ue));
+        }
     }
-    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d mailbox: %zu bytes, %s\n", h->rank, bytes, uncached ? "uncached (MTYPE_UC)" : "plain hipMalloc (uncached allocation refused)");
-    HIPCHK(h, hipMemset(h->ipc_block, 0, bytes));
-    HIPCHK(h, hipDeviceSynchronize());
+    h->ipc_uncached = true;
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d mailbox: %zu bytes, uncached (MTYPE_UC)\n", h->rank, bytes);
+    // (everything on the handle's own stream: another handle of this process may be capturing a graph on its thread right now,
+    // and legacy-stream operations are refused while any blocking capture is open)
+    HIPCHK(h, hipMemsetAsync(h->ipc_block, 0, bytes, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     h->ipc_block_bytes = bytes;
-    hipIpcMemHandle_t mh;
-    HIPCHK(h, hipIpcGetMemHandle(&mh, h->ipc_block));
-    static_assert(sizeof(hipIpcMemHandle_t) <= NXS_IPC_BLOB_BYTES, "blob too small");
+    IpcBlob b;
+    std::memset(&b, 0, sizeof b);
+    HIPCHK(h, hipIpcGetMemHandle(&b.mem, h->ipc_block));
+    b.magic = IPC_MAGIC;
+    b.pid = (long long)getpid();
+    b.ptr = (unsigned long long)(uintptr_t)h->ipc_block;
+    b.device = h->device; b.uncached = 1;
+    b.tr = (int)tr; b.nr = nr;
     std::memset(blob, 0, NXS_IPC_BLOB_BYTES);
-    std::memcpy(blob, &mh, sizeof mh);
+    std::memcpy(blob, &b, sizeof b);
     return NXS_OK;
 }
 
@@ -800,16 +891,37 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     HIPCHK(h, hipSetDevice(h->device));
     const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
     if (ns > 0 && (!blobs || !peer_recv_offset || !peer_recv_total || !peer_flag_slot)) return fail(h, NXS_ERR_INVALID, "ipc_connect: NULL tables");
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    release_graph(h);
+    ipc_disconnect(h);  // a second connect replaces the first: its peer mappings and tables go
     std::vector<double *> seg(ns);
     std::vector<long long> stride(ns);
     std::vector<unsigned long long *> flag(ns);
     for (int k = 0; k < ns; ++k) {
-        hipIpcMemHandle_t mh;
-        std::memcpy(&mh, (const char *)blobs + (size_t)k * NXS_IPC_BLOB_BYTES, sizeof mh);
+        // the tables are checked against what the neighbour itself published: a kernel that trusted a wrong offset would store
+        // outside the neighbour's mailbox, in another process's memory
+        IpcBlob b;
+        std::memcpy(&b, (const char *)blobs + (size_t)k * NXS_IPC_BLOB_BYTES, sizeof b);
+        const int q = h->send_procs[k], nseg = h->send_offsets[k + 1] - h->send_offsets[k];
+        if (b.magic != IPC_MAGIC) return fail(h, NXS_ERR_INVALID, "ipc_connect: blob of neighbour %d was not made by nxs_dyn_ipc_export", q);
+        if (!b.uncached) return fail(h, NXS_ERR_COMM, "ipc_connect: neighbour %d's mailbox is not uncached memory", q);
+        if (peer_recv_total[k] != b.tr) return fail(h, NXS_ERR_INVALID, "ipc_connect: neighbour %d receives %d nodes, the table says %d", q, b.tr, peer_recv_total[k]);
+        if (peer_flag_slot[k] < 0 || peer_flag_slot[k] >= b.nr) return fail(h, NXS_ERR_INVALID, "ipc_connect: flag slot %d outside neighbour %d's %d receive neighbours", peer_flag_slot[k], q, b.nr);
+        if (peer_recv_offset[k] < 0 || (long long)peer_recv_offset[k] + nseg > b.tr)
+            return fail(h, NXS_ERR_INVALID, "ipc_connect: my segment [%d, %d) does not fit neighbour %d's %d received nodes", peer_recv_offset[k], peer_recv_offset[k] + nseg, q, b.tr);
         void *base = nullptr;
-        hipError_t e = hipIpcOpenMemHandle(&base, mh, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return fail(h, NXS_ERR_COMM, "hipIpcOpenMemHandle(neighbour %d): %s", h->send_procs[k], hipGetErrorString(e));
-        h->ipc_peer_base.push_back(base);
+        if (b.pid == (long long)getpid()) {  // a handle of this process: its pointer is valid here, on another device after peer access
+            base = (void *)(uintptr_t)b.ptr;
+            if (b.device != h->device) {
+                const hipError_t pe = hipDeviceEnablePeerAccess(b.device, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(h, NXS_ERR_COMM, "hipDeviceEnablePeerAccess(%d -> %d): %s", h->device, b.device, hipGetErrorString(pe));
+                (void)hipGetLastError();
+            }
+        } else {
+            const hipError_t e = hipIpcOpenMemHandle(&base, b.mem, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return fail(h, NXS_ERR_COMM, "hipIpcOpenMemHandle(neighbour %d): %s", q, hipGetErrorString(e));
+            h->ipc_peer_base.push_back(base);
+        }
         double *mb = static_cast<double *>(base);
         seg[k] = mb + 2 * (size_t)peer_recv_offset[k];
         stride[k] = 2ll * peer_recv_total[k];
@@ -823,7 +935,8 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     int rc;
     unsigned long long *ctr = nullptr;
     if ((rc = dev_alloc(h, h->ipc_allocs, &ctr, 8))) return rc;
-    HIPCHK(h, hipMemset(ctr, 0, 8 * sizeof(unsigned long long)));
+    HIPCHK(h, hipMemsetAsync(ctr, 0, 8 * sizeof(unsigned long long), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     d.seq_push = ctr; d.seq_pull = ctr + 1;
     d.done_push = reinterpret_cast<unsigned int *>(ctr + 2); d.done_pull = reinterpret_cast<unsigned int *>(ctr + 3);
     d.error = reinterpret_cast<int *>(ctr + 4);
@@ -846,9 +959,12 @@ int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors) {
     HIPCHK(h, hipSetDevice(h->device));
     const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
     const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
+    // Odd rounds publish the way the in-kernel exchange of k_substep_fused / k_smooth_halo does -- every wave drains its stores,
+    // ONE release per launch, no acquire at the receiver -- even rounds the way k_halo_push does (a release per block): whichever
+    // variant the step uses later has then been through every link of this rank with checked payloads.
     for (int it = 0; it < rounds; ++it) {
         hipLaunchKernelGGL(k_halo_push, dim3(nblocks(ts)), dim3(BLOCK), 0, h->stream, (const double *)nullptr, h->dm.Nn, ts,
-                           h->d_send_index, h->d_send_seg, h->d_send_off, h->ipc, h->rank, 1);
+                           h->d_send_index, h->d_send_seg, h->d_send_off, h->ipc, h->rank, 1 + (it & 1));
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, (double *)nullptr, h->dm, h->ds, tr,
                            h->d_recv_index, h->d_recv_seg, h->d_recv_off, h->ipc, 0., 1, h->d_recv_procs, 0);
     }
@@ -1295,8 +1411,8 @@ int run_substeps(nxs_dyn_handle *h) {
     if (halo_in_kernel && h->d_hf_dirty) {  // (outside any stream capture)
         HaloFused tmp = h->hf;
         tmp.ipc = h->ipc;
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipMemcpy(h->d_hf, &tmp, sizeof tmp, hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpyAsync(h->d_hf, &tmp, sizeof tmp, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));  // tmp leaves scope
         h->d_hf_dirty = false;
     }
     auto pull_latest = [&](double *vec) {
@@ -1385,8 +1501,8 @@ int explicit_solve(nxs_dyn_handle *h) {
     (void)choose_depth(h);
     if (h->dp_dirty) {  // (outside any stream capture)
         if (!h->d_dp) HIPCHK(h, hipMalloc((void **)&h->d_dp, sizeof(DevParams)));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        HIPCHK(h, hipMemcpy(h->d_dp, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpyAsync(h->d_dp, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));  // h->dp may change right after
         h->dp_dirty = false;
     }
     LAUNCH(h, k_prep_elements, m.Ne, m, h->ds, h->dw, h->dp);
@@ -1465,6 +1581,9 @@ int explicit_solve(nxs_dyn_handle *h) {
         HIPCHK(h, hipGraphLaunch(h->tail_graph, h->stream));
     }
     if (timed) HIPCHK(h, hipEventRecord(h->cur[3], h->stream));
+    // a refused launch (a launch configuration the device rejects, e.g. more dynamic LDS than a CU has) is reported here,
+    // at the step that issued it, not as a generic error at the next synchronize
+    HIPCHK(h, hipGetLastError());
     return NXS_OK;
 }
 
@@ -1503,6 +1622,7 @@ int nxs_dyn_step(nxs_dyn_handle *h) {  // FE.cpp:8197-8214
     rc = explicit_solve(h);
     if (rc) { h->cur = nullptr; return rc; }
     LAUNCH(h, k_update, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    HIPCHK(h, hipGetLastError());
     if (k >= 0) {
         HIPCHK(h, hipEventRecord(h->cur[4], h->stream));
         h->set_pending[k] = true;
@@ -1519,7 +1639,8 @@ int nxs_dyn_synchronize(nxs_dyn_handle *h) {
     HIPCHK(h, hipGetLastError());
     if (h->ipc_ready) {
         int err = 0;
-        HIPCHK(h, hipMemcpy(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost));
+        HIPCHK(h, hipMemcpyAsync(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
         if (err) return fail(h, NXS_ERR_COMM, "device-direct halo exchange failed (%s)", err == 2 ? "self-test mismatch" : "a neighbour's flag did not arrive within 10 s");
     }
     return NXS_OK;

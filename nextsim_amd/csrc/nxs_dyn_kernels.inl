@@ -1224,7 +1224,8 @@ __global__ void __launch_bounds__(BLOCK) k_halo_unpack(double *__restrict__ vec,
 // Sequence numbers live in device memory, so the kernels replay unchanged from a hipGraph.  Two mailbox
 // buffers suffice: a neighbour cannot start exchange x+2 before it has received my exchange x+1, which I
 // send only after my pull of exchange x.  Every spin is bounded; a timeout raises ipc->error.
-// selftest != 0: the payload is a code of (rank, entry, sequence) instead of vec
+// selftest != 0: the payload is a code of (rank, entry, sequence) instead of vec; selftest == 2 publishes with the ONE release per
+// launch of the in-kernel exchange (k_substep_fused<HALO>, k_smooth_halo) instead of one per block
 __global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ vec, int Nn, int total, const int *__restrict__ index,
                                                      const int *__restrict__ seg_of, const int *__restrict__ offsets, IpcDev ipc,
                                                      int rank, int selftest) {
@@ -1250,7 +1251,7 @@ __global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     __shared__ int last;
-    if (threadIdx.x == 0) { __threadfence_system(); last = (atomicAdd(ipc.done_push, 1u) == gridDim.x - 1); }
+    if (threadIdx.x == 0) { if (selftest != 2) __threadfence_system(); last = (atomicAdd(ipc.done_push, 1u) == gridDim.x - 1); }
     __syncthreads();
     if (last) {
         __threadfence_system();

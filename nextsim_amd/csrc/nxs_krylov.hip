@@ -447,6 +447,7 @@ struct nxs_krylov_handle {
     nxs_krylov_exchange_fn exchange_fn = nullptr;
     nxs_krylov_allreduce_fn allreduce_fn = nullptr;
     void *user = nullptr;
+    long long n_rccl_allreduce = 0, n_rccl_exchange = 0;  // RCCL calls issued since create (nxs_krylov_comm_stats)
 };
 
 namespace {
@@ -523,6 +524,7 @@ int exchange(nxs_krylov_handle *h, double *vec) {
         const int e2 = h->rccl.GroupEnd();
         if (e == 0) e = e2;
         if (e != 0) return fail(NXS_ERR_COMM, "halo send/recv: %s", h->rccl.GetErrorString(e));
+        h->n_rccl_exchange++;
     }
     if (tr > 0) hipLaunchKernelGGL(k_unpack, dim3((tr + BS - 1) / BS), dim3(BS), 0, h->stream, tr, (const int *)h->d_recv_index, (const double *)h->d_recv_buf, vec);
     return NXS_OK;
@@ -530,7 +532,9 @@ int exchange(nxs_krylov_handle *h, double *vec) {
 
 // scal[slot .. slot+count) <- sum over the ranks
 int allreduce(nxs_krylov_handle *h, int slot, int count) {
-    if (!distributed(h)) return NXS_OK;
+    // a communicator of ONE rank still reduces (a sum over one rank): it costs an unusual caller a few microseconds per dot and
+    // lets a one-GPU box execute the very ncclAllReduce calls of the distributed solve (tests/test_krylov.py)
+    if (!distributed(h) && !h->comm) return NXS_OK;
     if (h->allreduce_fn) {
         KCHK(hipMemcpyAsync(h->h_scal, h->d_scal + slot, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         KCHK(hipStreamSynchronize(h->stream));
@@ -544,6 +548,7 @@ int allreduce(nxs_krylov_handle *h, int slot, int count) {
     const int ncclDouble = 8, ncclSum = 0;
     const int e = h->rccl.AllReduce(h->d_scal + slot, h->d_scal + slot, (size_t)count, ncclDouble, ncclSum, h->comm, h->stream);
     if (e != 0) return fail(NXS_ERR_COMM, "ncclAllReduce: %s", h->rccl.GetErrorString(e));
+    h->n_rccl_allreduce++;
     return NXS_OK;
 }
 
@@ -784,6 +789,13 @@ int nxs_krylov_comm_init(nxs_krylov_handle *h, const void *id128, int32_t rank, 
     const int e = init(&h->comm, nranks, id, rank);
     if (e != 0) { h->comm = nullptr; return fail(NXS_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, h->rccl.GetErrorString(e)); }
     h->rank = rank; h->nranks = nranks;
+    return NXS_OK;
+}
+
+int nxs_krylov_comm_stats(const nxs_krylov_handle *h, int64_t *rccl_allreduces, int64_t *rccl_exchanges) {
+    if (!h) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (rccl_allreduces) *rccl_allreduces = h->n_rccl_allreduce;
+    if (rccl_exchanges) *rccl_exchanges = h->n_rccl_exchange;
     return NXS_OK;
 }
 

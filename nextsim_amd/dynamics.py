@@ -59,6 +59,7 @@ def load_library():
     L.nxs_dyn_set_halo.argtypes = [H, P(_abi.Halo)]
     L.nxs_dyn_comm_unique_id.argtypes = [C.c_void_p]
     L.nxs_dyn_comm_init.argtypes = [H, C.c_void_p, C.c_int, C.c_int]
+    L.nxs_dyn_comm_selftest.argtypes = [H, P(C.c_int32)]
     L.nxs_dyn_set_halo_exchange_fn.argtypes = [H, HALO_FN, C.c_void_p]
     L.nxs_dyn_ipc_export.argtypes = [H, C.c_void_p]
     L.nxs_dyn_ipc_connect.argtypes = [H, C.c_void_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p]
@@ -102,7 +103,7 @@ IPC_BLOB_BYTES = 128
 EXPORTS = (
     "nxs_dyn_set_halo_exchange_fn", "nxs_dyn_ipc_export", "nxs_dyn_ipc_connect", "nxs_dyn_ipc_selftest",
     "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_create", "nxs_dyn_destroy",
-    "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init",
+    "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init", "nxs_dyn_comm_selftest",
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_set_forcing_pair", "nxs_dyn_set_forcing_time",
     "nxs_dyn_get_diag", "nxs_dyn_step",
     "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
@@ -196,6 +197,12 @@ class FiniteElementDynamics:
     def comm_init(self, unique_id: bytes, rank: int, nranks: int):
         buf = C.create_string_buffer(unique_id, 128)
         self._chk(self.L.nxs_dyn_comm_init(self.h, buf, rank, nranks))
+
+    def comm_selftest(self) -> int:
+        """Coded payloads through the RCCL communicator (self send/recv + the halo segments); returns the number of wrong values."""
+        err = C.c_int32(-1)
+        self._chk(self.L.nxs_dyn_comm_selftest(self.h, C.byref(err)))
+        return err.value
 
     def set_halo_exchange(self, fn):
         """fn(send: np.ndarray, recv: np.ndarray) -> None : host-staged updateGhosts through the caller's

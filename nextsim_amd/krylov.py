@@ -11,7 +11,7 @@ from .dynamics import NxsError, load_library
 
 KRYLOV_EXPORTS = ("nxs_fem_csr_pattern", "nxs_fem_colour_elements", "nxs_fem_poisson_solve", "nxs_krylov_solve", "nxs_krylov_last_error",
                   "nxs_krylov_create", "nxs_krylov_destroy", "nxs_krylov_set_matrix", "nxs_krylov_set_halo", "nxs_krylov_comm_init",
-                  "nxs_krylov_set_comm_fns", "nxs_krylov_spmv", "nxs_krylov_run", "nxs_krylov_info")
+                  "nxs_krylov_set_comm_fns", "nxs_krylov_spmv", "nxs_krylov_run", "nxs_krylov_info", "nxs_krylov_comm_stats")
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double))
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 CG, BICGSTAB = 0, 1
@@ -41,6 +41,7 @@ def _lib():
         L.nxs_krylov_spmv.argtypes = [C.c_void_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, P(C.c_double)]
         L.nxs_krylov_run.argtypes = [C.c_void_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_double, C.c_int32, P(C.c_int32), P(C.c_double), P(C.c_double)]
         L.nxs_krylov_info.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64), P(C.c_int64)]
+        L.nxs_krylov_comm_stats.argtypes = [C.c_void_p, P(C.c_int64), P(C.c_int64)]
         _decl = True
     return L
 
@@ -167,6 +168,11 @@ class Solver:
         it, res, ms = C.c_int32(), C.c_double(), C.c_double()
         _chk(self.L, self.L.nxs_krylov_run(self.h, _abi.dptr(b), _abi.dptr(x), int(method), float(rtol), int(max_iter), C.byref(it), C.byref(res), C.byref(ms)))
         return x, {"iterations": it.value, "rel_residual": res.value, "ms_solve": ms.value}
+
+    def comm_stats(self):
+        a, b = C.c_int64(), C.c_int64()
+        _chk(self.L, self.L.nxs_krylov_comm_stats(self.h, C.byref(a), C.byref(b)))
+        return {"rccl_allreduces": a.value, "rccl_exchanges": b.value}
 
     def info(self):
         a, b, c = C.c_int64(), C.c_int64(), C.c_int64()

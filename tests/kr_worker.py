@@ -80,6 +80,13 @@ try:
         s.set_halo(lm)
         x, info = s.solve(bN[own], method=krylov.BICGSTAB, rtol=1e-12, max_iter=5000)
         report["bicgstab"] = dict(info, err=float(np.abs(x - xs[own]).max() / np.abs(xs).max()))
+        report["comm_stats"] = s.comm_stats()
+        if mode == "rccl" and world == 1:   # a sum over one rank: the bits of the solve without any communicator
+            s1 = krylov.Solver(device=int(os.environ.get("NXS_TEST_DEVICE", "0")))
+            s1.set_matrix(rp2, ci2, va2, n_cols=n_loc)
+            x1, info1 = s1.solve(bN[own], method=krylov.BICGSTAB, rtol=1e-12, max_iter=5000)
+            report["same_bits_as_no_communicator"] = bool(np.array_equal(x, x1) and info1["iterations"] == info["iterations"])
+            s1.close()
         s.close()
     report["ok"] = True
 except Exception as e:  # noqa: BLE001

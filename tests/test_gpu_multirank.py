@@ -16,22 +16,54 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run(world, kind, nsteps, tmp_path, transport="rccl", over=None):
+def _start(world, kind, nsteps, tmp_path, transport="rccl", over=None, ranks_per_proc=1):
+    """world ranks as world / ranks_per_proc processes (a GPU box admits at most 6 processes on its card)."""
+    assert world % ranks_per_proc == 0 and world // ranks_per_proc <= 6
+    nproc = world // ranks_per_proc
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for rank in range(nproc):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(nproc), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", NXS_RANKS_PER_PROC=str(ranks_per_proc))
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "mr_worker.py"), str(tmp_path), kind, str(nsteps), transport,
                                        json.dumps(over or {})], env=env))
+    return procs
+
+
+def _finish(procs, world, tmp_path, timeout=300):
     for p in procs:
         try:
-            p.wait(timeout=300)
+            p.wait(timeout=timeout)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             pytest.fail("multi-rank workers hung")
     return [json.load(open(tmp_path / f"report{r}.json")) for r in range(world)]
+
+
+def _run(world, kind, nsteps, tmp_path, transport="rccl", over=None, ranks_per_proc=1):
+    return _finish(_start(world, kind, nsteps, tmp_path, transport, over, ranks_per_proc), world, tmp_path)
+
+
+def _against_the_multirank_oracle(kind, world, nsteps, tmp_path, reps, tol):
+    """The parent's half of a dump-mode run: the in-process multi-rank oracle, once, against every rank's dumped state."""
+    import numpy as np
+    import cases
+    from oracle import pyoracle as O
+    gm, p, g, lms, fields = cases.make_case(kind, nparts=world)
+    ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    for _ in range(nsteps):
+        O.multirank_step(ranks)
+    worst = {}
+    for r in reps:
+        assert r["ok"], r
+        assert r["crash"] == 0
+        z = np.load(tmp_path / f"state{r['rank']}.npz")
+        for k in z.files:
+            e = cases.rel_err(z[k], ranks[r["rank"]].arr[k])
+            worst[k] = max(worst.get(k, 0.), e)
+            assert e <= tol, (r["rank"], k, e)
+    return worst
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -92,6 +124,57 @@ def test_in_kernel_halo_exchange_with_the_vp_rheologies(dyn, tmp_path):
         assert r["crash"] == 0
         for k, e in r["errs"].items():
             assert e <= 1e-9, (r["rank"], k, e)
+
+
+def test_rccl_on_one_rank_runs_the_dlopened_entry_points(tmp_path):
+    """RCCL refuses two ranks on one device, but a communicator of ONE rank is legal: ncclGetUniqueId, ncclCommInitRank with
+    the by-value 128-byte id, and a grouped ncclSend/ncclRecv of coded payloads to itself on the handle's stream
+    (nxs_dyn_comm_selftest) -- the dlopen, the symbol table, the stream use and the error mapping of the RCCL transport
+    execute on hardware, then a step runs with the communicator attached (FE.cpp:13963-13996 is the code it stands for)."""
+    reps = _run(1, "small", 1, tmp_path, "rccl")
+    r = reps[0]
+    assert r["ok"], r
+    assert r["comm_selftest_errors"] == 0
+    for k, e in r["errs"].items():
+        assert e <= 1e-10, (k, e)
+
+
+@pytest.mark.parametrize("transport,ranks_per_proc", [("ipc", 2), ("host", 4)])
+def test_config3_10km_over_8_ranks_matches_the_multirank_oracle(transport, ranks_per_proc, tmp_path):
+    """BASELINE config 3 (10 km mesh domain-decomposed over 8 ranks), ranks sharing GPU 0, one step against the 8-rank oracle.
+    "ipc": 4 processes x 2 ranks -- mailboxes reached through hipIpc across processes and directly inside a process, the
+    exchange INSIDE the sub-step and smoother kernels (8 small grids co-schedule on one device), which must also give the bits
+    of the separate push / pull kernels.  "host": 2 processes x 4 ranks through the caller's communicator."""
+    procs = _start(8, "10km", 1, tmp_path, transport, over={"dump": True}, ranks_per_proc=ranks_per_proc)
+    reps = _finish(procs, 8, tmp_path)
+    if transport == "ipc":
+        for r in reps:
+            assert r["ok"], r
+            assert r["ipc_selftest"] is True and r["fused_equals_separate"] is True, r
+            assert r["launches_fused"] < r["launches_separate"]
+    _against_the_multirank_oracle("10km", 8, 1, tmp_path, reps, 1e-10)
+
+
+def test_config4_2km_over_8_ranks_matches_the_multirank_oracle(tmp_path):
+    """BASELINE config 4 (2 km mesh, BBM, 120 sub-steps, 8 ranks of ~183 k triangles), ranks sharing GPU 0 as 4 processes x 2
+    ranks, one step against the 8-rank oracle.  Separate push / pull kernels: eight grids that each fill the device cannot
+    co-schedule, so the in-kernel exchange would starve on ONE device; on eight devices it is the default."""
+    procs = _start(8, "2km", 1, tmp_path, "ipc_sep", over={"dump": True}, ranks_per_proc=2)
+    import numpy as np, cases
+    from oracle import pyoracle as O
+    gm, p, g, lms, fields = cases.make_case("2km", nparts=8)       # the oracle runs beside the workers
+    ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    O.multirank_step(ranks)
+    reps = _finish(procs, 8, tmp_path, timeout=600)
+    for r in reps:
+        assert r["ok"], r
+        assert r["ipc_selftest"] is True and r["crash"] == 0
+        z = np.load(tmp_path / f"state{r['rank']}.npz")
+        for k in z.files:
+            assert cases.rel_err(z[k], ranks[r["rank"]].arr[k]) <= 1e-10, (r["rank"], k)
+    # the partition is the one the bench strong-scales: ~1/8 of the triangles each, 2-5 neighbours, ~1.2 k shared nodes per neighbour
+    assert max(lm.local_nelements for lm in lms) < 1.05 * gm.num_elements / 8
+    assert all(2 <= len(lm.send_procs) <= 7 for lm in lms)
 
 
 @pytest.mark.parametrize("world", [2, 3])

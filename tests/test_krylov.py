@@ -229,6 +229,20 @@ def test_distributed_cg_and_bicgstab_through_the_callers_communicator(world, tmp
 
 
 @pytest.mark.gpu
+def test_rccl_all_reduce_on_a_communicator_of_one_rank(tmp_path):
+    """RCCL refuses two ranks on one device; a communicator of ONE rank is legal, and the solver reduces through it whenever one
+    is attached: every dot of CG and BiCGStab is followed by the ncclAllReduce of the distributed solve, on the solver's stream,
+    in place -- the dlopen'ed entry point, its argument order and the stream use execute on hardware.  A sum over one rank is the
+    identity, so the result must have the bits of the solve without a communicator."""
+    reps = _run_workers(1, "rccl", tmp_path)
+    r = reps[0]
+    assert r["ok"], r
+    assert r["cg"]["err"] <= 1e-8 and r["bicgstab"]["err"] <= 1e-8
+    assert r["comm_stats"]["rccl_allreduces"] >= 2 * r["cg"]["iterations"] + 3 * r["bicgstab"]["iterations"]
+    assert r["same_bits_as_no_communicator"] is True
+
+
+@pytest.mark.gpu
 def test_distributed_cg_over_rccl(tmp_path):
     """RCCL may refuse several ranks on one device (a one-GPU box): skipped with its message then."""
     reps = _run_workers(2, "rccl", tmp_path)
