@@ -42,36 +42,54 @@ def parse():
     return ap.parse_args()
 
 
+PMC_PROFILES = ("profiles/r02_pmc_traffic.json", "profiles/r01_v2_pmc_traffic.json")
+
+
 def pmc_traffic(mesh, launches_per_substep, world):
-    """HBM bytes per launch of the sub-step kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_v2_pmc_traffic.json: FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes, same kernel, same
-    mesh).  PMC counters cannot be collected from inside this process; null when the profile does not
-    apply to this run."""
+    """(HBM bytes per launch of the sub-step kernel, the file they come from): the committed rocprofv3 --pmc passes
+    (FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes, same command, same kernel, same mesh -- corrected as
+    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside this process, so this is a
+    REPLAY of the committed profile, labelled as such in the JSON line; (None, None) when no profile applies to this run."""
     if mesh != "2km" or launches_per_substep != 1 or world != 1:
-        return None
-    try:
-        prof = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_traffic.json")))
-        for k, v in prof["kernels"].items():
-            if k.startswith("k_substep_fused"):
-                return v["hbm_bytes_per_launch"]
-    except Exception:  # noqa: BLE001
-        pass
-    return None
+        return None, None
+    for rel in PMC_PROFILES:
+        try:
+            prof = json.load(open(os.path.join(ROOT, rel)))
+            for k, v in prof["kernels"].items():
+                if k.startswith("k_substep_fused"):
+                    return v["hbm_bytes_per_launch"], rel
+        except Exception:  # noqa: BLE001
+            continue
+    return None, None
 
 
-def build_case(kind, nparts, rank):
+_MESHES = {}
+
+
+def build_case(kind, nparts, rank, state="arctic"):
     from nextsim_amd import forcing as F, mesh as M
-    gm = M.make_mesh(kind)
+    if kind not in _MESHES:
+        _MESHES[kind] = M.make_mesh(kind)
+    gm = _MESHES[kind]
     p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
-    g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
+    g = F.global_fields(gm, p, state, C_fix, C_alea)
     lm = M.localize(gm, nparts)[rank]
     f = F.localize_fields(g, lm, gm.num_nodes)
+    f["_cover"] = ice_cover(g)      # of the whole mesh, not of this rank's partition
     return gm, p, lm, f
 
 
-def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn):
+def ice_cover(f):
+    """Fractions of the triangles that are ice free / in the 0 < A <= 0.1 band updateSigmaDamage skips (FE.cpp:4146)."""
+    if "_cover" in f:
+        return f["_cover"]
+    c = f["conc"]
+    return {"ice_free_fraction": float((c == 0).mean()), "low_concentration_fraction": float(((c > 0) & (c <= 0.1)).mean())}
+
+
+def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, state="arctic"):
     from nextsim_amd import dynamics
-    gm, p, lm, f = build_case(kind, world, rank)
+    gm, p, lm, f = build_case(kind, world, rank, state)
     fe = dynamics.FiniteElementDynamics(p, device=local_rank)
     fe.set_mesh(lm)
     transport = "none"
@@ -104,7 +122,7 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn):
     tm = fe.timing()
     crash = fe.checkFieldsFast()
     fe.close()
-    return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash, transport=transport)
+    return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash, transport=transport)  # (f: rank-local fields)
 
 
 def choose_halo_kernels(fe, f, rank, world, dist, torch):
@@ -195,7 +213,16 @@ def setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn):
     t = torch.tensor([ok], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     if float(t[0]) == 1.0:
-        return "rccl"
+        bad = 1.0
+        try:   # checked payloads through every halo segment before the transport is trusted (collective)
+            bad = float(fe.comm_selftest())
+        except dynamics.NxsError as e:
+            print(f"[bench rank {rank}] RCCL self-test failed: {e}", file=sys.stderr, flush=True)
+        t = torch.tensor([bad], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if float(t[0]) == 0.0:
+            return "rccl (grouped ncclSend/ncclRecv, self-test passed)"
+        print(f"[bench rank {rank}] RCCL self-test: {int(t[0])} wrong values somewhere; host-staged instead", file=sys.stderr, flush=True)
 
     def exchange(send, recv):
         reqs, bufs = [], []
@@ -235,6 +262,65 @@ def aux_spmv(gm, reps=100):
     return {"workload": f"SpMV, 2-dof (u, v) block pattern of the mesh: {A.shape[0]} rows, {inf['nnz']} non-zeros (extension, no live reference)",
             "us_per_spmv": ms * 1e3, "achieved": inf["spmv_bytes"] / ms / 1e6, "unit": "GB/s", "peak": 8000.0,
             "frac": inf["spmv_bytes"] / ms / 1e6 / 8000.0, "matches_scipy": ok}
+
+
+def split_adapted_mesh(gm, frac, seed):
+    """What a regrid leaves behind, at bench size and vectorised: `frac` of the triangles are split by a new interior vertex
+    (3 new triangles each), every other triangle survives with its three vertices, the triangles are renumbered.  Returns
+    x, y, tri (0-based), PreviousNumbering (1-based old vertex number, 0 = created by the remesher)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    tri = gm.tri
+    ne, nn = tri.shape[0], gm.num_nodes
+    pick = np.sort(rng.choice(ne, size=max(1, int(frac * ne)), replace=False))
+    w = rng.dirichlet([2.0, 2.0, 2.0], pick.size)
+    a, b, c = tri[pick, 0], tri[pick, 1], tri[pick, 2]
+    xm = w[:, 0] * gm.x[a] + w[:, 1] * gm.x[b] + w[:, 2] * gm.x[c]
+    ym = w[:, 0] * gm.y[a] + w[:, 1] * gm.y[b] + w[:, 2] * gm.y[c]
+    m = nn + np.arange(pick.size)
+    new = tri.copy()
+    new[pick] = np.column_stack([a, b, m])
+    new = np.vstack([new, np.column_stack([b, c, m]), np.column_stack([c, a, m])]).astype(np.int32)
+    new = new[rng.permutation(new.shape[0])]
+    prev = np.concatenate([np.arange(1, nn + 1), np.zeros(pick.size)]).astype(np.float64)
+    return np.concatenate([gm.x, xm]), np.concatenate([gm.y, ym]), np.ascontiguousarray(new), prev
+
+
+def aux_regrid(gm, with_cpu=True):
+    """BASELINE config 5 at 2 km size: the two interpolation kernels of a regrid (FE.cpp:3071-3154) -- P1 interpolation of the 6
+    nodal variables onto the new mesh's nodes and the conservative remapping of 30 element variables onto its triangles --
+    with the real contrib/bamg routines (oracle/_ref, one host core, what the reference's root rank runs) timed beside them
+    and the results compared bit for bit."""
+    import numpy as np
+    from nextsim_amd.interp import ConservativeRemappingMeshToMesh, InterpFromMeshToMesh2dx
+    rng = np.random.default_rng(2)
+    xn, yn, trin, prev = split_adapted_mesh(gm, 0.03, 9)
+    idx_old = (gm.tri + 1).astype(np.int32).ravel()
+    nodal = rng.standard_normal((gm.num_nodes, 6))
+    elemental = rng.random((gm.num_elements, 30))
+    for _ in range(2):   # second call: warm allocator
+        t0 = time.perf_counter(); vi, ii = InterpFromMeshToMesh2dx(idx_old, gm.x, gm.y, nodal, xn, yn, False, 0.0, return_info=True); wi = time.perf_counter() - t0
+    for _ in range(2):
+        t0 = time.perf_counter(); vr, ir = ConservativeRemappingMeshToMesh(elemental, idx_old, gm.x, gm.y, trin + 1, xn, yn, prev, 0, return_info=True); wr = time.perf_counter() - t0
+    out = {"workload": f"regrid of the 2 km mesh: {gm.num_elements} old triangles -> {trin.shape[0]} new ({100 * (ir['visits'] == 1).mean():.1f} % overlap a single old triangle), "
+                       f"6 nodal variables at {xn.size} nodes (isdefault=false as FE.cpp:3131) + conservative remap of 30 element variables",
+           "interp_kernel_ms": ii["kernel_ms"], "interp_call_ms": wi * 1e3, "remap_kernel_ms": ir["kernel_ms"], "remap_call_ms": wr * 1e3,
+           "remap_failed": int(ir["num_failed"]),
+           "note": "call = host tables (bucket grid, connectivity) + PCIe both ways + kernel; the reference runs both serially on its root rank"}
+    if with_cpu:
+        try:
+            from oracle import pyoracle as O
+            if O.bamg_shim() is None:
+                raise RuntimeError("oracle/_ref not built on this box")
+            t0 = time.perf_counter(); ref_i = O.bamg_interp_mesh_to_mesh(idx_old, gm.x, gm.y, nodal, xn, yn, False, 0.0); ci = time.perf_counter() - t0
+            t0 = time.perf_counter(); ref_r = O.bamg_conservative_remap(gm.tri + 1, gm.x, gm.y, trin + 1, xn, yn, prev, 0, elemental); cr = time.perf_counter() - t0
+            out["cpu_reference"] = {"kind": "reference", "what": "contrib/bamg InterpFromMeshToMesh2dx + ConservativeRemappingMeshToMesh compiled from the reference's sources, 1 host core",
+                                    "interp_ms": ci * 1e3, "remap_ms": cr * 1e3,
+                                    "interp_rows_identical": float(np.all(vi == ref_i, axis=1).mean()),
+                                    "remap_rows_identical": float(np.all((vr == ref_r) | (np.isnan(vr) & np.isnan(ref_r)), axis=1).mean())}
+        except Exception as e:  # noqa: BLE001
+            out["cpu_reference"] = {"error": repr(e)}
+    return out
 
 
 def cpu_baseline(kind, nsteps=1):
@@ -323,17 +409,28 @@ def main():
     gm, p, lm, tm = res["gm"], res["p"], res["lm"], res["timing"]
     S = p.substeps
     value = gm.num_elements * S * args.steps / res["dt"]
+    # which physical devices the ranks really ran on (a test box may wrap several ranks onto one GPU: its numbers then bound the
+    # protocol overhead, they are not a scaling measurement)
+    devices = [local_rank]
+    if world > 1:
+        devices = [None] * world
+        dist.all_gather_object(devices, (os.environ.get("GROUP_RANK", "0"), local_rank))
+    distinct_devices = len(set(devices))
 
     # roofline of the dominant kernel(s): the sub-step loop (sigma/damage + assembly + nodal solve)
     launches_per_substep = max(tm["substep_launches"] // S, 1)
     substep_ms = tm["substeps_ms"] / S                      # HIP events on the kernel's stream, avg over timed steps
     bytes_per_substep = BYTES_PER_ELEMENT * lm.num_elements + BYTES_PER_NODE * lm.num_nodes
     achieved = bytes_per_substep / (substep_ms * 1e-3) / 1e9
+    traffic, traffic_source = pmc_traffic(args.mesh, launches_per_substep, world)
+    achieved_counter = traffic / (substep_ms * 1e-3) / 1e9 if traffic else None
     out = {
         "metric": "element-updates/sec per dynamics step",
         "value": value,
         "unit": "element-updates/s",
         "n_gpus": world,
+        "distinct_devices": distinct_devices,
+        "ranks_share_device": distinct_devices < world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": res["dt"] / args.steps * 1e3,
@@ -345,9 +442,9 @@ def main():
         "config": {
             "workload": f"pan-Arctic-like synthetic mesh '{args.mesh}' ({gm.num_elements} triangles, {gm.num_nodes} nodes), "
                         f"BBM rheology, dt=200 s, {S} sub-steps, 50 smoother sweeps, update(); "
-                        f"domain-decomposed over {world} GPU(s)",
+                        f"domain-decomposed into {world} partition(s) on {distinct_devices} GPU(s)",
             "mesh": args.mesh, "elements": gm.num_elements, "nodes": gm.num_nodes, "substeps": S,
-            "rheology": "bbm", "partitions": world, "halo_transport": res["transport"],
+            "rheology": "bbm", "partitions": world, "halo_transport": res["transport"], **ice_cover(res["f"]),
         },
         "roofline": {
             "bound": "hbm",
@@ -357,10 +454,17 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args.mesh, launches_per_substep, world),
+            "traffic": traffic,
+            "traffic_source": (traffic_source + " -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; replayed "
+                               "here, NOT measured in this run (counters cannot be read in-process)") if traffic_source else None,
+            "achieved_counter": achieved_counter,
+            "frac_counter": achieved_counter / HBM_PEAK_GBS if achieved_counter else None,
             "bytes_per_launch_group": bytes_per_substep,
             "avg_ms_per_launch_group": substep_ms,
-            "note": "rank-0 partition; algorithmic bytes = 172 B/element + 217 B/node per sub-step",
+            "note": "rank-0 partition. achieved / frac = ALGORITHMIC bytes (SURVEY 8d: 172 B/element + 217 B/node per sub-step) over the "
+                    "event-timed launch; the kernel moves fewer bytes than that model (shape coefficients rebuilt from staged coordinates, "
+                    "M_UM / M_UT streamed once per step), so frac can exceed what HBM delivers (~6.3 TB/s = 0.79): achieved_counter / "
+                    "frac_counter = the counter bytes over the same time is the real HBM rate",
         },
         "phases_ms": {k: tm[k] for k in ("prep_ms", "substeps_ms", "smoother_ms", "update_ms", "total_ms")},
         "fields_ok": res["crash"] == 0,
@@ -389,6 +493,23 @@ def main():
         except Exception as e:  # noqa: BLE001 -- never lose the main line over a secondary measurement
             out["aux_10km"] = {"error": repr(e)}
     if world == 1 and not args.no_aux and args.mesh == "2km":
+        aux_args = argparse.Namespace(**vars(args)); aux_args.steps = min(args.steps, 10); aux_args.warmup = min(args.warmup, 2)
+        try:   # the same mesh with 29 % of the triangles ice free and 4 % in the 0 < A <= 0.1 band: the open-water smoother (FE.cpp:10578-10611),
+            # its tail and the skipped-element path do real work here
+            r3 = run_gpu("2km", aux_args, 0, 1, local_rank, dist, torch, None, state="arctic_ow")
+            out["aux_openwater"] = {
+                "workload": "mesh '2km', state 'arctic_ow' (half the rim ice free): the 50 smoother sweeps, the open-water mesh move and the "
+                            "concentration cut-off of updateSigmaDamage are exercised", **ice_cover(r3["f"]),
+                "value": r3["gm"].num_elements * S * aux_args.steps / r3["dt"], "unit": "element-updates/s",
+                "ms_per_step": r3["dt"] / aux_args.steps * 1e3, "fields_ok": r3["crash"] == 0,
+                "phases_ms": {k: r3["timing"][k] for k in ("prep_ms", "substeps_ms", "smoother_ms", "update_ms", "total_ms")},
+            }
+        except Exception as e:  # noqa: BLE001
+            out["aux_openwater"] = {"error": repr(e)}
+        try:   # BASELINE config 5: the regrid interpolation kernels at 2 km size, the real bamg routines beside them
+            out["aux_regrid"] = aux_regrid(res["gm"], with_cpu=not args.no_cpu_baseline)
+        except Exception as e:  # noqa: BLE001
+            out["aux_regrid"] = {"error": repr(e)}
         try:   # the N4 extension (no live reference): SpMV of the 2-dof block pattern a momentum matrix would have on this mesh
             out["aux_spmv"] = aux_spmv(res["gm"])
         except Exception as e:  # noqa: BLE001 -- never lose the main line over the extension

@@ -280,6 +280,9 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *   "pin_host"     1 = page-lock the caller's state / forcing vectors the first time they are seen (hipHostRegister), so the
  *                  per-step copies of a host that keeps its thermodynamics on the CPU run at PCIe speed; registrations are
  *                  dropped at set_mesh / destroy / pin_host 0.  Default 0: the library does not touch the caller's pages.
+ *   "work_arrays"  1 = the prep kernels also fill the one-array-per-quantity work vectors (M_shape_coeff, element mass, the per-step
+ *                  element constants, rlmass, C_bu, grad_ssh, fcor) that only the fused = 0 kernels and nxs_dyn_debug_array read;
+ *                  default 0: with fused != 0 the step writes its records only
  *   "halo_fused"   device-direct transport only: 1 = updateGhosts inside the fused sub-step kernel (default),
  *                  0 = separate push / pull kernels */
 NXS_API int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);

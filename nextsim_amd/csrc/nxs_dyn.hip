@@ -144,6 +144,9 @@ struct nxs_dyn_handle {
     double *f_snap[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // wind0, wind1, ocean0, ocean1, ssh0, ssh1 (forcing pair)
     bool have_pair = false;
     std::vector<void *> forcing_allocs;
+    int sig_loc = 0;                       // where M_sigma / M_damage are current: 0 = the state arrays, 1 = the records in S4a (left there by
+                                           // the fused sub-step loop; k_update works on them, the arrays follow on demand: ensure_arrays)
+    int work_arrays = 0;                   // option "work_arrays": the prep kernels also fill the one-array-per-quantity work vectors
     int pin_host = 0;                      // option "pin_host": page-lock the caller's state / forcing vectors on first use
     std::map<const void *, size_t> pinned; // what this handle has registered with hipHostRegister
     int halo_fused = 1;                    // option "halo_fused"
@@ -316,6 +319,17 @@ struct IpcBlob {
 static_assert(sizeof(IpcBlob) <= NXS_IPC_BLOB_BYTES, "blob too small");
 constexpr unsigned long long IPC_MAGIC = 0x4e58534950433031ull;
 
+// Layout of a mailbox allocation (doubles): [2 halves of 2*tr] [flags: nr] [sflags: nr] [sstatic: nr] [pad] [NXS_SMOOTH_SWEEPS slots of 2*tr]
+struct IpcLayout { size_t flags, sflags, sstatic, slots, total; };
+IpcLayout ipc_layout(size_t tr, int nr) {
+    const size_t n = (size_t)std::max(nr, 1);
+    IpcLayout l;
+    l.flags = 4 * tr; l.sflags = l.flags + n; l.sstatic = l.sflags + n;
+    l.slots = (l.sstatic + n + 1) & ~(size_t)1;  // 16-byte aligned
+    l.total = l.slots + (size_t)NXS_SMOOTH_SWEEPS * 2 * tr + 16;
+    return l;
+}
+
 void ipc_disconnect(nxs_dyn_handle *h) {  // the peer mappings and the tables of one nxs_dyn_ipc_connect
     for (void *p : h->ipc_peer_base) if (p) (void)hipIpcCloseMemHandle(p);
     h->ipc_peer_base.clear();
@@ -343,6 +357,13 @@ void unpin_all(nxs_dyn_handle *h) {
     for (auto &kv : h->pinned) (void)hipHostUnregister(const_cast<void *>(kv.first));
     (void)hipGetLastError();
     h->pinned.clear();
+}
+
+// M_sigma / M_damage back into their arrays when the sub-step loop left them as records
+void ensure_arrays(nxs_dyn_handle *h) {
+    if (h->sig_loc == 0 || !h->have_mesh) return;
+    hipLaunchKernelGGL(k_unpack_state, dim3(nblocks(h->dm.Ne)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, h->dp.dynamics_type == NXS_DYN_BBM ? 1 : 0, (const double *)h->ds.S4a);
+    h->sig_loc = 0;
 }
 
 void release_graph(nxs_dyn_handle *h) {
@@ -454,6 +475,10 @@ int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
     if (!h) return NXS_ERR_INVALID;
     int rc = check_params(h, p);
     if (rc) return rc;
+    if (h->sig_loc) {  // the records' damage slot belongs to the OLD dynamics type
+        HIPCHK(h, hipSetDevice(h->device));
+        ensure_arrays(h);
+    }
     h->params = *p;
     derive_params(h);
     return NXS_OK;
@@ -481,6 +506,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         if (value != 0 && (value < 16 || value > 512)) return fail(h, NXS_ERR_INVALID, "pair_nodes must be 0 (auto) or in [16,512]");
         h->pair_nodes = (int)value; h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
+    if (!std::strcmp(key, "work_arrays")) { h->work_arrays = value != 0; return NXS_OK; }
     if (!std::strcmp(key, "pin_host")) { h->pin_host = value != 0; if (!h->pin_host) unpin_all(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_fused")) { h->halo_fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
@@ -540,6 +566,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     unpin_all(h);
     h->ring = VTRing{};
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
+    h->sig_loc = 0;
     h->rank = 0; h->nranks = 1;
     h->send_procs.clear(); h->recv_procs.clear(); h->send_offsets.assign(1, 0); h->recv_offsets.assign(1, 0);
 
@@ -651,7 +678,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(s.cyoung, ne); A(s.hyoung, ne); A(s.hsyoung, ne); A(s.cmyi, ne); A(s.tmyi, ne);
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
-    A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 10 * ne);
+    A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 8 * ne); A(w.dragsurf, ne);
     A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn)); A(w.erec, 6 * ne); A(w.nrec, 10 * (size_t)Nn);
     A(w.force, 6 * ne);
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
@@ -846,7 +873,7 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
     ipc_release(h);
     const int nr = (int)h->recv_procs.size();
     const size_t tr = (size_t)h->recv_offsets[nr];
-    const size_t bytes = (4 * tr + (size_t)std::max(nr, 1) + 16) * sizeof(double);  // 2 buffers of 2*tr doubles + flags
+    const size_t bytes = ipc_layout(tr, nr).total * sizeof(double);
     // uncached (MTYPE_UC) device memory: neither my L2 nor a neighbour's can hold a stale copy of a mailbox line or a flag.
     // The kernels rely on that: a receiver takes no acquire after its flag wait and a sender releases once per launch.  With
     // ordinary (cached) device memory a receiver's L2 could serve a stale line, because peer stores do not pass through the home
@@ -894,9 +921,9 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     HIPCHK(h, hipStreamSynchronize(h->stream));
     release_graph(h);
     ipc_disconnect(h);  // a second connect replaces the first: its peer mappings and tables go
-    std::vector<double *> seg(ns);
+    std::vector<double *> seg(ns), sseg(ns);
     std::vector<long long> stride(ns);
-    std::vector<unsigned long long *> flag(ns);
+    std::vector<unsigned long long *> flag(ns), sflag(ns), sstat(ns);
     for (int k = 0; k < ns; ++k) {
         // the tables are checked against what the neighbour itself published: a kernel that trusted a wrong offset would store
         // outside the neighbour's mailbox, in another process's memory
@@ -925,12 +952,20 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
         double *mb = static_cast<double *>(base);
         seg[k] = mb + 2 * (size_t)peer_recv_offset[k];
         stride[k] = 2ll * peer_recv_total[k];
-        flag[k] = reinterpret_cast<unsigned long long *>(mb + 4 * (size_t)peer_recv_total[k]) + peer_flag_slot[k];
+        const IpcLayout pl = ipc_layout((size_t)b.tr, b.nr);
+        flag[k] = reinterpret_cast<unsigned long long *>(mb + pl.flags) + peer_flag_slot[k];
+        sflag[k] = reinterpret_cast<unsigned long long *>(mb + pl.sflags) + peer_flag_slot[k];
+        sstat[k] = reinterpret_cast<unsigned long long *>(mb + pl.sstatic) + peer_flag_slot[k];
+        sseg[k] = mb + pl.slots + 2 * (size_t)peer_recv_offset[k];
     }
     IpcDev &d = h->ipc;
     const size_t tr = (size_t)h->recv_offsets[nr];
+    const IpcLayout ml = ipc_layout(tr, nr);
     d.mailbox = static_cast<double *>(h->ipc_block);
-    d.flags = reinterpret_cast<unsigned long long *>(d.mailbox + 4 * tr);
+    d.flags = reinterpret_cast<unsigned long long *>(d.mailbox + ml.flags);
+    d.sflags = reinterpret_cast<unsigned long long *>(d.mailbox + ml.sflags);
+    d.sstatic = reinterpret_cast<unsigned long long *>(d.mailbox + ml.sstatic);
+    d.smb = d.mailbox + ml.slots;
     d.tr = (int)tr; d.ns = ns; d.nr = nr;
     int rc;
     unsigned long long *ctr = nullptr;
@@ -945,6 +980,22 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     if ((rc = dev_upload(h, h->ipc_allocs, &dstr, stride))) return rc;
     { const unsigned long long **tmp; std::vector<const unsigned long long *> v(flag.begin(), flag.end()); if ((rc = dev_upload(h, h->ipc_allocs, (const unsigned long long *const **)&tmp, v))) return rc; dfl = (unsigned long long *const *)tmp; }
     d.peer_seg = dseg; d.peer_parity_stride = dstr; d.peer_flag = dfl;
+    {   // the smoother's mailbox: peer addresses, my epoch, the static words
+        const double **tmp; std::vector<const double *> v(sseg.begin(), sseg.end());
+        if ((rc = dev_upload(h, h->ipc_allocs, (const double *const **)&tmp, v))) return rc;
+        d.peer_smb = (double *const *)tmp;
+        const unsigned long long **t2; std::vector<const unsigned long long *> v2(sflag.begin(), sflag.end());
+        if ((rc = dev_upload(h, h->ipc_allocs, (const unsigned long long *const **)&t2, v2))) return rc;
+        d.peer_sflag = (unsigned long long *const *)t2;
+        std::vector<const unsigned long long *> v3(sstat.begin(), sstat.end());
+        if ((rc = dev_upload(h, h->ipc_allocs, (const unsigned long long *const **)&t2, v3))) return rc;
+        d.peer_sstatic = (unsigned long long *const *)t2;
+        d.epoch = ctr + 5;  // (zeroed above)
+        const int *ip;
+        std::vector<int> ones((size_t)std::max(ns, 1), 1), zeros((size_t)std::max(nr, 1), 0);
+        if ((rc = dev_upload(h, h->ipc_allocs, &ip, ones))) return rc; d.my_static = const_cast<int *>(ip);
+        if ((rc = dev_upload(h, h->ipc_allocs, &ip, zeros))) return rc; d.peer_static = const_cast<int *>(ip);
+    }
     h->ipc_ready = true;
     h->d_hf_dirty = true;
     release_graph(h);
@@ -1003,6 +1054,7 @@ int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s) {
     // (a host whose thermodynamics only touched concentration and thickness uploads only those)
     if (!h->have_state)
         for (auto &c : cp) if (!c.src) return fail(h, NXS_ERR_INVALID, "put_state: %s is NULL", c.name);
+    if (s->damage || s->sigma[0] || s->sigma[1] || s->sigma[2]) ensure_arrays(h);  // the members not given must not be lost
     for (auto &c : cp) if (c.src) pin_host_buffer(h, c.src, c.bytes);
     for (auto &c : cp) if (c.src) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1024,6 +1076,7 @@ int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s) {
         {s->conc_young, d.cyoung, ne}, {s->h_young, d.hyoung, ne}, {s->hs_young, d.hsyoung, ne},
         {s->conc_myi, d.cmyi, ne}, {s->thick_myi, d.tmyi, ne},
     };
+    if (s->damage || s->sigma[0] || s->sigma[1] || s->sigma[2]) ensure_arrays(h);
     for (auto &c : cp) if (c.dst) pin_host_buffer(h, c.dst, c.bytes);
     for (auto &c : cp) if (c.dst) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1103,6 +1156,8 @@ int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_
     };
     for (auto &t : tab)
         if (!std::strcmp(t.nm, name)) {
+            if (h->fused != 0 && !h->work_arrays && std::strcmp(name, "VTM") && std::strcmp(name, "node_mass"))
+                return fail(h, NXS_ERR_STATE, "debug_array %s: the fused path fills records only; set option work_arrays = 1 before the step", name);
             if (n != t.len) return fail(h, NXS_ERR_INVALID, "debug_array %s has %lld entries, caller asked %lld", name, (long long)t.len, (long long)n);
             HIPCHK(h, hipMemcpyAsync(out, t.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(h, hipStreamSynchronize(h->stream));
@@ -1271,12 +1326,13 @@ int build_halo_fused(nxs_dyn_handle *h) {
             spos[q] = j - h->send_offsets[k];
         }
     // receiving side: where each ghost node sits inside a mailbox half (layout of k_halo_pull)
-    std::vector<int> goff(std::max(Nn - No, 1), 0), gsrl(std::max(Nn - No, 1), 0);
+    std::vector<int> goff(std::max(Nn - No, 1), 0), gsrl(std::max(Nn - No, 1), 0), gk(std::max(Nn - No, 1), 0);
     for (int k = 0; k < nr; ++k) {
         const int off = h->recv_offsets[k], srl = h->recv_offsets[k + 1] - off;
         for (int j = off; j < h->recv_offsets[k + 1]; ++j) {
             goff[h->h_recv_index[j] - No] = 2 * off + (j - off);
             gsrl[h->h_recv_index[j] - No] = srl;
+            gk[h->h_recv_index[j] - No] = k;
         }
     }
     // boundary patches: send something or stage a ghost node.  The patch arrays are re-uploaded with those patches
@@ -1320,6 +1376,7 @@ int build_halo_fused(nxs_dyn_handle *h) {
     if ((rc = dev_upload(h, h->hf_allocs, &f.send_pos, spos))) return rc;
     if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_off, goff))) return rc;
     if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_srl, gsrl))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_k, gk))) return rc;
     unsigned int *ctr = nullptr;
     if ((rc = dev_alloc(h, h->hf_allocs, &ctr, 32 * 17))) return rc;
     HIPCHK(h, hipMemsetAsync(ctr, 0, 32 * 17 * sizeof(unsigned int), h->stream));
@@ -1415,6 +1472,7 @@ int run_substeps(nxs_dyn_handle *h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));  // tmp leaves scope
         h->d_hf_dirty = false;
     }
+    const bool records_end_odd = pair ? ((S / D) & 1) : (S & 1);
     auto pull_latest = [&](double *vec) {
         const int tr = h->recv_offsets[h->recv_procs.size()];
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,
@@ -1422,7 +1480,6 @@ int run_substeps(nxs_dyn_handle *h) {
     };
     auto loop = [&]() -> int {
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
-        if (fused) LAUNCH(h, k_pack_state, h->dm.Ne, h->dm, h->ds, bbm, h->ds.S4a);
         for (int s = 0; s < S; ++s) {
             if (pair) {
                 launch_multi(h, s, D);
@@ -1460,11 +1517,16 @@ int run_substeps(nxs_dyn_handle *h) {
         if (fused) {  // bring the result back to the primary buffers
             const double *vt_src = (S % R) ? h->ring.slot[S % R] : nullptr;
             if (vt_src) LAUNCH(h, k_pingpong_copy_back, 2 * h->dm.Nn, h->dm, h->ds, vt_src);
-            const int odd = pair ? ((S / D) & 1) : (S & 1);  // the element state ended in the second record buffer
-            LAUNCH(h, k_unpack_state, h->dm.Ne, h->dm, h->ds, bbm, (const double *)(odd ? h->ds.S4b : h->ds.S4a));
+            // the element state stays in its records when the loop ends in the first buffer (an even number of launches): update()
+            // works on them and the arrays follow when somebody asks (ensure_arrays); from the second buffer it is unpacked here
+            if (records_end_odd) LAUNCH(h, k_unpack_state, h->dm.Ne, h->dm, h->ds, bbm, (const double *)h->ds.S4b);
         }
         return NXS_OK;
     };
+    // (outside the graph: whether the records are current depends on what the caller did since the last step)
+    if (fused && h->sig_loc == 0) LAUNCH(h, k_pack_state, h->dm.Ne, h->dm, h->ds, bbm, h->ds.S4a);
+    if (!fused) ensure_arrays(h);
+    if (fused) h->sig_loc = records_end_odd ? 0 : 1;
     h->timing.substep_launches = pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
     if (!h->use_graph || (mr && !device_halo)) return loop();
     if (!h->graph_valid) {
@@ -1505,8 +1567,14 @@ int explicit_solve(nxs_dyn_handle *h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));  // h->dp may change right after
         h->dp_dirty = false;
     }
-    LAUNCH(h, k_prep_elements, m.Ne, m, h->ds, h->dw, h->dp);
-    LAUNCH(h, k_prep_nodes, m.Nn, m, h->ds, h->dw, h->dp);
+    // the fused kernels read records only: the per-quantity work vectors (v1 kernels, debug door) are filled on request
+    if (h->fused != 0 && !h->work_arrays) {
+        LAUNCH(h, k_prep_elements<true>, m.Ne, m, h->ds, h->dw, h->dp);
+        LAUNCH(h, k_prep_nodes<true>, m.Nn, m, h->ds, h->dw, h->dp);
+    } else {
+        LAUNCH(h, k_prep_elements<false>, m.Ne, m, h->ds, h->dw, h->dp);
+        LAUNCH(h, k_prep_nodes<false>, m.Nn, m, h->ds, h->dw, h->dp);
+    }
     if (timed) HIPCHK(h, hipEventRecord(h->cur[1], h->stream));
     int rc = run_substeps(h);
     if (rc) return rc;
@@ -1540,16 +1608,20 @@ int explicit_solve(nxs_dyn_handle *h) {
             return NXS_OK;
         }
         const bool halo_in_kernel = multi_rank(h) && h->ipc_ready && !h->halo_fn && h->halo_fused && h->hf_ready && m.No > 0;
+        if (halo_in_kernel) {  // which of my directions carry values the sweeps cannot change (they are sent once)
+            const int ts = h->send_offsets[h->send_procs.size()];
+            if (ts > 0) LAUNCH(h, k_smooth_static, ts, ts, h->d_send_index, h->d_send_seg, m, h->dw, h->ipc.my_static);
+        }
+        static_assert(NXS_SMOOTH_SWEEPS == 50, "Q9: FE.cpp:10580 hard-codes 50 sweeps");
         for (int nit = 0; nit < 50; ++nit) {
             if (halo_in_kernel) {  // updateGhosts inside the sweep; the ghosts land in the array once, after the last sweep
                 HaloFused hf = h->hf;
                 hf.ipc = h->ipc;
-                hf.from_mailbox = nit > 0;
-                LAUNCH(h, k_smooth_halo, m.No, m, h->dw, (const double *)a, b, hf);
+                LAUNCH(h, k_smooth_halo, m.No, m, h->dw, (const double *)a, b, hf, nit);
                 if (nit == 49) {
                     const int tr = h->recv_offsets[h->recv_procs.size()];
-                    hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, b, h->dm, h->ds, tr, h->d_recv_index,
-                                       h->d_recv_seg, h->d_recv_off, h->ipc, 0., 0, h->d_recv_procs, 1);
+                    hipLaunchKernelGGL(k_smooth_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, b, m.Nn, tr, h->d_recv_index,
+                                       h->d_recv_seg, h->d_recv_off, h->ipc);
                 }
             } else {
                 LAUNCH(h, k_smooth, m.No, m, h->dw, a, b);
@@ -1599,7 +1671,8 @@ int nxs_dyn_explicit_solve(nxs_dyn_handle *h) {
 int nxs_dyn_update(nxs_dyn_handle *h) {
     int rc = ready(h);
     if (rc) return rc;
-    LAUNCH(h, k_update, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    if (h->sig_loc) LAUNCH(h, k_update<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    else LAUNCH(h, k_update<false>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     return NXS_OK;
 }
 
@@ -1621,7 +1694,8 @@ int nxs_dyn_step(nxs_dyn_handle *h) {  // FE.cpp:8197-8214
     }
     rc = explicit_solve(h);
     if (rc) { h->cur = nullptr; return rc; }
-    LAUNCH(h, k_update, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    if (h->sig_loc) LAUNCH(h, k_update<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+    else LAUNCH(h, k_update<false>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     HIPCHK(h, hipGetLastError());
     if (k >= 0) {
         HIPCHK(h, hipEventRecord(h->cur[4], h->stream));
@@ -1691,7 +1765,7 @@ int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local) {
     if (!h->have_mesh || !h->have_state) return fail(h, NXS_ERR_STATE, "check_fields_fast needs set_mesh and put_state");
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemsetAsync(h->d_crash, 0, sizeof(int), h->stream));
-    LAUNCH(h, k_check_fields, std::max(h->dm.Ne, h->dm.Nn), h->dm, h->ds, h->dp, h->d_crash);
+    LAUNCH(h, k_check_fields, std::max(h->dm.Ne, h->dm.Nn), h->dm, h->ds, h->dp, h->d_crash, (h->sig_loc && h->dp.dynamics_type == NXS_DYN_BBM) ? 1 : 0);
     int c = 0;
     HIPCHK(h, hipMemcpyAsync(&c, h->d_crash, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));

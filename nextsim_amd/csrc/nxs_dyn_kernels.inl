@@ -96,7 +96,8 @@ struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
 
 struct DevWork {
     double *delta_x, *surface, *shape /*[6][Ne]*/, *emass, *ecbu;
-    double *prec /*[Ne][10]: what k_prep_nodes gathers per fan entry, one record per element (see k_prep_elements)*/;
+    double *prec /*[Ne][8]: what k_prep_nodes gathers per fan entry, one 64-byte record per element (see k_prep_elements)*/;
+    double *dragsurf /*[Ne]: air drag coefficient x area, the other thing k_prep_nodes' bamg-order loop sums (FE.cpp:10383-10390)*/;
     double *expC, *pmax, *heal, *dxs, *volume;  // per-step element constants of the sub-step loop
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
     unsigned char *open_blk;                     // [ceil(Nn/BLOCK)] != 0: the block of BLOCK nodes holds a node the open-water smoother changes (zeroed by k_prep_elements, set by k_prep_nodes)
@@ -131,6 +132,10 @@ __device__ __forceinline__ double jacobian(const double vx[3], const double vy[3
 
 // ------------------------------------------------------------------------------------------------
 // K1a  prep elements, FE.cpp:10235-10308
+// LEAN: only what the fused sub-step kernels, update() and the diagnostics read is written (records, M_surface, M_delta_x); the
+// one-array-per-quantity work vectors of the v1 kernels and of the debug door (M_shape_coeff, element mass, the per-step constants:
+// 104 B per element of stores) are left out -- option "work_arrays" brings them back.
+template <bool LEAN>
 __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, DevWork w, DevParams p) {
     // threads past the end redo the last element (identical values to identical places): every thread reaches the barrier
     const int e = min(blockIdx.x * BLOCK + (int)threadIdx.x, m.Ne - 1);
@@ -153,11 +158,13 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
     const double jac = jacobian(vx, vy);
     const double surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
     w.surface[e] = surface;
+    if (!LEAN) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {  // FE.cpp:1956-1962
-        const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-        w.shape[(size_t)k * m.Ne + e] = (vy[kp1] - vy[kp2]) / jac;
-        w.shape[(size_t)(k + 3) * m.Ne + e] = (vx[kp2] - vx[kp1]) / jac;
+        for (int k = 0; k < 3; ++k) {  // FE.cpp:1956-1962
+            const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+            w.shape[(size_t)k * m.Ne + e] = (vy[kp1] - vy[kp2]) / jac;
+            w.shape[(size_t)(k + 3) * m.Ne + e] = (vx[kp2] - vx[kp1]) / jac;
+        }
     }
 
     // slab mass, FE.cpp:10255-10269
@@ -171,7 +178,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
     double element_mass = 0.;
     if (total_concentration > 0.)
         element_mass = (NXS_RHOI * total_thickness + NXS_RHOS * total_snow) / total_concentration;
-    w.emass[e] = element_mass;
+    if (!LEAN) w.emass[e] = element_mass;
 
     // basal stress numerator, FE.cpp:10273-10308
     double element_ssh = 0;
@@ -190,14 +197,16 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
         critical_h_mod = mean_keel_depth / p.k1;
     }
     const double ecbu = p.k2 * STD_MAX(0., critical_h_mod - critical_h) * exp(-p.Cb * (1. - conc));
-    w.ecbu[e] = ecbu;
+    if (!LEAN) w.ecbu[e] = ecbu;
 
-    // The record k_prep_nodes gathers for every fan entry -- everything the nodal loops of FE.cpp:10309-10340 and
-    // 10578-10602 take from this element, contiguous (80 B) instead of nine arrays: the products are formed with the
-    // reference's operand order, so the node side performs the same additions on the same values.
-    __shared__ double rec[BLOCK * 10];  // staged so that the 80-byte records leave the block as one contiguous stream
+    // The record k_prep_nodes gathers for every fan entry -- what the nodal scatter loop of FE.cpp:10309-10340 takes from this
+    // element besides its area, contiguous: 64 bytes, one aligned line per fan entry (as an 80-byte record with the area and the
+    // drag term inside it straddled two lines, and the bamg-order loop of prep nodes fetched both again for two of its doubles:
+    // 1.58 KB per node).  The products are formed with the reference's operand order, so the node side performs the same additions
+    // on the same values.  The area (M_surface) and drag coefficient x area travel as compact arrays.
+    __shared__ double rec[BLOCK * 8];  // staged so that the records leave the block as one contiguous stream
     {
-        double *r = rec + threadIdx.x * 10;
+        double *r = rec + threadIdx.x * 8;
         const double meA = element_mass * surface;           // node_mass += element_mass*surface, FE.cpp:10314
         const double m_g_A3rd = meA * (NXS_GRAVITY / 3.);    // FE.cpp:10321
         double dragp = s.drag_ui[e];                          // FE.cpp:10585-10596
@@ -205,19 +214,20 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
             const double cy = s.cyoung[e];
             if (conc + cy > 0.) dragp = (s.drag_ui[e] * conc + s.drag_ui_young[e] * cy) / (conc + cy);
         }
+        w.dragsurf[e] = dragp * surface;
         const double sshn[3] = {s.ssh[m.t0[e]], s.ssh[m.t1[e]], s.ssh[m.t2[e]]};
-        r[0] = surface; r[1] = meA; r[2] = ecbu; r[3] = dragp * surface;
+        r[0] = meA; r[1] = ecbu;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {                         // FE.cpp:10334-10339
             const int kp1 = (j + 1) % 3, kp2 = (j + 2) % 3;
-            r[4 + j] = (vy[kp1] - vy[kp2]) / jac * m_g_A3rd * sshn[j];
-            r[7 + j] = (vx[kp2] - vx[kp1]) / jac * m_g_A3rd * sshn[j];
+            r[2 + j] = (vy[kp1] - vy[kp2]) / jac * m_g_A3rd * sshn[j];
+            r[5 + j] = (vx[kp2] - vx[kp1]) / jac * m_g_A3rd * sshn[j];
         }
     }
     __syncthreads();
     {
-        const size_t base = (size_t)blockIdx.x * BLOCK * 10;
-        const int count = min(BLOCK, m.Ne - (int)blockIdx.x * BLOCK) * 10;
+        const size_t base = (size_t)blockIdx.x * BLOCK * 8;
+        const int count = min(BLOCK, m.Ne - (int)blockIdx.x * BLOCK) * 8;
         for (int i = threadIdx.x; i < count; i += BLOCK) w.prec[base + i] = rec[i];
     }
 
@@ -232,18 +242,22 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
         c_heal = p.dte / s.theal[e] * c_expC;                                  // FE.cpp:4257
         c_skip = (conc <= 0.1) ? 1 : 0;                                        // Q5, FE.cpp:4146-4151
         c_dxi = (conc <= 0.1) ? ~acc_div3 : acc_div3;                          // M_delta_x as the integer it is (Q1), 4 bytes instead of 9
-        w.expC[e] = c_expC; w.pmax[e] = c_pmax; w.heal[e] = c_heal;
-        w.dxs[e] = delta_x * p.sqrt_nu_rhoi;                                   // FE.cpp:4232
-        w.eskip[e] = (unsigned char)c_skip;
-        w.dxi[e] = c_dxi;
+        if (!LEAN) {
+            w.expC[e] = c_expC; w.pmax[e] = c_pmax; w.heal[e] = c_heal;
+            w.dxs[e] = delta_x * p.sqrt_nu_rhoi;                               // FE.cpp:4232
+            w.eskip[e] = (unsigned char)c_skip;
+            w.dxi[e] = c_dxi;
+        }
     } else {
         c_expC = p.evp_Pstar * exp(-p.evp_C * (1. - conc));                    // FE.cpp:10684 (P)
         c_skip = (thick == 0.) ? 1 : 0;                                        // FE.cpp:10656
-        w.expC[e] = c_expC;
-        w.eskip[e] = (unsigned char)c_skip;
+        if (!LEAN) {
+            w.expC[e] = c_expC;
+            w.eskip[e] = (unsigned char)c_skip;
+        }
     }
     const double c_vol = thick * surface;                                      // FE.cpp:10450
-    w.volume[e] = c_vol;
+    if (!LEAN) w.volume[e] = c_vol;
     // the same constants once more as one 48-byte record per element -- what the fused sub-step kernels read (one base pointer and
     // three 16-byte loads instead of six arrays) -- staged through LDS like the records above, so that they leave as one stream
     __syncthreads();
@@ -262,6 +276,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
 
 // ------------------------------------------------------------------------------------------------
 // K1b + K2  the nodal side of prep elements (as a gather) and prep nodes, FE.cpp:10309-10416
+template <bool LEAN>
 __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, DevWork w, DevParams p) {
     // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous range of nodes, so that the element records two rows of
     // nodes share are found in that XCD's L2 (each record is gathered by its three corner nodes)
@@ -280,17 +295,17 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     for (int slot = 0; slot < m.W; ++slot) {
         const int ent = m.fan[(size_t)slot * Nn + n];
         if (ent < 0) break;
-        const double *r = w.prec + (size_t)(ent >> 3) * 10;
+        const double *r = w.prec + (size_t)(ent >> 3) * 8;
         const bool ghost_corner = ent & 4;
-        rl += r[0];                                    // FE.cpp:10313
-        nm += r[1];                                    // FE.cpp:10314
-        cb = STD_MAX(cb, r[2]);                        // FE.cpp:10317
+        rl += w.surface[ent >> 3];                     // FE.cpp:10313
+        nm += r[0];                                    // FE.cpp:10314
+        cb = STD_MAX(cb, r[1]);                        // FE.cpp:10317
         // Q7: the skip test sees node_mass as accumulated so far (elements <= e)
         if (dirichlet || nm == 0. || ghost_corner) continue;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {                  // FE.cpp:10334-10339
-            gu -= r[4 + j];
-            gv -= r[7 + j];
+            gu -= r[2 + j];
+            gv -= r[5 + j];
         }
     }
     // same expression as load_vertices(): the fused sub-step kernel rebuilds the shape coefficients from these
@@ -298,9 +313,11 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
         typedef double d2 __attribute__((ext_vector_type(2)));
         reinterpret_cast<d2 *>(w.xy)[n] = d2{m.x0[n] + 1. * s.UM[n], m.y0[n] + 1. * s.UM[n + Nn]};
     }
-    w.C_bu[n] = cb;
-    w.grad_ssh[n] = gu;
-    w.grad_ssh[n + Nn] = gv;
+    if (!LEAN) {
+        w.C_bu[n] = cb;
+        w.grad_ssh[n] = gu;
+        w.grad_ssh[n + Nn] = gv;
+    }
 
     // prep nodes, FE.cpp:10356-10416
     double vu = s.VT[n], vv = s.VT[n + Nn];
@@ -310,9 +327,8 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     for (int j = 0; j < m.W1; ++j) {                  // bamg row order (summation order!)
         const int e = m.n2e[(size_t)j * Nn + n];
         if (e < 0) continue;                           // Q2
-        const double *r = w.prec + (size_t)e * 10;
-        drag += r[3];                                  // dragp * surface
-        surface += r[0];
+        drag += w.dragsurf[e];                         // dragp * surface
+        surface += w.surface[e];
     }
     const double wu = s.wind[n], wv = s.wind[n + Nn];
     drag *= NXS_RHOA * hypot(wu, wv) / surface;        // Q6
@@ -321,12 +337,12 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     w.D_tau_a[n + Nn] = tay;
 
     const double fc = 2 * NXS_OMEGA * sin(m.lat[n] * NXS_PI / 180.);
-    w.fcor[n] = fc;
+    if (!LEAN) w.fcor[n] = fc;
 
     rl = 1. / rl;                                      // FE.cpp:10400-10402
     nm *= rl;
     rl *= 3.;
-    w.rlmass[n] = rl;
+    if (!LEAN) w.rlmass[n] = rl;
     w.node_mass[n] = nm;
     if (n < m.No && !dirichlet && nm == 0.) w.open_blk[n / BLOCK] = 1;  // k_smooth's own test (FE.cpp:10589): its other blocks have nothing to do
 
@@ -602,7 +618,19 @@ struct IpcDev {
     double *const *peer_seg;        // [ns] neighbour k's mailbox address of MY segment (parity 0)
     const long long *peer_parity_stride;  // [ns] doubles between that neighbour's two buffers (2*tr_k)
     unsigned long long *const *peer_flag; // [ns] address of my flag slot in neighbour k's mailbox
+    // The open-water smoother's own mailbox (k_smooth_halo): one slot per sweep, so a sweep never overwrites what a neighbour may
+    // still be reading and needs no acknowledgement -- which is what lets a receiver stop waiting for a direction whose values
+    // cannot change during the sweeps ("static this step": no ice-free node among the nodes sent that way).
+    double *smb;                    // my slots: [NXS_SMOOTH_SWEEPS][2*tr] doubles, laid out like a mailbox half
+    unsigned long long *sflags;     // [nr] written by the neighbours: epoch * 64 + sweeps published
+    unsigned long long *sstatic;    // [nr] written by the neighbours with sweep 0: (epoch << 1) | static
+    double *const *peer_smb;        // [ns] neighbour k's slot-0 address of MY segment; slot stride = peer_parity_stride[k]
+    unsigned long long *const *peer_sflag, *const *peer_sstatic;  // [ns] my entries in neighbour k's sflags / sstatic
+    unsigned long long *epoch;      // smoother passes completed by this rank (one per step; the ranks stay aligned)
+    int *my_static;                 // [ns] 1 = nothing I send to neighbour k can change during this step's sweeps (reset to 1 by k_smooth_pull)
+    int *peer_static;               // [nr] what neighbour k said about its sends to me (cached by sweep 1 for the later ones)
 };
+#define NXS_SMOOTH_SWEEPS 50  // FE.cpp:10580 (Q9: hard-coded in the reference)
 
 __device__ __forceinline__ void sys_store(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
@@ -637,6 +665,7 @@ struct HaloFused {
     const int *send_k, *send_pos;      // neighbour (index into send_procs) and position inside its segment
     const int *send_off;               // [ns+1] segment offsets (segment length = v offset)
     const int *ghost_off, *ghost_srl;  // [Nn-No] u offset inside a mailbox half, and the v offset from it
+    const int *ghost_k;                // [Nn-No] the receive neighbour (index into recv_procs) the ghost comes from
     int No;
     int from_mailbox;                  // 0: first sub-step of a step, the ghosts are in the VT buffer
     unsigned int *done_all;            // k_smooth_halo: two-level ticket counters, [0] global, [32 (g+1)] group g
@@ -775,7 +804,6 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         bool skip = true;
         int dxi = 0;
         if (active) {
-            if (!bbm) skip = w.eskip[e];
             {
                 typedef double d2 __attribute__((ext_vector_type(2)));
                 const d2 *S = reinterpret_cast<const d2 *>(b.Sc) + 2 * (size_t)e;
@@ -791,6 +819,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 else { r0 = r[0]; r1 = r[1]; r2 = r[2]; }
                 c_expC = r0.x; volume = r0.y; c_pmax = r1.x; c_heal = r1.y; c_coh = r2.x;
                 dxi = (int)(__double_as_longlong(r2.y) & 0xffffffffll);
+                if (!bbm) skip = (__double_as_longlong(r2.y) >> 32) != 0;  // thick == 0 (FE.cpp:10656), from the record's high word
             }
         }
         if (base == 0) { __syncthreads(); NXS_STAMP(1); }  // staged velocities / coordinates visible
@@ -1341,36 +1370,64 @@ __global__ void __launch_bounds__(BLOCK) k_smooth(DevMesh m, DevWork w, const do
     dst[n + Nn] = v;
 }
 
-// The same sweep with updateGhosts inside (device-direct transport, see HaloFused): ghost neighbours are read from
-// the mailbox (exchange x-1), every sent node -- smoothed or not -- is stored into the neighbours' mailboxes
-// (exchange x), and the last block raises the flags.  One launch per sweep instead of three.
-__global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst, HaloFused hf) {
-    const unsigned long long xseq = *hf.ipc.seq_push;
+// The same sweep with updateGhosts inside (device-direct transport).  The smoother has its own mailbox with one slot per sweep
+// (IpcDev::smb), so no sweep overwrites what a neighbour may still read and nothing has to be acknowledged.  Sweep j of pass E:
+//   j >= 1: wait until every neighbour that still matters has published sweep j-1 (sflags >= 64 E + j); ghost neighbours of the
+//           ice-free nodes are read from slot j-1 -- or from slot 0 for a direction that declared itself static;
+//   every sent node is stored into the neighbours' slot j (only sweep 0 for a static direction), the last sending block raises the
+//   flags; with sweep 0 it first tells each neighbour whether that direction is static this step (k_smooth_static found no node the
+//   smoother can change among the nodes sent that way): such a neighbour waits for sweep 0 only, 1 wait per step instead of 50.
+// The reference exchanges all 50 times (FE.cpp:10609); the values a static direction would carry are the same 50 times over.
+__global__ void __launch_bounds__(BLOCK) k_smooth_static(int total, const int *__restrict__ index, const int *__restrict__ seg_of, DevMesh m, DevWork w, int *my_static) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= total) return;
+    const int n = index[j];
+    if (!((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) my_static[seg_of[j]] = 0;  // k_smooth's own test (FE.cpp:10589)
+}
+
+__global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, const double *__restrict__ src, double *__restrict__ dst, HaloFused hf, int sweep) {
+    const IpcDev &ipc = hf.ipc;
     const int Nn = m.Nn, No = m.No;
-    if (hf.from_mailbox) {
+    // What this block of BLOCK own nodes has to do in this sweep: smooth (it holds an ice-free node: the flag k_prep_nodes raised),
+    // send (it holds sent nodes, and this is sweep 0 or some direction is not static), or -- block 0 in sweep 1 -- note what the
+    // neighbours said about their directions.  Most blocks of most sweeps have nothing to do and leave at once.
+    const bool has_open = w.open_blk[blockIdx.x] != 0;
+    const int sr = hf.send_block_rank[blockIdx.x];
+    bool any_dynamic = sweep == 0;
+    for (int k = 0; k < ipc.ns && !any_dynamic; ++k) any_dynamic = !ipc.my_static[k];
+    const bool publisher = (sr >= 0 || (hf.n_send_blocks == 0 && blockIdx.x == 0)) && any_dynamic;
+    const bool scribe = sweep == 1 && blockIdx.x == 0;
+    if (!has_open && !publisher && !scribe) return;
+    const unsigned long long E = *ipc.epoch;
+    if (sweep >= 1 && (has_open || scribe)) {
         if (threadIdx.x == 0) {
             const long long t0 = wall_clock64();
             bool ok = true;
-            for (int k = 0; k < hf.ipc.nr && ok; ++k)
-                while (__hip_atomic_load(hf.ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
+            for (int k = 0; k < ipc.nr && ok; ++k) {
+                if (sweep >= 2 && ipc.peer_static[k]) continue;  // its values are in slot 0 for good
+                while (__hip_atomic_load(ipc.sflags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 64ull * E + (unsigned long long)sweep) {
                     __builtin_amdgcn_s_sleep(4);
-                    if (__hip_atomic_load(hf.ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
-                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hf.ipc.error, 4); break; }  // 10 s
+                    if (__hip_atomic_load(ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(ipc.error, 4); break; }  // 10 s
                 }
+            }
+            if (scribe && ok)  // the neighbours' words came with their sweep 0; sweeps >= 2 read this cached copy
+                for (int k = 0; k < ipc.nr; ++k)
+                    ipc.peer_static[k] = __hip_atomic_load(ipc.sstatic + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ((E << 1) | 1ull);
         }
         __syncthreads();
     }
     const int n = blockIdx.x * BLOCK + threadIdx.x;
-    if (n < No) {
+    if (n < No && (has_open || publisher)) {
         double u = src[n], v = src[n + Nn];
-        if (!((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) {
-            const double *mb = hf.ipc.mailbox + ((xseq - 1ull) & 1ull) * 2ull * (unsigned long long)hf.ipc.tr;
+        if (has_open && !((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) {
             u = 0.; v = 0.;
             const int num_neighbours = m.n2n_cnt[n];
             for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
                 const int nni = m.n2n[(size_t)j * Nn + n];
-                if (hf.from_mailbox && nni >= No) {
-                    const double *g = mb + hf.ghost_off[nni - No];
+                if (sweep >= 1 && nni >= No) {
+                    const int slot = (sweep >= 2 && ipc.peer_static[hf.ghost_k[nni - No]]) ? 0 : sweep - 1;
+                    const double *g = ipc.smb + (size_t)slot * 2 * (size_t)ipc.tr + hf.ghost_off[nni - No];
                     u += sys_load(g);
                     v += sys_load(g + hf.ghost_srl[nni - No]);
                 } else {
@@ -1383,18 +1440,20 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
             dst[n] = u;
             dst[n + Nn] = v;
         }
-        for (int q = hf.send_ptr[n]; q < hf.send_ptr[n + 1]; ++q) {
-            const int k = hf.send_k[q];
-            double *d = hf.ipc.peer_seg[k] + (xseq & 1ull) * hf.ipc.peer_parity_stride[k] + hf.send_pos[q];
-            sys_store(d, u);
-            sys_store(d + (hf.send_off[k + 1] - hf.send_off[k]), v);
-        }
+        if (publisher)
+            for (int q = hf.send_ptr[n]; q < hf.send_ptr[n + 1]; ++q) {
+                const int k = hf.send_k[q];
+                if (sweep >= 1 && ipc.my_static[k]) continue;  // slot 0 already holds this value, and the neighbour knows
+                double *d = ipc.peer_smb[k] + (long long)sweep * ipc.peer_parity_stride[k] + hf.send_pos[q];
+                sys_store(d, u);
+                sys_store(d + (hf.send_off[k + 1] - hf.send_off[k]), v);
+            }
     }
-    // as in the sub-step kernel: drain per wave, count the block in, release once.  Only blocks that sent something take a
-    // ticket, and the tickets are two-level (16 group counters, then one): atomics on one address are served ~10 ns apart,
-    // a counter over all blocks of a 2-rank 2 km partition (1 400) would cost more than the sweep itself.
-    const int sr = hf.send_block_rank[blockIdx.x];
-    if (sr < 0 && !(hf.n_send_blocks == 0 && blockIdx.x == 0)) return;
+    // Publishing as in the sub-step kernel: every wave drains its own stores, the barrier collects the waves, one lane counts the
+    // block in, the last one raises the flags behind one release.  Only blocks that can send take a ticket, and the tickets are
+    // two-level (16 group counters, then one): atomics on one address are served ~10 ns apart.  After sweep 0 a rank whose
+    // directions are all static publishes nothing at all.
+    if (!publisher) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -1408,11 +1467,51 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
         }
     }
     if (last) {
-        __threadfence_system();  // the one release of the launch
-        for (int k = 0; k < hf.ipc.ns; ++k)
-            __hip_atomic_store(hf.ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
+        if (sweep == 0)
+            for (int k = 0; k < ipc.ns; ++k)
+                __hip_atomic_store(ipc.peer_sstatic[k], (E << 1) | (unsigned long long)(ipc.my_static[k] != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __threadfence_system();  // the one release of the launch: data and words before the flags
+        for (int k = 0; k < ipc.ns; ++k)
+            if (sweep == 0 || !ipc.my_static[k])
+                __hip_atomic_store(ipc.peer_sflag[k], 64ull * E + (unsigned long long)sweep + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hf.done_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *hf.ipc.seq_push = xseq + 1ull;
+    }
+}
+
+// After the last sweep: the ghosts land in the array (FE.cpp:10609 does it after every sweep) from the last slot -- slot 0 for a
+// static direction -- and the pass is closed: epoch + 1, every direction presumed static again until k_smooth_static says otherwise.
+__global__ void __launch_bounds__(BLOCK) k_smooth_pull(double *__restrict__ vec, int Nn, int total, const int *__restrict__ index,
+                                                       const int *__restrict__ seg_of, const int *__restrict__ offsets, IpcDev ipc) {
+    const unsigned long long E = *ipc.epoch;
+    __shared__ int ok;
+    if (threadIdx.x == 0) {
+        ok = 1;
+        const long long t0 = wall_clock64();
+        for (int k = 0; k < ipc.nr && ok; ++k) {
+            if (ipc.peer_static[k]) continue;
+            while (__hip_atomic_load(ipc.sflags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 64ull * E + (unsigned long long)NXS_SMOOTH_SWEEPS) {
+                __builtin_amdgcn_s_sleep(8);
+                if (__hip_atomic_load(ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = 0; break; }
+                if (wall_clock64() - t0 > 1000000000ll) { ok = 0; atomicExch(ipc.error, 4); break; }  // 10 s
+            }
+        }
+    }
+    __syncthreads();
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (ok && j < total) {
+        const int k = seg_of[j];
+        const int off = offsets[k], srl = offsets[k + 1] - off;
+        const int slot = ipc.peer_static[k] ? 0 : NXS_SMOOTH_SWEEPS - 1;
+        const double *src = ipc.smb + (size_t)slot * 2 * (size_t)ipc.tr + 2 * (size_t)off;
+        const int n = index[j];
+        vec[n] = sys_load(src + (j - off));
+        vec[n + Nn] = sys_load(src + (j - off) + srl);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ipc.done_pull, 1u) == gridDim.x - 1) {
+        *ipc.done_pull = 0u;
+        *ipc.epoch = E + 1ull;
+        for (int k = 0; k < ipc.ns; ++k) ipc.my_static[k] = 1;
     }
 }
 
@@ -1500,6 +1599,8 @@ __global__ void __launch_bounds__(BLOCK) k_ow_tail(DevMesh m, DevState s, DevWor
 
 // ------------------------------------------------------------------------------------------------
 // K10 update(), FE.cpp:3946-4131
+// REC: M_sigma lives in the records the sub-step loop left in S4a (see k_pack_state); the arrays are brought up to date on demand
+template <bool REC>
 __global__ void __launch_bounds__(BLOCK) k_update(DevMesh m, DevState s, DevWork w, DevParams p) {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= m.Ne) return;
@@ -1518,7 +1619,15 @@ __global__ void __launch_bounds__(BLOCK) k_update(DevMesh m, DevState s, DevWork
     if ((conc > 0.) && to_be_updated) {
         const double surf_ratio = surface_old / surface;
         conc *= surf_ratio; thick *= surf_ratio; snow *= surf_ratio; tmyi *= surf_ratio;
-        s.s0[e] *= surf_ratio; s.s1[e] *= surf_ratio; s.s2[e] *= surf_ratio;
+        if (REC) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 *S = reinterpret_cast<d2 *>(s.S4a) + 2 * (size_t)e;
+            d2 a = S[0], c2 = S[1];
+            a.x *= surf_ratio; a.y *= surf_ratio; c2.x *= surf_ratio;
+            S[0] = a; S[1] = c2;
+        } else {
+            s.s0[e] *= surf_ratio; s.s1[e] *= surf_ratio; s.s2[e] *= surf_ratio;
+        }
         ridge = 1. - (1. - ridge) * STD_MIN(1., conc) / (old_conc * surf_ratio);
         if (p.young_cat) { hy *= surf_ratio; cy *= surf_ratio; hsy *= surf_ratio; }
         if (p.equal_ridging) {
@@ -1678,14 +1787,14 @@ __device__ __forceinline__ bool bad_range(double val, double lo, double hi) {
     return (val > hi) || (val < lo) || isnan(val);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_check_fields(DevMesh m, DevState s, DevParams p, int *crash) {
+__global__ void __launch_bounds__(BLOCK) k_check_fields(DevMesh m, DevState s, DevParams p, int *crash, int damage_in_records) {
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     bool bad = false;
     if (i < m.Ne) {
         bad |= bad_range(s.thick[i], 0., 50.);
         bad |= bad_range(s.snow[i], 0., 10.);
         bad |= bad_range(s.conc[i], 0., 1.);
-        bad |= bad_range(s.damage[i], 0., 1.);
+        bad |= bad_range(damage_in_records ? s.S4a[4 * (size_t)i + 3] : s.damage[i], 0., 1.);
         bad |= bad_range(s.ridge[i], 0., 1.);
         if (p.young_cat) {
             bad |= bad_range(s.hyoung[i], 0., 2.);

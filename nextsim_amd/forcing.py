@@ -102,12 +102,20 @@ def global_fields(mesh: GlobalMesh, p: _abi.Params, kind: str, C_fix: float, C_a
         wind = np.concatenate([np.full(Nn, 20.0), np.zeros(Nn)])
         ocean = z_n(); ssh = np.zeros(Nn); depth = np.full(Ne, 200.0)
         cyoung = z_e(); hyoung = z_e()
-    elif kind == "arctic":
+    elif kind in ("arctic", "arctic_ow"):
         R = np.hypot(x, y).max()
         # ice: full cover in the basin, marginal ice zone + open water towards the open boundary
         th = np.arctan2(cy, cx); r = np.hypot(cx, cy)
-        edge = np.clip((r / R - 0.55) / 0.25, 0.0, 1.0) * (np.abs(th - np.deg2rad(20.0)) < np.deg2rad(40.0))
-        conc = np.clip(1.0 - 1.25 * edge, 0.0, 1.0)
+        if kind == "arctic":     # an 80-degree sector: ~9 % of the triangles ice free
+            edge = np.clip((r / R - 0.55) / 0.25, 0.0, 1.0) * (np.abs(th - np.deg2rad(20.0)) < np.deg2rad(40.0))
+            conc = np.clip(1.0 - 1.25 * edge, 0.0, 1.0)
+        else:                    # half the rim: ~30 % of the triangles ice free, ~3 % in the 0 < A <= 0.1 band that
+            #                      updateSigmaDamage skips (FE.cpp:4146-4159) while update() and the drag still see its ice
+            dth = np.abs(np.angle(np.exp(1j * (th - np.deg2rad(20.0)))))
+            edge = np.clip((r / R - 0.36) / 0.25, 0.0, 1.0) * (dth < np.deg2rad(90.0))
+            conc = np.clip(1.0 - 1.25 * edge, 0.0, 1.0)
+            low = (conc > 0.0) & (conc <= 0.3)
+            conc[low] = conc[low] / 3.0
         thick = conc * (1.0 + 1.5 * np.exp(-((cx + 0.3 * R) ** 2 + cy ** 2) / (0.5 * R) ** 2))
         snow = 0.1 * conc
         cyoung = np.clip(0.5 * edge * (1 - conc), 0.0, 1.0 - conc)

@@ -57,7 +57,7 @@ def _assert_close(got, ref, keys, tol, what):
 def test_prep_arrays_bit_exact():
     """K1/K2: everything without a libm call is bit-identical to the serial loops (the node gather
     adds in ascending element order, FE.cpp:10309-10340); fcor (sin) within 2 ulp."""
-    fe, ref, lm = _pair("small", 1, substeps=1, dtime_step=200. / 120.)
+    fe, ref, lm = _pair("small", 1, substeps=1, dtime_step=200. / 120., options={"work_arrays": 1})
     Nn, Ne = lm.num_nodes, lm.num_elements
     for name, rname, n in (("rlmass", "rlmass_matrix", Nn), ("node_mass", "node_mass", Nn),
                            ("grad_ssh", "grad_ssh", 2 * Nn)):
