@@ -280,6 +280,7 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *   "pin_host"     1 = page-lock the caller's state / forcing vectors the first time they are seen (hipHostRegister), so the
  *                  per-step copies of a host that keeps its thermodynamics on the CPU run at PCIe speed; registrations are
  *                  dropped at set_mesh / destroy / pin_host 0.  Default 0: the library does not touch the caller's pages.
+ *   "trace_branches"  see nxs_dyn_get_branch_trace
  *   "work_arrays"  1 = the prep kernels also fill the one-array-per-quantity work vectors (M_shape_coeff, element mass, the per-step
  *                  element constants, rlmass, C_bu, grad_ssh, fcor) that only the fused = 0 kernels and nxs_dyn_debug_array read;
  *                  default 0: with fused != 0 the step writes its records only
@@ -290,6 +291,13 @@ NXS_API int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value
 /* Test door: copies a named internal work array (rlmass, node_mass, C_bu, grad_ssh, fcor, VTM, shape,
  * emass, ecbu, force, volume, expC) to the host so that parity tests can localise a difference. */
 NXS_API int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_t n);
+
+/* Test door: option "trace_branches" = 1 zeroes a per-element record and makes every following step run the one-kernel-per-loop
+ * family with the record kept: 4 words per element -- a hash of the branch updateSigmaDamage took at every sub-step (damage
+ * increment yes / no, FE.cpp:4229; skipped, conc <= 0.1, FE.cpp:4151), the number of damaging sub-steps, flag bits (|dcrit - 1| <
+ * 1e-9 seen, |conc - 0.1| < 1e-12 seen, skipped) and the sub-steps seen.  The oracle keeps the same record (oracle/dyn_ref.h), so a
+ * test can name the elements where the two implementations ever took different branches.  Results are unchanged by the option. */
+NXS_API int nxs_dyn_get_branch_trace(nxs_dyn_handle *h, uint64_t *out, int64_t num_words);
 
 /* Connectivity tables with the exact content and ordering of BamgConvertMeshx -> Mesh::WriteMesh
  * (contrib/bamg/src/Mesh.cpp:514-543, 798-865) for a mesh given as 1-based triangles.

@@ -146,6 +146,7 @@ struct nxs_dyn_handle {
     std::vector<void *> forcing_allocs;
     int sig_loc = 0;                       // where M_sigma / M_damage are current: 0 = the state arrays, 1 = the records in S4a (left there by
                                            // the fused sub-step loop; k_update works on them, the arrays follow on demand: ensure_arrays)
+    int trace_branches = 0;                // option "trace_branches": the per-loop kernels keep the branch trace of updateSigmaDamage (dw.trace)
     int work_arrays = 0;                   // option "work_arrays": the prep kernels also fill the one-array-per-quantity work vectors
     int pin_host = 0;                      // option "pin_host": page-lock the caller's state / forcing vectors on first use
     std::map<const void *, size_t> pinned; // what this handle has registered with hipHostRegister
@@ -183,6 +184,9 @@ struct nxs_dyn_handle {
 };
 
 namespace {
+
+// the kernel family of this step: option "fused", except that the branch trace lives in the per-loop kernels
+inline int eff_fused(const nxs_dyn_handle *h) { return h->trace_branches ? 0 : h->fused; }
 
 int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -507,6 +511,17 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         h->pair_nodes = (int)value; h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "work_arrays")) { h->work_arrays = value != 0; return NXS_OK; }
+    if (!std::strcmp(key, "trace_branches")) {  // 1 = start (or restart) the trace: zeroed records; the step then runs the per-loop kernels
+        if (value && !h->have_mesh) return fail(h, NXS_ERR_STATE, "trace_branches before set_mesh");
+        h->trace_branches = value != 0;
+        release_graph(h);
+        if (h->trace_branches) {
+            HIPCHK(h, hipSetDevice(h->device));
+            if (!h->dw.trace) { int rc = dev_alloc(h, h->state_allocs, &h->dw.trace, 4 * (size_t)h->dm.Ne); if (rc) return rc; }
+            HIPCHK(h, hipMemsetAsync(h->dw.trace, 0, 4 * (size_t)h->dm.Ne * sizeof(unsigned long long), h->stream));
+        }
+        return NXS_OK;
+    }
     if (!std::strcmp(key, "pin_host")) { h->pin_host = value != 0; if (!h->pin_host) unpin_all(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_fused")) { h->halo_fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
@@ -567,6 +582,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     h->ring = VTRing{};
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
     h->sig_loc = 0;
+    h->trace_branches = 0;
     h->rank = 0; h->nranks = 1;
     h->send_procs.clear(); h->recv_procs.clear(); h->send_offsets.assign(1, 0); h->recv_offsets.assign(1, 0);
 
@@ -1142,6 +1158,17 @@ int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *dg) {
     return NXS_OK;
 }
 
+// test door: the branch trace of updateSigmaDamage (option "trace_branches"), 4 words per element
+int nxs_dyn_get_branch_trace(nxs_dyn_handle *h, uint64_t *out, int64_t num_words) {
+    if (!h || !out) return NXS_ERR_INVALID;
+    if (!h->have_mesh || !h->dw.trace) return fail(h, NXS_ERR_STATE, "get_branch_trace: set option trace_branches = 1 first");
+    if (num_words != 4 * (int64_t)h->dm.Ne) return fail(h, NXS_ERR_INVALID, "get_branch_trace: %lld words expected", 4ll * h->dm.Ne);
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(out, h->dw.trace, (size_t)num_words * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return NXS_OK;
+}
+
 // debug / test door: copy a named work array to the host (n doubles)
 int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_t n) {
     if (!h || !name || !out) return NXS_ERR_INVALID;
@@ -1156,7 +1183,7 @@ int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_
     };
     for (auto &t : tab)
         if (!std::strcmp(t.nm, name)) {
-            if (h->fused != 0 && !h->work_arrays && std::strcmp(name, "VTM") && std::strcmp(name, "node_mass"))
+            if (eff_fused(h) != 0 && !h->work_arrays && std::strcmp(name, "VTM") && std::strcmp(name, "node_mass"))
                 return fail(h, NXS_ERR_STATE, "debug_array %s: the fused path fills records only; set option work_arrays = 1 before the step", name);
             if (n != t.len) return fail(h, NXS_ERR_INVALID, "debug_array %s has %lld entries, caller asked %lld", name, (long long)t.len, (long long)n);
             HIPCHK(h, hipMemcpyAsync(out, t.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1406,7 +1433,11 @@ int build_halo_fused(nxs_dyn_handle *h) {
 
 void launch_substep(nxs_dyn_handle *h, double move_dt) {
     if (h->dp.dynamics_type == NXS_DYN_BBM) {
-        if (h->dp.ers_int == 4) LAUNCH(h, k_sigma_bbm<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+        if (h->trace_branches) {
+            if (h->dp.ers_int == 4) LAUNCH(h, (k_sigma_bbm<true, true>), h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+            else LAUNCH(h, (k_sigma_bbm<false, true>), h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
+        }
+        else if (h->dp.ers_int == 4) LAUNCH(h, k_sigma_bbm<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
         else LAUNCH(h, k_sigma_bbm<false>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     }
     else
@@ -1421,10 +1452,10 @@ int choose_depth(nxs_dyn_handle *h) {
     int D = 1;
     // Automatic (fused == 3): only where ONE round of one patch per CU covers the mesh (<= 256 own nodes per patch: 65 k nodes, 130 k
     // triangles on 256 CUs) -- 111 k triangles: 1.47 (v2) -> 0.97 ms/step; 182 k triangles, two patches per CU: 1.65 -> 1.90-2.31.
-    if ((h->fused == 2 || (h->fused == 3 && (long long)h->dm.Nn <= 256ll * 1024)) && !multi_rank(h) && move_dt != 0. && S >= 2 && !h->pair_failed) {
+    if ((eff_fused(h) == 2 || (eff_fused(h) == 3 && (long long)h->dm.Nn <= 256ll * 1024)) && !multi_rank(h) && move_dt != 0. && S >= 2 && !h->pair_failed) {
         D = std::min(h->pair_depth > 0 ? h->pair_depth : 4, std::min(S, NXS_MAX_DEPTH));
         while (D > 1 && S % D != 0) --D;
-        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D, h->fused == 3) != NXS_OK) {
+        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D, eff_fused(h) == 3) != NXS_OK) {
             h->pair_failed = true;  // no patch size fits (a numbering without any locality, huge fans): one sub-step per launch
             D = 1;
         }
@@ -1436,7 +1467,7 @@ int choose_depth(nxs_dyn_handle *h) {
 int run_substeps(nxs_dyn_handle *h) {
     const int S = h->dp.substeps;
     const double move_dt = (h->dp.dynamics_type == NXS_DYN_MEVP) ? 0. : h->dp.dte;
-    const bool fused = h->fused != 0;
+    const bool fused = eff_fused(h) != 0;
     const int bbm = h->dp.dynamics_type == NXS_DYN_BBM;
     const bool mr = multi_rank(h);
     // deferred mesh move (fused path, not mEVP whose single move comes after the loop)
@@ -1568,7 +1599,7 @@ int explicit_solve(nxs_dyn_handle *h) {
         h->dp_dirty = false;
     }
     // the fused kernels read records only: the per-quantity work vectors (v1 kernels, debug door) are filled on request
-    if (h->fused != 0 && !h->work_arrays) {
+    if (eff_fused(h) != 0 && !h->work_arrays) {
         LAUNCH(h, k_prep_elements<true>, m.Ne, m, h->ds, h->dw, h->dp);
         LAUNCH(h, k_prep_nodes<true>, m.Nn, m, h->ds, h->dw, h->dp);
     } else {
@@ -1578,7 +1609,7 @@ int explicit_solve(nxs_dyn_handle *h) {
     if (timed) HIPCHK(h, hipEventRecord(h->cur[1], h->stream));
     int rc = run_substeps(h);
     if (rc) return rc;
-    if (!multi_rank(h) && h->depth_now < 2 && !h->sm_ready && !h->sm_failed && h->fused != 0) {
+    if (!multi_rank(h) && h->depth_now < 2 && !h->sm_ready && !h->sm_failed && eff_fused(h) != 0) {
         if (build_smooth_patches(h, 5) != NXS_OK) h->sm_failed = true;  // the smoother then runs sweep by sweep
         h->tail_graph_valid = false;
     }
@@ -1592,7 +1623,7 @@ int explicit_solve(nxs_dyn_handle *h) {
         LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
         // single rank: D sweeps per launch on patches with D rings of nodes (k_smooth_multi) -- those of k_substep_multi where that
         // kernel runs, else node-ring patches built for the smoother alone
-        const bool v3_patches = h->pair_ready && !h->pair_failed && h->dpch2.pnbr && h->fused >= 2 && h->depth_now >= 2;
+        const bool v3_patches = h->pair_ready && !h->pair_failed && h->dpch2.pnbr && eff_fused(h) >= 2 && h->depth_now >= 2;
         if (!multi_rank(h) && (v3_patches || h->sm_ready)) {
             const DevPatches2 &pp = v3_patches ? h->dpch2 : h->dsm;
             const size_t lds = v3_patches ? h->smooth_lds : h->sm_lds;

@@ -108,6 +108,7 @@ struct DevWork {
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
     double *xy;       // [Nn][2] node coordinates (x, y) on the displaced mesh at step start (frozen over the sub-steps, Q4)
     double *D_tau_a, *D_tau_w, *D_del;
+    unsigned long long *trace;  // [Ne][4] branch trace of updateSigmaDamage (option "trace_branches"; layout of ref_work.trace in oracle/dyn_ref.h), else NULL
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -369,7 +370,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
 template <bool POW4>
 __device__ __forceinline__ void bbm_stress(const DevParams &p, const double dxN[6], const double u[3], const double v[3],
                                            double sig[3], double &damage, const double expC, const double Pmax,
-                                           const double heal, const double dxs, const double cohesion) {
+                                           const double heal, const double dxs, const double cohesion, double *dcrit_out = nullptr) {
     const double dt = p.dte;
     // M_B0T (FE.cpp:10242-10249) rebuilt in registers, zeros included so that the sums below are the
     // reference's term for term (FE.cpp:4167-4176)
@@ -427,6 +428,7 @@ __device__ __forceinline__ void bbm_stress(const DevParams &p, const double dxN[
         dcrit = -p.compr_strength / sigma_n;
     else
         dcrit = cohesion / (sigma_s + p.tan_phi * sigma_n);
+    if (dcrit_out) *dcrit_out = dcrit;                                           // (branch trace only)
     if ((0. < dcrit) && (dcrit < 1.)) {                                          // FE.cpp:4229-4243
         const double rtd = sqrt(elasticity) / dxs;
         const double del_damage = (1.0 - damage) * (1.0 - dcrit) * dt * rtd;
@@ -501,7 +503,17 @@ __device__ __forceinline__ void nodal_solve(const DevParams &p, const double gx,
 
 // ------------------------------------------------------------------------------------------------
 // K3a  updateSigmaDamage, FE.cpp:4137-4260, + the element half of K4 (corner forces)
-template <bool POW4>
+// one sub-step of one element into the branch trace: the same record as trace_branch() of oracle/dyn_ref.c
+__device__ __forceinline__ void trace_branch(unsigned long long *t, int code, double dcrit, double conc) {
+    t[0] = t[0] * 0x9E3779B97F4A7C15ull + (unsigned long long)code + 1ull;
+    if (code == 1) t[1]++;
+    if (code != 2 && fabs(dcrit - 1.) < 1e-9) t[2] |= 1ull;
+    if (fabs(conc - 0.1) < 1e-12) t[2] |= 2ull;
+    if (code == 2) t[2] |= 4ull;
+    t[3]++;
+}
+
+template <bool POW4, bool TRACE = false>
 __global__ void __launch_bounds__(BLOCK) k_sigma_bbm(DevMesh m, DevState s, DevWork w, DevParams p) {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= m.Ne) return;
@@ -513,6 +525,7 @@ __global__ void __launch_bounds__(BLOCK) k_sigma_bbm(DevMesh m, DevState s, DevW
     if (w.eskip[e]) {  // FE.cpp:4151-4159
         s.damage[e] = 0.;
         sig[0] = sig[1] = sig[2] = 0.;
+        if (TRACE) trace_branch(w.trace + 4 * (size_t)e, 2, 0., s.conc[e]);
     } else {
         const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
         double u[3], v[3];
@@ -520,7 +533,13 @@ __global__ void __launch_bounds__(BLOCK) k_sigma_bbm(DevMesh m, DevState s, DevW
         for (int j = 0; j < 3; ++j) { u[j] = s.VT[n[j]]; v[j] = s.VT[n[j] + Nn]; }
         sig[0] = s.s0[e]; sig[1] = s.s1[e]; sig[2] = s.s2[e];
         double damage = s.damage[e];
-        bbm_stress<POW4>(p, dxN, u, v, sig, damage, w.expC[e], w.pmax[e], w.heal[e], w.dxs[e], s.cohesion[e]);
+        if (TRACE) {
+            double dcrit;
+            bbm_stress<POW4>(p, dxN, u, v, sig, damage, w.expC[e], w.pmax[e], w.heal[e], w.dxs[e], s.cohesion[e], &dcrit);
+            trace_branch(w.trace + 4 * (size_t)e, ((0. < dcrit) && (dcrit < 1.)) ? 1 : 0, dcrit, s.conc[e]);
+        } else {
+            bbm_stress<POW4>(p, dxN, u, v, sig, damage, w.expC[e], w.pmax[e], w.heal[e], w.dxs[e], s.cohesion[e]);
+        }
         s.damage[e] = damage;
     }
     s.s0[e] = sig[0]; s.s1[e] = sig[1]; s.s2[e] = sig[2];

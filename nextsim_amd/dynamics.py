@@ -80,6 +80,7 @@ def load_library():
     L.nxs_dyn_get_timing.argtypes = [H, P(_abi.Timing)]
     L.nxs_dyn_set_option.argtypes = [H, C.c_char_p, C.c_int64]
     L.nxs_dyn_debug_array.argtypes = [H, C.c_char_p, _abi.c_double_p, C.c_int64]
+    L.nxs_dyn_get_branch_trace.argtypes = [H, C.POINTER(C.c_uint64), C.c_int64]
     L.nxs_mesh_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, P(C.c_int32), _abi.c_double_p,
                                         P(C.c_int32), _abi.c_double_p]
     L.nxs_mesh_element_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, _abi.c_double_p]
@@ -108,7 +109,7 @@ EXPORTS = (
     "nxs_dyn_get_diag", "nxs_dyn_step",
     "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
     "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
-    "nxs_dyn_debug_array", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
+    "nxs_dyn_debug_array", "nxs_dyn_get_branch_trace", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
 )
 INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
                   "nxs_interp_last_error")
@@ -325,6 +326,12 @@ class FiniteElementDynamics:
             setattr(d, k, _abi.dptr(v))
         self._chk(self.L.nxs_dyn_get_diag(self.h, C.byref(d)))
         return out
+
+    def branch_trace(self) -> dict:
+        """The record option "trace_branches" keeps (include/nxs_dyn.h): {'hash', 'damage_substeps', 'flags', 'substeps'}."""
+        t = np.zeros((self.lm.num_elements, 4), np.uint64)
+        self._chk(self.L.nxs_dyn_get_branch_trace(self.h, t.ctypes.data_as(C.POINTER(C.c_uint64)), t.size))
+        return {"hash": t[:, 0], "damage_substeps": t[:, 1], "flags": t[:, 2], "substeps": t[:, 3]}
 
     def debug_array(self, name: str) -> np.ndarray:
         Nn, Ne = self.lm.num_nodes, self.lm.num_elements

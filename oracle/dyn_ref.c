@@ -57,12 +57,29 @@ ref_work *ref_work_create(int32_t Nn, int32_t Ne) {
     return w;
 }
 
+int ref_work_enable_trace(ref_work *w) {
+    if (!w) return -1;
+    free(w->trace);
+    w->trace = (uint64_t *)calloc(4 * (size_t)(w->Ne > 0 ? w->Ne : 1), sizeof(uint64_t));
+    return w->trace ? 0 : -1;
+}
+
+/* one sub-step of one element into the branch trace (see ref_work.trace) */
+static void trace_branch(uint64_t *t, int code, double dcrit, double conc) {
+    t[0] = t[0] * 0x9E3779B97F4A7C15ull + (uint64_t)code + 1ull;
+    if (code == 1) t[1]++;
+    if (code != 2 && fabs(dcrit - 1.) < 1e-9) t[2] |= 1ull;
+    if (fabs(conc - 0.1) < 1e-12) t[2] |= 2ull;
+    if (code == 2) t[2] |= 4ull;
+    t[3]++;
+}
+
 void ref_work_destroy(ref_work *w) {
     if (!w) return;
     free(w->delta_x); free(w->surface); free(w->shape_coeff); free(w->B0T);
     free(w->element_mass); free(w->rlmass_matrix); free(w->node_mass); free(w->C_bu);
     free(w->grad_ssh); free(w->grad_terms); free(w->fcor); free(w->VTM); free(w->tmp);
-    free(w->D_tau_a); free(w->D_tau_w); free(w->D_del_ci_ridge_myi);
+    free(w->D_tau_a); free(w->D_tau_w); free(w->D_del_ci_ridge_myi); free(w->trace);
     free(w);
 }
 
@@ -333,6 +350,7 @@ void ref_update_sigma_damage(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs
         if (s->conc[cpt] <= min_c) { /* FE.cpp:4151-4159 */
             s->damage[cpt] = 0.;
             for (int i = 0; i < 3; i++) sig[i][cpt] = 0.;
+            if (w->trace) trace_branch(w->trace + 4 * (size_t)cpt, 2, 0., s->conc[cpt]);
             continue;
         }
 
@@ -383,6 +401,7 @@ void ref_update_sigma_damage(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs
         else
             dcrit = s->cohesion[cpt] / (sigma_s + p->tan_phi * sigma_n);
 
+        if (w->trace) trace_branch(w->trace + 4 * (size_t)cpt, ((0. < dcrit) && (dcrit < 1.)) ? 1 : 0, dcrit, s->conc[cpt]);
         if ((0. < dcrit) && (dcrit < 1.)) { /* FE.cpp:4229-4243 */
             double const rtd = sqrt(elasticity) / (w->delta_x[cpt] * sqrt_nu_rhoi);
             double const del_damage = (1.0 - s->damage[cpt]) * (1.0 - dcrit) * dt * rtd;

@@ -44,12 +44,23 @@ typedef struct ref_work {
     double *D_tau_a;       /* [2Nn] */
     double *D_tau_w;       /* [2Nn] */
     double *D_del_ci_ridge_myi; /* [Ne] */
+    /* Branch trace of updateSigmaDamage (NULL = off; ref_work_enable_trace): per element 4 words
+     *   [0] hash of the branch taken at every sub-step so far: h = h*0x9E3779B97F4A7C15 + code + 1 with
+     *       code 0 = no damage increment, 1 = the 0 < dcrit < 1 branch (FE.cpp:4229), 2 = skipped, conc <= 0.1 (FE.cpp:4151)
+     *   [1] number of sub-steps that took the damage branch
+     *   [2] bit 0: |dcrit - 1| < 1e-9 at some sub-step, bit 1: |conc - 0.1| < 1e-12 at some sub-step (SURVEY 8d's
+     *       threshold-flip set), bit 2: skipped at some sub-step
+     *   [3] sub-steps seen
+     * The device keeps the same record (option "trace_branches"): two implementations whose hashes agree for an element took the
+     * same branches at every sub-step. */
+    uint64_t *trace;       /* [4*Ne] */
 } ref_work;
 
 typedef void (*ref_ghost_fn)(void *ctx, double *nodal_vec);
 
 ref_work *ref_work_create(int32_t Nn, int32_t Ne);
 void ref_work_destroy(ref_work *w);
+int ref_work_enable_trace(ref_work *w);   /* allocates and zeroes w->trace; 0 on success */
 
 void ref_default_params(nxs_dyn_params *p);
 

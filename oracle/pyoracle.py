@@ -21,7 +21,7 @@ class Work(C.Structure):
         (k, _abi.c_double_p) for k in (
             "delta_x", "surface", "shape_coeff", "B0T", "element_mass", "rlmass_matrix", "node_mass",
             "C_bu", "grad_ssh", "grad_terms", "fcor", "VTM", "tmp", "D_tau_a", "D_tau_w",
-            "D_del_ci_ridge_myi")]
+            "D_del_ci_ridge_myi")] + [("trace", C.POINTER(C.c_uint64))]
 
 
 GHOST_FN = C.CFUNCTYPE(None, C.c_void_p, _abi.c_double_p)
@@ -50,6 +50,8 @@ def lib(fast: bool = False):
     L.ref_work_create.restype = Wp
     L.ref_work_create.argtypes = [C.c_int32, C.c_int32]
     L.ref_work_destroy.argtypes = [Wp]
+    L.ref_work_enable_trace.argtypes = [Wp]
+    L.ref_work_enable_trace.restype = C.c_int
     L.ref_default_params.argtypes = [Pp]
     L.ref_prep.argtypes = [Mp, Pp, Sp, Fp, Wp]
     L.ref_update_sigma_damage.argtypes = [Mp, Pp, Sp, Wp, C.c_double]
@@ -184,6 +186,15 @@ class OracleRank:
     def check_fields_fast(self):
         m, p, s, f, w = self._a()
         return self.L.ref_check_fields_fast(m, p, s)
+
+    def enable_branch_trace(self):
+        """Start (or restart) the per-element branch trace of updateSigmaDamage (ref_work.trace in dyn_ref.h)."""
+        assert self.L.ref_work_enable_trace(self.work) == 0
+
+    def branch_trace(self) -> dict:
+        """{'hash', 'damage_substeps', 'flags', 'substeps'}: one uint64 per element each."""
+        t = np.ctypeslib.as_array(self.work.contents.trace, shape=(self.lm.num_elements, 4)).copy()
+        return {"hash": t[:, 0], "damage_substeps": t[:, 1], "flags": t[:, 2], "substeps": t[:, 3]}
 
     def work_array(self, name: str, n: int) -> np.ndarray:
         ptr = getattr(self.work.contents, name)
