@@ -14,10 +14,17 @@
  *   - a target point inside a triangle of the data mesh gets exactly the reference's value: area
  *     coordinates are ratios of the same 64-bit integer determinants, combined in the same order;
  *   - isdefault != 0: points outside the data mesh get defaultvalue (as the reference);
- *   - isdefault == 0: the reference walks bamg's hull-filling triangulation and projects exterior
- *     points on a boundary edge (CloseBoundaryEdge, Mesh.cpp:4590-4627).  Here an exterior point is
- *     projected on the NEAREST boundary edge with the same a/b formula; *num_exterior reports how
- *     many points took that path (they can differ from the reference near concave boundary corners).
+ *   - isdefault == 0 (the regrid call): the reference locates its points in bamg's RECONSTRUCTED mesh -- the data mesh plus
+ *     triangles that fill its holes and the concave parts of its boundary up to the convex hull (Mesh.cpp:3135-3440) -- and
+ *     projects points beyond the hull on a hull edge (CloseBoundaryEdge, Mesh.cpp:4590-4627).  The same here: the fill
+ *     triangles are rebuilt on the host (constrained Delaunay triangulation of every pocket and hole with exact integer
+ *     predicates, csrc/nxs_hull.inl: the same triangles as bamg's, checked against the real bamg), numbered behind the
+ *     mesh's, and the hull projection is CloseBoundaryEdge's.  A point beyond the hull whose hull edge belongs to a mesh
+ *     triangle gets the reference's bits; inside a fill triangle the three products of the P1 sum are the reference's but may
+ *     be added in a rotated order (bamg's vertex order inside a fill triangle depends on its insertion history): <= 1 ulp.
+ *     Element data outside the mesh (where the reference stops with an error) and meshes the completion does not cover
+ *     (several components, pinched boundaries) take the nearest boundary edge instead; nxs_interp_last_info says how many
+ *     points went which way.
  */
 #ifndef NXS_INTERP_H
 #define NXS_INTERP_H
@@ -106,6 +113,19 @@ NXS_INTERP_API int nxs_interp_grid_to_mesh(double *data_mesh, const double *x_in
                                            const double *data, int32_t M, int32_t N, int32_t N_data, const double *x_mesh,
                                            const double *y_mesh, int32_t nods, double default_value, int32_t interp, int32_t row_major,
                                            int32_t device, double *kernel_ms);
+
+/* Of this thread's last nxs_interp_mesh_to_mesh_2d call: size of the completion, and how many target points were in no
+ * triangle of the data mesh / of those, inside a fill triangle / projected on the hull / handled by the nearest-boundary-edge
+ * stand-in; *completion_refused = why no completion was built (NULL when one was, or when isdefault != 0).  Any pointer may be NULL. */
+NXS_INTERP_API int nxs_interp_last_info(int32_t *num_fill_triangles, int32_t *num_hull_edges, int32_t *num_exterior, int32_t *num_in_fill,
+                                        int32_t *num_on_hull, int32_t *num_stand_in, const char **completion_refused);
+
+/* Host only: bamg's convex completion of a mesh (index 1-based): the triangles ReconstructExistingMesh adds between the
+ * boundary and the convex hull and inside the holes (fill_tri: 1-based, counter-clockwise, [3*cap_fill]) and the hull edges
+ * counter-clockwise (hull_edges: 1-based vertex pairs, [2*cap_hull]).  Output arrays may be NULL to query the counts. */
+NXS_INTERP_API int nxs_mesh_convex_completion(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
+                                              int32_t *num_fill, int32_t *fill_tri, int32_t cap_fill, int32_t *num_hull,
+                                              int32_t *hull_edges, int32_t cap_hull);
 
 NXS_INTERP_API const char *nxs_interp_last_error(void);
 

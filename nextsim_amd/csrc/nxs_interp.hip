@@ -16,11 +16,13 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
 #include "nxs_dyn.h"
 #include "nxs_interp.h"
+#include "nxs_hull.inl"
 
 namespace {
 
@@ -40,8 +42,13 @@ struct BEdge {  // a boundary edge as seen from its (inside) triangle
     int tri, k;  // triangle number, local edge index (vertices VOTE[k][0] -> VOTE[k][1])
 };
 
+struct HullDev { int a, b, tri, k; };  // nxs_hull::HullEdge
+
 struct InterpDev {
     int nods, nels, N_data, N_interp, nodal;
+    int nels_all;                  // nels + the fill triangles of bamg's convex completion (isdefault == 0 only), numbered behind the mesh's
+    int nhull;                     // hull edges, counter-clockwise; 0 = no completion (then the nearest boundary edge stands in)
+    const HullDev *hull;
     const int *t0, *t1, *t2;       // 0-based vertices
     const int *ix, *iy;            // integer coordinates of the data vertices
     int G, shift;                  // bucket grid: G x G cells of 2^shift integer units
@@ -66,8 +73,12 @@ __device__ __forceinline__ long long det3(long long ax, long long ay, long long 
 __device__ __forceinline__ int locate(const InterpDev &d, double x, double y, long long dd[3], long long &Bx, long long &By) {
     const double fx = d.coef * (x - d.pminx), fy = d.coef * (y - d.pminy);
     const bool in_plane = fx > -1. && fx < 1073741824. && fy > -1. && fy < 1073741824.;
-    Bx = in_plane ? (long long)(int)fx : (fx < 0. ? -1073741824ll : 2147483647ll);
-    By = in_plane ? (long long)(int)fy : (fy < 0. ? -1073741824ll : 2147483647ll);
+    // (Icoor1) of a double: truncation; beyond the range of an int the x86 conversion the reference runs on yields INT_MIN.  A
+    // point outside the integer plane (more than 5 % of the extent beyond the data mesh's bounding box) keeps its true integer
+    // coordinates -- the hull projection below needs them
+    const bool fits_x = fx > -2147483649. && fx < 2147483648., fits_y = fy > -2147483649. && fy < 2147483648.;
+    Bx = fits_x ? (long long)(int)fx : -2147483648ll;
+    By = fits_y ? (long long)(int)fy : -2147483648ll;
     if (in_plane && Bx >= 0 && By >= 0) {
         const int cx = (int)(Bx >> d.shift), cy = (int)(By >> d.shift);
         if (cx < d.G && cy < d.G) {
@@ -86,6 +97,8 @@ __device__ __forceinline__ int locate(const InterpDev &d, double x, double y, lo
     return -1;
 }
 
+// counters of one call: [0] points in no triangle of the data mesh, [1] of those, interpolated inside a fill triangle,
+// [2] projected on the hull (CloseBoundaryEdge), [3] handled by the nearest-boundary-edge stand-in
 __global__ void __launch_bounds__(256) k_interp(InterpDev d, const double *__restrict__ data, const double *__restrict__ xi,
                                                 const double *__restrict__ yi, double *__restrict__ out, int *num_exterior) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -99,6 +112,15 @@ __global__ void __launch_bounds__(256) k_interp(InterpDev d, const double *__res
     long long dd[3] = {0, 0, 0}, Bx, By;
     int it = locate(d, x, y, dd, Bx, By);
     double a[3];
+    if (it >= d.nels) {  // inside the hull, outside the mesh: a fill triangle of bamg's reconstructed mesh (Mesh.cpp:3135-3440)
+        atomicAdd(num_exterior, 1);
+        if (d.isdefault) {   // InterpFromMeshToMesh2dx.cpp:124-128 (reft < 0)
+            for (int j = 0; j < d.N_data; ++j) o[j] = d.defaultvalue;
+            return;
+        }
+        if (d.nodal) atomicAdd(num_exterior + 1, 1);
+        else it = -2;        // element data: the reference stops with "Triangle number ... not in [0 nels]"; nearest boundary edge here
+    }
     if (it >= 0) {
         const long long det = dd[0] + dd[1] + dd[2];  // == det(v0,v1,v2) exactly
         a[0] = (double)dd[0] / det;                   // InterpFromMeshToMesh2dx.cpp:113-116
@@ -109,12 +131,57 @@ __global__ void __launch_bounds__(256) k_interp(InterpDev d, const double *__res
             for (int j = 0; j < d.N_data; ++j) o[j] = d.defaultvalue;
             return;
         }
-        // exterior point: nearest boundary edge, a/b as CloseBoundaryEdge (Mesh.cpp:4606-4625)
-        atomicAdd(num_exterior, 1);
+        if (it == -1) atomicAdd(num_exterior, 1);
+        const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+        // Beyond the hull: CloseBoundaryEdge (Mesh.cpp:4590-4627) slides along the hull edges until the point projects inside one
+        // (a = IJ.AJ / IJ2 for I, b = IJ.IA / IJ2 for J, placed in the slots of the triangle behind that edge,
+        // InterpFromMeshToMesh2dx.cpp:137-147) or changes direction at a vertex (weight 1 there).  On a convex hull the outward
+        // strips of the edges and the cones of the vertices tile the outside, so the edge or vertex it stops at does not depend on
+        // where it starts: the strip of a VISIBLE edge that holds the point, else the nearest hull vertex.
+        if (it == -1 && d.nhull > 0 && d.nodal) {
+            int hit = -1;
+            double ha = 0., hb = 0.;
+            long long bestd = 0x7fffffffffffffffll;
+            int bestv = -1;
+            for (int e = 0; e < d.nhull; ++e) {
+                const HullDev h = d.hull[e];
+                const long long ax = d.ix[h.a], ay = d.iy[h.a], bx = d.ix[h.b], by = d.iy[h.b];
+                if (det3(ax, ay, bx, by, Bx, By) >= 0) continue;  // not visible from the point
+                // seen from outside the edge runs I = b -> J = a
+                const long long IJx = ax - bx, IJy = ay - by;
+                const long long IJ_IA = IJx * (Bx - bx) + IJy * (By - by), IJ_AJ = IJx * (ax - Bx) + IJy * (ay - By);
+                if (IJ_IA >= 0 && IJ_AJ >= 0) {
+                    const double IJ2 = (double)(IJ_IA + IJ_AJ);
+                    hit = e; ha = IJ_AJ / IJ2; hb = IJ_IA / IJ2;
+                    break;
+                }
+                const long long da = (Bx - ax) * (Bx - ax) + (By - ay) * (By - ay), db = (Bx - bx) * (Bx - bx) + (By - by) * (By - by);
+                if (da < bestd) { bestd = da; bestv = h.a; }
+                if (db < bestd) { bestd = db; bestv = h.b; }
+            }
+            if (hit >= 0) {
+                atomicAdd(num_exterior + 2, 1);
+                const HullDev h = d.hull[hit];
+                const int tv[3] = {d.t0[h.tri], d.t1[h.tri], d.t2[h.tri]};
+                // in the triangle behind the edge: VOTE[k][1] is I = b, VOTE[k][0] is J = a
+                a[VOTE[h.k][1]] = ha;
+                a[VOTE[h.k][0]] = hb;
+                a[h.k] = 1 - ha - hb;
+                for (int j = 0; j < d.N_data; ++j)
+                    o[j] = a[0] * data[(size_t)d.N_data * tv[0] + j] + a[1] * data[(size_t)d.N_data * tv[1] + j] + a[2] * data[(size_t)d.N_data * tv[2] + j];
+                return;
+            }
+            if (bestv >= 0) {  // a = 1, b = 0 at a hull vertex: 1 * data + 0 * data + 0 * data
+                atomicAdd(num_exterior + 2, 1);
+                for (int j = 0; j < d.N_data; ++j) o[j] = data[(size_t)d.N_data * bestv + j];
+                return;
+            }
+        }
+        // stand-in (no completion for this mesh, or element data): nearest boundary edge, a/b as CloseBoundaryEdge
+        atomicAdd(num_exterior + 3, 1);
         double best = INFINITY;
         int bk = -1;
         double ba = 0., bb = 0.;
-        const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
         for (int e = 0; e < d.nbe; ++e) {
             const BEdge be = d.bedges[e];
             const int tv[3] = {d.t0[be.tri], d.t1[be.tri], d.t2[be.tri]};
@@ -226,11 +293,16 @@ __global__ void __launch_bounds__(256) k_mesh_to_grid(GridDev d, const double *_
 namespace {
 
 // The data mesh in bamg's integer plane + the bucket grid used by locate(), resident on the device.
+thread_local int g_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // of the last mesh-to-mesh call of this thread (nxs_interp_last_info)
+thread_local std::string g_completion_note;
+
 struct Locator {
     InterpDev d{};
     DevBuf<int> dt0, dt1, dt2, dix, diy, doff, dtri;
     DevBuf<BEdge> dbe;
+    DevBuf<HullDev> dhull;
     std::vector<int> t0, t1, t2;
+    nxs_hull::Completion comp;
 
     int build(const int32_t *index_data, const double *x_data, const double *y_data, int32_t nods, int32_t nels, bool need_boundary_edges) {
         // ---- SetIntCoor (Mesh.cpp:3441-3468)
@@ -252,6 +324,17 @@ struct Locator {
         }
         t0.resize(nels); t1.resize(nels); t2.resize(nels);
         for (int e = 0; e < nels; ++e) { t0[e] = index_data[3 * e] - 1; t1[e] = index_data[3 * e + 1] - 1; t2[e] = index_data[3 * e + 2] - 1; }
+        // ---- bamg's convex completion (isdefault == false only): fill triangles numbered behind the mesh's, hull edges
+        const int nels_mesh = nels;
+        std::vector<HullDev> hull;
+        if (need_boundary_edges) {
+            comp = nxs_hull::complete(index_data, ix.data(), iy.data(), nods, nels);
+            if (comp.ok) {
+                for (size_t i = 0; i + 2 < comp.fill.size(); i += 3) { t0.push_back(comp.fill[i]); t1.push_back(comp.fill[i + 1]); t2.push_back(comp.fill[i + 2]); }
+                for (const auto &h : comp.hull) hull.push_back(HullDev{h.a, h.b, h.tri, h.k});
+                nels = (int)t0.size();  // the bucket grid below covers the fill triangles too (ascending numbers: the mesh's first)
+            }
+        }
 
         // ---- bucket grid over the integer plane
         int G = 1;
@@ -283,8 +366,8 @@ struct Locator {
         if (need_boundary_edges) {
             static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
             std::vector<std::pair<long long, int>> keys;  // (sorted vertex pair, 3*tri + k)
-            keys.reserve(3 * (size_t)nels);
-            for (int e = 0; e < nels; ++e) {
+            keys.reserve(3 * (size_t)nels_mesh);
+            for (int e = 0; e < nels_mesh; ++e) {
                 const int tv[3] = {t0[e], t1[e], t2[e]};
                 for (int k = 0; k < 3; ++k) {
                     const int p = tv[VOTE[k][0]], q = tv[VOTE[k][1]];
@@ -302,9 +385,10 @@ struct Locator {
         }
         if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || dix.upload(ix.data(), nods) ||
             diy.upload(iy.data(), nods) || doff.upload(cnt.data(), cnt.size()) || dtri.upload(cell_tri.data(), cell_tri.size()) ||
-            dbe.upload(bedges.data(), bedges.size()))
+            dbe.upload(bedges.data(), bedges.size()) || dhull.upload(hull.data(), hull.size()))
             return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
-        d.nods = nods; d.nels = nels;
+        d.nods = nods; d.nels = nels_mesh; d.nels_all = nels;
+        d.nhull = (int)hull.size(); d.hull = dhull.p;
         d.t0 = dt0.p; d.t1 = dt1.p; d.t2 = dt2.p; d.ix = dix.p; d.iy = diy.p;
         d.G = G; d.shift = shift; d.cell_off = doff.p; d.cell_tri = dtri.p;
         d.nbe = (int)bedges.size(); d.bedges = dbe.p;
@@ -408,9 +492,9 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     DevBuf<int> dnext;
     DevBuf<double> ddata, dxi, dyi, dout;
     if (ddata.upload(data, (size_t)M_data * N_data) || dxi.upload(x_interp, N_interp) || dyi.upload(y_interp, N_interp) ||
-        dout.alloc((size_t)N_interp * N_data) || dnext.alloc(1))
+        dout.alloc((size_t)N_interp * N_data) || dnext.alloc(4))
         return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
-    if (hipMemset(dnext.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+    if (hipMemset(dnext.p, 0, 4 * sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
     d.N_data = N_data; d.N_interp = N_interp; d.nodal = (M_data == nods);
     d.isdefault = isdefault != 0; d.defaultvalue = defaultvalue;
 
@@ -429,9 +513,52 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     if (kernel_ms) *kernel_ms = ms;
     if (N_interp > 0 && hipMemcpy(data_interp, dout.p, (size_t)N_interp * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(NXS_ERR_HIP, "copy back failed");
-    int next = 0;
-    (void)hipMemcpy(&next, dnext.p, sizeof(int), hipMemcpyDeviceToHost);
-    if (num_exterior) *num_exterior = next;
+    int next[4] = {0, 0, 0, 0};
+    (void)hipMemcpy(next, dnext.p, sizeof next, hipMemcpyDeviceToHost);
+    if (num_exterior) *num_exterior = next[0];
+    g_info[0] = (int)loc.comp.fill.size() / 3; g_info[1] = (int)loc.comp.hull.size();
+    g_info[2] = next[0]; g_info[3] = next[1]; g_info[4] = next[2]; g_info[5] = next[3];
+    g_info[6] = (!isdefault && !loc.comp.ok) ? 1 : 0;
+    g_completion_note = loc.comp.ok ? "" : loc.comp.why;
+    return NXS_OK;
+}
+
+extern "C" int nxs_interp_last_info(int32_t *num_fill_triangles, int32_t *num_hull_edges, int32_t *num_exterior, int32_t *num_in_fill,
+                                    int32_t *num_on_hull, int32_t *num_stand_in, const char **completion_refused) {
+    if (num_fill_triangles) *num_fill_triangles = g_info[0];
+    if (num_hull_edges) *num_hull_edges = g_info[1];
+    if (num_exterior) *num_exterior = g_info[2];
+    if (num_in_fill) *num_in_fill = g_info[3];
+    if (num_on_hull) *num_on_hull = g_info[4];
+    if (num_stand_in) *num_stand_in = g_info[5];
+    if (completion_refused) *completion_refused = g_info[6] ? g_completion_note.c_str() : nullptr;
+    return NXS_OK;
+}
+
+// Host only: bamg's convex completion of a mesh (see nxs_hull.inl) -- what tests compare with the real bamg.
+extern "C" int nxs_mesh_convex_completion(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
+                                          int32_t *num_fill, int32_t *fill_tri, int32_t cap_fill, int32_t *num_hull, int32_t *hull_edges,
+                                          int32_t cap_hull) {
+    if (!index || !x || !y || nods < 3 || nels < 1 || !num_fill || !num_hull) return fail(NXS_ERR_INVALID, "bad arguments");
+    for (int64_t i = 0; i < 3ll * nels; ++i)
+        if (index[i] < 1 || index[i] > nods) return fail(NXS_ERR_INVALID, "index[%lld] out of range", (long long)i);
+    // SetIntCoor, Mesh.cpp:3441-3468 (as Locator::build)
+    double pminx = x[0], pminy = y[0], pmaxx = x[0], pmaxy = y[0];
+    for (int i = 0; i < nods; ++i) { pminx = std::min(pminx, x[i]); pminy = std::min(pminy, y[i]); pmaxx = std::max(pmaxx, x[i]); pmaxy = std::max(pmaxy, y[i]); }
+    const double DDx = (pmaxx - pminx) * 0.05, DDy = (pmaxy - pminy) * 0.05;
+    pminx = pminx - DDx; pminy = pminy - DDy; pmaxx = pmaxx + DDx; pmaxy = pmaxy + DDy;
+    const double coef = 1073741823. / std::max(pmaxx - pminx, pmaxy - pminy);
+    if (!(coef > 0.)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive");
+    std::vector<int> ix(nods), iy(nods);
+    for (int i = 0; i < nods; ++i) { ix[i] = (int)(coef * (x[i] - pminx)); iy[i] = (int)(coef * (y[i] - pminy)); }
+    const nxs_hull::Completion c = nxs_hull::complete(index, ix.data(), iy.data(), nods, nels);
+    if (!c.ok) return fail(NXS_ERR_INVALID, "no convex completion: %s", c.why.c_str());
+    *num_fill = (int)c.fill.size() / 3; *num_hull = (int)c.hull.size();
+    if (fill_tri) { if (cap_fill < *num_fill) return fail(NXS_ERR_INVALID, "fill_tri too small"); for (size_t i = 0; i < c.fill.size(); ++i) fill_tri[i] = c.fill[i] + 1; }
+    if (hull_edges) {
+        if (cap_hull < *num_hull) return fail(NXS_ERR_INVALID, "hull_edges too small");
+        for (size_t i = 0; i < c.hull.size(); ++i) { hull_edges[2 * i] = c.hull[i].a + 1; hull_edges[2 * i + 1] = c.hull[i].b + 1; }
+    }
     return NXS_OK;
 }
 

@@ -112,7 +112,7 @@ EXPORTS = (
     "nxs_dyn_debug_array", "nxs_dyn_get_branch_trace", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
 )
 INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
-                  "nxs_interp_last_error")
+                  "nxs_interp_last_error", "nxs_interp_last_info", "nxs_mesh_convex_completion")
 
 
 def mesh_connectivity(indices: np.ndarray, num_nodes: int):

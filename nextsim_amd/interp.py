@@ -26,8 +26,42 @@ def _lib():
                                                  C.POINTER(C.c_double)]
         L.nxs_interp_mesh_to_mesh_2d.restype = C.c_int
         L.nxs_interp_last_error.restype = C.c_char_p
+        I = C.POINTER(C.c_int32)
+        L.nxs_interp_last_info.argtypes = [I, I, I, I, I, I, C.POINTER(C.c_char_p)]
+        L.nxs_mesh_convex_completion.argtypes = [_abi.c_int32_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_int32, I, _abi.c_int32_p,
+                                                 C.c_int32, I, _abi.c_int32_p, C.c_int32]
         _declared = True
     return L
+
+
+def last_info() -> dict:
+    """Of this thread's last InterpFromMeshToMesh2dx call: the completion's size and which way the exterior points went."""
+    L = _lib()
+    v = [C.c_int32(0) for _ in range(6)]
+    why = C.c_char_p()
+    L.nxs_interp_last_info(*[C.byref(q) for q in v], C.byref(why))
+    keys = ("num_fill_triangles", "num_hull_edges", "num_exterior", "num_in_fill", "num_on_hull", "num_stand_in")
+    out = {k: q.value for k, q in zip(keys, v)}
+    out["completion_refused"] = why.value.decode() if why.value else None
+    return out
+
+
+def convex_completion(index, x, y):
+    """bamg's convex completion of a mesh (index 1-based): (fill triangles [n, 3], hull edges [m, 2]), 1-based, counter-clockwise.
+    Host code of the product library (csrc/nxs_hull.inl)."""
+    L = _lib()
+    index = np.ascontiguousarray(index, np.int32).ravel()
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    nf, nh = C.c_int32(0), C.c_int32(0)
+    rc = L.nxs_mesh_convex_completion(_abi.iptr(index), _abi.dptr(x), _abi.dptr(y), x.size, index.size // 3, C.byref(nf), None, 0, C.byref(nh), None, 0)
+    if rc:
+        raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
+    fill = np.zeros((max(nf.value, 1), 3), np.int32); hull = np.zeros((max(nh.value, 1), 2), np.int32)
+    rc = L.nxs_mesh_convex_completion(_abi.iptr(index), _abi.dptr(x), _abi.dptr(y), x.size, index.size // 3, C.byref(nf), _abi.iptr(fill), nf.value,
+                                      C.byref(nh), _abi.iptr(hull), nh.value)
+    if rc:
+        raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
+    return fill[:nf.value], hull[:nh.value]
 
 
 def InterpFromMeshToMesh2dx(index_data, x_data, y_data, data, x_interp, y_interp, isdefault=False, defaultvalue=1e-24,
@@ -50,7 +84,7 @@ def InterpFromMeshToMesh2dx(index_data, x_data, y_data, data, x_interp, y_interp
     if rc:
         raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
     if return_info:
-        return out, {"num_exterior": next_.value, "kernel_ms": ms.value}
+        return out, dict(last_info(), num_exterior=next_.value, kernel_ms=ms.value)
     return out
 
 

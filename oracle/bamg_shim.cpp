@@ -197,3 +197,30 @@ int shim_bamg_interp_grid_to_mesh(const double *x_in, int x_rows, const double *
 }
 
 } /* extern "C" */
+
+#include "Mesh.h"
+
+extern "C" {
+
+/* The convex completion InterpFromMeshToMesh2dx works on (InterpFromMeshToMesh2dx.cpp:60-65: Mesh(index, x, y, nods, nels) =
+ * ReadMesh + SetIntCoor + ReconstructExistingMesh, then TriangleReferenceList): every triangle of bamg's reconstructed mesh in
+ * bamg's own order and vertex order -- the given triangles first, then the triangles bamg added to fill holes and concave parts
+ * of the boundary, and its boundary ("infinite") triangles with one NULL vertex (-1 here).  tri: [3*max_nbt], reft: [max_nbt]
+ * (< 0 = outside the mesh).  Returns the number of triangles (or -1 - needed when max_nbt is too small). */
+int shim_bamg_completed_mesh(const int *index, const double *x, const double *y, int nods, int nels, int max_nbt, int *tri, long *reft) {
+    bamg::Mesh *Th = new bamg::Mesh(const_cast<int *>(index), const_cast<double *>(x), const_cast<double *>(y), nods, nels);
+    const int nbt = (int)Th->nbt;
+    if (nbt > max_nbt) { delete Th; return -1 - nbt; }
+    long *r = new long[nbt];
+    Th->TriangleReferenceList(r);
+    for (int i = 0; i < nbt; ++i) {
+        bamg::Triangle &t = Th->triangles[i];
+        for (int k = 0; k < 3; ++k) tri[3 * i + k] = t(k) ? (int)Th->GetId(t(k)) : -1;
+        reft[i] = r[i];
+    }
+    delete[] r;
+    delete Th;
+    return nbt;
+}
+
+} /* extern "C" */

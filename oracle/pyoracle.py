@@ -247,6 +247,22 @@ def multirank_step(ranks: list):
         r.update()
 
 
+def bamg_completed_mesh(index, x, y):
+    """The REAL bamg's reconstructed mesh (Mesh(index, x, y, ...), what InterpFromMeshToMesh2dx locates its points in): every
+    triangle in bamg's order and vertex order, 0-based, -1 = the NULL vertex of a boundary triangle; and TriangleReferenceList."""
+    L = C.CDLL(os.path.join(HERE, "_ref", "libbamg_shim.so"))
+    idx = np.ascontiguousarray(np.asarray(index).ravel().astype(np.intc))
+    x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
+    cap = 4 * (idx.size // 3) + 64
+    tri = np.zeros(3 * cap, np.intc); reft = np.zeros(cap, np.int64)
+    L.shim_bamg_completed_mesh.restype = C.c_int
+    L.shim_bamg_completed_mesh.argtypes = [C.POINTER(C.c_int), _abi.c_double_p, _abi.c_double_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_long)]
+    n = L.shim_bamg_completed_mesh(idx.ctypes.data_as(C.POINTER(C.c_int)), _abi.dptr(x), _abi.dptr(y), x.size, idx.size // 3, cap,
+                                   tri.ctypes.data_as(C.POINTER(C.c_int)), reft.ctypes.data_as(C.POINTER(C.c_long)))
+    assert n >= 0, n
+    return tri[:3 * n].reshape(-1, 3).copy(), reft[:n].copy()
+
+
 def bamg_interp_mesh_to_mesh(index_data, x_data, y_data, data, x_interp, y_interp, isdefault=False, defaultvalue=1e-24):
     """The REAL InterpFromMeshToMesh2dx (contrib/bamg/src/InterpFromMeshToMesh2dx.cpp) through the shim."""
     L = bamg_shim()

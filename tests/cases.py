@@ -39,6 +39,21 @@ def make_case(kind="small", forcing_kind=None, nparts=1, alea=0.33, ragged_seed=
     return gm, p, g, lms, fields
 
 
+def mesh_with_holes(kind="small", holes=((0.25, -0.1, 0.12), (-0.3, 0.3, 0.07))):
+    """The mesh `kind` with islands cut out of it: every triangle with a vertex inside one of the circles (centre and radius in
+    units of the mesh radius) is removed, unused nodes are dropped.  Returns x, y, tri (0-based): a domain with inner boundaries,
+    as a pan-Arctic mesh has around its islands."""
+    gm = global_mesh(kind)
+    R = np.hypot(gm.x, gm.y).max()
+    kill = np.zeros(gm.num_nodes, bool)
+    for cx, cy, r in holes:
+        kill |= np.hypot(gm.x - cx * R, gm.y - cy * R) < r * R
+    tri = gm.tri[~kill[gm.tri].any(1)]
+    used = np.unique(tri)
+    new = np.full(gm.num_nodes, -1, np.int64); new[used] = np.arange(used.size)
+    return gm.x[used].copy(), gm.y[used].copy(), np.ascontiguousarray(new[tri], np.int32)
+
+
 def rel_err(a, b):
     """max |a-b| / max|b| (fields here have a natural scale; pointwise relative error is meaningless
     near zero crossings)."""

@@ -16,6 +16,9 @@
                          nodal variables) -- pins both regrid kernels on what bamg really produces.
   bamg_grid_to_mesh.npz  REAL contrib/bamg InterpFromGridToMeshx (forcing ingest, externaldata.cpp:1436): bilinear / triangle /
                          nearest, descending axes, pixel contours, NaN data, row-major data, nodes on grid lines and outside.
+  bamg_completion.npz    REAL contrib/bamg Mesh(index, x, y, ...) = ReconstructExistingMesh: the triangles it adds between the boundary
+                         and the convex hull and inside holes, and its hull edges, on five meshes -- pins the convex completion the
+                         regrid interpolation needs for points outside the data mesh.
   mapx_lat.npz           REAL contrib/mapx inverse_mapx with mesh/NpsNextsim.mpp (GmshMesh::lat(), gmshmesh.cpp:1798-1824) at
                          600 points -- pins the latitude (Coriolis, sign of the turning angle) of the synthetic meshes.
   oracle_tiny.npz        oracle (liboracle.so) state on the 'tiny' toy case after 1 sub-step, 1 step
@@ -207,6 +210,39 @@ def make_mapx_fixture():
     np.savez_compressed(os.path.join(HERE, "mapx_lat.npz"), x=x, y=y, lat=O.mapx_lat(x, y))
 
 
+def completion_cases():
+    """Meshes of the completion fixture: name -> (x, y, tri 0-based)."""
+    out = {}
+    for kind in ("small", "40km"):
+        gm = cases.global_mesh(kind)
+        out[kind] = (gm.x, gm.y, gm.tri)
+        out[kind + "_holes"] = cases.mesh_with_holes(kind)
+    gm = cases.global_mesh("toy")
+    out["toy"] = (gm.x, gm.y, gm.tri)
+    return out
+
+
+def make_completion_fixture():
+    """bamg_completion.npz: what the REAL bamg adds to a mesh when it reconstructs it (Mesh(index, x, y, ...), the mesh
+    InterpFromMeshToMesh2dx works on): the fill triangles (sorted vertex triples, sorted) and the hull edges (from the boundary
+    triangles, as counter-clockwise pairs, sorted) -- pins csrc/nxs_hull.inl."""
+    out = {}
+    for name, (x, y, tri) in completion_cases().items():
+        T, reft = O.bamg_completed_mesh((tri + 1).ravel(), x, y)
+        ne = tri.shape[0]
+        assert np.array_equal(T[:ne], tri) and np.all(reft[:ne] >= 0)
+        extra = T[ne:]; inf = (extra < 0).any(1)
+        assert np.all(reft[ne:][~inf] < 0)
+        fill = np.array(sorted(tuple(sorted(r)) for r in extra[~inf].tolist()), np.int32).reshape(-1, 3)
+        hull = []
+        for r in extra[inf].tolist():
+            k = r.index(-1)
+            hull.append((r[(k + 2) % 3], r[(k + 1) % 3]))     # the boundary triangle sees its real edge clockwise
+        out[name + "_fill"] = fill
+        out[name + "_hull"] = np.array(sorted(hull), np.int32).reshape(-1, 2)
+    np.savez_compressed(os.path.join(HERE, "bamg_completion.npz"), **out)
+
+
 def make_connectivity_fixture():
     lm = M.localize(cases.global_mesh("tiny"), 1)[0]
     nec, nc = O.bamg_connectivity(lm.indices, lm.coord_x, lm.coord_y)
@@ -219,7 +255,7 @@ def main():
     assert O.bamg_shim() is not None, "build oracle/_ref first (make -C oracle ref)"
     makers = {"connectivity": make_connectivity_fixture, "interp": make_interp_fixture, "grid": make_grid_fixture,
               "remap": make_remap_fixture, "mapx": make_mapx_fixture, "grid_to_mesh": make_grid_to_mesh_fixture,
-              "regrid": make_regrid_fixture, "oracle": make_oracle_fixture}
+              "regrid": make_regrid_fixture, "oracle": make_oracle_fixture, "completion": make_completion_fixture}
     for name in (sys.argv[1:] or list(makers)):
         makers[name]()
         print("wrote", name)

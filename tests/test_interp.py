@@ -3,9 +3,12 @@ nxs_interp_mesh_to_mesh_2d against the REAL contrib/bamg InterpFromMeshToMesh2dx
 is present, and through the committed fixture tests/golden/bamg_interp.npz generated with it.
 
 Bar: bit-exact for every target point that lies in the data mesh (the weights are ratios of the same
-64-bit integer determinants, combined in the same order); default value outside when isdefault; for
-isdefault == false exterior points are projected on the nearest boundary edge (documented deviation:
-the reference walks bamg's hull triangulation), checked to a loose tolerance and counted."""
+64-bit integer determinants, combined in the same order); default value outside when isdefault.  With
+isdefault == false (the regrid call) the reference works on bamg's RECONSTRUCTED mesh -- fill triangles
+between the boundary and the convex hull and inside holes, hull projection beyond (CloseBoundaryEdge): the
+same completion is rebuilt here (csrc/nxs_hull.inl, pinned against the real bamg on five meshes) and
+exterior points get the reference's value to the last bit or -- inside a fill triangle, whose three
+vertices bamg may hold in a rotated order -- to one unit in the last place."""
 import os
 import sys
 
@@ -30,6 +33,47 @@ def test_real_bamg_reproduces_the_committed_fixture():
     assert np.array_equal(O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, nodal, xi, yi, True, -999.0), z["nodal_default"])
     ins = kind == 0
     assert np.array_equal(O.bamg_interp_mesh_to_mesh(idx, gm.x, gm.y, elemental, xi[ins], yi[ins], False), z["elemental"])
+
+
+def _completion_sets(x, y, tri):
+    from nextsim_amd.interp import convex_completion
+    fill, hull = convex_completion((tri + 1).ravel(), x, y)
+    return ({tuple(sorted((r - 1).tolist())) for r in fill}, {(int(a) - 1, int(b) - 1) for a, b in hull}, fill)
+
+
+def test_convex_completion_equals_what_the_real_bamg_builds():
+    """Host code of the product (csrc/nxs_hull.inl) against the committed fixture made with the REAL bamg: the triangles
+    ReconstructExistingMesh adds (Mesh.cpp:3135-3440) and its hull, on a disc with an irregular coast, the same with two
+    islands cut out, both at two resolutions, and the toy box -- identical sets; no fill triangle clockwise."""
+    z = np.load(os.path.join(os.path.dirname(GOLD), "bamg_completion.npz"))
+    for name, (x, y, tri) in make_golden.completion_cases().items():
+        mine_fill, mine_hull, fill = _completion_sets(x, y, tri)
+        assert mine_fill == {tuple(r) for r in z[name + "_fill"].tolist()}, name
+        assert mine_hull == {tuple(r) for r in z[name + "_hull"].tolist()}, name
+        f = fill - 1
+        jac = (x[f[:, 1]] - x[f[:, 0]]) * (y[f[:, 2]] - y[f[:, 0]]) - (x[f[:, 2]] - x[f[:, 0]]) * (y[f[:, 1]] - y[f[:, 0]])
+        assert (jac > -1e-2).all() and (jac > 1.).mean() > 0.8, name      # (a straight piece of coast gives zero-area fill triangles, in bamg too)
+    assert z["small_holes_fill"].shape[0] > z["small_fill"].shape[0] > 50       # the islands are filled too
+
+
+@pytest.mark.skipif(O.bamg_shim() is None, reason="oracle/_ref (real contrib/bamg) not built here")
+def test_convex_completion_equals_the_real_bamg_live_at_10km():
+    gm = cases.global_mesh("10km")
+    T, reft = O.bamg_completed_mesh((gm.tri + 1).ravel(), gm.x, gm.y)
+    extra = T[gm.num_elements:]; inf = (extra < 0).any(1)
+    mine_fill, mine_hull, _ = _completion_sets(gm.x, gm.y, gm.tri)
+    assert mine_fill == {tuple(sorted(r)) for r in extra[~inf].tolist()} and len(mine_hull) == int(inf.sum())
+
+
+def test_convex_completion_refuses_what_it_does_not_cover():
+    from nextsim_amd.interp import convex_completion
+    from nextsim_amd.dynamics import NxsError
+    x = np.array([0., 1., 0., 5., 6., 5.]); y = np.array([0., 0., 1., 0., 0., 1.])
+    with pytest.raises(NxsError, match="several outer boundary loops"):
+        convex_completion(np.array([1, 2, 3, 4, 5, 6]), x, y)                # two components
+    x = np.array([0., 1., 0., -1., 0.]); y = np.array([0., 0., 1., 0., -1.])
+    with pytest.raises(NxsError, match="two outgoing boundary edges"):
+        convex_completion(np.array([1, 2, 3, 1, 4, 5]), x, y)                # two triangles touching at one vertex
 
 
 def test_fixture_is_sane():
@@ -57,16 +101,19 @@ def test_gpu_interpolation_matches_real_bamg_fixture_bit_for_bit():
     out, info = InterpFromMeshToMesh2dx(idx, gm.x, gm.y, nodal, xi, yi, False, return_info=True)
     assert np.array_equal(out[inside], z["nodal"][inside])
     assert info["num_exterior"] == int((kind >= 2).sum())
-    # points 50 m outside the boundary (a mesh that moved a little), isdefault == false.  The reference
-    # interpolates those inside bamg's hull-filling triangles when the boundary is locally concave and
-    # projects on a boundary edge (CloseBoundaryEdge) otherwise; here: always the nearest boundary edge.
-    # Documented deviation -- only closeness is asserted: same value for most points, and always a convex
-    # combination of nodal values.
-    near = kind == 2
-    scale = np.abs(z["nodal"]).max(0)
-    rel = (np.abs(out[near] - z["nodal"][near]) / scale).max(1)
-    assert np.median(rel) < 1e-3
-    assert np.all(out[kind >= 2] >= nodal.min(0) - 1e-9) and np.all(out[kind >= 2] <= nodal.max(0) + 1e-9)
+    # points 50 m outside the boundary (a mesh that moved a little) and far outside, isdefault == false: the reference interpolates
+    # inside bamg's fill triangles where the boundary is concave and projects on the hull (CloseBoundaryEdge) beyond it.  Same
+    # completion here, so: the reference's bits wherever the triangle behind the point is a mesh triangle, and at most one unit in
+    # the last place inside a fill triangle (same three products, possibly added in a rotated order).
+    ext = kind >= 2
+    assert info["completion_refused"] is None and info["num_stand_in"] == 0
+    assert info["num_in_fill"] + info["num_on_hull"] == int(ext.sum()) and info["num_in_fill"] > 20 and info["num_on_hull"] > 20
+    scale = np.abs(nodal).max(0)
+    rel = (np.abs(out[ext] - z["nodal"][ext]) / scale).max(1)
+    assert rel.max() <= 4.5e-16, rel.max()
+    exact = np.all(out[ext] == z["nodal"][ext], axis=1)
+    assert exact.mean() > 0.5, exact.mean()
+    print(f"exterior points: {int(ext.sum())}, bit-identical {exact.mean():.3f}, worst {rel.max():.1e} of the field scale")
     outd = InterpFromMeshToMesh2dx(idx, gm.x, gm.y, nodal, xi, yi, True, -999.0)
     tie = (kind == 1) & np.all(z["nodal_default"] == -999.0, axis=1)   # see test_fixture_is_sane
     assert np.array_equal(outd[~tie], z["nodal_default"][~tie])
@@ -98,6 +145,28 @@ def test_gpu_interpolation_matches_real_bamg_live_regrid_shape():
     # ... or sits in bamg's hull-filling triangles outside the data mesh, where the reference does not
     # return the default although the point is outside (reft >= 0 there only inside the mesh)
     assert np.all(got[~same] == 0.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(O.bamg_shim() is None, reason="oracle/_ref (real contrib/bamg) not present on this box")
+def test_gpu_interpolation_on_a_mesh_with_islands_matches_real_bamg_live():
+    """isdefault == false on a domain with inner boundaries: target points inside the islands (bamg fills them with triangles
+    between their shore vertices), in the pockets of the coast, beyond the hull, and inside the mesh -- against the real bamg."""
+    from nextsim_amd.interp import InterpFromMeshToMesh2dx
+    x, y, tri = cases.mesh_with_holes("40km")
+    rng = np.random.default_rng(3)
+    R = np.hypot(x, y).max()
+    data = np.stack([np.sin(x / 5e5) + np.cos(y / 7e5), 1e-3 * x - 2e-3 * y, rng.standard_normal(x.size)], 1)
+    th = rng.uniform(0, 2 * np.pi, 3000); rr = R * np.sqrt(rng.uniform(0, 1.3 ** 2, 3000))
+    xi, yi = rr * np.cos(th), rr * np.sin(th)
+    idx = (tri + 1).ravel()
+    ref = O.bamg_interp_mesh_to_mesh(idx, x, y, data, xi, yi, False)
+    got, info = InterpFromMeshToMesh2dx(idx, x, y, data, xi, yi, False, return_info=True)
+    assert info["completion_refused"] is None and info["num_stand_in"] == 0
+    assert info["num_in_fill"] > 50 and info["num_on_hull"] > 200 and info["num_exterior"] == info["num_in_fill"] + info["num_on_hull"]
+    rel = (np.abs(got - ref) / np.abs(data).max(0)).max(1)
+    assert rel.max() <= 4.5e-16, rel.max()
+    assert np.all(got == ref, axis=1).mean() > 0.9
 
 
 @pytest.mark.gpu

@@ -239,8 +239,4 @@ def test_gpu_regrid_kernels_match_the_reference_on_a_real_regrid():
                                                 z["prev"], int(z["ngeom"]), return_info=True)
     assert info["num_failed"] == 0 and _same(out, z["elt_out"])
     nod, ninfo = InterpFromMeshToMesh2dx(z["tri_old"] + 1, z["x_old"], z["y_old"], z["nod_in"], z["x_new"], z["y_new"], False, return_info=True)
-    inside = np.ones(z["x_new"].size, bool)
-    inside[:int(z["ngeom"])] = False          # boundary vertices: the reference's walk may end in a hull triangle (documented tie)
-    assert np.array_equal(nod[inside], z["nod_out"][inside])
-    scale = np.abs(z["nod_out"]).max()
-    assert np.abs(nod[~inside] - z["nod_out"][~inside]).max() < 1e-6 * scale
+    assert np.array_equal(nod, z["nod_out"])      # every vertex of the new mesh, its boundary vertices included
