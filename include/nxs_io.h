@@ -8,9 +8,12 @@
  *             sidecar = one text line per record  "name type count min max".
  *   Moorings  model/gridoutput.cpp:805-1035  CF-1.6 NetCDF: dims time(unlimited), nv=2, x, y;
  *             time, time_bnds, longitude, latitude, one float variable per field with _FillValue,
- *             optional Polar_Stereographic_Grid mapping variable.  The reference links netcdf-cxx4
- *             (NetCDF-4/HDF5); no NetCDF library exists in this image, so the file is written by hand in
- *             the NetCDF-3 classic format (CDF-1), which every NetCDF reader opens; schema unchanged.
+ *             optional Polar_Stereographic_Grid mapping variable.  The reference writes NetCDF-4 through netcdf-cxx4;
+ *             no NetCDF library exists in this image, so the file is written as NetCDF-4 through the HDF5 C library
+ *             (resolved with dlopen at the first call: libhdf5 + libhdf5_hl >= 1.10, NXS_HDF5_LIBRARY / NXS_HDF5_HL_LIBRARY
+ *             override the search) following the netCDF-4 on-disk conventions -- dimension scales, _Netcdf4Dimid, tracked
+ *             creation order, chunked unlimited dimension -- or, without HDF5 or on request, by hand as NetCDF-3 classic
+ *             (CDF-1), which every NetCDF reader opens too; same schema either way.
  */
 #ifndef NXS_IO_H
 #define NXS_IO_H
@@ -75,12 +78,19 @@ typedef struct nxs_mooring_proj { /* createProjectionVariable, gridoutput.cpp:94
 } nxs_mooring_proj;
 
 /* initNetCDF (gridoutput.cpp:805-940).  lon/lat: [nrows*ncols] floats, row-major (y, x).
- * averaging_period in days (0 = snapshots: "time: point "). */
+ * averaging_period in days (0 = snapshots: "time: point ").  nxs_moorings_create = format NXS_NC_AUTO: NetCDF-4 as the reference
+ * when the HDF5 library can be loaded, NetCDF-3 classic otherwise. */
+enum { NXS_NC_AUTO = 0, NXS_NC_CLASSIC = 3, NXS_NC_NETCDF4 = 4 };
+NXS_IO_API int nxs_moorings_create_format(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat,
+                                          int32_t nvars, const nxs_mooring_var *vars, float miss_val, double averaging_period,
+                                          const nxs_mooring_proj *proj, int32_t format);
+/* NXS_NC_CLASSIC or NXS_NC_NETCDF4 from the file's magic bytes; negative on error */
+NXS_IO_API int nxs_moorings_file_format(const char *path);
 NXS_IO_API int nxs_moorings_create(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat,
                                    int32_t nvars, const nxs_mooring_var *vars, float miss_val, double averaging_period,
                                    const nxs_mooring_proj *proj);
 /* appendNetCDF (gridoutput.cpp:984-1030): one more record; data[v] is [nrows*ncols] floats. timestamp in days
- * since 1900-01-01. */
+ * since 1900-01-01.  Works on either container (told apart by the magic bytes). */
 NXS_IO_API int nxs_moorings_append(const char *path, double timestamp, double averaging_period, int32_t nvars,
                                    const float *const *data);
 

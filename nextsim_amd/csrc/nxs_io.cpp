@@ -1,10 +1,10 @@
 // nxs_io.cpp -- host-side output writers of include/nxs_io.h.
 //
 //   Exporter : core/src/exporter.cpp:32-189 (binary records + "name type count min max" sidecar lines)
-//   Moorings : model/gridoutput.cpp:805-1035 (CF-1.6 schema), written as NetCDF-3 classic (CDF-1) by hand
-//              because no NetCDF library is available here; layout per the NetCDF classic format
-//              specification: big-endian header (dim_list, gatt_list, var_list), fixed-size variables,
-//              then interleaved records.
+//   Moorings : model/gridoutput.cpp:805-1035 (CF-1.6 schema).  The reference writes it through netcdf-cxx4 as NetCDF-4; no
+//              NetCDF library exists in this image, so the file is written here as NetCDF-4 through the HDF5 C library
+//              (dlopen'ed: nxs_io_nc4.inl) or, where that is absent or on request, as NetCDF-3 classic (CDF-1) by hand:
+//              big-endian header (dim_list, gatt_list, var_list), fixed-size variables, then interleaved records.
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
@@ -354,20 +354,25 @@ bool parse_header(const std::vector<unsigned char> &f, Parsed &out) {
 
 }  // namespace
 
-extern "C" {
+namespace {
 
-int nxs_moorings_create(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat, int32_t nvars,
-                        const nxs_mooring_var *vars, float miss_val, double averaging_period, const nxs_mooring_proj *proj) {
-    if (!path || !lon || !lat || ncols < 1 || nrows < 1 || nvars < 0 || (nvars > 0 && !vars)) return fail(NXS_ERR_INVALID, "bad moorings arguments");
-    // dimensions in the reference's creation order: time (unlimited), nv, x, y   (gridoutput.cpp:862-884)
-    const std::vector<std::pair<std::string, uint32_t>> dims = {{"time", 0}, {"nv", 2}, {"x", (uint32_t)ncols}, {"y", (uint32_t)nrows}};
-    enum { D_TIME = 0, D_NV = 1, D_X = 2, D_Y = 3 };
+// The Moorings schema of initNetCDF (gridoutput.cpp:805-940), shared by the two container formats
+struct Schema {
+    std::vector<std::pair<std::string, uint32_t>> dims;  // time (0 = unlimited), nv, x, y: the reference's creation order
+    std::vector<Var> V;
+    std::vector<Att> gatts;
+};
+enum { D_TIME = 0, D_NV = 1, D_X = 2, D_Y = 3 };
+
+int build_schema(Schema &S, int32_t ncols, int32_t nrows, int32_t nvars, const nxs_mooring_var *vars, float miss_val,
+                 double averaging_period, const nxs_mooring_proj *proj) {
+    S.dims = {{"time", 0}, {"nv", 2}, {"x", (uint32_t)ncols}, {"y", (uint32_t)nrows}};
+    std::vector<Var> &V = S.V;
     std::string cm_time = "time: point ";
     if (averaging_period > 0) {  // gridoutput.cpp:887-894 (boost::format %1% of a double)
         char b[64]; snprintf(b, sizeof b, "%g", 24 * averaging_period);
         cm_time = std::string("time: mean (interval: ") + b + " hours) ";
     }
-    std::vector<Var> V;
     if (proj) {  // gridoutput.cpp:943-980
         Var v; v.name = "Polar_Stereographic_Grid"; v.type = NC_INT;
         char p4[256];
@@ -404,8 +409,21 @@ int nxs_moorings_create(const char *path, int32_t ncols, int32_t nrows, const fl
                   att_text("cell_methods", cm_time + s(vars[i].cell_methods)), att_float("_FillValue", miss_val)};
         V.push_back(d);
     }
-    const std::vector<Att> gatts = {att_text("Conventions", "CF-1.6"), att_text("institution", "NERSC, Jahnebakken 3, N-5007 Bergen, Norway"),
+    S.gatts = {att_text("Conventions", "CF-1.6"), att_text("institution", "NERSC, Jahnebakken 3, N-5007 Bergen, Norway"),
                                     att_text("source", "neXtSIM model fields")};
+    return NXS_OK;
+}
+
+}  // namespace
+
+#include "nxs_io_nc4.inl"
+
+extern "C" {
+
+static int create_classic(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat, Schema &S) {
+    const auto &dims = S.dims;
+    std::vector<Var> &V = S.V;
+    const std::vector<Att> &gatts = S.gatts;
     // sizes
     for (Var &v : V) {
         uint64_t n = 1;
@@ -445,8 +463,7 @@ int nxs_moorings_create(const char *path, int32_t ncols, int32_t nrows, const fl
     return NXS_OK;
 }
 
-int nxs_moorings_append(const char *path, double timestamp, double averaging_period, int32_t nvars, const float *const *data) {
-    if (!path || nvars < 0 || (nvars > 0 && !data)) return fail(NXS_ERR_INVALID, "bad moorings arguments");
+static int append_classic(const char *path, double timestamp, double averaging_period, int32_t nvars, const float *const *data) {
     FILE *f = fopen(path, "rb+");
     if (!f) return fail(NXS_ERR_INVALID, "cannot open %s", path);
     std::vector<unsigned char> head(1 << 16);
@@ -474,6 +491,43 @@ int nxs_moorings_append(const char *path, double timestamp, double averaging_per
     fwrite(n.b.data(), 1, 4, f);
     fclose(f);
     return NXS_OK;
+}
+
+
+int nxs_moorings_file_format(const char *path) {
+    if (!path) return fail(NXS_ERR_INVALID, "NULL path");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(NXS_ERR_INVALID, "cannot open %s", path);
+    unsigned char m[8] = {0};
+    const size_t got = fread(m, 1, 8, f);
+    fclose(f);
+    if (got >= 4 && !memcmp(m, "CDF\x01", 4)) return NXS_NC_CLASSIC;
+    if (got >= 8 && !memcmp(m, "\x89HDF\r\n\x1a\n", 8)) return NXS_NC_NETCDF4;
+    return fail(NXS_ERR_INVALID, "%s is neither a NetCDF classic nor a NetCDF-4 (HDF5) file", path);
+}
+
+int nxs_moorings_create_format(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat, int32_t nvars,
+                               const nxs_mooring_var *vars, float miss_val, double averaging_period, const nxs_mooring_proj *proj,
+                               int32_t format) {
+    if (!path || !lon || !lat || ncols < 1 || nrows < 1 || nvars < 0 || (nvars > 0 && !vars)) return fail(NXS_ERR_INVALID, "bad moorings arguments");
+    if (format != NXS_NC_AUTO && format != NXS_NC_CLASSIC && format != NXS_NC_NETCDF4) return fail(NXS_ERR_INVALID, "unknown format %d", format);
+    Schema S;
+    if (int rc = build_schema(S, ncols, nrows, nvars, vars, miss_val, averaging_period, proj)) return rc;
+    if (format == NXS_NC_AUTO) format = nc4::available() ? NXS_NC_NETCDF4 : NXS_NC_CLASSIC;
+    if (format == NXS_NC_NETCDF4) return nc4::create(path, ncols, nrows, lon, lat, S, miss_val);
+    return create_classic(path, ncols, nrows, lon, lat, S);
+}
+
+int nxs_moorings_create(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat, int32_t nvars,
+                        const nxs_mooring_var *vars, float miss_val, double averaging_period, const nxs_mooring_proj *proj) {
+    return nxs_moorings_create_format(path, ncols, nrows, lon, lat, nvars, vars, miss_val, averaging_period, proj, NXS_NC_AUTO);
+}
+
+int nxs_moorings_append(const char *path, double timestamp, double averaging_period, int32_t nvars, const float *const *data) {
+    if (!path || nvars < 0 || (nvars > 0 && !data)) return fail(NXS_ERR_INVALID, "bad moorings arguments");
+    const int fmt = nxs_moorings_file_format(path);
+    if (fmt < 0) return fmt;
+    return fmt == NXS_NC_NETCDF4 ? nc4::append(path, timestamp, averaging_period, nvars, data) : append_classic(path, timestamp, averaging_period, nvars, data);
 }
 
 }  // extern "C"

@@ -23,7 +23,9 @@ class MooringProj(C.Structure):
 IO_EXPORTS = ("nxs_exporter_open", "nxs_exporter_write_mesh", "nxs_exporter_write_field", "nxs_exporter_write_field_int",
               "nxs_exporter_close", "nxs_exporter_load", "nxs_exporter_file_num_records", "nxs_exporter_file_record",
               "nxs_exporter_file_get_double", "nxs_exporter_file_get_int", "nxs_exporter_file_close", "nxs_restart_write",
-              "nxs_restart_read", "nxs_moorings_create", "nxs_moorings_append", "nxs_io_last_error")
+              "nxs_restart_read", "nxs_moorings_create", "nxs_moorings_create_format", "nxs_moorings_file_format", "nxs_moorings_append",
+              "nxs_io_last_error")
+NC_AUTO, NC_CLASSIC, NC_NETCDF4 = 0, 3, 4
 _decl = False
 
 
@@ -39,6 +41,9 @@ def _lib():
         L.nxs_exporter_close.argtypes = [C.c_void_p]
         L.nxs_moorings_create.argtypes = [C.c_char_p, C.c_int32, C.c_int32, P(C.c_float), P(C.c_float), C.c_int32, P(MooringVar), C.c_float,
                                           C.c_double, P(MooringProj)]
+        L.nxs_moorings_create_format.argtypes = [C.c_char_p, C.c_int32, C.c_int32, P(C.c_float), P(C.c_float), C.c_int32, P(MooringVar), C.c_float,
+                                                 C.c_double, P(MooringProj), C.c_int32]
+        L.nxs_moorings_file_format.argtypes = [C.c_char_p]
         L.nxs_moorings_append.argtypes = [C.c_char_p, C.c_double, C.c_double, C.c_int32, P(P(C.c_float))]
         L.nxs_io_last_error.restype = C.c_char_p
         V = C.c_void_p
@@ -163,8 +168,18 @@ def read_restart(directory, name_str):
         L.nxs_exporter_file_close(mh); L.nxs_exporter_file_close(fh)
 
 
-def moorings_create(path, lon, lat, variables, miss_val=-1e14, averaging_period=0.0, proj=None):
-    """variables: list of dicts with name, standard_name, long_name, units, cell_methods."""
+def moorings_file_format(path) -> int:
+    """NC_CLASSIC or NC_NETCDF4, from the magic bytes."""
+    L = _lib()
+    r = L.nxs_moorings_file_format(str(path).encode())
+    if r < 0:
+        _chk(L, r)
+    return r
+
+
+def moorings_create(path, lon, lat, variables, miss_val=-1e14, averaging_period=0.0, proj=None, format=NC_AUTO):
+    """variables: list of dicts with name, standard_name, long_name, units, cell_methods.  format: NC_AUTO (NetCDF-4 as the
+    reference writes it when the HDF5 library can be loaded, else NetCDF-3 classic), NC_CLASSIC, NC_NETCDF4."""
     L = _lib()
     lon = np.ascontiguousarray(lon, np.float32); lat = np.ascontiguousarray(lat, np.float32)
     nrows, ncols = lon.shape
@@ -175,8 +190,9 @@ def moorings_create(path, lon, lat, variables, miss_val=-1e14, averaging_period=
     pj = None
     if proj is not None:
         pj = MooringProj(**proj)
-    _chk(L, L.nxs_moorings_create(path.encode(), ncols, nrows, lon.ctypes.data_as(C.POINTER(C.c_float)), lat.ctypes.data_as(C.POINTER(C.c_float)),
-                                  len(variables), arr, float(miss_val), float(averaging_period), C.byref(pj) if pj is not None else None))
+    _chk(L, L.nxs_moorings_create_format(path.encode(), ncols, nrows, lon.ctypes.data_as(C.POINTER(C.c_float)), lat.ctypes.data_as(C.POINTER(C.c_float)),
+                                         len(variables), arr, float(miss_val), float(averaging_period), C.byref(pj) if pj is not None else None,
+                                         int(format)))
 
 
 def moorings_append(path, timestamp, fields, averaging_period=0.0):

@@ -3,6 +3,8 @@ Boost, gridoutput.cpp needs netcdf-cxx4), so the writers are checked against the
 the Exporter's record layout (core/src/exporter.cpp:30-61, 130-189) by reading the bytes back, the Moorings
 file with an independent NetCDF reader (scipy.io.netcdf_file) against the schema of
 model/gridoutput.cpp:805-940."""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,7 +54,8 @@ def test_moorings_netcdf_schema_and_records(tmp_path):
                  dict(name="sit", standard_name="sea_ice_thickness", long_name="Sea Ice Thickness", units="m", cell_methods="area: mean")]
     proj = dict(semi_major_axis=6378273.0, semi_minor_axis=6356889.449, lat0=90.0, lat_ts=60.0, rotation=-45.0, false_easting=0)
     path = str(tmp_path / "Moorings.nc")
-    nio.moorings_create(path, lon, lat, variables, miss_val=-1e14, averaging_period=0.125, proj=proj)
+    nio.moorings_create(path, lon, lat, variables, miss_val=-1e14, averaging_period=0.125, proj=proj, format=nio.NC_CLASSIC)
+    assert nio.moorings_file_format(path) == nio.NC_CLASSIC
     rng = np.random.default_rng(1)
     recs = []
     for k in range(3):
@@ -82,7 +85,7 @@ def test_moorings_netcdf_schema_and_records(tmp_path):
     nc.close()
     # snapshots: "time: point " and no projection variable
     path2 = str(tmp_path / "snap.nc")
-    nio.moorings_create(path2, lon, lat, variables[:1])
+    nio.moorings_create(path2, lon, lat, variables[:1], format=nio.NC_CLASSIC)
     nio.moorings_append(path2, 1.0, [recs[0][0]])
     nc = netcdf_file(path2, "r", mmap=False)
     assert nc.variables["sic"].cell_methods == b"time: point area: mean" and "Polar_Stereographic_Grid" not in nc.variables
@@ -90,6 +93,90 @@ def test_moorings_netcdf_schema_and_records(tmp_path):
     nc.close()
     with pytest.raises(Exception):
         nio.moorings_append(path2, 2.0, [recs[0][0], recs[0][1]])   # wrong number of fields
+
+
+def _h5dump():
+    import shutil
+    for cand in (shutil.which("h5dump"), "/opt/conda/bin/h5dump"):
+        if cand and os.path.exists(cand):
+            return cand
+    return None
+
+
+@pytest.mark.skipif(_h5dump() is None, reason="no h5dump (HDF5 tools) on this box: no independent reader for NetCDF-4")
+def test_moorings_netcdf4_as_the_reference_writes_it(tmp_path):
+    """The default container is NetCDF-4 (gridoutput.cpp:857: netCDF::NcFile(..., replace)), written through the HDF5 C library
+    following the netCDF-4 conventions.  Read back with h5dump -- HDF5's own tool, independent of the writer: dimensions as
+    dimension scales with _Netcdf4Dimid and netCDF's naming, the scales attached to every variable, the unlimited time
+    dimension, the attributes of the reference's schema, and the data, record by record."""
+    import re, subprocess
+    nrows, ncols = 5, 9
+    lon = np.linspace(-180, 180, nrows * ncols, dtype=np.float32).reshape(nrows, ncols)
+    lat = np.linspace(60, 90, nrows * ncols, dtype=np.float32).reshape(nrows, ncols)
+    variables = [dict(name="sic", standard_name="sea_ice_area_fraction", long_name="Sea Ice Concentration", units="1", cell_methods="area: mean"),
+                 dict(name="sit", standard_name="sea_ice_thickness", long_name="Sea Ice Thickness", units="m", cell_methods="area: mean")]
+    proj = dict(semi_major_axis=6378273.0, semi_minor_axis=6356889.449, lat0=90.0, lat_ts=60.0, rotation=-45.0, false_easting=0)
+    path = str(tmp_path / "Moorings.nc")
+    nio.moorings_create(path, lon, lat, variables, miss_val=-1e14, averaging_period=0.125, proj=proj)     # NC_AUTO
+    assert nio.moorings_file_format(path) == nio.NC_NETCDF4
+    rng = np.random.default_rng(1)
+    recs = []
+    for k in range(3):
+        f = [rng.random((nrows, ncols)).astype(np.float32), rng.random((nrows, ncols)).astype(np.float32)]
+        nio.moorings_append(path, 42000.0 + 0.125 * k, f, averaging_period=0.125)
+        recs.append(f)
+    h5 = _h5dump()
+    head = subprocess.check_output([h5, "-H", "-A", path], text=True)
+
+    def block(name):        # the text of DATASET "name" { ... } (brace matching)
+        i = head.index(f'DATASET "{name}"')
+        depth, j = 0, head.index("{", i)
+        for j in range(j, len(head)):
+            depth += head[j] == "{"; depth -= head[j] == "}"
+            if depth == 0:
+                break
+        return head[i:j + 1]
+
+    order = re.findall(r'^   DATASET "([^"]+)"', head, re.M)
+    # (h5dump lists by name; the creation order the netCDF library uses for ids is checked through _Netcdf4Dimid below)
+    assert set(order) == {"Polar_Stereographic_Grid", "time", "nv", "time_bnds", "x", "y", "longitude", "latitude", "sic", "sit"}
+    t = block("time")
+    assert "H5S_UNLIMITED" in t and "H5T_IEEE_F64LE" in t and '"DIMENSION_SCALE"' in t and re.search(r'ATTRIBUTE "NAME".*?"time"', t, re.S)
+    assert re.search(r'ATTRIBUTE "_Netcdf4Dimid".*?\(0\): 0', t, re.S) and "REFERENCE_LIST" in t
+    for name, dimid, n in (("nv", 1, 2), ("x", 2, ncols), ("y", 3, nrows)):
+        b = block(name)
+        assert '"DIMENSION_SCALE"' in b and "H5T_IEEE_F32BE" in b
+        assert f"This is a netCDF dimension but not a netCDF variable.{n:10d}" in b
+        assert re.search(r'ATTRIBUTE "_Netcdf4Dimid".*?\(0\): %d' % dimid, b, re.S)
+        assert f"( {n} ) / ( {n} )" in b
+    sic = block("sic")
+    assert f"( 3, {nrows}, {ncols} ) / ( H5S_UNLIMITED, {nrows}, {ncols} )" in sic and "H5T_IEEE_F32LE" in sic
+    assert "DIMENSION_LIST" in sic and '"sea_ice_area_fraction"' in sic and '"latitude longitude"' in sic
+    assert '"time: mean (interval: 3 hours) area: mean"' in sic and re.search(r'ATTRIBUTE "_FillValue".*?-1e\+14', sic, re.S)
+    assert f"( 3, 2 ) / ( H5S_UNLIMITED, 2 )" in block("time_bnds")
+    assert f"( {nrows}, {ncols} ) / ( {nrows}, {ncols} )" in block("longitude") and '"degrees_east"' in block("longitude")
+    pv = block("Polar_Stereographic_Grid")
+    assert '"polar_stereographic"' in pv and "+proj=stere +a=6.37827e+06" in pv and "H5T_STD_I32LE" in pv
+    assert re.search(r'ATTRIBUTE "Conventions".*?"CF-1.6"', head, re.S) and '"neXtSIM model fields"' in head and "_NCProperties" in head
+
+    def data(name, dtype, count):
+        raw = subprocess.check_output([h5, "-d", "/" + name, "-b", "LE", "-o", str(tmp_path / "raw.bin"), path], text=True)
+        return np.fromfile(tmp_path / "raw.bin", dtype)[:count]
+    assert np.array_equal(data("time", "<f8", 3), 42000.0 + 0.125 * np.arange(3))
+    assert np.array_equal(data("time_bnds", "<f8", 6).reshape(3, 2), np.stack([42000.0 + 0.125 * np.arange(3) - 0.0625, 42000.0 + 0.125 * np.arange(3) + 0.0625], 1))
+    assert np.array_equal(data("longitude", "<f4", nrows * ncols).reshape(nrows, ncols), lon)
+    assert np.array_equal(data("latitude", "<f4", nrows * ncols).reshape(nrows, ncols), lat)
+    got = data("sic", "<f4", 3 * nrows * ncols).reshape(3, nrows, ncols)
+    got2 = data("sit", "<f4", 3 * nrows * ncols).reshape(3, nrows, ncols)
+    for k in range(3):
+        assert np.array_equal(got[k], recs[k][0]) and np.array_equal(got2[k], recs[k][1])
+    with pytest.raises(Exception):
+        nio.moorings_append(path, 43000.0, [recs[0][0]])          # wrong number of fields
+    # the same calls give the classic container on request, and append tells the two apart by itself
+    p3 = str(tmp_path / "classic.nc")
+    nio.moorings_create(p3, lon, lat, variables, format=nio.NC_CLASSIC)
+    nio.moorings_append(p3, 1.0, recs[0])
+    assert nio.moorings_file_format(p3) == nio.NC_CLASSIC and open(p3, "rb").read(4) == b"CDF\x01" and open(path, "rb").read(4) == b"\x89HDF"
 
 
 def test_library_loader_equals_the_independent_reader(tmp_path):
