@@ -64,6 +64,7 @@ def pmc_traffic(mesh, launches_per_substep, world):
 
 
 _MESHES = {}
+_COVER = {}
 
 
 def build_case(kind, nparts, rank, state="arctic"):
@@ -75,14 +76,14 @@ def build_case(kind, nparts, rank, state="arctic"):
     g = F.global_fields(gm, p, state, C_fix, C_alea)
     lm = M.localize(gm, nparts)[rank]
     f = F.localize_fields(g, lm, gm.num_nodes)
-    f["_cover"] = ice_cover(g)      # of the whole mesh, not of this rank's partition
+    _COVER[id(f)] = ice_cover(g)    # of the whole mesh, not of this rank's partition
     return gm, p, lm, f
 
 
 def ice_cover(f):
     """Fractions of the triangles that are ice free / in the 0 < A <= 0.1 band updateSigmaDamage skips (FE.cpp:4146)."""
-    if "_cover" in f:
-        return f["_cover"]
+    if id(f) in _COVER:
+        return _COVER[id(f)]
     c = f["conc"]
     return {"ice_free_fraction": float((c == 0).mean()), "low_concentration_fraction": float(((c > 0) & (c <= 0.1)).mean())}
 

@@ -53,61 +53,100 @@ struct Pts {
     }
 };
 
-// ear clipping of a simple counter-clockwise polygon; only reflex vertices can lie inside a candidate ear
-inline bool ear_clip(const Pts &P, std::vector<int> poly, std::vector<int> &tris) {
-    while (poly.size() > 3) {
-        const int n = (int)poly.size();
-        std::vector<char> reflex(n);
-        for (int i = 0; i < n; ++i) reflex[i] = P.orient(poly[(i + n - 1) % n], poly[i], poly[(i + 1) % n]) <= 0;
-        int ear = -1;
-        for (int i = 0; i < n && ear < 0; ++i) {
-            if (reflex[i]) continue;
-            const int a = poly[(i + n - 1) % n], b = poly[i], c = poly[(i + 1) % n];
-            bool empty = true;
-            for (int j = 0; j < n && empty; ++j) {
+// Ear clipping of a simple counter-clockwise polygon on a doubly linked list: after an ear is cut only its two neighbours
+// change (their reflex flags are redone), the search goes on from there, and only reflex vertices can lie inside a candidate
+// ear -- O(n r) for the coast pockets met here instead of O(n^2 r).
+inline bool ear_clip(const Pts &P, const std::vector<int> &poly, std::vector<int> &tris) {
+    const int n = (int)poly.size();
+    if (n < 3) return false;
+    std::vector<int> prv(n), nxt(n);
+    std::vector<char> reflex(n), alive(n, 1);
+    for (int i = 0; i < n; ++i) { prv[i] = (i + n - 1) % n; nxt[i] = (i + 1) % n; }
+    for (int i = 0; i < n; ++i) reflex[i] = P.orient(poly[prv[i]], poly[i], poly[nxt[i]]) <= 0;
+    int left = n, i = 0, since = 0;
+    while (left > 3) {
+        if (since > left) return false;  // a full round without an ear: not a simple polygon (or fully degenerate)
+        const int a = poly[prv[i]], b = poly[i], c = poly[nxt[i]];
+        bool ear = !reflex[i];
+        if (ear)
+            for (int j = nxt[nxt[i]]; j != prv[i] && ear; j = nxt[j]) {
                 if (!reflex[j]) continue;
                 const int q = poly[j];
                 if (q == a || q == b || q == c) continue;
-                if (P.orient(a, b, q) >= 0 && P.orient(b, c, q) >= 0 && P.orient(c, a, q) >= 0) empty = false;
+                if (P.orient(a, b, q) >= 0 && P.orient(b, c, q) >= 0 && P.orient(c, a, q) >= 0) ear = false;
             }
-            if (empty) ear = i;
-        }
-        if (ear < 0) return false;  // not a simple polygon (or fully degenerate)
-        const int n0 = (int)poly.size();
-        tris.push_back(poly[(ear + n0 - 1) % n0]); tris.push_back(poly[ear]); tris.push_back(poly[(ear + 1) % n0]);
-        poly.erase(poly.begin() + ear);
+        if (!ear) { i = nxt[i]; ++since; continue; }
+        tris.push_back(a); tris.push_back(b); tris.push_back(c);
+        const int p = prv[i], q = nxt[i];
+        alive[i] = 0; nxt[p] = q; prv[q] = p; --left; since = 0;
+        reflex[p] = P.orient(poly[prv[p]], poly[p], poly[nxt[p]]) <= 0;
+        reflex[q] = P.orient(poly[prv[q]], poly[q], poly[nxt[q]]) <= 0;
+        i = p;
     }
-    if (poly.size() == 3) {
-        if (P.orient(poly[0], poly[1], poly[2]) <= 0) return false;
-        tris.insert(tris.end(), poly.begin(), poly.end());
-    }
+    const int a = poly[prv[i]], b = poly[i], c = poly[nxt[i]];
+    if (P.orient(a, b, c) <= 0) return false;
+    tris.push_back(a); tris.push_back(b); tris.push_back(c);
     return true;
 }
 
-// Lawson flips of the interior diagonals of one polygon's triangulation until every one is locally Delaunay
+// Lawson flips of the interior diagonals of one polygon's triangulation until every one is locally Delaunay (a work list of
+// edges; a flip puts the four edges around it back on the list)
 inline void make_delaunay(const Pts &P, std::vector<int> &t /* 3 per triangle */) {
     const int nt = (int)t.size() / 3;
     if (nt < 2) return;
-    for (int guard = 0; guard < 64 * nt + 64; ++guard) {
-        std::map<std::pair<int, int>, int> half;  // directed edge -> 3*triangle + position of its first vertex
-        for (int i = 0; i < nt; ++i)
-            for (int k = 0; k < 3; ++k) half[{t[3 * i + k], t[3 * i + (k + 1) % 3]}] = 3 * i + k;
-        bool flipped = false;
-        for (const auto &h : half) {
-            const int a = h.first.first, b = h.first.second;
-            const auto o = half.find({b, a});
-            if (o == half.end() || a > b) continue;  // a polygon edge (no twin), or the twin's turn
-            const int i = h.second / 3, ki = h.second % 3, j = o->second / 3, kj = o->second % 3;
-            const int c = t[3 * i + (ki + 2) % 3], d = t[3 * j + (kj + 2) % 3];  // a, b, c and b, a, d are the two triangles
-            if (!P.in_circle(a, b, c, d)) continue;
-            if (P.orient(c, a, d) <= 0 || P.orient(d, b, c) <= 0) continue;  // the quadrilateral is not strictly convex
-            t[3 * i] = c; t[3 * i + 1] = a; t[3 * i + 2] = d;
-            t[3 * j] = d; t[3 * j + 1] = b; t[3 * j + 2] = c;
-            flipped = true;
-            break;
-        }
-        if (!flipped) return;
+    std::map<std::pair<int, int>, int> half;  // directed edge -> 3*triangle + position of its first vertex
+    for (int i = 0; i < nt; ++i)
+        for (int k = 0; k < 3; ++k) half[{t[3 * i + k], t[3 * i + (k + 1) % 3]}] = 3 * i + k;
+    std::vector<std::pair<int, int>> work;
+    for (const auto &h : half) if (h.first.first < h.first.second && half.count({h.first.second, h.first.first})) work.push_back(h.first);
+    long long guard = 64ll * nt * nt + 1024;
+    while (!work.empty() && guard-- > 0) {
+        const std::pair<int, int> e = work.back();
+        work.pop_back();
+        const auto h = half.find(e), o = half.find({e.second, e.first});
+        if (h == half.end() || o == half.end()) continue;  // flipped away meanwhile, or a polygon edge
+        const int a = e.first, b = e.second;
+        const int i = h->second / 3, ki = h->second % 3, j = o->second / 3, kj = o->second % 3;
+        const int c = t[3 * i + (ki + 2) % 3], d = t[3 * j + (kj + 2) % 3];  // a, b, c and b, a, d are the two triangles
+        if (!P.in_circle(a, b, c, d)) continue;
+        if (P.orient(c, a, d) <= 0 || P.orient(d, b, c) <= 0) continue;  // the quadrilateral is not strictly convex
+        half.erase({a, b}); half.erase({b, a});
+        t[3 * i] = c; t[3 * i + 1] = a; t[3 * i + 2] = d;
+        t[3 * j] = d; t[3 * j + 1] = b; t[3 * j + 2] = c;
+        half[{c, a}] = 3 * i; half[{a, d}] = 3 * i + 1; half[{d, c}] = 3 * i + 2;
+        half[{d, b}] = 3 * j; half[{b, c}] = 3 * j + 1; half[{c, d}] = 3 * j + 2;
+        for (const std::pair<int, int> &q : {std::pair<int, int>{c, a}, {a, d}, {d, b}, {b, c}}) work.push_back(q.first < q.second ? q : std::pair<int, int>{q.second, q.first});
     }
+}
+
+// Boundary edges of a triangle mesh (index 1-based): 3*e + k for every local edge k of triangle e (vertices VOTE[k][0] ->
+// VOTE[k][1]) whose reverse belongs to no triangle, in ascending order.  Directed edges are bucketed by their tail (counting
+// sort), then every edge looks for its reverse among the few edges leaving its head: linear time, no comparison sort.
+// Returns false when a directed edge occurs twice (an edge shared by more than two triangles / inconsistent orientation).
+inline bool find_boundary_edges(const int32_t *index, int nods, int nels, std::vector<int> &out) {
+    static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+    std::vector<int> start((size_t)nods + 1, 0);
+    for (int e = 0; e < nels; ++e) for (int k = 0; k < 3; ++k) start[(size_t)index[3 * e + k]]++;  // each vertex is the tail of one edge per triangle it is in
+    for (int v = 0; v < nods; ++v) start[(size_t)v + 1] += start[v];
+    std::vector<int> head((size_t)3 * nels), fill(start.begin(), start.end() - 1);
+    for (int e = 0; e < nels; ++e)
+        for (int k = 0; k < 3; ++k) {
+            const int p = index[3 * e + VOTE[k][0]] - 1, q = index[3 * e + VOTE[k][1]] - 1;
+            head[(size_t)fill[p]++] = q;
+        }
+    out.clear();
+    bool ok = true;
+    for (int e = 0; e < nels; ++e)
+        for (int k = 0; k < 3; ++k) {
+            const int p = index[3 * e + VOTE[k][0]] - 1, q = index[3 * e + VOTE[k][1]] - 1;
+            bool twin = false;
+            for (int i = start[q]; i < start[(size_t)q + 1] && !twin; ++i) twin = head[i] == p;
+            int same = 0;
+            for (int i = start[p]; i < start[(size_t)p + 1]; ++i) same += head[i] == q;
+            if (same > 1) ok = false;
+            if (!twin) out.push_back(3 * e + k);
+        }
+    return ok;
 }
 
 // index: 1-based triangles; ix, iy: bamg's integer coordinates of the vertices (SetIntCoor)
@@ -116,29 +155,16 @@ inline Completion complete(const int32_t *index, const int *ix, const int *iy, i
     const Pts P{ix, iy};
     static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
     // boundary edges, oriented as in their triangle (the domain on the left)
-    std::vector<std::pair<i64, int>> keys;
-    keys.reserve(3 * (size_t)nels);
-    for (int e = 0; e < nels; ++e)
-        for (int k = 0; k < 3; ++k) {
-            const int p = index[3 * e + VOTE[k][0]] - 1, q = index[3 * e + VOTE[k][1]] - 1;
-            keys.emplace_back((i64)std::min(p, q) * nods + std::max(p, q), 3 * e + k);
-        }
-    std::sort(keys.begin(), keys.end());
+    std::vector<int> bnd;
+    if (!find_boundary_edges(index, nods, nels, bnd)) { out.why = "an edge belongs to more than two triangles"; return out; }
     std::vector<int> nxt(nods, -1), etri(nods, -1);  // boundary edge leaving each vertex: its head, and 3*triangle + k
-    int nbe = 0;
-    for (size_t i = 0; i < keys.size();) {
-        size_t j = i + 1;
-        while (j < keys.size() && keys[j].first == keys[i].first) ++j;
-        if (j - i == 1) {
-            const int e = keys[i].second / 3, k = keys[i].second % 3;
-            const int p = index[3 * e + VOTE[k][0]] - 1, q = index[3 * e + VOTE[k][1]] - 1;
-            if (nxt[p] >= 0) { out.why = "a boundary vertex has two outgoing boundary edges (the domain pinches there)"; return out; }
-            nxt[p] = q; etri[p] = keys[i].second;
-            ++nbe;
-        } else if (j - i > 2) { out.why = "an edge belongs to more than two triangles"; return out; }
-        i = j;
+    for (int be : bnd) {
+        const int e = be / 3, k = be % 3;
+        const int p = index[3 * e + VOTE[k][0]] - 1, q = index[3 * e + VOTE[k][1]] - 1;
+        if (nxt[p] >= 0) { out.why = "a boundary vertex has two outgoing boundary edges (the domain pinches there)"; return out; }
+        nxt[p] = q; etri[p] = be;
     }
-    if (nbe < 3) { out.why = "no boundary"; return out; }
+    if (bnd.size() < 3) { out.why = "no boundary"; return out; }
     // loops; the outer one has positive area
     std::vector<std::vector<int>> loops;
     std::vector<char> seen(nods, 0);
@@ -211,6 +237,7 @@ inline Completion complete(const int32_t *index, const int *ix, const int *iy, i
     std::map<std::pair<int, int>, int> closing;  // hull edge a -> b that closes a pocket -> index of the fill triangle holding it
     auto add_polygon = [&](const std::vector<int> &poly) -> bool {
         std::vector<int> t;
+        if (getenv("NXS_DEBUG_HULL")) fprintf(stderr, "[hull] polygon of %zu vertices\n", poly.size());
         if (!ear_clip(P, poly, t)) return false;
         make_delaunay(P, t);
         out.fill.insert(out.fill.end(), t.begin(), t.end());

@@ -362,26 +362,11 @@ struct Locator {
         }
 
         // ---- boundary edges (edges held by exactly one triangle)
-        std::vector<BEdge> bedges;
-        if (need_boundary_edges) {
-            static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
-            std::vector<std::pair<long long, int>> keys;  // (sorted vertex pair, 3*tri + k)
-            keys.reserve(3 * (size_t)nels_mesh);
-            for (int e = 0; e < nels_mesh; ++e) {
-                const int tv[3] = {t0[e], t1[e], t2[e]};
-                for (int k = 0; k < 3; ++k) {
-                    const int p = tv[VOTE[k][0]], q = tv[VOTE[k][1]];
-                    keys.emplace_back((long long)std::min(p, q) * nods + std::max(p, q), 3 * e + k);
-                }
-            }
-            std::sort(keys.begin(), keys.end());
-            for (size_t i = 0; i < keys.size();) {
-                size_t j = i + 1;
-                while (j < keys.size() && keys[j].first == keys[i].first) ++j;
-                if (j - i == 1) bedges.push_back(BEdge{keys[i].second / 3, keys[i].second % 3});
-                i = j;
-            }
-            std::sort(bedges.begin(), bedges.end(), [](const BEdge &a, const BEdge &b) { return a.tri != b.tri ? a.tri < b.tri : a.k < b.k; });
+        std::vector<BEdge> bedges;  // (the stand-in for exterior points when no completion exists)
+        if (need_boundary_edges && !comp.ok) {
+            std::vector<int> bnd;
+            (void)nxs_hull::find_boundary_edges(index_data, nods, nels_mesh, bnd);
+            for (int be : bnd) bedges.push_back(BEdge{be / 3, be % 3});
         }
         if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || dix.upload(ix.data(), nods) ||
             diy.upload(iy.data(), nods) || doff.upload(cnt.data(), cnt.size()) || dtri.upload(cell_tri.data(), cell_tri.size()) ||

@@ -1,2 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_interp.py tests/test_remap.py tests/test_regrid_cycle.py -m gpu -x -q -s > gpurun_out/r2_interp1.log 2>&1; echo "rc=$?" ; tail -25 gpurun_out/r2_interp1.log
+python -m pytest tests -m gpu -x -q > gpurun_out/r2_suite3.log 2>&1; echo "suite rc=$?" ; tail -5 gpurun_out/r2_suite3.log
+python bench.py --steps 20 --warmup 5 > gpurun_out/r2_bench3.json 2> gpurun_out/r2_bench3.err; echo "bench rc=$?"; tail -c 600 gpurun_out/r2_bench3.err

@@ -187,3 +187,48 @@ def test_partitioned_gpu_run_matches_multirank_oracle(world, tmp_path):
         assert r["crash"] == 0
         for k, e in r["errs"].items():
             assert e <= 1e-10, (r["rank"], k, e)
+
+
+def test_ipc_connect_checks_its_tables_against_what_the_neighbour_published():
+    """Two ranks of a partition as two handles of THIS process (a host driving several GPUs from one process): the mailboxes
+    connect through plain pointers, and nxs_dyn_ipc_connect refuses tables that do not match the blob the neighbour exported
+    -- a wrong offset would make the kernels store outside the neighbour's mailbox -- and blobs it did not make."""
+    import ctypes as C
+    import numpy as np
+    import cases
+    from nextsim_amd import _abi, dynamics
+    gm, p, g, lms, fields = cases.make_case("small", nparts=2)
+    fes = [dynamics.FiniteElementDynamics(p) for _ in range(2)]
+    blobs = []
+    for fe, lm in zip(fes, lms):
+        fe.set_mesh(lm)
+        b = C.create_string_buffer(dynamics.IPC_BLOB_BYTES)
+        fe._chk(fe.L.nxs_dyn_ipc_export(fe.h, b))
+        blobs.append(b.raw)
+
+    def connect(r, off=None, tot=None, slot=None, blob=None):
+        lm, other = lms[r], lms[1 - r]
+        k = other.recv_procs.tolist().index(r)
+        a = [np.asarray([v], np.int32) for v in (other.recv_offsets[k] if off is None else off,
+                                                  other.recv_offsets[-1] if tot is None else tot, k if slot is None else slot)]
+        buf = C.create_string_buffer(blobs[1 - r] if blob is None else blob, dynamics.IPC_BLOB_BYTES)
+        return fes[r].L.nxs_dyn_ipc_connect(fes[r].h, buf, _abi.iptr(a[0]), _abi.iptr(a[1]), _abi.iptr(a[2]))
+
+    err = lambda r: (fes[r].L.nxs_dyn_last_error(fes[r].h) or b"").decode()  # noqa: E731
+    assert connect(0, tot=int(lms[1].recv_offsets[-1]) + 1) != 0 and "receives" in err(0)
+    assert connect(0, off=int(lms[1].recv_offsets[-1])) != 0 and "does not fit" in err(0)
+    assert connect(0, slot=7) != 0 and "flag slot" in err(0)
+    assert connect(0, blob=bytes(dynamics.IPC_BLOB_BYTES)) != 0 and "not made by nxs_dyn_ipc_export" in err(0)
+    assert connect(0) == 0 and connect(1) == 0
+    assert connect(0) == 0                                   # a second connect replaces the first
+    # the connected pair works: the self-test pushes both publishing protocols through the (in-process) links
+    import threading
+    errs = [C.c_int32(-1), C.c_int32(-1)]
+    th = [threading.Thread(target=lambda r=r: fes[r]._chk(fes[r].L.nxs_dyn_ipc_selftest(fes[r].h, 16, C.byref(errs[r])))) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert errs[0].value == 0 and errs[1].value == 0
+    for fe in fes:
+        fe.close()
