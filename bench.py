@@ -344,7 +344,7 @@ def cpu_baseline(kind, nsteps=1):
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))  # a one-GPU box's CPU share
-    out = {"value": single, "cores": 1, "seconds": dt1, "single_core_value": single}
+    out = {"value": single, "cores": 1, "seconds": dt1, "single_core_value": single, "single_seconds": dt1}
     if cores > 1:
         p2, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
         g = F.global_fields(gm, p2, "arctic", C_fix, C_alea)
@@ -477,8 +477,8 @@ def main():
                 "value": cb["value"], "unit": "element-updates/s", "cores": cb["cores"], "kind": "port",
                 "single_core_value": cb["single_core_value"],
                 "sample": f"1 full dynamics step ({S} sub-steps) of the same '{args.mesh}' mesh and forcing, "
-                          f"oracle/dyn_ref.c -O3 -march=native, {cb['cores']} thread(s) = one mesh partition per core with "
-                          f"shared-memory halo exchange, {cb['seconds']:.1f} s",
+                          f"oracle/dyn_ref.c -O3 -march=native: once on 1 core ({cb['single_seconds']:.1f} s, single_core_value) and once on "
+                          f"{cb['cores']} thread(s) = one mesh partition per core with shared-memory halo exchange ({cb['seconds']:.1f} s, value)",
             }
         except Exception as e:  # noqa: BLE001 -- the GPU line must survive a host-side failure of the baseline leg
             out["cpu_baseline"] = {"value": None, "unit": "element-updates/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
