@@ -280,6 +280,8 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *   "pin_host"     1 = page-lock the caller's state / forcing vectors the first time they are seen (hipHostRegister), so the
  *                  per-step copies of a host that keeps its thermodynamics on the CPU run at PCIe speed; registrations are
  *                  dropped at set_mesh / destroy / pin_host 0.  Default 0: the library does not touch the caller's pages.
+ *   "shape_mem"    the several-sub-steps kernel reads M_shape_coeff from a per-step 48-byte record (1, and -1 = automatic, the default)
+ *                  or rebuilds it from the staged frozen coordinates every sub-step as the one-sub-step kernel always does (0)
  *   "trace_branches"  see nxs_dyn_get_branch_trace
  *   "work_arrays"  1 = the prep kernels also fill the one-array-per-quantity work vectors (M_shape_coeff, element mass, the per-step
  *                  element constants, rlmass, C_bu, grad_ssh, fcor) that only the fused = 0 kernels and nxs_dyn_debug_array read;

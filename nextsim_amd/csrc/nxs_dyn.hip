@@ -147,6 +147,9 @@ struct nxs_dyn_handle {
     int sig_loc = 0;                       // where M_sigma / M_damage are current: 0 = the state arrays, 1 = the records in S4a (left there by
                                            // the fused sub-step loop; k_update works on them, the arrays follow on demand: ensure_arrays)
     int trace_branches = 0;                // option "trace_branches": the per-loop kernels keep the branch trace of updateSigmaDamage (dw.trace)
+    int shape_mem = -1;                    // option "shape_mem": the several-sub-steps kernel reads M_shape_coeff from per-step records (1, and -1 = automatic)
+                                           // or rebuilds it from the staged coordinates like the one-sub-step kernel (0)
+    double *d_srec = nullptr;              // the records (allocated at set_mesh)
     int work_arrays = 0;                   // option "work_arrays": the prep kernels also fill the one-array-per-quantity work vectors
     int pin_host = 0;                      // option "pin_host": page-lock the caller's state / forcing vectors on first use
     std::map<const void *, size_t> pinned; // what this handle has registered with hipHostRegister
@@ -511,6 +514,11 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         h->pair_nodes = (int)value; h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "work_arrays")) { h->work_arrays = value != 0; return NXS_OK; }
+    if (!std::strcmp(key, "shape_mem")) {
+        if (value < -1 || value > 1) return fail(h, NXS_ERR_INVALID, "shape_mem must be -1 (auto), 0 or 1");
+        h->shape_mem = (int)value; release_graph(h);
+        return NXS_OK;
+    }
     if (!std::strcmp(key, "trace_branches")) {  // 1 = start (or restart) the trace: zeroed records; the step then runs the per-loop kernels
         if (value && !h->have_mesh) return fail(h, NXS_ERR_STATE, "trace_branches before set_mesh");
         h->trace_branches = value != 0;
@@ -697,6 +705,8 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 8 * ne); A(w.dragsurf, ne);
     A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn)); A(w.erec, 6 * ne); A(w.nrec, 10 * (size_t)Nn);
     A(w.force, 6 * ne);
+    A(h->d_srec, 6 * ne);
+    w.srec = nullptr;  // (set per step: only the several-sub-steps kernel reads the records)
     A(w.rlmass, (size_t)Nn); A(w.node_mass, (size_t)Nn); A(w.C_bu, (size_t)Nn); A(w.grad_ssh, n2);
     A(w.fcor, (size_t)Nn); A(w.VTM, n2); A(w.xy, n2); A(w.D_tau_a, n2); A(w.D_tau_w, n2); A(w.D_del, ne);
 #undef A
@@ -1591,7 +1601,10 @@ int explicit_solve(nxs_dyn_handle *h) {
     // FE.cpp:10182-10643
     const DevMesh &m = h->dm;
     if (timed) HIPCHK(h, hipEventRecord(h->cur[0], h->stream));
-    (void)choose_depth(h);
+    {
+        double *want = (choose_depth(h) >= 2 && h->shape_mem != 0) ? h->d_srec : nullptr;
+        if (want != h->dw.srec) { h->dw.srec = want; release_graph(h); }  // (kernel arguments are baked into the graphs)
+    }
     if (h->dp_dirty) {  // (outside any stream capture)
         if (!h->d_dp) HIPCHK(h, hipMalloc((void **)&h->d_dp, sizeof(DevParams)));
         HIPCHK(h, hipMemcpyAsync(h->d_dp, &h->dp, sizeof(DevParams), hipMemcpyHostToDevice, h->stream));

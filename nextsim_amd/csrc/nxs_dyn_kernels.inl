@@ -103,6 +103,8 @@ struct DevWork {
     unsigned char *open_blk;                     // [ceil(Nn/BLOCK)] != 0: the block of BLOCK nodes holds a node the open-water smoother changes (zeroed by k_prep_elements, set by k_prep_nodes)
     int *dxi;                                    // BBM, fused kernel: M_delta_x as the integer it is (Q1), ~M_delta_x when the element is skipped
     double *erec;                                // [Ne][6]: (expC, volume, pmax, heal, cohesion, {dxi, eskip}) -- the fused kernels' per-step element constants as one record
+    double *srec;                                // [Ne][6] M_shape_coeff as one 48-byte record per element for k_substep_multi, or NULL: the coefficients
+                                                 // are then rebuilt from the staged coordinates every sub-step, as k_substep_fused always does
     double *nrec;                                // [Nn][10]: (node_mass, grad_ssh u, v, rlmass, C_bu, fcor, D_tau_a u, v, ocean u, v) -- their nodal inputs
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
@@ -159,12 +161,22 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
     const double jac = jacobian(vx, vy);
     const double surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
     w.surface[e] = surface;
-    if (!LEAN) {
+    if (!LEAN || w.srec) {
+        double sc[6];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {  // FE.cpp:1956-1962
             const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-            w.shape[(size_t)k * m.Ne + e] = (vy[kp1] - vy[kp2]) / jac;
-            w.shape[(size_t)(k + 3) * m.Ne + e] = (vx[kp2] - vx[kp1]) / jac;
+            sc[k] = (vy[kp1] - vy[kp2]) / jac;
+            sc[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+        }
+        if (!LEAN) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w.shape[(size_t)k * m.Ne + e] = sc[k];
+        }
+        if (w.srec && blockIdx.x * BLOCK + (int)threadIdx.x < m.Ne) {
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            d2 *r = reinterpret_cast<d2 *>(w.srec) + 3 * (size_t)e;
+            r[0] = d2{sc[0], sc[1]}; r[1] = d2{sc[2], sc[3]}; r[2] = d2{sc[4], sc[5]};
         }
     }
 
@@ -848,7 +860,10 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         }
         if (active) {
             {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates: the same operations as
-                // k_prep_elements, so the same bits as M_shape_coeff -- 48 B/element less to stream
+                // k_prep_elements, so the same bits as M_shape_coeff -- 48 B/element less to stream.  (Reading them from a 48-byte
+                // record instead was tried for meshes that live in the caches: three more loads before barrier 1 cost more than the
+                // six divisions -- 182 k triangles 1.30 -> 1.36 ms/step, and even the uniform branch around the two variants cost
+                // 2-4 % at every size.  The several-sub-steps kernel, bound by VALU issue on its own CU, does read the records.)
                 const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
                 const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
                 const double jac = jacobian(vx, vy);
@@ -1018,6 +1033,9 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
     constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
 
+    // (uniform) M_shape_coeff from its per-step records instead of six divisions per element and sub-step: this kernel has its CU to
+    // itself and its element phase is bound by VALU issue -- 10 km: 0.739 -> 0.709 ms/step
+    const bool shape_mem = w.srec != nullptr;
     // index rows are padded: the first loads depend on the launch arguments only
     const int my_node = (t < NDm) ? pn[t] : 0;
     int eraw0 = 0;
@@ -1026,13 +1044,13 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     for (int i = t; i < nD; i += T) {
         const int g = (i == t) ? my_node : pn[i];
         lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
-        { typedef double d2 __attribute__((ext_vector_type(2))); const d2 c = reinterpret_cast<const d2 *>(w.xy)[g]; lx[i] = c.x; ly[i] = c.y; }
+        if (!shape_mem) { typedef double d2 __attribute__((ext_vector_type(2))); const d2 c = reinterpret_cast<const d2 *>(w.xy)[g]; lx[i] = c.x; ly[i] = c.y; }
     }
 
     // one element of one sub-step (FE.cpp:10425-10467), split into its global loads and the rest so that the barrier
     // between them sits in uniform control flow.  first sub-step of the launch: state from HBM; last: result to HBM (if this
     // patch writes the element); in between the state lives in LDS
-    struct ElemIn { int e; bool writer, skip; int dxi; double sig[3], damage, expC, volume, pmax, heal, coh; };
+    struct ElemIn { int e; bool writer, skip; int dxi; double sig[3], damage, expC, volume, pmax, heal, coh, dxN[6]; };
     typedef double d2 __attribute__((ext_vector_type(2)));
     auto load_element = [&](const int eraw, const bool first, const bool last) {
         ElemIn in;
@@ -1056,6 +1074,11 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
         const long long pk = __double_as_longlong(r2.y);
         in.dxi = (int)(pk & 0xffffffffll);
         in.skip = bbm ? true : (int)(pk >> 32) != 0;
+        if (shape_mem) {
+            const d2 *q = reinterpret_cast<const d2 *>(w.srec) + 3 * (size_t)e;
+            const d2 q0 = q[0], q1 = q[1], q2 = q[2];
+            in.dxN[0] = q0.x; in.dxN[1] = q0.y; in.dxN[2] = q1.x; in.dxN[3] = q1.y; in.dxN[4] = q2.x; in.dxN[5] = q2.y;
+        }
         return in;
     };
     auto compute_element = [&](const int l, const ushort4 tr, ElemIn &in, const bool first, const bool last, const int keep) {
@@ -1066,7 +1089,10 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
             skip = in.dxi < 0;
             c_dxs = (double)(skip ? ~in.dxi : in.dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
         }
-        {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates, as k_substep_fused
+        if (shape_mem) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dxN[k] = in.dxN[k];
+        } else {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates, as k_substep_fused
             const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
             const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
             const double jac = jacobian(vx, vy);

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--mesh", default="2km"); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--torch-first", action="store_true"); ap.add_argument("--graph", type=int, default=1)
-ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=-1); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0)
+ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=-1); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0); ap.add_argument("--shape-mem", type=int, default=-1)
 a = ap.parse_args()
 if a.torch_first:
     import torch
@@ -18,10 +18,12 @@ fe = dynamics.FiniteElementDynamics(p); fe.set_option("graph", a.graph); fe.set_
 if a.patch_nodes: fe.set_option("patch_nodes", a.patch_nodes)
 if a.pair_nodes: fe.set_option("pair_nodes", a.pair_nodes)
 if a.depth: fe.set_option("substeps_per_launch", a.depth)
-fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+fe.set_mesh(lm)
+if a.shape_mem >= 0: fe.set_option("shape_mem", a.shape_mem)
+fe.put_state(f); fe.set_forcing(f)
 fe.step(); fe.synchronize(); fe.set_option("timing_reset", 1)
 t = time.perf_counter()
 for _ in range(a.steps): fe.step()
 fe.synchronize(); dt = time.perf_counter() - t
-print(f"ring={a.ring} nt={a.nt} fused={a.fused} patch_nodes={a.patch_nodes} {a.mesh}: {lm.num_elements} triangles, {a.steps} steps, {dt/a.steps*1e3:.3f} ms/step, {lm.num_elements*120*a.steps/dt:.4e} element-updates/s, timing {fe.timing()}, crash {fe.checkFieldsFast()}", flush=True)
+print(f"shape_mem={a.shape_mem} ring={a.ring} nt={a.nt} fused={a.fused} patch_nodes={a.patch_nodes} {a.mesh}: {lm.num_elements} triangles, {a.steps} steps, {dt/a.steps*1e3:.3f} ms/step, {lm.num_elements*120*a.steps/dt:.4e} element-updates/s, timing {fe.timing()}, crash {fe.checkFieldsFast()}", flush=True)
 fe.close()

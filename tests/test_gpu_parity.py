@@ -469,6 +469,19 @@ def test_patch_size_does_not_change_a_bit(patch_nodes):
     base.close(); other.close()
 
 
+@pytest.mark.parametrize("kind,over,opts", [("toy", {}, {"fused": 2}), ("toy", {"dynamics_type": 3}, {"fused": 2}), ("small", {}, {"fused": 2}),
+                                            ("10km", {}, {})])
+def test_shape_coefficients_from_records_or_rebuilt_do_not_change_a_bit(kind, over, opts):
+    """Option shape_mem: the several-sub-steps kernel reads M_shape_coeff from per-step records (default) or rebuilds it from the
+    staged frozen coordinates as the one-sub-step kernel does: the same quotients either way -- BBM and EVP, three meshes."""
+    a, _, _ = _pair(kind, 2, options=dict(opts, shape_mem=0), **over)
+    b, _, _ = _pair(kind, 2, options=dict(opts, shape_mem=1), **over)
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(sa[k], sb[k]), k
+    a.close(); b.close()
+
+
 def test_shuffled_numbering_still_matches_the_oracle():
     """A mesh whose node/element numbering has no locality (random permutation): patches are then cut
     along a Morton curve through the coordinates; results must still match the oracle on that mesh."""
