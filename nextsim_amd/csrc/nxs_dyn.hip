@@ -144,6 +144,7 @@ struct nxs_dyn_handle {
     double *f_snap[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // wind0, wind1, ocean0, ocean1, ssh0, ssh1 (forcing pair)
     bool have_pair = false;
     std::vector<void *> forcing_allocs;
+    double *smooth_second = nullptr;       // the ring slot that equals M_VT after the sub-step loop (the smoother's second buffer), or NULL
     int sig_loc = 0;                       // where M_sigma / M_damage are current: 0 = the state arrays, 1 = the records in S4a (left there by
                                            // the fused sub-step loop; k_update works on them, the arrays follow on demand: ensure_arrays)
     int trace_branches = 0;                // option "trace_branches": the per-loop kernels keep the branch trace of updateSigmaDamage (dw.trace)
@@ -1514,6 +1515,10 @@ int run_substeps(nxs_dyn_handle *h) {
         h->d_hf_dirty = false;
     }
     const bool records_end_odd = pair ? ((S / D) & 1) : (S & 1);
+    // with the deferred mesh move the last flush of the step reads the newest velocity anyway and puts it back into M_VT itself; the
+    // ring slot it came from then equals M_VT and serves the smoother as its second buffer (no copy before the sweeps)
+    double *const vt_back = (deferred && (S % R) != 0) ? h->ds.VT : nullptr;
+    h->smooth_second = vt_back ? h->ring.slot[S % R] : nullptr;
     auto pull_latest = [&](double *vec) {
         const int tr = h->recv_offsets[h->recv_procs.size()];
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,
@@ -1527,7 +1532,7 @@ int run_substeps(nxs_dyn_handle *h) {
                 s += D - 1;
                 pending += D;
                 if (pending == K || s == S - 1) {
-                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt);
+                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, s == S - 1 ? vt_back : (double *)nullptr);
                     pending = 0;
                 }
                 continue;
@@ -1538,7 +1543,7 @@ int run_substeps(nxs_dyn_handle *h) {
                 if (flush || s == S - 1) pull_latest(h->ring.slot[(s + 1) % R]);  // the newest ghosts, for the move / the end of the step
                 if (flush) {
                     ++pending;
-                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt);
+                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, s == S - 1 ? vt_back : (double *)nullptr);
                     pending = 0;
                 } else if (deferred) ++pending;
                 continue;
@@ -1551,13 +1556,13 @@ int run_substeps(nxs_dyn_handle *h) {
                 if (rc) return rc;
             }
             if (deferred && (++pending == K || s == S - 1)) {
-                LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt);
+                LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, s == S - 1 ? vt_back : (double *)nullptr);
                 pending = 0;
             }
         }
         if (fused) {  // bring the result back to the primary buffers
             const double *vt_src = (S % R) ? h->ring.slot[S % R] : nullptr;
-            if (vt_src) LAUNCH(h, k_pingpong_copy_back, 2 * h->dm.Nn, h->dm, h->ds, vt_src);
+            if (vt_src && !vt_back) LAUNCH(h, k_pingpong_copy_back, 2 * h->dm.Nn, h->dm, h->ds, vt_src);  // (else the last ring flush has done it)
             // the element state stays in its records when the loop ends in the first buffer (an even number of launches): update()
             // works on them and the arrays follow when somebody asks (ensure_arrays); from the second buffer it is unpacked here
             if (records_end_odd) LAUNCH(h, k_unpack_state, h->dm.Ne, h->dm, h->ds, bbm, (const double *)h->ds.S4b);
@@ -1632,8 +1637,8 @@ int explicit_solve(nxs_dyn_handle *h) {
     // Q9: 50 sweeps, hard-coded (FE.cpp:10580); + open-water mesh move.  52+ small launches: replayed from
     // a second hipGraph whenever no host work is needed inside (single rank, or device-direct halo).
     auto smooth_and_tail = [&]() -> int {
-        double *a = h->ds.VT, *b = h->ds.VT2;
-        LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);
+        double *a = h->ds.VT, *b = h->smooth_second ? h->smooth_second : h->ds.VT2;
+        if (!h->smooth_second) LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);  // both buffers equal: a sweep writes the ice-free nodes only
         // single rank: D sweeps per launch on patches with D rings of nodes (k_smooth_multi) -- those of k_substep_multi where that
         // kernel runs, else node-ring patches built for the smoother alone
         const bool v3_patches = h->pair_ready && !h->pair_failed && h->dpch2.pnbr && eff_fused(h) >= 2 && h->depth_now >= 2;

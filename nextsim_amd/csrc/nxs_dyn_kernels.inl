@@ -1203,13 +1203,15 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
 #define NXS_MAX_RING 129
 struct VTRing { double *slot[NXS_MAX_RING]; int R; };
 
-__global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRing ring, int first, int count, double dt) {
+// vt_out != NULL (the last flush of a step): the newest velocity also goes back into M_VT -- the flush has just read it
+__global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRing ring, int first, int count, double dt, double *__restrict__ vt_out) {
     const int n = blockIdx.x * BLOCK + threadIdx.x;
     if (n >= m.Nn) return;
     const int Nn = m.Nn;
     const bool free_node = !(m.nflags[n] & NF_NEUMANN);  // Neumann nodes keep M_UM (restore == skip)
     double umu = s.UM[n], umv = s.UM[n + Nn], utu = s.UT[n], utv = s.UT[n + Nn];
     int sl = first;
+    double lastu = 0., lastv = 0.;
     // the additions are sequential (the reference's order), the loads are not: eight slots in flight at a time
     int j = 0;
     for (; j + 8 <= count; j += 8) {
@@ -1225,15 +1227,18 @@ __global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRi
             if (free_node) { umu += dt * u[k]; umv += dt * v[k]; }
             utu += dt * u[k]; utv += dt * v[k];
         }
+        lastu = u[7]; lastv = v[7];
     }
     for (; j < count; ++j) {
         const double u = ring.slot[sl][n], v = ring.slot[sl][n + Nn];
         if (free_node) { umu += dt * u; umv += dt * v; }
         utu += dt * u; utv += dt * v;
         sl = (sl + 1 == ring.R) ? 0 : sl + 1;
+        lastu = u; lastv = v;
     }
     if (free_node) { s.UM[n] = umu; s.UM[n + Nn] = umv; }
     s.UT[n] = utu; s.UT[n + Nn] = utv;
+    if (vt_out) { vt_out[n] = lastu; vt_out[n + Nn] = lastv; }
 }
 
 // the velocity of the last sub-step back into M_VT when the ring ended elsewhere
