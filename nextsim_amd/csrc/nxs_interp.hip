@@ -38,6 +38,30 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// Every device operation of this file runs on a stream of its own (one per host thread, created on first use), never on the
+// legacy default stream: a host that drives several GPUs from one process may be capturing a graph of the dynamics step on
+// another thread, and legacy-stream work is refused while a capture is open.
+hipStream_t S() {
+    thread_local hipStream_t st = nullptr;
+    thread_local int st_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!st || st_dev != dev) {
+        st = nullptr;
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; (void)hipGetLastError(); }
+        st_dev = dev;
+    }
+    return st;
+}
+hipError_t copy_sync(void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, S());
+    return e != hipSuccess ? e : hipStreamSynchronize(S());
+}
+hipError_t memset_sync(void *dst, int value, size_t bytes) {
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, S());
+    return e != hipSuccess ? e : hipStreamSynchronize(S());
+}
+
 struct BEdge {  // a boundary edge as seen from its (inside) triangle
     int tri, k;  // triangle number, local edge index (vertices VOTE[k][0] -> VOTE[k][1])
 };
@@ -227,7 +251,7 @@ struct DevBuf {
     int alloc(size_t n) { return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
     int upload(const T *src, size_t n) {
         if (alloc(n)) return -1;
-        return (n == 0 || hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
+        return (n == 0 || copy_sync(p, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
     }
 };
 
@@ -440,16 +464,16 @@ extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_me
     d.default_value = default_value;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, nullptr);
-    hipLaunchKernelGGL(k_mesh_to_grid, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, nullptr, d, (const double *)ddata.p, dout.p);
-    (void)hipEventRecord(e1, nullptr);
-    hipError_t err = hipDeviceSynchronize();
+    (void)hipEventRecord(e0, S());
+    hipLaunchKernelGGL(k_mesh_to_grid, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, S(), d, (const double *)ddata.p, dout.p);
+    (void)hipEventRecord(e1, S());
+    hipError_t err = hipStreamSynchronize(S());
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (err != hipSuccess) return fail(NXS_ERR_HIP, "mesh-to-grid kernel failed: %s", hipGetErrorString(err));
     if (kernel_ms) *kernel_ms = ms;
-    if (hipMemcpy(griddata, dout.p, npts * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    if (copy_sync(griddata, dout.p, npts * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     return NXS_OK;
 }
 
@@ -479,27 +503,27 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     if (ddata.upload(data, (size_t)M_data * N_data) || dxi.upload(x_interp, N_interp) || dyi.upload(y_interp, N_interp) ||
         dout.alloc((size_t)N_interp * N_data) || dnext.alloc(4))
         return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
-    if (hipMemset(dnext.p, 0, 4 * sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+    if (memset_sync(dnext.p, 0, 4 * sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
     d.N_data = N_data; d.N_interp = N_interp; d.nodal = (M_data == nods);
     d.isdefault = isdefault != 0; d.defaultvalue = defaultvalue;
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, nullptr);
+    (void)hipEventRecord(e0, S());
     if (N_interp > 0)
-        hipLaunchKernelGGL(k_interp, dim3((N_interp + 255) / 256), dim3(256), 0, nullptr, d, (const double *)ddata.p, (const double *)dxi.p,
+        hipLaunchKernelGGL(k_interp, dim3((N_interp + 255) / 256), dim3(256), 0, S(), d, (const double *)ddata.p, (const double *)dxi.p,
                            (const double *)dyi.p, dout.p, dnext.p);
-    (void)hipEventRecord(e1, nullptr);
-    hipError_t err = hipDeviceSynchronize();
+    (void)hipEventRecord(e1, S());
+    hipError_t err = hipStreamSynchronize(S());
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (err != hipSuccess) return fail(NXS_ERR_HIP, "interpolation kernel failed: %s", hipGetErrorString(err));
     if (kernel_ms) *kernel_ms = ms;
-    if (N_interp > 0 && hipMemcpy(data_interp, dout.p, (size_t)N_interp * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+    if (N_interp > 0 && copy_sync(data_interp, dout.p, (size_t)N_interp * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
         return fail(NXS_ERR_HIP, "copy back failed");
     int next[4] = {0, 0, 0, 0};
-    (void)hipMemcpy(next, dnext.p, sizeof next, hipMemcpyDeviceToHost);
+    (void)copy_sync(next, dnext.p, sizeof next, hipMemcpyDeviceToHost);
     if (num_exterior) *num_exterior = next[0];
     g_info[0] = (int)loc.comp.fill.size() / 3; g_info[1] = (int)loc.comp.hull.size();
     g_info[2] = next[0]; g_info[3] = next[1]; g_info[4] = next[2]; g_info[5] = next[3];
@@ -686,7 +710,7 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
         dyn.upload(y_new, nods_new) || (previous_numbering && dprev.upload(previous_numbering, nods_new)) ||
         din.upload(interp_in, (size_t)nels_old * nb_var) || dout.alloc((size_t)nels_new * nb_var) || dfail.alloc(1) || (visits && dvis.alloc(nels_new)))
         return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
-    if (hipMemset(dfail.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+    if (memset_sync(dfail.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
 
     RemapDev r{};
     r.loc = loc.d;
@@ -697,20 +721,20 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
 
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, nullptr);
+    (void)hipEventRecord(e0, S());
     const int failed_cap = 1 << 16;
     DevBuf<int> dflist, dstill, dbt;
     DevBuf<double> dbw;
     DevBuf<nxs_remap::Frame> dbs;
-    if (dflist.alloc(failed_cap) || dstill.alloc(1) || hipMemset(dstill.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "device allocation failed");
-    hipLaunchKernelGGL(k_remap, dim3((nels_new + 127) / 128), dim3(128), 0, nullptr, r, (const double *)din.p, dout.p, dfail.p, visits ? dvis.p : nullptr,
+    if (dflist.alloc(failed_cap) || dstill.alloc(1) || memset_sync(dstill.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "device allocation failed");
+    hipLaunchKernelGGL(k_remap, dim3((nels_new + 127) / 128), dim3(128), 0, S(), r, (const double *)din.p, dout.p, dfail.p, visits ? dvis.p : nullptr,
                        dflist.p, failed_cap);
     int nf1 = 0;
-    if (hipMemcpy(&nf1, dfail.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    if (copy_sync(&nf1, dfail.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     int unrecoverable = 0, nbig = 0;
     if (nf1 > 0) {  // the few that exceeded the fast path's capacity: second pass with large lists in global memory
         std::vector<int> fl(std::min(nf1, failed_cap));
-        if (hipMemcpy(fl.data(), dflist.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+        if (copy_sync(fl.data(), dflist.p, fl.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
         std::vector<int> big;
         for (int v : fl) { if (v >= 0) big.push_back(v); else ++unrecoverable; }
         unrecoverable += nf1 - (int)fl.size();  // more failures than the list holds: left as failures
@@ -718,24 +742,24 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
         nbig = (int)big.size();
         const size_t per = (size_t)nxs_remap::kMaxVisitBig;
         if (nbig > 0) {
-            if (dflist.p && hipMemcpy(dflist.p, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(NXS_ERR_HIP, "upload failed");
+            if (dflist.p && copy_sync(dflist.p, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(NXS_ERR_HIP, "upload failed");
             if (dbt.alloc(nbig * per) || dbw.alloc(nbig * per) || dbs.alloc(nbig * (per + 1)))
                 return fail(NXS_ERR_HIP, "second remapping pass: %d triangles need %zu MB of lists", nbig, nbig * per * 28 >> 20);
-            hipLaunchKernelGGL(k_remap_big, dim3((nbig + 63) / 64), dim3(64), 0, nullptr, r, (const double *)din.p, dout.p, (const int *)dflist.p, nbig, dbt.p, dbw.p,
+            hipLaunchKernelGGL(k_remap_big, dim3((nbig + 63) / 64), dim3(64), 0, S(), r, (const double *)din.p, dout.p, (const int *)dflist.p, nbig, dbt.p, dbw.p,
                                dbs.p, dstill.p, visits ? dvis.p : nullptr);
         }
     }
-    (void)hipEventRecord(e1, nullptr);
-    hipError_t err = hipDeviceSynchronize();
+    (void)hipEventRecord(e1, S());
+    hipError_t err = hipStreamSynchronize(S());
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (err != hipSuccess) return fail(NXS_ERR_HIP, "remapping kernel failed: %s", hipGetErrorString(err));
     if (kernel_ms) *kernel_ms = ms;
-    if (hipMemcpy(interp_out, dout.p, (size_t)nels_new * nb_var * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
-    if (visits && hipMemcpy(visits, dvis.p, (size_t)nels_new * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    if (copy_sync(interp_out, dout.p, (size_t)nels_new * nb_var * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    if (visits && copy_sync(visits, dvis.p, (size_t)nels_new * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     int still = 0;
-    (void)hipMemcpy(&still, dstill.p, sizeof(int), hipMemcpyDeviceToHost);
+    (void)copy_sync(&still, dstill.p, sizeof(int), hipMemcpyDeviceToHost);
     if (num_failed) *num_failed = unrecoverable + still;
     return NXS_OK;
 }
@@ -860,15 +884,15 @@ extern "C" int nxs_interp_grid_to_mesh(double *data_mesh, const double *x_in, in
     G2M g{dx.p, dy.p, N, M, M, N, N_data, nods, interp, row_major != 0, monotone(x.data(), N), monotone(y.data(), M), default_value};
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, nullptr);
-    hipLaunchKernelGGL(k_grid_to_mesh, dim3((nods + 255) / 256), dim3(256), 0, nullptr, g, (const double *)dd.p, (const double *)dxm.p, (const double *)dym.p, dout.p);
-    (void)hipEventRecord(e1, nullptr);
-    hipError_t err = hipDeviceSynchronize();
+    (void)hipEventRecord(e0, S());
+    hipLaunchKernelGGL(k_grid_to_mesh, dim3((nods + 255) / 256), dim3(256), 0, S(), g, (const double *)dd.p, (const double *)dxm.p, (const double *)dym.p, dout.p);
+    (void)hipEventRecord(e1, S());
+    hipError_t err = hipStreamSynchronize(S());
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (err != hipSuccess) return fail(NXS_ERR_HIP, "grid-to-mesh kernel failed: %s", hipGetErrorString(err));
     if (kernel_ms) *kernel_ms = ms;
-    if (hipMemcpy(data_mesh, dout.p, (size_t)nods * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    if (copy_sync(data_mesh, dout.p, (size_t)nods * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     return NXS_OK;
 }

@@ -44,6 +44,16 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(NXS_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));          \
     } while (0)
 
+// (never the legacy default stream: another handle of this process may be capturing a graph on its own thread)
+inline hipError_t copy_on(hipStream_t st, void *dst, const void *src, size_t bytes, hipMemcpyKind kind) {
+    const hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+inline hipError_t memset_on(hipStream_t st, void *dst, int value, size_t bytes) {
+    const hipError_t e = hipMemsetAsync(dst, value, bytes, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+}
+
 constexpr int BS = 256;     // threads per block = 4 slices
 constexpr int SL = 64;      // rows per slice
 constexpr int MAXG = 2048;  // most blocks of a reducing kernel (= partial sums per value)
@@ -477,12 +487,12 @@ int upload_matrix(nxs_krylov_handle *h, int n, int n_local, const std::vector<in
     KCHK(hipMalloc((void **)&h->d_col, std::max<size_t>(col.size(), 1) * sizeof(int)));
     KCHK(hipMalloc((void **)&h->d_val, std::max<size_t>(val.size(), 1) * sizeof(double)));
     KCHK(hipMalloc((void **)&h->d_dinv, (size_t)n * sizeof(double)));
-    KCHK(hipMemcpy(h->d_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
-    KCHK(hipMemcpy(h->d_col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
-    KCHK(hipMemcpy(h->d_val, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
+    KCHK(copy_on(h->stream, h->d_off, off.data(), off.size() * sizeof(int), hipMemcpyHostToDevice));
+    KCHK(copy_on(h->stream, h->d_col, col.data(), col.size() * sizeof(int), hipMemcpyHostToDevice));
+    KCHK(copy_on(h->stream, h->d_val, val.data(), val.size() * sizeof(double), hipMemcpyHostToDevice));
     for (auto &v : h->vec) {
         KCHK(hipMalloc((void **)&v, (size_t)n_local * sizeof(double)));
-        KCHK(hipMemset(v, 0, (size_t)n_local * sizeof(double)));
+        KCHK(memset_on(h->stream, v, 0, (size_t)n_local * sizeof(double)));
     }
     return NXS_OK;
 }
@@ -702,7 +712,7 @@ int nxs_krylov_create(int32_t device, nxs_krylov_handle **out) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess || hipMalloc((void **)&h->d_partial, 2 * MAXG * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&h->d_scal, 16 * sizeof(double)) != hipSuccess || hipMalloc((void **)&h->d_counter, CSTRIDE * (NGRP + 1) * sizeof(unsigned int)) != hipSuccess ||
         hipMalloc((void **)&h->d_bad, sizeof(int)) != hipSuccess || hipHostMalloc((void **)&h->h_scal, 16 * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-        hipMemset(h->d_counter, 0, CSTRIDE * (NGRP + 1) * sizeof(unsigned int)) != hipSuccess || hipMemset(h->d_scal, 0, 16 * sizeof(double)) != hipSuccess) {
+        memset_on(h->stream, h->d_counter, 0, CSTRIDE * (NGRP + 1) * sizeof(unsigned int)) != hipSuccess || memset_on(h->stream, h->d_scal, 0, 16 * sizeof(double)) != hipSuccess) {
         fail(NXS_ERR_HIP, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
         nxs_krylov_destroy(h);
         return NXS_ERR_HIP;
@@ -770,8 +780,8 @@ int nxs_krylov_set_halo(nxs_krylov_handle *h, const nxs_dyn_halo *halo) {
     KCHK(hipMalloc((void **)&h->d_recv_index, std::max(tr, 1) * sizeof(int)));
     KCHK(hipMalloc((void **)&h->d_send_buf, std::max(ts, 1) * sizeof(double)));
     KCHK(hipMalloc((void **)&h->d_recv_buf, std::max(tr, 1) * sizeof(double)));
-    if (ts > 0) KCHK(hipMemcpy(h->d_send_index, halo->send_index, (size_t)ts * sizeof(int), hipMemcpyHostToDevice));
-    if (tr > 0) KCHK(hipMemcpy(h->d_recv_index, halo->recv_index, (size_t)tr * sizeof(int), hipMemcpyHostToDevice));
+    if (ts > 0) KCHK(copy_on(h->stream, h->d_send_index, halo->send_index, (size_t)ts * sizeof(int), hipMemcpyHostToDevice));
+    if (tr > 0) KCHK(copy_on(h->stream, h->d_recv_index, halo->recv_index, (size_t)tr * sizeof(int), hipMemcpyHostToDevice));
     KCHK(hipHostMalloc((void **)&h->h_send, std::max(ts, 1) * sizeof(double), hipHostMallocDefault));
     KCHK(hipHostMalloc((void **)&h->h_recv, std::max(tr, 1) * sizeof(double), hipHostMallocDefault));
     h->have_halo = true;
@@ -827,7 +837,7 @@ int nxs_krylov_spmv(nxs_krylov_handle *h, const double *in, double *out, int32_t
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (rc) return rc;
     if (err != hipSuccess) return fail(NXS_ERR_HIP, "spmv failed: %s", hipGetErrorString(err));
-    KCHK(hipMemcpy(out, h->vec[1], (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
+    KCHK(copy_on(h->stream, out, h->vec[1], (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
     if (ms_per_spmv) *ms_per_spmv = ms / reps;
     return NXS_OK;
 }
@@ -842,7 +852,7 @@ int nxs_krylov_run(nxs_krylov_handle *h, const double *b, double *x, int32_t met
     KCHK(hipMemcpyAsync(h->vec[1], b, (size_t)h->n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     int rc = run_solver(h, method, rtol, max_iter, iterations, rel_residual, ms_solve);
     if (rc) return rc;
-    KCHK(hipMemcpy(x, h->vec[0], (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
+    KCHK(copy_on(h->stream, x, h->vec[0], (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
     return NXS_OK;
 }
 
@@ -937,7 +947,7 @@ int nxs_fem_poisson_solve(const int32_t *indices, const double *x, const double 
 
     struct Tmp { void *p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } };
     Tmp dpeo, dptri, dpf, dpcol, dlpos, dlrow, ddir, dx, dy;
-    auto up = [&](Tmp &t, const void *src, size_t bytes) { return hipMalloc(&t.p, std::max<size_t>(bytes, 1)) == hipSuccess && (bytes == 0 || hipMemcpy(t.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess); };
+    auto up = [&](Tmp &t, const void *src, size_t bytes) { return hipMalloc(&t.p, std::max<size_t>(bytes, 1)) == hipSuccess && (bytes == 0 || copy_on(h->stream, t.p, src, bytes, hipMemcpyHostToDevice) == hipSuccess); };
     if (!up(dpeo, pel_off.data(), pel_off.size() * sizeof(int)) || !up(dptri, ptri.data(), ptri.size() * sizeof(int)) || !up(dpf, pf.data(), pf.size() * sizeof(double)) ||
         !up(dpcol, pcol.data(), pcol.size()) || !up(dlpos, lpos.data(), lpos.size() * sizeof(unsigned short)) || !up(dlrow, lrow.data(), lrow.size()) ||
         !up(ddir, dirichlet, Nn) || !up(dx, x, Nn * sizeof(double)) || !up(dy, y, Nn * sizeof(double)))
@@ -962,7 +972,7 @@ int nxs_fem_poisson_solve(const int32_t *indices, const double *x, const double 
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if ((rc = finish_matrix(h))) return rc;
     if ((rc = run_solver(h, NXS_KRYLOV_CG, rtol, max_iter, iterations, rel_residual, ms_solve))) return rc;
-    KCHK(hipMemcpy(u, h->vec[0], (size_t)Nn * sizeof(double), hipMemcpyDeviceToHost));
+    KCHK(copy_on(h->stream, u, h->vec[0], (size_t)Nn * sizeof(double), hipMemcpyDeviceToHost));
     if (ms_assembly) *ms_assembly = msa;
     return NXS_OK;
 }
