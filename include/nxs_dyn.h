@@ -269,7 +269,9 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *   "fused"        3 = automatic (default): several sub-steps per launch on single-rank meshes small enough for one patch
  *                  per CU (<= 256 nodes each, patches with that many rings of halo), one patch kernel per sub-step otherwise;
  *                  2 = several sub-steps per launch wherever possible (single rank, not mEVP, a depth that divides the
- *                  number of sub-steps); 1 = one patch kernel per sub-step; 0 = one kernel per reference loop
+ *                  number of sub-steps); 1 = one patch kernel per sub-step; 0 = one kernel per reference loop;
+ *                  4 = the whole sub-step loop in ONE resident launch whose workgroups wait for their neighbouring patches only
+ *                  (single rank, not mEVP, every workgroup resident at once -- checked, else as 1): for a device the handle has to itself
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)
  *   "patch_nodes"  own nodes per patch of the fused kernel, 64..1024; 0 = automatic (whole rounds of resident workgroups)
  *   "pair_nodes"   the same for the several-sub-steps kernel, 16..512; 0 = automatic

@@ -144,6 +144,11 @@ struct nxs_dyn_handle {
     double *f_snap[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // wind0, wind1, ocean0, ocean1, ssh0, ssh1 (forcing pair)
     bool have_pair = false;
     std::vector<void *> forcing_allocs;
+    // v4: the whole sub-step loop in one resident launch (option "fused" = 4; see k_substep_resident)
+    DevResident res{};
+    bool res_ready = false, res_failed = false;
+    size_t res_lds = 0;
+    double *d_vt3 = nullptr;
     double *smooth_second = nullptr;       // the ring slot that equals M_VT after the sub-step loop (the smoother's second buffer), or NULL
     int sig_loc = 0;                       // where M_sigma / M_damage are current: 0 = the state arrays, 1 = the records in S4a (left there by
                                            // the fused sub-step loop; k_update works on them, the arrays follow on demand: ensure_arrays)
@@ -503,8 +508,8 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     }
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }  // -1 = automatic
     if (!std::strcmp(key, "fused")) {
-        if (value < 0 || value > 3) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2 or 3");
-        h->fused = (int)value; release_graph(h); return NXS_OK;
+        if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
+        h->fused = (int)value; h->res_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "substeps_per_launch")) {
         if (value != 0 && (value < 2 || value > NXS_MAX_DEPTH)) return fail(h, NXS_ERR_INVALID, "substeps_per_launch must be 0 (auto) or in [2,%d]", NXS_MAX_DEPTH);
@@ -1442,6 +1447,58 @@ int build_halo_fused(nxs_dyn_handle *h) {
     return NXS_OK;
 }
 
+// Tables of the resident sub-step kernel: which patches own each patch's halo nodes; the counters; the exchange buffers.
+// NXS_OK with res_ready == false means "not possible here" (the caller then runs one kernel per sub-step).
+int build_resident(nxs_dyn_handle *h) {
+    h->res_ready = false;
+    if (!h->hp || h->hp->nP != h->dpch.nP) return NXS_OK;
+    const HostPatches &hp = *h->hp;
+    const int nP = hp.nP, No = h->dm.No, Nn = h->dm.Nn;
+    if (hp.Emax > 512 || hp.Pmax > 512 || No != Nn) { h->res_failed = true; return NXS_OK; }  // one element per thread; single rank for now
+    std::vector<int> owner(Nn, -1);
+    for (int q = 0; q < nP; ++q)
+        for (int i = 0; i < hp.own_cnt[q]; ++i) owner[hp.pnodes[(size_t)q * hp.Mmax + i]] = q;
+    std::vector<int> nbr((size_t)nP * NXS_RES_NBR, -1), cnt(nP, 0);
+    for (int q = 0; q < nP; ++q)
+        for (int i = hp.own_cnt[q]; i < hp.node_cnt[q]; ++i) {
+            const int o = owner[hp.pnodes[(size_t)q * hp.Mmax + i]];
+            if (o < 0 || o == q) { h->res_failed = true; return NXS_OK; }  // a staged node nobody solves: not a single-rank patch set
+            int *row = nbr.data() + (size_t)q * NXS_RES_NBR;
+            bool have = false;
+            for (int k = 0; k < cnt[q]; ++k) have = have || row[k] == o;
+            if (have) continue;
+            if (cnt[q] == NXS_RES_NBR) { h->res_failed = true; return NXS_OK; }
+            row[cnt[q]++] = o;
+        }
+    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax) * sizeof(double);
+    // every workgroup must be resident at once
+    int per_cu = 0, cus = 0;
+    hipError_t e = h->dp.ers_int == 4
+        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true>, 512, h->res_lds)
+        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false>, 512, h->res_lds);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    if (e != hipSuccess || (long long)per_cu * cus < nP) {
+        (void)hipGetLastError();
+        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] resident kernel not possible: %d patches, %d x %d workgroups fit (%zu B of LDS each)\n", nP, per_cu, cus, h->res_lds);
+        h->res_failed = true;
+        return NXS_OK;
+    }
+    int rc;
+    DevResident &r = h->res;
+    r = DevResident{};
+    if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr, nbr))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr_cnt, cnt))) return rc;
+    if ((rc = dev_alloc(h, h->patch_allocs, &r.flag, 32 * (size_t)nP))) return rc;
+    if ((rc = dev_alloc(h, h->patch_allocs, &r.error, 1))) return rc;
+    HIPCHK(h, hipMemsetAsync(r.error, 0, sizeof(int), h->stream));
+    if (!h->d_vt3 && (rc = dev_alloc(h, h->state_allocs, &h->d_vt3, 2 * (size_t)Nn))) return rc;
+    r.X0 = h->ds.VT2; r.X1 = h->d_vt3;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] resident kernel: %d patches (%d x %d fit), %zu B of LDS each, up to %d neighbours\n", nP, per_cu, cus, h->res_lds, *std::max_element(cnt.begin(), cnt.end()));
+    h->res_ready = true;
+    return NXS_OK;
+}
+
 void launch_substep(nxs_dyn_handle *h, double move_dt) {
     if (h->dp.dynamics_type == NXS_DYN_BBM) {
         if (h->trace_branches) {
@@ -1514,7 +1571,12 @@ int run_substeps(nxs_dyn_handle *h) {
         HIPCHK(h, hipStreamSynchronize(h->stream));  // tmp leaves scope
         h->d_hf_dirty = false;
     }
-    const bool records_end_odd = pair ? ((S / D) & 1) : (S & 1);
+    if (h->fused == 4 && !h->trace_branches && !mr && !pair && move_dt != 0. && !h->res_ready && !h->res_failed) {  // (outside any capture)
+        int rcr = build_resident(h);
+        if (rcr) return rcr;
+    }
+    const bool resident = h->fused == 4 && !h->trace_branches && !mr && !pair && move_dt != 0. && h->res_ready && !h->res_failed;
+    const bool records_end_odd = resident ? false : (pair ? ((S / D) & 1) : (S & 1));
     // with the deferred mesh move the last flush of the step reads the newest velocity anyway and puts it back into M_VT itself; the
     // ring slot it came from then equals M_VT and serves the smoother as its second buffer (no copy before the sweeps)
     double *const vt_back = (deferred && (S % R) != 0) ? h->ds.VT : nullptr;
@@ -1525,6 +1587,13 @@ int run_substeps(nxs_dyn_handle *h) {
                            h->d_recv_seg, h->d_recv_off, h->ipc, 0., 0, h->d_recv_procs, 1);
     };
     auto loop = [&]() -> int {
+        if (resident) {  // the whole loop in one launch; the element state goes from S4a to S4b, then back into S4a's role by a copy
+            HIPCHK(h, hipMemsetAsync(h->res.flag, 0, 32 * (size_t)h->dpch.nP * sizeof(unsigned int), h->stream));
+            const dim3 grid(h->dpch.nP);
+            if (h->dp.ers_int == 4) hipLaunchKernelGGL((k_substep_resident<512, true>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt);
+            else hipLaunchKernelGGL((k_substep_resident<512, false>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt);
+            return NXS_OK;
+        }
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
         for (int s = 0; s < S; ++s) {
             if (pair) {
@@ -1573,7 +1642,7 @@ int run_substeps(nxs_dyn_handle *h) {
     if (fused && h->sig_loc == 0) LAUNCH(h, k_pack_state, h->dm.Ne, h->dm, h->ds, bbm, h->ds.S4a);
     if (!fused) ensure_arrays(h);
     if (fused) h->sig_loc = records_end_odd ? 0 : 1;
-    h->timing.substep_launches = pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
+    h->timing.substep_launches = resident ? 1 : pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
     if (!h->use_graph || (mr && !device_halo)) return loop();
     if (!h->graph_valid) {
         release_graph(h);
@@ -1760,6 +1829,16 @@ int nxs_dyn_synchronize(nxs_dyn_handle *h) {
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
+    if (h->res_ready) {
+        int err = 0;
+        HIPCHK(h, hipMemcpyAsync(&err, h->res.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (err) {
+            h->res_failed = true; h->res_ready = false; release_graph(h);
+            return fail(h, NXS_ERR_HIP, "the resident sub-step kernel timed out waiting for a neighbouring patch (its workgroups were not all resident: is the "
+                                        "device shared?); the step is lost, later steps run one kernel per sub-step");
+        }
+    }
     if (h->ipc_ready) {
         int err = 0;
         HIPCHK(h, hipMemcpyAsync(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost, h->stream));

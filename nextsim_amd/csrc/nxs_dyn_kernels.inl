@@ -1196,6 +1196,220 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4  The whole sub-step loop in ONE launch: a patch stays on its CU for all the sub-steps and waits for its NEIGHBOURING
+// patches only (FE.cpp:10425-10553 as k_substep_fused; same operations in the same order, same bits).
+// Where one round of resident workgroups covers the partition the sub-step of k_substep_fused is a latency chain -- launch,
+// index hop, staging of velocities / element constants / nodal inputs, two barriers, tail: 10.2 us at 182 k triangles, of which
+// ~3 are arithmetic.  Here a workgroup loads all that ONCE per step (stress, damage and element constants in registers, shape
+// coefficients, nodal inputs and the running M_UM / M_UT of its own nodes in LDS) and per sub-step only exchanges velocities:
+//   node phase -> every own node's new velocity goes to the exchange buffer X[s & 1] with write-through (sc1) stores, every wave
+//   drains them, barrier, one lane raises the patch's counter to s + 1;
+//   before the next element phase a few lanes wait until the counters of the patches that own this patch's halo nodes have
+//   reached s + 1, then the halo velocities are read from X[s & 1] with cache-bypassing (sc1) loads into LDS.
+// Two exchange buffers suffice: a patch overwrites X[s & 1] (sub-step s + 2) only after all its neighbours have raised their
+// counters to s + 2, i.e. after they have read X[s & 1] (they did that before their sub-step s + 1).  scripts/micro/nbrsync.hip:
+// that exchange costs 3.1 us per sub-step with 511 workgroups; a grid-wide barrier costs 6-9 (MI355X_MICROARCH.md, barrier-xcd).
+// REQUIRES every workgroup of the grid to be resident at once (the host checks the occupancy and falls back otherwise; every
+// wait is bounded and reports through r.error), one element per thread (Emax <= T), not mEVP.
+#define NXS_RES_NBR 24
+struct DevResident {
+    const int *pnbr;       // [nP][NXS_RES_NBR] the patches that own this patch's halo nodes
+    const int *pnbr_cnt;   // [nP]
+    unsigned int *flag;    // [nP * 32] sub-steps published by each patch (one counter per 128-byte line; zeroed before every launch)
+    double *X0, *X1;       // [2 Nn] exchange buffers: velocities after an even / an odd sub-step
+    int *error;            // != 0: a wait timed out (the workgroups were not all resident): the step is lost, nobody waits again
+};
+
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+template <int T, bool POW4>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
+                                                        const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt) {
+    const DevParams &p0 = *pdev;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int Mmax = pp.Mmax, Emax = pp.Emax, Pmax = pp.Pmax;
+    double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*[6][Emax]*/, *ldx = lF + 6 * (size_t)Emax /*[6][Emax]*/,
+           *lN = ldx + 6 * (size_t)Emax /*[10][Pmax]*/, *lM = lN + 10 * (size_t)Pmax /*[4][Pmax]*/;
+    __shared__ int lerr;
+    int blk;
+    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
+        const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, rr = n & 7, x = pos & 7;
+        blk = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (pos >> 3);
+    }
+    const int t = threadIdx.x, Nn = m.Nn, S = p0.substeps;
+    const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk], nNb = r.pnbr_cnt[blk];
+    const int *pn = pp.pnodes + (size_t)blk * Mmax;
+    const bool bbm = p0.dynamics_type == NXS_DYN_BBM;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    if (t == 0) lerr = 0;
+
+    // ---- once per step: indices, velocities and frozen coordinates of the staged nodes, this thread's element, this thread's node
+    double *sx = lF, *sy = lF + Mmax;  // (scratch: the corner forces are not needed yet)
+    for (int i = t; i < nM; i += T) {
+        const int g = pn[i];
+        lu[i] = s.VT[g]; lv[i] = s.VT[g + Nn];
+        const d2 c = reinterpret_cast<const d2 *>(w.xy)[g];
+        sx[i] = c.x; sy[i] = c.y;
+    }
+    const bool has_elem = t < nE;
+    int e = 0;
+    bool writer = false, skip = true;
+    ushort4 tr = make_ushort4(0, 0, 0, 0);
+    double sig[3] = {0., 0., 0.}, damage = 0., c_expC = 0., volume = 0., c_pmax = 0., c_heal = 0., c_coh = 0., c_dxs = 1.;
+    if (has_elem) {
+        const int eraw = pp.pelem[(size_t)blk * Emax + t];
+        tr = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + t];
+        writer = eraw >= 0;
+        e = writer ? eraw : ~eraw;
+        const d2 *S4 = reinterpret_cast<const d2 *>(Sc) + 2 * (size_t)e;
+        const d2 a = S4[0], c2 = S4[1];
+        sig[0] = a.x; sig[1] = a.y; sig[2] = c2.x; damage = c2.y;
+        const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
+        const d2 r0 = q[0], r1 = q[1], r2 = q[2];
+        c_expC = r0.x; volume = r0.y; c_pmax = r1.x; c_heal = r1.y; c_coh = r2.x;
+        const long long pk = __double_as_longlong(r2.y);
+        const int dxi = (int)(pk & 0xffffffffll);
+        if (bbm) { skip = dxi < 0; c_dxs = (double)(skip ? ~dxi : dxi) * p0.sqrt_nu_rhoi; }  // FE.cpp:4232
+        else skip = (pk >> 32) != 0;
+    }
+    const bool has_node = t < nO;
+    const int n = has_node ? pn[t] : 0;
+    unsigned char nf = 0;
+    unsigned short fan[8];
+    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fan[k] = (has_node && k < pp.Wp) ? pf[(size_t)k * Pmax + t] : (unsigned short)0xFFFFu;
+    if (has_node) {
+        nf = m.nflags[n];
+        const d2 *q = reinterpret_cast<const d2 *>(w.nrec) + 5 * (size_t)n;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) { const d2 v = q[k]; lN[(size_t)(2 * k) * Pmax + t] = v.x; lN[(size_t)(2 * k + 1) * Pmax + t] = v.y; }
+        lM[t] = s.UM[n]; lM[Pmax + t] = s.UM[n + Nn]; lM[2 * (size_t)Pmax + t] = s.UT[n]; lM[3 * (size_t)Pmax + t] = s.UT[n + Nn];
+    }
+    int nbr = -1;
+    if (t < nNb) nbr = r.pnbr[(size_t)blk * NXS_RES_NBR + t];
+    __syncthreads();
+    if (has_elem) {  // shapeCoeff (FE.cpp:1951-1964): frozen over the sub-steps (Q4), built once, the same quotients as k_prep_elements
+        const double vx[3] = {sx[tr.x], sx[tr.y], sx[tr.z]};
+        const double vy[3] = {sy[tr.x], sy[tr.y], sy[tr.z]};
+        const double jac = jacobian(vx, vy);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+            ldx[(size_t)k * Emax + t] = (vy[kp1] - vy[kp2]) / jac;
+            ldx[(size_t)(k + 3) * Emax + t] = (vx[kp2] - vx[kp1]) / jac;
+        }
+    }
+    __syncthreads();  // (sx / sy are read; lF may be written from here on)
+
+    for (int ss = 0; ss < S; ++ss) {
+        // the parameters are re-read where they are used (scalar loads that hit the constant cache): held across the loop their ~40
+        // values would push the element's own state out of the registers
+        const DevParams *pl = pdev;
+        asm volatile("" : "+s"(pl));
+        const DevParams &p = *pl;
+        // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467)
+        if (has_elem) {
+            double dxN[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) dxN[k] = ldx[(size_t)k * Emax + t];
+            if (skip) {
+                sig[0] = sig[1] = sig[2] = 0.;
+                damage = 0.;
+            } else {
+                const double u[3] = {lu[tr.x], lu[tr.y], lu[tr.z]};
+                const double v[3] = {lv[tr.x], lv[tr.y], lv[tr.z]};
+                if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, c_expC, c_pmax, c_heal, c_dxs, c_coh);
+                else vp_stress(p, dxN, u, v, sig, c_expC);
+            }
+            double F[6];
+            corner_forces(volume, sig, dxN, F);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + t] = F[k];
+        }
+        __syncthreads();
+        const DevParams *pq = pdev;
+        asm volatile("" : "+s"(pq));
+        const DevParams &q = *pq;
+        // ---- node phase (FE.cpp:10445-10553): fan gather in ascending element order, 2x2 solve, mesh move, publish
+        if (has_node) {
+            double uice = lu[t], vice = lv[t];
+            const double node_mass = lN[t];
+            if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
+                double gx = lN[(size_t)Pmax + t], gy = lN[2 * (size_t)Pmax + t];
+                bool more = true;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const unsigned ent = fan[k];
+                    if (!more || ent == 0xFFFFu) { more = false; continue; }
+                    if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
+                    const int l = ent >> 3, c = ent & 3u;
+                    gx -= lF[(size_t)c * Emax + l];
+                    gy -= lF[(size_t)(c + 3) * Emax + l];
+                }
+                for (int k = 8; more && k < pp.Wp; ++k) {
+                    const unsigned ent = pf[(size_t)k * Pmax + t];
+                    if (ent == 0xFFFFu) break;
+                    if (ent & 4u) continue;
+                    const int l = ent >> 3, c = ent & 3u;
+                    gx -= lF[(size_t)c * Emax + l];
+                    gy -= lF[(size_t)(c + 3) * Emax + l];
+                }
+                nodal_solve(q, gx, gy, uice, vice, node_mass, lN[3 * (size_t)Pmax + t], lN[4 * (size_t)Pmax + t], lN[5 * (size_t)Pmax + t],
+                            (nf & NF_LAT_NEG) ? -1. : 1., lN[6 * (size_t)Pmax + t], lN[7 * (size_t)Pmax + t], lN[8 * (size_t)Pmax + t],
+                            lN[9 * (size_t)Pmax + t], 0., 0.);
+            }
+            lu[t] = uice; lv[t] = vice;
+            if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
+                if (!(nf & NF_NEUMANN)) { lM[t] += move_dt * uice; lM[Pmax + t] += move_dt * vice; }
+                lM[2 * (size_t)Pmax + t] += move_dt * uice; lM[3 * (size_t)Pmax + t] += move_dt * vice;
+            }
+            if (ss == S - 1) { s.VT[n] = uice; s.VT[n + Nn] = vice; }
+            else {
+                double *X = (ss & 1) ? r.X1 : r.X0;
+                st_agent(X + n, uice); st_agent(X + n + Nn, vice);
+            }
+        }
+        if (ss == S - 1) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's stores have left; the corner forces have been read
+        if (t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (nbr >= 0) {
+            const long long t0 = wall_clock64();  // 100 MHz
+            while (__hip_atomic_load(r.flag + 32 * (size_t)nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
+                if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 5); break; }  // 2 s
+            }
+        }
+        __syncthreads();
+        if (lerr) break;
+        {   // the halo nodes' new velocities, past the caches
+            const double *X = (ss & 1) ? r.X1 : r.X0;
+            for (int i = nO + t; i < nM; i += T) {
+                const int g = pn[i];
+                lu[i] = ld_agent(X + g); lv[i] = ld_agent(X + g + Nn);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- once per step: the element state and the moved mesh go back
+    if (has_elem && writer) {
+        d2 *S4 = reinterpret_cast<d2 *>(Sn) + 2 * (size_t)e;
+        S4[0] = d2{sig[0], sig[1]}; S4[1] = d2{sig[2], damage};
+    }
+    if (has_node && move_dt != 0.) {
+        if (!(nf & NF_NEUMANN)) { s.UM[n] = lM[t]; s.UM[n + Nn] = lM[Pmax + t]; }
+        s.UT[n] = lM[2 * (size_t)Pmax + t]; s.UT[n + Nn] = lM[3 * (size_t)Pmax + t];
+    }
+}
+
 // Deferred mesh move of the fused path: the fused kernel leaves every sub-step's velocity in a ring of
 // VT buffers; every `count` sub-steps this kernel applies the same sequence of additions
 // M_UM += dte*M_VT, M_UT += dte*M_VT (FE.cpp:10543-10550) for all nodes, owned and ghost -- same

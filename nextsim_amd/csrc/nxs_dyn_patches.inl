@@ -353,6 +353,7 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
 
 int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
     free_pool(h->patch_allocs);
+    h->res_ready = false; h->res_failed = false;  // (its tables lived in this pool)
     DevPatches &d = h->dpch;
     d = DevPatches{};
     d.nP = hp.nP; d.Pmax = hp.Pmax; d.Emax = hp.Emax; d.Mmax = hp.Mmax; d.Wp = hp.Wp;
@@ -369,6 +370,7 @@ int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
 
 int upload_patches(nxs_dyn_handle *h) {
     free_pool(h->patch_allocs);
+    h->res_ready = false; h->res_failed = false;
     h->dpch = DevPatches{};
     h->fused_lds = 0;
     const DevMesh &m = h->dm;

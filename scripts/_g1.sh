@@ -1,3 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-python -m pytest tests -m gpu -x -q > gpurun_out/r2_suite4.log 2>&1; echo "suite rc=$?" ; tail -3 gpurun_out/r2_suite4.log
-python bench.py --steps 20 --warmup 5 > gpurun_out/r2_bench5.json 2> gpurun_out/r2_bench5.err; echo "bench rc=$?"
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "resident" > gpurun_out/r2_res1.log 2>&1; echo "rc=$?"; tail -15 gpurun_out/r2_res1.log

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--mesh", default="2km"); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--torch-first", action="store_true"); ap.add_argument("--graph", type=int, default=1)
-ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=-1); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0); ap.add_argument("--shape-mem", type=int, default=-1)
+ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=-1); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0); ap.add_argument("--shape-mem", type=int, default=-1); ap.add_argument("--compare-fused", type=int, default=-1, help="also run with this value of option fused and compare the states bit for bit")
 a = ap.parse_args()
 if a.torch_first:
     import torch
@@ -26,4 +26,16 @@ t = time.perf_counter()
 for _ in range(a.steps): fe.step()
 fe.synchronize(); dt = time.perf_counter() - t
 print(f"shape_mem={a.shape_mem} ring={a.ring} nt={a.nt} fused={a.fused} patch_nodes={a.patch_nodes} {a.mesh}: {lm.num_elements} triangles, {a.steps} steps, {dt/a.steps*1e3:.3f} ms/step, {lm.num_elements*120*a.steps/dt:.4e} element-updates/s, timing {fe.timing()}, crash {fe.checkFieldsFast()}", flush=True)
+if a.compare_fused >= 0:
+    import numpy as np
+    fe2 = dynamics.FiniteElementDynamics(p); fe2.set_option("fused", a.compare_fused); fe2.set_mesh(lm); fe2.put_state(f); fe2.set_forcing(f)
+    fe3 = dynamics.FiniteElementDynamics(p); fe3.set_option("fused", a.fused); fe3.set_mesh(lm); fe3.put_state(f); fe3.set_forcing(f)
+    for _ in range(2): fe3.step()
+    fe3.synchronize()          # (one after the other: the resident kernel needs the device to itself)
+    for _ in range(2): fe2.step()
+    fe2.synchronize()
+    s2, s3 = fe2.get_state(), fe3.get_state()
+    bad = [k for k in s2 if not np.array_equal(s2[k], s3[k])]
+    print("bitwise fused=%d vs fused=%d after 2 steps:" % (a.fused, a.compare_fused), "IDENTICAL" if not bad else "DIFFERENT in %s" % bad, "launches", fe3.timing()["substep_launches"], fe2.timing()["substep_launches"], flush=True)
+    fe2.close(); fe3.close()
 fe.close()

@@ -482,6 +482,34 @@ def test_shape_coefficients_from_records_or_rebuilt_do_not_change_a_bit(kind, ov
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("kind,over", [("h15600", {}), ("small", {}), ("toy", {"dynamics_type": 3}), ("h15600", {"substeps": 7, "dtime_step": 200. * 7 / 120})])
+def test_resident_sub_step_loop_does_not_change_a_bit(kind, over):
+    """Option fused = 4: ONE launch for the whole sub-step loop, every patch resident on its CU and waiting for its neighbouring
+    patches only (stress, damage and element constants in registers, nodal inputs and the moving mesh in LDS, velocities
+    exchanged through write-through stores and cache-bypassing loads) -- bit for bit the one-kernel-per-sub-step path: 182 k
+    triangles (the size it is meant for: 511 patches, two per CU), a few patches, EVP, an odd number of sub-steps."""
+    a, _, _ = _pair(kind, 2, options={"fused": 1}, **over)
+    b, _, _ = _pair(kind, 2, options={"fused": 4}, **over)
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert b.timing()["substep_launches"] == 1 and a.timing()["substep_launches"] == over.get("substeps", 120)
+    a.close(); b.close()
+
+
+def test_resident_sub_step_loop_falls_back_where_it_cannot_run():
+    """mEVP (its sub-steps need the velocity of the step's start) and meshes whose patches do not fit one round of resident
+    workgroups run one kernel per sub-step although fused = 4 was asked for -- same results, no error."""
+    from nextsim_amd import _abi
+    a, ref, _ = _pair("small", 1, options={"fused": 4}, dynamics_type=_abi.NXS_DYN_MEVP)
+    assert a.timing()["substep_launches"] == 120
+    _assert_close(a.get_state(), ref.arr, ("VT", "sigma0", "sigma1", "sigma2"), 1e-9, "mEVP with fused = 4")
+    a.close()
+    b, _, _ = _pair("h9000", 1, options={"fused": 4})        # ~550 k triangles: several rounds of patches
+    assert b.timing()["substep_launches"] == 120
+    b.close()
+
+
 def test_shuffled_numbering_still_matches_the_oracle():
     """A mesh whose node/element numbering has no locality (random permutation): patches are then cut
     along a Morton curve through the coordinates; results must still match the oracle on that mesh."""
