@@ -1447,22 +1447,32 @@ int build_halo_fused(nxs_dyn_handle *h) {
     return NXS_OK;
 }
 
-// Tables of the resident sub-step kernel: which patches own each patch's halo nodes; the counters; the exchange buffers.
-// NXS_OK with res_ready == false means "not possible here" (the caller then runs one kernel per sub-step).
+// Tables of the resident sub-step kernel: which patches own each patch's halo nodes; the counters; the exchange buffers; with
+// several ranks, which patch moves which ghost node.  NXS_OK with res_ready == false means "not possible here" (the caller then
+// runs one kernel per sub-step).
 int build_resident(nxs_dyn_handle *h) {
     h->res_ready = false;
     if (!h->hp || h->hp->nP != h->dpch.nP) return NXS_OK;
     const HostPatches &hp = *h->hp;
     const int nP = hp.nP, No = h->dm.No, Nn = h->dm.Nn;
-    if (hp.Emax > 512 || hp.Pmax > 512 || No != Nn) { h->res_failed = true; return NXS_OK; }  // one element per thread; single rank for now
+    const bool mr = multi_rank(h);
+    if (hp.Emax > 512 || hp.Pmax > 512 || h->dp.substeps > NXS_RES_MAXS) { h->res_failed = true; return NXS_OK;  }  // one element per thread
     std::vector<int> owner(Nn, -1);
     for (int q = 0; q < nP; ++q)
         for (int i = 0; i < hp.own_cnt[q]; ++i) owner[hp.pnodes[(size_t)q * hp.Mmax + i]] = q;
-    std::vector<int> nbr((size_t)nP * NXS_RES_NBR, -1), cnt(nP, 0);
+    std::vector<int> nbr((size_t)nP * NXS_RES_NBR, -1), cnt(nP, 0), gcnt(nP, 0);
+    std::vector<std::vector<unsigned short>> glist(nP);
+    std::vector<char> ghost_taken(std::max(Nn - No, 1), 0);
     for (int q = 0; q < nP; ++q)
         for (int i = hp.own_cnt[q]; i < hp.node_cnt[q]; ++i) {
-            const int o = owner[hp.pnodes[(size_t)q * hp.Mmax + i]];
-            if (o < 0 || o == q) { h->res_failed = true; return NXS_OK; }  // a staged node nobody solves: not a single-rank patch set
+            const int g = hp.pnodes[(size_t)q * hp.Mmax + i];
+            if (g >= No) {  // a ghost node (several ranks): it comes from the mailbox; the first patch that stages it moves it
+                if (!mr) { h->res_failed = true; return NXS_OK; }
+                if (!ghost_taken[g - No]) { ghost_taken[g - No] = 1; glist[q].push_back((unsigned short)i); }
+                continue;
+            }
+            const int o = owner[g];
+            if (o < 0 || o == q) { h->res_failed = true; return NXS_OK; }  // a staged node nobody solves
             int *row = nbr.data() + (size_t)q * NXS_RES_NBR;
             bool have = false;
             for (int k = 0; k < cnt[q]; ++k) have = have || row[k] == o;
@@ -1470,12 +1480,20 @@ int build_resident(nxs_dyn_handle *h) {
             if (cnt[q] == NXS_RES_NBR) { h->res_failed = true; return NXS_OK; }
             row[cnt[q]++] = o;
         }
-    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax) * sizeof(double);
+    for (int g = No; g < Nn; ++g) if (!ghost_taken[g - No]) { h->res_failed = true; return NXS_OK; }  // a ghost node no patch stages
+    int Gmax = 1;
+    for (int q = 0; q < nP; ++q) { gcnt[q] = (int)glist[q].size(); Gmax = std::max(Gmax, gcnt[q]); }
+    if (Gmax > 512) { h->res_failed = true; return NXS_OK; }
+    std::vector<unsigned short> gslot((size_t)nP * Gmax, 0);
+    for (int q = 0; q < nP; ++q) std::copy(glist[q].begin(), glist[q].end(), gslot.begin() + (size_t)q * Gmax);
+    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 4 * (size_t)Gmax) * sizeof(double);
     // every workgroup must be resident at once
     int per_cu = 0, cus = 0;
-    hipError_t e = h->dp.ers_int == 4
-        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true>, 512, h->res_lds)
-        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false>, 512, h->res_lds);
+    const bool p4 = h->dp.ers_int == 4;
+    hipError_t e = mr ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true>, 512, h->res_lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, true>, 512, h->res_lds))
+                      : (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, false>, 512, h->res_lds)
+                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, false>, 512, h->res_lds));
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     if (e != hipSuccess || (long long)per_cu * cus < nP) {
         (void)hipGetLastError();
@@ -1488,13 +1506,18 @@ int build_resident(nxs_dyn_handle *h) {
     r = DevResident{};
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr, nbr))) return rc;
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr_cnt, cnt))) return rc;
-    if ((rc = dev_alloc(h, h->patch_allocs, &r.flag, 32 * (size_t)nP))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &r.gslot, gslot))) return rc;
+    if ((rc = dev_upload(h, h->patch_allocs, &r.gcnt, gcnt))) return rc;
+    r.Gmax = Gmax;
+    if ((rc = dev_alloc(h, h->patch_allocs, &r.flag, 32 * (size_t)nP + NXS_RES_MAXS + 32))) return rc;  // counters behind the flags: one memset per launch
+    r.cnt = r.flag + 32 * (size_t)nP;
+    r.raised = r.cnt + NXS_RES_MAXS;
     if ((rc = dev_alloc(h, h->patch_allocs, &r.error, 1))) return rc;
     HIPCHK(h, hipMemsetAsync(r.error, 0, sizeof(int), h->stream));
     if (!h->d_vt3 && (rc = dev_alloc(h, h->state_allocs, &h->d_vt3, 2 * (size_t)Nn))) return rc;
     r.X0 = h->ds.VT2; r.X1 = h->d_vt3;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] resident kernel: %d patches (%d x %d fit), %zu B of LDS each, up to %d neighbours\n", nP, per_cu, cus, h->res_lds, *std::max_element(cnt.begin(), cnt.end()));
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %d patches (%d x %d fit), %zu B of LDS each, up to %d neighbour patches, up to %d ghosts moved per patch\n", h->rank, nP, per_cu, cus, h->res_lds, *std::max_element(cnt.begin(), cnt.end()), Gmax);
     h->res_ready = true;
     return NXS_OK;
 }
@@ -1564,22 +1587,25 @@ int run_substeps(nxs_dyn_handle *h) {
     // or no move at all (mEVP)
     const bool halo_in_kernel = device_halo && fused && h->halo_fused && (deferred || move_dt == 0.);
     if (halo_in_kernel && !h->hf_ready) { int rc = build_halo_fused(h); if (rc) return rc; }
-    if (halo_in_kernel && h->d_hf_dirty) {  // (outside any stream capture)
+    // v4: resident sub-step loop (opt-in).  Several ranks: only with the exchange inside the kernels (device-direct mailboxes).
+    const bool res_wanted = h->fused == 4 && !h->trace_branches && !pair && move_dt != 0. && (!mr || (device_halo && h->halo_fused));
+    if (res_wanted && mr && !h->hf_ready) { int rc = build_halo_fused(h); if (rc) return rc; }  // (re-uploads the patches boundary-first)
+    if (res_wanted && !h->res_ready && !h->res_failed) {  // (outside any capture)
+        int rcr = build_resident(h);
+        if (rcr) return rcr;
+    }
+    const bool resident = res_wanted && h->res_ready && !h->res_failed;
+    if ((halo_in_kernel || (resident && mr)) && h->d_hf_dirty) {  // (outside any stream capture)
         HaloFused tmp = h->hf;
         tmp.ipc = h->ipc;
         HIPCHK(h, hipMemcpyAsync(h->d_hf, &tmp, sizeof tmp, hipMemcpyHostToDevice, h->stream));
         HIPCHK(h, hipStreamSynchronize(h->stream));  // tmp leaves scope
         h->d_hf_dirty = false;
     }
-    if (h->fused == 4 && !h->trace_branches && !mr && !pair && move_dt != 0. && !h->res_ready && !h->res_failed) {  // (outside any capture)
-        int rcr = build_resident(h);
-        if (rcr) return rcr;
-    }
-    const bool resident = h->fused == 4 && !h->trace_branches && !mr && !pair && move_dt != 0. && h->res_ready && !h->res_failed;
     const bool records_end_odd = resident ? false : (pair ? ((S / D) & 1) : (S & 1));
     // with the deferred mesh move the last flush of the step reads the newest velocity anyway and puts it back into M_VT itself; the
     // ring slot it came from then equals M_VT and serves the smoother as its second buffer (no copy before the sweeps)
-    double *const vt_back = (deferred && (S % R) != 0) ? h->ds.VT : nullptr;
+    double *const vt_back = (deferred && !resident && (S % R) != 0) ? h->ds.VT : nullptr;
     h->smooth_second = vt_back ? h->ring.slot[S % R] : nullptr;
     auto pull_latest = [&](double *vec) {
         const int tr = h->recv_offsets[h->recv_procs.size()];
@@ -1587,11 +1613,21 @@ int run_substeps(nxs_dyn_handle *h) {
                            h->d_recv_seg, h->d_recv_off, h->ipc, 0., 0, h->d_recv_procs, 1);
     };
     auto loop = [&]() -> int {
-        if (resident) {  // the whole loop in one launch; the element state goes from S4a to S4b, then back into S4a's role by a copy
-            HIPCHK(h, hipMemsetAsync(h->res.flag, 0, 32 * (size_t)h->dpch.nP * sizeof(unsigned int), h->stream));
+        if (resident) {  // the whole loop in one launch; the element state is read from and written back to S4a (each record by its one writer)
+            HIPCHK(h, hipMemsetAsync(h->res.flag, 0, (32 * (size_t)h->dpch.nP + NXS_RES_MAXS + 32) * sizeof(unsigned int), h->stream));
             const dim3 grid(h->dpch.nP);
-            if (h->dp.ers_int == 4) hipLaunchKernelGGL((k_substep_resident<512, true>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt);
-            else hipLaunchKernelGGL((k_substep_resident<512, false>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt);
+            const bool p4 = h->dp.ers_int == 4;
+#define RESIDENT(PP, HH, HFP, NB) hipLaunchKernelGGL((k_substep_resident<512, PP, HH>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, HFP, NB)
+            if (mr) {
+                if (p4) RESIDENT(true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary); else RESIDENT(false, true, (const HaloFused *)h->d_hf, h->hf.n_boundary);
+                // the exchange of the last sub-step: the ghosts land in M_VT and make their last move (the earlier ones were made in the kernel)
+                const int tr = h->recv_offsets[h->recv_procs.size()];
+                hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, h->ds.VT, h->dm, h->ds, tr, h->d_recv_index,
+                                   h->d_recv_seg, h->d_recv_off, h->ipc, move_dt, 0, h->d_recv_procs, 1);
+            } else {
+                if (p4) RESIDENT(true, false, (const HaloFused *)nullptr, 0); else RESIDENT(false, false, (const HaloFused *)nullptr, 0);
+            }
+#undef RESIDENT
             return NXS_OK;
         }
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT

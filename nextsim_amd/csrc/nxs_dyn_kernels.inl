@@ -1219,7 +1219,14 @@ struct DevResident {
     unsigned int *flag;    // [nP * 32] sub-steps published by each patch (one counter per 128-byte line; zeroed before every launch)
     double *X0, *X1;       // [2 Nn] exchange buffers: velocities after an even / an odd sub-step
     int *error;            // != 0: a wait timed out (the workgroups were not all resident): the step is lost, nobody waits again
+    // several ranks (the device-direct mailboxes of HaloFused inside the resident loop):
+    unsigned int *cnt;     // [NXS_RES_MAXS] boundary patches that have finished each sub-step (zeroed before every launch)
+    unsigned int *raised;  // [1] sub-steps whose exchange has been published to the neighbour ranks (keeps the flags monotone)
+    const unsigned short *gslot;  // [nP][Gmax] staged slots of the ghost nodes whose M_UM / M_UT this patch moves (each ghost: one patch)
+    const int *gcnt;       // [nP]
+    int Gmax;
 };
+#define NXS_RES_MAXS 512
 
 __device__ __forceinline__ void st_agent(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1228,19 +1235,34 @@ __device__ __forceinline__ double ld_agent(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-template <int T, bool POW4>
+// HALO: several ranks.  Boundary patches (they lead the grid, see HaloFused) also send their sent nodes into the neighbour ranks'
+// mailboxes in the node phase (exchange x0 + s, half (x0 + s) & 1), read their ghost nodes from this rank's mailbox before the next
+// element phase -- after the neighbours' flags have reached x0 + s + 1 -- and move the ghost nodes assigned to them; the last
+// boundary patch to finish a sub-step raises this rank's flag at the neighbours, in sub-step order.  The exchange of the LAST
+// sub-step is taken by k_halo_pull after the launch (with the last mesh move of the ghosts), as in the one-launch-per-sub-step path.
+template <int T, bool POW4, bool HALO>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
-                                                        const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt) {
+                                                        const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
+                                                        const HaloFused *__restrict__ hfp, int n_boundary) {
     const DevParams &p0 = *pdev;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int Mmax = pp.Mmax, Emax = pp.Emax, Pmax = pp.Pmax;
     double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*[6][Emax]*/, *ldx = lF + 6 * (size_t)Emax /*[6][Emax]*/,
-           *lN = ldx + 6 * (size_t)Emax /*[10][Pmax]*/, *lM = lN + 10 * (size_t)Pmax /*[4][Pmax]*/;
+           *lN = ldx + 6 * (size_t)Emax /*[10][Pmax]*/, *lM = lN + 10 * (size_t)Pmax /*[4][Pmax]*/, *lG = lM + 4 * (size_t)Pmax /*[4][Gmax]*/;
     __shared__ int lerr;
-    int blk;
-    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
-        const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, rr = n & 7, x = pos & 7;
-        blk = (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (pos >> 3);
+    auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
+        const int q = n >> 3, rr = n & 7, x = pos & 7;
+        return (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (pos >> 3);
+    };
+    int blk = blockIdx.x;
+    bool boundary = false;
+    unsigned long long x0 = 0ull;
+    if (HALO) {
+        boundary = blk < n_boundary;
+        if (boundary) x0 = *hfp->ipc.seq_push;  // exchanges this rank has published so far; changed only after every boundary patch has finished
+        blk = boundary ? xcd_remap(blk, n_boundary) : n_boundary + xcd_remap(blk - n_boundary, (int)gridDim.x - n_boundary);
+    } else {
+        blk = xcd_remap(blk, (int)gridDim.x);
     }
     const int t = threadIdx.x, Nn = m.Nn, S = p0.substeps;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk], nNb = r.pnbr_cnt[blk];
@@ -1294,6 +1316,18 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
     int nbr = -1;
     if (t < nNb) nbr = r.pnbr[(size_t)blk * NXS_RES_NBR + t];
+    // ghost nodes this patch moves (HALO): their running M_UM / M_UT in LDS like the own nodes'
+    const int nG = HALO ? r.gcnt[blk] : 0;
+    int gsl = 0, gnode = 0;
+    unsigned char gnf = 0;
+    if (HALO && t < nG) {
+        gsl = r.gslot[(size_t)blk * r.Gmax + t];
+        gnode = pn[gsl];
+        gnf = m.nflags[gnode];
+        lG[t] = s.UM[gnode]; lG[r.Gmax + t] = s.UM[gnode + Nn]; lG[2 * (size_t)r.Gmax + t] = s.UT[gnode]; lG[3 * (size_t)r.Gmax + t] = s.UT[gnode + Nn];
+    }
+    int sq0 = 0, sq1 = 0;
+    if (HALO && boundary && has_node) { sq0 = hfp->send_ptr[n]; sq1 = hfp->send_ptr[n + 1]; }
     __syncthreads();
     if (has_elem) {  // shapeCoeff (FE.cpp:1951-1964): frozen over the sub-steps (Q4), built once, the same quotients as k_prep_elements
         const double vx[3] = {sx[tr.x], sx[tr.y], sx[tr.z]};
@@ -1375,11 +1409,45 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 double *X = (ss & 1) ? r.X1 : r.X0;
                 st_agent(X + n, uice); st_agent(X + n + Nn, vice);
             }
+            if (HALO) {  // updateGhosts, sending side: straight into the neighbour ranks' mailboxes (as k_substep_fused)
+                for (int qq = sq0; qq < sq1; ++qq) {
+                    const int k = hfp->send_k[qq];
+                    double *dst = hfp->ipc.peer_seg[k] + ((x0 + (unsigned long long)ss) & 1ull) * hfp->ipc.peer_parity_stride[k] + hfp->send_pos[qq];
+                    sys_store(dst, uice);
+                    sys_store(dst + (hfp->send_off[k + 1] - hfp->send_off[k]), vice);
+                }
+            }
         }
-        if (ss == S - 1) break;
+        if (!HALO && ss == S - 1) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // every wave's stores have left; the corner forces have been read
+        if (HALO && boundary && t == 0) {
+            // the last boundary patch to finish this sub-step publishes it to the neighbour ranks -- in sub-step order: patches far
+            // apart may be several sub-steps apart, so the one that completes sub-step ss waits for ss - 1 to have been published
+            if (atomicAdd(r.cnt + ss, 1u) == (unsigned)n_boundary - 1u) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ss) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
+                }
+                __threadfence_system();  // the one release of the sub-step
+                for (int k = 0; k < hfp->ipc.ns; ++k)
+                    __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (ss == S - 1) *hfp->ipc.seq_push = x0 + (unsigned long long)S;
+                __hip_atomic_store(r.raised, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (ss == S - 1) break;
         if (t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (HALO && boundary && t >= 64 && t < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
+            const int k = t - 64;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x0 + (unsigned long long)ss + 1ull) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
+                if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 7); break; }  // 2 s
+            }
+        }
         if (nbr >= 0) {
             const long long t0 = wall_clock64();  // 100 MHz
             while (__hip_atomic_load(r.flag + 32 * (size_t)nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
@@ -1394,10 +1462,20 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const double *X = (ss & 1) ? r.X1 : r.X0;
             for (int i = nO + t; i < nM; i += T) {
                 const int g = pn[i];
-                lu[i] = ld_agent(X + g); lv[i] = ld_agent(X + g + Nn);
+                if (HALO && g >= m.No) {  // a ghost node: from this rank's mailbox, past the caches
+                    const double *src = hfp->ipc.mailbox + ((x0 + (unsigned long long)ss) & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr + hfp->ghost_off[g - m.No];
+                    lu[i] = sys_load(src); lv[i] = sys_load(src + hfp->ghost_srl[g - m.No]);
+                } else {
+                    lu[i] = ld_agent(X + g); lv[i] = ld_agent(X + g + Nn);
+                }
             }
         }
         __syncthreads();
+        if (HALO && t < nG && move_dt != 0.) {  // the ghosts' mesh move with the velocity that has just arrived (FE.cpp:10543-10550)
+            const double gu = lu[gsl], gv = lv[gsl];
+            if (!(gnf & NF_NEUMANN)) { lG[t] += move_dt * gu; lG[r.Gmax + t] += move_dt * gv; }
+            lG[2 * (size_t)r.Gmax + t] += move_dt * gu; lG[3 * (size_t)r.Gmax + t] += move_dt * gv;
+        }
     }
     // ---- once per step: the element state and the moved mesh go back
     if (has_elem && writer) {
@@ -1407,6 +1485,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (has_node && move_dt != 0.) {
         if (!(nf & NF_NEUMANN)) { s.UM[n] = lM[t]; s.UM[n + Nn] = lM[Pmax + t]; }
         s.UT[n] = lM[2 * (size_t)Pmax + t]; s.UT[n + Nn] = lM[3 * (size_t)Pmax + t];
+    }
+    if (HALO && t < nG && move_dt != 0.) {
+        if (!(gnf & NF_NEUMANN)) { s.UM[gnode] = lG[t]; s.UM[gnode + Nn] = lG[r.Gmax + t]; }
+        s.UT[gnode] = lG[2 * (size_t)r.Gmax + t]; s.UT[gnode + Nn] = lG[3 * (size_t)r.Gmax + t];
     }
 }
 

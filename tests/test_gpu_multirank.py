@@ -232,3 +232,21 @@ def test_ipc_connect_checks_its_tables_against_what_the_neighbour_published():
     assert errs[0].value == 0 and errs[1].value == 0
     for fe in fes:
         fe.close()
+
+
+@pytest.mark.parametrize("world,kind,rpp,over", [(2, "small", 1, {}), (3, "small", 1, {"ragged_seed": 1}), (3, "small", 1, {"dynamics_type": 3}),
+                                                 (8, "10km", 2, {})])
+def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rpp, over, tmp_path):
+    """Option fused = 4 on several ranks: ONE launch per rank for the whole sub-step loop; boundary patches send into the
+    neighbour ranks' mailboxes and read their ghosts from their own once per sub-step, the last boundary patch of a sub-step
+    raises the flags (in sub-step order although patches far apart may be several sub-steps apart), ghost nodes are moved by
+    the patch that stages them first.  Bitwise equal to separate push / pull kernels around one kernel per sub-step, and within
+    1e-10 of the multi-rank oracle.  (The meshes are small enough for every rank's workgroups to be resident on ONE device.)"""
+    reps = _run(world, kind, 1, tmp_path, "ipc", over=dict(over, options={"fused": 4}), ranks_per_proc=rpp)
+    for r in reps:
+        assert r["ok"], r
+        assert r["fused_equals_separate"] is True, r
+        assert r["launches_fused"] == 1, r
+        assert r["crash"] == 0
+        for k, e in r["errs"].items():
+            assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
