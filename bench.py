@@ -88,7 +88,7 @@ def ice_cover(f):
     return {"ice_free_fraction": float((c == 0).mean()), "low_concentration_fraction": float(((c > 0) & (c <= 0.1)).mean())}
 
 
-def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, state="arctic"):
+def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, state="arctic", own_device=False):
     from nextsim_amd import dynamics
     gm, p, lm, f = build_case(kind, world, rank, state)
     fe = dynamics.FiniteElementDynamics(p, device=local_rank)
@@ -99,7 +99,7 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
     fe.put_state(f)
     fe.set_forcing(f)
     if transport.startswith("device-direct"):
-        transport += choose_halo_kernels(fe, f, rank, world, dist, torch)
+        transport += choose_halo_kernels(fe, f, rank, world, dist, torch, own_device)
         fe.put_state(f)
 
     def barrier():
@@ -126,63 +126,69 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
     return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash, transport=transport)  # (f: rank-local fields)
 
 
-def choose_halo_kernels(fe, f, rank, world, dist, torch):
-    """The device-direct exchange can run inside the fused sub-step kernel (one launch per sub-step) or as separate
-    push / pull kernels.  The in-kernel variant is kept only if, on this machine and this partition, one full step
-    gives the bits of the separate kernels on every rank (NXS_HALO_FUSED=0/1 forces a choice)."""
+def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
+    """How updateGhosts runs over the device-direct mailboxes: (a) inside ONE resident launch per step (option fused = 4: needs the
+    device to itself, so only tried when every rank has its own GPU), (b) inside one launch per sub-step, (c) as separate push / pull
+    kernels.  Each candidate runs one full step on this machine and this partition; a candidate is kept only if it gives, on every
+    rank, the bits of (c), and the fastest of those is used (NXS_HALO_VARIANT=resident|inkernel|separate forces one)."""
     import numpy as np
     from nextsim_amd import dynamics
-    force = os.environ.get("NXS_HALO_FUSED")
-    if force is not None:
-        fe.set_option("halo_fused", int(force))
-        return " + exchange inside the sub-step kernel (forced)" if int(force) else ", separate push/pull kernels (forced)"
+    variants = {"resident": (4, 1, " + exchange inside ONE resident launch per step"), "inkernel": (3, 1, " + exchange inside the sub-step kernel"),
+                "separate": (3, 0, ", separate push/pull kernels")}
+    force = os.environ.get("NXS_HALO_VARIANT")
+    if force in variants:
+        fe.set_option("fused", variants[force][0]); fe.set_option("halo_fused", variants[force][1])
+        return variants[force][2] + " (forced)"
+
     def agree(flag):   # every rank calls this the same number of times, whatever happened to it
         t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return float(t[0]) == 1.0
 
-    states, secs, good = [], [0.0, 0.0], True
-    for i, mode in enumerate((1, 0)):
-        mine = True
-        try:
-            fe.set_option("halo_fused", mode)
-            fe.put_state(f)
-            fe.step(); fe.synchronize()           # (graph capture happens here)
-            states.append(fe.get_state())
-        except dynamics.NxsError as e:
-            print(f"[bench rank {rank}] halo_fused={mode}: {e}", file=sys.stderr, flush=True)
-            mine = False
-        if not agree(mine):
-            good = False
-            break
-        t0 = time.perf_counter()
-        try:
-            fe.step(); fe.step(); fe.synchronize()
-        except dynamics.NxsError as e:
-            print(f"[bench rank {rank}] halo_fused={mode}: {e}", file=sys.stderr, flush=True)
-            mine = False
-        secs[i] = time.perf_counter() - t0
-        if not agree(mine):
-            good = False
-            break
-    if good:
-        good = agree(all(np.array_equal(states[0][k], states[1][k]) for k in states[0]))
-    if good:
-        tt = torch.tensor(secs, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        inside = float(tt[0]) <= float(tt[1])
-        fe.set_option("halo_fused", 1 if inside else 0)
-        note = f"both variants bit-identical; {float(tt[0])*500:.2f} vs {float(tt[1])*500:.2f} ms/step in-kernel vs separate"
-        return (" + exchange inside the sub-step kernel (" if inside else ", separate push/pull kernels (") + note + ")"
-    # a rank that timed out is out of step with its neighbours: fresh mailboxes, then the separate kernels
-
     def all_gather(obj):
         out = [None] * world
         dist.all_gather_object(out, obj)
         return out
-    fe.ipc_setup(all_gather)
-    fe.set_option("halo_fused", 0)
-    return ", separate push/pull kernels (in-kernel exchange failed its check)"
+
+    # (NXS_BENCH_TRY_RESIDENT=1: rehearsal on a shared device with a mesh small enough for every rank's workgroups to be resident)
+    order = (["resident"] if (own_device or os.environ.get("NXS_BENCH_TRY_RESIDENT") == "1") else []) + ["inkernel", "separate"]
+    results = {}
+    for name in order:
+        fused, halo_fused, _ = variants[name]
+        mine, state, secs = True, None, 0.0
+        try:
+            fe.set_option("fused", fused); fe.set_option("halo_fused", halo_fused)
+            fe.put_state(f)
+            fe.step(); fe.synchronize()           # (graph capture happens here)
+            state = fe.get_state()
+            t0 = time.perf_counter()
+            fe.step(); fe.step(); fe.synchronize()
+            secs = time.perf_counter() - t0
+            if name == "resident" and fe.timing()["substep_launches"] != 1:
+                mine = False                       # the library fell back (partition too large for one round of workgroups)
+        except dynamics.NxsError as e:
+            print(f"[bench rank {rank}] halo variant {name}: {e}", file=sys.stderr, flush=True)
+            mine = False
+        if agree(mine):
+            tt = torch.tensor([secs], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            results[name] = (state, float(tt[0]))
+        else:
+            # a rank that timed out is out of step with its neighbours: fresh mailboxes before the next candidate
+            fe.set_option("fused", 3)
+            fe.ipc_setup(all_gather)
+    fe.set_option("fused", 3)
+    if "separate" not in results:
+        fe.set_option("halo_fused", 0)
+        return ", separate push/pull kernels (its own check step failed on some rank: see stderr)"
+    ref = results["separate"][0]
+    ok = {n: agree(all(np.array_equal(st[k], ref[k]) for k in ref)) for n, (st, _) in results.items()}
+    good = [n for n in order if n in results and ok[n]]
+    best = min(good, key=lambda n: results[n][1])
+    fe.set_option("fused", variants[best][0]); fe.set_option("halo_fused", variants[best][1])
+    note = "; ".join(f"{n} {results[n][1] * 500:.2f} ms/step" + ("" if ok[n] else " (bits differ: rejected)") for n in order if n in results)
+    dropped = [n for n in order if n not in results]
+    return variants[best][2] + f" (kept variants bit-identical to the separate kernels; {note}" + (f"; failed: {', '.join(dropped)}" if dropped else "") + ")"
 
 
 def setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn):
@@ -406,17 +412,17 @@ def main():
             dist.broadcast_object_list(ids, src=0)
             return ids[0]
 
-    res = run_gpu(args.mesh, args, rank, world, local_rank, dist, torch, unique_id_fn)
-    gm, p, lm, tm = res["gm"], res["p"], res["lm"], res["timing"]
-    S = p.substeps
-    value = gm.num_elements * S * args.steps / res["dt"]
-    # which physical devices the ranks really ran on (a test box may wrap several ranks onto one GPU: its numbers then bound the
+    # which physical devices the ranks really run on (a test box may wrap several ranks onto one GPU: its numbers then bound the
     # protocol overhead, they are not a scaling measurement)
     devices = [local_rank]
     if world > 1:
         devices = [None] * world
         dist.all_gather_object(devices, (os.environ.get("GROUP_RANK", "0"), local_rank))
     distinct_devices = len(set(devices))
+    res = run_gpu(args.mesh, args, rank, world, local_rank, dist, torch, unique_id_fn, own_device=distinct_devices == world)
+    gm, p, lm, tm = res["gm"], res["p"], res["lm"], res["timing"]
+    S = p.substeps
+    value = gm.num_elements * S * args.steps / res["dt"]
 
     # roofline of the dominant kernel(s): the sub-step loop (sigma/damage + assembly + nodal solve)
     launches_per_substep = max(tm["substep_launches"] // S, 1)
@@ -449,8 +455,8 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve + mesh move)"
-                      if launches_per_substep == 1 else f"sub-step loop ({launches_per_substep} launches per sub-step incl. halo pack/unpack)",
+            "kernel": "k_substep_resident (ONE launch per step: the fused sub-step loop, patches waiting for their neighbours only)" if tm["substep_launches"] == 1
+                      else "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve + mesh move)" if launches_per_substep == 1 else f"sub-step loop ({launches_per_substep} launches per sub-step incl. halo pack/unpack)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
