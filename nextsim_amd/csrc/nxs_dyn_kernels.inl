@@ -1348,6 +1348,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const DevParams *pl = pdev;
         asm volatile("" : "+s"(pl));
         const DevParams &p = *pl;
+#ifdef NXS_PHASE_TIMING
+#define RSTAMP(k) do { if (ss == 60 && threadIdx.x == 0 && blk < 8192) g_phase_t[8 * blk + (k)] = wall_clock64(); } while (0)
+#else
+#define RSTAMP(k) do { } while (0)
+#endif
+        RSTAMP(0);
         // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467)
         if (has_elem) {
             double dxN[6];
@@ -1368,6 +1374,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + t] = F[k];
         }
         __syncthreads();
+        RSTAMP(1);
         const DevParams *pq = pdev;
         asm volatile("" : "+s"(pq));
         const DevParams &q = *pq;
@@ -1419,8 +1426,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
         }
         if (!HALO && ss == S - 1) break;
+        RSTAMP(2);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // every wave's stores have left; the corner forces have been read
+        RSTAMP(3);
         if (HALO && boundary && t == 0) {
             // the last boundary patch to finish this sub-step publishes it to the neighbour ranks -- in sub-step order: patches far
             // apart may be several sub-steps apart, so the one that completes sub-step ss waits for ss - 1 to have been published
@@ -1457,6 +1466,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
         }
         __syncthreads();
+        RSTAMP(4);
         if (lerr) break;
         {   // the halo nodes' new velocities, past the caches
             const double *X = (ss & 1) ? r.X1 : r.X0;
@@ -1471,6 +1481,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
         }
         __syncthreads();
+        RSTAMP(5);
         if (HALO && t < nG && move_dt != 0.) {  // the ghosts' mesh move with the velocity that has just arrived (FE.cpp:10543-10550)
             const double gu = lu[gsl], gv = lv[gsl];
             if (!(gnf & NF_NEUMANN)) { lG[t] += move_dt * gu; lG[r.Gmax + t] += move_dt * gv; }

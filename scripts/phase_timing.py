@@ -5,7 +5,7 @@
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true"); ap.add_argument("--resident", action="store_true")
 a = ap.parse_args()
 csrc = os.path.join(ROOT, "nextsim_amd", "csrc")
 if a.build:
@@ -21,9 +21,19 @@ p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.
 g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
 lm = M.localize(gm, 1)[0]; f = F.localize_fields(g, lm, gm.num_nodes)
 fe = dynamics.FiniteElementDynamics(p); fe.set_option("graph", 0)
+if a.resident: fe.set_option("fused", 4)
 fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
 fe.step(); fe.step(); fe.synchronize()
 t = fe.debug_array("phase_times")
+if a.resident:  # k_substep_resident, sub-step 60 of the launch: start of the element phase, barrier 1, end of the node phase, stores drained + barrier, neighbours' counters seen, halo loaded
+    t = t.reshape(8192, 8)[:, :6]
+    t = t[t[:, 0] > 0]
+    d = np.diff(t, axis=1) * 10e-3
+    print(f"{gm.num_elements} triangles, {t.shape[0]} workgroups, sub-step 60 of the resident launch; spread of the workgroups' start of that sub-step {(t[:, 0].max() - t[:, 0].min()) * 10e-3:.2f} us")
+    for nm, col in zip(("element phase (to barrier 1)", "node phase + publishing stores issued", "stores drained + barrier", "wait for the neighbours' counters + barrier", "halo loads + barrier"), d.T):
+        print(f"  {nm:45s} mean {col.mean():6.2f} us   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
+    print(f"  one sub-step                                  mean {(t[:, 5] - t[:, 0]).mean():6.2f} us")
+    fe.close(); sys.exit(0)
 if a.multi:  # k_substep_multi (small single-rank meshes), D = 4: start, barrier 1, forces of sub-step 0, end of sub-steps 0..3
     t = t.reshape(8192, 8)[:, :7]
     t = t[t[:, 0] > 0]
