@@ -1249,6 +1249,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const int Mmax = pp.Mmax, Emax = pp.Emax, Pmax = pp.Pmax;
     double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*[6][Emax]*/, *ldx = lF + 6 * (size_t)Emax /*[6][Emax]*/,
            *lN = ldx + 6 * (size_t)Emax /*[10][Pmax]*/, *lM = lN + 10 * (size_t)Pmax /*[4][Pmax]*/, *lG = lM + 4 * (size_t)Pmax /*[4][Gmax]*/;
+    unsigned short *lFan = reinterpret_cast<unsigned short *>(lG + 4 * (size_t)r.Gmax);  // [8][Pmax] the first eight fan entries of every own node
     __shared__ int lerr;
     auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
         const int q = n >> 3, rr = n & 7, x = pos & 7;
@@ -1283,7 +1284,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     int e = 0;
     bool writer = false, skip = true;
     ushort4 tr = make_ushort4(0, 0, 0, 0);
-    double sig[3] = {0., 0., 0.}, damage = 0., c_expC = 0., volume = 0., c_pmax = 0., c_heal = 0., c_coh = 0., c_dxs = 1.;
+    double sig[3] = {0., 0., 0.}, damage = 0.;
     if (has_elem) {
         const int eraw = pp.pelem[(size_t)blk * Emax + t];
         tr = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + t];
@@ -1292,21 +1293,17 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const d2 *S4 = reinterpret_cast<const d2 *>(Sc) + 2 * (size_t)e;
         const d2 a = S4[0], c2 = S4[1];
         sig[0] = a.x; sig[1] = a.y; sig[2] = c2.x; damage = c2.y;
-        const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
-        const d2 r0 = q[0], r1 = q[1], r2 = q[2];
-        c_expC = r0.x; volume = r0.y; c_pmax = r1.x; c_heal = r1.y; c_coh = r2.x;
-        const long long pk = __double_as_longlong(r2.y);
-        const int dxi = (int)(pk & 0xffffffffll);
-        if (bbm) { skip = dxi < 0; c_dxs = (double)(skip ? ~dxi : dxi) * p0.sqrt_nu_rhoi; }  // FE.cpp:4232
-        else skip = (pk >> 32) != 0;
+        const long long pk = __double_as_longlong(w.erec[6 * (size_t)e + 5]);
+        skip = bbm ? (int)(pk & 0xffffffffll) < 0 : (pk >> 32) != 0;
     }
     const bool has_node = t < nO;
     const int n = has_node ? pn[t] : 0;
     unsigned char nf = 0;
-    unsigned short fan[8];
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
+    if (has_node) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) fan[k] = (has_node && k < pp.Wp) ? pf[(size_t)k * Pmax + t] : (unsigned short)0xFFFFu;
+        for (int k = 0; k < 8; ++k) lFan[(size_t)k * Pmax + t] = (k < pp.Wp) ? pf[(size_t)k * Pmax + t] : (unsigned short)0xFFFFu;
+    }
     if (has_node) {
         nf = m.nflags[n];
         const d2 *q = reinterpret_cast<const d2 *>(w.nrec) + 5 * (size_t)n;
@@ -1326,8 +1323,6 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         gnf = m.nflags[gnode];
         lG[t] = s.UM[gnode]; lG[r.Gmax + t] = s.UM[gnode + Nn]; lG[2 * (size_t)r.Gmax + t] = s.UT[gnode]; lG[3 * (size_t)r.Gmax + t] = s.UT[gnode + Nn];
     }
-    int sq0 = 0, sq1 = 0;
-    if (HALO && boundary && has_node) { sq0 = hfp->send_ptr[n]; sq1 = hfp->send_ptr[n + 1]; }
     __syncthreads();
     if (has_elem) {  // shapeCoeff (FE.cpp:1951-1964): frozen over the sub-steps (Q4), built once, the same quotients as k_prep_elements
         const double vx[3] = {sx[tr.x], sx[tr.y], sx[tr.z]};
@@ -1343,6 +1338,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     __syncthreads();  // (sx / sy are read; lF may be written from here on)
 
     for (int ss = 0; ss < S; ++ss) {
+        // (the thread index through an opaque copy: otherwise every LDS address of the loop body -- some forty of them -- is computed
+        // once before the loop and kept in a register of its own across all the sub-steps)
+        int tt = t;
+        asm volatile("" : "+v"(tt));
         // the parameters are re-read where they are used (scalar loads that hit the constant cache): held across the loop their ~40
         // values would push the element's own state out of the registers
         const DevParams *pl = pdev;
@@ -1356,9 +1355,19 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         RSTAMP(0);
         // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467)
         if (has_elem) {
+            // the element constants: one 48-byte record, re-read every sub-step (it stays in the L2; the loads were issued ahead of
+            // the barrier above) -- held in registers across the loop they pushed 36 others out to scratch
+            double c_expC, volume, c_pmax, c_heal, c_coh, c_dxs = 1.;
+            {
+                const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
+                const d2 r0 = q[0], r1 = q[1], r2 = q[2];
+                c_expC = r0.x; volume = r0.y; c_pmax = r1.x; c_heal = r1.y; c_coh = r2.x;
+                const int dxi = (int)(__double_as_longlong(r2.y) & 0xffffffffll);
+                if (bbm) c_dxs = (double)(dxi < 0 ? ~dxi : dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
+            }
             double dxN[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) dxN[k] = ldx[(size_t)k * Emax + t];
+            for (int k = 0; k < 6; ++k) dxN[k] = ldx[(size_t)k * Emax + tt];
             if (skip) {
                 sig[0] = sig[1] = sig[2] = 0.;
                 damage = 0.;
@@ -1371,7 +1380,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             double F[6];
             corner_forces(volume, sig, dxN, F);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + t] = F[k];
+            for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + tt] = F[k];
         }
         __syncthreads();
         RSTAMP(1);
@@ -1380,14 +1389,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const DevParams &q = *pq;
         // ---- node phase (FE.cpp:10445-10553): fan gather in ascending element order, 2x2 solve, mesh move, publish
         if (has_node) {
-            double uice = lu[t], vice = lv[t];
-            const double node_mass = lN[t];
+            double uice = lu[tt], vice = lv[tt];
+            const double node_mass = lN[tt];
             if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
-                double gx = lN[(size_t)Pmax + t], gy = lN[2 * (size_t)Pmax + t];
+                double gx = lN[(size_t)Pmax + tt], gy = lN[2 * (size_t)Pmax + tt];
                 bool more = true;
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
-                    const unsigned ent = fan[k];
+                    const unsigned ent = lFan[(size_t)k * Pmax + tt];
                     if (!more || ent == 0xFFFFu) { more = false; continue; }
                     if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
                     const int l = ent >> 3, c = ent & 3u;
@@ -1395,28 +1404,29 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     gy -= lF[(size_t)(c + 3) * Emax + l];
                 }
                 for (int k = 8; more && k < pp.Wp; ++k) {
-                    const unsigned ent = pf[(size_t)k * Pmax + t];
+                    const unsigned ent = pf[(size_t)k * Pmax + tt];
                     if (ent == 0xFFFFu) break;
                     if (ent & 4u) continue;
                     const int l = ent >> 3, c = ent & 3u;
                     gx -= lF[(size_t)c * Emax + l];
                     gy -= lF[(size_t)(c + 3) * Emax + l];
                 }
-                nodal_solve(q, gx, gy, uice, vice, node_mass, lN[3 * (size_t)Pmax + t], lN[4 * (size_t)Pmax + t], lN[5 * (size_t)Pmax + t],
-                            (nf & NF_LAT_NEG) ? -1. : 1., lN[6 * (size_t)Pmax + t], lN[7 * (size_t)Pmax + t], lN[8 * (size_t)Pmax + t],
-                            lN[9 * (size_t)Pmax + t], 0., 0.);
+                nodal_solve(q, gx, gy, uice, vice, node_mass, lN[3 * (size_t)Pmax + tt], lN[4 * (size_t)Pmax + tt], lN[5 * (size_t)Pmax + tt],
+                            (nf & NF_LAT_NEG) ? -1. : 1., lN[6 * (size_t)Pmax + tt], lN[7 * (size_t)Pmax + tt], lN[8 * (size_t)Pmax + tt],
+                            lN[9 * (size_t)Pmax + tt], 0., 0.);
             }
-            lu[t] = uice; lv[t] = vice;
+            lu[tt] = uice; lv[tt] = vice;
             if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
-                if (!(nf & NF_NEUMANN)) { lM[t] += move_dt * uice; lM[Pmax + t] += move_dt * vice; }
-                lM[2 * (size_t)Pmax + t] += move_dt * uice; lM[3 * (size_t)Pmax + t] += move_dt * vice;
+                if (!(nf & NF_NEUMANN)) { lM[tt] += move_dt * uice; lM[Pmax + tt] += move_dt * vice; }
+                lM[2 * (size_t)Pmax + tt] += move_dt * uice; lM[3 * (size_t)Pmax + tt] += move_dt * vice;
             }
             if (ss == S - 1) { s.VT[n] = uice; s.VT[n + Nn] = vice; }
             else {
                 double *X = (ss & 1) ? r.X1 : r.X0;
                 st_agent(X + n, uice); st_agent(X + n + Nn, vice);
             }
-            if (HALO) {  // updateGhosts, sending side: straight into the neighbour ranks' mailboxes (as k_substep_fused)
+            if (HALO && boundary) {  // updateGhosts, sending side: straight into the neighbour ranks' mailboxes (as k_substep_fused)
+                const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
                 for (int qq = sq0; qq < sq1; ++qq) {
                     const int k = hfp->send_k[qq];
                     double *dst = hfp->ipc.peer_seg[k] + ((x0 + (unsigned long long)ss) & 1ull) * hfp->ipc.peer_parity_stride[k] + hfp->send_pos[qq];
@@ -1483,9 +1493,11 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         __syncthreads();
         RSTAMP(5);
         if (HALO && t < nG && move_dt != 0.) {  // the ghosts' mesh move with the velocity that has just arrived (FE.cpp:10543-10550)
-            const double gu = lu[gsl], gv = lv[gsl];
-            if (!(gnf & NF_NEUMANN)) { lG[t] += move_dt * gu; lG[r.Gmax + t] += move_dt * gv; }
-            lG[2 * (size_t)r.Gmax + t] += move_dt * gu; lG[3 * (size_t)r.Gmax + t] += move_dt * gv;
+            const int gsl2 = r.gslot[(size_t)blk * r.Gmax + tt];
+            const unsigned char gnf2 = m.nflags[pn[gsl2]];
+            const double gu = lu[gsl2], gv = lv[gsl2];
+            if (!(gnf2 & NF_NEUMANN)) { lG[tt] += move_dt * gu; lG[r.Gmax + tt] += move_dt * gv; }
+            lG[2 * (size_t)r.Gmax + tt] += move_dt * gu; lG[3 * (size_t)r.Gmax + tt] += move_dt * gv;
         }
     }
     // ---- once per step: the element state and the moved mesh go back

@@ -32,7 +32,7 @@ if a.resident:  # k_substep_resident, sub-step 60 of the launch: start of the el
     print(f"{gm.num_elements} triangles, {t.shape[0]} workgroups, sub-step 60 of the resident launch; spread of the workgroups' start of that sub-step {(t[:, 0].max() - t[:, 0].min()) * 10e-3:.2f} us")
     for nm, col in zip(("element phase (to barrier 1)", "node phase + publishing stores issued", "stores drained + barrier", "wait for the neighbours' counters + barrier", "halo loads + barrier"), d.T):
         print(f"  {nm:45s} mean {col.mean():6.2f} us   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
-    print(f"  one sub-step                                  mean {(t[:, 5] - t[:, 0]).mean():6.2f} us")
+    print(f"  one sub-step                                  mean {(t[:, 5] - t[:, 0]).mean() * 10e-3:6.2f} us")
     fe.close(); sys.exit(0)
 if a.multi:  # k_substep_multi (small single-rank meshes), D = 4: start, barrier 1, forces of sub-step 0, end of sub-steps 0..3
     t = t.reshape(8192, 8)[:, :7]

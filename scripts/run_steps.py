@@ -3,6 +3,7 @@ import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--mesh", default="2km"); ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--h", type=float, default=0., help="disc mesh of this edge length (m) instead of a named mesh: 15600 = one rank of eight of the 2 km mesh")
 ap.add_argument("--torch-first", action="store_true"); ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=-1); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0); ap.add_argument("--shape-mem", type=int, default=-1); ap.add_argument("--compare-fused", type=int, default=-1, help="also run with this value of option fused and compare the states bit for bit")
 a = ap.parse_args()
@@ -10,7 +11,7 @@ if a.torch_first:
     import torch
     print("torch", torch.__version__, "cuda", torch.cuda.is_available(), flush=True)
 from nextsim_amd import dynamics, forcing as F, mesh as M
-gm = M.make_mesh(a.mesh)
+gm = M.make_disc_mesh(a.h, seed=M.SEED, name="custom") if a.h > 0 else M.make_mesh(a.mesh)
 p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
 g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
 lm = M.localize(gm, 1)[0]; f = F.localize_fields(g, lm, gm.num_nodes)
