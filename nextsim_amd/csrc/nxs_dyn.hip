@@ -1486,7 +1486,7 @@ int build_resident(nxs_dyn_handle *h) {
     if (Gmax > 512) { h->res_failed = true; return NXS_OK; }
     std::vector<unsigned short> gslot((size_t)nP * Gmax, 0);
     for (int q = 0; q < nP; ++q) std::copy(glist[q].begin(), glist[q].end(), gslot.begin() + (size_t)q * Gmax);
-    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 4 * (size_t)Gmax) * sizeof(double) + 16 * (size_t)hp.Pmax;  // + [8][Pmax] fan entries
+    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 4 * (size_t)Gmax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax;  // + the pair of zeros behind the corner forces + [Pmax][8] fan entries
     // every workgroup must be resident at once
     int per_cu = 0, cus = 0;
     const bool p4 = h->dp.ers_int == 4;

@@ -1247,9 +1247,15 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const DevParams &p0 = *pdev;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int Mmax = pp.Mmax, Emax = pp.Emax, Pmax = pp.Pmax;
-    double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*[6][Emax]*/, *ldx = lF + 6 * (size_t)Emax /*[6][Emax]*/,
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    // lF2: the corner forces as (x, y) pairs, [3][Emax] + one pair of zeros behind them: a node's gather is eight independent 16-byte
+    // reads (pad entries and ghost corners read the zeros: x - (+0) == x, bit for bit) followed by the reference's subtractions in
+    // the reference's order -- not eight dependent rounds of "entry, branch, two reads, two subtractions"
+    double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*d2 [3][Emax] + 1*/, *ldx = lF + 6 * (size_t)Emax + 2 /*[6][Emax]*/,
            *lN = ldx + 6 * (size_t)Emax /*[10][Pmax]*/, *lM = lN + 10 * (size_t)Pmax /*[4][Pmax]*/, *lG = lM + 4 * (size_t)Pmax /*[4][Gmax]*/;
-    unsigned short *lFan = reinterpret_cast<unsigned short *>(lG + 4 * (size_t)r.Gmax);  // [8][Pmax] the first eight fan entries of every own node
+    d2 *lF2 = reinterpret_cast<d2 *>(lF);
+    uint4 *lFan4 = reinterpret_cast<uint4 *>(lG + 4 * (size_t)r.Gmax);  // [Pmax] the first eight fan entries of every own node as indices into lF2 (16 bits each)
+    const unsigned ZIDX = 3u * (unsigned)Emax;
     __shared__ int lerr;
     auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
         const int q = n >> 3, rr = n & 7, x = pos & 7;
@@ -1269,8 +1275,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk], nNb = r.pnbr_cnt[blk];
     const int *pn = pp.pnodes + (size_t)blk * Mmax;
     const bool bbm = p0.dynamics_type == NXS_DYN_BBM;
-    typedef double d2 __attribute__((ext_vector_type(2)));
-    if (t == 0) lerr = 0;
+    if (t == 0) { lerr = 0; lF2[ZIDX] = d2{0., 0.}; }
 
     // ---- once per step: indices, velocities and frozen coordinates of the staged nodes, this thread's element, this thread's node
     double *sx = lF, *sy = lF + Mmax;  // (scratch: the corner forces are not needed yet)
@@ -1301,8 +1306,13 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     unsigned char nf = 0;
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
     if (has_node) {
+        unsigned idx[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) lFan[(size_t)k * Pmax + t] = (k < pp.Wp) ? pf[(size_t)k * Pmax + t] : (unsigned short)0xFFFFu;
+        for (int k = 0; k < 8; ++k) {
+            const unsigned ent = (k < pp.Wp) ? pf[(size_t)k * Pmax + t] : 0xFFFFu;
+            idx[k] = (ent == 0xFFFFu || (ent & 4u)) ? ZIDX : (ent & 3u) * (unsigned)Emax + (ent >> 3);  // pad, or ghostNodes[i] (FE.cpp:10456)
+        }
+        lFan4[t] = make_uint4(idx[0] | (idx[1] << 16), idx[2] | (idx[3] << 16), idx[4] | (idx[5] << 16), idx[6] | (idx[7] << 16));
     }
     if (has_node) {
         nf = m.nflags[n];
@@ -1380,7 +1390,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             double F[6];
             corner_forces(volume, sig, dxN, F);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + tt] = F[k];
+            for (int k = 0; k < 3; ++k) lF2[(size_t)k * Emax + tt] = d2{F[k], F[k + 3]};
         }
         __syncthreads();
         RSTAMP(1);
@@ -1393,23 +1403,21 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const double node_mass = lN[tt];
             if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
                 double gx = lN[(size_t)Pmax + tt], gy = lN[2 * (size_t)Pmax + tt];
-                bool more = true;
+                {
+                    const uint4 fw = lFan4[tt];
+                    const unsigned w4[4] = {fw.x, fw.y, fw.z, fw.w};
+                    d2 f[8];
 #pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    const unsigned ent = lFan[(size_t)k * Pmax + tt];
-                    if (!more || ent == 0xFFFFu) { more = false; continue; }
-                    if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
-                    const int l = ent >> 3, c = ent & 3u;
-                    gx -= lF[(size_t)c * Emax + l];
-                    gy -= lF[(size_t)(c + 3) * Emax + l];
+                    for (int k = 0; k < 8; ++k) f[k] = lF2[(w4[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { gx -= f[k].x; gy -= f[k].y; }
                 }
-                for (int k = 8; more && k < pp.Wp; ++k) {
+                for (int k = 8; k < pp.Wp; ++k) {  // (fans of more than eight elements: the most irregular vertices)
                     const unsigned ent = pf[(size_t)k * Pmax + tt];
                     if (ent == 0xFFFFu) break;
                     if (ent & 4u) continue;
-                    const int l = ent >> 3, c = ent & 3u;
-                    gx -= lF[(size_t)c * Emax + l];
-                    gy -= lF[(size_t)(c + 3) * Emax + l];
+                    const d2 f = lF2[(ent & 3u) * (unsigned)Emax + (ent >> 3)];
+                    gx -= f.x; gy -= f.y;
                 }
                 nodal_solve(q, gx, gy, uice, vice, node_mass, lN[3 * (size_t)Pmax + tt], lN[4 * (size_t)Pmax + tt], lN[5 * (size_t)Pmax + tt],
                             (nf & NF_LAT_NEG) ? -1. : 1., lN[6 * (size_t)Pmax + tt], lN[7 * (size_t)Pmax + tt], lN[8 * (size_t)Pmax + tt],

@@ -4,6 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 ap = argparse.ArgumentParser(); ap.add_argument("--mesh", default="2km"); ap.add_argument("--steps", type=int, default=5)
 ap.add_argument("--h", type=float, default=0., help="disc mesh of this edge length (m) instead of a named mesh: 15600 = one rank of eight of the 2 km mesh")
+ap.add_argument("--opt", action="append", default=[], help="key=value for set_option (before set_mesh)")
 ap.add_argument("--torch-first", action="store_true"); ap.add_argument("--graph", type=int, default=1)
 ap.add_argument("--fused", type=int, default=3); ap.add_argument("--patch-nodes", type=int, default=0); ap.add_argument("--nt", type=int, default=-1); ap.add_argument("--ring", type=int, default=0); ap.add_argument("--pair-nodes", type=int, default=0); ap.add_argument("--depth", type=int, default=0); ap.add_argument("--shape-mem", type=int, default=-1); ap.add_argument("--compare-fused", type=int, default=-1, help="also run with this value of option fused and compare the states bit for bit")
 a = ap.parse_args()
@@ -19,6 +20,7 @@ fe = dynamics.FiniteElementDynamics(p); fe.set_option("graph", a.graph); fe.set_
 if a.patch_nodes: fe.set_option("patch_nodes", a.patch_nodes)
 if a.pair_nodes: fe.set_option("pair_nodes", a.pair_nodes)
 if a.depth: fe.set_option("substeps_per_launch", a.depth)
+for kv in a.opt: fe.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 fe.set_mesh(lm)
 if a.shape_mem >= 0: fe.set_option("shape_mem", a.shape_mem)
 fe.put_state(f); fe.set_forcing(f)
@@ -30,7 +32,7 @@ print(f"shape_mem={a.shape_mem} ring={a.ring} nt={a.nt} fused={a.fused} patch_no
 if a.compare_fused >= 0:
     import numpy as np
     fe2 = dynamics.FiniteElementDynamics(p); fe2.set_option("fused", a.compare_fused); fe2.set_mesh(lm); fe2.put_state(f); fe2.set_forcing(f)
-    fe3 = dynamics.FiniteElementDynamics(p); fe3.set_option("fused", a.fused); fe3.set_mesh(lm); fe3.put_state(f); fe3.set_forcing(f)
+    fe3 = dynamics.FiniteElementDynamics(p); fe3.set_option("fused", a.fused); [fe3.set_option(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.opt]; fe3.set_mesh(lm); fe3.put_state(f); fe3.set_forcing(f)
     for _ in range(2): fe3.step()
     fe3.synchronize()          # (one after the other: the resident kernel needs the device to itself)
     for _ in range(2): fe2.step()
