@@ -739,7 +739,11 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     const DevParams &p = PMEM ? *pdev : pval;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     double *lu = lds, *lv = lds + pp.Mmax, *lx = lds + 2 * (size_t)pp.Mmax, *ly = lds + 3 * (size_t)pp.Mmax,
-           *lF = lds + 4 * (size_t)pp.Mmax;  // lF[6][Emax]
+           *lF = lds + 4 * (size_t)pp.Mmax;  // the corner forces as (x, y) pairs, [3][Emax], + one pair of zeros (see fan_gather8)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 *lF2 = reinterpret_cast<d2 *>(lF);
+    const unsigned ZIDX = 3u * (unsigned)pp.Emax;
+    if (threadIdx.x == 0) lF2[ZIDX] = d2{0., 0.};
     // consecutive patches are neighbours in space: keep them on one XCD (blocks are dealt round-robin
     // over the 8 XCDs) so that shared halo elements / nodes hit that XCD's L2.  Speed only.
     auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index, classes pos%8 -> contiguous index ranges
@@ -892,7 +896,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             double F[6];
             corner_forces(volume, sig, dxN, F);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) lF[(size_t)k * Emax + l] = F[k];
+            for (int k = 0; k < 3; ++k) lF2[(size_t)k * Emax + l] = d2{F[k], F[k + 3]};
         }
 #if NXS_PF >= 1
         eraw = eraw1; tr = tr1; eraw1 = eraw2; tr1 = tr2;
@@ -933,30 +937,32 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             if (HALO && boundary) { sq0 = hfp->send_ptr[n]; sq1 = hfp->send_ptr[n + 1]; }
         }
         // the node's fan (element slot, corner) too: 8 entries cover all but the most irregular vertices
-        unsigned short fan[8];
+        unsigned fw[4];  // as LDS indices, two per word: pad entries and ghost corners (ghostNodes[i], FE.cpp:10456) name the pair of zeros
 #pragma unroll
-        for (int k = 0; k < 8; ++k) fan[k] = (active && k < pp.Wp) ? pf[(size_t)k * pp.Pmax + i] : (unsigned short)0xFFFFu;
+        for (int k = 0; k < 4; ++k) {
+            const unsigned e0 = (active && 2 * k < pp.Wp) ? pf[(size_t)(2 * k) * pp.Pmax + i] : 0xFFFFu;
+            const unsigned e1 = (active && 2 * k + 1 < pp.Wp) ? pf[(size_t)(2 * k + 1) * pp.Pmax + i] : 0xFFFFu;
+            const unsigned i0 = (e0 == 0xFFFFu || (e0 & 4u)) ? ZIDX : (e0 & 3u) * (unsigned)Emax + (e0 >> 3);
+            const unsigned i1 = (e1 == 0xFFFFu || (e1 & 4u)) ? ZIDX : (e1 & 3u) * (unsigned)Emax + (e1 >> 3);
+            fw[k] = i0 | (i1 << 16);
+        }
         if (base == 0) { __syncthreads(); NXS_STAMP(3); }  // corner forces visible
         if (!active) continue;
         double uice = lu[i], vice = lv[i];
         if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
-            bool more = true;
+            {   // eight independent 16-byte reads, then the reference's subtractions in the reference's order (x - (+0) == x bit for bit)
+                d2 f[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const unsigned ent = fan[k];
-                if (!more || ent == 0xFFFFu) { more = false; continue; }
-                if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
-                const int l = ent >> 3, c = ent & 3u;
-                gx -= lF[(size_t)c * Emax + l];
-                gy -= lF[(size_t)(c + 3) * Emax + l];
+                for (int k = 0; k < 8; ++k) f[k] = lF2[(fw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { gx -= f[k].x; gy -= f[k].y; }
             }
-            for (int k = 8; more && k < pp.Wp; ++k) {
+            for (int k = 8; k < pp.Wp; ++k) {  // (fans of more than eight elements)
                 const unsigned ent = pf[(size_t)k * pp.Pmax + i];
                 if (ent == 0xFFFFu) break;
                 if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
-                const int l = ent >> 3, c = ent & 3u;
-                gx -= lF[(size_t)c * Emax + l];
-                gy -= lF[(size_t)(c + 3) * Emax + l];
+                const d2 f = lF2[(ent & 3u) * (unsigned)Emax + (ent >> 3)];
+                gx -= f.x; gy -= f.y;
             }
             nodal_solve(q, gx, gy, uice, vice, node_mass, rlm, cbu, fcor, lat, tax, tay, ou, ov, vtmu, vtmv);
         }
@@ -1016,7 +1022,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     const DevParams &p = *pdev;  // read from device memory where they are used (see k_substep_fused)
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int NDm = pp.NDmax, EDm = pp.EDmax, ESm = pp.ESmax, D = pp.D;
-    double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm, *lF = ly + NDm /*[6][EDm]*/, *lS = lF + 6 * (size_t)EDm /*[4][ESm]*/;
+    double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm, *lF = ly + NDm /*(x, y) pairs [3][EDm] + a pair of zeros*/, *lS = lF + 6 * (size_t)EDm + 2 /*[4][ESm]*/;
     int blk;
     {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
         const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, r = n & 7, x = pos & 7;
@@ -1052,6 +1058,9 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     // patch writes the element); in between the state lives in LDS
     struct ElemIn { int e; bool writer, skip; int dxi; double sig[3], damage, expC, volume, pmax, heal, coh, dxN[6]; };
     typedef double d2 __attribute__((ext_vector_type(2)));
+    d2 *lF2 = reinterpret_cast<d2 *>(lF);
+    const unsigned ZIDX = 3u * (unsigned)EDm;
+    if (threadIdx.x == 0) lF2[ZIDX] = d2{0., 0.};  // (read behind the barriers of the first sub-step)
     auto load_element = [&](const int eraw, const bool first, const bool last) {
         ElemIn in;
         in.writer = eraw >= 0;
@@ -1122,10 +1131,10 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
         double F[6];
         corner_forces(in.volume, sig, dxN, F);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) lF[(size_t)k * EDm + l] = F[k];
+        for (int k = 0; k < 3; ++k) lF2[(size_t)k * EDm + l] = d2{F[k], F[k + 3]};
     };
     // one node of one sub-step (FE.cpp:10472-10529), loads and solve apart for the same reason
-    struct NodeIn { unsigned char nf; double node_mass, gx, gy, rlm, cbu, fcor, tax, tay, ou, ov; unsigned short fan[8]; };
+    struct NodeIn { unsigned char nf; double node_mass, gx, gy, rlm, cbu, fcor, tax, tay, ou, ov; unsigned fw[4]; };  // fw: the first eight fan entries as LDS indices, two per word
     auto load_node = [&](const int i, const int n) {
         NodeIn in;
         in.nf = m.nflags[n];
@@ -1134,30 +1143,32 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
         in.node_mass = r0.x; in.gx = r0.y; in.gy = r1.x; in.rlm = r1.y; in.cbu = r2.x; in.fcor = r2.y;
         in.tax = r3.x; in.tay = r3.y; in.ou = r4.x; in.ov = r4.y;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) in.fan[k] = (k < pp.Wp) ? pf[(size_t)k * pp.NSmax + i] : (unsigned short)0xFFFFu;
+        for (int k = 0; k < 4; ++k) {  // pad entries and ghost corners (ghostNodes[i], FE.cpp:10456) name the pair of zeros
+            const unsigned e0 = (2 * k < pp.Wp) ? pf[(size_t)(2 * k) * pp.NSmax + i] : 0xFFFFu;
+            const unsigned e1 = (2 * k + 1 < pp.Wp) ? pf[(size_t)(2 * k + 1) * pp.NSmax + i] : 0xFFFFu;
+            const unsigned i0 = (e0 == 0xFFFFu || (e0 & 4u)) ? ZIDX : (e0 & 3u) * (unsigned)EDm + (e0 >> 3);
+            const unsigned i1 = (e1 == 0xFFFFu || (e1 & 4u)) ? ZIDX : (e1 & 3u) * (unsigned)EDm + (e1 >> 3);
+            in.fw[k] = i0 | (i1 << 16);
+        }
         return in;
     };
     auto solve_node = [&](const int i, NodeIn &in, double &uice, double &vice) {
         uice = lu[i]; vice = lv[i];
         if ((in.nf & NF_DIRICHLET) || in.node_mass == 0.) return;
         double gx = in.gx, gy = in.gy;
-        bool more = true;
+        {   // eight independent 16-byte reads, then the reference's subtractions in the reference's order (x - (+0) == x bit for bit)
+            d2 f[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const unsigned ent = in.fan[k];
-            if (!more || ent == 0xFFFFu) { more = false; continue; }
-            if (ent & 4u) continue;  // ghostNodes[i] (FE.cpp:10456)
-            const int l = ent >> 3, c = ent & 3u;
-            gx -= lF[(size_t)c * EDm + l];
-            gy -= lF[(size_t)(c + 3) * EDm + l];
+            for (int k = 0; k < 8; ++k) f[k] = lF2[(in.fw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gx -= f[k].x; gy -= f[k].y; }
         }
-        for (int k = 8; more && k < pp.Wp; ++k) {
+        for (int k = 8; k < pp.Wp; ++k) {  // (fans of more than eight elements)
             const unsigned ent = pf[(size_t)k * pp.NSmax + i];
             if (ent == 0xFFFFu) break;
             if (ent & 4u) continue;
-            const int l = ent >> 3, c = ent & 3u;
-            gx -= lF[(size_t)c * EDm + l];
-            gy -= lF[(size_t)(c + 3) * EDm + l];
+            const d2 f = lF2[(ent & 3u) * (unsigned)EDm + (ent >> 3)];
+            gx -= f.x; gy -= f.y;
         }
         nodal_solve(p, gx, gy, uice, vice, in.node_mass, in.rlm, in.cbu, in.fcor, (in.nf & NF_LAT_NEG) ? -1. : 1., in.tax, in.tay, in.ou, in.ov, 0., 0.);
     };

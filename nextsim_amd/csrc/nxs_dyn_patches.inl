@@ -271,7 +271,7 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only) {
     // the caller's numbering if it has locality, else the Hilbert curve the single-ring patches were cut along
     if (h->hp && h->hp->used_hilbert) hilbert_order(h->h_x0.data(), h->h_y0.data(), m.Nn, order);
     HostPatches2 hp;
-    auto lds_of = [](const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 4 * (size_t)x.ESmax) * sizeof(double); };
+    auto lds_of = [](const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 2 + 4 * (size_t)x.ESmax) * sizeof(double); };
     int P = 0, threads = 512;
     if (h->pair_nodes > 0) {
         P = h->pair_nodes;
@@ -379,7 +379,7 @@ int upload_patches(nxs_dyn_handle *h) {
     int P = 0;
     auto build = [&](int PP) -> bool {
         if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, PP, hp)) return false;
-        h->fused_lds = (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax) * sizeof(double);
+        h->fused_lds = (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax + 2) * sizeof(double);  // staged nodes, corner forces + their pair of zeros
         return true;
     };
     if (!automatic) {
