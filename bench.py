@@ -330,6 +330,45 @@ def aux_regrid(gm, with_cpu=True):
     return out
 
 
+def aux_partition_floor(args, local_rank, torch, S):
+    """The compute floor of strong scaling, measured on THIS one GPU: single-rank meshes of 1/4 and 1/8 of the 2 km mesh's triangles (what
+    a rank holds on 4 / 8 GPUs), no halo exchange.  The 1/8 mesh is one round of resident workgroups: the whole sub-step loop runs as one
+    launch (option fused = 4) when the device is free, else one launch per sub-step."""
+    from nextsim_amd import dynamics, forcing as F, mesh as M
+    out = []
+    for share, h_edge in ((4, 11000.), (8, 15600.)):
+        gm = M.make_disc_mesh(h_edge, seed=M.SEED, name="custom")
+        p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
+        g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
+        lm = M.localize(gm, 1)[0]
+        f = F.localize_fields(g, lm, gm.num_nodes)
+        row = {"share_of_2km_mesh": f"1/{share}", "elements": gm.num_elements}
+        for name, fused in (("one_launch_per_substep", 1), ("resident_one_launch_per_step", 4)):
+            fe = dynamics.FiniteElementDynamics(p, device=local_rank)
+            fe.set_option("fused", fused)
+            fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+            for _ in range(3):
+                fe.step()
+            fe.synchronize(); fe.set_option("timing_reset", 1)
+            n = 40
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(n):
+                fe.step()
+            fe.synchronize(); torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            launches = fe.timing()["substep_launches"]
+            ok = fe.checkFieldsFast() == 0
+            fe.close()
+            if fused == 4 and launches != 1:
+                row[name] = None   # the partition does not fit one round of resident workgroups
+                continue
+            row[name] = {"ms_per_step": dt / n * 1e3, "value": gm.num_elements * S * n / dt, "unit": "element-updates/s", "fields_ok": ok}
+        out.append(row)
+    return {"workload": "single-rank disc meshes with 1/4 and 1/8 of the 2 km mesh's triangles, same state and forcing, no halo exchange: what "
+                        "one rank of 4 / 8 computes per step -- the ceiling of strong scaling is (ms_per_step of the whole mesh) / (this)",
+            "meshes": out}
+
+
 def cpu_baseline(kind, nsteps=1):
     """The restated reference CPU path (oracle/dyn_ref.c, -O3 -march=native) on the same mesh and forcing.
     (i) one core, the serial loops; (ii) all host cores this process may use: one mesh partition per core
@@ -513,6 +552,10 @@ def main():
             }
         except Exception as e:  # noqa: BLE001
             out["aux_openwater"] = {"error": repr(e)}
+        try:   # what a rank of 4 / 8 would compute per step (strong-scaling ceiling, measured on this GPU)
+            out["aux_partition_floor"] = aux_partition_floor(args, local_rank, torch, S)
+        except Exception as e:  # noqa: BLE001
+            out["aux_partition_floor"] = {"error": repr(e)}
         try:   # BASELINE config 5: the regrid interpolation kernels at 2 km size, the real bamg routines beside them
             out["aux_regrid"] = aux_regrid(res["gm"], with_cpu=not args.no_cpu_baseline)
         except Exception as e:  # noqa: BLE001

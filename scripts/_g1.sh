@@ -1,5 +1,4 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-NXS_DYN_LIBRARY=$PWD/nextsim_amd/csrc/libnxsdyn_old.so timeout -k 10 300 python3 scripts/run_steps.py --mesh 2km --steps 30 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-160
-timeout -k 10 300 python3 scripts/run_steps.py --mesh 2km --steps 30 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-160
-done
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r2b_suite1.log 2>&1; echo "suite rc $?"
+tail -3 gpurun_out/r2b_suite1.log
+timeout -k 10 600 python3 bench.py > gpurun_out/r2b_bench1.json 2> gpurun_out/r2b_bench1.err; echo "bench rc $?"
