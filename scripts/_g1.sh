@@ -1,4 +1,5 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r2b_suite1.log 2>&1; echo "suite rc $?"
-tail -3 gpurun_out/r2b_suite1.log
-timeout -k 10 600 python3 bench.py > gpurun_out/r2b_bench1.json 2> gpurun_out/r2b_bench1.err; echo "bench rc $?"
+export NXS_DEBUG_PATCHES=1
+NXS_DYN_LIBRARY=$PWD/nextsim_amd/csrc/libnxsdyn_phase.so timeout -k 10 120 python3 scripts/phase_timing.py --h 11000 2>&1 | grep -v amdgpu | tail -9
+NXS_DYN_LIBRARY=$PWD/nextsim_amd/csrc/libnxsdyn_phase.so timeout -k 10 120 python3 scripts/phase_timing.py --h 7800 2>&1 | grep -v amdgpu | tail -9
+NXS_DYN_LIBRARY=$PWD/nextsim_amd/csrc/libnxsdyn_phase.so timeout -k 10 120 python3 scripts/phase_timing.py --mesh 2km 2>&1 | grep -v amdgpu | tail -9

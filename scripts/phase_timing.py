@@ -49,5 +49,5 @@ d = np.diff(t, axis=1) * 10e-3  # 100 MHz ticks -> us
 print(f"{gm.num_elements} triangles, {t.shape[0]} workgroups; kernel span {(t[:, 4].max() - k0) * 10e-3:.2f} us")
 for nm, col in zip(("index hop + staging (to barrier 1)", "element rounds", "wait at barrier 2 (+ node loads)", "fan gather + solve + stores"), d.T):
     print(f"  {nm:38s} mean {col.mean():6.2f} us   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
-print(f"  workgroup total                        mean {(t[:, 4] - t[:, 0]).mean():6.2f} us; start of the last workgroup {(t[:, 0].max() - k0) * 10e-3:.2f} us after the first")
+print(f"  workgroup total                        mean {(t[:, 4] - t[:, 0]).mean() * 10e-3:6.2f} us; start of the last workgroup {(t[:, 0].max() - k0) * 10e-3:.2f} us after the first")
 fe.close()
