@@ -68,6 +68,7 @@ struct DevPatches {
     const int *pelem;             // [nP][Emax] global element id, ascending; ~id when another patch writes it
     const unsigned short *ptri;   // [nP][Emax][4] patch-local node slots of the 3 corners (+ pad)
     const unsigned short *pfan;   // [nP][Wp][Pmax] (element slot << 3 | ghost << 2 | corner), 0xFFFF pad
+    const int2 *pet;              // [nP][Emax] {pelem, the three corner slots in 10 bits each} -- what k_substep_fused reads: 8 bytes per element instead of 12
 };
 
 // Patches of the several-sub-steps-per-launch kernel (k_substep_multi): D rings of halo around the own nodes.
@@ -764,8 +765,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     const int t = threadIdx.x, Nn = m.Nn, Emax = pp.Emax;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
     const int *pn = pp.pnodes + (size_t)blk * pp.Mmax;
-    const int *pe = pp.pelem + (size_t)blk * Emax;
-    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * Emax;
+    const int2 *pet = pp.pet + (size_t)blk * Emax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
     constexpr bool NT_S = NTM & 1, NT_U = NTM & 2, NT_C = NTM & 4;  // sigma/damage, UM/UT, element constants
 
@@ -776,16 +776,14 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     // patch's counts (one more dependent hop; the counts arrive meanwhile and mask the uses).
     const int my_node = (t < pp.Mmax) ? pn[t] : 0;  // patch-local slot t (an own node when t < nO)
     const int my_node2 = (t + T < pp.Mmax) ? pn[t + T] : 0;  // a patch stages ~1.25 nodes per own node: second staging slot
-    int eraw = 0;
-    ushort4 tr = make_ushort4(0, 0, 0, 0);
-    if (t < Emax) { eraw = pe[t]; tr = pt[t]; }
+    int2 et = make_int2(0, 0);  // {element, corner slots}
+    if (t < Emax) et = pet[t];
 #if NXS_PF >= 1
     // element rounds 1 and 2 (a patch holds ~2.2 elements per own node): their indices are fetched now, so
     // that a later round starts with its data loads instead of an index hop
-    int eraw1 = 0, eraw2 = 0;
-    ushort4 tr1 = tr, tr2 = tr;
-    if (t + T < Emax) { eraw1 = pe[t + T]; tr1 = pt[t + T]; }
-    if (t + 2 * T < Emax) { eraw2 = pe[t + 2 * T]; tr2 = pt[t + 2 * T]; }
+    int2 et1 = et, et2 = et;
+    if (t + T < Emax) et1 = pet[t + T];
+    if (t + 2 * T < Emax) et2 = pet[t + 2 * T];
 #endif
 
     const bool mailbox_ghosts = HALO && boundary && from_mailbox;
@@ -828,11 +826,13 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     for (int base = 0; base < nE; base += T) {
         const int l = base + t;
 #if NXS_PF >= 1
-        if (base >= 3 * T && l < nE) { eraw = pe[l]; tr = pt[l]; }  // very large patches: rounds beyond the prefetched ones
+        if (base >= 3 * T && l < nE) et = pet[l];  // very large patches: rounds beyond the prefetched ones
 #else
-        if (base > 0 && l < nE) { eraw = pe[l]; tr = pt[l]; }  // patches larger than the block: extra rounds
+        if (base > 0 && l < nE) et = pet[l];  // patches larger than the block: extra rounds
 #endif
         const bool active = l < nE;
+        const int eraw = et.x;
+        const ushort4 tr = make_ushort4((unsigned short)(et.y & 1023), (unsigned short)((et.y >> 10) & 1023), (unsigned short)((et.y >> 20) & 1023), 0);
         const bool writer = eraw >= 0;
         const int e = writer ? eraw : ~eraw;
         double dxN[6], sig[3] = {0., 0., 0.}, damage = 0., c_expC = 0., c_pmax = 0., c_heal = 0., c_dxs = 1., c_coh = 0., volume = 0.;
@@ -899,7 +899,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             for (int k = 0; k < 3; ++k) lF2[(size_t)k * Emax + l] = d2{F[k], F[k + 3]};
         }
 #if NXS_PF >= 1
-        eraw = eraw1; tr = tr1; eraw1 = eraw2; tr1 = tr2;
+        et = et1; et1 = et2;
 #endif
     }
 

@@ -365,6 +365,11 @@ int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
     if ((rc = dev_upload(h, h->patch_allocs, &d.pelem, hp.pelem))) return rc;
     if ((rc = dev_upload(h, h->patch_allocs, &d.ptri, hp.ptri))) return rc;
     if ((rc = dev_upload(h, h->patch_allocs, &d.pfan, hp.pfan))) return rc;
+    if (hp.Mmax > 1024) return fail(h, NXS_ERR_INVALID, "a patch stages %d nodes (at most 1024: choose smaller patches)", hp.Mmax);
+    std::vector<int2> pet((size_t)hp.nP * hp.Emax);
+    for (size_t i = 0; i < pet.size(); ++i)
+        pet[i] = make_int2(hp.pelem[i], (int)hp.ptri[4 * i] | ((int)hp.ptri[4 * i + 1] << 10) | ((int)hp.ptri[4 * i + 2] << 20));
+    if ((rc = dev_upload(h, h->patch_allocs, &d.pet, pet))) return rc;
     return NXS_OK;
 }
 
@@ -386,7 +391,7 @@ int upload_patches(nxs_dyn_handle *h) {
         P = std::max(64, std::min(h->patch_nodes, 1024));
         for (;;) {
             if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
-            if (h->fused_lds <= 80 * 1024 || P <= 64) break;
+            if ((h->fused_lds <= 80 * 1024 && hp.Mmax <= 1024) || P <= 64) break;
             P = std::max(64, P * 3 / 4);
         }
     } else {
@@ -408,7 +413,7 @@ int upload_patches(nxs_dyn_handle *h) {
             for (int it = 0; it < 4 && !done; ++it) {  // orphan patches (multi-rank) may add a few workgroups
                 if (it > 0) P += 4;
                 if (!build(P)) return fail(h, NXS_ERR_INVALID, "patch construction failed (patch_nodes=%d)", P);
-                if (h->fused_lds > 80 * 1024) break;            // does not fit twice: more rounds of smaller patches
+                if (h->fused_lds > 80 * 1024 || hp.Mmax > 1024) break;  // does not fit twice (or its corner slots do not fit 10 bits): more rounds of smaller patches
                 done = hp.nP <= k * slots512;
             }
         }
