@@ -271,7 +271,9 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  2 = several sub-steps per launch wherever possible (single rank, not mEVP, a depth that divides the
  *                  number of sub-steps); 1 = one patch kernel per sub-step; 0 = one kernel per reference loop;
  *                  4 = the whole sub-step loop in ONE resident launch whose workgroups wait for their neighbouring patches only
- *                  (single rank, not mEVP, every workgroup resident at once -- checked, else as 1): for a device the handle has to itself
+ *                  (one rank, or several with the device-direct mailboxes and "halo_fused" 1: the exchange between ranks then happens
+ *                  inside that launch too; not mEVP; one element per thread and every workgroup resident at once -- checked, else
+ *                  as 1): for a device the handle has to itself -- one rank of eight of a 1.5 M-triangle mesh: 0.85 instead of 1.3 ms
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)
  *   "patch_nodes"  own nodes per patch of the fused kernel, 64..1024; 0 = automatic (whole rounds of resident workgroups)
  *   "pair_nodes"   the same for the several-sub-steps kernel, 16..512; 0 = automatic
