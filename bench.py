@@ -39,6 +39,7 @@ def parse():
                     "HBM roofline are quoted on), 10km (~60k), 40km, small")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-aux", action="store_true", help="skip the secondary 10 km measurement")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not measure roofline.traffic with two rocprofv3 --pmc child runs (replay the committed profile)")
     return ap.parse_args()
 
 
@@ -61,6 +62,49 @@ def pmc_traffic(mesh, launches_per_substep, world):
         except Exception:  # noqa: BLE001
             continue
     return None, None
+
+
+def pmc_traffic_live(mesh, launches_per_substep, world, timeout_s=240):
+    """(HBM bytes per launch of the sub-step kernel MEASURED NOW, how): two child runs of one step of the same mesh
+    (scripts/run_steps.py) under `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` -- separate passes, counters only, no
+    tracing beside them -- reduced as scripts/make_pmc_profile.py does: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over the launches of
+    k_substep_fused (gfx950 counts half of the coalesced streaming reads: MI355X_MICROARCH.md; calibrated in
+    profiles/r01_v1_pmc_traffic.json).  (None, reason) when it cannot be done here (no rocprofv3, already under a profiler, a failure)."""
+    import csv, glob, shutil, subprocess, tempfile
+    if mesh != "2km" or launches_per_substep != 1 or world != 1:
+        return None, "not the single-GPU one-launch-per-sub-step workload"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="nxs_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NXS_DYN_LIBRARY")}
+    env["TMPDIR"] = "/tmp"
+    vals = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, counter)
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "scripts", "run_steps.py"), "--mesh", mesh, "--steps", "1", "--graph", "0"]
+            subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
+            acc, n = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if r["Counter_Name"] == counter and r["Kernel_Name"].split("(")[0].replace("void ", "").startswith("k_substep_fused"):
+                        acc += float(r["Counter_Value"]); n += 1
+            if n == 0:
+                return None, f"no {counter} rows for k_substep_fused"
+            vals[counter] = (acc / n, n)
+        b = int((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024)
+        return b, (f"MEASURED IN THIS RUN: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate, counters only) over one step of "
+                   f"the same mesh (scripts/run_steps.py --mesh {mesh} --steps 1 --graph 0), (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over "
+                   f"{vals['FETCH_SIZE'][1]} launches of k_substep_fused (gfx950 reports half of the coalesced streaming reads, "
+                   f"MI355X_MICROARCH.md); FETCH_SIZE {vals['FETCH_SIZE'][0]:.1f} KiB, WRITE_SIZE {vals['WRITE_SIZE'][0]:.1f} KiB per launch")
+    except Exception as e:  # noqa: BLE001 -- the bench line survives without it (the committed profile is replayed instead)
+        return None, "failed: " + repr(e)[:200]
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
 
 
 _MESHES = {}
@@ -468,7 +512,14 @@ def main():
     substep_ms = tm["substeps_ms"] / S                      # HIP events on the kernel's stream, avg over timed steps
     bytes_per_substep = BYTES_PER_ELEMENT * lm.num_elements + BYTES_PER_NODE * lm.num_nodes
     achieved = bytes_per_substep / (substep_ms * 1e-3) / 1e9
-    traffic, traffic_source = pmc_traffic(args.mesh, launches_per_substep, world)
+    traffic_profile, profile_file = pmc_traffic(args.mesh, launches_per_substep, world)
+    traffic, traffic_source = (None, "skipped (--no-live-pmc)") if (args.no_live_pmc or rank != 0) else pmc_traffic_live(args.mesh, launches_per_substep, world)
+    traffic_live = traffic is not None
+    if not traffic_live:   # replay of the committed profile, labelled as such
+        why = traffic_source
+        traffic, traffic_source = traffic_profile, (
+            (profile_file + " -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; REPLAYED here, not measured in this run ("
+             + why + ")") if profile_file else None)
     achieved_counter = traffic / (substep_ms * 1e-3) / 1e9 if traffic else None
     out = {
         "metric": "element-updates/sec per dynamics step",
@@ -501,8 +552,9 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic,
-            "traffic_source": (traffic_source + " -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; replayed "
-                               "here, NOT measured in this run (counters cannot be read in-process)") if traffic_source else None,
+            "traffic_source": traffic_source,
+            "traffic_measured_in_this_run": traffic_live,
+            "traffic_committed_profile": {"bytes": traffic_profile, "file": profile_file} if traffic_profile else None,
             "achieved_counter": achieved_counter,
             "frac_counter": achieved_counter / HBM_PEAK_GBS if achieved_counter else None,
             "bytes_per_launch_group": bytes_per_substep,
