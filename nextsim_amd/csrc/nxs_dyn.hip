@@ -116,6 +116,7 @@ struct nxs_dyn_handle {
     DevPatches2 dsm{};
     std::vector<void *> sm_allocs;
     bool sm_ready = false, sm_failed = false;
+    int sm_depth = 0;  // option smooth_depth: sweeps per launch of the smoother on its own node-ring patches (0 = automatic)
     size_t sm_lds = 0;
     std::vector<unsigned char> h_ghost;
     std::vector<double> h_x0, h_y0;
@@ -510,6 +511,10 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
         h->fused = (int)value; h->res_failed = false; release_graph(h); return NXS_OK;
+    }
+    if (!std::strcmp(key, "smooth_depth")) {
+        if (value != 0 && value != 5 && value != 10 && value != 25) return fail(h, NXS_ERR_INVALID, "smooth_depth must be 0 (auto), 5, 10 or 25");
+        h->sm_depth = (int)value; h->sm_ready = false; h->sm_failed = false; h->tail_graph_valid = false; return NXS_OK;
     }
     if (!std::strcmp(key, "substeps_per_launch")) {
         if (value != 0 && (value < 2 || value > NXS_MAX_DEPTH)) return fail(h, NXS_ERR_INVALID, "substeps_per_launch must be 0 (auto) or in [2,%d]", NXS_MAX_DEPTH);
@@ -1732,8 +1737,10 @@ int explicit_solve(nxs_dyn_handle *h) {
     if (timed) HIPCHK(h, hipEventRecord(h->cur[1], h->stream));
     int rc = run_substeps(h);
     if (rc) return rc;
-    if (!multi_rank(h) && h->depth_now < 2 && !h->sm_ready && !h->sm_failed && eff_fused(h) != 0) {
-        if (build_smooth_patches(h, 5) != NXS_OK) h->sm_failed = true;  // the smoother then runs sweep by sweep
+    if (!multi_rank(h) && !h->sm_ready && !h->sm_failed && eff_fused(h) != 0) {
+        // automatic: ten sweeps per launch (five launches; 10 km: smoother 43 -> 25 us per step) where ten rings fit the LDS, else five
+        if (h->sm_depth > 0) { if (build_smooth_patches(h, h->sm_depth) != NXS_OK) h->sm_failed = true; }  // the smoother then runs sweep by sweep
+        else if (build_smooth_patches(h, 10) != NXS_OK && build_smooth_patches(h, 5) != NXS_OK) h->sm_failed = true;
         h->tail_graph_valid = false;
     }
     if (h->dp.dynamics_type == NXS_DYN_MEVP)  // FE.cpp:10559-10573
@@ -1746,7 +1753,7 @@ int explicit_solve(nxs_dyn_handle *h) {
         if (!h->smooth_second) LAUNCH(h, k_copy_vt, 2 * m.Nn, 2 * m.Nn, a, b);  // both buffers equal: a sweep writes the ice-free nodes only
         // single rank: D sweeps per launch on patches with D rings of nodes (k_smooth_multi) -- those of k_substep_multi where that
         // kernel runs, else node-ring patches built for the smoother alone
-        const bool v3_patches = h->pair_ready && !h->pair_failed && h->dpch2.pnbr && eff_fused(h) >= 2 && h->depth_now >= 2;
+        const bool v3_patches = h->pair_ready && !h->pair_failed && h->dpch2.pnbr && eff_fused(h) >= 2 && h->depth_now >= 2 && !h->sm_ready;  // (only where the smoother's own patches could not be built)
         if (!multi_rank(h) && (v3_patches || h->sm_ready)) {
             const DevPatches2 &pp = v3_patches ? h->dpch2 : h->dsm;
             const size_t lds = v3_patches ? h->smooth_lds : h->sm_lds;
