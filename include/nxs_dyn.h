@@ -274,6 +274,8 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  (one rank, or several with the device-direct mailboxes and "halo_fused" 1: the exchange between ranks then happens
  *                  inside that launch too; not mEVP; one element per thread and every workgroup resident at once -- checked, else
  *                  as 1): for a device the handle has to itself -- one rank of eight of a 1.5 M-triangle mesh: 0.85 instead of 1.3 ms
+ *   "smooth_depth" sweeps of the open-water smoother per launch on its own node-ring patches (single rank): 5, 10 or 25; 0 = automatic
+ *                  (10 where ten rings of neighbours fit the LDS, else 5; sweep by sweep where neither fits)
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)
  *   "patch_nodes"  own nodes per patch of the fused kernel, 64..1024; 0 = automatic (whole rounds of resident workgroups)
  *   "pair_nodes"   the same for the several-sub-steps kernel, 16..512; 0 = automatic
