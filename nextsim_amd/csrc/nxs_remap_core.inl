@@ -38,82 +38,85 @@ struct Pt {
     double x, y;
 };
 
-// CWSort, ConservativeRemapping.cpp:614-645
-NXS_HD inline bool cw_less(Pt p1, Pt p2) {
-    const int dax = (p1.x > 0) ? 1 : 0, day = (p1.y > 0) ? 1 : 0;
-    const int qa = (1 - dax) + (1 - day) + ((dax & (1 - day)) << 1);
-    const int dbx = (p2.x > 0) ? 1 : 0, dby = (p2.y > 0) ? 1 : 0;
-    const int qb = (1 - dbx) + (1 - dby) + ((dbx & (1 - dby)) << 1);
-    if (qa == qb) return p2.x * p1.y < p2.y * p1.x;
-    return qa < qb;
+// Order of two points (relative to the centroid) on the clockwise tour the reference sorts its polygon along (its comparator:
+// ConservativeRemapping.cpp:614-645): quadrants in the order (+,+), (-,+), (-,-), (+,-) -- a coordinate that is exactly zero counts as
+// negative -- and inside a quadrant by the sign of the cross product, evaluated as b.x*a.y < b.y*a.x.
+NXS_HD inline int tour_quadrant(const Pt &p) {
+    return (p.y > 0) ? ((p.x > 0) ? 0 : 1) : ((p.x > 0) ? 3 : 2);
+}
+NXS_HD inline bool cw_less(Pt a, Pt b) {
+    const int ka = tour_quadrant(a), kb = tour_quadrant(b);
+    return (ka != kb) ? (ka < kb) : (b.x * a.y < b.y * a.x);
 }
 
-// area() + sortClockwise(), ConservativeRemapping.cpp:556-611.  p is modified as the reference modifies it.
+// Area of the polygon spanned by n <= 16 unordered points: they are put on the tour above around their mean (which is subtracted
+// before the sort and added back after it, as the reference does -- the roundings of both passes are part of the result), then the
+// shoelace sum is taken in that order (ConservativeRemapping.cpp:556-611).  The array is left sorted.
 NXS_HD inline double polygon_area(Pt *p, int n) {
     if (n < 3) return 0.;
-    double cx = 0., cy = 0.;
-    for (int i = 0; i < n; ++i) { cx += p[i].x; cy += p[i].y; }
-    const double rn = 1. / double(n);
-    cx *= rn; cy *= rn;
-    for (int i = 0; i < n; ++i) { p[i].x -= cx; p[i].y -= cy; }
-    for (int i = 1; i < n; ++i) {  // std::sort, n <= 16
-        const Pt val = p[i];
-        if (cw_less(val, p[0])) {
-            for (int k = i; k > 0; --k) p[k] = p[k - 1];
-            p[0] = val;
+    Pt mean = {0., 0.};
+    for (int k = 0; k < n; ++k) { mean.x += p[k].x; mean.y += p[k].y; }
+    const double inv_n = 1. / double(n);
+    mean.x *= inv_n; mean.y *= inv_n;
+    for (int k = 0; k < n; ++k) { p[k].x -= mean.x; p[k].y -= mean.y; }
+    // std::sort on fewer than 17 elements is libstdc++'s insertion sort: a new minimum is rotated to the front, anything else sinks
+    // from the back without a bound check (bits/stl_algo.h) -- the same comparisons in the same order, hence the same permutation
+    // where the comparator is not a strict weak order (coincident points)
+    for (int k = 1; k < n; ++k) {
+        const Pt moving = p[k];
+        int hole = k;
+        if (cw_less(moving, p[0])) {
+            for (; hole > 0; --hole) p[hole] = p[hole - 1];
         } else {
-            int last = i;
-            while (cw_less(val, p[last - 1])) { p[last] = p[last - 1]; --last; }
-            p[last] = val;
+            for (; cw_less(moving, p[hole - 1]); --hole) p[hole] = p[hole - 1];
         }
+        p[hole] = moving;
     }
-    for (int i = 0; i < n; ++i) { p[i].x += cx; p[i].y += cy; }
-    double area = 0.;
-    int j = n - 1;
-    for (int i = 0; i < n; j = i++) area += (p[j].x + p[i].x) * (p[j].y - p[i].y);
-    return fabs(area) * 0.5;
+    for (int k = 0; k < n; ++k) { p[k].x += mean.x; p[k].y += mean.y; }
+    double twice = 0.;
+    for (int k = 0, before = n - 1; k < n; before = k++) twice += (p[before].x + p[k].x) * (p[before].y - p[k].y);
+    return fabs(twice) * 0.5;
 }
 
-// checkIfInside, ConservativeRemapping.cpp:463-514 (always a 3-gon here)
-NXS_HD inline bool inside3(const double *vx, const double *vy, double tx, double ty, bool inclusive) {
-    const double eps = 1.e-3;
-    for (int i = 0; i < 3; ++i)
-        if (fabs(tx - vx[i]) < eps && fabs(ty - vy[i]) < eps) return inclusive;
-    bool hasPos = false, hasNeg = false, hasMaybe = false;
-    const double epsx = 1e-8;
-    for (int i = 0; i < 3; ++i) {
-        const double ax = vx[i], ay = vy[i];
-        const int n = (i + 1) % 3;
-        const double bx = vx[n], by = vy[n];
-        const double cp = (bx - ax) * (ty - ay) - (by - ay) * (tx - ax);
-        if (cp > epsx) hasPos = true;
-        else if (cp < -epsx) hasNeg = true;
-        else hasMaybe = true;
-        if (hasPos && hasNeg) return false;
+// Is (qx, qy) inside the triangle (tx, ty)?  The reference's test (ConservativeRemapping.cpp:463-514), with its tolerances: a point
+// within 1 mm (in both coordinates) of a corner, or with an edge cross product inside the band of +-1e-8, is "on the boundary" and
+// gets the answer the caller asks for (`boundary_counts`); cross products of both signs mean outside.
+NXS_HD inline bool inside3(const double *tx, const double *ty, double qx, double qy, bool boundary_counts) {
+    const double corner_tol = 1.e-3, band = 1e-8;
+    for (int k = 0; k < 3; ++k)
+        if (fabs(qx - tx[k]) < corner_tol && fabs(qy - ty[k]) < corner_tol) return boundary_counts;
+    int left = 0, right = 0;
+    for (int k = 0; k < 3; ++k) {
+        const int k1 = (k + 1) % 3;
+        const double turn = (tx[k1] - tx[k]) * (qy - ty[k]) - (ty[k1] - ty[k]) * (qx - tx[k]);
+        if (turn > band) ++left;
+        else if (turn < -band) ++right;
     }
-    if (hasMaybe) return inclusive;
-    return true;
+    if (left > 0 && right > 0) return false;
+    return (left + right < 3) ? boundary_counts : true;
 }
 
-// checkIfIntersecting, ConservativeRemapping.cpp:518-553
-NXS_HD inline bool intersect3(double X, double Y, double Xp, double Yp, const double *cx, const double *cy, Pt *pts, int &npts) {
-    bool ret = false;
-    const double s1_x = X - Xp, s1_y = Y - Yp;
-    int prev = 2;
-    for (int i = 0; i < 3; prev = i++) {
-        const double s2_x = cx[i] - cx[prev], s2_y = cy[i] - cy[prev];
-        const double det = -s2_x * s1_y + s1_x * s2_y;
-        if (fabs(det) < 1e-6) continue;
-        const double rdet = 1. / det;
-        const double s = (-s1_y * (Xp - cx[prev]) + s1_x * (Yp - cy[prev])) * rdet;
-        const double t = (s2_x * (Yp - cy[prev]) - s2_y * (Xp - cx[prev])) * rdet;
-        if (s > 0. && s < 1. && t > 0. && t < 1.) {
-            if (npts < kMaxPoints) { pts[npts].x = Xp + (t * s1_x); pts[npts].y = Yp + (t * s1_y); }
+// The proper crossings of the segment (x0, y0) -> (x1, y1) with the three edges of the cell, appended to pts in edge order (edge k
+// runs from corner k-1 to corner k).  Parametric form of ConservativeRemapping.cpp:518-553: with d the segment and e the edge,
+// D = -e.x*d.y + d.x*e.y (edges with |D| < 1e-6 are taken as parallel), both parameters strictly inside (0, 1), the point taken on
+// the segment as start + t*d.  Every product and sum in the reference's operand order.
+NXS_HD inline bool intersect3(double x1, double y1, double x0, double y0, const double *cx, const double *cy, Pt *pts, int &npts) {
+    bool crossed = false;
+    const double dx = x1 - x0, dy = y1 - y0;
+    for (int k = 0, from = 2; k < 3; from = k++) {
+        const double ex = cx[k] - cx[from], ey = cy[k] - cy[from];
+        const double D = -ex * dy + dx * ey;
+        if (fabs(D) < 1e-6) continue;
+        const double inv = 1. / D;
+        const double on_edge = (-dy * (x0 - cx[from]) + dx * (y0 - cy[from])) * inv;
+        const double on_segment = (ex * (y0 - cy[from]) - ey * (x0 - cx[from])) * inv;
+        if (on_edge > 0. && on_edge < 1. && on_segment > 0. && on_segment < 1.) {
+            if (npts < kMaxPoints) { pts[npts].x = x0 + (on_segment * dx); pts[npts].y = y0 + (on_segment * dy); }
             ++npts;
-            ret = true;
+            crossed = true;
         }
     }
-    return ret;
+    return crossed;
 }
 
 // What checkTriangle computes for ONE old triangle against the cell, independent of the recursion:
