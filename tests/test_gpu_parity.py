@@ -350,12 +350,14 @@ def test_fused_substep_kernel_is_bitwise_equal_to_the_per_loop_kernels(dyn, subs
         assert np.array_equal(outs[0][k], outs[1][k]), k
 
 
-def test_smoother_with_open_water_five_sweeps_per_launch_equals_sweep_by_sweep():
-    """The toy case has an ice-free strip: the open-water smoother really changes velocities there.  fused=1 runs it five sweeps
-    per launch on node-ring patches (k_smooth_multi), fused=0 one sweep per launch (k_smooth): the same bits after three steps."""
+@pytest.mark.parametrize("smooth_depth", [0, 5, 10, 25])
+def test_smoother_with_open_water_several_sweeps_per_launch_equal_sweep_by_sweep(smooth_depth):
+    """The toy case has an ice-free strip: the open-water smoother really changes velocities there.  fused=1 runs it 5, 10 or 25 sweeps
+    per launch on node-ring patches of that many rings (k_smooth_multi; 0 = automatic: ten where they fit the LDS), fused=0 one sweep per
+    launch (k_smooth): the same bits after three steps."""
     outs = []
-    for fused in (1, 0):
-        fe, ref, lm = _pair("toy", 3, options={"fused": fused})
+    for options in ({"fused": 1, "smooth_depth": smooth_depth}, {"fused": 0}):
+        fe, ref, lm = _pair("toy", 3, options=options)
         outs.append(fe.get_state())
         fe.close()
     for k in STATE_KEYS:
