@@ -546,6 +546,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": "k_substep_resident (ONE launch per step: the fused sub-step loop, patches waiting for their neighbours only)" if tm["substep_launches"] == 1
+                      else f"k_substep_multi ({S // max(tm['substep_launches'], 1)} sub-steps per launch on patches with that many rings of halo)" if tm["substep_launches"] < S
                       else "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve + mesh move)" if launches_per_substep == 1 else f"sub-step loop ({launches_per_substep} launches per sub-step incl. halo pack/unpack)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
