@@ -177,11 +177,18 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
     rank, the bits of (c), and the fastest of those is used (NXS_HALO_VARIANT=resident|inkernel|separate forces one)."""
     import numpy as np
     from nextsim_amd import dynamics
-    variants = {"resident": (4, 1, " + exchange inside ONE resident launch per step"), "inkernel": (3, 1, " + exchange inside the sub-step kernel"),
+    variants = {"resident": (4, 1, " + exchange inside ONE resident launch per step"),
+                "resident_overlap": (4, 1, " + exchange inside ONE resident launch per step, interior elements computed under the exchange"),
+                "inkernel": (3, 1, " + exchange inside the sub-step kernel"),
                 "separate": (3, 0, ", separate push/pull kernels")}
+
+    def select(name):
+        fe.set_option("resident_overlap", 1 if name == "resident_overlap" else 0)
+        fe.set_option("fused", variants[name][0]); fe.set_option("halo_fused", variants[name][1])
+
     force = os.environ.get("NXS_HALO_VARIANT")
     if force in variants:
-        fe.set_option("fused", variants[force][0]); fe.set_option("halo_fused", variants[force][1])
+        select(force)
         return variants[force][2] + " (forced)"
 
     def agree(flag):   # every rank calls this the same number of times, whatever happened to it
@@ -195,20 +202,21 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
         return out
 
     # (NXS_BENCH_TRY_RESIDENT=1: rehearsal on a shared device with a mesh small enough for every rank's workgroups to be resident)
-    order = (["resident"] if (own_device or os.environ.get("NXS_BENCH_TRY_RESIDENT") == "1") else []) + ["inkernel", "separate"]
+    order = (["resident", "resident_overlap"] if (own_device or os.environ.get("NXS_BENCH_TRY_RESIDENT") == "1") else []) + ["inkernel", "separate"]
     results = {}
     for name in order:
-        fused, halo_fused, _ = variants[name]
+        if name == "resident_overlap" and "resident" not in results:
+            continue                               # (the same on every rank: `results` only holds what all ranks agreed on)
         mine, state, secs = True, None, 0.0
         try:
-            fe.set_option("fused", fused); fe.set_option("halo_fused", halo_fused)
+            select(name)
             fe.put_state(f)
             fe.step(); fe.synchronize()           # (graph capture happens here)
             state = fe.get_state()
             t0 = time.perf_counter()
             fe.step(); fe.step(); fe.synchronize()
             secs = time.perf_counter() - t0
-            if name == "resident" and fe.timing()["substep_launches"] != 1:
+            if name.startswith("resident") and fe.timing()["substep_launches"] != 1:
                 mine = False                       # the library fell back (partition too large for one round of workgroups)
         except dynamics.NxsError as e:
             print(f"[bench rank {rank}] halo variant {name}: {e}", file=sys.stderr, flush=True)
@@ -229,7 +237,7 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
     ok = {n: agree(all(np.array_equal(st[k], ref[k]) for k in ref)) for n, (st, _) in results.items()}
     good = [n for n in order if n in results and ok[n]]
     best = min(good, key=lambda n: results[n][1])
-    fe.set_option("fused", variants[best][0]); fe.set_option("halo_fused", variants[best][1])
+    select(best)
     note = "; ".join(f"{n} {results[n][1] * 500:.2f} ms/step" + ("" if ok[n] else " (bits differ: rejected)") for n in order if n in results)
     dropped = [n for n in order if n not in results]
     return variants[best][2] + f" (kept variants bit-identical to the separate kernels; {note}" + (f"; failed: {', '.join(dropped)}" if dropped else "") + ")"

@@ -148,6 +148,7 @@ struct nxs_dyn_handle {
     // v4: the whole sub-step loop in one resident launch (option "fused" = 4; see k_substep_resident)
     DevResident res{};
     bool res_ready = false, res_failed = false;
+    int res_overlap = 0;  // option resident_overlap (several ranks): interior elements of the next sub-step computed while the exchange is awaited
     size_t res_lds = 0;
     double *d_vt3 = nullptr;
     double *smooth_second = nullptr;       // the ring slot that equals M_VT after the sub-step loop (the smoother's second buffer), or NULL
@@ -511,6 +512,9 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
         h->fused = (int)value; h->res_failed = false; release_graph(h); return NXS_OK;
+    }
+    if (!std::strcmp(key, "resident_overlap")) {
+        h->res_overlap = value != 0; h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "smooth_depth")) {
         if (value != 0 && value != 5 && value != 10 && value != 25) return fail(h, NXS_ERR_INVALID, "smooth_depth must be 0 (auto), 5, 10 or 25");
@@ -1495,7 +1499,10 @@ int build_resident(nxs_dyn_handle *h) {
     // every workgroup must be resident at once
     int per_cu = 0, cus = 0;
     const bool p4 = h->dp.ers_int == 4;
-    hipError_t e = mr ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true>, 512, h->res_lds)
+    const bool ovl = mr && h->res_overlap;
+    hipError_t e = ovl ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, true>, 512, h->res_lds)
+                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, true, true>, 512, h->res_lds))
+                 : mr ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true>, 512, h->res_lds)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, true>, 512, h->res_lds))
                       : (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, false>, 512, h->res_lds)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, false>, 512, h->res_lds));
@@ -1509,6 +1516,40 @@ int build_resident(nxs_dyn_handle *h) {
     int rc;
     DevResident &r = h->res;
     r = DevResident{};
+    if (ovl) {
+        // Interior elements first: an element none of whose corners is a halo node of its patch needs nothing from outside, so its next
+        // update can be computed while the patch waits for the exchange.  A stable partition of every patch's element list (whole
+        // wavefronts of interior elements only: ecut is a multiple of 64); the fan entries keep their (ascending global element) order and
+        // only name the new slots, so the additions of the gather stay the reference's.
+        std::vector<int> rpelem(hp.pelem.size()), ecut(nP, 0), newslot(hp.Emax);
+        std::vector<unsigned short> rptri(hp.ptri.size()), rpfan(hp.pfan.size(), 0xFFFF);
+        long long tot_early = 0, tot_e = 0;
+        for (int q = 0; q < nP; ++q) {
+            const int nE = hp.elem_cnt[q], nO = hp.own_cnt[q];
+            const unsigned short *tq = hp.ptri.data() + (size_t)q * hp.Emax * 4;
+            auto interior = [&](int l) { return tq[4 * l] < nO && tq[4 * l + 1] < nO && tq[4 * l + 2] < nO; };
+            int nint = 0;
+            for (int l = 0; l < nE; ++l) nint += interior(l) ? 1 : 0;
+            int a = 0, b2 = nint;
+            for (int l = 0; l < nE; ++l) newslot[l] = interior(l) ? a++ : b2++;
+            for (int l = nE; l < hp.Emax; ++l) newslot[l] = l;
+            for (int l = 0; l < hp.Emax; ++l) {
+                rpelem[(size_t)q * hp.Emax + newslot[l]] = hp.pelem[(size_t)q * hp.Emax + l];
+                for (int k = 0; k < 4; ++k) rptri[((size_t)q * hp.Emax + newslot[l]) * 4 + k] = tq[4 * l + k];
+            }
+            for (size_t i = (size_t)q * hp.Wp * hp.Pmax; i < (size_t)(q + 1) * hp.Wp * hp.Pmax; ++i) {
+                const unsigned short ent = hp.pfan[i];
+                rpfan[i] = ent == 0xFFFF ? ent : (unsigned short)((newslot[ent >> 3] << 3) | (ent & 7));
+            }
+            ecut[q] = (nint / 64) * 64;
+            tot_early += ecut[q]; tot_e += nE;
+        }
+        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %.1f %% of the patch elements computed under the exchange\n", h->rank, 100. * tot_early / std::max(1ll, tot_e));
+        if ((rc = dev_upload(h, h->patch_allocs, &r.pelem, rpelem))) return rc;
+        if ((rc = dev_upload(h, h->patch_allocs, &r.ptri, rptri))) return rc;
+        if ((rc = dev_upload(h, h->patch_allocs, &r.pfan, rpfan))) return rc;
+        if ((rc = dev_upload(h, h->patch_allocs, &r.ecut, ecut))) return rc;
+    }
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr, nbr))) return rc;
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr_cnt, cnt))) return rc;
     if ((rc = dev_upload(h, h->patch_allocs, &r.gslot, gslot))) return rc;
@@ -1624,7 +1665,10 @@ int run_substeps(nxs_dyn_handle *h) {
             const bool p4 = h->dp.ers_int == 4;
 #define RESIDENT(PP, HH, HFP, NB) hipLaunchKernelGGL((k_substep_resident<512, PP, HH>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, HFP, NB)
             if (mr) {
-                if (p4) RESIDENT(true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary); else RESIDENT(false, true, (const HaloFused *)h->d_hf, h->hf.n_boundary);
+#define RESIDENT_OVL(PP) hipLaunchKernelGGL((k_substep_resident<512, PP, true, true>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, (const HaloFused *)h->d_hf, h->hf.n_boundary)
+                if (h->res_overlap) { if (p4) RESIDENT_OVL(true); else RESIDENT_OVL(false); }
+                else if (p4) RESIDENT(true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary); else RESIDENT(false, true, (const HaloFused *)h->d_hf, h->hf.n_boundary);
+#undef RESIDENT_OVL
                 // the exchange of the last sub-step: the ghosts land in M_VT and make their last move (the earlier ones were made in the kernel)
                 const int tr = h->recv_offsets[h->recv_procs.size()];
                 hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, h->ds.VT, h->dm, h->ds, tr, h->d_recv_index,

@@ -1225,6 +1225,11 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
 // wait is bounded and reports through r.error), one element per thread (Emax <= T), not mEVP.
 #define NXS_RES_NBR 24
 struct DevResident {
+    // variant OVL only (option resident_overlap): the patch's elements with the INTERIOR ones first (no corner is a halo node of the patch)
+    const int *pelem;             // [nP][Emax] as DevPatches::pelem in that order
+    const unsigned short *ptri;   // [nP][Emax][4]
+    const unsigned short *pfan;   // [nP][Wp][Pmax] DevPatches::pfan naming the new slots (entry order unchanged: ascending global element)
+    const int *ecut;              // [nP] the first ecut elements (a multiple of 64, all interior) are updated for sub-step s + 1 while the exchange of sub-step s is awaited
     const int *pnbr;       // [nP][NXS_RES_NBR] the patches that own this patch's halo nodes
     const int *pnbr_cnt;   // [nP]
     unsigned int *flag;    // [nP * 32] sub-steps published by each patch (one counter per 128-byte line; zeroed before every launch)
@@ -1246,12 +1251,50 @@ __device__ __forceinline__ double ld_agent(const double *p) {
     return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// element phase of the resident kernel for this thread's element (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467);
+// the OVL variant calls it from three places, the plain variant keeps its own copy in line
+template <bool POW4>
+__device__ __forceinline__ void resident_element(const DevParams &p, const double *__restrict__ erec, const bool bbm, const bool skip, const int e,
+                                                 const ushort4 tr, const int tt, const int Emax, const double *lu, const double *lv,
+                                                 const double *ldx, double *lF, double sig[3], double &damage) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double c_expC, volume, c_pmax, c_heal, c_coh, c_dxs = 1.;
+    {
+        const d2 *q = reinterpret_cast<const d2 *>(erec) + 3 * (size_t)e;
+        const d2 r0 = q[0], r1 = q[1], r2 = q[2];
+        c_expC = r0.x; volume = r0.y; c_pmax = r1.x; c_heal = r1.y; c_coh = r2.x;
+        const int dxi = (int)(__double_as_longlong(r2.y) & 0xffffffffll);
+        if (bbm) c_dxs = (double)(dxi < 0 ? ~dxi : dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
+    }
+    double dxN[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dxN[k] = ldx[(size_t)k * Emax + tt];
+    if (skip) {
+        sig[0] = sig[1] = sig[2] = 0.;
+        damage = 0.;
+    } else {
+        const double u[3] = {lu[tr.x], lu[tr.y], lu[tr.z]};
+        const double v[3] = {lv[tr.x], lv[tr.y], lv[tr.z]};
+        if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, c_expC, c_pmax, c_heal, c_dxs, c_coh);
+        else vp_stress(p, dxN, u, v, sig, c_expC);
+    }
+    double F[6];
+    corner_forces(volume, sig, dxN, F);
+    d2 *lF2 = reinterpret_cast<d2 *>(lF);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) lF2[(size_t)k * Emax + tt] = d2{F[k], F[k + 3]};
+}
+
 // HALO: several ranks.  Boundary patches (they lead the grid, see HaloFused) also send their sent nodes into the neighbour ranks'
 // mailboxes in the node phase (exchange x0 + s, half (x0 + s) & 1), read their ghost nodes from this rank's mailbox before the next
 // element phase -- after the neighbours' flags have reached x0 + s + 1 -- and move the ghost nodes assigned to them; the last
 // boundary patch to finish a sub-step raises this rank's flag at the neighbours, in sub-step order.  The exchange of the LAST
 // sub-step is taken by k_halo_pull after the launch (with the last mesh move of the ghosts), as in the one-launch-per-sub-step path.
-template <int T, bool POW4, bool HALO>
+// OVL (option resident_overlap, with HALO): the interior elements of a patch -- no corner is a halo node -- run one exchange ahead: their
+// update for sub-step s + 1 is computed while the exchange of sub-step s is awaited, only the rim elements follow the halo loads.  Inside one
+// GPU that buys nothing (the other workgroup of the CU fills the wait); between GPUs the wait is a round trip over xGMI.  Same
+// operations on the same values in the same order: bit-identical (bench.py keeps whichever variant is faster on the machine it runs on).
+template <int T, bool POW4, bool HALO, bool OVL = false>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
                                                         const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
                                                         const HaloFused *__restrict__ hfp, int n_boundary) {
@@ -1302,8 +1345,8 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     ushort4 tr = make_ushort4(0, 0, 0, 0);
     double sig[3] = {0., 0., 0.}, damage = 0.;
     if (has_elem) {
-        const int eraw = pp.pelem[(size_t)blk * Emax + t];
-        tr = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + t];
+        const int eraw = (OVL ? r.pelem : pp.pelem)[(size_t)blk * Emax + t];
+        tr = reinterpret_cast<const ushort4 *>(OVL ? r.ptri : pp.ptri)[(size_t)blk * Emax + t];
         writer = eraw >= 0;
         e = writer ? eraw : ~eraw;
         const d2 *S4 = reinterpret_cast<const d2 *>(Sc) + 2 * (size_t)e;
@@ -1312,10 +1355,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const long long pk = __double_as_longlong(w.erec[6 * (size_t)e + 5]);
         skip = bbm ? (int)(pk & 0xffffffffll) < 0 : (pk >> 32) != 0;
     }
+    // OVL: whole wavefronts of interior elements ("early") run one exchange ahead, the others ("late") follow the halo loads
+    const bool early = OVL && t < r.ecut[blk], late = has_elem && !early;
     const bool has_node = t < nO;
     const int n = has_node ? pn[t] : 0;
     unsigned char nf = 0;
-    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
+    const unsigned short *pf = (OVL ? r.pfan : pp.pfan) + (size_t)blk * pp.Wp * Pmax;
     if (has_node) {
         unsigned idx[8];
 #pragma unroll
@@ -1358,6 +1403,13 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
     __syncthreads();  // (sx / sy are read; lF may be written from here on)
 
+    if (OVL && early) {  // sub-step 0 of the interior elements
+        int tt = t;
+        asm volatile("" : "+v"(tt));
+        const DevParams *pl = pdev;
+        asm volatile("" : "+s"(pl));
+        resident_element<POW4>(*pl, w.erec, bbm, skip, e, tr, tt, Emax, lu, lv, ldx, lF, sig, damage);
+    }
     for (int ss = 0; ss < S; ++ss) {
         // (the thread index through an opaque copy: otherwise every LDS address of the loop body -- some forty of them -- is computed
         // once before the loop and kept in a register of its own across all the sub-steps)
@@ -1375,7 +1427,9 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #endif
         RSTAMP(0);
         // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467)
-        if (has_elem) {
+        if (OVL) {
+            if (late) resident_element<POW4>(p, w.erec, bbm, skip, e, tr, tt, Emax, lu, lv, ldx, lF, sig, damage);  // (the interior ones are already one sub-step ahead)
+        } else if (has_elem) {
             // the element constants: one 48-byte record, re-read every sub-step (it stays in the L2; the loads were issued ahead of
             // the barrier above) -- held in registers across the loop they pushed 36 others out to scratch
             double c_expC, volume, c_pmax, c_heal, c_coh, c_dxs = 1.;
@@ -1477,6 +1531,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
         if (ss == S - 1) break;
         if (t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (OVL && early) {  // the interior elements' update for sub-step ss + 1, under the exchange: their corners are own nodes (lu / lv of
+                             // the node phase above), their corner forces of sub-step ss have been read (the barrier above)
+            const DevParams *pe = pdev;
+            asm volatile("" : "+s"(pe));
+            resident_element<POW4>(*pe, w.erec, bbm, skip, e, tr, tt, Emax, lu, lv, ldx, lF, sig, damage);
+        }
         if (HALO && boundary && t >= 64 && t < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
             const int k = t - 64;
             const long long t0 = wall_clock64();

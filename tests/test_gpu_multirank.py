@@ -234,15 +234,18 @@ def test_ipc_connect_checks_its_tables_against_what_the_neighbour_published():
         fe.close()
 
 
-@pytest.mark.parametrize("world,kind,rpp,over", [(2, "small", 1, {}), (3, "small", 1, {"ragged_seed": 1}), (3, "small", 1, {"dynamics_type": 3}),
-                                                 (8, "10km", 2, {})])
-def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rpp, over, tmp_path):
+@pytest.mark.parametrize("world,kind,rpp,over,overlap", [(2, "small", 1, {}, 0), (3, "small", 1, {"ragged_seed": 1}, 0), (3, "small", 1, {"dynamics_type": 3}, 0),
+                                                         (8, "10km", 2, {}, 0), (2, "small", 1, {}, 1), (3, "small", 1, {"ragged_seed": 1, "dynamics_type": 3}, 1),
+                                                         (8, "10km", 2, {}, 1), (2, "40km", 1, {}, 1)])
+def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rpp, over, overlap, tmp_path):
     """Option fused = 4 on several ranks: ONE launch per rank for the whole sub-step loop; boundary patches send into the
     neighbour ranks' mailboxes and read their ghosts from their own once per sub-step, the last boundary patch of a sub-step
     raises the flags (in sub-step order although patches far apart may be several sub-steps apart), ghost nodes are moved by
     the patch that stages them first.  Bitwise equal to separate push / pull kernels around one kernel per sub-step, and within
-    1e-10 of the multi-rank oracle.  (The meshes are small enough for every rank's workgroups to be resident on ONE device.)"""
-    reps = _run(world, kind, 1, tmp_path, "ipc", over=dict(over, options={"fused": 4}), ranks_per_proc=rpp)
+    1e-10 of the multi-rank oracle.  (The meshes are small enough for every rank's workgroups to be resident on ONE device.)
+    overlap = 1: option resident_overlap -- the interior elements of every patch run one exchange ahead (their next update is computed
+    while the exchange is awaited): the same bits."""
+    reps = _run(world, kind, 1, tmp_path, "ipc", over=dict(over, options={"fused": 4, "resident_overlap": overlap}), ranks_per_proc=rpp)
     for r in reps:
         assert r["ok"], r
         assert r["fused_equals_separate"] is True, r
