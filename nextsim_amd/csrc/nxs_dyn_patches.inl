@@ -405,6 +405,20 @@ int upload_patches(nxs_dyn_handle *h) {
         cus = std::max(cus, 1);
         const int slots512 = 2 * cus, slots256 = 4 * cus;  // 16 waves per CU (112 VGPRs): 2 x 512 or 4 x 256 threads
         bool done = false;
+        if (h->fused == 4 && m.No > 0) {
+            // the resident sub-step loop was asked for (before set_mesh): ONE round of 512-thread workgroups with one element per thread --
+            // two patches per CU, or one of twice the size where those would be smaller than ~100 nodes (10 km, 30 k nodes: 255 patches of
+            // 116 nodes 0.625 ms/step, 462 of 64 nodes 0.653) -- also where the one-launch-per-sub-step kernel would take smaller patches
+            // (65 k - 90 k nodes: 256-thread workgroups, four per CU)
+            int Pr = (int)(((long long)m.No + 2 * cus - 1) / (2 * cus));
+            if (Pr < 100) Pr = (int)(((long long)m.No + cus - 1) / cus);
+            Pr = std::max(32, (Pr + 3) & ~3);
+            for (int it = 0; it < 4 && Pr <= 208 && !done; ++it, Pr += 4) {  // orphan patches (multi-rank) may add a few workgroups
+                if (!build(Pr)) break;
+                done = hp.Emax <= 512 && hp.nP <= 2 * cus && h->fused_lds <= 80 * 1024;
+                if (done) P = Pr;
+            }
+        }
         for (int k = 1; k <= 64 && !done; ++k) {
             P = (int)(((long long)m.No + (long long)k * slots512 - 1) / ((long long)k * slots512));
             P = (P + 3) & ~3;

@@ -1,3 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r2b_suite3.log 2>&1; echo "suite rc $?"
-tail -3 gpurun_out/r2b_suite3.log
+timeout -k 10 800 python3 scripts/soak_resident.py 100 2>&1 | grep -v amdgpu.ids | tail -6
