@@ -274,6 +274,9 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  (one rank, or several with the device-direct mailboxes and "halo_fused" 1: the exchange between ranks then happens
  *                  inside that launch too; not mEVP; one element per thread and every workgroup resident at once -- checked, else
  *                  as 1): for a device the handle has to itself -- one rank of eight of a 1.5 M-triangle mesh: 0.85 instead of 1.3 ms
+ *   "resident_dryrun"  (an action, not a setting) builds the tables of the resident loop for the mesh and halo lists set so far -- no transport,
+ *                  no neighbours needed -- and fails with NXS_ERR_INVALID when this partition cannot run it (a patch with more elements than
+ *                  threads, more than one round of workgroups, LDS, > 24 neighbouring patches): a partition can be checked on its own
  *   "resident_overlap"  with "fused" 4 on several ranks: 1 = the interior elements of every patch (no corner is a halo node) run one exchange
  *                  ahead -- their next update is computed while the exchange of the sub-step is awaited; default 0 (inside one GPU the wait is
  *                  filled by the other workgroup of the CU anyway; between GPUs it is a round trip over xGMI: bench.py times both and keeps one)

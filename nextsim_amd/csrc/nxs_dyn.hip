@@ -198,6 +198,9 @@ namespace {
 
 // the kernel family of this step: option "fused", except that the branch trace lives in the per-loop kernels
 inline int eff_fused(const nxs_dyn_handle *h) { return h->trace_branches ? 0 : h->fused; }
+int build_halo_fused(nxs_dyn_handle *h);  // (defined with the launch logic below)
+int build_resident(nxs_dyn_handle *h);
+bool multi_rank(const nxs_dyn_handle *h);
 
 int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -512,6 +515,17 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
         h->fused = (int)value; h->res_failed = false; release_graph(h); return NXS_OK;
+    }
+    if (!std::strcmp(key, "resident_dryrun")) {  // builds the tables of the resident loop now (mesh and, on several ranks, halo lists set; no
+        // transport needed) and says whether this partition can run it: checks a rank's partition without its neighbours
+        if (!h->have_mesh || (multi_rank(h) && !h->have_halo)) return fail(h, NXS_ERR_STATE, "resident_dryrun needs set_mesh (and set_halo)");
+        HIPCHK(h, hipSetDevice(h->device));
+        h->res_ready = false; h->res_failed = false;
+        int rc = NXS_OK;
+        if (multi_rank(h) && !h->hf_ready && (rc = build_halo_fused(h))) return rc;
+        if ((rc = build_resident(h))) return rc;
+        if (!h->res_ready) return fail(h, NXS_ERR_INVALID, "the resident sub-step loop cannot run this partition (NXS_DEBUG_PATCHES=1 says why)");
+        return NXS_OK;
     }
     if (!std::strcmp(key, "resident_overlap")) {
         h->res_overlap = value != 0; h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;

@@ -4,8 +4,11 @@
 // Host: node patches for the fused sub-step kernel (see DevPatches).
 
 // order: owned nodes in the order they are cut into patches of P.
+// Ecap > 0: a patch is closed early when one more own node would take it past Ecap elements (the resident kernel holds one element per
+// thread; a partition whose own nodes are not contiguous along the numbering -- an RCB part of a Hilbert-numbered mesh -- otherwise has a few
+// patches of two distant blobs with 1.5 times the elements of the others, and the whole round waits for them).
 bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int No, int P,
-                              const std::vector<int> &order, HostPatches &out) {
+                              const std::vector<int> &order, HostPatches &out, int Ecap = 0) {
     // node -> elements CSR
     std::vector<int> off(Nn + 1, 0);
     for (int k = 0; k < 3; ++k) for (int e = 0; e < Ne; ++e) off[t[k][e] + 1]++;
@@ -13,9 +16,31 @@ bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *
     std::vector<int> adj(off[Nn]), fill(off.begin(), off.end() - 1);
     for (int e = 0; e < Ne; ++e) for (int k = 0; k < 3; ++k) adj[fill[t[k][e]]++] = e;  // ascending e per node
 
-    const int nNodePatches = (No + P - 1) / P;
+    std::vector<int> pstart;  // patch q owns order[pstart[q] .. pstart[q + 1])
+    if (Ecap <= 0) {
+        for (int a = 0; a < No; a += P) pstart.push_back(a);
+    } else {
+        std::vector<int> seen(Ne, -1);
+        int cnt_n = 0, cnt_e = 0, q = 0;
+        if (No > 0) pstart.push_back(0);
+        for (int i = 0; i < No; ++i) {
+            const int n = order[i];
+            int fresh = 0;
+            for (int j = off[n]; j < off[n + 1]; ++j) fresh += seen[adj[j]] != q ? 1 : 0;
+            if (cnt_n > 0 && (cnt_n == P || cnt_e + fresh > Ecap)) {  // close the patch before this node
+                pstart.push_back(i);
+                ++q; cnt_n = 0; cnt_e = 0;
+                fresh = off[n + 1] - off[n];
+            }
+            for (int j = off[n]; j < off[n + 1]; ++j) if (seen[adj[j]] != q) { seen[adj[j]] = q; }
+            ++cnt_n; cnt_e += fresh;
+        }
+    }
+    const int nNodePatches = (int)pstart.size();
+    pstart.push_back(No);
     std::vector<int> patch_of(Nn, -1);
-    for (int i = 0; i < No; ++i) patch_of[order[i]] = i / P;
+    for (int q = 0; q + 1 < (int)pstart.size(); ++q)
+        for (int i = pstart[q]; i < pstart[q + 1]; ++i) patch_of[order[i]] = q;
     // writer patch of an element = smallest patch id among its owned nodes; none -> orphan
     std::vector<int> writer(Ne, -1);
     std::vector<int> orphans;
@@ -37,7 +62,7 @@ bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *
     std::vector<int> mark(Ne, -1), slot_of(Nn, -1);
     size_t tot_e = 0;
     for (int q = 0; q < nNodePatches; ++q) {
-        const int a = q * P, bnd = std::min(No, a + P);
+        const int a = pstart[q], bnd = pstart[q + 1];
         own_cnt[q] = bnd - a;
         auto &el = pel[q];
         for (int i = a; i < bnd; ++i) {
@@ -61,7 +86,7 @@ bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *
     for (int q = 0; q < nP; ++q) {
         auto &nd = pnd[q];
         if (q < nNodePatches) {
-            const int a = q * P;
+            const int a = pstart[q];
             for (int i = 0; i < own_cnt[q]; ++i) { nd.push_back(order[a + i]); slot_of[order[a + i]] = i; }
         }
         std::vector<int> halo;
@@ -148,17 +173,17 @@ void hilbert_order(const double *x0, const double *y0, int No, std::vector<int> 
 }
 
 bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
-                   int No, int P, HostPatches &out) {
+                   int No, int P, HostPatches &out, int Ecap = 0) {
     // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
     std::vector<int> order(No);
     for (int i = 0; i < No; ++i) order[i] = i;
-    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out);
+    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out, Ecap);
     if (ok && out.avg_elems_per_own_node <= 3.0) return true;
     // numbering without locality: cut patches along a Hilbert curve through the node coordinates
     // (consecutive runs of a Hilbert curve are compact blobs: small halos)
     hilbert_order(x0, y0, No, order);
     HostPatches alt;
-    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
+    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt, Ecap) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
         out = std::move(alt);
         out.used_hilbert = true;
         return true;
@@ -383,7 +408,9 @@ int upload_patches(nxs_dyn_handle *h) {
     HostPatches hp;
     int P = 0;
     auto build = [&](int PP) -> bool {
-        if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, PP, hp)) return false;
+        // patches of up to ~200 nodes hold one element per thread of a 512-thread workgroup (the resident loop requires it, and one round
+        // of the one-launch-per-sub-step kernel is as slow as its largest patch): none may exceed 480 elements
+        if (!build_patches(h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), m.Nn, m.Ne, m.No, PP, hp, (PP > NXS_T256_MAXP && PP <= 208) ? 480 : 0)) return false;
         h->fused_lds = (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax + 2) * sizeof(double);  // staged nodes, corner forces + their pair of zeros
         return true;
     };

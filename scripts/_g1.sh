@@ -1,2 +1,2 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 800 python3 scripts/soak_resident.py 100 2>&1 | grep -v amdgpu.ids | tail -6
+timeout -k 10 900 python3 -m pytest tests/test_gpu_multirank.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -3

@@ -253,3 +253,23 @@ def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rp
         assert r["crash"] == 0
         for k, e in r["errs"].items():
             assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
+
+
+@pytest.mark.parametrize("kind,world", [("2km", 8), ("10km", 8)])
+def test_every_partition_of_the_baseline_configurations_can_run_the_resident_loop(kind, world):
+    """BASELINE configs 3 and 4 on eight GPUs are meant to run the whole sub-step loop of a rank as ONE resident launch (option fused = 4).
+    Eight ranks of 183 k triangles cannot be resident together on one device, but whether a partition CAN run it is decided by its own
+    tables: every patch at most one element per thread (the RCB parts of a Hilbert-numbered mesh used to have a few patches of two distant
+    blobs with 530-650 elements: the patch cutter now closes a patch at 480), one round of workgroups, the LDS of two workgroups per CU,
+    at most 24 neighbouring patches.  Option resident_dryrun builds them (patches, boundary-first order, neighbour and ghost tables,
+    occupancy) without stepping: every rank must say yes, with and without the interior-first element order."""
+    import cases
+    from nextsim_amd import dynamics
+    gm, p, g, lms, fields = cases.make_case(kind, nparts=world)
+    for rank, lm in enumerate(lms):
+        fe = dynamics.FiniteElementDynamics(p)
+        fe.set_mesh(lm)
+        for overlap in (0, 1):
+            fe.set_option("resident_overlap", overlap)
+            fe.set_option("resident_dryrun", 1)      # raises NxsError when this partition could not run it
+        fe.close()
