@@ -1,2 +1,3 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python3 -m pytest tests/test_gpu_multirank.py tests/test_gpu_parity.py -x -q -m gpu 2>&1 | grep -v amdgpu.ids | tail -3
+timeout -k 10 900 python3 -m pytest tests -x -q -m gpu > gpurun_out/r2b_suite4.log 2>&1; echo "suite rc $?"
+tail -3 gpurun_out/r2b_suite4.log
