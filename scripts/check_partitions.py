@@ -1,5 +1,5 @@
 """Can every rank's partition run the resident sub-step loop?  (One GPU: each partition is cut and its tables are built, nothing is stepped.)
-    python3 scripts/_chk8.py [mesh] [ranks]"""
+    python3 scripts/check_partitions.py [mesh] [ranks]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
