@@ -137,6 +137,8 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
     gm, p, lm, f = build_case(kind, world, rank, state)
     fe = dynamics.FiniteElementDynamics(p, device=local_rank)
     fe.set_mesh(lm)
+    if os.environ.get("NXS_BENCH_PATCH_NODES"):   # rehearsals: e.g. two ranks of 91 k triangles with the 180-node patches a rank of eight has
+        fe.set_option("patch_nodes", int(os.environ["NXS_BENCH_PATCH_NODES"]))
     transport = "none"
     if world > 1:
         transport = setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn)

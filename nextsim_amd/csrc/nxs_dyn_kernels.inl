@@ -1522,7 +1522,9 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                     __builtin_amdgcn_s_sleep(1);
                     if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
                 }
-                __threadfence_system();  // the one release of the sub-step
+                // the one release of the sub-step -- a RELEASE only: __threadfence_system() is an acquire as well, i.e. it also invalidates this
+                // XCD's L2, and every patch on the XCD then re-reads its element constants from memory instead of the L2, every sub-step
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
                 for (int k = 0; k < hfp->ipc.ns; ++k)
                     __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (ss == S - 1) *hfp->ipc.seq_push = x0 + (unsigned long long)S;

@@ -1,0 +1,19 @@
+"""What a CU does on one rank of eight, rehearsed on ONE GPU: the 182 k-triangle mesh (1/8 of the 2 km mesh) over TWO ranks hosted by one process
+(two threads, two handles, in-process mailboxes), both cut into the 192-node patches (180 on the real machine; here 2 x 245 workgroups must fit the 512 slots together) a rank of eight has -- 2 x 256 workgroups, i.e. every CU holds
+two resident patches exactly as on the real machine, and the exchange between the ranks runs inside the resident launch (minus xGMI: both ranks
+share the device).  Prints each rank's per-step timing for the resident launch (plain and with the interior elements under the exchange) and checks
+the bits against the separate kernels and the oracle.        python3 scripts/rehearse_rank_of_eight.py [steps]"""
+import json, os, sys, tempfile, pathlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import test_gpu_multirank as T
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+for overlap in (0, 1):
+    with tempfile.TemporaryDirectory() as d:
+        reps = T._run(2, "h15600", steps, pathlib.Path(d), "ipc", over={"options": {"fused": 4, "patch_nodes": 192, "resident_overlap": overlap}}, ranks_per_proc=2)
+    for r in reps:
+        tm = r.get("timing", {})
+        if not r["ok"]: print("   ", {k: v for k, v in r.items() if k not in ("timing",)})
+        print(f"overlap {overlap} rank {r['rank']}: ok {r['ok']}, launches per step {r.get('launches_fused')}, bits equal to the separate kernels {r.get('fused_equals_separate')}, "
+              f"substeps {tm.get('substeps_ms', 0):.3f} ms, smoother {tm.get('smoother_ms', 0):.3f} ms, step {tm.get('total_ms', 0):.3f} ms; worst error vs the 2-rank oracle "
+              f"{max(r.get('errs', {'-': 0}).values()):.2e}", flush=True)

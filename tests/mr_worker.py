@@ -87,7 +87,9 @@ def run_rank(li, report):
         fe.set_option("halo_fused", 0)      # k_halo_push / k_halo_pull as separate kernels
     fe.put_state(fields[rank]); fe.set_forcing(fields[rank])
     all_gather(0)                           # nobody steps before every rank's state is resident
-    for _ in range(nsteps):
+    for i in range(nsteps):
+        if i == 2 and nsteps > 4:            # rehearsals time the steps after the warm-up ones (graph capture, lazily built tables)
+            fe.synchronize(); all_gather(0); fe.set_option("timing_reset", 1)
         fe.step()
     fe.synchronize()
     got = fe.get_state()
