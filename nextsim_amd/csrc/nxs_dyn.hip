@@ -1483,15 +1483,14 @@ int build_resident(nxs_dyn_handle *h) {
     std::vector<int> owner(Nn, -1);
     for (int q = 0; q < nP; ++q)
         for (int i = 0; i < hp.own_cnt[q]; ++i) owner[hp.pnodes[(size_t)q * hp.Mmax + i]] = q;
-    std::vector<int> nbr((size_t)nP * NXS_RES_NBR, -1), cnt(nP, 0), gcnt(nP, 0);
-    std::vector<std::vector<unsigned short>> glist(nP);
+    std::vector<int> nbr((size_t)nP * NXS_RES_NBR, -1), cnt(nP, 0);
     std::vector<char> ghost_taken(std::max(Nn - No, 1), 0);
     for (int q = 0; q < nP; ++q)
         for (int i = hp.own_cnt[q]; i < hp.node_cnt[q]; ++i) {
             const int g = hp.pnodes[(size_t)q * hp.Mmax + i];
-            if (g >= No) {  // a ghost node (several ranks): it comes from the mailbox; the first patch that stages it moves it
+            if (g >= No) {  // a ghost node (several ranks): it comes from the mailbox, and every patch that stages it notes what arrived in the ghosts' ring
                 if (!mr) { h->res_failed = true; return NXS_OK; }
-                if (!ghost_taken[g - No]) { ghost_taken[g - No] = 1; glist[q].push_back((unsigned short)i); }
+                ghost_taken[g - No] = 1;
                 continue;
             }
             const int o = owner[g];
@@ -1503,13 +1502,10 @@ int build_resident(nxs_dyn_handle *h) {
             if (cnt[q] == NXS_RES_NBR) { h->res_failed = true; return NXS_OK; }
             row[cnt[q]++] = o;
         }
-    for (int g = No; g < Nn; ++g) if (!ghost_taken[g - No]) { h->res_failed = true; return NXS_OK; }  // a ghost node no patch stages
-    int Gmax = 1;
-    for (int q = 0; q < nP; ++q) { gcnt[q] = (int)glist[q].size(); Gmax = std::max(Gmax, gcnt[q]); }
-    if (Gmax > 512) { h->res_failed = true; return NXS_OK; }
-    std::vector<unsigned short> gslot((size_t)nP * Gmax, 0);
-    for (int q = 0; q < nP; ++q) std::copy(glist[q].begin(), glist[q].end(), gslot.begin() + (size_t)q * Gmax);
-    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 4 * (size_t)Gmax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax;  // + the pair of zeros behind the corner forces + [Pmax][8] fan entries
+    for (int g = No; g < Nn; ++g) if (!ghost_taken[g - No]) { h->res_failed = true; return NXS_OK; }  // a ghost node no patch stages: nobody would note its velocities
+    if (mr && (int)h->send_procs.size() > NXS_RES_MAXNB) { h->res_failed = true; return NXS_OK; }
+    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax  // + the pair of zeros behind the corner forces + [Pmax][8] fan entries
+                 + (mr ? 16 * (size_t)std::min(hp.Mmax, 512) + 20 * (size_t)NXS_RES_MAXNB : 0);  // + the halo slots' sources and the neighbour ranks' mailbox addresses
     // every workgroup must be resident at once
     int per_cu = 0, cus = 0;
     const bool p4 = h->dp.ers_int == 4;
@@ -1566,9 +1562,10 @@ int build_resident(nxs_dyn_handle *h) {
     }
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr, nbr))) return rc;
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr_cnt, cnt))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &r.gslot, gslot))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &r.gcnt, gcnt))) return rc;
-    r.Gmax = Gmax;
+    if (mr) {  // the ghosts' ring: what arrived after every sub-step but the last
+        r.NG = Nn - No;
+        if ((rc = dev_alloc(h, h->patch_allocs, &r.gring, std::max<size_t>((size_t)(NXS_RES_MAXS - 1) * 2 * (size_t)r.NG, 1)  /* (any number of sub-steps the kernel accepts: the parameters may change) */))) return rc;
+    }
     if ((rc = dev_alloc(h, h->patch_allocs, &r.flag, 32 * (size_t)nP + NXS_RES_MAXS + 32))) return rc;  // counters behind the flags: one memset per launch
     r.cnt = r.flag + 32 * (size_t)nP;
     r.raised = r.cnt + NXS_RES_MAXS;
@@ -1577,7 +1574,7 @@ int build_resident(nxs_dyn_handle *h) {
     if (!h->d_vt3 && (rc = dev_alloc(h, h->state_allocs, &h->d_vt3, 2 * (size_t)Nn))) return rc;
     r.X0 = h->ds.VT2; r.X1 = h->d_vt3;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %d patches (%d x %d fit), %zu B of LDS each, up to %d neighbour patches, up to %d ghosts moved per patch\n", h->rank, nP, per_cu, cus, h->res_lds, *std::max_element(cnt.begin(), cnt.end()), Gmax);
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %d patches (%d x %d fit), %zu B of LDS each, up to %d neighbour patches, %d ghost nodes\n", h->rank, nP, per_cu, cus, h->res_lds, *std::max_element(cnt.begin(), cnt.end()), mr ? Nn - No : 0);
     h->res_ready = true;
     return NXS_OK;
 }
@@ -1683,7 +1680,10 @@ int run_substeps(nxs_dyn_handle *h) {
                 if (h->res_overlap) { if (p4) RESIDENT_OVL(true); else RESIDENT_OVL(false); }
                 else if (p4) RESIDENT(true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary); else RESIDENT(false, true, (const HaloFused *)h->d_hf, h->hf.n_boundary);
 #undef RESIDENT_OVL
-                // the exchange of the last sub-step: the ghosts land in M_VT and make their last move (the earlier ones were made in the kernel)
+                // the ghosts' mesh moves of all sub-steps but the last, from the ring the launch filled ...
+                if (move_dt != 0. && h->res.NG > 0 && S > 1)
+                    hipLaunchKernelGGL(k_ghost_ring_move, dim3(nblocks(h->res.NG)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, (const double *)h->res.gring, h->res.NG, S - 1, move_dt);
+                // ... and the exchange of the last sub-step: the ghosts land in M_VT and make their last move
                 const int tr = h->recv_offsets[h->recv_procs.size()];
                 hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, h->ds.VT, h->dm, h->ds, tr, h->d_recv_index,
                                    h->d_recv_seg, h->d_recv_off, h->ipc, move_dt, 0, h->d_recv_procs, 1);

@@ -1238,11 +1238,11 @@ struct DevResident {
     // several ranks (the device-direct mailboxes of HaloFused inside the resident loop):
     unsigned int *cnt;     // [NXS_RES_MAXS] boundary patches that have finished each sub-step (zeroed before every launch)
     unsigned int *raised;  // [1] sub-steps whose exchange has been published to the neighbour ranks (keeps the flags monotone)
-    const unsigned short *gslot;  // [nP][Gmax] staged slots of the ghost nodes whose M_UM / M_UT this patch moves (each ghost: one patch)
-    const int *gcnt;       // [nP]
-    int Gmax;
+    double *gring;         // [S - 1][2 NG] the ghost nodes' velocities as they arrived after every sub-step but the last ([u-block | v-block] of the NG = Nn - No
+    int NG;                //   ghosts): k_ghost_ring_move applies their mesh moves after the launch -- nothing of that sits in the sub-step loop
 };
 #define NXS_RES_MAXS 512
+#define NXS_RES_MAXNB 16  // neighbour ranks whose mailbox addresses the several-rank variant keeps in LDS
 
 __device__ __forceinline__ void st_agent(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1306,9 +1306,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     // reads (pad entries and ghost corners read the zeros: x - (+0) == x, bit for bit) followed by the reference's subtractions in
     // the reference's order -- not eight dependent rounds of "entry, branch, two reads, two subtractions"
     double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*d2 [3][Emax] + 1*/, *ldx = lF + 6 * (size_t)Emax + 2 /*[6][Emax]*/,
-           *lN = ldx + 6 * (size_t)Emax /*[10][Pmax]*/, *lM = lN + 10 * (size_t)Pmax /*[4][Pmax]*/, *lG = lM + 4 * (size_t)Pmax /*[4][Gmax]*/;
+           *lN = ldx + 6 * (size_t)Emax /*[10][Pmax]*/, *lM = lN + 10 * (size_t)Pmax /*[4][Pmax]*/;
     d2 *lF2 = reinterpret_cast<d2 *>(lF);
-    uint4 *lFan4 = reinterpret_cast<uint4 *>(lG + 4 * (size_t)r.Gmax);  // [Pmax] the first eight fan entries of every own node as indices into lF2 (16 bits each)
+    uint4 *lFan4 = reinterpret_cast<uint4 *>(lM + 4 * (size_t)Pmax);  // [Pmax] the first eight fan entries of every own node as indices into lF2 (16 bits each)
+    // HALO: what a boundary patch needs every sub-step, looked up ONCE (each of these was a chain of two or three dependent loads in the loop):
+    int4 *lH = reinterpret_cast<int4 *>(lFan4 + Pmax);   // [min(Mmax, T)] halo slot nO + t: {node, -1, -, -} or, a ghost, {offset of u in a mailbox half, distance to v, ghost number, -}
+    double **lPeerSeg = reinterpret_cast<double **>(lH + (Mmax < T ? Mmax : T));  // [NXS_RES_MAXNB] the neighbour ranks' mailbox segments for my values,
+    long long *lPeerStride = reinterpret_cast<long long *>(lPeerSeg + NXS_RES_MAXNB);  // the distance of their second half,
+    int *lPeerVd = reinterpret_cast<int *>(lPeerStride + NXS_RES_MAXNB);                // and of the v-block inside a segment
     const unsigned ZIDX = 3u * (unsigned)Emax;
     __shared__ int lerr;
     auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
@@ -1379,15 +1384,25 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     }
     int nbr = -1;
     if (t < nNb) nbr = r.pnbr[(size_t)blk * NXS_RES_NBR + t];
-    // ghost nodes this patch moves (HALO): their running M_UM / M_UT in LDS like the own nodes'
-    const int nG = HALO ? r.gcnt[blk] : 0;
-    int gsl = 0, gnode = 0;
-    unsigned char gnf = 0;
-    if (HALO && t < nG) {
-        gsl = r.gslot[(size_t)blk * r.Gmax + t];
-        gnode = pn[gsl];
-        gnf = m.nflags[gnode];
-        lG[t] = s.UM[gnode]; lG[r.Gmax + t] = s.UM[gnode + Nn]; lG[2 * (size_t)r.Gmax + t] = s.UT[gnode]; lG[3 * (size_t)r.Gmax + t] = s.UT[gnode + Nn];
+    // HALO: where this thread's halo slot gets its velocity from, and where this thread's own node is sent to -- bit 31: it is sent somewhere;
+    // bit 30: to more than one neighbour rank (a corner of the partition: the tables are walked as in k_substep_fused); else bits 29-26 the
+    // neighbour, bits 25-0 the position in its segment
+    unsigned sinfo = 0u;
+    if (HALO) {
+        if (nO + t < nM) {
+            const int g = pn[nO + t];
+            lH[t] = (g >= m.No) ? make_int4(hfp->ghost_off[g - m.No], hfp->ghost_srl[g - m.No], g - m.No, 0) : make_int4(g, -1, 0, 0);
+        }
+        if (t < hfp->ipc.ns && t < NXS_RES_MAXNB) {
+            lPeerSeg[t] = hfp->ipc.peer_seg[t];
+            lPeerStride[t] = hfp->ipc.peer_parity_stride[t];
+            lPeerVd[t] = hfp->send_off[t + 1] - hfp->send_off[t];
+        }
+        if (boundary && has_node) {
+            const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
+            if (sq1 - sq0 == 1) sinfo = 0x80000000u | ((unsigned)hfp->send_k[sq0] << 26) | (unsigned)hfp->send_pos[sq0];
+            else if (sq1 > sq0) sinfo = 0xC0000000u;
+        }
     }
     __syncthreads();
     if (has_elem) {  // shapeCoeff (FE.cpp:1951-1964): frozen over the sub-steps (Q4), built once, the same quotients as k_prep_elements
@@ -1498,7 +1513,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 double *X = (ss & 1) ? r.X1 : r.X0;
                 st_agent(X + n, uice); st_agent(X + n + Nn, vice);
             }
-            if (HALO && boundary) {  // updateGhosts, sending side: straight into the neighbour ranks' mailboxes (as k_substep_fused)
+            if (HALO && (sinfo & 0x80000000u) && !(sinfo & 0x40000000u)) {  // updateGhosts, sending side: straight into the neighbour rank's mailbox
+                const unsigned k = (sinfo >> 26) & 15u;
+                double *dst = lPeerSeg[k] + ((x0 + (unsigned long long)ss) & 1ull) * lPeerStride[k] + (sinfo & 0x3FFFFFFu);
+                sys_store(dst, uice);
+                sys_store(dst + lPeerVd[k], vice);
+            } else if (HALO && (sinfo & 0x40000000u)) {  // ... into several (as k_substep_fused)
                 const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
                 for (int qq = sq0; qq < sq1; ++qq) {
                     const int k = hfp->send_k[qq];
@@ -1561,25 +1581,41 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         if (lerr) break;
         {   // the halo nodes' new velocities, past the caches
             const double *X = (ss & 1) ? r.X1 : r.X0;
-            for (int i = nO + t; i < nM; i += T) {
-                const int g = pn[i];
-                if (HALO && g >= m.No) {  // a ghost node: from this rank's mailbox, past the caches
-                    const double *src = hfp->ipc.mailbox + ((x0 + (unsigned long long)ss) & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr + hfp->ghost_off[g - m.No];
-                    lu[i] = sys_load(src); lv[i] = sys_load(src + hfp->ghost_srl[g - m.No]);
-                } else {
+            if (HALO) {
+                // a ghost node comes from this rank's mailbox; what arrived also goes to the ghosts' ring (every patch that stages the node
+                // writes the same two values): k_ghost_ring_move makes the ghosts' mesh moves of all sub-steps after the launch
+                const double *mb = hfp->ipc.mailbox + ((x0 + (unsigned long long)ss) & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr;
+                double *gr = r.gring + (size_t)ss * 2 * (size_t)r.NG;
+                if (nO + tt < nM) {
+                    const int4 hv = lH[tt];
+                    if (hv.y >= 0) {
+                        const double gu = sys_load(mb + hv.x), gv = sys_load(mb + hv.x + hv.y);
+                        lu[nO + tt] = gu; lv[nO + tt] = gv;
+                        if (move_dt != 0.) { gr[hv.z] = gu; gr[r.NG + hv.z] = gv; }
+                    } else {
+                        lu[nO + tt] = ld_agent(X + hv.x); lv[nO + tt] = ld_agent(X + hv.x + Nn);
+                    }
+                }
+                for (int i = nO + T + t; i < nM; i += T) {  // (more halo nodes than threads: not with the patch sizes this kernel is used for)
+                    const int g = pn[i];
+                    if (g >= m.No) {
+                        const int go = hfp->ghost_off[g - m.No], gs = hfp->ghost_srl[g - m.No];
+                        const double gu = sys_load(mb + go), gv = sys_load(mb + go + gs);
+                        lu[i] = gu; lv[i] = gv;
+                        if (move_dt != 0.) { gr[g - m.No] = gu; gr[r.NG + g - m.No] = gv; }
+                    } else {
+                        lu[i] = ld_agent(X + g); lv[i] = ld_agent(X + g + Nn);
+                    }
+                }
+            } else {
+                for (int i = nO + t; i < nM; i += T) {
+                    const int g = pn[i];
                     lu[i] = ld_agent(X + g); lv[i] = ld_agent(X + g + Nn);
                 }
             }
         }
         __syncthreads();
         RSTAMP(5);
-        if (HALO && t < nG && move_dt != 0.) {  // the ghosts' mesh move with the velocity that has just arrived (FE.cpp:10543-10550)
-            const int gsl2 = r.gslot[(size_t)blk * r.Gmax + tt];
-            const unsigned char gnf2 = m.nflags[pn[gsl2]];
-            const double gu = lu[gsl2], gv = lv[gsl2];
-            if (!(gnf2 & NF_NEUMANN)) { lG[tt] += move_dt * gu; lG[r.Gmax + tt] += move_dt * gv; }
-            lG[2 * (size_t)r.Gmax + tt] += move_dt * gu; lG[3 * (size_t)r.Gmax + tt] += move_dt * gv;
-        }
     }
     // ---- once per step: the element state and the moved mesh go back
     if (has_elem && writer) {
@@ -1590,10 +1626,24 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         if (!(nf & NF_NEUMANN)) { s.UM[n] = lM[t]; s.UM[n + Nn] = lM[Pmax + t]; }
         s.UT[n] = lM[2 * (size_t)Pmax + t]; s.UT[n + Nn] = lM[3 * (size_t)Pmax + t];
     }
-    if (HALO && t < nG && move_dt != 0.) {
-        if (!(gnf & NF_NEUMANN)) { s.UM[gnode] = lG[t]; s.UM[gnode + Nn] = lG[r.Gmax + t]; }
-        s.UT[gnode] = lG[2 * (size_t)r.Gmax + t]; s.UT[gnode + Nn] = lG[3 * (size_t)r.Gmax + t];
+}
+
+// The ghost nodes' mesh moves of a resident launch (FE.cpp:10543-10550): M_UM += dte * M_VT, M_UT += dte * M_VT with the velocity that arrived after
+// each of the first `count` sub-steps, in sub-step order -- the additions the reference makes, from the ring the launch filled (the move of the
+// last sub-step follows in k_halo_pull, with the last exchange).
+__global__ void __launch_bounds__(BLOCK) k_ghost_ring_move(DevMesh m, DevState s, const double *__restrict__ gring, int NG, int count, double dt) {
+    const int j = blockIdx.x * BLOCK + threadIdx.x;
+    if (j >= NG) return;
+    const int n = m.No + j, Nn = m.Nn;
+    const bool free_node = !(m.nflags[n] & NF_NEUMANN);  // Neumann nodes keep M_UM (restore == skip)
+    double umu = s.UM[n], umv = s.UM[n + Nn], utu = s.UT[n], utv = s.UT[n + Nn];
+    for (int c = 0; c < count; ++c) {
+        const double u = gring[(size_t)c * 2 * NG + j], v = gring[(size_t)c * 2 * NG + NG + j];
+        if (free_node) { umu += dt * u; umv += dt * v; }
+        utu += dt * u; utv += dt * v;
     }
+    if (free_node) { s.UM[n] = umu; s.UM[n + Nn] = umv; }
+    s.UT[n] = utu; s.UT[n + Nn] = utv;
 }
 
 // Deferred mesh move of the fused path: the fused kernel leaves every sub-step's velocity in a ring of
