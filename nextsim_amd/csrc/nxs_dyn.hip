@@ -1562,6 +1562,7 @@ int build_resident(nxs_dyn_handle *h) {
     }
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr, nbr))) return rc;
     if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr_cnt, cnt))) return rc;
+    r.rank = h->rank;
     if (mr) {  // the ghosts' ring: what arrived after every sub-step but the last
         r.NG = Nn - No;
         if ((rc = dev_alloc(h, h->patch_allocs, &r.gring, std::max<size_t>((size_t)(NXS_RES_MAXS - 1) * 2 * (size_t)r.NG, 1)  /* (any number of sub-steps the kernel accepts: the parameters may change) */))) return rc;

@@ -1240,6 +1240,7 @@ struct DevResident {
     unsigned int *raised;  // [1] sub-steps whose exchange has been published to the neighbour ranks (keeps the flags monotone)
     double *gring;         // [S - 1][2 NG] the ghost nodes' velocities as they arrived after every sub-step but the last ([u-block | v-block] of the NG = Nn - No
     int NG;                //   ghosts): k_ghost_ring_move applies their mesh moves after the launch -- nothing of that sits in the sub-step loop
+    int rank;              // (the microscope of scripts/phase_timing.py stamps rank 0 only: several handles of a process share its table)
 };
 #define NXS_RES_MAXS 512
 #define NXS_RES_MAXNB 16  // neighbour ranks whose mailbox addresses the several-rank variant keeps in LDS
@@ -1436,7 +1437,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         asm volatile("" : "+s"(pl));
         const DevParams &p = *pl;
 #ifdef NXS_PHASE_TIMING
-#define RSTAMP(k) do { if (ss == 60 && threadIdx.x == 0 && blk < 8192) g_phase_t[8 * blk + (k)] = wall_clock64(); } while (0)
+#define RSTAMP(k) do { if (ss == 60 && threadIdx.x == 0 && blk < 8192 && r.rank == 0) g_phase_t[8 * blk + (k)] = wall_clock64(); } while (0)
 #else
 #define RSTAMP(k) do { } while (0)
 #endif
@@ -1637,7 +1638,19 @@ __global__ void __launch_bounds__(BLOCK) k_ghost_ring_move(DevMesh m, DevState s
     const int n = m.No + j, Nn = m.Nn;
     const bool free_node = !(m.nflags[n] & NF_NEUMANN);  // Neumann nodes keep M_UM (restore == skip)
     double umu = s.UM[n], umv = s.UM[n + Nn], utu = s.UT[n], utv = s.UT[n + Nn];
-    for (int c = 0; c < count; ++c) {
+    // the additions are sequential (the reference's order), the loads are not: sixteen slots in flight at a time (a few hundred ghosts: latency only)
+    int c = 0;
+    for (; c + 16 <= count; c += 16) {
+        double u[16], v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { u[k] = gring[(size_t)(c + k) * 2 * NG + j]; v[k] = gring[(size_t)(c + k) * 2 * NG + NG + j]; }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (free_node) { umu += dt * u[k]; umv += dt * v[k]; }
+            utu += dt * u[k]; utv += dt * v[k];
+        }
+    }
+    for (; c < count; ++c) {
         const double u = gring[(size_t)c * 2 * NG + j], v = gring[(size_t)c * 2 * NG + NG + j];
         if (free_node) { umu += dt * u; umv += dt * v; }
         utu += dt * u; utv += dt * v;

@@ -1,5 +1,5 @@
 """What a CU does on one rank of eight, rehearsed on ONE GPU: the 182 k-triangle mesh (1/8 of the 2 km mesh) over TWO ranks hosted by one process
-(two threads, two handles, in-process mailboxes), both cut into the 192-node patches (180 on the real machine; here 2 x 245 workgroups must fit the 512 slots together) a rank of eight has -- 2 x 256 workgroups, i.e. every CU holds
+(two threads, two handles, in-process mailboxes), both cut into the 180-node patches a rank of eight has (a mesh of 173 k triangles, so that 2 x 245 workgroups fit the 512 slots together) a rank of eight has -- 2 x 256 workgroups, i.e. every CU holds
 two resident patches exactly as on the real machine, and the exchange between the ranks runs inside the resident launch (minus xGMI: both ranks
 share the device).  Prints each rank's per-step timing for the resident launch (plain and with the interior elements under the exchange) and checks
 the bits against the separate kernels and the oracle.        python3 scripts/rehearse_rank_of_eight.py [steps]"""
@@ -8,9 +8,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import test_gpu_multirank as T
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+KIND = sys.argv[2] if len(sys.argv) > 2 else "h16000"   # 173 k triangles: two ranks of ~245 patches of 180 nodes fit the 512 slots together
 for overlap in (0, 1):
     with tempfile.TemporaryDirectory() as d:
-        reps = T._run(2, "h15600", steps, pathlib.Path(d), "ipc", over={"options": {"fused": 4, "patch_nodes": 192, "resident_overlap": overlap}}, ranks_per_proc=2)
+        reps = T._run(2, KIND, steps, pathlib.Path(d), "ipc", over={"options": {"fused": 4, "patch_nodes": 180, "resident_overlap": overlap}}, ranks_per_proc=int(os.environ.get("NXS_RPP", "2")))
     for r in reps:
         tm = r.get("timing", {})
         if not r["ok"]: print("   ", {k: v for k, v in r.items() if k not in ("timing",)})

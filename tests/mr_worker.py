@@ -94,6 +94,8 @@ def run_rank(li, report):
     fe.synchronize()
     got = fe.get_state()
     report["timing"] = fe.timing()
+    if os.environ.get("NXS_PHASE_DUMP") and rank == 0:   # (a library built with -DNXS_PHASE_TIMING: scripts/phase_timing.py --build)
+        np.save(os.path.join(os.environ["NXS_PHASE_DUMP"], "phase0.npy"), fe.debug_array("phase_times"))
     if transport == "ipc":
         # the exchange inside the sub-step kernel (default) must give the bits of the separate kernels
         report["launches_fused"] = report["timing"]["substep_launches"]
