@@ -1534,6 +1534,8 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // every wave's stores have left; the corner forces have been read
         RSTAMP(3);
+        // this patch's own counter first: the patches of this rank that wait for it should not wait for the round trip of the atomic below
+        if (ss < S - 1 && t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (HALO && boundary && t == 0) {
             // the last boundary patch to finish this sub-step publishes it to the neighbour ranks -- in sub-step order: patches far
             // apart may be several sub-steps apart, so the one that completes sub-step ss waits for ss - 1 to have been published
@@ -1553,7 +1555,6 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             }
         }
         if (ss == S - 1) break;
-        if (t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (OVL && early) {  // the interior elements' update for sub-step ss + 1, under the exchange: their corners are own nodes (lu / lv of
                              // the node phase above), their corner forces of sub-step ss have been read (the barrier above)
             const DevParams *pe = pdev;
