@@ -22,6 +22,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the host driver of this pool supports dmabuf IPC only: without this hipIpcGetMemHandle (the mailboxes of the device-direct halo transport, RCCL)
+# fails with "invalid argument"; it is exported on the GPU boxes already -- kept here for a launcher that builds its own environment
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 # Algorithmic HBM bytes per element-update of the sub-step loop (DESIGN.md "Roofline model"):
 # 172 B per element + 217 B per node per sub-step.

@@ -1,5 +1,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
-timeout -k 10 800 python3 scripts/rehearse_rank_of_eight.py 12 2>&1 | grep -v "amdgpu.ids\|socket.cpp\|Gloo" | grep "^overlap 0" | cut -c1-160
-done
-timeout -k 10 200 python3 scripts/run_steps.py --h 15600 --steps 200 --fused 4 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c54-130
+timeout -k 10 900 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 4 --master-addr 127.0.0.1 --master-port 29523 bench.py --gpus 4 --steps 3 --warmup 1 > gpurun_out/r2b_bench_g4.json 2> gpurun_out/r2b_bench_g4.err; echo "rc $?"
+python3 -c "
+import json
+d=json.loads(open('gpurun_out/r2b_bench_g4.json').read().strip().splitlines()[-1])
+print(d['ms_per_step'], d['n_gpus'], d['ranks_share_device'], d['config']['halo_transport'][:300], d['fields_ok'])
+"
