@@ -1223,6 +1223,9 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
 // that exchange costs 3.1 us per sub-step with 511 workgroups; a grid-wide barrier costs 6-9 (MI355X_MICROARCH.md, barrier-xcd).
 // REQUIRES every workgroup of the grid to be resident at once (the host checks the occupancy and falls back otherwise; every
 // wait is bounded and reports through r.error), one element per thread (Emax <= T), not mEVP.
+#ifndef NXS_RES_WAVES
+#define NXS_RES_WAVES 4   // waves per SIMD the resident kernel is compiled for: 4 = 128 VGPRs = two 512-thread workgroups per CU
+#endif
 #define NXS_RES_NBR 24
 struct DevResident {
     // variant OVL only (option resident_overlap): the patch's elements with the INTERIOR ones first (no corner is a halo node of the patch)
@@ -1296,7 +1299,7 @@ __device__ __forceinline__ void resident_element(const DevParams &p, const doubl
 // GPU that buys nothing (the other workgroup of the CU fills the wait); between GPUs the wait is a round trip over xGMI.  Same
 // operations on the same values in the same order: bit-identical (bench.py keeps whichever variant is faster on the machine it runs on).
 template <int T, bool POW4, bool HALO, bool OVL = false>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(NXS_RES_WAVES, NXS_RES_WAVES))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
                                                         const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
                                                         const HaloFused *__restrict__ hfp, int n_boundary) {
     const DevParams &p0 = *pdev;
@@ -1326,7 +1329,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     unsigned long long x0 = 0ull;
     if (HALO) {
         boundary = blk < n_boundary;
-        if (boundary) x0 = *hfp->ipc.seq_push;  // exchanges this rank has published so far; changed only after every boundary patch has finished
+        if (boundary) {  // exchanges this rank has published so far; changed only after every boundary patch has finished (uniform: kept in scalar registers)
+            const unsigned long long xv = *hfp->ipc.seq_push;
+            x0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(xv & 0xffffffffull));
+        }
         blk = boundary ? xcd_remap(blk, n_boundary) : n_boundary + xcd_remap(blk - n_boundary, (int)gridDim.x - n_boundary);
     } else {
         blk = xcd_remap(blk, (int)gridDim.x);
@@ -1514,12 +1520,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 double *X = (ss & 1) ? r.X1 : r.X0;
                 st_agent(X + n, uice); st_agent(X + n + Nn, vice);
             }
-            if (HALO && (sinfo & 0x80000000u) && !(sinfo & 0x40000000u)) {  // updateGhosts, sending side: straight into the neighbour rank's mailbox
-                const unsigned k = (sinfo >> 26) & 15u;
-                double *dst = lPeerSeg[k] + ((x0 + (unsigned long long)ss) & 1ull) * lPeerStride[k] + (sinfo & 0x3FFFFFFu);
+            unsigned si = sinfo;
+            if (HALO) asm volatile("" : "+v"(si));  // (decoded here every sub-step: hoisted out of the loop, neighbour, position and the LDS addresses would each hold a register across it)
+            if (HALO && (si & 0x80000000u) && !(si & 0x40000000u)) {  // updateGhosts, sending side: straight into the neighbour rank's mailbox
+                const unsigned k = (si >> 26) & 15u;
+                double *dst = lPeerSeg[k] + ((x0 + (unsigned long long)ss) & 1ull) * lPeerStride[k] + (si & 0x3FFFFFFu);
                 sys_store(dst, uice);
                 sys_store(dst + lPeerVd[k], vice);
-            } else if (HALO && (sinfo & 0x40000000u)) {  // ... into several (as k_substep_fused)
+            } else if (HALO && (si & 0x40000000u)) {  // ... into several (as k_substep_fused)
                 const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
                 for (int qq = sq0; qq < sq1; ++qq) {
                     const int k = hfp->send_k[qq];
@@ -1561,8 +1569,8 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             asm volatile("" : "+s"(pe));
             resident_element<POW4>(*pe, w.erec, bbm, skip, e, tr, tt, Emax, lu, lv, ldx, lF, sig, damage);
         }
-        if (HALO && boundary && t >= 64 && t < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
-            const int k = t - 64;
+        if (HALO && boundary && tt >= 64 && tt < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
+            const int k = tt - 64;
             const long long t0 = wall_clock64();
             while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x0 + (unsigned long long)ss + 1ull) {
                 __builtin_amdgcn_s_sleep(2);
@@ -1570,9 +1578,11 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 7); break; }  // 2 s
             }
         }
-        if (nbr >= 0) {
+        int nb = nbr;
+        asm volatile("" : "+v"(nb));  // (its counter's address is formed here, not kept across the loop)
+        if (nb >= 0) {
             const long long t0 = wall_clock64();  // 100 MHz
-            while (__hip_atomic_load(r.flag + 32 * (size_t)nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
+            while (__hip_atomic_load(r.flag + 32 * (size_t)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
                 __builtin_amdgcn_s_sleep(1);
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
                 if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 5); break; }  // 2 s
