@@ -188,6 +188,7 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
                 "separate": (3, 0, ", separate push/pull kernels")}
 
     def select(name):
+        fe.set_option("resident_wide", 1 if own_device else 0)   # (only matters where one workgroup per CU covers a rank's partition)
         fe.set_option("resident_overlap", 1 if name == "resident_overlap" else 0)
         fe.set_option("fused", variants[name][0]); fe.set_option("halo_fused", variants[name][1])
 

@@ -277,6 +277,9 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *   "resident_dryrun"  (an action, not a setting) builds the tables of the resident loop for the mesh and halo lists set so far -- no transport,
  *                  no neighbours needed -- and fails with NXS_ERR_INVALID when this partition cannot run it (a patch with more elements than
  *                  threads, more than one round of workgroups, LDS, > 24 neighbouring patches): a partition can be checked on its own
+ *   "resident_wide"  with "fused" 4 on several ranks, a device that is this handle's alone and a partition that one workgroup per CU covers:
+ *                  1 = the build of the resident kernel compiled for two waves per SIMD (no register limit to speak of: 15 % faster there);
+ *                  default 0, because one such workgroup fills a CU and ranks sharing a device would no longer be resident side by side
  *   "resident_overlap"  with "fused" 4 on several ranks: 1 = the interior elements of every patch (no corner is a halo node) run one exchange
  *                  ahead -- their next update is computed while the exchange of the sub-step is awaited; default 0 (inside one GPU the wait is
  *                  filled by the other workgroup of the CU anyway; between GPUs it is a round trip over xGMI: bench.py times both and keeps one)

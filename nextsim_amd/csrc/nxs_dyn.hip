@@ -148,6 +148,8 @@ struct nxs_dyn_handle {
     // v4: the whole sub-step loop in one resident launch (option "fused" = 4; see k_substep_resident)
     DevResident res{};
     bool res_ready = false, res_failed = false;
+    int res_wide = 0;     // option resident_wide
+    int res_wpe = 4;      // waves per SIMD of the resident kernel build in use (2 on several ranks where one workgroup per CU covers the partition)
     int res_overlap = 0;  // option resident_overlap (several ranks): interior elements of the next sub-step computed while the exchange is awaited
     size_t res_lds = 0;
     double *d_vt3 = nullptr;
@@ -526,6 +528,9 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         if ((rc = build_resident(h))) return rc;
         if (!h->res_ready) return fail(h, NXS_ERR_INVALID, "the resident sub-step loop cannot run this partition (NXS_DEBUG_PATCHES=1 says why)");
         return NXS_OK;
+    }
+    if (!std::strcmp(key, "resident_wide")) {
+        h->res_wide = value != 0; h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "resident_overlap")) {
         h->res_overlap = value != 0; h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;
@@ -1510,7 +1515,13 @@ int build_resident(nxs_dyn_handle *h) {
     int per_cu = 0, cus = 0;
     const bool p4 = h->dp.ers_int == 4;
     const bool ovl = mr && h->res_overlap;
-    hipError_t e = ovl ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, true>, 512, h->res_lds)
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    // one workgroup per CU is enough and the caller says the device is this handle's alone (option resident_wide): the several-rank build with all
+    // the registers it wants -- one such workgroup fills a CU, so ranks that share a device (the tests) would no longer fit side by side
+    h->res_wpe = (mr && p4 && h->res_wide && nP <= cus) ? 2 : 4;
+    hipError_t e = (mr && h->res_wpe == 2) ? (ovl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, true, 2>, 512, h->res_lds)
+                                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, false, 2>, 512, h->res_lds))
+                 : ovl ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, true>, 512, h->res_lds)
                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, true, true>, 512, h->res_lds))
                  : mr ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true>, 512, h->res_lds)
                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, true>, 512, h->res_lds))
@@ -1678,9 +1689,12 @@ int run_substeps(nxs_dyn_handle *h) {
 #define RESIDENT(PP, HH, HFP, NB) hipLaunchKernelGGL((k_substep_resident<512, PP, HH>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, HFP, NB)
             if (mr) {
 #define RESIDENT_OVL(PP) hipLaunchKernelGGL((k_substep_resident<512, PP, true, true>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, (const HaloFused *)h->d_hf, h->hf.n_boundary)
-                if (h->res_overlap) { if (p4) RESIDENT_OVL(true); else RESIDENT_OVL(false); }
+#define RESIDENT_W2(OO) hipLaunchKernelGGL((k_substep_resident<512, true, true, OO, 2>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, (const HaloFused *)h->d_hf, h->hf.n_boundary)
+                if (h->res_wpe == 2 && p4) { if (h->res_overlap) RESIDENT_W2(true); else RESIDENT_W2(false); }
+                else if (h->res_overlap) { if (p4) RESIDENT_OVL(true); else RESIDENT_OVL(false); }
                 else if (p4) RESIDENT(true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary); else RESIDENT(false, true, (const HaloFused *)h->d_hf, h->hf.n_boundary);
 #undef RESIDENT_OVL
+#undef RESIDENT_W2
                 // the ghosts' mesh moves of all sub-steps but the last, from the ring the launch filled ...
                 if (move_dt != 0. && h->res.NG > 0 && S > 1)
                     hipLaunchKernelGGL(k_ghost_ring_move, dim3(nblocks(h->res.NG)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, (const double *)h->res.gring, h->res.NG, S - 1, move_dt);

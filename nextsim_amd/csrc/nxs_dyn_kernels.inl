@@ -1298,8 +1298,10 @@ __device__ __forceinline__ void resident_element(const DevParams &p, const doubl
 // update for sub-step s + 1 is computed while the exchange of sub-step s is awaited, only the rim elements follow the halo loads.  Inside one
 // GPU that buys nothing (the other workgroup of the CU fills the wait); between GPUs the wait is a round trip over xGMI.  Same
 // operations on the same values in the same order: bit-identical (bench.py keeps whichever variant is faster on the machine it runs on).
-template <int T, bool POW4, bool HALO, bool OVL = false>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(NXS_RES_WAVES, NXS_RES_WAVES))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
+// WPE: waves per SIMD the kernel is compiled for -- 4 (128 VGPRs: two 512-thread workgroups per CU) or, where one workgroup per CU covers the
+// partition, 2 (the several-rank variant then takes the 148 registers it wants: 15 % faster at that occupancy; the single-rank one gains nothing)
+template <int T, bool POW4, bool HALO, bool OVL = false, int WPE = NXS_RES_WAVES>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
                                                         const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
                                                         const HaloFused *__restrict__ hfp, int n_boundary) {
     const DevParams &p0 = *pdev;

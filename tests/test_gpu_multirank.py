@@ -273,3 +273,18 @@ def test_every_partition_of_the_baseline_configurations_can_run_the_resident_loo
             fe.set_option("resident_overlap", overlap)
             fe.set_option("resident_dryrun", 1)      # raises NxsError when this partition could not run it
         fe.close()
+
+
+@pytest.mark.parametrize("world,kind,over", [(2, "small", {}), (3, "40km", {"dynamics_type": 3})])
+def test_resident_loop_in_the_build_with_all_its_registers(world, kind, over, tmp_path):
+    """Option resident_wide: where one workgroup per CU covers a rank's partition and the device is the handle's alone, the several-rank resident
+    kernel runs in its build for two waves per SIMD (148 registers instead of 128 with spills).  The few small grids of this test fit one GPU
+    side by side even so: bitwise equal to the separate kernels, and the multi-rank oracle's results."""
+    reps = _run(world, kind, 1, tmp_path, "ipc", over=dict(over, options={"fused": 4, "resident_wide": 1}))
+    for r in reps:
+        assert r["ok"], r
+        assert r["fused_equals_separate"] is True, r
+        assert r["launches_fused"] == 1, r
+        assert r["crash"] == 0
+        for k, e in r["errs"].items():
+            assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
