@@ -51,6 +51,8 @@ extern "C" {
 #define NXS_ERR_HIP (-3)       /* a HIP runtime call failed */
 #define NXS_ERR_STATE (-4)     /* call order (e.g. step before set_mesh) */
 #define NXS_ERR_COMM (-5)      /* RCCL failure */
+#define NXS_ERR_NOMEM (-6)     /* host memory exhausted (a std::bad_alloc inside the library, caught at the boundary) */
+#define NXS_ERR_INTERNAL (-7)  /* any other C++ exception inside the library, caught at the boundary; the text names it */
 
 /* setup::DynamicsType, model/enums.hpp:142-149 */
 enum { NXS_DYN_BBM = 0, NXS_DYN_NO_MOTION = 1, NXS_DYN_FREE_DRIFT = 2, NXS_DYN_EVP = 3, NXS_DYN_MEVP = 4 };

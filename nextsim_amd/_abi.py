@@ -21,7 +21,7 @@ DYNAMICS_TYPES = {"bbm": NXS_DYN_BBM, "no_motion": NXS_DYN_NO_MOTION, "free_drif
                   "evp": NXS_DYN_EVP, "mevp": NXS_DYN_MEVP}
 
 ERRORS = {0: "NXS_OK", -1: "NXS_ERR_INVALID", -2: "NXS_ERR_NO_DEVICE", -3: "NXS_ERR_HIP",
-          -4: "NXS_ERR_STATE", -5: "NXS_ERR_COMM"}
+          -4: "NXS_ERR_STATE", -5: "NXS_ERR_COMM", -6: "NXS_ERR_NOMEM", -7: "NXS_ERR_INTERNAL"}
 
 
 class Params(C.Structure):

@@ -31,11 +31,14 @@
 #include <dlfcn.h>
 #include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <unistd.h>
 #include <vector>
 
 #include "nxs_dyn.h"
+#include "nxs_guard.hpp"
+#include "nxs_patchcut.hpp"
 
 #include "nxs_dyn_kernels.inl"
 
@@ -63,19 +66,10 @@ struct Rccl {  // RCCL entry points, resolved at comm_init (no link-time depende
 struct NcclId { char internal[128]; };
 typedef int (*nccl_comm_init_rank_t)(void **, int, NcclId, int);
 
-struct HostPatches {
-    int nP = 0, Pmax = 0, Emax = 0, Mmax = 0, Wp = 0;
-    std::vector<int> own_cnt, elem_cnt, node_cnt, pnodes, pelem;
-    std::vector<unsigned short> ptri, pfan;
-    double avg_elems_per_own_node = 0.;
-    bool used_hilbert = false;  // the caller's numbering had no locality: patches cut along a Hilbert curve
-};
-
-struct HostPatches2 {
-    int nP = 0, D = 0, NDmax = 0, NSmax = 0, EDmax = 0, ESmax = 0, Wp = 0;
-    std::vector<int> ncnt, ecnt, pnodes, pelem;
-    std::vector<unsigned short> ptri, pfan;
-};
+using nxs_cut::HostPatches;
+using nxs_cut::HostPatches2;
+static_assert(NXS_CUT_BLOCK == BLOCK && NXS_CUT_T256_MAXP == NXS_T256_MAXP && NXS_CUT_RES_NBR == NXS_RES_NBR && NXS_CUT_RES_MAXNB == NXS_RES_MAXNB,
+              "nxs_patchcut.hpp and nxs_dyn_kernels.inl disagree about a limit");
 
 struct nxs_dyn_handle {
     int device = 0;
@@ -147,8 +141,11 @@ struct nxs_dyn_handle {
     std::vector<void *> forcing_allocs;
     // v4: the whole sub-step loop in one resident launch (option "fused" = 4; see k_substep_resident)
     DevResident res{};
+    std::vector<void *> res_allocs;  // its tables, exchange buffer and ghost ring (a pool of their own: rebuilt whenever an option of the loop changes)
     bool res_ready = false, res_failed = false;
     int res_wide = 0;     // option resident_wide
+    bool res_pow4 = true; // the build for BBM's default exponent (two squarings instead of pow)
+    int res_substeps = 0; // the number of sub-steps the tables (the ghosts' ring) were sized for
     int res_wpe = 4;      // waves per SIMD of the resident kernel build in use (2 on several ranks where one workgroup per CU covers the partition)
     int res_overlap = 0;  // option resident_overlap (several ranks): interior elements of the next sub-step computed while the exchange is awaited
     size_t res_lds = 0;
@@ -202,6 +199,7 @@ namespace {
 inline int eff_fused(const nxs_dyn_handle *h) { return h->trace_branches ? 0 : h->fused; }
 int build_halo_fused(nxs_dyn_handle *h);  // (defined with the launch logic below)
 int build_resident(nxs_dyn_handle *h);
+void resident_registry_release(const nxs_dyn_handle *h);
 bool multi_rank(const nxs_dyn_handle *h);
 
 int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
@@ -212,6 +210,12 @@ int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
     va_end(ap);
     if (h) h->err = buf; else g_create_error = buf;
     return code;
+}
+
+// handler of every extern "C" function-try-block of this file (nxs_guard.hpp): a std::bad_alloc from a table that cannot grow, or anything
+// else the host code throws, becomes a status code and nxs_dyn_last_error's text -- never an exception across the ABI
+int dyn_caught(nxs_dyn_handle *h, const char *entry) noexcept {
+    return nxs_guard::caught(entry, [h](int code, const char *text) { (void)fail(h, code, "%s", text); });
 }
 
 #define HIPCHK(h, call)                                                                         \
@@ -393,6 +397,34 @@ void release_graph(nxs_dyn_handle *h) {
     h->tail_graph_valid = false;
 }
 
+// the resident loop's tables and its claim on the device's workgroup slots
+void release_resident(nxs_dyn_handle *h) {
+    free_pool(h->res_allocs);
+    h->res = DevResident{};
+    h->d_vt3 = nullptr;
+    h->res_ready = false; h->res_failed = false;
+    resident_registry_release(h);
+}
+
+// A resident launch that gave up (k_substep_resident's bounded waits) leaves the state of the step's start behind; whoever hands state to
+// the host next says so.  Call with the stream synchronised.
+int resident_error(nxs_dyn_handle *h) {
+    if (!h->res_ready) return NXS_OK;
+    int err = 0;
+    HIPCHK(h, hipMemcpyAsync(&err, h->res.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (!err) return NXS_OK;
+    HIPCHK(h, hipMemsetAsync(h->res.error, 0, sizeof(int), h->stream));
+    h->res_failed = true; h->res_ready = false; release_graph(h);
+    resident_registry_release(h);
+    const char *what = err == 5 ? "a patch waited 12 s for a neighbouring patch of its own rank: the workgroups of the grid were not all resident (is the device shared with another process?)"
+                     : err == 6 ? "the boundary patches' publishing order stalled for 10 s (an earlier sub-step was never published: a patch of this rank is missing)"
+                     : err == 7 ? "a neighbour rank's flag did not arrive within 10 s (that rank started its step late, stopped, or its launch failed)"
+                                : "unknown wait";
+    return fail(h, NXS_ERR_HIP, "the resident sub-step launch gave up (code %d): %s; M_UM, M_UT, sigma and damage were not advanced by that step -- the step is lost, "
+                                "later steps run one kernel per sub-step", err, what);
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -402,7 +434,7 @@ int nxs_dyn_abi_version(void) { return NXS_DYN_ABI_VERSION; }
 
 const char *nxs_dyn_last_error(const nxs_dyn_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-int nxs_dyn_default_params(nxs_dyn_params *p) {  // model/options.cpp:43,80,109-111,314-376,397,545-547
+int nxs_dyn_default_params(nxs_dyn_params *p) try {  // model/options.cpp:43,80,109-111,314-376,397,545-547
     if (!p) return NXS_ERR_INVALID;
     std::memset(p, 0, sizeof *p);
     p->dtime_step = 200.; p->substeps = 120;
@@ -419,9 +451,9 @@ int nxs_dyn_default_params(nxs_dyn_params *p) {  // model/options.cpp:43,80,109-
     p->mevp_alpha = 500.; p->mevp_beta = 500.;
     p->regrid_angle = 10.;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(nullptr, "nxs_dyn_default_params"); }
 
-int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) {
+int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) try {
     if (!out) return fail(nullptr, NXS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     int ndev = 0;
@@ -453,9 +485,9 @@ int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) {
     derive_params(h);
     *out = h;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(nullptr, "nxs_dyn_create"); }
 
-int nxs_dyn_destroy(nxs_dyn_handle *h) {
+int nxs_dyn_destroy(nxs_dyn_handle *h) try {
     if (!h) return NXS_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -466,6 +498,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
+    release_resident(h);
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
@@ -489,9 +522,9 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) {
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_destroy"); }
 
-int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
+int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p) try {
     if (!h) return NXS_ERR_INVALID;
     int rc = check_params(h, p);
     if (rc) return rc;
@@ -501,10 +534,11 @@ int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
     }
     h->params = *p;
     derive_params(h);
+    h->res_failed = false;  // (what the resident loop was refused for may have been the old parameters; its tables are re-checked at the next step)
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_params"); }
 
-int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
+int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
     if (!h || !key) return NXS_ERR_INVALID;
     if (!std::strcmp(key, "graph")) { h->use_graph = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "timing")) { h->timing_enabled = value != 0; return NXS_OK; }
@@ -580,10 +614,10 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) {
         return NXS_OK;
     }
     return fail(h, NXS_ERR_INVALID, "unknown option '%s'", key);
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_option"); }
 
 // ------------------------------------------------------------------------------------------------
-int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
+int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     if (!h || !m) return NXS_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     const int Nn = m->num_nodes, Ne = m->num_elements, No = m->local_ndof, Neo = m->local_nelements;
@@ -608,6 +642,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
+    release_resident(h);
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
@@ -757,10 +792,10 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) {
     if ((rc = upload_patches(h))) return rc;
     h->have_mesh = true;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_mesh"); }
 
 // ------------------------------------------------------------------------------------------------
-int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
+int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
     if (!h || !halo) return NXS_ERR_INVALID;
     if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "set_halo before set_mesh");
     HIPCHK(h, hipSetDevice(h->device));
@@ -829,7 +864,7 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) {
     HIPCHK(h, hipHostMalloc((void **)&h->h_recv, std::max<size_t>(2 * (size_t)tr, 1) * sizeof(double), hipHostMallocDefault));
     h->have_halo = true;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_halo"); }
 
 static int load_rccl(nxs_dyn_handle *h, Rccl &r) {
     if (r.lib) return NXS_OK;
@@ -854,16 +889,16 @@ static int load_rccl(nxs_dyn_handle *h, Rccl &r) {
     return NXS_OK;
 }
 
-int nxs_dyn_comm_unique_id(void *id128) {
+int nxs_dyn_comm_unique_id(void *id128) try {
     if (!id128) return NXS_ERR_INVALID;
     Rccl r;
     int rc = load_rccl(nullptr, r);
     if (rc) return rc;
     int e = r.GetUniqueId(id128);
     return e == 0 ? NXS_OK : fail(nullptr, NXS_ERR_COMM, "ncclGetUniqueId: %s", r.GetErrorString(e));
-}
+} catch (...) { return dyn_caught(nullptr, "nxs_dyn_comm_unique_id"); }
 
-int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks) {
+int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks) try {
     if (!h || !id128) return NXS_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     int rc = load_rccl(h, h->rccl);
@@ -874,13 +909,13 @@ int nxs_dyn_comm_init(nxs_dyn_handle *h, const void *id128, int rank, int nranks
     int e = init(&h->comm, nranks, id, rank);
     if (e != 0) return fail(h, NXS_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, h->rccl.GetErrorString(e));
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_comm_init"); }
 
 // One exchange of coded payloads through the RCCL communicator (collective when nranks > 1): a grouped ncclSend/ncclRecv of the
 // rank to ITSELF, and -- when halo lists are set -- the grouped send/recv of updateGhosts with every segment carrying
 // (sending rank, position).  *errors = number of wrong values received.  With nranks == 1 this runs the dlopen'ed entry points,
 // the by-value ncclUniqueId, the stream use and the error mapping on one GPU.
-int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors) {
+int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors) try {
     if (!h || !errors) return NXS_ERR_INVALID;
     if (!h->comm) return fail(h, NXS_ERR_STATE, "comm_selftest before comm_init");
     HIPCHK(h, hipSetDevice(h->device));
@@ -921,10 +956,10 @@ int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors) {
         for (int i = 2 * h->recv_offsets[k]; i < 2 * h->recv_offsets[k + 1]; ++i) bad += hrecv[i] != 1e6 * h->recv_procs[k] + (i - 2 * h->recv_offsets[k]) + 0.5;
     *errors = bad;
     return done(NXS_OK);
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_comm_selftest"); }
 
 // Device-direct transport, step 1: allocate my mailbox and export it.  blob receives NXS_IPC_BLOB_BYTES.
-int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
+int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) try {
     if (!h || !blob) return NXS_ERR_INVALID;
     if (!h->have_halo) return fail(h, NXS_ERR_STATE, "ipc_export before set_halo");
     HIPCHK(h, hipSetDevice(h->device));
@@ -965,14 +1000,14 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) {
     std::memset(blob, 0, NXS_IPC_BLOB_BYTES);
     std::memcpy(blob, &b, sizeof b);
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_ipc_export"); }
 
 // Step 2: map the neighbours' mailboxes.  For send neighbour k (order of nxs_dyn_halo.send_procs):
 // blobs + k*NXS_IPC_BLOB_BYTES is its exported blob, peer_recv_offset[k] the offset (in nodes) of MY
 // segment inside its receive lists, peer_recv_total[k] its total number of received nodes and
 // peer_flag_slot[k] my position in its recv_procs.
 int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset, const int32_t *peer_recv_total,
-                        const int32_t *peer_flag_slot) {
+                        const int32_t *peer_flag_slot) try {
     if (!h) return NXS_ERR_INVALID;
     if (!h->ipc_block) return fail(h, NXS_ERR_STATE, "ipc_connect before ipc_export");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1060,11 +1095,11 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     h->d_hf_dirty = true;
     release_graph(h);
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_ipc_connect"); }
 
 // Step 3 (collective): `rounds` exchanges of a synthetic pattern through the mailboxes; *errors gets
 // 0 when every value arrived intact and in time on this rank.
-int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors) {
+int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors) try {
     if (!h || !errors) return NXS_ERR_INVALID;
     if (!h->ipc_ready) return fail(h, NXS_ERR_STATE, "ipc_selftest before ipc_connect");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1084,17 +1119,17 @@ int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *errors = err;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_ipc_selftest"); }
 
-int nxs_dyn_set_halo_exchange_fn(nxs_dyn_handle *h, nxs_dyn_halo_fn fn, void *ctx) {
+int nxs_dyn_set_halo_exchange_fn(nxs_dyn_handle *h, nxs_dyn_halo_fn fn, void *ctx) try {
     if (!h) return NXS_ERR_INVALID;
     h->halo_fn = fn;
     h->halo_ctx = ctx;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_halo_exchange_fn"); }
 
 // ------------------------------------------------------------------------------------------------
-int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s) {
+int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s) try {
     if (!h || !s) return NXS_ERR_INVALID;
     if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "put_state before set_mesh");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1120,9 +1155,9 @@ int nxs_dyn_put_state(nxs_dyn_handle *h, const nxs_dyn_state *s) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_state = true;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_put_state"); }
 
-int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s) {
+int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s) try {
     if (!h || !s) return NXS_ERR_INVALID;
     if (!h->have_state) return fail(h, NXS_ERR_STATE, "get_state before put_state");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1136,14 +1171,15 @@ int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s) {
         {s->conc_young, d.cyoung, ne}, {s->h_young, d.hyoung, ne}, {s->hs_young, d.hsyoung, ne},
         {s->conc_myi, d.cmyi, ne}, {s->thick_myi, d.tmyi, ne},
     };
+    if (h->res_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); int rc = resident_error(h); if (rc) return rc; }  // never a half-made step without an error
     if (s->damage || s->sigma[0] || s->sigma[1] || s->sigma[2]) ensure_arrays(h);
     for (auto &c : cp) if (c.dst) pin_host_buffer(h, c.dst, c.bytes);
     for (auto &c : cp) if (c.dst) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_get_state"); }
 
-int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f) {
+int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f) try {
     if (!h || !f) return NXS_ERR_INVALID;
     if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "set_forcing before set_mesh");
     if (!f->wind || !f->ocean || !f->ssh || !f->element_depth) return fail(h, NXS_ERR_INVALID, "forcing has NULL arrays");
@@ -1158,9 +1194,9 @@ int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f) {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_forcing = true;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_forcing"); }
 
-int nxs_dyn_set_forcing_pair(nxs_dyn_handle *h, const nxs_dyn_forcing *f0, const nxs_dyn_forcing *f1) {
+int nxs_dyn_set_forcing_pair(nxs_dyn_handle *h, const nxs_dyn_forcing *f0, const nxs_dyn_forcing *f1) try {
     if (!h || !f0 || !f1) return NXS_ERR_INVALID;
     if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "set_forcing_pair before set_mesh");
     if (!f0->wind || !f0->ocean || !f0->ssh || !f0->element_depth || !f1->wind || !f1->ocean || !f1->ssh) return fail(h, NXS_ERR_INVALID, "forcing has NULL arrays");
@@ -1175,9 +1211,9 @@ int nxs_dyn_set_forcing_pair(nxs_dyn_handle *h, const nxs_dyn_forcing *f0, const
     HIPCHK(h, hipStreamSynchronize(h->stream));
     h->have_pair = true;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_forcing_pair"); }
 
-int nxs_dyn_set_forcing_time(nxs_dyn_handle *h, double fcoeff0, double fcoeff1, const double factor[3], const double bias[3]) {
+int nxs_dyn_set_forcing_time(nxs_dyn_handle *h, double fcoeff0, double fcoeff1, const double factor[3], const double bias[3]) try {
     if (!h) return NXS_ERR_INVALID;
     if (!h->have_pair) return fail(h, NXS_ERR_STATE, "set_forcing_time before set_forcing_pair");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1186,9 +1222,9 @@ int nxs_dyn_set_forcing_time(nxs_dyn_handle *h, double fcoeff0, double fcoeff1, 
     hipLaunchKernelGGL(k_blend_forcing, dim3(nblocks(2 * h->dm.Nn)), dim3(BLOCK), 0, h->stream, h->dm.Nn, b, h->ds.wind, h->ds.ocean, h->ds.ssh);
     h->have_forcing = true;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_set_forcing_time"); }
 
-int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *dg) {
+int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *dg) try {
     if (!h || !dg) return NXS_ERR_INVALID;
     if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "get_diag before set_mesh");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1200,10 +1236,10 @@ int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *dg) {
     if (dg->D_del_ci_ridge_myi) HIPCHK(h, hipMemcpyAsync(dg->D_del_ci_ridge_myi, h->dw.D_del, ne, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_get_diag"); }
 
 // test door: the branch trace of updateSigmaDamage (option "trace_branches"), 4 words per element
-int nxs_dyn_get_branch_trace(nxs_dyn_handle *h, uint64_t *out, int64_t num_words) {
+int nxs_dyn_get_branch_trace(nxs_dyn_handle *h, uint64_t *out, int64_t num_words) try {
     if (!h || !out) return NXS_ERR_INVALID;
     if (!h->have_mesh || !h->dw.trace) return fail(h, NXS_ERR_STATE, "get_branch_trace: set option trace_branches = 1 first");
     if (num_words != 4 * (int64_t)h->dm.Ne) return fail(h, NXS_ERR_INVALID, "get_branch_trace: %lld words expected", 4ll * h->dm.Ne);
@@ -1211,10 +1247,10 @@ int nxs_dyn_get_branch_trace(nxs_dyn_handle *h, uint64_t *out, int64_t num_words
     HIPCHK(h, hipMemcpyAsync(out, h->dw.trace, (size_t)num_words * sizeof(uint64_t), hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_get_branch_trace"); }
 
 // debug / test door: copy a named work array to the host (n doubles)
-int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_t n) {
+int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_t n) try {
     if (!h || !name || !out) return NXS_ERR_INVALID;
     if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "debug_array before set_mesh");
     HIPCHK(h, hipSetDevice(h->device));
@@ -1244,7 +1280,7 @@ int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_
     }
 #endif
     return fail(h, NXS_ERR_INVALID, "unknown debug array '%s'", name);
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_debug_array"); }
 
 // ------------------------------------------------------------------------------------------------
 // the launches
@@ -1376,93 +1412,78 @@ int setup_ring(nxs_dyn_handle *h, int K) {
     return NXS_OK;
 }
 
+// The resident sub-step kernel of this handle: ONE place decides the instantiation, for the occupancy query and for the launch alike.
+// (WPE = 2: the several-rank build with all the registers it wants, BBM's default exponent only.)
+const void *resident_kernel(const nxs_dyn_handle *h, bool mr, bool ovl) {
+    const bool p4 = h->res_pow4;
+    if (mr && h->res_wpe == 2 && p4) return ovl ? (const void *)k_substep_resident<512, true, true, true, 2> : (const void *)k_substep_resident<512, true, true, false, 2>;
+    if (mr && ovl) return p4 ? (const void *)k_substep_resident<512, true, true, true> : (const void *)k_substep_resident<512, false, true, true>;
+    if (mr) return p4 ? (const void *)k_substep_resident<512, true, true> : (const void *)k_substep_resident<512, false, true>;
+    return p4 ? (const void *)k_substep_resident<512, true, false> : (const void *)k_substep_resident<512, false, false>;
+}
+
+// The resident launch needs every workgroup of its grid on a CU at once, and its workgroups spin: two such grids on one device whose
+// sum does not fit keep each other's missing workgroups from ever starting (both then time out).  A handle therefore claims its
+// workgroup slots per device in this registry and gives them back when its tables go; a grid that would not fit beside the ones already
+// claimed is refused up front (the step then runs one kernel per sub-step).  Handles of OTHER processes on the same device cannot be
+// seen from here: option fused = 4 remains "this process has the device to itself".
+struct ResidentRegistry {
+    std::mutex mu;
+    std::map<int, std::map<const nxs_dyn_handle *, std::pair<int, int>>> claims;  // device -> handle -> (workgroups, the device's slots for that kernel build)
+};
+ResidentRegistry g_resident_registry;
+void resident_registry_release(const nxs_dyn_handle *h) {
+    ResidentRegistry &R = g_resident_registry;
+    std::lock_guard<std::mutex> lk(R.mu);
+    auto it = R.claims.find(h->device);
+    if (it != R.claims.end()) it->second.erase(h);
+}
+bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots) {
+    ResidentRegistry &R = g_resident_registry;
+    std::lock_guard<std::mutex> lk(R.mu);
+    auto &dev = R.claims[h->device];
+    dev.erase(h);
+    // fractions of the device, because the builds differ in how many of their workgroups a CU holds
+    double used = (double)workgroups / std::max(slots, 1);
+    for (const auto &kv : dev) used += (double)kv.second.first / std::max(kv.second.second, 1);
+    if (used > 1.0 + 1e-9) return false;
+    dev[h] = std::make_pair(workgroups, slots);
+    return true;
+}
+
 // tables of the halo exchange fused into the sub-step kernel (see HaloFused)
 int build_halo_fused(nxs_dyn_handle *h) {
     free_pool(h->hf_allocs);
     h->hf = HaloFused{};
     h->hf_ready = false;
     const int Nn = h->dm.Nn, No = h->dm.No, nP = h->dpch.nP;
-    const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
-    if (!h->hp || h->hp->nP != nP || (int)h->h_recv_index.size() != Nn - No) return fail(h, NXS_ERR_STATE, "fused halo tables: patches / halo lists missing");
-    // sending side: CSR over own nodes
-    std::vector<int> sptr(No + 1, 0);
-    for (int k = 0; k < ns; ++k)
-        for (int j = h->send_offsets[k]; j < h->send_offsets[k + 1]; ++j) sptr[h->h_send_index[j] + 1]++;
-    for (int n = 0; n < No; ++n) sptr[n + 1] += sptr[n];
-    std::vector<int> sk(std::max(sptr[No], 1)), spos(std::max(sptr[No], 1)), fill(sptr.begin(), sptr.end() - 1);
-    for (int k = 0; k < ns; ++k)
-        for (int j = h->send_offsets[k]; j < h->send_offsets[k + 1]; ++j) {
-            const int q = fill[h->h_send_index[j]]++;
-            sk[q] = k;
-            spos[q] = j - h->send_offsets[k];
-        }
-    // receiving side: where each ghost node sits inside a mailbox half (layout of k_halo_pull)
-    std::vector<int> goff(std::max(Nn - No, 1), 0), gsrl(std::max(Nn - No, 1), 0), gk(std::max(Nn - No, 1), 0);
-    for (int k = 0; k < nr; ++k) {
-        const int off = h->recv_offsets[k], srl = h->recv_offsets[k + 1] - off;
-        for (int j = off; j < h->recv_offsets[k + 1]; ++j) {
-            goff[h->h_recv_index[j] - No] = 2 * off + (j - off);
-            gsrl[h->h_recv_index[j] - No] = srl;
-            gk[h->h_recv_index[j] - No] = k;
-        }
-    }
-    // boundary patches: send something or stage a ghost node.  The patch arrays are re-uploaded with those patches
-    // FIRST, so that the grid starts with them and "boundary" is blk < n_boundary (no lookup on the critical path)
-    HostPatches &hp = *h->hp;
-    std::vector<int> order_b, order_i;
-    for (int q = 0; q < nP; ++q) {
-        const int *nd = hp.pnodes.data() + (size_t)q * hp.Mmax;
-        bool bnd = false;
-        for (int i = 0; i < hp.node_cnt[q] && !bnd; ++i) {
-            const int n = nd[i];
-            bnd = (n >= No) || (i < hp.own_cnt[q] && sptr[n + 1] > sptr[n]);
-        }
-        (bnd ? order_b : order_i).push_back(q);
-    }
-    const int nb = (int)order_b.size();
-    bool sorted = true;
-    for (int q = 0; q < nb; ++q) sorted = sorted && order_b[q] == q;
-    if (!sorted) {
-        std::vector<int> order(order_b);
-        order.insert(order.end(), order_i.begin(), order_i.end());
-        HostPatches r = hp;
-        for (int q = 0; q < nP; ++q) {
-            const int o = order[q];
-            r.own_cnt[q] = hp.own_cnt[o]; r.elem_cnt[q] = hp.elem_cnt[o]; r.node_cnt[q] = hp.node_cnt[o];
-            std::copy_n(hp.pnodes.begin() + (size_t)o * hp.Mmax, hp.Mmax, r.pnodes.begin() + (size_t)q * hp.Mmax);
-            std::copy_n(hp.pelem.begin() + (size_t)o * hp.Emax, hp.Emax, r.pelem.begin() + (size_t)q * hp.Emax);
-            std::copy_n(hp.ptri.begin() + (size_t)o * hp.Emax * 4, (size_t)hp.Emax * 4, r.ptri.begin() + (size_t)q * hp.Emax * 4);
-            std::copy_n(hp.pfan.begin() + (size_t)o * hp.Wp * hp.Pmax, (size_t)hp.Wp * hp.Pmax, r.pfan.begin() + (size_t)q * hp.Wp * hp.Pmax);
-        }
-        hp = std::move(r);
+    if (!h->hp || h->hp->nP != nP) return fail(h, NXS_ERR_STATE, "fused halo tables: patches / halo lists missing");
+    const nxs_cut::HaloLists hl{&h->send_offsets, &h->recv_offsets, &h->h_send_index, &h->h_recv_index, (int)h->send_procs.size(), (int)h->recv_procs.size()};
+    nxs_cut::HaloFusedPlan plan;
+    const std::string why = nxs_cut::plan_halo_fused(Nn, No, hl, *h->hp, plan);  // (host only: nxs_patchcut.hpp)
+    if (!why.empty()) return fail(h, NXS_ERR_STATE, "%s", why.c_str());
+    if (plan.reordered) {  // the patch arrays again, boundary patches first: the grid starts with them and "boundary" is blk < n_boundary
         HIPCHK(h, hipStreamSynchronize(h->stream));
         release_graph(h);
-        int rcu = upload_host_patches(h, hp);
+        int rcu = upload_host_patches(h, *h->hp);
         if (rcu) return rcu;
     }
     HaloFused &f = h->hf;
     int rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.send_ptr, sptr))) return rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.send_k, sk))) return rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.send_pos, spos))) return rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_off, goff))) return rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_srl, gsrl))) return rc;
-    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_k, gk))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.send_ptr, plan.sptr))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.send_k, plan.sk))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.send_pos, plan.spos))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_off, plan.goff))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_srl, plan.gsrl))) return rc;
+    if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_k, plan.gk))) return rc;
     unsigned int *ctr = nullptr;
     if ((rc = dev_alloc(h, h->hf_allocs, &ctr, 32 * 17))) return rc;
     HIPCHK(h, hipMemsetAsync(ctr, 0, 32 * 17 * sizeof(unsigned int), h->stream));
     f.done_all = ctr;
-    {   // k_smooth_halo runs BLOCK own nodes per block: which blocks store into a mailbox
-        const int nblk = std::max(1, (No + BLOCK - 1) / BLOCK);
-        std::vector<int> rank_of(nblk, -1);
-        int cnt = 0;
-        for (int b = 0; b < nblk; ++b)
-            if (sptr[std::min(No, (b + 1) * BLOCK)] > sptr[std::min(No, b * BLOCK)]) rank_of[b] = cnt++;
-        if ((rc = dev_upload(h, h->hf_allocs, &f.send_block_rank, rank_of))) return rc;
-        f.n_send_blocks = cnt;
-    }
+    if ((rc = dev_upload(h, h->hf_allocs, &f.send_block_rank, plan.send_block_rank))) return rc;  // k_smooth_halo: which blocks store into a mailbox
+    f.n_send_blocks = plan.n_send_blocks;
     f.send_off = h->d_send_off;
-    f.n_boundary = nb;
+    f.n_boundary = plan.n_boundary;
     f.No = No;
     {
         unsigned long long *raw = nullptr;  // device copy of the struct itself (filled in by run_substeps once the mailboxes are connected)
@@ -1471,122 +1492,79 @@ int build_halo_fused(nxs_dyn_handle *h) {
         h->d_hf_dirty = true;
     }
     h->hf_ready = true;
-    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d fused halo: %d of %d patches on the boundary, %d sent nodes, %d ghosts\n", h->rank, nb, nP, sptr[No], Nn - No);
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d fused halo: %d of %d patches on the boundary, %d sent nodes, %d ghosts\n", h->rank, plan.n_boundary, nP, plan.sptr[No], Nn - No);
     return NXS_OK;
 }
 
-// Tables of the resident sub-step kernel: which patches own each patch's halo nodes; the counters; the exchange buffers; with
-// several ranks, which patch moves which ghost node.  NXS_OK with res_ready == false means "not possible here" (the caller then
-// runs one kernel per sub-step).
+// Tables of the resident sub-step kernel (nxs_cut::plan_resident), the counters, the exchange buffers.  NXS_OK with res_ready == false
+// means "not possible here" (the caller then runs one kernel per sub-step).  Everything lives in a pool of its own that is given back
+// before it is rebuilt (options fused / resident_wide / resident_overlap / resident_dryrun, a change of parameters, a timed-out launch).
 int build_resident(nxs_dyn_handle *h) {
     h->res_ready = false;
+    free_pool(h->res_allocs);
+    h->res = DevResident{};
+    h->d_vt3 = nullptr;
     if (!h->hp || h->hp->nP != h->dpch.nP) return NXS_OK;
     const HostPatches &hp = *h->hp;
-    const int nP = hp.nP, No = h->dm.No, Nn = h->dm.Nn;
+    const int nP = hp.nP, No = h->dm.No, Nn = h->dm.Nn, S = h->dp.substeps;
     const bool mr = multi_rank(h);
-    if (hp.Emax > 512 || hp.Pmax > 512 || h->dp.substeps > NXS_RES_MAXS) { h->res_failed = true; return NXS_OK;  }  // one element per thread
-    std::vector<int> owner(Nn, -1);
-    for (int q = 0; q < nP; ++q)
-        for (int i = 0; i < hp.own_cnt[q]; ++i) owner[hp.pnodes[(size_t)q * hp.Mmax + i]] = q;
-    std::vector<int> nbr((size_t)nP * NXS_RES_NBR, -1), cnt(nP, 0);
-    std::vector<char> ghost_taken(std::max(Nn - No, 1), 0);
-    for (int q = 0; q < nP; ++q)
-        for (int i = hp.own_cnt[q]; i < hp.node_cnt[q]; ++i) {
-            const int g = hp.pnodes[(size_t)q * hp.Mmax + i];
-            if (g >= No) {  // a ghost node (several ranks): it comes from the mailbox, and every patch that stages it notes what arrived in the ghosts' ring
-                if (!mr) { h->res_failed = true; return NXS_OK; }
-                ghost_taken[g - No] = 1;
-                continue;
-            }
-            const int o = owner[g];
-            if (o < 0 || o == q) { h->res_failed = true; return NXS_OK; }  // a staged node nobody solves
-            int *row = nbr.data() + (size_t)q * NXS_RES_NBR;
-            bool have = false;
-            for (int k = 0; k < cnt[q]; ++k) have = have || row[k] == o;
-            if (have) continue;
-            if (cnt[q] == NXS_RES_NBR) { h->res_failed = true; return NXS_OK; }
-            row[cnt[q]++] = o;
-        }
-    for (int g = No; g < Nn; ++g) if (!ghost_taken[g - No]) { h->res_failed = true; return NXS_OK; }  // a ghost node no patch stages: nobody would note its velocities
-    if (mr && (int)h->send_procs.size() > NXS_RES_MAXNB) { h->res_failed = true; return NXS_OK; }
+    const bool ovl = mr && h->res_overlap;
+    auto refuse = [&](const char *why) {
+        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel not possible: %s\n", h->rank, why);
+        h->res_failed = true;
+        return NXS_OK;
+    };
+    if (S > NXS_RES_MAXS) return refuse("more sub-steps than the kernel keeps counters for");
+    nxs_cut::ResidentPlan plan;
+    nxs_cut::plan_resident(hp, Nn, No, mr, (int)h->send_procs.size(), ovl, plan);
+    if (!plan.ok) return refuse(plan.why.c_str());
     h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax  // + the pair of zeros behind the corner forces + [Pmax][8] fan entries
                  + (mr ? 16 * (size_t)std::min(hp.Mmax, 512) + 20 * (size_t)NXS_RES_MAXNB : 0);  // + the halo slots' sources and the neighbour ranks' mailbox addresses
     // every workgroup must be resident at once
-    int per_cu = 0, cus = 0;
+    int per_cu = 0;
+    const int cus = device_cus(h);
     const bool p4 = h->dp.ers_int == 4;
-    const bool ovl = mr && h->res_overlap;
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
     // one workgroup per CU is enough and the caller says the device is this handle's alone (option resident_wide): the several-rank build with all
     // the registers it wants -- one such workgroup fills a CU, so ranks that share a device (the tests) would no longer fit side by side
     h->res_wpe = (mr && p4 && h->res_wide && nP <= cus) ? 2 : 4;
-    hipError_t e = (mr && h->res_wpe == 2) ? (ovl ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, true, 2>, 512, h->res_lds)
-                                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, false, 2>, 512, h->res_lds))
-                 : ovl ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true, true>, 512, h->res_lds)
-                             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, true, true>, 512, h->res_lds))
-                 : mr ? (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, true>, 512, h->res_lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, true>, 512, h->res_lds))
-                      : (p4 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, true, false>, 512, h->res_lds)
-                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_substep_resident<512, false, false>, 512, h->res_lds));
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device);
+    h->res_pow4 = p4;
+    const void *kern = resident_kernel(h, mr, ovl);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, h->res_lds);
     if (e != hipSuccess || (long long)per_cu * cus < nP) {
         (void)hipGetLastError();
-        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] resident kernel not possible: %d patches, %d x %d workgroups fit (%zu B of LDS each)\n", nP, per_cu, cus, h->res_lds);
-        h->res_failed = true;
-        return NXS_OK;
+        char why[160];
+        snprintf(why, sizeof why, "%d patches, %d x %d workgroups fit (%zu B of LDS each)", nP, per_cu, cus, h->res_lds);
+        return refuse(why);
     }
+    // the device's other resident grids (other handles of this process: the ranks a host drives from one process, the tests): all of them
+    // together must fit, or the spinning workgroups of one keep the other's from ever starting
+    if (!resident_registry_claim(h, nP, per_cu * cus)) return refuse("the device's resident workgroup slots are taken by other handles of this process");
     int rc;
     DevResident &r = h->res;
-    r = DevResident{};
     if (ovl) {
-        // Interior elements first: an element none of whose corners is a halo node of its patch needs nothing from outside, so its next
-        // update can be computed while the patch waits for the exchange.  A stable partition of every patch's element list (whole
-        // wavefronts of interior elements only: ecut is a multiple of 64); the fan entries keep their (ascending global element) order and
-        // only name the new slots, so the additions of the gather stay the reference's.
-        std::vector<int> rpelem(hp.pelem.size()), ecut(nP, 0), newslot(hp.Emax);
-        std::vector<unsigned short> rptri(hp.ptri.size()), rpfan(hp.pfan.size(), 0xFFFF);
-        long long tot_early = 0, tot_e = 0;
-        for (int q = 0; q < nP; ++q) {
-            const int nE = hp.elem_cnt[q], nO = hp.own_cnt[q];
-            const unsigned short *tq = hp.ptri.data() + (size_t)q * hp.Emax * 4;
-            auto interior = [&](int l) { return tq[4 * l] < nO && tq[4 * l + 1] < nO && tq[4 * l + 2] < nO; };
-            int nint = 0;
-            for (int l = 0; l < nE; ++l) nint += interior(l) ? 1 : 0;
-            int a = 0, b2 = nint;
-            for (int l = 0; l < nE; ++l) newslot[l] = interior(l) ? a++ : b2++;
-            for (int l = nE; l < hp.Emax; ++l) newslot[l] = l;
-            for (int l = 0; l < hp.Emax; ++l) {
-                rpelem[(size_t)q * hp.Emax + newslot[l]] = hp.pelem[(size_t)q * hp.Emax + l];
-                for (int k = 0; k < 4; ++k) rptri[((size_t)q * hp.Emax + newslot[l]) * 4 + k] = tq[4 * l + k];
-            }
-            for (size_t i = (size_t)q * hp.Wp * hp.Pmax; i < (size_t)(q + 1) * hp.Wp * hp.Pmax; ++i) {
-                const unsigned short ent = hp.pfan[i];
-                rpfan[i] = ent == 0xFFFF ? ent : (unsigned short)((newslot[ent >> 3] << 3) | (ent & 7));
-            }
-            ecut[q] = (nint / 64) * 64;
-            tot_early += ecut[q]; tot_e += nE;
-        }
-        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %.1f %% of the patch elements computed under the exchange\n", h->rank, 100. * tot_early / std::max(1ll, tot_e));
-        if ((rc = dev_upload(h, h->patch_allocs, &r.pelem, rpelem))) return rc;
-        if ((rc = dev_upload(h, h->patch_allocs, &r.ptri, rptri))) return rc;
-        if ((rc = dev_upload(h, h->patch_allocs, &r.pfan, rpfan))) return rc;
-        if ((rc = dev_upload(h, h->patch_allocs, &r.ecut, ecut))) return rc;
+        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %.1f %% of the patch elements computed under the exchange\n", h->rank, 100. * plan.early_fraction);
+        if ((rc = dev_upload(h, h->res_allocs, &r.pelem, plan.rpelem))) return rc;
+        if ((rc = dev_upload(h, h->res_allocs, &r.ptri, plan.rptri))) return rc;
+        if ((rc = dev_upload(h, h->res_allocs, &r.pfan, plan.rpfan))) return rc;
+        if ((rc = dev_upload(h, h->res_allocs, &r.ecut, plan.ecut))) return rc;
     }
-    if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr, nbr))) return rc;
-    if ((rc = dev_upload(h, h->patch_allocs, &r.pnbr_cnt, cnt))) return rc;
+    if ((rc = dev_upload(h, h->res_allocs, &r.pnbr, plan.nbr))) return rc;
+    if ((rc = dev_upload(h, h->res_allocs, &r.pnbr_cnt, plan.cnt))) return rc;
     r.rank = h->rank;
-    if (mr) {  // the ghosts' ring: what arrived after every sub-step but the last
+    if (mr) {  // the ghosts' ring: what arrived after every sub-step but the last (sized for THIS number of sub-steps: a change of parameters rebuilds the tables)
         r.NG = Nn - No;
-        if ((rc = dev_alloc(h, h->patch_allocs, &r.gring, std::max<size_t>((size_t)(NXS_RES_MAXS - 1) * 2 * (size_t)r.NG, 1)  /* (any number of sub-steps the kernel accepts: the parameters may change) */))) return rc;
+        if ((rc = dev_alloc(h, h->res_allocs, &r.gring, std::max<size_t>((size_t)std::max(S - 1, 1) * 2 * (size_t)r.NG, 1)))) return rc;
     }
-    if ((rc = dev_alloc(h, h->patch_allocs, &r.flag, 32 * (size_t)nP + NXS_RES_MAXS + 32))) return rc;  // counters behind the flags: one memset per launch
+    h->res_substeps = S;
+    if ((rc = dev_alloc(h, h->res_allocs, &r.flag, 32 * (size_t)nP + NXS_RES_MAXS + 32))) return rc;  // counters behind the flags: one memset per launch
     r.cnt = r.flag + 32 * (size_t)nP;
     r.raised = r.cnt + NXS_RES_MAXS;
-    if ((rc = dev_alloc(h, h->patch_allocs, &r.error, 1))) return rc;
+    if ((rc = dev_alloc(h, h->res_allocs, &r.error, 1))) return rc;
     HIPCHK(h, hipMemsetAsync(r.error, 0, sizeof(int), h->stream));
-    if (!h->d_vt3 && (rc = dev_alloc(h, h->state_allocs, &h->d_vt3, 2 * (size_t)Nn))) return rc;
+    if ((rc = dev_alloc(h, h->res_allocs, &h->d_vt3, 2 * (size_t)Nn))) return rc;
     r.X0 = h->ds.VT2; r.X1 = h->d_vt3;
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %d patches (%d x %d fit), %zu B of LDS each, up to %d neighbour patches, %d ghost nodes\n", h->rank, nP, per_cu, cus, h->res_lds, *std::max_element(cnt.begin(), cnt.end()), mr ? Nn - No : 0);
+    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel: %d patches (%d x %d fit), %zu B of LDS each, up to %d neighbour patches, %d ghost nodes\n", h->rank, nP, per_cu, cus, h->res_lds, plan.max_nbr, mr ? Nn - No : 0);
     h->res_ready = true;
     return NXS_OK;
 }
@@ -1659,6 +1637,10 @@ int run_substeps(nxs_dyn_handle *h) {
     // v4: resident sub-step loop (opt-in).  Several ranks: only with the exchange inside the kernels (device-direct mailboxes).
     const bool res_wanted = h->fused == 4 && !h->trace_branches && !pair && move_dt != 0. && (!mr || (device_halo && h->halo_fused));
     if (res_wanted && mr && !h->hf_ready) { int rc = build_halo_fused(h); if (rc) return rc; }  // (re-uploads the patches boundary-first)
+    if (h->res_ready && (h->res_substeps != S || h->res_pow4 != (h->dp.ers_int == 4))) {  // parameters changed since the tables were built:
+        h->res_ready = false;                                                           // another kernel build (its residency unchecked), a ring of another length
+        release_graph(h);
+    }
     if (res_wanted && !h->res_ready && !h->res_failed) {  // (outside any capture)
         int rcr = build_resident(h);
         if (rcr) return rcr;
@@ -1684,28 +1666,25 @@ int run_substeps(nxs_dyn_handle *h) {
     auto loop = [&]() -> int {
         if (resident) {  // the whole loop in one launch; the element state is read from and written back to S4a (each record by its one writer)
             HIPCHK(h, hipMemsetAsync(h->res.flag, 0, (32 * (size_t)h->dpch.nP + NXS_RES_MAXS + 32) * sizeof(unsigned int), h->stream));
-            const dim3 grid(h->dpch.nP);
-            const bool p4 = h->dp.ers_int == 4;
-#define RESIDENT(PP, HH, HFP, NB) hipLaunchKernelGGL((k_substep_resident<512, PP, HH>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, HFP, NB)
+            {
+                const DevParams *pdev = h->d_dp;
+                const double *Sc = h->ds.S4a;
+                double *Sn = h->ds.S4a;
+                double mdt = move_dt;
+                const HaloFused *hfp = mr ? h->d_hf : nullptr;
+                int nb = mr ? h->hf.n_boundary : 0;
+                void *args[] = {&h->dm, &h->dpch, &h->ds, &h->dw, &pdev, &h->res, &Sc, &Sn, &mdt, &hfp, &nb};
+                HIPCHK(h, hipLaunchKernel(resident_kernel(h, mr, mr && h->res_overlap), dim3(h->dpch.nP), dim3(512), args, h->res_lds, h->stream));
+            }
             if (mr) {
-#define RESIDENT_OVL(PP) hipLaunchKernelGGL((k_substep_resident<512, PP, true, true>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, (const HaloFused *)h->d_hf, h->hf.n_boundary)
-#define RESIDENT_W2(OO) hipLaunchKernelGGL((k_substep_resident<512, true, true, OO, 2>), grid, dim3(512), h->res_lds, h->stream, h->dm, h->dpch, h->ds, h->dw, (const DevParams *)h->d_dp, h->res, (const double *)h->ds.S4a, h->ds.S4a, move_dt, (const HaloFused *)h->d_hf, h->hf.n_boundary)
-                if (h->res_wpe == 2 && p4) { if (h->res_overlap) RESIDENT_W2(true); else RESIDENT_W2(false); }
-                else if (h->res_overlap) { if (p4) RESIDENT_OVL(true); else RESIDENT_OVL(false); }
-                else if (p4) RESIDENT(true, true, (const HaloFused *)h->d_hf, h->hf.n_boundary); else RESIDENT(false, true, (const HaloFused *)h->d_hf, h->hf.n_boundary);
-#undef RESIDENT_OVL
-#undef RESIDENT_W2
                 // the ghosts' mesh moves of all sub-steps but the last, from the ring the launch filled ...
                 if (move_dt != 0. && h->res.NG > 0 && S > 1)
-                    hipLaunchKernelGGL(k_ghost_ring_move, dim3(nblocks(h->res.NG)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, (const double *)h->res.gring, h->res.NG, S - 1, move_dt);
+                    hipLaunchKernelGGL(k_ghost_ring_move, dim3(nblocks(h->res.NG)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, (const double *)h->res.gring, h->res.NG, S - 1, move_dt, (const int *)h->res.error);
                 // ... and the exchange of the last sub-step: the ghosts land in M_VT and make their last move
                 const int tr = h->recv_offsets[h->recv_procs.size()];
                 hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, h->ds.VT, h->dm, h->ds, tr, h->d_recv_index,
                                    h->d_recv_seg, h->d_recv_off, h->ipc, move_dt, 0, h->d_recv_procs, 1);
-            } else {
-                if (p4) RESIDENT(true, false, (const HaloFused *)nullptr, 0); else RESIDENT(false, false, (const HaloFused *)nullptr, 0);
             }
-#undef RESIDENT
             return NXS_OK;
         }
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
@@ -1895,22 +1874,22 @@ int explicit_solve(nxs_dyn_handle *h) {
 
 }  // namespace
 
-int nxs_dyn_explicit_solve(nxs_dyn_handle *h) {
+int nxs_dyn_explicit_solve(nxs_dyn_handle *h) try {
     int rc = ready(h);
     if (rc) return rc;
     h->cur = nullptr;
     return explicit_solve(h);
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_explicit_solve"); }
 
-int nxs_dyn_update(nxs_dyn_handle *h) {
+int nxs_dyn_update(nxs_dyn_handle *h) try {
     int rc = ready(h);
     if (rc) return rc;
     if (h->sig_loc) LAUNCH(h, k_update<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     else LAUNCH(h, k_update<false>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_update"); }
 
-int nxs_dyn_step(nxs_dyn_handle *h) {  // FE.cpp:8197-8214
+int nxs_dyn_step(nxs_dyn_handle *h) try {  // FE.cpp:8197-8214
     int rc = ready(h);
     if (rc) return rc;
     const int type = h->dp.dynamics_type;
@@ -1938,23 +1917,14 @@ int nxs_dyn_step(nxs_dyn_handle *h) {  // FE.cpp:8197-8214
         h->cur = nullptr;
     }
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_step"); }
 
-int nxs_dyn_synchronize(nxs_dyn_handle *h) {
+int nxs_dyn_synchronize(nxs_dyn_handle *h) try {
     if (!h) return NXS_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     HIPCHK(h, hipGetLastError());
-    if (h->res_ready) {
-        int err = 0;
-        HIPCHK(h, hipMemcpyAsync(&err, h->res.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(h, hipStreamSynchronize(h->stream));
-        if (err) {
-            h->res_failed = true; h->res_ready = false; release_graph(h);
-            return fail(h, NXS_ERR_HIP, "the resident sub-step kernel timed out waiting for a neighbouring patch (its workgroups were not all resident: is the "
-                                        "device shared?); the step is lost, later steps run one kernel per sub-step");
-        }
-    }
+    { int rc = resident_error(h); if (rc) return rc; }
     if (h->ipc_ready) {
         int err = 0;
         HIPCHK(h, hipMemcpyAsync(&err, h->ipc.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
@@ -1962,9 +1932,9 @@ int nxs_dyn_synchronize(nxs_dyn_handle *h) {
         if (err) return fail(h, NXS_ERR_COMM, "device-direct halo exchange failed (%s)", err == 2 ? "self-test mismatch" : "a neighbour's flag did not arrive within 10 s");
     }
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_synchronize"); }
 
-int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t) {
+int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t) try {
     if (!h || !t) return NXS_ERR_INVALID;
     HIPCHK(h, hipSetDevice(h->device));
     for (int k = 0; k < nxs_dyn_handle::NSETS; ++k) {
@@ -1978,17 +1948,17 @@ int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t) {
     h->timing.steps_averaged = h->sum_steps;
     *t = h->timing;
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_get_timing"); }
 
-int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f) {
+int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f) try {
     int rc;
     if ((rc = nxs_dyn_put_state(h, s))) return rc;
     if ((rc = nxs_dyn_set_forcing(h, f))) return rc;
     if ((rc = nxs_dyn_step(h))) return rc;
     return nxs_dyn_get_state(h, s);
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_step_host"); }
 
-int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32_t *flip, int32_t *regrid_local) {
+int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32_t *flip, int32_t *regrid_local) try {
     if (!h) return NXS_ERR_INVALID;
     if (!h->have_mesh || !h->have_state) return fail(h, NXS_ERR_STATE, "check_regridding needs set_mesh and put_state");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2001,10 +1971,11 @@ int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32_t *flip
     if (min_angle) *min_angle = r.min_angle;
     if (flip) *flip = fl;
     if (regrid_local) *regrid_local = (r.min_angle < h->params.regrid_angle) || fl;  // FE.cpp:8303-8305
+    { int rc = resident_error(h); if (rc) return rc; }
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_check_regridding"); }
 
-int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local) {
+int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local) try {
     if (!h || !crash_local) return NXS_ERR_INVALID;
     if (!h->have_mesh || !h->have_state) return fail(h, NXS_ERR_STATE, "check_fields_fast needs set_mesh and put_state");
     HIPCHK(h, hipSetDevice(h->device));
@@ -2014,7 +1985,8 @@ int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local) {
     HIPCHK(h, hipMemcpyAsync(&c, h->d_crash, sizeof c, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     *crash_local = c;
+    { int rc = resident_error(h); if (rc) return rc; }
     return NXS_OK;
-}
+} catch (...) { return dyn_caught(h, "nxs_dyn_check_fields_fast"); }
 
 }  // extern "C"

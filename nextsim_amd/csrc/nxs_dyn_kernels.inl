@@ -1553,7 +1553,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
                 const long long t0 = wall_clock64();
                 while (__hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ss) {
                     __builtin_amdgcn_s_sleep(1);
-                    if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
+                    if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }  // 10 s, as every other inter-rank wait
                 }
                 // the one release of the sub-step -- a RELEASE only: __threadfence_system() is an acquire as well, i.e. it also invalidates this
                 // XCD's L2, and every patch on the XCD then re-reads its element constants from memory instead of the L2, every sub-step
@@ -1577,7 +1577,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
             while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x0 + (unsigned long long)ss + 1ull) {
                 __builtin_amdgcn_s_sleep(2);
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
-                if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 7); break; }  // 2 s
+                if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 7); break; }  // 10 s: the transport's bound (a neighbour rank may start its step late: output, a regrid, host thermodynamics)
             }
         }
         int nb = nbr;
@@ -1587,7 +1587,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
             while (__hip_atomic_load(r.flag + 32 * (size_t)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
                 __builtin_amdgcn_s_sleep(1);
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
-                if (wall_clock64() - t0 > 200000000ll) { lerr = 1; atomicExch(r.error, 5); break; }  // 2 s
+                if (wall_clock64() - t0 > 1200000000ll) { lerr = 1; atomicExch(r.error, 5); break; }  // 12 s: longer than the inter-rank waits, so that a late neighbour RANK is reported as that (7) by the patch that waits for it, not as a missing patch (5) by that patch's neighbours
             }
         }
         __syncthreads();
@@ -1631,7 +1631,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
         __syncthreads();
         RSTAMP(5);
     }
-    // ---- once per step: the element state and the moved mesh go back
+    // ---- once per step: the element state and the moved mesh go back -- unless a wait timed out: then nothing of this patch is written
+    // (M_UM, M_UT, sigma and damage keep their values of the step's start; nxs_dyn_synchronize and every call that hands state to the host report it)
+    __syncthreads();
+    if (lerr) return;
     if (has_elem && writer) {
         d2 *S4 = reinterpret_cast<d2 *>(Sn) + 2 * (size_t)e;
         S4[0] = d2{sig[0], sig[1]}; S4[1] = d2{sig[2], damage};
@@ -1645,9 +1648,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
 // The ghost nodes' mesh moves of a resident launch (FE.cpp:10543-10550): M_UM += dte * M_VT, M_UT += dte * M_VT with the velocity that arrived after
 // each of the first `count` sub-steps, in sub-step order -- the additions the reference makes, from the ring the launch filled (the move of the
 // last sub-step follows in k_halo_pull, with the last exchange).
-__global__ void __launch_bounds__(BLOCK) k_ghost_ring_move(DevMesh m, DevState s, const double *__restrict__ gring, int NG, int count, double dt) {
+__global__ void __launch_bounds__(BLOCK) k_ghost_ring_move(DevMesh m, DevState s, const double *__restrict__ gring, int NG, int count, double dt, const int *__restrict__ error) {
     const int j = blockIdx.x * BLOCK + threadIdx.x;
     if (j >= NG) return;
+    if (*error != 0) return;  // the resident launch gave up: the ring is not complete and the own nodes were not moved either
     const int n = m.No + j, Nn = m.Nn;
     const bool free_node = !(m.nflags[n] & NF_NEUMANN);  // Neumann nodes keep M_UM (restore == skip)
     double umu = s.UM[n], umv = s.UM[n + Nn], utu = s.UT[n], utv = s.UT[n + Nn];

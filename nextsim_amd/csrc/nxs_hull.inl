@@ -38,6 +38,30 @@ struct Completion {
 typedef long long i64;
 typedef __int128 i128;
 
+// bamg's integer plane (SetIntCoor, Mesh.cpp:3441-3468; R2ToI2): bounding box + 5 %, 2^30 - 1 units along its longer side, truncation.
+// false: "coefIcoor should be positive" (a degenerate or non-finite geometry).
+inline bool int_plane(const double *x, const double *y, int nods, std::vector<int> &ix, std::vector<int> &iy, double &coef, double &pminx, double &pminy) {
+    if (nods < 1) return false;
+    double pmaxx = x[0], pmaxy = y[0];
+    pminx = x[0]; pminy = y[0];
+    for (int i = 0; i < nods; ++i) {
+        pminx = std::min(pminx, x[i]); pminy = std::min(pminy, y[i]);
+        pmaxx = std::max(pmaxx, x[i]); pmaxy = std::max(pmaxy, y[i]);
+    }
+    const double DDx = (pmaxx - pminx) * 0.05, DDy = (pmaxy - pminy) * 0.05;
+    pminx = pminx - DDx; pminy = pminy - DDy;
+    pmaxx = pmaxx + DDx; pmaxy = pmaxy + DDy;
+    coef = 1073741823. / std::max(pmaxx - pminx, pmaxy - pminy);
+    if (!(coef > 0.) || !(coef < 1e300)) return false;
+    ix.resize(nods); iy.resize(nods);
+    for (int i = 0; i < nods; ++i) {
+        const double fx = coef * (x[i] - pminx), fy = coef * (y[i] - pminy);
+        if (!(fx >= 0. && fx < 1073741824. && fy >= 0. && fy < 1073741824.)) return false;  // a NaN coordinate: its conversion would be undefined
+        ix[i] = (int)fx; iy[i] = (int)fy;
+    }
+    return true;
+}
+
 struct Pts {
     const int *ix, *iy;
     i64 orient(int a, int b, int c) const {  // include/det.h:8-12; |coordinates| < 2^30, so the result fits

@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "nxs_dyn.h"
+#include "nxs_guard.hpp"
 #include "nxs_interp.h"
 #include "nxs_hull.inl"
 
@@ -36,6 +37,11 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// handler of every extern "C" function-try-block of this file (nxs_guard.hpp): status code + text, never an exception across the ABI
+int entry_caught(const char *entry) noexcept {
+    return nxs_guard::caught(entry, [](int code, const char *text) { (void)fail(code, "%s", text); });
 }
 
 // Every device operation of this file runs on a stream of its own (one per host thread, created on first use), never on the
@@ -336,16 +342,10 @@ struct Locator {
             pmaxx = std::max(pmaxx, x_data[i]); pmaxy = std::max(pmaxy, y_data[i]);
         }
         d.xmin = pminx; d.xmax = pmaxx; d.ymin = pminy; d.ymax = pmaxy;
-        const double DDx = (pmaxx - pminx) * 0.05, DDy = (pmaxy - pminy) * 0.05;
-        pminx = pminx - DDx; pminy = pminy - DDy;
-        pmaxx = pmaxx + DDx; pmaxy = pmaxy + DDy;
-        const double coef = 1073741823. / std::max(pmaxx - pminx, pmaxy - pminy);
-        if (!(coef > 0.)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive, a problem in the geometry is likely");
-        std::vector<int> ix(nods), iy(nods);
-        for (int i = 0; i < nods; ++i) {  // R2ToI2
-            ix[i] = (int)(coef * (x_data[i] - pminx));
-            iy[i] = (int)(coef * (y_data[i] - pminy));
-        }
+        double coef = 0.;
+        std::vector<int> ix, iy;
+        if (!nxs_hull::int_plane(x_data, y_data, nods, ix, iy, coef, pminx, pminy))
+            return fail(NXS_ERR_INVALID, "coefIcoor should be positive, a problem in the geometry is likely");
         t0.resize(nels); t1.resize(nels); t2.resize(nels);
         for (int e = 0; e < nels; ++e) { t0[e] = index_data[3 * e] - 1; t1[e] = index_data[3 * e + 1] - 1; t2[e] = index_data[3 * e + 2] - 1; }
         // ---- bamg's convex completion (isdefault == false only): fill triangles numbered behind the mesh's, hull edges
@@ -411,7 +411,7 @@ struct Locator {
 extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
                                        int32_t nods, int32_t nels, const double *data_mesh, int32_t data_length, int32_t N_data,
                                        double xmin, double ymax, double xposting, double yposting, int32_t nrows, int32_t ncols,
-                                       double default_value, int32_t device, double *kernel_ms) {
+                                       double default_value, int32_t device, double *kernel_ms) try {
     if (!griddata || !index_mesh || !x_mesh || !y_mesh || !data_mesh) return fail(NXS_ERR_INVALID, "NULL argument");
     if (nels < 1 || nods < 3 || ncols < 1 || nrows < 1 || xposting == 0 || yposting == 0 || N_data < 1)  // :34-36
         return fail(NXS_ERR_INVALID, "nothing to be done according to the mesh given in input");
@@ -475,7 +475,7 @@ extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_me
     if (kernel_ms) *kernel_ms = ms;
     if (copy_sync(griddata, dout.p, npts * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_interp_mesh_to_grid"); }
 
 extern "C" const char *nxs_interp_last_error(void) { return g_err.c_str(); }
 
@@ -483,7 +483,7 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
                                           const double *y_data, int32_t nods, int32_t nels, const double *data, int32_t M_data,
                                           int32_t N_data, const double *x_interp, const double *y_interp, int32_t N_interp,
                                           int32_t isdefault, double defaultvalue, int32_t device, int32_t *num_exterior,
-                                          double *kernel_ms) {
+                                          double *kernel_ms) try {
     if (!data_interp || !index_data || !x_data || !y_data || !data || !x_interp || !y_interp) return fail(NXS_ERR_INVALID, "NULL argument");
     if (nods <= 0 || nels <= 0 || N_data <= 0 || N_interp < 0) return fail(NXS_ERR_INVALID, "bad sizes");
     if (M_data != nods && M_data != nels)  // InterpFromMeshToMesh2dx.cpp:39-42
@@ -530,10 +530,10 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     g_info[6] = (!isdefault && !loc.comp.ok) ? 1 : 0;
     g_completion_note = loc.comp.ok ? "" : loc.comp.why;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_interp_mesh_to_mesh_2d"); }
 
 extern "C" int nxs_interp_last_info(int32_t *num_fill_triangles, int32_t *num_hull_edges, int32_t *num_exterior, int32_t *num_in_fill,
-                                    int32_t *num_on_hull, int32_t *num_stand_in, const char **completion_refused) {
+                                    int32_t *num_on_hull, int32_t *num_stand_in, const char **completion_refused) try {
     if (num_fill_triangles) *num_fill_triangles = g_info[0];
     if (num_hull_edges) *num_hull_edges = g_info[1];
     if (num_exterior) *num_exterior = g_info[2];
@@ -542,24 +542,19 @@ extern "C" int nxs_interp_last_info(int32_t *num_fill_triangles, int32_t *num_hu
     if (num_stand_in) *num_stand_in = g_info[5];
     if (completion_refused) *completion_refused = g_info[6] ? g_completion_note.c_str() : nullptr;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_interp_last_info"); }
 
 // Host only: bamg's convex completion of a mesh (see nxs_hull.inl) -- what tests compare with the real bamg.
 extern "C" int nxs_mesh_convex_completion(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
                                           int32_t *num_fill, int32_t *fill_tri, int32_t cap_fill, int32_t *num_hull, int32_t *hull_edges,
-                                          int32_t cap_hull) {
+                                          int32_t cap_hull) try {
     if (!index || !x || !y || nods < 3 || nels < 1 || !num_fill || !num_hull) return fail(NXS_ERR_INVALID, "bad arguments");
     for (int64_t i = 0; i < 3ll * nels; ++i)
         if (index[i] < 1 || index[i] > nods) return fail(NXS_ERR_INVALID, "index[%lld] out of range", (long long)i);
     // SetIntCoor, Mesh.cpp:3441-3468 (as Locator::build)
-    double pminx = x[0], pminy = y[0], pmaxx = x[0], pmaxy = y[0];
-    for (int i = 0; i < nods; ++i) { pminx = std::min(pminx, x[i]); pminy = std::min(pminy, y[i]); pmaxx = std::max(pmaxx, x[i]); pmaxy = std::max(pmaxy, y[i]); }
-    const double DDx = (pmaxx - pminx) * 0.05, DDy = (pmaxy - pminy) * 0.05;
-    pminx = pminx - DDx; pminy = pminy - DDy; pmaxx = pmaxx + DDx; pmaxy = pmaxy + DDy;
-    const double coef = 1073741823. / std::max(pmaxx - pminx, pmaxy - pminy);
-    if (!(coef > 0.)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive");
-    std::vector<int> ix(nods), iy(nods);
-    for (int i = 0; i < nods; ++i) { ix[i] = (int)(coef * (x[i] - pminx)); iy[i] = (int)(coef * (y[i] - pminy)); }
+    double coef = 0., pminx = 0., pminy = 0.;
+    std::vector<int> ix, iy;
+    if (!nxs_hull::int_plane(x, y, nods, ix, iy, coef, pminx, pminy)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive");
     const nxs_hull::Completion c = nxs_hull::complete(index, ix.data(), iy.data(), nods, nels);
     if (!c.ok) return fail(NXS_ERR_INVALID, "no convex completion: %s", c.why.c_str());
     *num_fill = (int)c.fill.size() / 3; *num_hull = (int)c.hull.size();
@@ -569,7 +564,7 @@ extern "C" int nxs_mesh_convex_completion(const int32_t *index, const double *x,
         for (size_t i = 0; i < c.hull.size(); ++i) { hull_edges[2 * i] = c.hull[i].a + 1; hull_edges[2 * i + 1] = c.hull[i].b + 1; }
     }
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_mesh_convex_completion"); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Conservative remapping of the element variables at regrid (ConservativeRemappingMeshToMesh, FE.cpp:3108)
@@ -659,7 +654,7 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
                                              const double *nec_old, int32_t nec_width, const double *ec_old, const int32_t *index_new,
                                              const double *x_new, const double *y_new, int32_t nods_new, int32_t nels_new,
                                              const double *previous_numbering, int32_t n_geom_vertices, int32_t device,
-                                             int32_t *num_failed, int32_t *visits, double *kernel_ms) {
+                                             int32_t *num_failed, int32_t *visits, double *kernel_ms) try {
     if (!interp_out || !interp_in || !index_old || !x_old || !y_old || !index_new || !x_new || !y_new) return fail(NXS_ERR_INVALID, "NULL argument");
     if (nb_var < 1 || nods_old < 3 || nels_old < 1 || nods_new < 3 || nels_new < 1) return fail(NXS_ERR_INVALID, "bad sizes");
     if (nec_old && nec_width < 1) return fail(NXS_ERR_INVALID, "nec_width must be given with the NodalElementConnectivity table");
@@ -762,7 +757,7 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
     (void)copy_sync(&still, dstill.p, sizeof(int), hipMemcpyDeviceToHost);
     if (num_failed) *num_failed = unrecoverable + still;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_interp_conservative_remap"); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Structured grid -> mesh nodes: the forcing ingest (InterpFromGridToMeshx, called at externaldata.cpp:1436)
@@ -860,7 +855,7 @@ int monotone(const double *a, int n) {
 
 extern "C" int nxs_interp_grid_to_mesh(double *data_mesh, const double *x_in, int32_t x_rows, const double *y_in, int32_t y_rows, const double *data,
                                        int32_t M, int32_t N, int32_t N_data, const double *x_mesh, const double *y_mesh, int32_t nods,
-                                       double default_value, int32_t interp, int32_t row_major, int32_t device, double *kernel_ms) {
+                                       double default_value, int32_t interp, int32_t row_major, int32_t device, double *kernel_ms) try {
     if (!data_mesh || !x_in || !y_in || !data || !x_mesh || !y_mesh) return fail(NXS_ERR_INVALID, "NULL argument");
     if ((M < 2) || (N < 2) || (nods <= 0) || N_data < 1) return fail(NXS_ERR_INVALID, "nothing to be done according to the dimensions of input matrices and vectors.");
     if (interp != NXS_INTERP_TRIANGLE && interp != NXS_INTERP_BILINEAR && interp != NXS_INTERP_NEAREST) return fail(NXS_ERR_INVALID, "Interpolation %d not supported yet", interp);
@@ -895,4 +890,4 @@ extern "C" int nxs_interp_grid_to_mesh(double *data_mesh, const double *x_in, in
     if (kernel_ms) *kernel_ms = ms;
     if (copy_sync(data_mesh, dout.p, (size_t)nods * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_interp_grid_to_mesh"); }

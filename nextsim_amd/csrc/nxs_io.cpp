@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "nxs_dyn.h"
+#include "nxs_guard.hpp"
 #include "nxs_io.h"
 
 namespace {
@@ -27,6 +28,11 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// handler of every extern "C" function-try-block of this file (nxs_guard.hpp): status code + text, never an exception across the ABI
+int entry_caught(const char *entry) noexcept {
+    return nxs_guard::caught(entry, [](int code, const char *text) { (void)fail(code, "%s", text); });
 }
 
 // "%g" as boost::format applies it in exporter.cpp:88-94: integers print as integers, reals with %g
@@ -69,7 +75,7 @@ extern "C" {
 
 const char *nxs_io_last_error(void) { return g_err.c_str(); }
 
-int nxs_exporter_open(const char *bin_path, const char *dat_path, const char *precision, nxs_exporter **out) {
+int nxs_exporter_open(const char *bin_path, const char *dat_path, const char *precision, nxs_exporter **out) try {
     if (!bin_path || !dat_path || !precision || !out) return fail(NXS_ERR_INVALID, "NULL argument");
     const std::string prec = precision;
     if (prec != "float" && prec != "double") return fail(NXS_ERR_INVALID, "Exporter: Unknown precision: %s", precision);  // exporter.cpp:23-27
@@ -80,10 +86,10 @@ int nxs_exporter_open(const char *bin_path, const char *dat_path, const char *pr
     e->precision = prec;
     *out = e;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_open"); }
 
 int nxs_exporter_write_mesh(nxs_exporter *e, const double *xnod, const double *ynod, const int32_t *idnod, int64_t nn,
-                            const int32_t *elements, int64_t n3) {
+                            const int32_t *elements, int64_t n3) try {
     if (!e || !xnod || !ynod || !idnod || !elements || nn <= 0 || n3 <= 0) return fail(NXS_ERR_INVALID, "bad mesh arguments");
     int rc;
     if ((rc = write_container(e, elements, n3, "int"))) return rc;
@@ -97,9 +103,9 @@ int nxs_exporter_write_mesh(nxs_exporter *e, const double *xnod, const double *y
     if ((rc = write_container(e, ynod, nn, "double"))) return rc;
     e->records.push_back("Nodes_y double " + g_int(nn) + " " + g_dbl(*std::min_element(ynod, ynod + nn)) + " " + g_dbl(*std::max_element(ynod, ynod + nn)));
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_write_mesh"); }
 
-int nxs_exporter_write_field(nxs_exporter *e, const char *name, const double *v, int64_t n) {
+int nxs_exporter_write_field(nxs_exporter *e, const char *name, const double *v, int64_t n) try {
     if (!e || !name || (n > 0 && !v) || n < 0) return fail(NXS_ERR_INVALID, "bad field arguments");
     std::string prec = e->precision;
     if (!strcmp(name, "Time")) prec = "double";  // exporter.cpp:143-145
@@ -108,18 +114,18 @@ int nxs_exporter_write_field(nxs_exporter *e, const char *name, const double *v,
     e->records.push_back(std::string(name) + " " + prec + " " + g_int(n) + " " + g_dbl(n > 0 ? *std::min_element(v, v + n) : 0.) + " " +
                          g_dbl(n > 0 ? *std::max_element(v, v + n) : 0.));
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_write_field"); }
 
-int nxs_exporter_write_field_int(nxs_exporter *e, const char *name, const int32_t *v, int64_t n) {
+int nxs_exporter_write_field_int(nxs_exporter *e, const char *name, const int32_t *v, int64_t n) try {
     if (!e || !name || (n > 0 && !v) || n < 0) return fail(NXS_ERR_INVALID, "bad field arguments");
     int rc = write_container(e, v, n, "int");
     if (rc) return rc;
     e->records.push_back(std::string(name) + " int " + g_int(n) + " " + g_int(n > 0 ? *std::min_element(v, v + n) : 0) + " " +
                          g_int(n > 0 ? *std::max_element(v, v + n) : 0));
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_write_field_int"); }
 
-int nxs_exporter_close(nxs_exporter *e) {
+int nxs_exporter_close(nxs_exporter *e) try {
     if (!e) return NXS_OK;
     int rc = NXS_OK;
     if (e->bin && fclose(e->bin) != 0) rc = fail(NXS_ERR_INVALID, "close failed");
@@ -131,7 +137,7 @@ int nxs_exporter_close(nxs_exporter *e) {
     }
     delete e;
     return rc;
-}
+} catch (...) { return entry_caught("nxs_exporter_close"); }
 
 }  // extern "C"
 
@@ -145,7 +151,7 @@ struct nxs_exporter_file {
 
 extern "C" {
 
-int nxs_exporter_load(const char *bin_path, const char *dat_path, nxs_exporter_file **out) {
+int nxs_exporter_load(const char *bin_path, const char *dat_path, nxs_exporter_file **out) try {
     if (!bin_path || !dat_path || !out) return fail(NXS_ERR_INVALID, "NULL argument");
     FILE *dat = fopen(dat_path, "r");
     if (!dat) return fail(NXS_ERR_INVALID, "File not found: %s", dat_path);
@@ -177,18 +183,18 @@ int nxs_exporter_load(const char *bin_path, const char *dat_path, nxs_exporter_f
     if (rc) { delete f; return rc; }
     *out = f;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_load"); }
 
 int nxs_exporter_file_num_records(const nxs_exporter_file *f) { return f ? (int)f->recs.size() : 0; }
 
-int nxs_exporter_file_record(const nxs_exporter_file *f, int index, const char **name, const char **type, int64_t *count) {
+int nxs_exporter_file_record(const nxs_exporter_file *f, int index, const char **name, const char **type, int64_t *count) try {
     if (!f || index < 0 || index >= (int)f->recs.size()) return fail(NXS_ERR_INVALID, "record index out of range");
     const auto &r = f->recs[index];
     if (name) *name = r.name.c_str();
     if (type) *type = r.type.c_str();
     if (count) *count = (int64_t)(r.type == "int" ? r.i.size() : r.d.size());
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_file_record"); }
 
 static const nxs_exporter_file::Rec *find_rec(const nxs_exporter_file *f, const char *name) {
     if (!f || !name) return nullptr;
@@ -196,23 +202,23 @@ static const nxs_exporter_file::Rec *find_rec(const nxs_exporter_file *f, const 
     return nullptr;
 }
 
-int nxs_exporter_file_get_double(const nxs_exporter_file *f, const char *name, double *out, int64_t count) {
+int nxs_exporter_file_get_double(const nxs_exporter_file *f, const char *name, double *out, int64_t count) try {
     const auto *r = find_rec(f, name);
     if (!r) return fail(NXS_ERR_INVALID, "no record named %s", name ? name : "(null)");
     if (r->type == "int") return fail(NXS_ERR_INVALID, "record %s holds integers", name);
     if ((int64_t)r->d.size() != count || (count > 0 && !out)) return fail(NXS_ERR_INVALID, "record %s has %zu values, not %lld", name, r->d.size(), (long long)count);
     std::copy(r->d.begin(), r->d.end(), out);
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_file_get_double"); }
 
-int nxs_exporter_file_get_int(const nxs_exporter_file *f, const char *name, int32_t *out, int64_t count) {
+int nxs_exporter_file_get_int(const nxs_exporter_file *f, const char *name, int32_t *out, int64_t count) try {
     const auto *r = find_rec(f, name);
     if (!r) return fail(NXS_ERR_INVALID, "no record named %s", name ? name : "(null)");
     if (r->type != "int") return fail(NXS_ERR_INVALID, "record %s holds reals", name);
     if ((int64_t)r->i.size() != count || (count > 0 && !out)) return fail(NXS_ERR_INVALID, "record %s has %zu values, not %lld", name, r->i.size(), (long long)count);
     std::copy(r->i.begin(), r->i.end(), out);
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_exporter_file_get_int"); }
 
 int nxs_exporter_file_close(nxs_exporter_file *f) { delete f; return NXS_OK; }
 
@@ -220,7 +226,7 @@ int nxs_restart_write(const char *directory, const char *name_str, const double 
                       int64_t num_nodes, const int32_t *elements, int64_t num_indices, const int32_t misc_int[4],
                       const int32_t *dirichlet_flags, int64_t num_dirichlet, double current_time, int32_t num_elt_vars,
                       const char *const *elt_names, const double *const *elt_values, const double *VT, const double *UM,
-                      const double *UT, const double *previous_numbering) {
+                      const double *UT, const double *previous_numbering) try {
     if (!directory || !name_str || !misc_int || !VT || !UM || !UT || !previous_numbering || (num_elt_vars > 0 && (!elt_names || !elt_values)))
         return fail(NXS_ERR_INVALID, "NULL argument");
     const std::string base = std::string(directory) + "/";
@@ -244,9 +250,9 @@ int nxs_restart_write(const char *directory, const char *name_str, const double 
     if (!rc) rc = nxs_exporter_write_field(e, "PreviousNumbering", previous_numbering, num_nodes);
     rc2 = nxs_exporter_close(e);
     return rc ? rc : rc2;
-}
+} catch (...) { return entry_caught("nxs_restart_write"); }
 
-int nxs_restart_read(const char *directory, const char *name_str, nxs_exporter_file **mesh, nxs_exporter_file **field) {
+int nxs_restart_read(const char *directory, const char *name_str, nxs_exporter_file **mesh, nxs_exporter_file **field) try {
     if (!directory || !name_str || !mesh || !field) return fail(NXS_ERR_INVALID, "NULL argument");
     const std::string base = std::string(directory) + "/";
     int rc = nxs_exporter_load((base + "mesh_" + name_str + ".bin").c_str(), (base + "mesh_" + name_str + ".dat").c_str(), mesh);
@@ -260,7 +266,7 @@ int nxs_restart_read(const char *directory, const char *name_str, nxs_exporter_f
         if (!find_rec(*field, need)) rc = fail(NXS_ERR_INVALID, "restart field file lacks %s", need);
     if (rc) { nxs_exporter_file_close(*mesh); nxs_exporter_file_close(*field); *mesh = *field = nullptr; }
     return rc;
-}
+} catch (...) { return entry_caught("nxs_restart_read"); }
 
 }  // extern "C"
 
@@ -494,7 +500,7 @@ static int append_classic(const char *path, double timestamp, double averaging_p
 }
 
 
-int nxs_moorings_file_format(const char *path) {
+int nxs_moorings_file_format(const char *path) try {
     if (!path) return fail(NXS_ERR_INVALID, "NULL path");
     FILE *f = fopen(path, "rb");
     if (!f) return fail(NXS_ERR_INVALID, "cannot open %s", path);
@@ -504,11 +510,11 @@ int nxs_moorings_file_format(const char *path) {
     if (got >= 4 && !memcmp(m, "CDF\x01", 4)) return NXS_NC_CLASSIC;
     if (got >= 8 && !memcmp(m, "\x89HDF\r\n\x1a\n", 8)) return NXS_NC_NETCDF4;
     return fail(NXS_ERR_INVALID, "%s is neither a NetCDF classic nor a NetCDF-4 (HDF5) file", path);
-}
+} catch (...) { return entry_caught("nxs_moorings_file_format"); }
 
 int nxs_moorings_create_format(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat, int32_t nvars,
                                const nxs_mooring_var *vars, float miss_val, double averaging_period, const nxs_mooring_proj *proj,
-                               int32_t format) {
+                               int32_t format) try {
     if (!path || !lon || !lat || ncols < 1 || nrows < 1 || nvars < 0 || (nvars > 0 && !vars)) return fail(NXS_ERR_INVALID, "bad moorings arguments");
     if (format != NXS_NC_AUTO && format != NXS_NC_CLASSIC && format != NXS_NC_NETCDF4) return fail(NXS_ERR_INVALID, "unknown format %d", format);
     Schema S;
@@ -516,18 +522,18 @@ int nxs_moorings_create_format(const char *path, int32_t ncols, int32_t nrows, c
     if (format == NXS_NC_AUTO) format = nc4::available() ? NXS_NC_NETCDF4 : NXS_NC_CLASSIC;
     if (format == NXS_NC_NETCDF4) return nc4::create(path, ncols, nrows, lon, lat, S, miss_val);
     return create_classic(path, ncols, nrows, lon, lat, S);
-}
+} catch (...) { return entry_caught("nxs_moorings_create_format"); }
 
 int nxs_moorings_create(const char *path, int32_t ncols, int32_t nrows, const float *lon, const float *lat, int32_t nvars,
-                        const nxs_mooring_var *vars, float miss_val, double averaging_period, const nxs_mooring_proj *proj) {
+                        const nxs_mooring_var *vars, float miss_val, double averaging_period, const nxs_mooring_proj *proj) try {
     return nxs_moorings_create_format(path, ncols, nrows, lon, lat, nvars, vars, miss_val, averaging_period, proj, NXS_NC_AUTO);
-}
+} catch (...) { return entry_caught("nxs_moorings_create"); }
 
-int nxs_moorings_append(const char *path, double timestamp, double averaging_period, int32_t nvars, const float *const *data) {
+int nxs_moorings_append(const char *path, double timestamp, double averaging_period, int32_t nvars, const float *const *data) try {
     if (!path || nvars < 0 || (nvars > 0 && !data)) return fail(NXS_ERR_INVALID, "bad moorings arguments");
     const int fmt = nxs_moorings_file_format(path);
     if (fmt < 0) return fmt;
     return fmt == NXS_NC_NETCDF4 ? nc4::append(path, timestamp, averaging_period, nvars, data) : append_classic(path, timestamp, averaging_period, nvars, data);
-}
+} catch (...) { return entry_caught("nxs_moorings_append"); }
 
 }  // extern "C"

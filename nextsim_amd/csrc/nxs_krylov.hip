@@ -24,6 +24,7 @@
 #include <vector>
 
 #include "nxs_dyn.h"
+#include "nxs_guard.hpp"
 #include "nxs_krylov.h"
 
 namespace {
@@ -37,6 +38,11 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     g_err = buf;
     return code;
+}
+
+// handler of every extern "C" function-try-block of this file (nxs_guard.hpp): status code + text, never an exception across the ABI
+int entry_caught(const char *entry) noexcept {
+    return nxs_guard::caught(entry, [](int code, const char *text) { (void)fail(code, "%s", text); });
 }
 #define KCHK(call)                                                                                       \
     do {                                                                                                 \
@@ -678,7 +684,7 @@ extern "C" {
 
 const char *nxs_krylov_last_error(void) { return g_err.c_str(); }
 
-int nxs_fem_csr_pattern(const int32_t *indices, int32_t Nn, int32_t Ne, int32_t *rowptr, int32_t *colidx, int64_t *nnz) {
+int nxs_fem_csr_pattern(const int32_t *indices, int32_t Nn, int32_t Ne, int32_t *rowptr, int32_t *colidx, int64_t *nnz) try {
     int rc = check_mesh(indices, Nn, Ne);
     if (rc) return rc;
     if (!rowptr || !nnz) return fail(NXS_ERR_INVALID, "NULL argument");
@@ -688,9 +694,9 @@ int nxs_fem_csr_pattern(const int32_t *indices, int32_t Nn, int32_t Ne, int32_t 
     *nnz = (int64_t)ci.size();
     if (colidx) std::copy(ci.begin(), ci.end(), colidx);
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_fem_csr_pattern"); }
 
-int nxs_fem_colour_elements(const int32_t *indices, int32_t Nn, int32_t Ne, int32_t *colour, int32_t *ncolours) {
+int nxs_fem_colour_elements(const int32_t *indices, int32_t Nn, int32_t Ne, int32_t *colour, int32_t *ncolours) try {
     int rc = check_mesh(indices, Nn, Ne);
     if (rc) return rc;
     if (!colour || !ncolours) return fail(NXS_ERR_INVALID, "NULL argument");
@@ -699,9 +705,9 @@ int nxs_fem_colour_elements(const int32_t *indices, int32_t Nn, int32_t Ne, int3
     std::copy(c.begin(), c.end(), colour);
     *ncolours = n;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_fem_colour_elements"); }
 
-int nxs_krylov_create(int32_t device, nxs_krylov_handle **out) {
+int nxs_krylov_create(int32_t device, nxs_krylov_handle **out) try {
     if (!out) return fail(NXS_ERR_INVALID, "NULL argument");
     *out = nullptr;
     int ndev = 0;
@@ -719,9 +725,9 @@ int nxs_krylov_create(int32_t device, nxs_krylov_handle **out) {
     }
     *out = h;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_create"); }
 
-void nxs_krylov_destroy(nxs_krylov_handle *h) {
+void nxs_krylov_destroy(nxs_krylov_handle *h) try {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -732,9 +738,9 @@ void nxs_krylov_destroy(nxs_krylov_handle *h) {
     if (h->h_scal) (void)hipHostFree(h->h_scal);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
-}
+} catch (...) { (void)entry_caught("nxs_krylov_destroy"); }
 
-int nxs_krylov_set_matrix(nxs_krylov_handle *h, int32_t n_rows, int32_t n_cols, const int32_t *rowptr, const int32_t *colidx, const double *val) {
+int nxs_krylov_set_matrix(nxs_krylov_handle *h, int32_t n_rows, int32_t n_cols, const int32_t *rowptr, const int32_t *colidx, const double *val) try {
     if (!h || n_rows < 1 || n_cols < n_rows || !rowptr || !colidx || !val) return fail(NXS_ERR_INVALID, "NULL argument / empty system / n_cols < n_rows");
     if (rowptr[0] != 0) return fail(NXS_ERR_INVALID, "rowptr[0] must be 0");
     for (int i = 0; i < n_rows; ++i) {
@@ -753,9 +759,9 @@ int nxs_krylov_set_matrix(nxs_krylov_handle *h, int32_t n_rows, int32_t n_cols, 
     int rc = upload_matrix(h, n_rows, n_cols, off, col, sval, (size_t)rowptr[n_rows]);
     if (rc) return rc;
     return finish_matrix(h);
-}
+} catch (...) { return entry_caught("nxs_krylov_set_matrix"); }
 
-int nxs_krylov_set_halo(nxs_krylov_handle *h, const nxs_dyn_halo *halo) {
+int nxs_krylov_set_halo(nxs_krylov_handle *h, const nxs_dyn_halo *halo) try {
     if (!h || !halo) return fail(NXS_ERR_INVALID, "NULL argument");
     if (h->n < 1) return fail(NXS_ERR_STATE, "set_halo before set_matrix");
     if (halo->nranks < 1 || halo->rank < 0 || halo->rank >= halo->nranks || halo->num_send_procs < 0 || halo->num_recv_procs < 0)
@@ -786,9 +792,9 @@ int nxs_krylov_set_halo(nxs_krylov_handle *h, const nxs_dyn_halo *halo) {
     KCHK(hipHostMalloc((void **)&h->h_recv, std::max(tr, 1) * sizeof(double), hipHostMallocDefault));
     h->have_halo = true;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_set_halo"); }
 
-int nxs_krylov_comm_init(nxs_krylov_handle *h, const void *id128, int32_t rank, int32_t nranks) {
+int nxs_krylov_comm_init(nxs_krylov_handle *h, const void *id128, int32_t rank, int32_t nranks) try {
     if (!h || !id128) return fail(NXS_ERR_INVALID, "NULL argument");
     KCHK(hipSetDevice(h->device));
     int rc = load_rccl(h->rccl);
@@ -800,23 +806,23 @@ int nxs_krylov_comm_init(nxs_krylov_handle *h, const void *id128, int32_t rank, 
     if (e != 0) { h->comm = nullptr; return fail(NXS_ERR_COMM, "ncclCommInitRank(rank %d of %d): %s", rank, nranks, h->rccl.GetErrorString(e)); }
     h->rank = rank; h->nranks = nranks;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_comm_init"); }
 
-int nxs_krylov_comm_stats(const nxs_krylov_handle *h, int64_t *rccl_allreduces, int64_t *rccl_exchanges) {
+int nxs_krylov_comm_stats(const nxs_krylov_handle *h, int64_t *rccl_allreduces, int64_t *rccl_exchanges) try {
     if (!h) return fail(NXS_ERR_INVALID, "NULL argument");
     if (rccl_allreduces) *rccl_allreduces = h->n_rccl_allreduce;
     if (rccl_exchanges) *rccl_exchanges = h->n_rccl_exchange;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_comm_stats"); }
 
-int nxs_krylov_set_comm_fns(nxs_krylov_handle *h, nxs_krylov_exchange_fn exchange_fn, nxs_krylov_allreduce_fn allreduce_fn, void *user) {
+int nxs_krylov_set_comm_fns(nxs_krylov_handle *h, nxs_krylov_exchange_fn exchange_fn, nxs_krylov_allreduce_fn allreduce_fn, void *user) try {
     if (!h) return fail(NXS_ERR_INVALID, "NULL argument");
     if ((exchange_fn == nullptr) != (allreduce_fn == nullptr)) return fail(NXS_ERR_INVALID, "give both callbacks or neither");
     h->exchange_fn = exchange_fn; h->allreduce_fn = allreduce_fn; h->user = user;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_set_comm_fns"); }
 
-int nxs_krylov_spmv(nxs_krylov_handle *h, const double *in, double *out, int32_t reps, double *ms_per_spmv) {
+int nxs_krylov_spmv(nxs_krylov_handle *h, const double *in, double *out, int32_t reps, double *ms_per_spmv) try {
     if (!h || !in || !out || reps < 1) return fail(NXS_ERR_INVALID, "NULL argument / reps < 1");
     if (h->n < 1) return fail(NXS_ERR_STATE, "spmv before set_matrix");
     KCHK(hipSetDevice(h->device));
@@ -840,10 +846,10 @@ int nxs_krylov_spmv(nxs_krylov_handle *h, const double *in, double *out, int32_t
     KCHK(copy_on(h->stream, out, h->vec[1], (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
     if (ms_per_spmv) *ms_per_spmv = ms / reps;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_spmv"); }
 
 int nxs_krylov_run(nxs_krylov_handle *h, const double *b, double *x, int32_t method, double rtol, int32_t max_iter, int32_t *iterations,
-                   double *rel_residual, double *ms_solve) {
+                   double *rel_residual, double *ms_solve) try {
     if (!h || !b || !x) return fail(NXS_ERR_INVALID, "NULL argument");
     if (h->n < 1) return fail(NXS_ERR_STATE, "solve before set_matrix");
     if (method != NXS_KRYLOV_CG && method != NXS_KRYLOV_BICGSTAB) return fail(NXS_ERR_INVALID, "method must be NXS_KRYLOV_CG or NXS_KRYLOV_BICGSTAB");
@@ -854,18 +860,18 @@ int nxs_krylov_run(nxs_krylov_handle *h, const double *b, double *x, int32_t met
     if (rc) return rc;
     KCHK(copy_on(h->stream, x, h->vec[0], (size_t)h->n * sizeof(double), hipMemcpyDeviceToHost));
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_run"); }
 
-int nxs_krylov_info(const nxs_krylov_handle *h, int64_t *nnz, int64_t *stored_entries, int64_t *spmv_bytes) {
+int nxs_krylov_info(const nxs_krylov_handle *h, int64_t *nnz, int64_t *stored_entries, int64_t *spmv_bytes) try {
     if (!h || h->n < 1) return fail(NXS_ERR_STATE, "no matrix");
     if (nnz) *nnz = (int64_t)h->nnz;
     if (stored_entries) *stored_entries = (int64_t)h->entries;
     if (spmv_bytes) *spmv_bytes = (int64_t)h->nnz * 12 + (int64_t)h->n * 16;  // value + column per entry, operand read + result write per row
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_krylov_info"); }
 
 int nxs_krylov_solve(int32_t n, const int32_t *rowptr, const int32_t *colidx, const double *val, const double *b, double *x, int32_t method,
-                     double rtol, int32_t max_iter, int32_t device, int32_t *iterations, double *rel_residual, double *ms_solve) {
+                     double rtol, int32_t max_iter, int32_t device, int32_t *iterations, double *rel_residual, double *ms_solve) try {
     if (n < 1 || !rowptr || !colidx || !val || !b || !x) return fail(NXS_ERR_INVALID, "NULL argument / empty system");
     if (method != NXS_KRYLOV_CG && method != NXS_KRYLOV_BICGSTAB) return fail(NXS_ERR_INVALID, "method must be NXS_KRYLOV_CG or NXS_KRYLOV_BICGSTAB");
     nxs_krylov_handle *h = nullptr;
@@ -875,11 +881,11 @@ int nxs_krylov_solve(int32_t n, const int32_t *rowptr, const int32_t *colidx, co
     if (!rc) rc = nxs_krylov_run(h, b, x, method, rtol, max_iter, iterations, rel_residual, ms_solve);
     nxs_krylov_destroy(h);
     return rc;
-}
+} catch (...) { return entry_caught("nxs_krylov_solve"); }
 
 int nxs_fem_poisson_solve(const int32_t *indices, const double *x, const double *y, int32_t Nn, int32_t Ne, const uint8_t *dirichlet,
                           const double *f_elem, double *u, double rtol, int32_t max_iter, int32_t device, int32_t *iterations,
-                          double *rel_residual, double *ms_assembly, double *ms_solve) {
+                          double *rel_residual, double *ms_assembly, double *ms_solve) try {
     int rc = check_mesh(indices, Nn, Ne);
     if (rc) return rc;
     if (!x || !y || !dirichlet || !f_elem || !u) return fail(NXS_ERR_INVALID, "NULL argument");
@@ -975,6 +981,6 @@ int nxs_fem_poisson_solve(const int32_t *indices, const double *x, const double 
     KCHK(copy_on(h->stream, u, h->vec[0], (size_t)Nn * sizeof(double), hipMemcpyDeviceToHost));
     if (ms_assembly) *ms_assembly = msa;
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_fem_poisson_solve"); }
 
 }  // extern "C"

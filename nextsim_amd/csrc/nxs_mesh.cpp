@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "nxs_dyn.h"
+#include "nxs_guard.hpp"
 
 namespace {
 
@@ -26,10 +27,13 @@ struct EdgeRec {
     int32_t first, second;  // oriented ends as seen in the creating triangle (0-based)
 };
 
+// handler of the function-try-blocks below (nxs_guard.hpp).  These entry points keep no error text of their own.
+int entry_caught(const char *entry) noexcept { return nxs_guard::caught(entry, [](int, const char *) {}); }
+
 }  // namespace
 
 extern "C" int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
-                                     int32_t *nec_width, double *nec, int32_t *nc_width, double *nc) {
+                                     int32_t *nec_width, double *nec, int32_t *nc_width, double *nc) try {
     if (!indices || num_nodes <= 0 || num_elements <= 0) return NXS_ERR_INVALID;
     const int64_t Nn = num_nodes, Ne = num_elements;
     for (int64_t i = 0; i < 3 * Ne; ++i)
@@ -97,13 +101,13 @@ extern "C" int nxs_mesh_connectivity(const int32_t *indices, int32_t num_nodes, 
         for (int64_t v = 0; v < Nn; ++v) nc[v * w2 + (w2 - 1)] = double(ndeg[v]);
     }
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_mesh_connectivity"); }
 
 // bamgmesh->ElementConnectivity (contrib/bamg/src/Mesh.cpp:777-796): column j = 1-based number of the
 // triangle across local edge j (vertices (j+1)%3, (j+2)%3), NaN on the boundary.  The rows are what
 // ConservativeRemapping's checkTriangle walks (ConservativeRemapping.cpp:411-436), which stops at the first
 // NaN of a row -- so the column of a neighbour matters, not only the set.
-extern "C" int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements, double *ec) {
+extern "C" int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements, double *ec) try {
     if (!indices || !ec || num_nodes <= 0 || num_elements <= 0) return NXS_ERR_INVALID;
     const int64_t Ne = num_elements;
     for (int64_t i = 0; i < 3 * Ne; ++i)
@@ -132,7 +136,7 @@ extern "C" int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num
             }
         }
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_mesh_element_connectivity"); }
 
 // calcCohesion (FE.cpp:3909-3914) on top of initIce's random field (FE.cpp:11459-11475): one draw of
 // boost::uniform_01<boost::minstd_rand> (default seed 1; x_{k+1} = 48271 x_k mod 2^31-1) per GLOBAL element, indexed by the
@@ -142,7 +146,7 @@ extern "C" int nxs_mesh_element_connectivity(const int32_t *indices, int32_t num
 // 1 / 2147483646.0 once and returns double(x - min) * _factor, drawing again while the result is >= 1.  A MULTIPLICATION by the
 // rounded reciprocal, not a division: the two differ in the last bit for about one draw in a hundred, first at draw 142 (tests/test_mesh_partition.py).
 extern "C" int nxs_calc_cohesion(double C_fix, double C_alea, const int32_t *global_element_id, int64_t num_elements,
-                                 int64_t num_global_elements, double *cohesion) {
+                                 int64_t num_global_elements, double *cohesion) try {
     if (!global_element_id || !cohesion || num_elements < 0 || num_global_elements < 1) return NXS_ERR_INVALID;
     std::vector<double> random_number_root((size_t)num_global_elements);
     unsigned long long x = 1ull;
@@ -161,4 +165,4 @@ extern "C" int nxs_calc_cohesion(double C_fix, double C_alea, const int32_t *glo
         cohesion[i] = C_fix + C_alea * (random_number_root[(size_t)id - 1]);
     }
     return NXS_OK;
-}
+} catch (...) { return entry_caught("nxs_calc_cohesion"); }

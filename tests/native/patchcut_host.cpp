@@ -1,0 +1,303 @@
+// tests/native/patchcut_host.cpp -- TEST INFRASTRUCTURE.  Host build of the library's host-only mesh preparation (nextsim_amd/csrc/nxs_patchcut.hpp:
+// patch cutter, Hilbert re-cut, D-ring patches, smoother patches, tables of the in-kernel halo exchange and of the resident loop;
+// nextsim_amd/csrc/nxs_hull.inl: bamg's convex completion) with doors for tests/sanitize_worker.py.  tests/test_sanitizers.py compiles
+// this file with -fsanitize=address,undefined and drives it through the inputs nxs_dyn_set_mesh meets: a numbering without locality, a
+// large mesh followed by a small one, ragged partitions, every part of both BASELINE meshes, patches closed at 480 elements.  Every
+// door also CHECKS what was built (each own node solved by one patch, each element written by one, fans complete and ascending, slots
+// inside their rows ...), so a wrong table is caught here and not as a memory fault on a GPU.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../nextsim_amd/csrc/nxs_guard.hpp"
+#include "../../nextsim_amd/csrc/nxs_patchcut.hpp"
+#include "../../nextsim_amd/csrc/nxs_hull.inl"
+
+namespace {
+
+using namespace nxs_cut;
+
+struct Fail { std::string what; };
+#define REQUIRE(cond, ...) do { if (!(cond)) { char b_[400]; snprintf(b_, sizeof b_, __VA_ARGS__); throw Fail{std::string(#cond) + ": " + b_}; } } while (0)
+
+struct Mesh {
+    std::vector<int> t[3];
+    std::vector<unsigned char> ghost3;
+    std::vector<double> x, y;
+    int Nn = 0, Ne = 0, No = 0;
+    MeshView view() const { return MeshView{t, ghost3.data(), x.data(), y.data(), Nn, Ne, No}; }
+};
+
+Mesh make_mesh(const int32_t *indices, const uint8_t *ghost3, const double *x, const double *y, int Nn, int Ne, int No) {
+    Mesh m;
+    m.Nn = Nn; m.Ne = Ne; m.No = No;
+    for (int k = 0; k < 3; ++k) { m.t[k].resize(Ne); for (int e = 0; e < Ne; ++e) m.t[k][e] = indices[3 * e + k] - 1; }
+    m.ghost3.assign(ghost3, ghost3 + 3 * (size_t)Ne);
+    m.x.assign(x, x + Nn); m.y.assign(y, y + Nn);
+    return m;
+}
+
+// the invariants of single-ring patches (what k_substep_fused / k_substep_resident index with)
+void check_patches(const Mesh &m, const HostPatches &hp) {
+    const int nP = hp.nP;
+    REQUIRE(nP >= 1 || m.No == 0, "nP=%d", nP);
+    REQUIRE(hp.Emax % 2 == 0 && hp.Mmax % 2 == 0 && hp.Pmax >= 1 && hp.Wp >= 1, "Emax=%d Mmax=%d Pmax=%d Wp=%d", hp.Emax, hp.Mmax, hp.Pmax, hp.Wp);
+    REQUIRE((int)hp.own_cnt.size() == nP && (int)hp.elem_cnt.size() == nP && (int)hp.node_cnt.size() == nP, "count arrays");
+    REQUIRE(hp.pnodes.size() == (size_t)nP * hp.Mmax && hp.pelem.size() == (size_t)nP * hp.Emax && hp.ptri.size() == (size_t)nP * hp.Emax * 4 &&
+            hp.pfan.size() == (size_t)nP * hp.Wp * hp.Pmax, "array sizes");
+    std::vector<int> off, adj;
+    node_fans(m.t, m.Nn, m.Ne, off, adj);
+    std::vector<int> solved(m.Nn, 0), written(m.Ne, 0), in_patch(m.Ne, -1);
+    for (int q = 0; q < nP; ++q) {
+        const int nO = hp.own_cnt[q], nE = hp.elem_cnt[q], nM = hp.node_cnt[q];
+        REQUIRE(nO >= 0 && nO <= hp.Pmax && nE >= 0 && nE <= hp.Emax && nM >= nO && nM <= hp.Mmax, "patch %d: nO=%d nE=%d nM=%d", q, nO, nE, nM);
+        const int *pn = hp.pnodes.data() + (size_t)q * hp.Mmax;
+        for (int i = 0; i < nM; ++i) REQUIRE(pn[i] >= 0 && pn[i] < m.Nn, "patch %d slot %d names node %d", q, i, pn[i]);
+        for (int i = 0; i < nO; ++i) { REQUIRE(pn[i] < m.No, "patch %d solves the ghost node %d", q, pn[i]); solved[pn[i]]++; }
+        for (int l = 0; l < nE; ++l) {
+            const int raw = hp.pelem[(size_t)q * hp.Emax + l], e = raw >= 0 ? raw : ~raw;
+            REQUIRE(e >= 0 && e < m.Ne, "patch %d element slot %d names %d", q, l, e);
+            if (l > 0) { const int rp = hp.pelem[(size_t)q * hp.Emax + l - 1]; REQUIRE((rp >= 0 ? rp : ~rp) < e, "patch %d: elements not ascending at slot %d", q, l); }
+            if (raw >= 0) written[e]++;
+            in_patch[e] = q;
+            for (int k = 0; k < 3; ++k) {
+                const int sl = hp.ptri[((size_t)q * hp.Emax + l) * 4 + k];
+                REQUIRE(sl < nM && pn[sl] == m.t[k][e], "patch %d element %d corner %d: slot %d", q, e, k, sl);
+                REQUIRE(sl < 1024, "corner slot %d does not fit ten bits", sl);
+            }
+        }
+        // fans: exactly the node's elements, ascending, with the corner and its ghost flag
+        for (int i = 0; i < nO; ++i) {
+            const int n = pn[i];
+            int k = 0;
+            for (int j = off[n]; j < off[n + 1]; ++j, ++k) {
+                REQUIRE(k < hp.Wp, "patch %d node %d: fan longer than Wp=%d", q, n, hp.Wp);
+                const unsigned ent = hp.pfan[(size_t)q * hp.Wp * hp.Pmax + (size_t)k * hp.Pmax + i];
+                REQUIRE(ent != 0xFFFFu, "patch %d node %d: fan entry %d missing", q, n, k);
+                const int l = (int)(ent >> 3), c = (int)(ent & 3u), e = adj[j];
+                REQUIRE(l < nE, "patch %d node %d: fan names element slot %d of %d", q, n, l, nE);
+                const int raw = hp.pelem[(size_t)q * hp.Emax + l];
+                REQUIRE((raw >= 0 ? raw : ~raw) == e && c < 3 && m.t[c][e] == n, "patch %d node %d: fan entry %d is not element %d", q, n, k, e);
+                REQUIRE(((ent & 4u) != 0) == (m.ghost3[3 * (size_t)e + c] != 0), "patch %d node %d: ghost flag of element %d", q, n, e);
+            }
+            for (; k < hp.Wp; ++k) REQUIRE(hp.pfan[(size_t)q * hp.Wp * hp.Pmax + (size_t)k * hp.Pmax + i] == 0xFFFFu, "patch %d node %d: stale fan entry %d", q, n, k);
+        }
+    }
+    for (int n = 0; n < m.No; ++n) REQUIRE(solved[n] == 1, "own node %d is solved by %d patches", n, solved[n]);
+    for (int e = 0; e < m.Ne; ++e) REQUIRE(written[e] == 1, "element %d is written by %d patches", e, written[e]);
+}
+
+void check_patches2(const Mesh &m, const HostPatches2 &hp) {
+    const int nP = hp.nP, D = hp.D;
+    std::vector<int> off, adj;
+    node_fans(m.t, m.Nn, m.Ne, off, adj);
+    std::vector<int> written(m.Ne, 0), own(m.Nn, 0);
+    REQUIRE(hp.pnodes.size() == (size_t)nP * hp.NDmax && hp.pelem.size() == (size_t)nP * hp.EDmax && hp.pfan.size() == (size_t)nP * hp.Wp * hp.NSmax, "array sizes");
+    for (int q = 0; q < nP; ++q) {
+        const int *nc = hp.ncnt.data() + (size_t)q * (D + 1), *ec = hp.ecnt.data() + (size_t)q * D;
+        for (int l = 0; l < D; ++l) REQUIRE(nc[l] <= nc[l + 1] && (l == 0 || ec[l - 1] <= ec[l]), "patch %d: levels not nested", q);
+        REQUIRE(nc[D] <= hp.NDmax && nc[D - 1] <= hp.NSmax && ec[D - 1] <= hp.EDmax, "patch %d: level sizes", q);
+        const int *pn = hp.pnodes.data() + (size_t)q * hp.NDmax;
+        for (int i = 0; i < nc[0]; ++i) own[pn[i]]++;
+        for (int l = 0; l < ec[D - 1]; ++l) {
+            const int raw = hp.pelem[(size_t)q * hp.EDmax + l], e = raw >= 0 ? raw : ~raw;
+            REQUIRE(e >= 0 && e < m.Ne, "patch %d: element %d", q, e);
+            if (raw >= 0) written[e]++;
+            for (int k = 0; k < 3; ++k) {
+                const int sl = hp.ptri[((size_t)q * hp.EDmax + l) * 4 + k];
+                REQUIRE(sl < nc[D] && pn[sl] == m.t[k][e], "patch %d element %d corner %d", q, e, k);
+            }
+        }
+        for (int i = 0; i < nc[D - 1]; ++i) {  // every solved node has its complete fan among the patch's elements
+            const int n = pn[i];
+            int k = 0;
+            for (int j = off[n]; j < off[n + 1]; ++j, ++k) {
+                const unsigned ent = hp.pfan[(size_t)q * hp.Wp * hp.NSmax + (size_t)k * hp.NSmax + i];
+                REQUIRE(ent != 0xFFFFu && (int)(ent >> 3) < ec[D - 1], "patch %d node %d: fan entry %d", q, n, k);
+                const int raw = hp.pelem[(size_t)q * hp.EDmax + (ent >> 3)];
+                REQUIRE((raw >= 0 ? raw : ~raw) == adj[j], "patch %d node %d: fan entry %d is not element %d", q, n, k, adj[j]);
+            }
+        }
+    }
+    for (int n = 0; n < m.Nn; ++n) REQUIRE(own[n] == 1, "node %d is an own node of %d patches", n, own[n]);
+    for (int e = 0; e < m.Ne; ++e) REQUIRE(written[e] == 1, "element %d is written by %d patches", e, written[e]);
+}
+
+void put_msg(char *msg, int cap, const std::string &s) { if (msg && cap > 0) { snprintf(msg, (size_t)cap, "%s", s.c_str()); } }
+
+int caught(char *msg, int cap) {
+    try { throw; }
+    catch (const Fail &f) { put_msg(msg, cap, f.what); return 1; }
+    catch (...) { return nxs_guard::caught("patchcut_host", [&](int, const char *t) { put_msg(msg, cap, t); }); }
+}
+
+}  // namespace
+
+extern "C" {
+
+// One rank's mesh through everything nxs_dyn_set_mesh / set_halo / the first step build on the host.  stats (int64[16]): nP, Pmax, Emax,
+// Mmax, Wp, used_hilbert, fused_lds, P, resident ok, resident max neighbours, n_boundary, reordered, multi nP, multi EDmax, smoother nP, smoother NDmax.
+// Returns 0, 1 (a check failed: msg says which) or an NXS_ERR_* of the guard (an exception: msg says which).
+int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const double *y, int Nn, int Ne, int No, int patch_nodes,
+           int want_resident, int cus, int res_ept, int ns, const int32_t *send_offsets, const int32_t *send_index, int nr,
+           const int32_t *recv_offsets, const int32_t *recv_index, int overlap, const int32_t *n2n /*[W2][Nn] or NULL*/, const int32_t *n2n_cnt,
+           int W2, int depth_multi, int depth_smooth, int64_t *stats, char *msg, int msg_cap) try {
+    put_msg(msg, msg_cap, "");
+    for (int i = 0; i < 16; ++i) stats[i] = 0;
+    const Mesh m = make_mesh(indices, ghost3, x, y, Nn, Ne, No);
+    PatchPlan plan;
+    const std::string why = plan_patches(m.view(), patch_nodes, want_resident != 0, cus, plan, res_ept);
+    if (!why.empty()) { put_msg(msg, msg_cap, why); return 2; }
+    HostPatches &hp = plan.hp;
+    check_patches(m, hp);
+    REQUIRE(plan.fused_lds == fused_lds_of(hp) && plan.fused_lds <= 160 * 1024, "fused_lds=%zu", plan.fused_lds);
+    std::vector<int> pet;
+    pack_pet(hp, pet);
+    REQUIRE(pet.size() == 2 * (size_t)hp.nP * hp.Emax, "pet size");
+    stats[0] = hp.nP; stats[1] = hp.Pmax; stats[2] = hp.Emax; stats[3] = hp.Mmax; stats[4] = hp.Wp; stats[5] = hp.used_hilbert; stats[6] = (int64_t)plan.fused_lds; stats[7] = plan.P;
+    const bool mr = ns > 0 || nr > 0 || No < Nn;
+    if (mr) {
+        const std::vector<int> so(send_offsets, send_offsets + ns + 1), ro(recv_offsets, recv_offsets + nr + 1);
+        const std::vector<int> si(send_index, send_index + so[ns]), ri(recv_index, recv_index + ro[nr]);
+        const HaloLists hl{&so, &ro, &si, &ri, ns, nr};
+        HaloFusedPlan hf;
+        const std::string w2 = plan_halo_fused(Nn, No, hl, hp, hf);
+        if (!w2.empty()) { put_msg(msg, msg_cap, w2); return 2; }
+        check_patches(m, hp);  // (rewritten boundary-first)
+        // boundary patches lead; every sent node has its (neighbour, position) entries; every ghost its mailbox slot
+        REQUIRE(hf.n_boundary >= 0 && hf.n_boundary <= hp.nP, "n_boundary=%d", hf.n_boundary);
+        for (int q = 0; q < hp.nP; ++q) {
+            bool bnd = false;
+            for (int i = 0; i < hp.node_cnt[q]; ++i) {
+                const int n = hp.pnodes[(size_t)q * hp.Mmax + i];
+                bnd = bnd || n >= No || (i < hp.own_cnt[q] && hf.sptr[n + 1] > hf.sptr[n]);
+            }
+            REQUIRE(bnd == (q < hf.n_boundary), "patch %d: boundary=%d but n_boundary=%d", q, (int)bnd, hf.n_boundary);
+        }
+        REQUIRE(hf.sptr[No] == so[ns], "%d send entries for %d sent nodes", hf.sptr[No], so[ns]);
+        for (int n = 0; n < No; ++n)
+            for (int j = hf.sptr[n]; j < hf.sptr[n + 1]; ++j) {
+                const int k = hf.sk[j], pos = hf.spos[j];
+                REQUIRE(k >= 0 && k < ns && pos >= 0 && pos < so[k + 1] - so[k] && si[so[k] + pos] == n, "send entry %d of node %d", j, n);
+            }
+        for (int g = 0; g < Nn - No; ++g) {
+            const int k = hf.gk[g];
+            REQUIRE(k >= 0 && k < nr && hf.gsrl[g] == ro[k + 1] - ro[k], "ghost %d: neighbour %d", g, k);
+            const int j = hf.goff[g] - 2 * ro[k];
+            REQUIRE(j >= 0 && j < hf.gsrl[g] && ri[ro[k] + j] == No + g, "ghost %d: mailbox offset %d", g, hf.goff[g]);
+        }
+        stats[10] = hf.n_boundary; stats[11] = hf.reordered;
+    }
+    {
+        ResidentPlan rp;
+        plan_resident(hp, Nn, No, mr, ns, overlap != 0 && mr, rp, res_ept);
+        stats[8] = rp.ok; stats[9] = rp.max_nbr;
+        if (rp.ok) {
+            for (int q = 0; q < hp.nP; ++q) {
+                REQUIRE(rp.cnt[q] >= 0 && rp.cnt[q] <= NXS_CUT_RES_NBR, "patch %d waits for %d patches", q, rp.cnt[q]);
+                for (int k = 0; k < rp.cnt[q]; ++k) { const int o = rp.nbr[(size_t)q * NXS_CUT_RES_NBR + k]; REQUIRE(o >= 0 && o < hp.nP && o != q, "patch %d neighbour %d", q, o); }
+            }
+            if (overlap && mr) {  // the overlap variant's lists are a permutation of the patch's with interior elements first
+                HostPatches alt = hp;
+                alt.pelem = rp.rpelem; alt.ptri = rp.rptri; alt.pfan = rp.rpfan;
+                for (int q = 0; q < hp.nP; ++q) {
+                    REQUIRE(rp.ecut[q] % 64 == 0 && rp.ecut[q] <= hp.elem_cnt[q], "patch %d: ecut=%d", q, rp.ecut[q]);
+                    std::vector<int> a(hp.pelem.begin() + (size_t)q * hp.Emax, hp.pelem.begin() + (size_t)q * hp.Emax + hp.elem_cnt[q]);
+                    std::vector<int> b(rp.rpelem.begin() + (size_t)q * hp.Emax, rp.rpelem.begin() + (size_t)q * hp.Emax + hp.elem_cnt[q]);
+                    std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+                    REQUIRE(a == b, "patch %d: the overlap list is not a permutation", q);
+                    for (int l = 0; l < rp.ecut[q]; ++l)
+                        for (int k = 0; k < 3; ++k) REQUIRE(rp.rptri[((size_t)q * hp.Emax + l) * 4 + k] < hp.own_cnt[q], "patch %d: early element %d touches a halo node", q, l);
+                }
+            }
+        }
+    }
+    if (!mr && n2n && n2n_cnt) {
+        const std::vector<int> vn(n2n, n2n + (size_t)W2 * Nn), vc(n2n_cnt, n2n_cnt + Nn);
+        if (depth_multi >= 2) {
+            Patch2Plan p2;
+            const std::string w3 = plan_patches2(m.view(), hp.used_hilbert, 0, depth_multi, false, cus, vn, vc, W2, p2);
+            if (w3.empty()) {
+                check_patches2(m, p2.hp);
+                REQUIRE(p2.lds <= 160 * 1024, "multi lds %zu", p2.lds);
+                stats[12] = p2.hp.nP; stats[13] = p2.hp.EDmax;
+            }
+        }
+        if (depth_smooth >= 1) {
+            SmoothPlan sp;
+            const std::string w4 = plan_smooth_patches(m.view(), hp.used_hilbert, depth_smooth, vn, vc, W2, sp);
+            if (w4.empty()) {
+                for (int q = 0; q < sp.nP; ++q) {
+                    const int nS = sp.ncnt[(size_t)q * (sp.D + 1) + sp.D - 1], nD = sp.ncnt[(size_t)q * (sp.D + 1) + sp.D];
+                    REQUIRE(nS <= sp.NSmax && nD <= sp.NDmax, "smoother patch %d", q);
+                    for (int i = 0; i < nS; ++i) {
+                        const int n = sp.pnodes[(size_t)q * sp.NDmax + i];
+                        for (int k = 0; k < vc[n]; ++k) {
+                            const int sl = sp.pnbr[((size_t)q * W2 + k) * sp.NSmax + i];
+                            REQUIRE(sl < nD && sp.pnodes[(size_t)q * sp.NDmax + sl] == vn[(size_t)k * Nn + n], "smoother patch %d node %d neighbour %d", q, n, k);
+                        }
+                    }
+                }
+                stats[14] = sp.nP; stats[15] = sp.NDmax;
+            }
+        }
+    }
+    return 0;
+} catch (...) { return caught(msg, msg_cap); }
+
+// The Hilbert order alone: any coordinates (NaN, infinities, all equal) must give a permutation
+int pc_hilbert(const double *x, const double *y, int n, int32_t *order_out, char *msg, int msg_cap) try {
+    std::vector<int> order;
+    hilbert_order(x, y, n, order);
+    REQUIRE((int)order.size() == std::max(n, 0), "size");
+    std::vector<char> seen((size_t)std::max(n, 0), 0);
+    for (int v : order) { REQUIRE(v >= 0 && v < n && !seen[v], "not a permutation at %d", v); seen[v] = 1; }
+    for (int i = 0; i < n; ++i) order_out[i] = order[i];
+    return 0;
+} catch (...) { return caught(msg, msg_cap); }
+
+// bamg's convex completion (nxs_hull.inl).  out: [0] ok, [1] fill triangles, [2] hull edges.  When it is built: the fill triangles are
+// counter-clockwise and, with the mesh, cover the hull polygon exactly (integer areas).
+int pc_hull(const int32_t *index, const double *x, const double *y, int nods, int nels, int64_t *out, char *msg, int msg_cap) try {
+    put_msg(msg, msg_cap, "");
+    out[0] = out[1] = out[2] = 0;
+    std::vector<int> ix, iy;
+    double coef, px, py;
+    if (!nxs_hull::int_plane(x, y, nods, ix, iy, coef, px, py)) { put_msg(msg, msg_cap, "coefIcoor should be positive"); return 2; }
+    const nxs_hull::Completion c = nxs_hull::complete(index, ix.data(), iy.data(), nods, nels);
+    out[0] = c.ok;
+    if (!c.ok) { put_msg(msg, msg_cap, c.why); return 0; }
+    out[1] = (int64_t)c.fill.size() / 3; out[2] = (int64_t)c.hull.size();
+    const nxs_hull::Pts P{ix.data(), iy.data()};
+    typedef __int128 i128;
+    i128 area_mesh = 0, area_fill = 0, area_hull = 0;
+    for (int e = 0; e < nels; ++e) area_mesh += P.orient(index[3 * e] - 1, index[3 * e + 1] - 1, index[3 * e + 2] - 1);
+    for (size_t i = 0; i + 2 < c.fill.size(); i += 3) {
+        const long long a = P.orient(c.fill[i], c.fill[i + 1], c.fill[i + 2]);
+        REQUIRE(a > 0, "fill triangle %zu is not counter-clockwise", i / 3);
+        area_fill += a;
+    }
+    for (const auto &h : c.hull) {
+        area_hull += (i128)ix[h.a] * iy[h.b] - (i128)ix[h.b] * iy[h.a];
+        REQUIRE(h.tri >= 0 && h.tri < nels + (int)c.fill.size() / 3 && h.k >= 0 && h.k < 3, "hull edge %d -> %d: triangle %d", h.a, h.b, h.tri);
+    }
+    REQUIRE(area_mesh + area_fill == area_hull, "mesh + fill triangles do not cover the hull (%lld + %lld vs %lld)", (long long)area_mesh, (long long)area_fill, (long long)area_hull);
+    return 0;
+} catch (...) { return caught(msg, msg_cap); }
+
+// the guard itself: a std::bad_alloc, a std::length_error and a foreign exception become status codes
+int pc_guard_selftest(int which, char *msg, int msg_cap) try {
+    if (which == 0) { std::vector<double> v; v.resize(v.max_size() + 1); }
+    if (which == 1) throw std::bad_alloc();
+    if (which == 2) throw std::runtime_error("boom");
+    if (which == 3) throw 42;
+    return 0;
+} catch (...) { return nxs_guard::caught("pc_guard_selftest", [&](int, const char *t) { put_msg(msg, msg_cap, t); }); }
+
+}  // extern "C"

@@ -14,7 +14,7 @@ import cases  # noqa: E402
 from nextsim_amd import _abi  # noqa: E402
 from oracle import pyoracle as O  # noqa: E402
 
-host = C.CDLL(sys.argv[1]); remap = C.CDLL(sys.argv[2])
+host = C.CDLL(sys.argv[1]); remap = C.CDLL(sys.argv[2]); cut = C.CDLL(sys.argv[3])
 IP, D = C.POINTER(C.c_int32), _abi.c_double_p
 
 # 1. the oracle: every rheology, young-ice category on and off, 2 ranks with ghosts, checks
@@ -134,4 +134,107 @@ for xn, yn, tn, prev, expect_fail in ((x2, y2, tri2, np.zeros(x2.size), 0), (x, 
     nf = remap.remap_host(ip(t32), _abi.dptr(x), _abi.dptr(y), x.size, t32.shape[0], ip(neci), neci.shape[1], ip(eci), ip(tn), _abi.dptr(xn),
                           _abi.dptr(yn), tn.shape[0], _abi.dptr(np.ascontiguousarray(prev)), ng, ip(sd), _abi.dptr(data), 2, _abi.dptr(out), ip(vis))
     assert nf == expect_fail, (nf, expect_fail)
+
+# 4. the host-only mesh preparation of nxs_dyn_set_mesh (nextsim_amd/csrc/nxs_patchcut.hpp) and bamg's convex completion (nxs_hull.inl):
+#    tests/native/patchcut_host.cpp builds AND checks every table (each own node solved once, each element written once, complete
+#    ascending fans, slots inside their rows, boundary patches first, send / ghost entries consistent with the halo lists ...)
+from nextsim_amd import mesh as M  # noqa: E402
+U8 = C.POINTER(C.c_uint8); I64 = C.POINTER(C.c_int64)
+cut.pc_run.argtypes = [IP, U8, D, D] + [C.c_int] * 8 + [IP, IP, C.c_int, IP, IP, C.c_int, IP, IP] + [C.c_int] * 3 + [I64, C.c_char_p, C.c_int]
+cut.pc_hilbert.argtypes = [D, D, C.c_int, IP, C.c_char_p, C.c_int]
+cut.pc_hull.argtypes = [IP, D, D, C.c_int, C.c_int, I64, C.c_char_p, C.c_int]
+cut.pc_guard_selftest.argtypes = [C.c_int, C.c_char_p, C.c_int]
+
+
+def i32(a):
+    return np.ascontiguousarray(a, np.int32)
+
+
+def run_cut(lm, patch_nodes=0, want_resident=0, overlap=0, cus=256, res_ept=1, tables=False, depth_multi=0, depth_smooth=0, expect=0):
+    idx = i32(lm.indices); g3 = np.ascontiguousarray(lm.ghost_nodes, np.uint8)
+    x = np.ascontiguousarray(lm.coord_x, np.float64); y = np.ascontiguousarray(lm.coord_y, np.float64)
+    so, si, ro, ri = i32(lm.send_offsets), i32(lm.send_index), i32(lm.recv_offsets), i32(lm.recv_index)
+    n2n = cnt = None; W2 = 0
+    if tables:   # NodalConnectivity as nxs_dyn_set_mesh converts it: [W2][Nn] 0-based rows + counts
+        _, nc_ = O.connectivity(lm.indices, lm.num_nodes)
+        W2 = nc_.shape[1] - 1
+        cnt = i32(nc_[:, -1]); n2n = i32(np.maximum(nc_[:, :W2].T - 1, 0))
+    stats = np.zeros(16, np.int64); msg = C.create_string_buffer(512)
+    rc = cut.pc_run(_abi.iptr(idx), g3.ctypes.data_as(U8), _abi.dptr(x), _abi.dptr(y), lm.num_nodes, lm.num_elements, lm.local_ndof, patch_nodes,
+                    want_resident, cus, res_ept, len(lm.send_procs), _abi.iptr(so), _abi.iptr(si) if si.size else None, len(lm.recv_procs), _abi.iptr(ro),
+                    _abi.iptr(ri) if ri.size else None, overlap, _abi.iptr(n2n) if n2n is not None else None, _abi.iptr(cnt) if cnt is not None else None,
+                    W2, depth_multi, depth_smooth, stats.ctypes.data_as(I64), msg, 512)
+    assert rc == expect, (rc, msg.value.decode())
+    return dict(zip(("nP", "Pmax", "Emax", "Mmax", "Wp", "hilbert", "lds", "P", "res_ok", "res_nbr", "n_boundary", "reordered", "m_nP", "m_EDmax",
+                     "s_nP", "s_NDmax"), stats.tolist()))
+
+
+def shuffled(gm, seed):
+    rng = np.random.default_rng(seed)
+    pn = rng.permutation(gm.num_nodes); pe = rng.permutation(gm.num_elements)
+    inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
+    return M.GlobalMesh(x=gm.x[pn].copy(), y=gm.y[pn].copy(), tri=np.ascontiguousarray(inv[gm.tri][pe].astype(np.int32)),
+                        dirichlet=gm.dirichlet[pn].copy(), neumann=gm.neumann[pn].copy(), lat=gm.lat[pn].copy(), name="shuffled")
+
+
+# 4a. the sequence of the GPU suite's abort (gpurun_out/r2_suite5.log, round 2): a 550 k-triangle mesh cut for the resident loop, then the small
+#     mesh with a numbering WITHOUT locality (tests/test_gpu_parity.py::test_shuffled_numbering_still_matches_the_oracle: seed 7) -- first the
+#     caller's numbering (rejected: ~6 elements per own node), then the Hilbert curve through the coordinates
+big = M.localize(M.make_mesh("h9000"), 1)[0]
+r = run_cut(big, want_resident=1)
+assert r["res_ok"] == 0 and r["nP"] > 512, r                      # several rounds of patches: no resident loop, one kernel per sub-step
+sm = cases.global_mesh("small")
+r = run_cut(M.localize(shuffled(sm, 7), 1)[0], tables=True, depth_multi=4, depth_smooth=10)
+assert r["hilbert"] == 1 and r["Mmax"] <= 1024, r
+for seed in (1, 2, 3):                                             # more permutations, explicit sizes, the resident cut, the toy box
+    for kind in ("toy", "small"):
+        lm_s = M.localize(shuffled(cases.global_mesh(kind), seed), 1)[0]
+        assert run_cut(lm_s, tables=True, depth_multi=2, depth_smooth=5)["hilbert"] == 1
+        run_cut(lm_s, patch_nodes=64); run_cut(lm_s, patch_nodes=1024); run_cut(lm_s, want_resident=1)
+r = run_cut(M.localize(shuffled(cases.global_mesh("40km"), 5), 1)[0], tables=True, depth_multi=4, depth_smooth=10)
+assert r["hilbert"] == 1, r
+# 4b. regular numbering: every explicit size, D-ring patches, smoother patches, a device with few CUs
+lm1 = M.localize(sm, 1)[0]
+for pn_ in (64, 100, 200, 512, 1024):
+    run_cut(lm1, patch_nodes=pn_, tables=True, depth_multi=2 + pn_ % 3, depth_smooth=5)
+for cus_ in (1, 8, 104, 256, 304):
+    run_cut(M.localize(cases.global_mesh("40km"), 1)[0], cus=cus_, tables=True, depth_multi=4, depth_smooth=10)
+    run_cut(M.localize(cases.global_mesh("40km"), 1)[0], cus=cus_, want_resident=1)
+# 4c. ragged 3- and 4-rank partitions (every rank a neighbour of every other, disconnected pieces, ghost elements without an own node -> orphan
+#     patches, corner nodes sent to several ranks), the exchange tables, the overlap variant of the resident loop
+for kind, nparts, seed in (("toy", 3, 11), ("toy", 4, 12), ("small", 3, 13), ("small", 4, 14), ("40km", 4, 15)):
+    gmk = cases.global_mesh(kind)
+    for lm_r in M.localize(gmk, nparts, elem_part=cases.ragged_partition(gmk, nparts, seed)):
+        r0 = run_cut(lm_r); r1 = run_cut(lm_r, want_resident=1, overlap=1); run_cut(lm_r, patch_nodes=64, overlap=1)
+        assert r0["n_boundary"] >= 1 and r1["n_boundary"] >= 1, (r0, r1)
+for lm_r in M.localize(sm, 2):
+    run_cut(lm_r, want_resident=1, overlap=1)
+# 4d. the partitions the 8-GPU runs have (BASELINE configs 3 and 4): all eight RCB parts of the 10 km and of the 2 km mesh, cut for the resident
+#     loop -- the 2 km parts are the ones whose patches are closed at 480 elements (Ecap): every one must qualify
+for kind in ("10km", "2km"):
+    for lm_p in M.localize(M.make_mesh(kind), 8):
+        r = run_cut(lm_p, want_resident=1)
+        assert r["res_ok"] == 1 and r["Emax"] <= 512 and r["nP"] <= 512, (kind, lm_p.rank, r)
+# 4e. the Hilbert order on coordinates nobody should pass: NaN, infinities, one point, all equal, empty
+msg = C.create_string_buffer(256)
+for xs, ys in ((np.array([0., np.nan, 1., np.inf, -np.inf, 2.]), np.array([np.nan, 0., 1., 5., -5., np.inf])), (np.zeros(7), np.zeros(7)),
+               (np.array([3.]), np.array([4.])), (np.zeros(0), np.zeros(0)), (np.array([1e308, -1e308, 0.]), np.array([-1e308, 1e308, 0.]))):
+    out = np.zeros(max(xs.size, 1), np.int32)
+    assert cut.pc_hilbert(_abi.dptr(np.ascontiguousarray(xs)), _abi.dptr(np.ascontiguousarray(ys)), xs.size, _abi.iptr(out), msg, 256) == 0, msg.value
+# 4f. bamg's convex completion: the disc with its irregular coast, with islands, the toy box; meshes it refuses say why
+hs = np.zeros(3, np.int64)
+for xk, yk, tk in ((sm.x, sm.y, sm.tri), cases.mesh_with_holes("small"), (cases.global_mesh("toy").x, cases.global_mesh("toy").y, cases.global_mesh("toy").tri),
+                   cases.mesh_with_holes("40km")):
+    ti = i32((tk + 1).ravel())
+    assert cut.pc_hull(_abi.iptr(ti), _abi.dptr(np.ascontiguousarray(xk)), _abi.dptr(np.ascontiguousarray(yk)), xk.size, tk.shape[0], hs.ctypes.data_as(I64), msg, 256) == 0, msg.value
+    assert hs[0] == 1 and hs[2] >= 3, (hs, msg.value)
+two = np.concatenate([sm.tri, sm.tri + sm.num_nodes])   # two components
+assert cut.pc_hull(_abi.iptr(i32((two + 1).ravel())), _abi.dptr(np.concatenate([sm.x, sm.x + 1e7])), _abi.dptr(np.concatenate([sm.y, sm.y])), 2 * sm.num_nodes,
+                   two.shape[0], hs.ctypes.data_as(I64), msg, 256) == 0
+print("two components:", int(hs[0]), msg.value.decode())
+# 4g. the guard of the ABI (nxs_guard.hpp): length_error / bad_alloc -> NXS_ERR_NOMEM, anything else -> NXS_ERR_INTERNAL, with a text
+assert cut.pc_guard_selftest(0, msg, 256) == -6 and b"length_error" in msg.value
+assert cut.pc_guard_selftest(1, msg, 256) == -6 and b"bad_alloc" in msg.value
+assert cut.pc_guard_selftest(2, msg, 256) == -7 and b"boom" in msg.value
+assert cut.pc_guard_selftest(3, msg, 256) == -7
 print("sanitize worker ok")

@@ -88,3 +88,52 @@ def test_product_package_never_imports_the_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".h")) or fn == "Makefile":
                 text = open(os.path.join(dirpath, fn)).read()
                 assert "pyoracle" not in text and "dyn_ref" not in text and "liboracle" not in text, fn
+
+
+def test_every_entry_point_is_a_function_try_block():
+    """'Never throws across the ABI' (include/nxs_dyn.h): every extern "C" definition of the library with a body of its own is
+    a function-try-block whose handler maps the exception to a status code (csrc/nxs_guard.hpp).  Checked on the source text, so that
+    an entry point added later cannot forget it."""
+    csrc = os.path.join(ROOT, "nextsim_amd", "csrc")
+    sig = re.compile(r'^(?:extern "C" )?(?:int|void) (nxs_\w+)\(')
+    guarded, total = 0, 0
+    for fn in ("nxs_dyn.hip", "nxs_interp.hip", "nxs_krylov.hip", "nxs_io.cpp", "nxs_mesh.cpp"):
+        lines = open(os.path.join(csrc, fn)).read().split("\n")
+        for i, line in enumerate(lines):
+            m = sig.match(line)
+            if not m:
+                continue
+            j = i
+            while not lines[j].split("//")[0].rstrip().endswith(("{", "}", ";")):
+                j += 1
+            head = lines[j].split("//")[0].rstrip()
+            if not head.endswith("{"):
+                continue                       # a declaration, or a one-line body that only returns a member
+            total += 1
+            assert head.endswith("try {"), f"{fn}:{j + 1}: {m.group(1)} is not a function-try-block"
+            k = j + 1
+            while not lines[k].startswith("}"):
+                k += 1
+            assert "catch (...)" in lines[k] and m.group(1) in lines[k], f"{fn}:{k + 1}: handler of {m.group(1)}"
+            guarded += 1
+    assert guarded == total and total >= 65, (guarded, total)
+
+
+def test_allocation_failure_inside_the_library_is_a_status_code(tmp_path):
+    """A std::bad_alloc inside an entry point comes back as NXS_ERR_NOMEM (-6), not as std::terminate: with the address space capped just above
+    what the process already uses, nxs_mesh_connectivity is asked for the tables of 60 M nodes (its first vector alone needs 240 MB)."""
+    code = r'''
+import ctypes as C, resource, sys
+import numpy as np
+sys.path.insert(0, %r)
+from nextsim_amd import dynamics
+L = dynamics.load_library()
+idx = np.array([1, 2, 3], np.int32)
+w1, w2 = C.c_int32(), C.c_int32()
+vm = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (vm + (128 << 20), resource.RLIM_INFINITY))
+rc = L.nxs_mesh_connectivity(idx.ctypes.data_as(C.POINTER(C.c_int32)), 60_000_000, 1, C.byref(w1), None, C.byref(w2), None)
+print("rc", rc)
+''' % ROOT
+    r = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rc -6" in r.stdout, (r.stdout, r.stderr[-2000:])

@@ -256,6 +256,44 @@ def test_error_codes_on_gpu():
     fe.close()
 
 
+def test_allocation_failure_in_set_mesh_is_a_status_code_and_the_handle_lives_on():
+    """'Never throws across the ABI': with the address space of a child process capped 512 MB above what it uses, nxs_dyn_set_mesh is handed a
+    NodalElementConnectivity of 2^21 columns (its int table alone would take 12 GB): the std::bad_alloc is caught at the boundary
+    (csrc/nxs_guard.hpp) and comes back as NXS_ERR_NOMEM with a text; with the cap lifted the same handle takes the mesh and steps."""
+    import subprocess
+    import sys
+    code = r'''
+import resource, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import cases
+from nextsim_amd import dynamics
+gm, p, g, lms, fields = cases.make_case("small")
+lm = lms[0]
+fe = dynamics.FiniteElementDynamics(p)
+fe.set_mesh(lm); fe.put_state(fields[0]); fe.set_forcing(fields[0]); fe.step(); fe.synchronize()
+ref = fe.get_state()["VT"].copy()
+nec, nc = dynamics.mesh_connectivity(lm.indices, lm.num_nodes)
+class Wide:
+    shape = (lm.num_nodes, 2 ** 21)
+    dtype, flags, ctypes = nec.dtype, nec.flags, nec.ctypes
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+vm = int(open("/proc/self/statm").read().split()[0]) * resource.getpagesize()
+resource.setrlimit(resource.RLIMIT_AS, (vm + (512 << 20), hard))
+try:
+    fe.set_mesh(lm, (Wide(), nc))
+    print("no error")
+except dynamics.NxsError as e:
+    print("code", e.code, str(e))
+resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+fe.set_mesh(lm); fe.put_state(fields[0]); fe.set_forcing(fields[0]); fe.step(); fe.synchronize()
+print("same bits", bool(np.array_equal(fe.get_state()["VT"], ref)))
+fe.close()
+''' % (cases.__file__.rsplit("/", 2)[0], cases.__file__.rsplit("/", 1)[0])
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "code -6" in r.stdout and "bad_alloc" in r.stdout and "same bits True" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 # ---- full-size properties (the oracle would take minutes here; use what the domain offers) ----
 
 def test_full_size_10km_invariants_and_rigid_state():
@@ -510,6 +548,42 @@ def test_resident_sub_step_loop_falls_back_where_it_cannot_run():
     b, _, _ = _pair("h9000", 1, options={"fused": 4})        # ~550 k triangles: several rounds of patches
     assert b.timing()["substep_launches"] == 120
     b.close()
+
+
+def test_resident_loop_survives_a_remesh_a_change_of_sub_steps_and_a_second_handle():
+    """What the resident loop's tables are tied to may change under it: (a) nxs_dyn_set_mesh on a live handle (every regrid) -- its second exchange
+    buffer used to stay a pointer into the freed arrays of the OLD mesh (round 3: a device-side use-after-free found by reading, the tables now
+    live in a pool of their own that goes with the mesh); (b) nxs_dyn_set_params with another number of sub-steps or another exponent (another
+    kernel build, a ghost ring of another length): re-checked at the next step; (c) a SECOND handle of this process asking for the resident loop
+    on the same device when the first one's workgroups fill it: refused up front by the per-device registry (one kernel per sub-step, no spin
+    against each other until the time-out).  Always the bits of one kernel per sub-step."""
+    from nextsim_amd import dynamics
+    gm1, p1, g1, lms1, f1 = cases.make_case("h15600")
+    gm2, p2, g2, lms2, f2 = cases.make_case("small")
+
+    def run(fused, second_substeps):
+        fe = dynamics.FiniteElementDynamics(p2)
+        fe.set_option("fused", fused)
+        fe.set_mesh(lms2[0]); fe.put_state(f2[0]); fe.set_forcing(f2[0]); fe.step(); fe.step()
+        fe.set_params(p1)
+        fe.set_mesh(lms1[0]); fe.put_state(f1[0]); fe.set_forcing(f1[0]); fe.step()
+        q = p1.copy(); q.substeps = second_substeps; q.dtime_step = 200. * second_substeps / 120; q.exponent_relaxation_sigma = 4.
+        fe.set_params(q)
+        fe.step(); fe.synchronize()
+        return fe
+    a, b = run(1, 7), run(4, 7)
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert b.timing()["substep_launches"] == 1 and a.timing()["substep_launches"] == 7
+    # (c) b holds 511 of the device's 512 resident workgroup slots: c is refused the resident loop and runs one kernel per sub-step
+    c = dynamics.FiniteElementDynamics(p1); c.set_option("fused", 4)
+    c.set_mesh(lms1[0]); c.put_state(f1[0]); c.set_forcing(f1[0]); c.step(); c.synchronize()
+    assert c.timing()["substep_launches"] == 120
+    b.close()                                   # its claim goes with it
+    c.set_option("fused", 4); c.step(); c.synchronize()
+    assert c.timing()["substep_launches"] == 1
+    a.close(); c.close()
 
 
 def test_shuffled_numbering_still_matches_the_oracle():
