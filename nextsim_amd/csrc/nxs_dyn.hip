@@ -133,6 +133,7 @@ struct nxs_dyn_handle {
     size_t ipc_block_bytes = 0;
     bool ipc_uncached = false;             // the mailbox is MTYPE_UC memory (what the fence-less in-kernel exchange relies on)
     std::vector<void *> ipc_peer_base;     // opened peer mailboxes (to close)
+    std::vector<void *> ipc_local_peers;   // mailboxes of other handles of THIS process this handle stores through (counted in g_mailboxes)
     std::vector<void *> ipc_allocs;
     int *d_recv_procs = nullptr;
     // halo exchange fused into the sub-step kernel (device-direct transport + fused path)
@@ -339,6 +340,7 @@ struct IpcBlob {
     unsigned long long ptr;     // the mailbox in the exporting process
     int device, uncached;
     int tr, nr;                 // received nodes in total, receive neighbours
+    unsigned long long token;   // drawn once per process: equal pids in two containers that share a GPU are not "the same process"
 };
 static_assert(sizeof(IpcBlob) <= NXS_IPC_BLOB_BYTES, "blob too small");
 constexpr unsigned long long IPC_MAGIC = 0x4e58534950433031ull;
@@ -354,16 +356,60 @@ IpcLayout ipc_layout(size_t tr, int nr) {
     return l;
 }
 
+// Mailboxes of THIS process.  A neighbour handle of the same process stores through the exporter's raw device pointer (hipIpc cannot open
+// its own process's handle), and its tables and captured graphs keep that pointer: the allocation must outlive them.  Every exported
+// mailbox is registered here; a same-process connect counts itself in, and a mailbox whose owner lets go of it (a second
+// nxs_dyn_ipc_export, nxs_dyn_set_halo, nxs_dyn_destroy) while peers are still connected is freed by the LAST peer that disconnects.
+struct MailboxRegistry {
+    struct Entry { int device; bool owner_alive; int peers; };
+    std::mutex mu;
+    std::map<void *, Entry> boxes;
+};
+MailboxRegistry g_mailboxes;
+unsigned long long process_token() {
+    static const unsigned long long tok = [] {
+        unsigned long long t = 0;
+        if (FILE *f = fopen("/dev/urandom", "rb")) { if (fread(&t, sizeof t, 1, f) != 1) t = 0; fclose(f); }
+        if (t == 0) t = 0x9E3779B97F4A7C15ull * (unsigned long long)getpid() ^ (unsigned long long)(uintptr_t)&g_mailboxes;
+        return t;
+    }();
+    return tok;
+}
+void mailbox_drop_locked(std::map<void *, MailboxRegistry::Entry>::iterator it) {  // (g_mailboxes.mu held)
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (it->second.device != cur) (void)hipSetDevice(it->second.device);
+    (void)hipFree(it->first);
+    if (it->second.device != cur) (void)hipSetDevice(cur);
+    g_mailboxes.boxes.erase(it);
+}
+
 void ipc_disconnect(nxs_dyn_handle *h) {  // the peer mappings and the tables of one nxs_dyn_ipc_connect
     for (void *p : h->ipc_peer_base) if (p) (void)hipIpcCloseMemHandle(p);
     h->ipc_peer_base.clear();
+    {
+        std::lock_guard<std::mutex> lk(g_mailboxes.mu);
+        for (void *p : h->ipc_local_peers) {
+            auto it = g_mailboxes.boxes.find(p);
+            if (it == g_mailboxes.boxes.end()) continue;
+            if (--it->second.peers <= 0 && !it->second.owner_alive) mailbox_drop_locked(it);  // its owner is gone: the last peer frees it
+        }
+    }
+    h->ipc_local_peers.clear();
     free_pool(h->ipc_allocs);
     h->ipc_ready = false;
     h->ipc = IpcDev{};
 }
 void ipc_release(nxs_dyn_handle *h) {
     ipc_disconnect(h);
-    if (h->ipc_block) { (void)hipFree(h->ipc_block); h->ipc_block = nullptr; }
+    if (h->ipc_block) {
+        std::lock_guard<std::mutex> lk(g_mailboxes.mu);
+        auto it = g_mailboxes.boxes.find(h->ipc_block);
+        if (it == g_mailboxes.boxes.end()) (void)hipFree(h->ipc_block);
+        else if (it->second.peers > 0) it->second.owner_alive = false;  // handles of this process still store through it: freed by the last of them
+        else mailbox_drop_locked(it);
+        h->ipc_block = nullptr;
+    }
     h->ipc_uncached = false;
 }
 // option "pin_host": the caller's vectors (FiniteElement's M_VT, M_conc, ... live as long as the mesh) are page-locked the first
@@ -983,6 +1029,10 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) try {
         }
     }
     h->ipc_uncached = true;
+    {
+        std::lock_guard<std::mutex> lk(g_mailboxes.mu);
+        g_mailboxes.boxes[h->ipc_block] = MailboxRegistry::Entry{h->device, true, 0};
+    }
     if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d mailbox: %zu bytes, uncached (MTYPE_UC)\n", h->rank, bytes);
     // (everything on the handle's own stream: another handle of this process may be capturing a graph on its thread right now,
     // and legacy-stream operations are refused while any blocking capture is open)
@@ -997,6 +1047,7 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) try {
     b.ptr = (unsigned long long)(uintptr_t)h->ipc_block;
     b.device = h->device; b.uncached = 1;
     b.tr = (int)tr; b.nr = nr;
+    b.token = process_token();
     std::memset(blob, 0, NXS_IPC_BLOB_BYTES);
     std::memcpy(blob, &b, sizeof b);
     return NXS_OK;
@@ -1032,8 +1083,16 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
         if (peer_recv_offset[k] < 0 || (long long)peer_recv_offset[k] + nseg > b.tr)
             return fail(h, NXS_ERR_INVALID, "ipc_connect: my segment [%d, %d) does not fit neighbour %d's %d received nodes", peer_recv_offset[k], peer_recv_offset[k] + nseg, q, b.tr);
         void *base = nullptr;
-        if (b.pid == (long long)getpid()) {  // a handle of this process: its pointer is valid here, on another device after peer access
+        if (b.pid == (long long)getpid() && b.token == process_token()) {  // a handle of this process: its pointer is valid here, on another device after peer access
             base = (void *)(uintptr_t)b.ptr;
+            {
+                std::lock_guard<std::mutex> lk(g_mailboxes.mu);
+                auto it = g_mailboxes.boxes.find(base);
+                if (it == g_mailboxes.boxes.end() || !it->second.owner_alive)
+                    return fail(h, NXS_ERR_STATE, "ipc_connect: neighbour %d's mailbox no longer exists (exported again, or its handle was destroyed, since the blob was made)", q);
+                it->second.peers++;
+            }
+            h->ipc_local_peers.push_back(base);
             if (b.device != h->device) {
                 const hipError_t pe = hipDeviceEnablePeerAccess(b.device, 0);
                 if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) return fail(h, NXS_ERR_COMM, "hipDeviceEnablePeerAccess(%d -> %d): %s", h->device, b.device, hipGetErrorString(pe));

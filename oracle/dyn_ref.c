@@ -10,6 +10,7 @@
  * signed zeros differ), hence the macros.
  */
 #define _GNU_SOURCE
+#define _POSIX_C_SOURCE 200809L  /* pthread barriers (ref_multirank_steps) under -std=c11 */
 #include "dyn_ref.h"
 
 #include <math.h>
@@ -1032,4 +1033,116 @@ int ref_mesh_connectivity(const int32_t *indices, int32_t Nn, int32_t Ne,
     free(e_i); free(e_j); free(e_next); free(e_first); free(e_head);
     free(ie0); free(ie1); free(head_2); free(next_2); free(size_2);
     return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* P in-process ranks stepped in lock-step by a pool of threads: the CPU analogue of the reference's MPI run (one partition per
+ * core, every updateGhosts(M_VT) of FE.cpp:10425-10611 a shared-memory exchange between two barriers), used by bench.py's
+ * cpu_baseline leg and checked against the serial multirank_step of oracle/pyoracle.py (tests/test_multirank_oracle.py).
+ * Thread t runs the ranks t, t + nthreads, ...; the phases are those of ref_explicit_solve / ref_step. */
+#include <pthread.h>
+
+typedef struct ref_mr_job {
+    int nranks, nthreads, nsteps;
+    const nxs_dyn_mesh *const *m;
+    const nxs_dyn_params *p;
+    nxs_dyn_state *const *s;
+    const nxs_dyn_forcing *const *f;
+    ref_work *const *w;
+    const nxs_dyn_halo *const *h;
+    double **sendbuf;       /* [nranks] rank r's packed segments, segment k at 2 * send_offsets[k] */
+    int **peer_seg;         /* [nranks][num_recv_procs] the index k' of me among the sender's send_procs */
+    pthread_barrier_t bar;
+} ref_mr_job;
+
+typedef struct ref_mr_arg { ref_mr_job *job; int tid; } ref_mr_arg;
+
+static void mr_pack(ref_mr_job *j, int r) {
+    const nxs_dyn_halo *h = j->h[r];
+    for (int k = 0; k < h->num_send_procs; k++)
+        ref_ghosts_pack(h, j->m[r]->num_nodes, j->s[r]->VT, k, j->sendbuf[r] + 2 * (size_t)h->send_offsets[k]);
+}
+static void mr_unpack(ref_mr_job *j, int r) {
+    const nxs_dyn_halo *h = j->h[r];
+    for (int k = 0; k < h->num_recv_procs; k++) {
+        const int q = h->recv_procs[k], kk = j->peer_seg[r][k];
+        ref_ghosts_unpack(h, j->m[r]->num_nodes, j->s[r]->VT, k, j->sendbuf[q] + 2 * (size_t)j->h[q]->send_offsets[kk]);
+    }
+}
+
+#define MR_EACH(stmt) do { for (int r = tid; r < J->nranks; r += J->nthreads) { stmt; } pthread_barrier_wait(&J->bar); } while (0)
+
+static void *mr_thread(void *arg_) {
+    ref_mr_arg *a = (ref_mr_arg *)arg_;
+    ref_mr_job *J = a->job;
+    const int tid = a->tid;
+    const nxs_dyn_params *p = J->p;
+    const int S = p->substeps;
+    const double dte = p->dtime_step / (double)S;
+    for (int it = 0; it < J->nsteps; it++) {
+        if (p->dynamics_type == NXS_DYN_NO_MOTION) break;
+        if (p->dynamics_type == NXS_DYN_FREE_DRIFT) { MR_EACH(ref_free_drift(J->m[r], p, J->s[r], J->f[r])); continue; }
+        MR_EACH(ref_prep(J->m[r], p, J->s[r], J->f[r], J->w[r]));
+        for (int ss = 0; ss < S; ss++) {
+            MR_EACH(ref_substep_solve(J->m[r], p, J->s[r], J->f[r], J->w[r]); mr_pack(J, r));
+            if (p->dynamics_type != NXS_DYN_MEVP) MR_EACH(mr_unpack(J, r); ref_move_mesh(J->m[r], J->s[r], J->w[r], dte));
+            else MR_EACH(mr_unpack(J, r));
+        }
+        if (p->dynamics_type == NXS_DYN_MEVP) MR_EACH(ref_move_mesh(J->m[r], J->s[r], J->w[r], p->dtime_step));
+        for (int nit = 0; nit < 50; nit++) {  /* Q9 */
+            MR_EACH(ref_smoother_sweep(J->m[r], J->s[r], J->w[r]); mr_pack(J, r));
+            MR_EACH(mr_unpack(J, r));
+        }
+        MR_EACH(ref_ow_tail(J->m[r], p, J->s[r], J->f[r], J->w[r]); ref_update(J->m[r], p, J->s[r], J->w[r]));
+    }
+    return NULL;
+}
+
+/* 0 on success; -1: bad arguments / inconsistent halo lists; -2: out of memory / threads */
+int ref_multirank_steps(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_params *p, nxs_dyn_state *const *s,
+                        const nxs_dyn_forcing *const *f, ref_work *const *w, const nxs_dyn_halo *const *h, int nsteps, int nthreads) {
+    if (nranks < 1 || nsteps < 0 || !m || !p || !s || !f || !w || !h) return -1;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > nranks) nthreads = nranks;
+    ref_mr_job J;
+    memset(&J, 0, sizeof J);
+    J.nranks = nranks; J.nthreads = nthreads; J.nsteps = nsteps;
+    J.m = m; J.p = p; J.s = s; J.f = f; J.w = w; J.h = h;
+    int rc = 0;
+    J.sendbuf = (double **)calloc((size_t)nranks, sizeof(double *));
+    J.peer_seg = (int **)calloc((size_t)nranks, sizeof(int *));
+    pthread_t *th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    ref_mr_arg *args = (ref_mr_arg *)calloc((size_t)nthreads, sizeof(ref_mr_arg));
+    if (!J.sendbuf || !J.peer_seg || !th || !args) rc = -2;
+    for (int r = 0; r < nranks && rc == 0; r++) {
+        const nxs_dyn_halo *hr = h[r];
+        const int ns = hr->num_send_procs, nr = hr->num_recv_procs;
+        J.sendbuf[r] = (double *)malloc(sizeof(double) * (2 * (size_t)(ns ? hr->send_offsets[ns] : 0) + 1));
+        J.peer_seg[r] = (int *)malloc(sizeof(int) * (size_t)(nr + 1));
+        if (!J.sendbuf[r] || !J.peer_seg[r]) { rc = -2; break; }
+        for (int k = 0; k < nr && rc == 0; k++) {
+            const int q = hr->recv_procs[k];
+            if (q < 0 || q >= nranks) { rc = -1; break; }
+            int found = -1;
+            for (int kk = 0; kk < h[q]->num_send_procs; kk++) if (h[q]->send_procs[kk] == hr->rank) found = kk;
+            if (found < 0 || h[q]->send_offsets[found + 1] - h[q]->send_offsets[found] != hr->recv_offsets[k + 1] - hr->recv_offsets[k]) { rc = -1; break; }
+            J.peer_seg[r][k] = found;
+        }
+    }
+    if (rc == 0 && pthread_barrier_init(&J.bar, NULL, (unsigned)nthreads) != 0) rc = -2;
+    if (rc == 0) {
+        int started = 0;
+        for (int t = 0; t < nthreads; t++) {
+            args[t].job = &J; args[t].tid = t;
+            if (t == nthreads - 1) { mr_thread(&args[t]); }          /* the caller's thread works too */
+            else if (pthread_create(&th[t], NULL, mr_thread, &args[t]) != 0) { rc = -2; break; }  /* (a missing thread would hang the barrier: cannot happen past this point) */
+            else started++;
+        }
+        for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+        pthread_barrier_destroy(&J.bar);
+    }
+    if (J.sendbuf) for (int r = 0; r < nranks; r++) free(J.sendbuf[r]);
+    if (J.peer_seg) for (int r = 0; r < nranks; r++) free(J.peer_seg[r]);
+    free(J.sendbuf); free(J.peer_seg); free(th); free(args);
+    return rc;
 }

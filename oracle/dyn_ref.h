@@ -96,6 +96,11 @@ int ref_check_fields_fast(const nxs_dyn_mesh *m, const nxs_dyn_params *p, const 
 void ref_ghosts_pack(const nxs_dyn_halo *h, int32_t Nn, const double *vec, int k, double *buf);
 void ref_ghosts_unpack(const nxs_dyn_halo *h, int32_t Nn, double *vec, int k, const double *buf);
 
+/* P in-process ranks in lock-step on `nthreads` threads (thread t runs ranks t, t + nthreads, ...): step() of every rank with every
+ * updateGhosts(M_VT) a shared-memory exchange -- the CPU analogue of the reference's MPI run (bench.py's cpu_baseline) */
+int ref_multirank_steps(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_params *p, nxs_dyn_state *const *s,
+                        const nxs_dyn_forcing *const *f, ref_work *const *w, const nxs_dyn_halo *const *h, int nsteps, int nthreads);
+
 /* restatement of Mesh::WriteMesh's two connectivity tables (contrib/bamg/src/Mesh.cpp:514-543, 798-865) */
 int ref_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
                           int32_t *nec_width, double *nec, int32_t *nc_width, double *nc);

@@ -73,6 +73,8 @@ def lib(fast: bool = False):
     L.ref_mesh_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, P(C.c_int32), _abi.c_double_p,
                                         P(C.c_int32), _abi.c_double_p]
     L.ref_mesh_connectivity.restype = C.c_int
+    L.ref_multirank_steps.argtypes = [C.c_int, P(Mp), Pp, P(Sp), P(Fp), P(Wp), P(P(_abi.Halo)), C.c_int, C.c_int]
+    L.ref_multirank_steps.restype = C.c_int
     _libs[fast] = L
     return L
 
@@ -324,6 +326,23 @@ def multirank_step_threaded(ranks: list, pool) -> None:
         run(lambda r: r.smoother_sweep())
         exchange_ghosts(ranks)
     run(lambda r: (r.ow_tail(), r.update()))
+
+
+def multirank_steps_native(ranks: list, nsteps: int = 1, nthreads: int = 0) -> None:
+    """`nsteps` lock-step steps of the in-process ranks on `nthreads` host threads inside the oracle library itself
+    (ref_multirank_steps: pthreads + barriers, shared-memory updateGhosts) -- what multirank_step does, without a Python call per
+    phase and rank: the cpu_baseline of bench.py at the core counts of a GPU box."""
+    n = len(ranks)
+    P = C.POINTER
+    Mp, Sp, Fp, Wp, Hp = P(_abi.Mesh), P(_abi.State), P(_abi.Forcing), P(Work), P(_abi.Halo)
+    m = (Mp * n)(*[C.pointer(r.mesh) for r in ranks])
+    s = (Sp * n)(*[C.pointer(r.state) for r in ranks])
+    f = (Fp * n)(*[C.pointer(r.forcing) for r in ranks])
+    w = (Wp * n)(*[r.work for r in ranks])
+    h = (Hp * n)(*[C.pointer(r.halo) for r in ranks])
+    rc = ranks[0].L.ref_multirank_steps(n, m, C.byref(ranks[0].params), s, f, w, h, nsteps, nthreads or n)
+    if rc != 0:
+        raise RuntimeError(f"ref_multirank_steps failed ({rc})")
 
 
 def bamg_element_connectivity(indices, x, y):

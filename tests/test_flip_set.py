@@ -131,6 +131,6 @@ def test_threshold_flip_set_and_the_surveys_ten_step_figure(kind, capsys):
         assert r["v_all"] <= 1e-10 and r["sig_all"] <= 1e-10 and r["d_all"] <= 1e-10, r
     for r in rows:
         for dev, tw in (("v_all", "twin_v"), ("sig_all", "twin_sig"), ("d_all", "twin_d")):
-            assert r[dev] <= 50.0 * r[tw] + 1e-12, (r["steps"], dev, r[dev], r[tw])
+            assert r[dev] <= 5.0 * r[tw] + 1e-12, (r["steps"], dev, r[dev], r[tw])   # measured 0.2 .. 1.6
     ten = rows[-1]
     assert ten["twin_sig"] > 1e-8 and ten["sig_not_near"] > 1e-8, "if this fails the survey's bound became attainable: tighten the tests"

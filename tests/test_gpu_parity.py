@@ -335,6 +335,42 @@ def test_full_size_10km_invariants_and_rigid_state():
     fe.close()
 
 
+@pytest.mark.parametrize("kind,state,options,expect_launches", [("2km", "arctic", {}, 120), ("2km", "arctic_ow", {}, 120), ("h15600", "arctic", {"fused": 4}, 1),
+                                                                 ("10km", "arctic_ow", {}, 30)])
+def test_the_bench_workloads_themselves_against_the_oracle(kind, state, options, expect_launches):
+    """What bench.py times, tied to the oracle DIRECTLY (not through the per-loop kernels): the 2 km mesh (BASELINE's headline configuration,
+    1.46 M triangles) on a single rank with the library's automatic kernel choice -- streaming hints, 476-node patches in three element rounds,
+    the once-per-step ring flush, ten smoother sweeps per launch -- with bench.py's two states ('arctic' and 'arctic_ow': 29 % of the triangles
+    ice free, 4 % in the 0 < A <= 0.1 band); the 182 k-triangle partition of aux_partition_floor in ONE resident launch (fused = 4); the 10 km
+    mesh of aux_10km on the several-sub-steps kernel.  One full step (120 BBM sub-steps + 50 sweeps + update), every state array <= 1e-10 of
+    the serial oracle (which takes ~9 s at 2 km and runs in a thread beside the GPU)."""
+    import threading
+    from nextsim_amd import dynamics
+    from oracle import pyoracle as O
+    gm, p, g, lms, fields = cases.make_case(kind, state)
+    lm, f = lms[0], fields[0]
+    ref = O.OracleRank(lm, p, f, fast=False)
+    th = threading.Thread(target=ref.step)
+    th.start()
+    fe = dynamics.FiniteElementDynamics(p)
+    for k, v in options.items():
+        fe.set_option(k, v)
+    fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+    fe.step(); fe.synchronize()
+    got = fe.get_state()
+    assert fe.timing()["substep_launches"] == expect_launches      # the kernel family bench.py reports for this workload
+    assert fe.checkFieldsFast() == 0
+    dg = fe.get_diag()
+    fe.close()
+    th.join()
+    _assert_close(got, ref.arr, STATE_KEYS, 1e-10, f"{kind} / {state}: one step of the bench workload")
+    Nn, Ne = lm.num_nodes, lm.num_elements
+    for k, n in (("surface", Ne), ("D_tau_w", 2 * Nn), ("D_tau_a", 2 * Nn)):
+        assert cases.rel_err(dg[k], ref.work_array(k, n)) <= 1e-10, k
+    if state == "arctic_ow":   # the workload really has open water: nodes without mass, which the smoother moves
+        assert (f["conc"] == 0).mean() > 0.2
+
+
 def test_full_size_2km_bench_workload_two_kernel_families_agree_bit_for_bit():
     """The workload bench.py times (BASELINE's 2 km configuration, 1.46 M triangles) is far beyond what the oracle
     finishes in seconds.  Size-independent evidence instead: (1) the fused patch kernel and the per-loop kernels --

@@ -81,3 +81,19 @@ def test_callback_form_of_explicit_solve_matches_phase_form():
     assert len(calls) == 120 + 50
     for k in KEYS_N + KEYS_E:
         assert np.array_equal(a.arr[k], b.arr[k])
+
+
+@pytest.mark.parametrize("kind,nparts,nthreads,over", [("toy", 3, 2, {}), ("small", 5, 5, {}), ("small", 4, 3, {"dynamics_type": 4}),
+                                                      ("small", 3, 8, {"ragged_seed": 21}), ("toy", 2, 1, {"dynamics_type": 3})])
+def test_threaded_lock_step_in_the_library_equals_the_phase_by_phase_driver(kind, nparts, nthreads, over):
+    """ref_multirank_steps (pthreads, barriers, shared-memory updateGhosts: the cpu_baseline of bench.py) gives, bit for bit, what the
+    phase-by-phase Python driver gives: more ranks than threads, fewer, ragged partitions, BBM / EVP / mEVP, two steps."""
+    gm, p, g, lms, fields = cases.make_case(kind, nparts=nparts, **over)
+    a = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    b = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    for _ in range(2):
+        O.multirank_step(a)
+    O.multirank_steps_native(b, nsteps=2, nthreads=nthreads)
+    for ra, rb in zip(a, b):
+        for k in KEYS_N + KEYS_E:
+            assert np.array_equal(ra.arr[k], rb.arr[k]), (ra.lm.rank, k)
