@@ -146,6 +146,9 @@ struct nxs_dyn_handle {
     bool res_ready = false, res_failed = false;
     int res_wide = 0;     // option resident_wide
     bool res_pow4 = true; // the build for BBM's default exponent (two squarings instead of pow)
+    bool res_big = false; // k_substep_resident_big: one large patch per CU (the patches hold more than one element per thread)
+    bool cut_big = false; // the mesh was cut for that kernel (not what the one-launch-per-sub-step kernel wants: re-cut if the resident loop is refused)
+    bool no_big_cut = false;
     int res_substeps = 0; // the number of sub-steps the tables (the ghosts' ring) were sized for
     int res_wpe = 4;      // waves per SIMD of the resident kernel build in use (2 on several ranks where one workgroup per CU covers the partition)
     int res_overlap = 0;  // option resident_overlap (several ranks): interior elements of the next sub-step computed while the exchange is awaited
@@ -596,7 +599,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }  // -1 = automatic
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
-        h->fused = (int)value; h->res_failed = false; release_graph(h); return NXS_OK;
+        h->fused = (int)value; h->res_failed = false; h->no_big_cut = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "resident_dryrun")) {  // builds the tables of the resident loop now (mesh and, on several ranks, halo lists set; no
         // transport needed) and says whether this partition can run it: checks a rank's partition without its neighbours
@@ -704,6 +707,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     unpin_all(h);
     h->ring = VTRing{};
     h->have_mesh = h->have_state = h->have_forcing = h->have_halo = false;
+    h->no_big_cut = false;
     h->sig_loc = 0;
     h->trace_branches = 0;
     h->rank = 0; h->nranks = 1;
@@ -1475,6 +1479,10 @@ int setup_ring(nxs_dyn_handle *h, int K) {
 // (WPE = 2: the several-rank build with all the registers it wants, BBM's default exponent only.)
 const void *resident_kernel(const nxs_dyn_handle *h, bool mr, bool ovl) {
     const bool p4 = h->res_pow4;
+    if (h->res_big) {  // one large patch per CU, four elements and two own nodes per thread
+        if (mr) return p4 ? (const void *)k_substep_resident_big<true, true> : (const void *)k_substep_resident_big<false, true>;
+        return p4 ? (const void *)k_substep_resident_big<true, false> : (const void *)k_substep_resident_big<false, false>;
+    }
     if (mr && h->res_wpe == 2 && p4) return ovl ? (const void *)k_substep_resident<512, true, true, true, 2> : (const void *)k_substep_resident<512, true, true, false, 2>;
     if (mr && ovl) return p4 ? (const void *)k_substep_resident<512, true, true, true> : (const void *)k_substep_resident<512, false, true, true>;
     if (mr) return p4 ? (const void *)k_substep_resident<512, true, true> : (const void *)k_substep_resident<512, false, true>;
@@ -1567,7 +1575,8 @@ int build_resident(nxs_dyn_handle *h) {
     const HostPatches &hp = *h->hp;
     const int nP = hp.nP, No = h->dm.No, Nn = h->dm.Nn, S = h->dp.substeps;
     const bool mr = multi_rank(h);
-    const bool ovl = mr && h->res_overlap;
+    const bool big = nxs_cut::resident_is_big(hp);
+    const bool ovl = mr && h->res_overlap && !big;
     auto refuse = [&](const char *why) {
         if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel not possible: %s\n", h->rank, why);
         h->res_failed = true;
@@ -1577,15 +1586,16 @@ int build_resident(nxs_dyn_handle *h) {
     nxs_cut::ResidentPlan plan;
     nxs_cut::plan_resident(hp, Nn, No, mr, (int)h->send_procs.size(), ovl, plan);
     if (!plan.ok) return refuse(plan.why.c_str());
-    h->res_lds = (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax  // + the pair of zeros behind the corner forces + [Pmax][8] fan entries
-                 + (mr ? 16 * (size_t)std::min(hp.Mmax, 512) + 20 * (size_t)NXS_RES_MAXNB : 0);  // + the halo slots' sources and the neighbour ranks' mailbox addresses
+    h->res_big = big;
+    h->res_lds = big ? nxs_cut::resident_big_lds_of(hp, mr) : nxs_cut::resident_lds_of(hp, mr);
+    if (h->res_lds > 160 * 1024) return refuse("a patch needs more LDS than a CU has");
     // every workgroup must be resident at once
     int per_cu = 0;
     const int cus = device_cus(h);
     const bool p4 = h->dp.ers_int == 4;
     // one workgroup per CU is enough and the caller says the device is this handle's alone (option resident_wide): the several-rank build with all
     // the registers it wants -- one such workgroup fills a CU, so ranks that share a device (the tests) would no longer fit side by side
-    h->res_wpe = (mr && p4 && h->res_wide && nP <= cus) ? 2 : 4;
+    h->res_wpe = (mr && p4 && h->res_wide && nP <= cus && !big) ? 2 : 4;
     h->res_pow4 = p4;
     const void *kern = resident_kernel(h, mr, ovl);
     hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, h->res_lds);
@@ -1703,6 +1713,17 @@ int run_substeps(nxs_dyn_handle *h) {
     if (res_wanted && !h->res_ready && !h->res_failed) {  // (outside any capture)
         int rcr = build_resident(h);
         if (rcr) return rcr;
+        if (h->res_failed && h->cut_big && !h->no_big_cut) {
+            // the mesh was cut into one large patch per CU for k_substep_resident_big and that launch is not possible after all (the device's
+            // workgroup slots are taken, ...): the one-launch-per-sub-step kernel wants its own cut (two smaller workgroups per CU, whole rounds)
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            release_graph(h);
+            h->no_big_cut = true;
+            int rcu = upload_patches(h);
+            if (rcu) return rcu;
+            h->res_failed = true;
+            if (mr && !h->hf_ready) { int rc = build_halo_fused(h); if (rc) return rc; }
+        }
     }
     const bool resident = res_wanted && h->res_ready && !h->res_failed;
     if ((halo_in_kernel || (resident && mr)) && h->d_hf_dirty) {  // (outside any stream capture)

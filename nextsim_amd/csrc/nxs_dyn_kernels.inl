@@ -1645,6 +1645,322 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// v4b  The resident sub-step loop for partitions of up to ~400 k triangles (a rank of four of the 2 km mesh): ONE 512-thread workgroup per
+// CU, compiled for two waves per SIMD (256 VGPRs), EPT = 4 elements and NPT = 2 own nodes per thread.  What k_substep_resident keeps in LDS for a
+// patch of 180 nodes does not fit a CU for a patch of 720 (1 600 elements: corner forces 77 KB, shape coefficients 77 KB, nodal inputs 58 KB,
+// M_UM / M_UT 23 KB ...), but the register file of a CU is 512 KB: here an element's stress, damage AND its six frozen shape coefficients (Q4) stay
+// in registers (20 per element), the running M_UM / M_UT of the own nodes too (8 per node); LDS holds only what crosses threads -- the staged
+// velocities, the corner forces, the first eight fan entries of every own node; the element constants (48 B) and the nodal inputs (80 B) are
+// re-read from L2 every sub-step, the loads issued ahead of the barrier they wait behind.  The exchange between patches (and, HALO, between
+// ranks through the mailboxes) is k_substep_resident's, statement for statement; so are the operations and their order: bit-identical to one
+// launch per sub-step (tests/test_gpu_parity.py::test_resident_sub_step_loop_does_not_change_a_bit).
+#define NXS_RESB_EPT 4
+#define NXS_RESB_NPT 2
+template <bool POW4, bool HALO>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_substep_resident_big(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
+                                                        const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
+                                                        const HaloFused *__restrict__ hfp, int n_boundary) {
+    constexpr int T = 512, EPT = NXS_RESB_EPT, NPT = NXS_RESB_NPT;
+    const DevParams &p0 = *pdev;
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int Mmax = pp.Mmax, Emax = pp.Emax, Pmax = pp.Pmax;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*d2 [3][Emax] + 1*/;
+    d2 *lF2 = reinterpret_cast<d2 *>(lF);
+    uint4 *lFan4 = reinterpret_cast<uint4 *>(lF + 6 * (size_t)Emax + 2);  // [Pmax] the first eight fan entries of every own node as indices into lF2 (16 bits each)
+    int4 *lH = reinterpret_cast<int4 *>(lFan4 + Pmax);                    // HALO: [Mmax] halo slot i - nO: {node, -1, -, -} or, a ghost, {offset of u in a mailbox half, distance to v, ghost number, -}
+    const unsigned ZIDX = 3u * (unsigned)Emax;
+    __shared__ int lerr;
+    auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
+        const int q = n >> 3, rr = n & 7, x = pos & 7;
+        return (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (pos >> 3);
+    };
+    int blk = blockIdx.x;
+    bool boundary = false;
+    unsigned long long x0 = 0ull;
+    if (HALO) {
+        boundary = blk < n_boundary;
+        if (boundary) {
+            const unsigned long long xv = *hfp->ipc.seq_push;
+            x0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(xv & 0xffffffffull));
+        }
+        blk = boundary ? xcd_remap(blk, n_boundary) : n_boundary + xcd_remap(blk - n_boundary, (int)gridDim.x - n_boundary);
+    } else {
+        blk = xcd_remap(blk, (int)gridDim.x);
+    }
+    const int t = threadIdx.x, Nn = m.Nn, S = p0.substeps;
+    const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk], nNb = r.pnbr_cnt[blk];
+    const int *pn = pp.pnodes + (size_t)blk * Mmax;
+    const bool bbm = p0.dynamics_type == NXS_DYN_BBM;
+    if (t == 0) { lerr = 0; lF2[ZIDX] = d2{0., 0.}; }
+
+    // ---- once per step: velocities and frozen coordinates of the staged nodes, this thread's elements, this thread's nodes
+    double *sx = lF, *sy = lF + Mmax;  // (scratch: the corner forces are not needed yet; 2 Mmax <= 6 Emax)
+    for (int i = t; i < nM; i += T) {
+        const int g = pn[i];
+        lu[i] = s.VT[g]; lv[i] = s.VT[g + Nn];
+        const d2 c = reinterpret_cast<const d2 *>(w.xy)[g];
+        sx[i] = c.x; sy[i] = c.y;
+    }
+    int e[EPT];
+    unsigned trp[EPT];            // the three corner slots, ten bits each (Mmax <= 1024)
+    unsigned eflags = 0u;         // per element j: bit j has an element, bit 8 + j writer, bit 16 + j skip
+    double sig[EPT][3], damage[EPT], dxN[EPT][6];
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {
+        const int l = t + T * j;
+        e[j] = 0; trp[j] = 0u;
+        sig[j][0] = sig[j][1] = sig[j][2] = 0.; damage[j] = 0.;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dxN[j][k] = 0.;
+        if (l < nE) {
+            const int eraw = pp.pelem[(size_t)blk * Emax + l];
+            const ushort4 tr = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + l];
+            trp[j] = (unsigned)tr.x | ((unsigned)tr.y << 10) | ((unsigned)tr.z << 20);
+            const bool writer = eraw >= 0;
+            e[j] = writer ? eraw : ~eraw;
+            const d2 *S4 = reinterpret_cast<const d2 *>(Sc) + 2 * (size_t)e[j];
+            const d2 a = S4[0], c2 = S4[1];
+            sig[j][0] = a.x; sig[j][1] = a.y; sig[j][2] = c2.x; damage[j] = c2.y;
+            const long long pk = __double_as_longlong(w.erec[6 * (size_t)e[j] + 5]);
+            const bool skip = bbm ? (int)(pk & 0xffffffffll) < 0 : (pk >> 32) != 0;
+            eflags |= (1u << j) | (writer ? (1u << (8 + j)) : 0u) | (skip ? (1u << (16 + j)) : 0u);
+        }
+    }
+    int n[NPT];
+    unsigned nfl = 0u;            // per node i: bits 8 i .. 8 i + 7 the node flags, bit 24 + i has a node
+    double um[NPT][4];            // the running M_UM (u, v) and M_UT (u, v) of the own nodes
+    unsigned sinfo[NPT];          // HALO: where the own node is sent (see k_substep_resident)
+    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
+#pragma unroll
+    for (int i = 0; i < NPT; ++i) {
+        const int sl = t + T * i;
+        n[i] = 0; sinfo[i] = 0u;
+        um[i][0] = um[i][1] = um[i][2] = um[i][3] = 0.;
+        if (sl < nO) {
+            n[i] = pn[sl];
+            nfl |= ((unsigned)m.nflags[n[i]] << (8 * i)) | (1u << (24 + i));
+            unsigned idx[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const unsigned ent = (k < pp.Wp) ? pf[(size_t)k * Pmax + sl] : 0xFFFFu;
+                idx[k] = (ent == 0xFFFFu || (ent & 4u)) ? ZIDX : (ent & 3u) * (unsigned)Emax + (ent >> 3);  // pad, or ghostNodes[i] (FE.cpp:10456)
+            }
+            lFan4[sl] = make_uint4(idx[0] | (idx[1] << 16), idx[2] | (idx[3] << 16), idx[4] | (idx[5] << 16), idx[6] | (idx[7] << 16));
+            um[i][0] = s.UM[n[i]]; um[i][1] = s.UM[n[i] + Nn]; um[i][2] = s.UT[n[i]]; um[i][3] = s.UT[n[i] + Nn];
+            if (HALO && boundary) {
+                const int sq0 = hfp->send_ptr[n[i]], sq1 = hfp->send_ptr[n[i] + 1];
+                if (sq1 - sq0 == 1) sinfo[i] = 0x80000000u | ((unsigned)hfp->send_k[sq0] << 26) | (unsigned)hfp->send_pos[sq0];
+                else if (sq1 > sq0) sinfo[i] = 0xC0000000u;
+            }
+        }
+    }
+    int nbr = -1;
+    if (t < nNb) nbr = r.pnbr[(size_t)blk * NXS_RES_NBR + t];
+    if (HALO) {
+        for (int i = nO + t; i < nM; i += T) {
+            const int g = pn[i];
+            lH[i - nO] = (g >= m.No) ? make_int4(hfp->ghost_off[g - m.No], hfp->ghost_srl[g - m.No], g - m.No, 0) : make_int4(g, -1, 0, 0);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < EPT; ++j) {  // shapeCoeff (FE.cpp:1951-1964): frozen over the sub-steps (Q4), built once, the same quotients as k_prep_elements
+        if (eflags & (1u << j)) {
+            const unsigned a = trp[j] & 1023u, b = (trp[j] >> 10) & 1023u, c = (trp[j] >> 20) & 1023u;
+            const double vx[3] = {sx[a], sx[b], sx[c]};
+            const double vy[3] = {sy[a], sy[b], sy[c]};
+            const double jac = jacobian(vx, vy);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+                dxN[j][k] = (vy[kp1] - vy[kp2]) / jac;
+                dxN[j][k + 3] = (vx[kp2] - vx[kp1]) / jac;
+            }
+        }
+    }
+    __syncthreads();  // (sx / sy are read; lF may be written from here on)
+
+    for (int ss = 0; ss < S; ++ss) {
+        // the parameters are re-read where they are used (scalar loads that hit the constant cache), not held across the loop
+        const DevParams *pl = pdev;
+        asm volatile("" : "+s"(pl));
+        const DevParams &p = *pl;
+        // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467)
+#pragma unroll
+        for (int j = 0; j < EPT; ++j) {
+            if (!(eflags & (1u << j))) continue;
+            const int l = t + T * j;
+            double c_expC, volume, c_pmax, c_heal, c_coh, c_dxs = 1.;
+            {   // the element constants: one 48-byte record, re-read every sub-step (it stays in the L2)
+                const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e[j];
+                const d2 r0 = q[0], r1 = q[1], r2 = q[2];
+                c_expC = r0.x; volume = r0.y; c_pmax = r1.x; c_heal = r1.y; c_coh = r2.x;
+                const int dxi = (int)(__double_as_longlong(r2.y) & 0xffffffffll);
+                if (bbm) c_dxs = (double)(dxi < 0 ? ~dxi : dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
+            }
+            if (eflags & (1u << (16 + j))) {
+                sig[j][0] = sig[j][1] = sig[j][2] = 0.;
+                damage[j] = 0.;
+            } else {
+                const unsigned a = trp[j] & 1023u, b = (trp[j] >> 10) & 1023u, c = (trp[j] >> 20) & 1023u;
+                const double u[3] = {lu[a], lu[b], lu[c]};
+                const double v[3] = {lv[a], lv[b], lv[c]};
+                if (bbm) bbm_stress<POW4>(p, dxN[j], u, v, sig[j], damage[j], c_expC, c_pmax, c_heal, c_dxs, c_coh);
+                else vp_stress(p, dxN[j], u, v, sig[j], c_expC);
+            }
+            double F[6];
+            corner_forces(volume, sig[j], dxN[j], F);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) lF2[(size_t)k * Emax + l] = d2{F[k], F[k + 3]};
+        }
+        // the nodal inputs of this thread's own nodes (80-byte records, from the L2): issued ahead of the barrier
+        d2 nr[NPT][5];
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) nr[i][k] = d2{0., 0.};
+            if (nfl & (1u << (24 + i))) {
+                const d2 *q = reinterpret_cast<const d2 *>(w.nrec) + 5 * (size_t)n[i];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) nr[i][k] = q[k];
+            }
+        }
+        __syncthreads();
+        const DevParams *pq = pdev;
+        asm volatile("" : "+s"(pq));
+        const DevParams &q = *pq;
+        // ---- node phase (FE.cpp:10445-10553): fan gather in ascending element order, 2x2 solve, mesh move, publish
+#pragma unroll
+        for (int i = 0; i < NPT; ++i) {
+            if (!(nfl & (1u << (24 + i)))) continue;
+            const int sl = t + T * i;
+            const unsigned nf = (nfl >> (8 * i)) & 0xFFu;
+            double uice = lu[sl], vice = lv[sl];
+            const double node_mass = nr[i][0].x;
+            if (!((nf & NF_DIRICHLET) || node_mass == 0.)) {
+                double gx = nr[i][0].y, gy = nr[i][1].x;
+                {
+                    const uint4 fw = lFan4[sl];
+                    const unsigned w4[4] = {fw.x, fw.y, fw.z, fw.w};
+                    d2 f[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) f[k] = lF2[(w4[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) { gx -= f[k].x; gy -= f[k].y; }
+                }
+                for (int k = 8; k < pp.Wp; ++k) {  // (fans of more than eight elements: the most irregular vertices)
+                    const unsigned ent = pf[(size_t)k * Pmax + sl];
+                    if (ent == 0xFFFFu) break;
+                    if (ent & 4u) continue;
+                    const d2 f = lF2[(ent & 3u) * (unsigned)Emax + (ent >> 3)];
+                    gx -= f.x; gy -= f.y;
+                }
+                nodal_solve(q, gx, gy, uice, vice, node_mass, nr[i][1].y, nr[i][2].x, nr[i][2].y, (nf & NF_LAT_NEG) ? -1. : 1., nr[i][3].x, nr[i][3].y, nr[i][4].x, nr[i][4].y, 0., 0.);
+            }
+            lu[sl] = uice; lv[sl] = vice;
+            if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)
+                if (!(nf & NF_NEUMANN)) { um[i][0] += move_dt * uice; um[i][1] += move_dt * vice; }
+                um[i][2] += move_dt * uice; um[i][3] += move_dt * vice;
+            }
+            if (ss == S - 1) { s.VT[n[i]] = uice; s.VT[n[i] + Nn] = vice; }
+            else {
+                double *X = (ss & 1) ? r.X1 : r.X0;
+                st_agent(X + n[i], uice); st_agent(X + n[i] + Nn, vice);
+            }
+            if (HALO && (sinfo[i] & 0x80000000u)) {  // updateGhosts, sending side: straight into the neighbour ranks' mailboxes (as k_substep_fused)
+                const int sq0 = hfp->send_ptr[n[i]], sq1 = hfp->send_ptr[n[i] + 1];
+                for (int qq = sq0; qq < sq1; ++qq) {
+                    const int k = hfp->send_k[qq];
+                    double *dst = hfp->ipc.peer_seg[k] + ((x0 + (unsigned long long)ss) & 1ull) * hfp->ipc.peer_parity_stride[k] + hfp->send_pos[qq];
+                    sys_store(dst, uice);
+                    sys_store(dst + (hfp->send_off[k + 1] - hfp->send_off[k]), vice);
+                }
+            }
+        }
+        if (!HALO && ss == S - 1) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave's stores have left; the corner forces have been read
+        if (ss < S - 1 && t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (HALO && boundary && t == 0) {  // the last boundary patch to finish this sub-step publishes it to the neighbour ranks, in sub-step order
+            if (atomicAdd(r.cnt + ss, 1u) == (unsigned)n_boundary - 1u) {
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ss) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                for (int k = 0; k < hfp->ipc.ns; ++k)
+                    __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (ss == S - 1) *hfp->ipc.seq_push = x0 + (unsigned long long)S;
+                __hip_atomic_store(r.raised, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (ss == S - 1) break;
+        if (HALO && boundary && t >= 64 && t < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
+            const int k = t - 64;
+            const long long t0 = wall_clock64();
+            while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x0 + (unsigned long long)ss + 1ull) {
+                __builtin_amdgcn_s_sleep(2);
+                if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
+                if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 7); break; }
+            }
+        }
+        if (nbr >= 0) {
+            const long long t0 = wall_clock64();  // 100 MHz
+            while (__hip_atomic_load(r.flag + 32 * (size_t)nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
+                __builtin_amdgcn_s_sleep(1);
+                if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
+                if (wall_clock64() - t0 > 1200000000ll) { lerr = 1; atomicExch(r.error, 5); break; }
+            }
+        }
+        __syncthreads();
+        if (lerr) break;
+        {   // the halo nodes' new velocities, past the caches
+            const double *X = (ss & 1) ? r.X1 : r.X0;
+            if (HALO) {
+                const double *mb = hfp->ipc.mailbox + ((x0 + (unsigned long long)ss) & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr;
+                double *gr = r.gring + (size_t)ss * 2 * (size_t)r.NG;
+                for (int i = nO + t; i < nM; i += T) {
+                    const int4 hv = lH[i - nO];
+                    if (hv.y >= 0) {
+                        const double gu = sys_load(mb + hv.x), gv = sys_load(mb + hv.x + hv.y);
+                        lu[i] = gu; lv[i] = gv;
+                        if (move_dt != 0.) { gr[hv.z] = gu; gr[r.NG + hv.z] = gv; }
+                    } else {
+                        lu[i] = ld_agent(X + hv.x); lv[i] = ld_agent(X + hv.x + Nn);
+                    }
+                }
+            } else {
+                for (int i = nO + t; i < nM; i += T) {
+                    const int g = pn[i];
+                    lu[i] = ld_agent(X + g); lv[i] = ld_agent(X + g + Nn);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- once per step: the element state and the moved mesh go back -- unless a wait timed out (see k_substep_resident)
+    __syncthreads();
+    if (lerr) return;
+#pragma unroll
+    for (int j = 0; j < EPT; ++j)
+        if ((eflags & (1u << j)) && (eflags & (1u << (8 + j)))) {
+            d2 *S4 = reinterpret_cast<d2 *>(Sn) + 2 * (size_t)e[j];
+            S4[0] = d2{sig[j][0], sig[j][1]}; S4[1] = d2{sig[j][2], damage[j]};
+        }
+    if (move_dt != 0.) {
+#pragma unroll
+        for (int i = 0; i < NPT; ++i)
+            if (nfl & (1u << (24 + i))) {
+                const unsigned nf = (nfl >> (8 * i)) & 0xFFu;
+                if (!(nf & NF_NEUMANN)) { s.UM[n[i]] = um[i][0]; s.UM[n[i] + Nn] = um[i][1]; }
+                s.UT[n[i]] = um[i][2]; s.UT[n[i] + Nn] = um[i][3];
+            }
+    }
+}
+
 // The ghost nodes' mesh moves of a resident launch (FE.cpp:10543-10550): M_UM += dte * M_VT, M_UT += dte * M_VT with the velocity that arrived after
 // each of the first `count` sub-steps, in sub-step order -- the additions the reference makes, from the ring the launch filled (the move of the
 // last sub-step follows in k_halo_pull, with the last exchange).

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstddef>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -19,7 +20,9 @@
 #define NXS_CUT_T256_MAXP 128     // NXS_T256_MAXP: patches of up to this many own nodes run in 256-thread workgroups
 #define NXS_CUT_RES_NBR 24        // NXS_RES_NBR: neighbour patches a resident patch can wait for
 #define NXS_CUT_RES_MAXNB 16      // NXS_RES_MAXNB: neighbour ranks of the several-rank resident kernel
-#define NXS_CUT_RES_EPT 1         // elements per thread the resident kernel holds (512 threads: patches of up to 512 elements)
+#define NXS_CUT_RES_EPT 1         // elements per thread k_substep_resident holds (512 threads: patches of up to 512 elements, two workgroups per CU)
+#define NXS_CUT_RESB_EPT 4        // NXS_RESB_EPT / NXS_RESB_NPT: elements / own nodes per thread of k_substep_resident_big (one workgroup per CU:
+#define NXS_CUT_RESB_NPT 2        //   patches of up to 2048 elements and 1024 own nodes, corner slots in ten bits: at most 1024 staged nodes)
 
 namespace nxs_cut {
 
@@ -60,7 +63,7 @@ inline void node_fans(const std::vector<int> t[3], int Nn, int Ne, std::vector<i
 // elements per thread; a partition whose own nodes are not contiguous along the numbering -- an RCB part of a Hilbert-numbered mesh --
 // otherwise has a few patches of two distant blobs with 1.5 times the elements of the others, and the whole round waits for them).
 inline bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int No, int P,
-                                     const std::vector<int> &order, HostPatches &out, int Ecap = 0) {
+                                     const std::vector<int> &order, HostPatches &out, int Ecap = 0, int Mcap = 0) {
     if (P < 1 || No < 0 || No > Nn || (int)order.size() < No) return false;
     std::vector<int> off, adj;
     node_fans(t, Nn, Ne, off, adj);
@@ -69,20 +72,43 @@ inline bool build_patches_from_order(const std::vector<int> t[3], const unsigned
     if (Ecap <= 0) {
         for (int a = 0; a < No; a += P) pstart.push_back(a);
     } else {
-        std::vector<int> seen(Ne, -1);
-        int cnt_n = 0, cnt_e = 0, q = 0;
+        // Mcap > 0: ... or past Mcap staged nodes (own + halo; the large-patch resident kernel names a corner's slot in ten bits)
+        std::vector<int> seen(Ne, -1), seen_n, trial_n;
+        if (Mcap > 0) { seen_n.assign(Nn, -1); trial_n.assign(Nn, -1); }
+        int cnt_n = 0, cnt_e = 0, cnt_m = 0, q = 0, stamp = 0;
+        auto fresh_nodes = [&](int n) {  // nodes the elements of n that are new to patch q would add to its staged nodes
+            if (Mcap <= 0) return 0;
+            ++stamp;
+            int c = 0;
+            for (int j = off[n]; j < off[n + 1]; ++j) {
+                const int e = adj[j];
+                if (seen[e] == q) continue;
+                for (int k = 0; k < 3; ++k) {
+                    const int v = t[k][e];
+                    if (seen_n[v] != q && trial_n[v] != stamp) { trial_n[v] = stamp; ++c; }
+                }
+            }
+            return c;
+        };
         if (No > 0) pstart.push_back(0);
         for (int i = 0; i < No; ++i) {
             const int n = order[i];
             int fresh = 0;
             for (int j = off[n]; j < off[n + 1]; ++j) fresh += seen[adj[j]] != q ? 1 : 0;
-            if (cnt_n > 0 && (cnt_n == P || cnt_e + fresh > Ecap)) {  // close the patch before this node
+            int fresh_m = fresh_nodes(n);
+            if (cnt_n > 0 && (cnt_n == P || cnt_e + fresh > Ecap || (Mcap > 0 && cnt_m + fresh_m > Mcap))) {  // close the patch before this node
                 pstart.push_back(i);
-                ++q; cnt_n = 0; cnt_e = 0;
+                ++q; cnt_n = 0; cnt_e = 0; cnt_m = 0;
                 fresh = off[n + 1] - off[n];
+                fresh_m = fresh_nodes(n);
             }
-            for (int j = off[n]; j < off[n + 1]; ++j) if (seen[adj[j]] != q) { seen[adj[j]] = q; }
-            ++cnt_n; cnt_e += fresh;
+            for (int j = off[n]; j < off[n + 1]; ++j) {
+                const int e = adj[j];
+                if (seen[e] == q) continue;
+                seen[e] = q;
+                if (Mcap > 0) for (int k = 0; k < 3; ++k) seen_n[t[k][e]] = q;
+            }
+            ++cnt_n; cnt_e += fresh; cnt_m += fresh_m;
         }
     }
     const int nNodePatches = (int)pstart.size();
@@ -229,17 +255,17 @@ inline void hilbert_order(const double *x0, const double *y0, int n_nodes, std::
 }
 
 inline bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
-                          int No, int P, HostPatches &out, int Ecap = 0) {
+                          int No, int P, HostPatches &out, int Ecap = 0, int Mcap = 0) {
     // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
     std::vector<int> order(No);
     for (int i = 0; i < No; ++i) order[i] = i;
-    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out, Ecap);
+    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out, Ecap, Mcap);
     if (ok && out.avg_elems_per_own_node <= 3.0) return true;
     // numbering without locality: cut patches along a Hilbert curve through the node coordinates
     // (consecutive runs of a Hilbert curve are compact blobs: small halos)
     hilbert_order(x0, y0, No, order);
     HostPatches alt;
-    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt, Ecap) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
+    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt, Ecap, Mcap) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
         out = std::move(alt);
         out.used_hilbert = true;
         return true;
@@ -348,27 +374,39 @@ struct PatchPlan {
     HostPatches hp;
     int P = 0;
     size_t fused_lds = 0;  // staged nodes, corner forces + their pair of zeros
+    bool cut_big = false;  // cut for k_substep_resident_big (one large patch per CU): not what the one-launch-per-sub-step kernel wants
 };
 
 inline size_t fused_lds_of(const HostPatches &hp) { return (4 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax + 2) * sizeof(double); }
+// LDS of k_substep_resident (velocities, corner forces + zeros, shape coefficients, nodal inputs, M_UM / M_UT, eight fan entries per own node;
+// several ranks: + the halo slots' sources and the neighbour ranks' mailbox addresses) and of k_substep_resident_big (velocities, corner forces,
+// fan entries; several ranks: + the halo slots' sources)
+inline size_t resident_lds_of(const HostPatches &hp, bool multi_rank) {
+    return (2 * (size_t)hp.Mmax + 12 * (size_t)hp.Emax + 14 * (size_t)hp.Pmax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax +
+           (multi_rank ? 16 * (size_t)std::min(hp.Mmax, 512) + 20 * (size_t)NXS_CUT_RES_MAXNB : 0);
+}
+inline size_t resident_big_lds_of(const HostPatches &hp, bool multi_rank) {
+    return (2 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax + (multi_rank ? 16 * (size_t)hp.Mmax : 0);
+}
+inline bool resident_is_big(const HostPatches &hp) { return hp.Emax > 512 * NXS_CUT_RES_EPT || hp.Pmax > 512; }
 
 // patch_nodes > 0: the caller's size (shrunk until it fits); else automatic.  want_resident: option fused = 4 was set before set_mesh (the mesh is
 // then cut for ONE round of resident 512-thread workgroups where that is possible), res_ept: elements per thread the resident kernel holds.
 // cus: compute units of the device.  Returns "" or the reason it failed.
-inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_resident, int cus, PatchPlan &out, int res_ept = NXS_CUT_RES_EPT) {
+inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_resident, int cus, PatchPlan &out, int res_ept = NXS_CUT_RES_EPT, bool allow_big = true) {
     char msg[160];
     HostPatches &hp = out.hp;
     int P = 0;
     out.fused_lds = 0;
-    auto build = [&](int PP) -> bool {
-        // patches of up to ~200 nodes hold one element per thread of a 512-thread workgroup (the first resident loop required it, and one round
-        // of the one-launch-per-sub-step kernel is as slow as its largest patch): none may exceed 480 elements; patches of up to ~420 nodes
-        // (the resident loop with two elements per thread: a rank of four of the 2 km mesh) none 960
-        const int Ecap = (PP > NXS_CUT_T256_MAXP && PP <= 208) ? 480 : (want_resident && res_ept >= 2 && PP > 208 && PP <= 420) ? 960 : 0;
-        if (!build_patches(m.t, m.ghost3, m.x0, m.y0, m.Nn, m.Ne, m.No, PP, hp, Ecap)) return false;
+    auto build = [&](int PP, int Ecap_big = 0) -> bool {
+        // patches of up to ~200 nodes hold one element per thread of a 512-thread workgroup (k_substep_resident requires it, and one round
+        // of the one-launch-per-sub-step kernel is as slow as its largest patch): none may exceed 480 elements
+        const int Ecap = Ecap_big > 0 ? Ecap_big : (PP > NXS_CUT_T256_MAXP && PP <= 208) ? 480 : 0;
+        if (!build_patches(m.t, m.ghost3, m.x0, m.y0, m.Nn, m.Ne, m.No, PP, hp, Ecap, Ecap_big > 0 ? 1000 : 0)) return false;
         out.fused_lds = fused_lds_of(hp);
         return true;
     };
+    out.cut_big = false;
     cus = std::max(cus, 1);
     if (patch_nodes > 0) {
         P = std::max(64, std::min(patch_nodes, 1024));
@@ -394,10 +432,23 @@ inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_re
             int Pr = (int)(((long long)m.No + 2 * cus - 1) / (2 * cus));
             if (Pr < 100) Pr = (int)(((long long)m.No + cus - 1) / cus);
             Pr = std::max(32, (Pr + 3) & ~3);
-            for (int it = 0; it < 4 && Pr <= (res_ept >= 2 ? 420 : 208) && !done; ++it, Pr += 4) {  // orphan patches (multi-rank) may add a few workgroups
+            for (int it = 0; it < 4 && Pr <= 208 && !done; ++it, Pr += 4) {  // orphan patches (multi-rank) may add a few workgroups
                 if (!build(Pr)) break;
                 done = hp.Emax <= 512 * res_ept && hp.nP <= 2 * cus && out.fused_lds <= 80 * 1024;
                 if (done) P = Pr;
+            }
+            // too large for that: ONE workgroup per CU with four elements and two own nodes per thread (k_substep_resident_big: the partition a
+            // rank of four of the 2 km mesh holds -- 256 patches of ~720 nodes / ~1 600 elements)
+            if (!done && allow_big) {
+                int Pb = (int)(((long long)m.No + cus - 1) / cus);
+                Pb = std::max(256, (Pb + 3) & ~3);
+                for (int it = 0; it < 8 && Pb <= 512 * NXS_CUT_RESB_NPT && !done; ++it, Pb += 8) {  // orphan patches and patches closed early add a few workgroups
+                    if (!build(Pb, 512 * NXS_CUT_RESB_EPT - 64)) break;
+                    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] large-patch cut: P=%d -> nP=%d Pmax=%d Emax=%d Mmax=%d lds=%zu\n", Pb, hp.nP, hp.Pmax, hp.Emax, hp.Mmax, resident_big_lds_of(hp, m.No < m.Nn));
+                    done = hp.Emax <= 512 * NXS_CUT_RESB_EPT && hp.Pmax <= 512 * NXS_CUT_RESB_NPT && hp.Mmax <= 1024 && hp.nP <= cus &&
+                           resident_big_lds_of(hp, m.No < m.Nn) <= 160 * 1024 && out.fused_lds <= 160 * 1024;
+                    if (done) { P = Pb; out.cut_big = true; }
+                }
             }
         }
         for (int k = 1; k <= 64 && !done; ++k) {
@@ -672,15 +723,17 @@ struct ResidentPlan {
     double early_fraction = 0.;
 };
 
-inline void plan_resident(const HostPatches &hp, int Nn, int No, bool multi_rank, int n_send_procs, bool overlap, ResidentPlan &out, int res_ept = NXS_CUT_RES_EPT) {
+inline void plan_resident(const HostPatches &hp, int Nn, int No, bool multi_rank, int n_send_procs, bool overlap, ResidentPlan &out) {
     out = ResidentPlan{};
     const int nP = hp.nP;
     char msg[160];
     auto refuse = [&](const char *w) { out.ok = false; out.why = w; };
-    if (hp.Emax > 512 * res_ept || hp.Pmax > 512) {
-        snprintf(msg, sizeof msg, "a patch holds %d elements / %d own nodes (at most %d / 512)", hp.Emax, hp.Pmax, 512 * res_ept);
+    const bool big = resident_is_big(hp);
+    if (hp.Emax > 512 * NXS_CUT_RESB_EPT || hp.Pmax > 512 * NXS_CUT_RESB_NPT || (big && hp.Mmax > 1024)) {
+        snprintf(msg, sizeof msg, "a patch holds %d elements / %d own nodes / %d staged nodes (at most %d / %d / 1024)", hp.Emax, hp.Pmax, hp.Mmax, 512 * NXS_CUT_RESB_EPT, 512 * NXS_CUT_RESB_NPT);
         return refuse(msg);
     }
+    if (big && overlap) return refuse("the overlap variant exists for patches of one element per thread only");
     std::vector<int> owner(Nn, -1);
     for (int q = 0; q < nP; ++q)
         for (int i = 0; i < hp.own_cnt[q]; ++i) owner[hp.pnodes[(size_t)q * hp.Mmax + i]] = q;

@@ -141,15 +141,15 @@ int caught(char *msg, int cap) {
 
 extern "C" {
 
-// One rank's mesh through everything nxs_dyn_set_mesh / set_halo / the first step build on the host.  stats (int64[16]): nP, Pmax, Emax,
-// Mmax, Wp, used_hilbert, fused_lds, P, resident ok, resident max neighbours, n_boundary, reordered, multi nP, multi EDmax, smoother nP, smoother NDmax.
+// One rank's mesh through everything nxs_dyn_set_mesh / set_halo / the first step build on the host.  stats (int64[20]): nP, Pmax, Emax,
+// Mmax, Wp, used_hilbert, fused_lds, P, resident ok, resident max neighbours, n_boundary, reordered, multi nP, multi EDmax, smoother nP, smoother NDmax, cut for the large-patch resident kernel.
 // Returns 0, 1 (a check failed: msg says which) or an NXS_ERR_* of the guard (an exception: msg says which).
 int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const double *y, int Nn, int Ne, int No, int patch_nodes,
            int want_resident, int cus, int res_ept, int ns, const int32_t *send_offsets, const int32_t *send_index, int nr,
            const int32_t *recv_offsets, const int32_t *recv_index, int overlap, const int32_t *n2n /*[W2][Nn] or NULL*/, const int32_t *n2n_cnt,
            int W2, int depth_multi, int depth_smooth, int64_t *stats, char *msg, int msg_cap) try {
     put_msg(msg, msg_cap, "");
-    for (int i = 0; i < 16; ++i) stats[i] = 0;
+    for (int i = 0; i < 20; ++i) stats[i] = 0;
     const Mesh m = make_mesh(indices, ghost3, x, y, Nn, Ne, No);
     PatchPlan plan;
     const std::string why = plan_patches(m.view(), patch_nodes, want_resident != 0, cus, plan, res_ept);
@@ -160,7 +160,7 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     std::vector<int> pet;
     pack_pet(hp, pet);
     REQUIRE(pet.size() == 2 * (size_t)hp.nP * hp.Emax, "pet size");
-    stats[0] = hp.nP; stats[1] = hp.Pmax; stats[2] = hp.Emax; stats[3] = hp.Mmax; stats[4] = hp.Wp; stats[5] = hp.used_hilbert; stats[6] = (int64_t)plan.fused_lds; stats[7] = plan.P;
+    stats[16] = plan.cut_big; stats[0] = hp.nP; stats[1] = hp.Pmax; stats[2] = hp.Emax; stats[3] = hp.Mmax; stats[4] = hp.Wp; stats[5] = hp.used_hilbert; stats[6] = (int64_t)plan.fused_lds; stats[7] = plan.P;
     const bool mr = ns > 0 || nr > 0 || No < Nn;
     if (mr) {
         const std::vector<int> so(send_offsets, send_offsets + ns + 1), ro(recv_offsets, recv_offsets + nr + 1);
@@ -196,14 +196,14 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     }
     {
         ResidentPlan rp;
-        plan_resident(hp, Nn, No, mr, ns, overlap != 0 && mr, rp, res_ept);
+        plan_resident(hp, Nn, No, mr, ns, overlap != 0 && mr && !resident_is_big(hp), rp);
         stats[8] = rp.ok; stats[9] = rp.max_nbr;
         if (rp.ok) {
             for (int q = 0; q < hp.nP; ++q) {
                 REQUIRE(rp.cnt[q] >= 0 && rp.cnt[q] <= NXS_CUT_RES_NBR, "patch %d waits for %d patches", q, rp.cnt[q]);
                 for (int k = 0; k < rp.cnt[q]; ++k) { const int o = rp.nbr[(size_t)q * NXS_CUT_RES_NBR + k]; REQUIRE(o >= 0 && o < hp.nP && o != q, "patch %d neighbour %d", q, o); }
             }
-            if (overlap && mr) {  // the overlap variant's lists are a permutation of the patch's with interior elements first
+            if (overlap && mr && !resident_is_big(hp)) {  // the overlap variant's lists are a permutation of the patch's with interior elements first
                 HostPatches alt = hp;
                 alt.pelem = rp.rpelem; alt.ptri = rp.rptri; alt.pfan = rp.rpfan;
                 for (int q = 0; q < hp.nP; ++q) {

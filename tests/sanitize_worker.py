@@ -159,14 +159,14 @@ def run_cut(lm, patch_nodes=0, want_resident=0, overlap=0, cus=256, res_ept=1, t
         _, nc_ = O.connectivity(lm.indices, lm.num_nodes)
         W2 = nc_.shape[1] - 1
         cnt = i32(nc_[:, -1]); n2n = i32(np.maximum(nc_[:, :W2].T - 1, 0))
-    stats = np.zeros(16, np.int64); msg = C.create_string_buffer(512)
+    stats = np.zeros(20, np.int64); msg = C.create_string_buffer(512)
     rc = cut.pc_run(_abi.iptr(idx), g3.ctypes.data_as(U8), _abi.dptr(x), _abi.dptr(y), lm.num_nodes, lm.num_elements, lm.local_ndof, patch_nodes,
                     want_resident, cus, res_ept, len(lm.send_procs), _abi.iptr(so), _abi.iptr(si) if si.size else None, len(lm.recv_procs), _abi.iptr(ro),
                     _abi.iptr(ri) if ri.size else None, overlap, _abi.iptr(n2n) if n2n is not None else None, _abi.iptr(cnt) if cnt is not None else None,
                     W2, depth_multi, depth_smooth, stats.ctypes.data_as(I64), msg, 512)
     assert rc == expect, (rc, msg.value.decode())
     return dict(zip(("nP", "Pmax", "Emax", "Mmax", "Wp", "hilbert", "lds", "P", "res_ok", "res_nbr", "n_boundary", "reordered", "m_nP", "m_EDmax",
-                     "s_nP", "s_NDmax"), stats.tolist()))
+                     "s_nP", "s_NDmax", "cut_big"), stats.tolist()))
 
 
 def shuffled(gm, seed):
@@ -182,7 +182,9 @@ def shuffled(gm, seed):
 #     caller's numbering (rejected: ~6 elements per own node), then the Hilbert curve through the coordinates
 big = M.localize(M.make_mesh("h9000"), 1)[0]
 r = run_cut(big, want_resident=1)
-assert r["res_ok"] == 0 and r["nP"] > 512, r                      # several rounds of patches: no resident loop, one kernel per sub-step
+assert r["nP"] > 512 and r["cut_big"] == 0, r   # 550 k triangles: several rounds of patches (the occupancy check then refuses the resident loop: one kernel per sub-step)
+r = run_cut(M.localize(M.make_mesh("h11000"), 1)[0], want_resident=1)
+assert r["res_ok"] == 1 and r["cut_big"] == 1 and r["nP"] <= 256 and r["Emax"] <= 2048 and r["Pmax"] <= 1024 and r["Mmax"] <= 1024, r   # 367 k: one large patch per CU
 sm = cases.global_mesh("small")
 r = run_cut(M.localize(shuffled(sm, 7), 1)[0], tables=True, depth_multi=4, depth_smooth=10)
 assert r["hilbert"] == 1 and r["Mmax"] <= 1024, r
@@ -214,7 +216,10 @@ for lm_r in M.localize(sm, 2):
 for kind in ("10km", "2km"):
     for lm_p in M.localize(M.make_mesh(kind), 8):
         r = run_cut(lm_p, want_resident=1)
-        assert r["res_ok"] == 1 and r["Emax"] <= 512 and r["nP"] <= 512, (kind, lm_p.rank, r)
+        assert r["res_ok"] == 1 and r["Emax"] <= 512 and r["nP"] <= 512 and r["cut_big"] == 0, (kind, lm_p.rank, r)
+for lm_p in M.localize(M.make_mesh("2km"), 4):     # ... and the four parts of a 4-GPU run: one large patch per CU (k_substep_resident_big)
+    r = run_cut(lm_p, want_resident=1)
+    assert r["res_ok"] == 1 and r["cut_big"] == 1 and r["nP"] <= 256, (lm_p.rank, r)
 # 4e. the Hilbert order on coordinates nobody should pass: NaN, infinities, one point, all equal, empty
 msg = C.create_string_buffer(256)
 for xs, ys in ((np.array([0., np.nan, 1., np.inf, -np.inf, 2.]), np.array([np.nan, 0., 1., 5., -5., np.inf])), (np.zeros(7), np.zeros(7)),
