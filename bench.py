@@ -471,26 +471,52 @@ def split_adapted_mesh(gm, frac, seed):
 
 
 def aux_regrid(gm, with_cpu=True):
-    """BASELINE config 5 at 2 km size: the two interpolation kernels of a regrid (FE.cpp:3071-3154) -- P1 interpolation of the 6
-    nodal variables onto the new mesh's nodes and the conservative remapping of 30 element variables onto its triangles --
-    with the real contrib/bamg routines (oracle/_ref, one host core, what the reference's root rank runs) timed beside them
-    and the results compared bit for bit."""
+    """BASELINE config 5 at 2 km size: the two interpolation calls of a regrid (FE.cpp:3071-3154) -- the conservative remapping of 30 element
+    variables onto the new mesh's triangles and the P1 interpolation of the 6 nodal variables onto its nodes -- through ONE regrid context
+    (nxs_regrid_*: the old mesh's bucket grid and connectivity tables built once, on the device; bamg's convex completion once, on the host),
+    (a) with the variables in host arrays, as the reference's root rank holds them, and (b) with the variables resident on the device, as
+    nxs_dyn holds them; the real contrib/bamg routines (oracle/_ref, one host core, what the reference's root rank runs) timed beside
+    them and the results compared bit for bit."""
+    import ctypes as C
     import numpy as np
-    from nextsim_amd.interp import ConservativeRemappingMeshToMesh, InterpFromMeshToMesh2dx
+    from nextsim_amd import dynamics
+    from nextsim_amd.interp import Regrid
     rng = np.random.default_rng(2)
     xn, yn, trin, prev = split_adapted_mesh(gm, 0.03, 9)
     idx_old = (gm.tri + 1).astype(np.int32).ravel()
     nodal = rng.standard_normal((gm.num_nodes, 6))
     elemental = rng.random((gm.num_elements, 30))
-    for _ in range(2):   # second call: warm allocator
-        t0 = time.perf_counter(); vi, ii = InterpFromMeshToMesh2dx(idx_old, gm.x, gm.y, nodal, xn, yn, False, 0.0, return_info=True); wi = time.perf_counter() - t0
-    for _ in range(2):
-        t0 = time.perf_counter(); vr, ir = ConservativeRemappingMeshToMesh(elemental, idx_old, gm.x, gm.y, trin + 1, xn, yn, prev, 0, return_info=True); wr = time.perf_counter() - t0
+    L = dynamics.load_library()
+    L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; L.hipFree.argtypes = [C.c_void_p]
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    for _ in range(2):   # second round: warm allocator
+        t0 = time.perf_counter(); rg = Regrid(idx_old, gm.x, gm.y); w_ctx = time.perf_counter() - t0
+        t0 = time.perf_counter(); vr, ir = rg.remap_elements(elemental, trin + 1, xn, yn, prev, 0, return_info=True); wr = time.perf_counter() - t0
+        t0 = time.perf_counter(); vi, ii = rg.interp_nodes(nodal, xn, yn, False, 0.0, return_info=True); wi = time.perf_counter() - t0
+        # (b) device-resident variables
+        bufs = [C.c_void_p() for _ in range(4)]
+        sizes = (elemental.nbytes, trin.shape[0] * 30 * 8, nodal.nbytes, xn.size * 6 * 8)
+        for bq, sz in zip(bufs, sizes):
+            assert L.hipMalloc(C.byref(bq), sz) == 0
+        L.hipMemcpy(bufs[0], elemental.ctypes.data, elemental.nbytes, 1); L.hipMemcpy(bufs[2], nodal.ctypes.data, nodal.nbytes, 1)
+        t0 = time.perf_counter(); _, ird = rg.remap_elements(None, trin + 1, xn, yn, prev, 0, in_device=(bufs[0].value, 30), out_device=bufs[1].value, return_info=True); wrd = time.perf_counter() - t0
+        t0 = time.perf_counter(); _, iid = rg.interp_nodes(None, xn, yn, False, 0.0, data_device=(bufs[2].value, gm.num_nodes, 6), out_device=bufs[3].value, return_info=True); wid = time.perf_counter() - t0
+        back_r = np.empty_like(vr); back_i = np.empty_like(vi)
+        L.hipMemcpy(back_r.ctypes.data, bufs[1], back_r.nbytes, 2); L.hipMemcpy(back_i.ctypes.data, bufs[3], back_i.nbytes, 2)
+        for bq in bufs:
+            L.hipFree(bq)
+        rg.close()
+    same_dev = bool(np.array_equal(back_r, vr, equal_nan=True) and np.array_equal(back_i, vi))
     out = {"workload": f"regrid of the 2 km mesh: {gm.num_elements} old triangles -> {trin.shape[0]} new ({100 * (ir['visits'] == 1).mean():.1f} % overlap a single old triangle), "
-                       f"6 nodal variables at {xn.size} nodes (isdefault=false as FE.cpp:3131) + conservative remap of 30 element variables",
-           "interp_kernel_ms": ii["kernel_ms"], "interp_call_ms": wi * 1e3, "remap_kernel_ms": ir["kernel_ms"], "remap_call_ms": wr * 1e3,
+                       f"conservative remap of 30 element variables + 6 nodal variables at {xn.size} nodes (isdefault=false as FE.cpp:3131), one regrid context for both",
+           "context_create_ms": w_ctx * 1e3,
+           "remap_kernel_ms": ir["kernel_ms"], "remap_call_ms": wr * 1e3, "remap_call_breakdown_ms": ir["timing"],
+           "interp_kernel_ms": ii["kernel_ms"], "interp_call_ms": wi * 1e3, "interp_call_breakdown_ms": ii["timing"],
+           "device_resident_variables": {"remap_call_ms": wrd * 1e3, "remap_breakdown_ms": ird["timing"], "interp_call_ms": wid * 1e3, "interp_breakdown_ms": iid["timing"],
+                                         "same_bits_as_host_arrays": same_dev},
            "remap_failed": int(ir["num_failed"]),
-           "note": "call = host tables (bucket grid, connectivity) + PCIe both ways + kernel; the reference runs both serially on its root rank"}
+           "note": "call = what is left on the host (index checks, integer plane, the convex completion for isdefault=false) + device-built tables (first call on the context) + "
+                   "PCIe both ways for host arrays + kernel; the second call on the context reuses the tables; the reference runs both serially on its root rank"}
     if with_cpu:
         try:
             from oracle import pyoracle as O

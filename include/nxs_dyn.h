@@ -169,6 +169,20 @@ typedef struct nxs_dyn_diag {
     double *D_del_ci_ridge_myi; /* [Ne] */
 } nxs_dyn_diag;
 
+/* updateIceDiagnostics() (FE.cpp:7860-7905), the element diagnostics checkOutputs() / exportResults() feed to the Moorings and the Exporter:
+ * totals over the ice categories, the principal stresses, the divergence of the velocity on the displaced mesh.  NULL = skip.
+ * (D_tsurf mixes thermodynamic variables -- M_tice, M_tsurf_young, M_sst -- that never cross this boundary: it stays with the host;
+ * D_dmean / D_dmax are 0 without OASIS, FE.cpp:7903-7904.) */
+typedef struct nxs_dyn_ice_diag {
+    double *D_conc;         /* [Ne] M_conc (+ M_conc_young with the young-ice category) */
+    double *D_thick;        /* [Ne] M_thick (+ M_h_young) */
+    double *D_snow_thick;   /* [Ne] M_snow_thick (+ M_hs_young) */
+    double *D_sigma0;       /* [Ne] (sigma11 + sigma22) / 2 */
+    double *D_sigma1;       /* [Ne] hypot((sigma11 - sigma22) / 2, sigma12) */
+    double *D_divergence;   /* [Ne] sum_j dxN_j u_j + dyN_j v_j with shapeCoeff on x0 + M_UM */
+} nxs_dyn_ice_diag;
+#define NXS_ICE_DIAG_FIELDS 6   /* order of the interleaved device rows: D_conc, D_thick, D_snow_thick, D_sigma0, D_sigma1, D_divergence */
+
 /* Per-phase device time of nxs_dyn_step, averaged over the steps since the last "timing_reset"
  * option (HIP events on the handle's stream; steps stay asynchronous), named after the reference's
  * Timer rows (FE.cpp:8197-8221, 10217-10642). Milliseconds per step. */
@@ -248,6 +262,10 @@ NXS_API int nxs_dyn_set_forcing(nxs_dyn_handle *h, const nxs_dyn_forcing *f);
 NXS_API int nxs_dyn_set_forcing_pair(nxs_dyn_handle *h, const nxs_dyn_forcing *f0, const nxs_dyn_forcing *f1);
 NXS_API int nxs_dyn_set_forcing_time(nxs_dyn_handle *h, double fcoeff0, double fcoeff1, const double factor[3], const double bias[3]);
 NXS_API int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *d);
+/* updateIceDiagnostics() on the device-resident state.  d (may be NULL): host arrays to fill.  device_rows (may be NULL): receives a DEVICE
+ * pointer to the same diagnostics as [Ne][NXS_ICE_DIAG_FIELDS] interleaved rows (library-owned, valid until the next call on this handle
+ * or nxs_dyn_set_mesh) -- the layout nxs_interp_mesh_to_grid_device samples, so a Moorings record needs no round trip of the state. */
+NXS_API int nxs_dyn_ice_diagnostics(nxs_dyn_handle *h, nxs_dyn_ice_diag *d, const double **device_rows);
 
 /* One dynamics step on the device-resident state: FE.cpp:8197-8214.  Asynchronous on the
  * handle's stream; nxs_dyn_synchronize() waits for it. */

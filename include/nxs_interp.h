@@ -63,6 +63,12 @@ NXS_INTERP_API int nxs_interp_mesh_to_grid(double *griddata, const int32_t *inde
                                            int32_t nods, int32_t nels, const double *data_mesh, int32_t data_length, int32_t N_data,
                                            double xmin, double ymax, double xposting, double yposting, int32_t nrows,
                                            int32_t ncols, double default_value, int32_t device, double *kernel_ms);
+/* The same with the mesh data already on `device` (a device pointer to [data_length][N_data] rows, e.g. what nxs_dyn_ice_diagnostics returns):
+ * a Moorings record without a round trip of the element state through the host. */
+NXS_INTERP_API int nxs_interp_mesh_to_grid_device(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
+                                           int32_t nods, int32_t nels, const double *data_mesh_device, int32_t data_length, int32_t N_data,
+                                           double xmin, double ymax, double xposting, double yposting, int32_t nrows,
+                                           int32_t ncols, double default_value, int32_t device, double *kernel_ms);
 
 /* Conservative remapping of the element variables at regrid: replaces the root-serial
  *
@@ -128,6 +134,29 @@ NXS_INTERP_API int nxs_mesh_convex_completion(const int32_t *index, const double
                                               int32_t *hull_edges, int32_t cap_hull);
 
 NXS_INTERP_API const char *nxs_interp_last_error(void);
+
+/* ---- a regrid's context: the old mesh's search tables built once (on the device) and shared by the two interpolation calls of
+ * FiniteElement::interpFields (FE.cpp:3071-3154) and by any later call on the same mesh.  The one-shot functions above make one per call. */
+typedef struct nxs_regrid nxs_regrid;
+#define NXS_REGRID_IN_DEVICE 1   /* flags: the input data is a device pointer on the context's device */
+#define NXS_REGRID_OUT_DEVICE 2  /*        the output array is */
+NXS_INTERP_API int nxs_regrid_create(const int32_t *index_old, const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old, int32_t device,
+                                     nxs_regrid **out);
+NXS_INTERP_API int nxs_regrid_destroy(nxs_regrid *r);
+/* InterpFromMeshToMesh2dx (arguments as nxs_interp_mesh_to_mesh_2d) */
+NXS_INTERP_API int nxs_regrid_interp_nodes(nxs_regrid *r, double *data_interp, const double *data, int32_t M_data, int32_t N_data, const double *x_interp,
+                                           const double *y_interp, int32_t N_interp, int32_t isdefault, double defaultvalue, int32_t flags,
+                                           int32_t *num_exterior, double *kernel_ms);
+/* ConservativeRemappingMeshToMesh (arguments as nxs_interp_conservative_remap) */
+NXS_INTERP_API int nxs_regrid_remap_elements(nxs_regrid *r, double *interp_out, const double *interp_in, int32_t nb_var, const double *nec_old, int32_t nec_width,
+                                             const double *ec_old, const int32_t *index_new, const double *x_new, const double *y_new, int32_t nods_new,
+                                             int32_t nels_new, const double *previous_numbering, int32_t n_geom_vertices, int32_t flags,
+                                             int32_t *num_failed, int32_t *visits, double *kernel_ms);
+/* where the last regrid call of this thread spent its time, ms: [0] connectivity tables, [1] integer plane + bucket grid, [2] convex completion,
+ * [3] host -> device copies, [4] kernels, [5] device -> host copies, [6] the whole call */
+NXS_INTERP_API int nxs_interp_last_timing(double *ms8);
+/* test door: the device-built tables (which = 0 bucket grid offsets, 1 its lists, 2 NodalElementConnectivity, 3 ElementConnectivity; ints, -1 = NaN) */
+NXS_INTERP_API int nxs_regrid_debug_tables(nxs_regrid *r, int32_t which, int32_t *out, int64_t cap, int64_t *count);
 
 #ifdef __cplusplus
 }

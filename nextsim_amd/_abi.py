@@ -130,6 +130,13 @@ class Diag(C.Structure):
                 ("D_tau_w", c_double_p), ("D_del_ci_ridge_myi", c_double_p)]
 
 
+ICE_DIAG = ("D_conc", "D_thick", "D_snow_thick", "D_sigma0", "D_sigma1", "D_divergence")
+
+
+class IceDiag(C.Structure):
+    _fields_ = [(k, c_double_p) for k in ICE_DIAG]
+
+
 class Timing(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("substeps_ms", C.c_double), ("smoother_ms", C.c_double),
                 ("update_ms", C.c_double), ("total_ms", C.c_double),

@@ -154,6 +154,7 @@ struct nxs_dyn_handle {
     int res_overlap = 0;  // option resident_overlap (several ranks): interior elements of the next sub-step computed while the exchange is awaited
     size_t res_lds = 0;
     double *d_vt3 = nullptr;
+    double *d_icediag = nullptr;           // [Ne][NXS_ICE_DIAG_FIELDS] rows of nxs_dyn_ice_diagnostics (state pool: goes with the mesh)
     double *smooth_second = nullptr;       // the ring slot that equals M_VT after the sub-step loop (the smoother's second buffer), or NULL
     int sig_loc = 0;                       // where M_sigma / M_damage are current: 0 = the state arrays, 1 = the records in S4a (left there by
                                            // the fused sub-step loop; k_update works on them, the arrays follow on demand: ensure_arrays)
@@ -811,6 +812,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     DevState &s = h->ds;
     DevWork &w = h->dw;
     s = DevState{}; w = DevWork{};
+    h->d_icediag = nullptr;
     auto &P = h->state_allocs;
     const size_t n2 = 2 * (size_t)Nn, ne = Ne;
 #define A(ptr, cnt) if ((rc = dev_alloc(h, P, &(ptr), (cnt)))) return rc
@@ -1300,6 +1302,26 @@ int nxs_dyn_get_diag(nxs_dyn_handle *h, nxs_dyn_diag *dg) try {
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return NXS_OK;
 } catch (...) { return dyn_caught(h, "nxs_dyn_get_diag"); }
+
+int nxs_dyn_ice_diagnostics(nxs_dyn_handle *h, nxs_dyn_ice_diag *dg, const double **device_rows) try {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->have_mesh || !h->have_state) return fail(h, NXS_ERR_STATE, "ice_diagnostics needs set_mesh and put_state");
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t Ne = (size_t)h->dm.Ne;
+    if (h->res_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); int rc = resident_error(h); if (rc) return rc; }
+    if (!h->d_icediag) { int rc = dev_alloc(h, h->state_allocs, &h->d_icediag, NXS_ICE_DIAG_FIELDS * Ne); if (rc) return rc; }
+    hipLaunchKernelGGL(k_ice_diagnostics, dim3(nblocks(h->dm.Ne)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, h->dp.young_cat ? 1 : 0,
+                       h->sig_loc ? (const double *)h->ds.S4a : (const double *)nullptr, h->d_icediag);
+    HIPCHK(h, hipGetLastError());
+    if (dg) {
+        double *dst[NXS_ICE_DIAG_FIELDS] = {dg->D_conc, dg->D_thick, dg->D_snow_thick, dg->D_sigma0, dg->D_sigma1, dg->D_divergence};
+        for (int k = 0; k < NXS_ICE_DIAG_FIELDS; ++k)
+            if (dst[k]) HIPCHK(h, hipMemcpy2DAsync(dst[k], sizeof(double), h->d_icediag + k, NXS_ICE_DIAG_FIELDS * sizeof(double), sizeof(double), Ne, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (device_rows) *device_rows = h->d_icediag;
+    return NXS_OK;
+} catch (...) { return dyn_caught(h, "nxs_dyn_ice_diagnostics"); }
 
 // test door: the branch trace of updateSigmaDamage (option "trace_branches"), 4 words per element
 int nxs_dyn_get_branch_trace(nxs_dyn_handle *h, uint64_t *out, int64_t num_words) try {

@@ -1300,10 +1300,14 @@ __device__ __forceinline__ void resident_element(const DevParams &p, const doubl
 // operations on the same values in the same order: bit-identical (bench.py keeps whichever variant is faster on the machine it runs on).
 // WPE: waves per SIMD the kernel is compiled for -- 4 (128 VGPRs: two 512-thread workgroups per CU) or, where one workgroup per CU covers the
 // partition, 2 (the several-rank variant then takes the 148 registers it wants: 15 % faster at that occupancy; the single-rank one gains nothing)
-template <int T, bool POW4, bool HALO, bool OVL = false, int WPE = NXS_RES_WAVES>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
-                                                        const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
-                                                        const HaloFused *__restrict__ hfp, int n_boundary) {
+// The body of one patch.  HALO here means "this patch takes part in the exchange between RANKS" (a boundary patch of a several-rank run); the
+// interior patches of a several-rank run send nothing and stage no ghost node, so they run the single-rank body (HALO = false) -- the kernel
+// below branches once, per workgroup, and each branch keeps the register allocation it has in its own build (the interior patches of the
+// several-rank kernel used to carry that build's seven spilled registers and its longer element and node phases: DESIGN 4.1c).
+template <int T, bool POW4, bool HALO, bool OVL>
+__device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches &pp, const DevState &s, const DevWork &w, const DevParams *__restrict__ pdev, const DevResident &r,
+                                              const double *__restrict__ Sc, double *__restrict__ Sn, const double move_dt,
+                                              const HaloFused *__restrict__ hfp, const int n_boundary, const int blk, const bool boundary, const unsigned long long x0) {
     const DevParams &p0 = *pdev;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int Mmax = pp.Mmax, Emax = pp.Emax, Pmax = pp.Pmax;
@@ -1322,23 +1326,6 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
     int *lPeerVd = reinterpret_cast<int *>(lPeerStride + NXS_RES_MAXNB);                // and of the v-block inside a segment
     const unsigned ZIDX = 3u * (unsigned)Emax;
     __shared__ int lerr;
-    auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
-        const int q = n >> 3, rr = n & 7, x = pos & 7;
-        return (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (pos >> 3);
-    };
-    int blk = blockIdx.x;
-    bool boundary = false;
-    unsigned long long x0 = 0ull;
-    if (HALO) {
-        boundary = blk < n_boundary;
-        if (boundary) {  // exchanges this rank has published so far; changed only after every boundary patch has finished (uniform: kept in scalar registers)
-            const unsigned long long xv = *hfp->ipc.seq_push;
-            x0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(xv & 0xffffffffull));
-        }
-        blk = boundary ? xcd_remap(blk, n_boundary) : n_boundary + xcd_remap(blk - n_boundary, (int)gridDim.x - n_boundary);
-    } else {
-        blk = xcd_remap(blk, (int)gridDim.x);
-    }
     const int t = threadIdx.x, Nn = m.Nn, S = p0.substeps;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk], nNb = r.pnbr_cnt[blk];
     const int *pn = pp.pnodes + (size_t)blk * Mmax;
@@ -1642,6 +1629,30 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
     if (has_node && move_dt != 0.) {
         if (!(nf & NF_NEUMANN)) { s.UM[n] = lM[t]; s.UM[n + Nn] = lM[Pmax + t]; }
         s.UT[n] = lM[2 * (size_t)Pmax + t]; s.UT[n + Nn] = lM[3 * (size_t)Pmax + t];
+    }
+}
+
+template <int T, bool POW4, bool HALO, bool OVL = false, int WPE = NXS_RES_WAVES>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_substep_resident(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
+                                                        const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
+                                                        const HaloFused *__restrict__ hfp, int n_boundary) {
+    auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
+        const int q = n >> 3, rr = n & 7, x = pos & 7;
+        return (x < rr ? x * (q + 1) : rr * (q + 1) + (x - rr) * q) + (pos >> 3);
+    };
+    int blk = blockIdx.x;
+    if (HALO) {
+        const bool boundary = blk < n_boundary;  // boundary patches lead the grid (HaloFused)
+        blk = boundary ? xcd_remap(blk, n_boundary) : n_boundary + xcd_remap(blk - n_boundary, (int)gridDim.x - n_boundary);
+        if (boundary) {  // exchanges this rank has published so far; changed only after every boundary patch has finished (uniform: kept in scalar registers)
+            const unsigned long long xv = *hfp->ipc.seq_push;
+            const unsigned long long x0 = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(xv >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)(xv & 0xffffffffull));
+            resident_body<T, POW4, true, OVL>(m, pp, s, w, pdev, r, Sc, Sn, move_dt, hfp, n_boundary, blk, true, x0);
+        } else {
+            resident_body<T, POW4, false, false>(m, pp, s, w, pdev, r, Sc, Sn, move_dt, nullptr, 0, blk, false, 0ull);
+        }
+    } else {
+        resident_body<T, POW4, false, false>(m, pp, s, w, pdev, r, Sc, Sn, move_dt, nullptr, 0, xcd_remap(blk, (int)gridDim.x), false, 0ull);
     }
 }
 
@@ -1990,6 +2001,36 @@ __global__ void __launch_bounds__(BLOCK) k_ghost_ring_move(DevMesh m, DevState s
     }
     if (free_node) { s.UM[n] = umu; s.UM[n + Nn] = umv; }
     s.UT[n] = utu; s.UT[n + Nn] = utv;
+}
+
+// K14  updateIceDiagnostics(), FE.cpp:7860-7905: totals over the ice categories, principal stresses, divergence of M_VT on the mesh displaced by
+// M_UM (shapeCoeff, FE.cpp:1951-1964).  One [Ne][6] row per element (D_conc, D_thick, D_snow_thick, D_sigma0, D_sigma1, D_divergence), staged through
+// LDS so that the rows leave as one stream.  S4 != NULL: sigma lives in the records the sub-step loop left behind (k_pack_state's layout).
+__global__ void __launch_bounds__(BLOCK) k_ice_diagnostics(DevMesh m, DevState s, int young_cat, const double *__restrict__ S4, double *__restrict__ out) {
+    const int e = min(blockIdx.x * BLOCK + (int)threadIdx.x, m.Ne - 1);  // (threads past the end redo the last element: every thread reaches the barrier)
+    __shared__ double rows[BLOCK * 6];
+    double dc = s.conc[e], dt = s.thick[e], ds = s.snow[e];
+    if (young_cat) { dc += s.cyoung[e]; dt += s.hyoung[e]; ds += s.hsyoung[e]; }
+    double s0, s1, s2;
+    if (S4) { s0 = S4[4 * (size_t)e]; s1 = S4[4 * (size_t)e + 1]; s2 = S4[4 * (size_t)e + 2]; }
+    else { s0 = s.s0[e]; s1 = s.s1[e]; s2 = s.s2[e]; }
+    double vx[3], vy[3];
+    load_vertices(m, s.UM, e, vx, vy);
+    const double jac = jacobian(vx, vy);
+    const int n[3] = {m.t0[e], m.t1[e], m.t2[e]};
+    double div = 0.;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int kp1 = (j + 1) % 3, kp2 = (j + 2) % 3;
+        const double dxN = (vy[kp1] - vy[kp2]) / jac, dyN = (vx[kp2] - vx[kp1]) / jac;
+        div += dxN * s.VT[n[j]] + dyN * s.VT[n[j] + m.Nn];
+    }
+    double *r = rows + 6 * threadIdx.x;
+    r[0] = dc; r[1] = dt; r[2] = ds; r[3] = (s0 + s1) / 2.; r[4] = hypot((s0 - s1) / 2., s2); r[5] = div;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * BLOCK * 6;
+    const int count = min(BLOCK, m.Ne - (int)blockIdx.x * BLOCK) * 6;
+    for (int i = threadIdx.x; i < count; i += BLOCK) out[base + i] = rows[i];
 }
 
 // Deferred mesh move of the fused path: the fused kernel leaves every sub-step's velocity in a ring of

@@ -11,13 +11,18 @@
 // (one thread per target point, candidates tested in ascending triangle number).
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <future>
 #include <map>
+#include <memory>
 #include <string>
+#include <system_error>
 #include <vector>
 
 #include "nxs_dyn.h"
@@ -43,6 +48,15 @@ int fail(int code, const char *fmt, ...) {
 int entry_caught(const char *entry) noexcept {
     return nxs_guard::caught(entry, [](int code, const char *text) { (void)fail(code, "%s", text); });
 }
+
+// Where the time of the last regrid call of this thread went (nxs_interp_last_timing): [0] connectivity tables of the old mesh, [1] integer
+// plane + bucket grid, [2] convex completion, [3] host -> device copies, [4] kernels (HIP events), [5] device -> host copies, [6] whole call; ms.
+thread_local double g_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+struct Tick {
+    int slot; std::chrono::steady_clock::time_point t0;
+    explicit Tick(int s) : slot(s), t0(std::chrono::steady_clock::now()) {}
+    ~Tick() { g_ms[slot] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+};
 
 // Every device operation of this file runs on a stream of its own (one per host thread, created on first use), never on the
 // legacy default stream: a host that drives several GPUs from one process may be capturing a graph of the dynamics step on
@@ -256,12 +270,15 @@ struct DevBuf {
     ~DevBuf() { if (p) (void)hipFree(p); }
     int alloc(size_t n) { return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
     int upload(const T *src, size_t n) {
+        Tick tk(3);
         if (alloc(n)) return -1;
         return (n == 0 || copy_sync(p, src, n * sizeof(T), hipMemcpyHostToDevice) == hipSuccess) ? 0 : -1;
     }
 };
 
 }  // namespace
+
+#include "nxs_regrid_tables.inl"
 
 namespace {
 
@@ -322,81 +339,116 @@ __global__ void __launch_bounds__(256) k_mesh_to_grid(GridDev d, const double *_
 
 namespace {
 
+// [n][3] triangles (1-based when `one_based`) -> three 0-based arrays
+__global__ void __launch_bounds__(256) k_split_triangles(int n, const int *__restrict__ tri3, int one_based, int *__restrict__ t0, int *__restrict__ t1, int *__restrict__ t2) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    t0[e] = tri3[3 * e] - one_based; t1[e] = tri3[3 * e + 1] - one_based; t2[e] = tri3[3 * e + 2] - one_based;
+}
+
+__global__ void __launch_bounds__(256) k_add_int(int n, int *__restrict__ a, int c) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) a[i] += c;
+}
+
 // The data mesh in bamg's integer plane + the bucket grid used by locate(), resident on the device.
 thread_local int g_info[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // of the last mesh-to-mesh call of this thread (nxs_interp_last_info)
 thread_local std::string g_completion_note;
 
 struct Locator {
     InterpDev d{};
-    DevBuf<int> dt0, dt1, dt2, dix, diy, doff, dtri;
+    DevBuf<int> dtri3, dt0, dt1, dt2, dix, diy, doff, dtri;
     DevBuf<BEdge> dbe;
     DevBuf<HullDev> dhull;
-    std::vector<int> t0, t1, t2;
+    std::vector<int> ix, iy;      // host copies of the integer plane (the completion is host code)
     nxs_hull::Completion comp;
+    bool with_completion = false;
+    int nods = 0, nels_mesh = 0;
+    double coef = 0., pminx = 0., pminy = 0.;
 
-    int build(const int32_t *index_data, const double *x_data, const double *y_data, int32_t nods, int32_t nels, bool need_boundary_edges) {
-        // ---- SetIntCoor (Mesh.cpp:3441-3468)
-        double pminx = x_data[0], pminy = y_data[0], pmaxx = x_data[0], pmaxy = y_data[0];
-        for (int i = 0; i < nods; ++i) {
-            pminx = std::min(pminx, x_data[i]); pminy = std::min(pminy, y_data[i]);
-            pmaxx = std::max(pmaxx, x_data[i]); pmaxy = std::max(pmaxy, y_data[i]);
+    // the data mesh in bamg's integer plane + the bucket grid of locate(), the grid built on the device (nxs_regrid_tables.inl)
+    int build(const int32_t *index_data, const double *x_data, const double *y_data, int32_t nods_, int32_t nels, bool need_boundary_edges,
+              const nxs_hull::Completion *ready = nullptr) {
+        nods = nods_; nels_mesh = nels;
+        {   // ---- SetIntCoor (Mesh.cpp:3441-3468)
+            Tick tk(1);
+            double bx0 = x_data[0], by0 = y_data[0], bx1 = x_data[0], by1 = y_data[0];
+            for (int i = 0; i < nods; ++i) {
+                bx0 = std::min(bx0, x_data[i]); by0 = std::min(by0, y_data[i]);
+                bx1 = std::max(bx1, x_data[i]); by1 = std::max(by1, y_data[i]);
+            }
+            d.xmin = bx0; d.xmax = bx1; d.ymin = by0; d.ymax = by1;
+            if (!nxs_hull::int_plane(x_data, y_data, nods, ix, iy, coef, pminx, pminy))
+                return fail(NXS_ERR_INVALID, "coefIcoor should be positive, a problem in the geometry is likely");
         }
-        d.xmin = pminx; d.xmax = pmaxx; d.ymin = pminy; d.ymax = pmaxy;
-        double coef = 0.;
-        std::vector<int> ix, iy;
-        if (!nxs_hull::int_plane(x_data, y_data, nods, ix, iy, coef, pminx, pminy))
-            return fail(NXS_ERR_INVALID, "coefIcoor should be positive, a problem in the geometry is likely");
-        t0.resize(nels); t1.resize(nels); t2.resize(nels);
-        for (int e = 0; e < nels; ++e) { t0[e] = index_data[3 * e] - 1; t1[e] = index_data[3 * e + 1] - 1; t2[e] = index_data[3 * e + 2] - 1; }
-        // ---- bamg's convex completion (isdefault == false only): fill triangles numbered behind the mesh's, hull edges
-        const int nels_mesh = nels;
+        // ---- bamg's convex completion (isdefault == 0 only): fill triangles numbered behind the mesh's, hull edges
         std::vector<HullDev> hull;
+        std::vector<int> fill3;  // AoS, 0-based
         if (need_boundary_edges) {
-            comp = nxs_hull::complete(index_data, ix.data(), iy.data(), nods, nels);
+            Tick tk(2);
+            comp = ready ? *ready : nxs_hull::complete(index_data, ix.data(), iy.data(), nods, nels);
+            with_completion = true;
             if (comp.ok) {
-                for (size_t i = 0; i + 2 < comp.fill.size(); i += 3) { t0.push_back(comp.fill[i]); t1.push_back(comp.fill[i + 1]); t2.push_back(comp.fill[i + 2]); }
+                fill3 = comp.fill;
                 for (const auto &h : comp.hull) hull.push_back(HullDev{h.a, h.b, h.tri, h.k});
-                nels = (int)t0.size();  // the bucket grid below covers the fill triangles too (ascending numbers: the mesh's first)
             }
         }
-
-        // ---- bucket grid over the integer plane
-        int G = 1;
-        while ((long long)G * G * 2 < nels && G < 4096) G <<= 1;
-        int shift = 30;
-        for (int g = G; g > 1; g >>= 1) --shift;  // cell = 2^shift units, G cells cover [0, 2^30)
-        std::vector<int> cnt((size_t)G * G + 1, 0);
-        auto cell_range = [&](int e, int &cx0, int &cx1, int &cy0, int &cy1) {
-            const int xs[3] = {ix[t0[e]], ix[t1[e]], ix[t2[e]]}, ys[3] = {iy[t0[e]], iy[t1[e]], iy[t2[e]]};
-            cx0 = std::min({xs[0], xs[1], xs[2]}) >> shift; cx1 = std::max({xs[0], xs[1], xs[2]}) >> shift;
-            cy0 = std::min({ys[0], ys[1], ys[2]}) >> shift; cy1 = std::max({ys[0], ys[1], ys[2]}) >> shift;
-            cx0 = std::max(cx0, 0); cy0 = std::max(cy0, 0); cx1 = std::min(cx1, G - 1); cy1 = std::min(cy1, G - 1);
-        };
-        for (int e = 0; e < nels; ++e) {
-            int a, b, c, dd2;
-            cell_range(e, a, b, c, dd2);
-            for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cnt[(size_t)cy * G + cx + 1]++;
-        }
-        for (size_t c = 0; c < (size_t)G * G; ++c) cnt[c + 1] += cnt[c];
-        std::vector<int> cell_tri(cnt[(size_t)G * G]), fill(cnt.begin(), cnt.end() - 1);
-        for (int e = 0; e < nels; ++e) {  // ascending e => ascending lists
-            int a, b, c, dd2;
-            cell_range(e, a, b, c, dd2);
-            for (int cy = c; cy <= dd2; ++cy) for (int cx = a; cx <= b; ++cx) cell_tri[fill[(size_t)cy * G + cx]++] = e;
-        }
-
-        // ---- boundary edges (edges held by exactly one triangle)
-        std::vector<BEdge> bedges;  // (the stand-in for exterior points when no completion exists)
+        const int nfill = (int)fill3.size() / 3, nall = nels + nfill;
+        // ---- boundary edges (edges held by exactly one triangle): the stand-in for exterior points when no completion exists
+        std::vector<BEdge> bedges;
         if (need_boundary_edges && !comp.ok) {
+            Tick tk(2);
             std::vector<int> bnd;
-            (void)nxs_hull::find_boundary_edges(index_data, nods, nels_mesh, bnd);
+            (void)nxs_hull::find_boundary_edges(index_data, nods, nels, bnd);
             for (int be : bnd) bedges.push_back(BEdge{be / 3, be % 3});
         }
-        if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || dix.upload(ix.data(), nods) ||
-            diy.upload(iy.data(), nods) || doff.upload(cnt.data(), cnt.size()) || dtri.upload(cell_tri.data(), cell_tri.size()) ||
-            dbe.upload(bedges.data(), bedges.size()) || dhull.upload(hull.data(), hull.size()))
+        // ---- triangles to the device (1-based AoS as the caller has them), SoA 0-based there; the fill triangles behind them
+        if (dtri3.alloc(3 * (size_t)nall) || dt0.alloc(nall) || dt1.alloc(nall) || dt2.alloc(nall))
+            return fail(NXS_ERR_HIP, "device allocation failed: %s", hipGetErrorString(hipGetLastError()));
+        {
+            Tick tk(3);
+            if (copy_sync(dtri3.p, index_data, 3 * (size_t)nels * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(NXS_ERR_HIP, "upload failed");
+        }
+        hipLaunchKernelGGL(k_split_triangles, dim3((nels + 255) / 256), dim3(256), 0, S(), nels, dtri3.p, 1, dt0.p, dt1.p, dt2.p);
+        if (nfill > 0) {
+            Tick tk(3);
+            if (copy_sync(dtri3.p + 3 * (size_t)nels, fill3.data(), fill3.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(NXS_ERR_HIP, "upload failed");
+            hipLaunchKernelGGL(k_split_triangles, dim3((nfill + 255) / 256), dim3(256), 0, S(), nfill, dtri3.p + 3 * (size_t)nels, 0, dt0.p + nels, dt1.p + nels, dt2.p + nels);
+        }
+        if (dix.upload(ix.data(), nods) || diy.upload(iy.data(), nods) || dbe.upload(bedges.data(), bedges.size()) || dhull.upload(hull.data(), hull.size()))
             return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
-        d.nods = nods; d.nels = nels_mesh; d.nels_all = nels;
+        // ---- bucket grid over the integer plane, on the device: count -> scan -> fill -> sort every cell's list ascending
+        int G = 1;
+        while ((long long)G * G * 2 < nall && G < 4096) G <<= 1;
+        int shift = 30;
+        for (int g = G; g > 1; g >>= 1) --shift;  // cell = 2^shift units, G cells cover [0, 2^30)
+        const size_t ncell = (size_t)G * G;
+        DevBuf<int> cursor, wide, nwide;
+        if (doff.alloc(ncell + 1) || cursor.alloc(ncell) || wide.alloc(nall) || nwide.alloc(1)) return fail(NXS_ERR_HIP, "device allocation failed");
+        int total = 0, n_wide = 0;
+        {
+            Tick tk(1);
+            if (hipMemsetAsync(doff.p, 0, (ncell + 1) * sizeof(int), S()) != hipSuccess || hipMemsetAsync(cursor.p, 0, ncell * sizeof(int), S()) != hipSuccess ||
+                hipMemsetAsync(nwide.p, 0, sizeof(int), S()) != hipSuccess)
+                return fail(NXS_ERR_HIP, "hipMemset failed");
+            hipLaunchKernelGGL(regrid_tables::k_grid_count, dim3((nall + 255) / 256), dim3(256), 0, S(), nall, (const int *)dt0.p, (const int *)dt1.p, (const int *)dt2.p,
+                               (const int *)dix.p, (const int *)diy.p, shift, G, doff.p, wide.p, nwide.p);
+            if (copy_sync(&n_wide, nwide.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+            if (n_wide > 0)  // triangles that span many cells (fill triangles across a bay): a workgroup each
+                hipLaunchKernelGGL(regrid_tables::k_grid_count_wide, dim3(n_wide), dim3(256), 0, S(), (const int *)wide.p, (const int *)dt0.p, (const int *)dt1.p, (const int *)dt2.p,
+                                   (const int *)dix.p, (const int *)diy.p, shift, G, doff.p);
+            if (regrid_tables::exclusive_scan(doff.p, (int)(ncell + 1), S()) != hipSuccess) return fail(NXS_ERR_HIP, "scan of the bucket grid failed");
+            if (copy_sync(&total, doff.p + ncell, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+            if (dtri.alloc((size_t)std::max(total, 1))) return fail(NXS_ERR_HIP, "device allocation failed");
+            hipLaunchKernelGGL(regrid_tables::k_grid_fill, dim3((nall + 255) / 256), dim3(256), 0, S(), nall, (const int *)dt0.p, (const int *)dt1.p, (const int *)dt2.p,
+                               (const int *)dix.p, (const int *)diy.p, shift, G, (const int *)doff.p, cursor.p, dtri.p);
+            if (n_wide > 0)
+                hipLaunchKernelGGL(regrid_tables::k_grid_fill_wide, dim3(n_wide), dim3(256), 0, S(), (const int *)wide.p, (const int *)dt0.p, (const int *)dt1.p, (const int *)dt2.p,
+                                   (const int *)dix.p, (const int *)diy.p, shift, G, (const int *)doff.p, cursor.p, dtri.p);
+            hipLaunchKernelGGL(regrid_tables::k_rows_sort, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, S(), (int)ncell, (const int *)doff.p, dtri.p, 0);
+            if (hipStreamSynchronize(S()) != hipSuccess) return fail(NXS_ERR_HIP, "bucket grid kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        }
+        d.nods = nods; d.nels = nels; d.nels_all = nall;
         d.nhull = (int)hull.size(); d.hull = dhull.p;
         d.t0 = dt0.p; d.t1 = dt1.p; d.t2 = dt2.p; d.ix = dix.p; d.iy = diy.p;
         d.G = G; d.shift = shift; d.cell_off = doff.p; d.cell_tri = dtri.p;
@@ -408,10 +460,11 @@ struct Locator {
 
 }  // namespace
 
-extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
-                                       int32_t nods, int32_t nels, const double *data_mesh, int32_t data_length, int32_t N_data,
-                                       double xmin, double ymax, double xposting, double yposting, int32_t nrows, int32_t ncols,
-                                       double default_value, int32_t device, double *kernel_ms) try {
+namespace {
+int mesh_to_grid(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
+                 int32_t nods, int32_t nels, const double *data_mesh, bool data_on_device, int32_t data_length, int32_t N_data,
+                 double xmin, double ymax, double xposting, double yposting, int32_t nrows, int32_t ncols,
+                 double default_value, int32_t device, double *kernel_ms) {
     if (!griddata || !index_mesh || !x_mesh || !y_mesh || !data_mesh) return fail(NXS_ERR_INVALID, "NULL argument");
     if (nels < 1 || nods < 3 || ncols < 1 || nrows < 1 || xposting == 0 || yposting == 0 || N_data < 1)  // :34-36
         return fail(NXS_ERR_INVALID, "nothing to be done according to the mesh given in input");
@@ -455,7 +508,7 @@ extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_me
     const size_t npts = (size_t)nrows * ncols;
     if (dt0.upload(t0.data(), nels) || dt1.upload(t1.data(), nels) || dt2.upload(t2.data(), nels) || doff.upload(cnt.data(), cnt.size()) ||
         dtri.upload(cell_tri.data(), cell_tri.size()) || dx.upload(x_mesh, nods) || dy.upload(y_mesh, nods) || dxg.upload(xg.data(), nrows) ||
-        dyg.upload(yg.data(), ncols) || ddata.upload(data_mesh, (size_t)data_length * N_data) || dout.alloc(npts * N_data))
+        dyg.upload(yg.data(), ncols) || (!data_on_device && ddata.upload(data_mesh, (size_t)data_length * N_data)) || dout.alloc(npts * N_data))
         return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
     GridDev d{};
     d.nods = nods; d.nels = nels; d.N_data = N_data; d.nrows = nrows; d.ncols = ncols; d.nodal = (data_length == nods);
@@ -465,7 +518,7 @@ extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_me
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0, S());
-    hipLaunchKernelGGL(k_mesh_to_grid, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, S(), d, (const double *)ddata.p, dout.p);
+    hipLaunchKernelGGL(k_mesh_to_grid, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0, S(), d, data_on_device ? data_mesh : (const double *)ddata.p, dout.p);
     (void)hipEventRecord(e1, S());
     hipError_t err = hipStreamSynchronize(S());
     float ms = 0.f;
@@ -475,9 +528,230 @@ extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_me
     if (kernel_ms) *kernel_ms = ms;
     if (copy_sync(griddata, dout.p, npts * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
     return NXS_OK;
+}
+}  // namespace
+
+extern "C" int nxs_interp_mesh_to_grid(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
+                                       int32_t nods, int32_t nels, const double *data_mesh, int32_t data_length, int32_t N_data,
+                                       double xmin, double ymax, double xposting, double yposting, int32_t nrows, int32_t ncols,
+                                       double default_value, int32_t device, double *kernel_ms) try {
+    return mesh_to_grid(griddata, index_mesh, x_mesh, y_mesh, nods, nels, data_mesh, false, data_length, N_data, xmin, ymax, xposting, yposting, nrows, ncols,
+                        default_value, device, kernel_ms);
 } catch (...) { return entry_caught("nxs_interp_mesh_to_grid"); }
 
+// The same sampling with the mesh data ALREADY ON THE DEVICE (e.g. the rows of nxs_dyn_ice_diagnostics, or any [data_length][N_data] array of
+// the caller's on `device`): a Moorings record (gridoutput.cpp:496) then needs no round trip of the element state through the host.  The caller
+// makes sure the producer of data_mesh_device has finished (nxs_dyn_ice_diagnostics returns synchronised).
+extern "C" int nxs_interp_mesh_to_grid_device(double *griddata, const int32_t *index_mesh, const double *x_mesh, const double *y_mesh,
+                                              int32_t nods, int32_t nels, const double *data_mesh_device, int32_t data_length, int32_t N_data,
+                                              double xmin, double ymax, double xposting, double yposting, int32_t nrows, int32_t ncols,
+                                              double default_value, int32_t device, double *kernel_ms) try {
+    return mesh_to_grid(griddata, index_mesh, x_mesh, y_mesh, nods, nels, data_mesh_device, true, data_length, N_data, xmin, ymax, xposting, yposting, nrows, ncols,
+                        default_value, device, kernel_ms);
+} catch (...) { return entry_caught("nxs_interp_mesh_to_grid_device"); }
+
 extern "C" const char *nxs_interp_last_error(void) { return g_err.c_str(); }
+
+// ---------------------------------------------------------------------------------------------------------
+// A regrid's context: everything about the OLD mesh that both interpolation calls of FiniteElement::interpFields (FE.cpp:3071-3154: the
+// conservative remapping of the element variables, then InterpFromMeshToMesh2dx of the nodal ones) and any later call on the same mesh need --
+// the integer plane, the bucket grid, bamg's convex completion, the two connectivity tables -- built once, on the device where that is
+// possible (nxs_regrid_tables.inl), and kept.  The one-shot entry points below make a context, use it and drop it.
+// ---------------------------------------------------------------------------------------------------------
+struct nxs_regrid {
+    std::future<nxs_hull::Completion> completion;   // bamg's convex completion, started on a host thread when the context is made (it is pure
+                                                    // host work on the context's own copies): ready by the time the nodal interpolation asks for it
+    int device = 0;
+    int32_t nods = 0, nels = 0;
+    std::vector<int32_t> index;   // host copies (the completion is host code; the caller's arrays may go away)
+    std::vector<double> x, y;
+    Locator plain, full;          // without / with bamg's convex completion (isdefault != 0 / == 0)
+    bool have_plain = false, have_full = false;
+    DevBuf<int> dtrio, ddeg, dnec, dec;   // old triangles (AoS, 0-based), NodalElementConnectivity, ElementConnectivity as ints
+    DevBuf<double> dxo, dyo;
+    int nec_width = 0;
+    bool have_conn = false;
+};
+
+namespace {
+
+int regrid_locator(nxs_regrid *r, bool with_completion, Locator **out) {
+    Locator &L = with_completion ? r->full : r->plain;
+    bool &have = with_completion ? r->have_full : r->have_plain;
+    if (!have) {
+        nxs_hull::Completion ready;
+        const bool use_ready = with_completion && r->completion.valid();
+        if (use_ready) { Tick tk(2); ready = r->completion.get(); }   // (what is left to wait for, if anything)
+        if (int rc = L.build(r->index.data(), r->x.data(), r->y.data(), r->nods, r->nels, with_completion, use_ready ? &ready : nullptr)) return rc;
+        have = true;
+    }
+    *out = &L;
+    return 0;
+}
+
+// the two tables checkTriangle walks, as ints (-1 = bamg's NaN): built on the device, or converted from the caller's bamg tables
+int regrid_connectivity(nxs_regrid *r, const double *nec_old, int32_t nec_width, const double *ec_old) {
+    if (r->have_conn && !nec_old && !ec_old) return 0;
+    Tick tk(0);
+    const int nods = r->nods, nels = r->nels;
+    if (r->dtrio.p == nullptr) {
+        if (r->dtrio.alloc(3 * (size_t)nels) || r->dxo.upload(r->x.data(), nods) || r->dyo.upload(r->y.data(), nods)) return fail(NXS_ERR_HIP, "device allocation / upload failed");
+        if (copy_sync(r->dtrio.p, r->index.data(), 3 * (size_t)nels * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(NXS_ERR_HIP, "upload failed");
+        hipLaunchKernelGGL(k_add_int, dim3((3 * nels + 255) / 256), dim3(256), 0, S(), 3 * nels, r->dtrio.p, -1);
+    }
+    auto to_index = [&](double v, int hi) -> int {  // "(int)(v - 1)" of the reference; NaN and junk become "no more entries"
+        if (!(v >= 1.) || !(v <= (double)hi)) return -1;
+        return (int)v - 1;
+    };
+    if (nec_old) {  // bamgmesh_previous->NodalElementConnectivity as bamg left it
+        if (nec_width < 1 || nec_width > 255) return fail(NXS_ERR_INVALID, "NodalElementConnectivity width %d (1 .. 255 expected)", nec_width);
+        std::vector<int> neci((size_t)nods * nec_width);
+        for (size_t i = 0; i < neci.size(); ++i) neci[i] = to_index(nec_old[i], nels);
+        DevBuf<int> nb;
+        if (nb.upload(neci.data(), neci.size())) return fail(NXS_ERR_HIP, "upload failed");
+        std::swap(r->dnec.p, nb.p);
+        r->nec_width = nec_width;
+    } else if (!r->have_conn) {
+        DevBuf<int> cursor, maxdeg;
+        if (r->ddeg.alloc(nods) || cursor.alloc(nods) || maxdeg.alloc(1)) return fail(NXS_ERR_HIP, "device allocation failed");
+        if (hipMemsetAsync(r->ddeg.p, 0, (size_t)nods * sizeof(int), S()) != hipSuccess || hipMemsetAsync(cursor.p, 0, (size_t)nods * sizeof(int), S()) != hipSuccess ||
+            hipMemsetAsync(maxdeg.p, 0, sizeof(int), S()) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+        hipLaunchKernelGGL(regrid_tables::k_fan_count, dim3((3 * nels + 255) / 256), dim3(256), 0, S(), nels, (const int *)r->dtrio.p, r->ddeg.p, maxdeg.p);
+        int w1 = 0;
+        if (copy_sync(&w1, maxdeg.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+        if (w1 < 1 || w1 > 255) return fail(NXS_ERR_INVALID, "NodalElementConnectivity wider than 255 (%d)", w1);
+        if (r->dnec.alloc((size_t)nods * w1)) return fail(NXS_ERR_HIP, "device allocation failed");
+        hipLaunchKernelGGL(regrid_tables::k_fan_fill, dim3((3 * nels + 255) / 256), dim3(256), 0, S(), nels, (const int *)r->dtrio.p, cursor.p, r->dnec.p, w1);
+        hipLaunchKernelGGL(regrid_tables::k_fan_sort_desc, dim3((nods + 255) / 256), dim3(256), 0, S(), nods, (const int *)r->ddeg.p, r->dnec.p, w1);
+        if (hipStreamSynchronize(S()) != hipSuccess) return fail(NXS_ERR_HIP, "connectivity kernels failed: %s", hipGetErrorString(hipGetLastError()));
+        r->nec_width = w1;
+    }
+    if (ec_old) {
+        std::vector<int> eci(3 * (size_t)nels);
+        for (size_t i = 0; i < eci.size(); ++i) eci[i] = to_index(ec_old[i], nels);
+        DevBuf<int> eb;
+        if (eb.upload(eci.data(), eci.size())) return fail(NXS_ERR_HIP, "upload failed");
+        std::swap(r->dec.p, eb.p);
+    } else if (!r->have_conn || nec_old) {
+        // (from the ascending-independent fans: with the caller's NodalElementConnectivity the degrees are not known here, so the fans are rebuilt)
+        DevBuf<int> deg2, cur2, nec2, maxdeg, bad;
+        const int *deg = r->ddeg.p; const int *nec = r->dnec.p; int w = r->nec_width;
+        if (nec_old) {
+            if (deg2.alloc(nods) || cur2.alloc(nods) || maxdeg.alloc(1)) return fail(NXS_ERR_HIP, "device allocation failed");
+            if (hipMemsetAsync(deg2.p, 0, (size_t)nods * sizeof(int), S()) != hipSuccess || hipMemsetAsync(cur2.p, 0, (size_t)nods * sizeof(int), S()) != hipSuccess ||
+                hipMemsetAsync(maxdeg.p, 0, sizeof(int), S()) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+            hipLaunchKernelGGL(regrid_tables::k_fan_count, dim3((3 * nels + 255) / 256), dim3(256), 0, S(), nels, (const int *)r->dtrio.p, deg2.p, maxdeg.p);
+            int w1 = 0;
+            if (copy_sync(&w1, maxdeg.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+            if (nec2.alloc((size_t)nods * std::max(w1, 1))) return fail(NXS_ERR_HIP, "device allocation failed");
+            hipLaunchKernelGGL(regrid_tables::k_fan_fill, dim3((3 * nels + 255) / 256), dim3(256), 0, S(), nels, (const int *)r->dtrio.p, cur2.p, nec2.p, w1);
+            deg = deg2.p; nec = nec2.p; w = w1;
+        }
+        if (bad.alloc(1) || hipMemsetAsync(bad.p, 0, sizeof(int), S()) != hipSuccess) return fail(NXS_ERR_HIP, "device allocation failed");
+        if (r->dec.p == nullptr && r->dec.alloc(3 * (size_t)nels)) return fail(NXS_ERR_HIP, "device allocation failed");
+        hipLaunchKernelGGL(regrid_tables::k_elem_conn, dim3((3 * nels + 255) / 256), dim3(256), 0, S(), nels, (const int *)r->dtrio.p, deg, nec, w, r->dec.p, bad.p);
+        int nbad = 0;
+        if (copy_sync(&nbad, bad.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+        if (nbad > 0) return fail(NXS_ERR_INVALID, "an edge of the old mesh is shared by more than two triangles");
+    }
+    r->have_conn = !nec_old && !ec_old;   // (tables converted from the caller's are not kept for a later call without them)
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int nxs_regrid_create(const int32_t *index_old, const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old, int32_t device,
+                                 nxs_regrid **out) try {
+    if (!out) return fail(NXS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!index_old || !x_old || !y_old) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (nods_old < 3 || nels_old < 1) return fail(NXS_ERR_INVALID, "bad sizes");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the regrid interpolation has no CPU path");
+    if (device < 0 || device >= ndev) return fail(NXS_ERR_INVALID, "device %d out of range", device);
+    if (hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
+    for (int64_t i = 0; i < 3ll * nels_old; ++i)
+        if (index_old[i] < 1 || index_old[i] > nods_old) return fail(NXS_ERR_INVALID, "index_old[%lld] out of range", (long long)i);
+    std::unique_ptr<nxs_regrid> r(new nxs_regrid());
+    r->device = device; r->nods = nods_old; r->nels = nels_old;
+    r->index.assign(index_old, index_old + 3 * (size_t)nels_old);
+    r->x.assign(x_old, x_old + nods_old); r->y.assign(y_old, y_old + nods_old);
+    try {   // bamg's convex completion on a host thread, from now on (pure host work on this context's own copies); without a thread it is made when asked for
+        nxs_regrid *q = r.get();
+        r->completion = std::async(std::launch::async, [q]() {
+            std::vector<int> ix, iy;
+            double coef = 0., px = 0., py = 0.;
+            if (!nxs_hull::int_plane(q->x.data(), q->y.data(), q->nods, ix, iy, coef, px, py)) { nxs_hull::Completion c; c.why = "coefIcoor should be positive"; return c; }
+            return nxs_hull::complete(q->index.data(), ix.data(), iy.data(), q->nods, q->nels);
+        });
+    } catch (const std::system_error &) { }
+    *out = r.release();
+    return NXS_OK;
+} catch (...) { return entry_caught("nxs_regrid_create"); }
+
+extern "C" int nxs_regrid_destroy(nxs_regrid *r) try {
+    if (!r) return NXS_OK;
+    (void)hipSetDevice(r->device);
+    if (r->completion.valid()) { try { (void)r->completion.get(); } catch (...) { } }   // the thread reads this context: it ends before the context does
+    delete r;
+    return NXS_OK;
+} catch (...) { return entry_caught("nxs_regrid_destroy"); }
+
+// InterpFromMeshToMesh2dx on the context's mesh.  flags: NXS_REGRID_IN_DEVICE = `data` is a device pointer, NXS_REGRID_OUT_DEVICE = `data_interp` is.
+extern "C" int nxs_regrid_interp_nodes(nxs_regrid *r, double *data_interp, const double *data, int32_t M_data, int32_t N_data, const double *x_interp,
+                                       const double *y_interp, int32_t N_interp, int32_t isdefault, double defaultvalue, int32_t flags,
+                                       int32_t *num_exterior, double *kernel_ms) try {
+    if (!r || !data_interp || !data || !x_interp || !y_interp) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (N_data <= 0 || N_interp < 0) return fail(NXS_ERR_INVALID, "bad sizes");
+    const int nods = r->nods, nels = r->nels;
+    if (M_data != nods && M_data != nels)  // InterpFromMeshToMesh2dx.cpp:39-42
+        return fail(NXS_ERR_INVALID, "data provided should have either %d or %d lines (not %d)", nods, nels, M_data);
+    if (hipSetDevice(r->device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
+    for (double &v : g_ms) v = 0.;
+    Tick whole(6);
+    Locator *locp = nullptr;
+    if (int rc = regrid_locator(r, !isdefault, &locp)) return rc;
+    Locator &loc = *locp;
+    InterpDev d = loc.d;
+    DevBuf<int> dnext;
+    DevBuf<double> ddata, dxi, dyi, dout;
+    const bool in_dev = flags & NXS_REGRID_IN_DEVICE, out_dev = flags & NXS_REGRID_OUT_DEVICE;
+    if ((!in_dev && ddata.upload(data, (size_t)M_data * N_data)) || dxi.upload(x_interp, N_interp) || dyi.upload(y_interp, N_interp) ||
+        (!out_dev && dout.alloc((size_t)N_interp * N_data)) || dnext.alloc(4))
+        return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
+    if (memset_sync(dnext.p, 0, 4 * sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+    d.N_data = N_data; d.N_interp = N_interp; d.nodal = (M_data == nods);
+    d.isdefault = isdefault != 0; d.defaultvalue = defaultvalue;
+    double *outp = out_dev ? data_interp : dout.p;
+
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    (void)hipEventRecord(e0, S());
+    if (N_interp > 0)
+        hipLaunchKernelGGL(k_interp, dim3((N_interp + 255) / 256), dim3(256), 0, S(), d, in_dev ? data : (const double *)ddata.p, (const double *)dxi.p,
+                           (const double *)dyi.p, outp, dnext.p);
+    (void)hipEventRecord(e1, S());
+    hipError_t err = hipStreamSynchronize(S());
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (err != hipSuccess) return fail(NXS_ERR_HIP, "interpolation kernel failed: %s", hipGetErrorString(err));
+    g_ms[4] += ms;
+    if (kernel_ms) *kernel_ms = ms;
+    {
+        Tick tk(5);
+        if (!out_dev && N_interp > 0 && copy_sync(data_interp, dout.p, (size_t)N_interp * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
+            return fail(NXS_ERR_HIP, "copy back failed");
+    }
+    int next[4] = {0, 0, 0, 0};
+    (void)copy_sync(next, dnext.p, sizeof next, hipMemcpyDeviceToHost);
+    if (num_exterior) *num_exterior = next[0];
+    g_info[0] = (int)loc.comp.fill.size() / 3; g_info[1] = (int)loc.comp.hull.size();
+    g_info[2] = next[0]; g_info[3] = next[1]; g_info[4] = next[2]; g_info[5] = next[3];
+    g_info[6] = (!isdefault && !loc.comp.ok) ? 1 : 0;
+    g_completion_note = loc.comp.ok ? "" : loc.comp.why;
+    return NXS_OK;
+} catch (...) { return entry_caught("nxs_regrid_interp_nodes"); }
 
 extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *index_data, const double *x_data,
                                           const double *y_data, int32_t nods, int32_t nels, const double *data, int32_t M_data,
@@ -488,49 +762,18 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     if (nods <= 0 || nels <= 0 || N_data <= 0 || N_interp < 0) return fail(NXS_ERR_INVALID, "bad sizes");
     if (M_data != nods && M_data != nels)  // InterpFromMeshToMesh2dx.cpp:39-42
         return fail(NXS_ERR_INVALID, "data provided should have either %d or %d lines (not %d)", nods, nels, M_data);
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the interpolation has no CPU path");
-    if (device < 0 || device >= ndev) return fail(NXS_ERR_INVALID, "device %d out of range", device);
-    if (hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
-    for (int64_t i = 0; i < 3ll * nels; ++i)
-        if (index_data[i] < 1 || index_data[i] > nods) return fail(NXS_ERR_INVALID, "index_data[%lld] out of range", (long long)i);
-
-    Locator loc;
-    if (int rc = loc.build(index_data, x_data, y_data, nods, nels, !isdefault)) return rc;
-    InterpDev d = loc.d;
-    DevBuf<int> dnext;
-    DevBuf<double> ddata, dxi, dyi, dout;
-    if (ddata.upload(data, (size_t)M_data * N_data) || dxi.upload(x_interp, N_interp) || dyi.upload(y_interp, N_interp) ||
-        dout.alloc((size_t)N_interp * N_data) || dnext.alloc(4))
-        return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
-    if (memset_sync(dnext.p, 0, 4 * sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
-    d.N_data = N_data; d.N_interp = N_interp; d.nodal = (M_data == nods);
-    d.isdefault = isdefault != 0; d.defaultvalue = defaultvalue;
-
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    (void)hipEventRecord(e0, S());
-    if (N_interp > 0)
-        hipLaunchKernelGGL(k_interp, dim3((N_interp + 255) / 256), dim3(256), 0, S(), d, (const double *)ddata.p, (const double *)dxi.p,
-                           (const double *)dyi.p, dout.p, dnext.p);
-    (void)hipEventRecord(e1, S());
-    hipError_t err = hipStreamSynchronize(S());
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (err != hipSuccess) return fail(NXS_ERR_HIP, "interpolation kernel failed: %s", hipGetErrorString(err));
-    if (kernel_ms) *kernel_ms = ms;
-    if (N_interp > 0 && copy_sync(data_interp, dout.p, (size_t)N_interp * N_data * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)
-        return fail(NXS_ERR_HIP, "copy back failed");
-    int next[4] = {0, 0, 0, 0};
-    (void)copy_sync(next, dnext.p, sizeof next, hipMemcpyDeviceToHost);
-    if (num_exterior) *num_exterior = next[0];
-    g_info[0] = (int)loc.comp.fill.size() / 3; g_info[1] = (int)loc.comp.hull.size();
-    g_info[2] = next[0]; g_info[3] = next[1]; g_info[4] = next[2]; g_info[5] = next[3];
-    g_info[6] = (!isdefault && !loc.comp.ok) ? 1 : 0;
-    g_completion_note = loc.comp.ok ? "" : loc.comp.why;
-    return NXS_OK;
+    nxs_regrid *r = nullptr;
+    if (int rc = nxs_regrid_create(index_data, x_data, y_data, nods, nels, device, &r)) return rc;
+    const int rc = nxs_regrid_interp_nodes(r, data_interp, data, M_data, N_data, x_interp, y_interp, N_interp, isdefault, defaultvalue, 0, num_exterior, kernel_ms);
+    (void)nxs_regrid_destroy(r);
+    return rc;
 } catch (...) { return entry_caught("nxs_interp_mesh_to_mesh_2d"); }
+
+extern "C" int nxs_interp_last_timing(double *ms8) try {
+    if (!ms8) return fail(NXS_ERR_INVALID, "NULL argument");
+    for (int i = 0; i < 8; ++i) ms8[i] = g_ms[i];
+    return NXS_OK;
+} catch (...) { return entry_caught("nxs_interp_last_timing"); }
 
 extern "C" int nxs_interp_last_info(int32_t *num_fill_triangles, int32_t *num_hull_edges, int32_t *num_exterior, int32_t *num_in_fill,
                                     int32_t *num_on_hull, int32_t *num_stand_in, const char **completion_refused) try {
@@ -649,68 +892,45 @@ __global__ void __launch_bounds__(64) k_remap_big(RemapDev r, const double *__re
 
 }  // namespace
 
-extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *interp_in, int32_t nb_var, const int32_t *index_old,
-                                             const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old,
-                                             const double *nec_old, int32_t nec_width, const double *ec_old, const int32_t *index_new,
-                                             const double *x_new, const double *y_new, int32_t nods_new, int32_t nels_new,
-                                             const double *previous_numbering, int32_t n_geom_vertices, int32_t device,
-                                             int32_t *num_failed, int32_t *visits, double *kernel_ms) try {
-    if (!interp_out || !interp_in || !index_old || !x_old || !y_old || !index_new || !x_new || !y_new) return fail(NXS_ERR_INVALID, "NULL argument");
-    if (nb_var < 1 || nods_old < 3 || nels_old < 1 || nods_new < 3 || nels_new < 1) return fail(NXS_ERR_INVALID, "bad sizes");
+// ConservativeRemappingMeshToMesh on the context's (old) mesh.  flags: NXS_REGRID_IN_DEVICE = interp_in is a device pointer ([nels_old][nb_var]),
+// NXS_REGRID_OUT_DEVICE = interp_out is ([nels_new][nb_var]) -- the element state of nxs_dyn lives on the device already.
+// nec_old / ec_old (may be NULL): bamg's own tables instead of the ones built here.
+extern "C" int nxs_regrid_remap_elements(nxs_regrid *rg, double *interp_out, const double *interp_in, int32_t nb_var, const double *nec_old, int32_t nec_width,
+                                         const double *ec_old, const int32_t *index_new, const double *x_new, const double *y_new, int32_t nods_new,
+                                         int32_t nels_new, const double *previous_numbering, int32_t n_geom_vertices, int32_t flags,
+                                         int32_t *num_failed, int32_t *visits, double *kernel_ms) try {
+    if (!rg || !interp_out || !interp_in || !index_new || !x_new || !y_new) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (nb_var < 1 || nods_new < 3 || nels_new < 1) return fail(NXS_ERR_INVALID, "bad sizes");
     if (nec_old && nec_width < 1) return fail(NXS_ERR_INVALID, "nec_width must be given with the NodalElementConnectivity table");
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(NXS_ERR_NO_DEVICE, "no HIP device visible: the remapping has no CPU path");
-    if (device < 0 || device >= ndev) return fail(NXS_ERR_INVALID, "device %d out of range", device);
-    if (hipSetDevice(device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
-    for (int64_t i = 0; i < 3ll * nels_old; ++i)
-        if (index_old[i] < 1 || index_old[i] > nods_old) return fail(NXS_ERR_INVALID, "index_old[%lld] out of range", (long long)i);
+    if (hipSetDevice(rg->device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
+    const int nods_old = rg->nods, nels_old = rg->nels;
     for (int64_t i = 0; i < 3ll * nels_new; ++i)
         if (index_new[i] < 1 || index_new[i] > nods_new) return fail(NXS_ERR_INVALID, "index_new[%lld] out of range", (long long)i);
-
-    // the two tables checkTriangle walks, as bamg leaves them (doubles, NaN padding); built here when not given
-    std::vector<double> nec_own, ec_own;
-    if (!nec_old) {
-        int32_t w1 = 0, w2 = 0;
-        if (nxs_mesh_connectivity(index_old, nods_old, nels_old, &w1, nullptr, &w2, nullptr)) return fail(NXS_ERR_INVALID, "connectivity of the old mesh failed");
-        nec_own.resize((size_t)nods_old * w1);
-        if (nxs_mesh_connectivity(index_old, nods_old, nels_old, &w1, nec_own.data(), nullptr, nullptr)) return fail(NXS_ERR_INVALID, "connectivity of the old mesh failed");
-        nec_old = nec_own.data();
-        nec_width = w1;
-    }
-    if (!ec_old) {
-        ec_own.resize(3 * (size_t)nels_old);
-        if (nxs_mesh_element_connectivity(index_old, nods_old, nels_old, ec_own.data())) return fail(NXS_ERR_INVALID, "an edge of the old mesh is shared by more than two triangles");
-        ec_old = ec_own.data();
-    }
-    if (nec_width > 255) return fail(NXS_ERR_INVALID, "NodalElementConnectivity wider than 255");
-    std::vector<int> neci((size_t)nods_old * nec_width), eci(3 * (size_t)nels_old), trio(3 * (size_t)nels_old), trin(3 * (size_t)nels_new);
-    auto to_index = [&](double v, int hi) -> int {  // "(int)(v - 1)" of the reference; NaN and junk become "no more entries"
-        if (!(v >= 1.) || !(v <= (double)hi)) return -1;
-        return (int)v - 1;
-    };
-    for (size_t i = 0; i < neci.size(); ++i) neci[i] = to_index(nec_old[i], nels_old);
-    for (size_t i = 0; i < eci.size(); ++i) eci[i] = to_index(ec_old[i], nels_old);
-    for (size_t i = 0; i < trio.size(); ++i) trio[i] = index_old[i] - 1;
-    for (size_t i = 0; i < trin.size(); ++i) trin[i] = index_new[i] - 1;
     if (previous_numbering)
         for (int i = 0; i < nods_new; ++i)
             if (!(previous_numbering[i] >= 0.) || previous_numbering[i] > (double)nods_old) return fail(NXS_ERR_INVALID, "previous_numbering[%d] out of range", i);
-
-    Locator loc;
-    if (int rc = loc.build(index_old, x_old, y_old, nods_old, nels_old, false)) return rc;
-    DevBuf<int> dnec, dec, dtrio, dtrin, dfail, dvis;
-    DevBuf<double> dxo, dyo, dxn, dyn, dprev, din, dout;
-    if (dnec.upload(neci.data(), neci.size()) || dec.upload(eci.data(), eci.size()) || dtrio.upload(trio.data(), trio.size()) ||
-        dtrin.upload(trin.data(), trin.size()) || dxo.upload(x_old, nods_old) || dyo.upload(y_old, nods_old) || dxn.upload(x_new, nods_new) ||
+    for (double &v : g_ms) v = 0.;
+    Tick whole(6);
+    if (int rc = regrid_connectivity(rg, nec_old, nec_width, ec_old)) return rc;
+    Locator *locp = nullptr;
+    if (int rc = regrid_locator(rg, false, &locp)) return rc;
+    Locator &loc = *locp;
+    const bool in_dev = flags & NXS_REGRID_IN_DEVICE, out_dev = flags & NXS_REGRID_OUT_DEVICE;
+    DevBuf<int> dtrin, dfail, dvis;
+    DevBuf<double> dxn, dyn, dprev, din, dout;
+    if (dtrin.upload(index_new, 3 * (size_t)nels_new) || dxn.upload(x_new, nods_new) ||
         dyn.upload(y_new, nods_new) || (previous_numbering && dprev.upload(previous_numbering, nods_new)) ||
-        din.upload(interp_in, (size_t)nels_old * nb_var) || dout.alloc((size_t)nels_new * nb_var) || dfail.alloc(1) || (visits && dvis.alloc(nels_new)))
+        (!in_dev && din.upload(interp_in, (size_t)nels_old * nb_var)) || (!out_dev && dout.alloc((size_t)nels_new * nb_var)) || dfail.alloc(1) || (visits && dvis.alloc(nels_new)))
         return fail(NXS_ERR_HIP, "device allocation / upload failed: %s", hipGetErrorString(hipGetLastError()));
+    hipLaunchKernelGGL(k_add_int, dim3((3 * nels_new + 255) / 256), dim3(256), 0, S(), 3 * nels_new, dtrin.p, -1);
     if (memset_sync(dfail.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "hipMemset failed");
+    const double *inp = in_dev ? interp_in : (const double *)din.p;
+    double *outp = out_dev ? interp_out : dout.p;
 
     RemapDev r{};
     r.loc = loc.d;
     r.loc.isdefault = 1;
-    r.m = nxs_remap::OldMesh{nels_old, nods_old, dtrio.p, dxo.p, dyo.p, dnec.p, nec_width, dec.p};
+    r.m = nxs_remap::OldMesh{nels_old, nods_old, rg->dtrio.p, rg->dxo.p, rg->dyo.p, rg->dnec.p, rg->nec_width, rg->dec.p};
     r.nels_new = nels_new; r.nb_var = nb_var; r.n_geom = n_geom_vertices;
     r.tri_new = dtrin.p; r.xn = dxn.p; r.yn = dyn.p; r.prev = previous_numbering ? dprev.p : nullptr;
 
@@ -722,7 +942,7 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
     DevBuf<double> dbw;
     DevBuf<nxs_remap::Frame> dbs;
     if (dflist.alloc(failed_cap) || dstill.alloc(1) || memset_sync(dstill.p, 0, sizeof(int)) != hipSuccess) return fail(NXS_ERR_HIP, "device allocation failed");
-    hipLaunchKernelGGL(k_remap, dim3((nels_new + 127) / 128), dim3(128), 0, S(), r, (const double *)din.p, dout.p, dfail.p, visits ? dvis.p : nullptr,
+    hipLaunchKernelGGL(k_remap, dim3((nels_new + 127) / 128), dim3(128), 0, S(), r, inp, outp, dfail.p, visits ? dvis.p : nullptr,
                        dflist.p, failed_cap);
     int nf1 = 0;
     if (copy_sync(&nf1, dfail.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
@@ -740,7 +960,7 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
             if (dflist.p && copy_sync(dflist.p, big.data(), big.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return fail(NXS_ERR_HIP, "upload failed");
             if (dbt.alloc(nbig * per) || dbw.alloc(nbig * per) || dbs.alloc(nbig * (per + 1)))
                 return fail(NXS_ERR_HIP, "second remapping pass: %d triangles need %zu MB of lists", nbig, nbig * per * 28 >> 20);
-            hipLaunchKernelGGL(k_remap_big, dim3((nbig + 63) / 64), dim3(64), 0, S(), r, (const double *)din.p, dout.p, (const int *)dflist.p, nbig, dbt.p, dbw.p,
+            hipLaunchKernelGGL(k_remap_big, dim3((nbig + 63) / 64), dim3(64), 0, S(), r, inp, outp, (const int *)dflist.p, nbig, dbt.p, dbw.p,
                                dbs.p, dstill.p, visits ? dvis.p : nullptr);
         }
     }
@@ -750,14 +970,55 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
     (void)hipEventElapsedTime(&ms, e0, e1);
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (err != hipSuccess) return fail(NXS_ERR_HIP, "remapping kernel failed: %s", hipGetErrorString(err));
+    g_ms[4] += ms;
     if (kernel_ms) *kernel_ms = ms;
-    if (copy_sync(interp_out, dout.p, (size_t)nels_new * nb_var * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
-    if (visits && copy_sync(visits, dvis.p, (size_t)nels_new * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    {
+        Tick tk(5);
+        if (!out_dev && copy_sync(interp_out, dout.p, (size_t)nels_new * nb_var * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+        if (visits && copy_sync(visits, dvis.p, (size_t)nels_new * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    }
     int still = 0;
     (void)copy_sync(&still, dstill.p, sizeof(int), hipMemcpyDeviceToHost);
     if (num_failed) *num_failed = unrecoverable + still;
     return NXS_OK;
+} catch (...) { return entry_caught("nxs_regrid_remap_elements"); }
+
+extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *interp_in, int32_t nb_var, const int32_t *index_old,
+                                             const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old,
+                                             const double *nec_old, int32_t nec_width, const double *ec_old, const int32_t *index_new,
+                                             const double *x_new, const double *y_new, int32_t nods_new, int32_t nels_new,
+                                             const double *previous_numbering, int32_t n_geom_vertices, int32_t device,
+                                             int32_t *num_failed, int32_t *visits, double *kernel_ms) try {
+    if (!interp_out || !interp_in || !index_old || !x_old || !y_old || !index_new || !x_new || !y_new) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (nb_var < 1 || nods_old < 3 || nels_old < 1 || nods_new < 3 || nels_new < 1) return fail(NXS_ERR_INVALID, "bad sizes");
+    nxs_regrid *r = nullptr;
+    if (int rc = nxs_regrid_create(index_old, x_old, y_old, nods_old, nels_old, device, &r)) return rc;
+    const int rc = nxs_regrid_remap_elements(r, interp_out, interp_in, nb_var, nec_old, nec_width, ec_old, index_new, x_new, y_new, nods_new, nels_new,
+                                             previous_numbering, n_geom_vertices, 0, num_failed, visits, kernel_ms);
+    (void)nxs_regrid_destroy(r);
+    return rc;
 } catch (...) { return entry_caught("nxs_interp_conservative_remap"); }
+
+// test door: the device-built tables of a context (the bucket grid's offsets and lists; NodalElementConnectivity and ElementConnectivity as ints)
+extern "C" int nxs_regrid_debug_tables(nxs_regrid *rg, int32_t which, int32_t *out, int64_t cap, int64_t *count) try {
+    if (!rg || !count) return fail(NXS_ERR_INVALID, "NULL argument");
+    if (hipSetDevice(rg->device) != hipSuccess) return fail(NXS_ERR_HIP, "hipSetDevice failed");
+    Locator *loc = nullptr;
+    if (which <= 1) { if (int rc = regrid_locator(rg, false, &loc)) return rc; }
+    else if (int rc = regrid_connectivity(rg, nullptr, 0, nullptr)) return rc;
+    const int *src = nullptr; int64_t n = 0;
+    if (which == 0) { src = loc->d.cell_off; n = (int64_t)loc->d.G * loc->d.G + 1; }
+    else if (which == 1) { src = loc->d.cell_tri; int tot = 0; (void)copy_sync(&tot, loc->d.cell_off + (size_t)loc->d.G * loc->d.G, sizeof(int), hipMemcpyDeviceToHost); n = tot; }
+    else if (which == 2) { src = rg->dnec.p; n = (int64_t)rg->nods * rg->nec_width; }
+    else if (which == 3) { src = rg->dec.p; n = 3ll * rg->nels; }
+    else return fail(NXS_ERR_INVALID, "which must be 0 .. 3");
+    *count = n;
+    if (out) {
+        if (cap < n) return fail(NXS_ERR_INVALID, "buffer too small (%lld entries)", (long long)n);
+        if (n > 0 && copy_sync(out, src, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return fail(NXS_ERR_HIP, "copy back failed");
+    }
+    return NXS_OK;
+} catch (...) { return entry_caught("nxs_regrid_debug_tables"); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Structured grid -> mesh nodes: the forcing ingest (InterpFromGridToMeshx, called at externaldata.cpp:1436)

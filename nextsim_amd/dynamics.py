@@ -68,6 +68,7 @@ def load_library():
     L.nxs_dyn_get_state.argtypes = [H, P(_abi.State)]
     L.nxs_dyn_set_forcing.argtypes = [H, P(_abi.Forcing)]
     L.nxs_dyn_get_diag.argtypes = [H, P(_abi.Diag)]
+    L.nxs_dyn_ice_diagnostics.argtypes = [H, P(_abi.IceDiag), P(C.c_void_p)]
     L.nxs_dyn_step.argtypes = [H]
     L.nxs_dyn_explicit_solve.argtypes = [H]
     L.nxs_dyn_update.argtypes = [H]
@@ -106,13 +107,14 @@ EXPORTS = (
     "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_create", "nxs_dyn_destroy",
     "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init", "nxs_dyn_comm_selftest",
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_set_forcing_pair", "nxs_dyn_set_forcing_time",
-    "nxs_dyn_get_diag", "nxs_dyn_step",
+    "nxs_dyn_get_diag", "nxs_dyn_ice_diagnostics", "nxs_dyn_step",
     "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
     "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
     "nxs_dyn_debug_array", "nxs_dyn_get_branch_trace", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
 )
-INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
-                  "nxs_interp_last_error", "nxs_interp_last_info", "nxs_mesh_convex_completion")
+INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_mesh_to_grid_device", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
+                  "nxs_interp_last_error", "nxs_interp_last_info", "nxs_mesh_convex_completion", "nxs_regrid_create", "nxs_regrid_destroy",
+                  "nxs_regrid_interp_nodes", "nxs_regrid_remap_elements", "nxs_interp_last_timing", "nxs_regrid_debug_tables")
 
 
 def mesh_connectivity(indices: np.ndarray, num_nodes: int):
@@ -326,6 +328,20 @@ class FiniteElementDynamics:
             setattr(d, k, _abi.dptr(v))
         self._chk(self.L.nxs_dyn_get_diag(self.h, C.byref(d)))
         return out
+
+    def updateIceDiagnostics(self, want_host: bool = True):
+        """updateIceDiagnostics() (FE.cpp:7860-7905) on the device-resident state.  Returns (dict of host arrays or None, device pointer of the
+        [Ne][6] interleaved rows D_conc, D_thick, D_snow_thick, D_sigma0, D_sigma1, D_divergence -- what interp.InterpFromMeshToGridx_device samples)."""
+        Ne = self.lm.num_elements
+        out, d = None, None
+        if want_host:
+            out = {k: np.empty(Ne) for k in _abi.ICE_DIAG}
+            d = _abi.IceDiag()
+            for k in _abi.ICE_DIAG:
+                setattr(d, k, _abi.dptr(out[k]))
+        dev = C.c_void_p()
+        self._chk(self.L.nxs_dyn_ice_diagnostics(self.h, C.byref(d) if d is not None else None, C.byref(dev)))
+        return out, dev.value
 
     def branch_trace(self) -> dict:
         """The record option "trace_branches" keeps (include/nxs_dyn.h): {'hash', 'damage_substeps', 'flags', 'substeps'}."""

@@ -114,6 +114,29 @@ def InterpFromMeshToGridx(index_mesh, x_mesh, y_mesh, data, xmin, ymax, xposting
     return (out, {"kernel_ms": ms.value}) if return_info else out
 
 
+def InterpFromMeshToGridx_device(index_mesh, x_mesh, y_mesh, data_device_ptr, data_length, N_data, xmin, ymax, xposting, yposting, nrows, ncols,
+                                 default_value, device=0):
+    """InterpFromMeshToGridx with the mesh data already on the device: `data_device_ptr` is a device address of [data_length][N_data]
+    rows (e.g. the second value of FiniteElementDynamics.updateIceDiagnostics)."""
+    L = _lib()
+    if not hasattr(L, "_grid_dev_declared"):
+        L.nxs_interp_mesh_to_grid_device.argtypes = [_abi.c_double_p, _abi.c_int32_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_int32,
+                                                     C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double,
+                                                     C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double)]
+        L.nxs_interp_mesh_to_grid_device.restype = C.c_int
+        L._grid_dev_declared = True
+    index_mesh = np.ascontiguousarray(index_mesh, np.int32).ravel()
+    x_mesh = np.ascontiguousarray(x_mesh, np.float64); y_mesh = np.ascontiguousarray(y_mesh, np.float64)
+    out = np.empty((nrows, ncols, N_data))
+    ms = C.c_double(0.0)
+    rc = L.nxs_interp_mesh_to_grid_device(_abi.dptr(out), _abi.iptr(index_mesh), _abi.dptr(x_mesh), _abi.dptr(y_mesh), x_mesh.size,
+                                          index_mesh.size // 3, C.c_void_p(data_device_ptr), int(data_length), int(N_data), float(xmin), float(ymax),
+                                          float(xposting), float(yposting), int(nrows), int(ncols), float(default_value), device, C.byref(ms))
+    if rc:
+        raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
+    return out
+
+
 def ConservativeRemappingMeshToMesh(interp_in, index_old, x_old, y_old, index_new, x_new, y_new, previous_numbering=None,
                                     n_geom_vertices=0, nec_old=None, ec_old=None, device=0, return_info=False):
     """Element variables old mesh -> new mesh, argument meaning of contrib/bamg's ConservativeRemappingMeshToMesh
@@ -149,6 +172,127 @@ def ConservativeRemappingMeshToMesh(interp_in, index_old, x_old, y_old, index_ne
     if return_info:
         return out, {"num_failed": nfail.value, "visits": visits, "kernel_ms": ms.value}
     return out
+
+
+def last_timing() -> dict:
+    """Where this thread's last regrid call spent its time (ms)."""
+    L = _lib()
+    v = (C.c_double * 8)()
+    L.nxs_interp_last_timing.argtypes = [C.POINTER(C.c_double)]
+    L.nxs_interp_last_timing(v)
+    keys = ("connectivity_ms", "plane_and_grid_ms", "completion_ms", "h2d_ms", "kernel_ms", "d2h_ms", "call_ms")
+    return {k: float(v[i]) for i, k in enumerate(keys)}
+
+
+class Regrid:
+    """A regrid's context (include/nxs_interp.h, nxs_regrid_*): the OLD mesh's search tables -- integer plane, bucket grid, convex completion,
+    the two connectivity tables -- built once, on the device, and shared by interpFields' two interpolation calls (FE.cpp:3071-3154)."""
+
+    IN_DEVICE, OUT_DEVICE = 1, 2
+
+    def __init__(self, index_old, x_old, y_old, device=0):
+        L = self.L = _lib()
+        if not hasattr(L, "_regrid_declared"):
+            D, I, V = _abi.c_double_p, _abi.c_int32_p, C.c_void_p
+            L.nxs_regrid_create.argtypes = [I, D, D, C.c_int32, C.c_int32, C.c_int32, C.POINTER(V)]
+            L.nxs_regrid_destroy.argtypes = [V]
+            L.nxs_regrid_interp_nodes.argtypes = [V, V, V, C.c_int32, C.c_int32, D, D, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+            L.nxs_regrid_remap_elements.argtypes = [V, V, V, C.c_int32, D, C.c_int32, D, I, D, D, C.c_int32, C.c_int32, D, C.c_int32, C.c_int32,
+                                                    C.POINTER(C.c_int32), I, C.POINTER(C.c_double)]
+            L.nxs_regrid_debug_tables.argtypes = [V, C.c_int32, I, C.c_int64, C.POINTER(C.c_int64)]
+            for n in ("nxs_regrid_create", "nxs_regrid_destroy", "nxs_regrid_interp_nodes", "nxs_regrid_remap_elements", "nxs_regrid_debug_tables"):
+                getattr(L, n).restype = C.c_int
+            L._regrid_declared = True
+        self.index = np.ascontiguousarray(index_old, np.int32).ravel()
+        self.x = np.ascontiguousarray(x_old, np.float64); self.y = np.ascontiguousarray(y_old, np.float64)
+        self.h = C.c_void_p()
+        rc = L.nxs_regrid_create(_abi.iptr(self.index), _abi.dptr(self.x), _abi.dptr(self.y), self.x.size, self.index.size // 3, device, C.byref(self.h))
+        if rc:
+            raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.nxs_regrid_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise NxsError(rc, (self.L.nxs_interp_last_error() or b"").decode())
+
+    def interp_nodes(self, data, x_interp, y_interp, isdefault=False, defaultvalue=1e-24, data_device=None, out_device=None, return_info=False):
+        """InterpFromMeshToMesh2dx.  data_device = (device pointer, M_data, N_data) instead of `data`; out_device = a device pointer for the result."""
+        x_interp = np.ascontiguousarray(x_interp, np.float64); y_interp = np.ascontiguousarray(y_interp, np.float64)
+        flags = 0
+        if data_device is not None:
+            dptr, M, N = data_device
+            src = C.c_void_p(dptr); flags |= self.IN_DEVICE
+        else:
+            data = np.ascontiguousarray(data, np.float64)
+            if data.ndim == 1:
+                data = data[:, None]
+            M, N = data.shape
+            src = C.c_void_p(data.ctypes.data)
+        out = None
+        if out_device is not None:
+            dst = C.c_void_p(out_device); flags |= self.OUT_DEVICE
+        else:
+            out = np.empty((x_interp.size, N))
+            dst = C.c_void_p(out.ctypes.data)
+        next_, ms = C.c_int32(0), C.c_double(0.0)
+        self._chk(self.L.nxs_regrid_interp_nodes(self.h, dst, src, M, N, _abi.dptr(x_interp), _abi.dptr(y_interp), x_interp.size, int(bool(isdefault)),
+                                                 float(defaultvalue), flags, C.byref(next_), C.byref(ms)))
+        if return_info:
+            return out, dict(last_info(), num_exterior=next_.value, kernel_ms=ms.value, timing=last_timing())
+        return out
+
+    def remap_elements(self, interp_in, index_new, x_new, y_new, previous_numbering=None, n_geom_vertices=0, nec_old=None, ec_old=None,
+                       in_device=None, out_device=None, return_info=False):
+        """ConservativeRemappingMeshToMesh.  in_device = (device pointer, nb_var) instead of `interp_in`; out_device = a device pointer for the result."""
+        f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
+        index_new = np.ascontiguousarray(index_new, np.int32).ravel()
+        x_new, y_new = f64(x_new), f64(y_new)
+        flags = 0
+        if in_device is not None:
+            dptr, nv = in_device
+            src = C.c_void_p(dptr); flags |= self.IN_DEVICE
+        else:
+            interp_in = f64(interp_in)
+            if interp_in.ndim == 1:
+                interp_in = interp_in[:, None]
+            nv = interp_in.shape[1]
+            src = C.c_void_p(interp_in.ctypes.data)
+        ne_new = index_new.size // 3
+        out = None
+        if out_device is not None:
+            dst = C.c_void_p(out_device); flags |= self.OUT_DEVICE
+        else:
+            out = np.empty((ne_new, nv))
+            dst = C.c_void_p(out.ctypes.data)
+        visits = np.zeros(ne_new, np.int32)
+        prev = None if previous_numbering is None else f64(previous_numbering)
+        nec = None if nec_old is None else f64(nec_old)
+        ec = None if ec_old is None else f64(ec_old)
+        nfail, ms = C.c_int32(0), C.c_double(0.0)
+        self._chk(self.L.nxs_regrid_remap_elements(self.h, dst, src, nv, None if nec is None else _abi.dptr(nec), 0 if nec is None else nec.shape[1],
+                                                   None if ec is None else _abi.dptr(ec), _abi.iptr(index_new), _abi.dptr(x_new), _abi.dptr(y_new), x_new.size, ne_new,
+                                                   None if prev is None else _abi.dptr(prev), int(n_geom_vertices), flags, C.byref(nfail), _abi.iptr(visits), C.byref(ms)))
+        if return_info:
+            return out, {"num_failed": nfail.value, "visits": visits, "kernel_ms": ms.value, "timing": last_timing()}
+        return out
+
+    def debug_table(self, which: int) -> np.ndarray:
+        """0 bucket-grid offsets, 1 its lists, 2 NodalElementConnectivity, 3 ElementConnectivity -- as the device built them (ints, -1 = NaN)."""
+        n = C.c_int64(0)
+        self._chk(self.L.nxs_regrid_debug_tables(self.h, which, None, 0, C.byref(n)))
+        out = np.empty(max(n.value, 1), np.int32)
+        self._chk(self.L.nxs_regrid_debug_tables(self.h, which, _abi.iptr(out), out.size, C.byref(n)))
+        return out[:n.value]
 
 
 TRIANGLE, BILINEAR, NEAREST = 0, 1, 2

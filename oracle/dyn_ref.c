@@ -1036,6 +1036,47 @@ int ref_mesh_connectivity(const int32_t *indices, int32_t Nn, int32_t Ne,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* updateIceDiagnostics(), FE.cpp:7860-7905 (D_tsurf and the FSD parameters excepted: thermodynamic / OASIS variables).  out[k] may be NULL. */
+void ref_ice_diagnostics(const nxs_dyn_mesh *m, const nxs_dyn_params *p, const nxs_dyn_state *s, double *D_conc, double *D_thick,
+                         double *D_snow_thick, double *D_sigma0, double *D_sigma1, double *D_divergence) {
+    int const Nn = m->num_nodes;
+    for (int i = 0; i < m->num_elements; i++) {
+        double dc = s->conc[i], dt = s->thick[i], ds = s->snow_thick[i];   /* :7872-7874 */
+        if (p->ice_cat_type == NXS_ICECAT_YOUNG_ICE) {                       /* :7876-7882 */
+            dc += s->conc_young[i];
+            dt += s->h_young[i];
+            ds += s->hs_young[i];
+        }
+        if (D_conc) D_conc[i] = dc;
+        if (D_thick) D_thick[i] = dt;
+        if (D_snow_thick) D_snow_thick[i] = ds;
+        /* principal stresses, :7885-7887 */
+        if (D_sigma0) D_sigma0[i] = (s->sigma[0][i] + s->sigma[1][i]) / 2.;
+        if (D_sigma1) D_sigma1[i] = hypot((s->sigma[0][i] - s->sigma[1][i]) / 2., s->sigma[2][i]);
+        /* divergence, :7889-7900: shapeCoeff on the mesh displaced by M_UM (FE.cpp:1951-1964, 1613-1618) */
+        if (D_divergence) {
+            double vx[3], vy[3];
+            for (int j = 0; j < 3; j++) {
+                int const n = m->indices[3 * i + j] - 1;
+                vx[j] = m->coord_x[n] + 1. * s->UM[n];
+                vy[j] = m->coord_y[n] + 1. * s->UM[n + Nn];
+            }
+            double jac = (vx[1] - vx[0]) * (vy[2] - vy[0]);
+            jac -= (vx[2] - vx[0]) * (vy[1] - vy[0]);
+            double div = 0.;
+            for (int j = 0; j < 3; j++) {
+                int const n = m->indices[3 * i + j] - 1;
+                int const kp1 = (j + 1) % 3, kp2 = (j + 2) % 3;
+                double const dxN = (vy[kp1] - vy[kp2]) / jac, dyN = (vx[kp2] - vx[kp1]) / jac;
+                double const u = s->VT[n], v = s->VT[n + Nn];
+                div += dxN * u + dyN * v;
+            }
+            D_divergence[i] = div;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* P in-process ranks stepped in lock-step by a pool of threads: the CPU analogue of the reference's MPI run (one partition per
  * core, every updateGhosts(M_VT) of FE.cpp:10425-10611 a shared-memory exchange between two barriers), used by bench.py's
  * cpu_baseline leg and checked against the serial multirank_step of oracle/pyoracle.py (tests/test_multirank_oracle.py).

@@ -92,6 +92,10 @@ int ref_check_regridding(const nxs_dyn_mesh *m, const nxs_dyn_params *p, const n
                          double *min_angle, int32_t *flip);            /* FE.cpp:8298-8309 */
 int ref_check_fields_fast(const nxs_dyn_mesh *m, const nxs_dyn_params *p, const nxs_dyn_state *s); /* :14536 */
 
+/* updateIceDiagnostics(), FE.cpp:7860-7905 (without D_tsurf / FSD); NULL outputs are skipped */
+void ref_ice_diagnostics(const nxs_dyn_mesh *m, const nxs_dyn_params *p, const nxs_dyn_state *s, double *D_conc, double *D_thick,
+                         double *D_snow_thick, double *D_sigma0, double *D_sigma1, double *D_divergence);
+
 /* updateGhosts() halves (FE.cpp:13963-13996): pack what I send to neighbour k / unpack what k sent */
 void ref_ghosts_pack(const nxs_dyn_halo *h, int32_t Nn, const double *vec, int k, double *buf);
 void ref_ghosts_unpack(const nxs_dyn_halo *h, int32_t Nn, double *vec, int k, const double *buf);

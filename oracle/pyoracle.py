@@ -73,6 +73,7 @@ def lib(fast: bool = False):
     L.ref_mesh_connectivity.argtypes = [_abi.c_int32_p, C.c_int32, C.c_int32, P(C.c_int32), _abi.c_double_p,
                                         P(C.c_int32), _abi.c_double_p]
     L.ref_mesh_connectivity.restype = C.c_int
+    L.ref_ice_diagnostics.argtypes = [Mp, Pp, Sp] + [_abi.c_double_p] * 6
     L.ref_multirank_steps.argtypes = [C.c_int, P(Mp), Pp, P(Sp), P(Fp), P(Wp), P(P(_abi.Halo)), C.c_int, C.c_int]
     L.ref_multirank_steps.restype = C.c_int
     _libs[fast] = L
@@ -178,6 +179,12 @@ class OracleRank:
 
     def update_sigma_damage(self, dt):
         m, p, s, f, w = self._a(); self.L.ref_update_sigma_damage(m, p, s, w, dt)
+
+    def ice_diagnostics(self) -> dict:
+        """updateIceDiagnostics(), FE.cpp:7860-7905 (without D_tsurf / FSD)."""
+        out = {k: np.empty(self.lm.num_elements) for k in _abi.ICE_DIAG}
+        self.L.ref_ice_diagnostics(C.byref(self.mesh), C.byref(self.params), C.byref(self.state), *[_abi.dptr(out[k]) for k in _abi.ICE_DIAG])
+        return out
 
     def check_regridding(self):
         m, p, s, f, w = self._a()

@@ -220,6 +220,36 @@ def test_check_regridding_and_fields_fast():
     fe.close()
 
 
+def test_ice_diagnostics_kernel_and_a_moorings_record_from_device_arrays():
+    """K14 updateIceDiagnostics (FE.cpp:7860-7905) as a kernel on the device-resident state -- sigma read from the records the sub-step loop leaves
+    behind, the divergence from shapeCoeff on the displaced mesh: bit for bit the oracle's restatement on the SAME state, D_sigma[1] to an ulp
+    (OCML's hypot against glibc's).  And the Moorings sampling (gridoutput.cpp:496) fed from the device rows gives, bit for bit, the grid it gives
+    from the host arrays: a record needs no round trip of the element state."""
+    from nextsim_amd import interp
+    fe, ref, lm = _pair("small", 2)
+    got = fe.get_state()
+    host, dev = fe.updateIceDiagnostics()
+    only_dev, dev2 = fe.updateIceDiagnostics(want_host=False)
+    assert only_dev is None and dev2 == dev and dev
+    # the oracle's diagnostics of the DEVICE's state (the two states differ in the last bits after two steps)
+    from oracle import pyoracle as O
+    f = dict(ref.arr); f.update({k: got[k] for k in got})
+    want = O.OracleRank(lm, fe.params, f).ice_diagnostics()
+    for k in ("D_conc", "D_thick", "D_snow_thick", "D_sigma0", "D_divergence"):
+        assert np.array_equal(host[k], want[k]), k
+    np.testing.assert_allclose(host["D_sigma1"], want["D_sigma1"], rtol=4e-16, atol=0)
+    assert np.abs(host["D_divergence"]).max() > 0 and np.abs(host["D_sigma1"]).max() > 0
+    tri = lm.indices.reshape(-1, 3)
+    x0, x1, y0, y1 = lm.coord_x.min(), lm.coord_x.max(), lm.coord_y.min(), lm.coord_y.max()
+    nrows, ncols = 120, 90
+    args = (x0, y1, (x1 - x0) / (nrows - 1), (y1 - y0) / (ncols - 1), nrows, ncols, -1e14)
+    rows = np.column_stack([host[k] for k in ("D_conc", "D_thick", "D_snow_thick", "D_sigma0", "D_sigma1", "D_divergence")])
+    a = interp.InterpFromMeshToGridx(tri, lm.coord_x, lm.coord_y, rows, *args)
+    b = interp.InterpFromMeshToGridx_device(tri, lm.coord_x, lm.coord_y, dev, lm.num_elements, 6, *args)
+    assert np.array_equal(a, b) and (a[..., 0] != -1e14).mean() > 0.3
+    fe.close()
+
+
 def test_step_host_drop_in():
     """nxs_dyn_step_host = the three lines of FiniteElement::step() on host vectors."""
     import ctypes as C

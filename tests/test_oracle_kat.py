@@ -407,3 +407,34 @@ def test_mirror_image_is_the_other_hemisphere():
     lmw = dataclasses.replace(lmm, lat=lm.lat)
     c = O.OracleRank(lmw, p, fm); c.step()
     assert np.abs(c.arr["VT"] - mir(a.arr["VT"])).max() > 1e-6 * np.abs(a.arr["VT"]).max()
+
+
+def test_ice_diagnostics_known_answer():
+    """updateIceDiagnostics (FE.cpp:7860-7905) on one triangle by hand: totals over the categories, the principal stresses of a diagonal + shear
+    stress state, and the divergence of u = (a x, b y) -- exactly a + b on any triangle, displaced or not (P1 reproduces linear fields)."""
+    x = np.array([0., 1000., 0.]); y = np.array([0., 0., 2000.])
+    if True:
+        from nextsim_amd import mesh as M
+        gm = M.GlobalMesh(x=x, y=y, tri=np.array([[0, 1, 2]], np.int32), dirichlet=np.zeros(3, bool), neumann=np.zeros(3, bool), lat=np.full(3, 80.), name="one")
+        lm = M.localize(gm, 1)[0]
+    from nextsim_amd import forcing as F
+    p = F.default_params()
+    Nn = 3
+    f = {k: np.zeros(2 * Nn) for k in ("VT", "UM", "UT", "wind", "ocean")}
+    f.update({k: np.zeros(1) for k in ("conc", "thick", "snow_thick", "damage", "ridge_ratio", "sigma0", "sigma1", "sigma2", "conc_young", "h_young", "hs_young",
+                                       "conc_myi", "thick_myi", "cohesion", "time_relaxation_damage", "drag_ui", "drag_ui_young", "element_depth")})
+    f["ssh"] = np.zeros(Nn)
+    f["conc"][:] = 0.7; f["conc_young"][:] = 0.2; f["thick"][:] = 1.4; f["h_young"][:] = 0.05; f["snow_thick"][:] = 0.1; f["hs_young"][:] = 0.01
+    f["sigma0"][:] = 300.; f["sigma1"][:] = -100.; f["sigma2"][:] = 150.
+    f["UM"][:] = np.array([10., -20., 5., 7., 3., -8.])           # the mesh has moved: the divergence is taken on x0 + UM
+    a, b = 2e-6, -5e-7
+    X = x + f["UM"][:Nn]; Y = y + f["UM"][Nn:]
+    f["VT"][:Nn] = a * X; f["VT"][Nn:] = b * Y
+    r = O.OracleRank(lm, p, f)
+    d = r.ice_diagnostics()
+    assert d["D_conc"][0] == 0.7 + 0.2 and d["D_thick"][0] == 1.4 + 0.05 and d["D_snow_thick"][0] == 0.1 + 0.01
+    assert d["D_sigma0"][0] == 100. and d["D_sigma1"][0] == np.hypot(200., 150.) == 250.
+    assert abs(d["D_divergence"][0] - (a + b)) <= 1e-15 * abs(a)
+    q = p.copy(); q.ice_cat_type = 0                               # classic categories: the young ice does not count
+    d = O.OracleRank(lm, q, f).ice_diagnostics()
+    assert d["D_conc"][0] == 0.7 and d["D_thick"][0] == 1.4 and d["D_snow_thick"][0] == 0.1

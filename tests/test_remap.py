@@ -240,3 +240,67 @@ def test_gpu_regrid_kernels_match_the_reference_on_a_real_regrid():
     assert info["num_failed"] == 0 and _same(out, z["elt_out"])
     nod, ninfo = InterpFromMeshToMesh2dx(z["tri_old"] + 1, z["x_old"], z["y_old"], z["nod_in"], z["x_new"], z["y_new"], False, return_info=True)
     assert np.array_equal(nod, z["nod_out"])      # every vertex of the new mesh, its boundary vertices included
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["small", "40km", "holes"])
+def test_device_built_regrid_tables_equal_the_host_built_ones_and_a_context_serves_both_calls(kind):
+    """The regrid context (nxs_regrid_*): the bucket grid of the exact locator and the two connectivity tables checkTriangle walks are built ON
+    THE DEVICE (count -> scan -> fill with atomic cursors -> per-row sort): entry for entry the tables the host code builds -- NodalElementConnectivity
+    (descending fans) and ElementConnectivity against nxs_mesh_connectivity / nxs_mesh_element_connectivity (which are checked against the real
+    bamg), the grid against a numpy restatement of its definition.  One context then serves the conservative remapping AND the nodal
+    interpolation of a regrid (FE.cpp:3071-3154), host or device-resident data, with the bits of the one-shot calls."""
+    import ctypes as C
+    from nextsim_amd import dynamics, interp
+    if kind == "holes":
+        x, y, tri = cases.mesh_with_holes("small")
+    else:
+        gm = cases.global_mesh(kind); x, y, tri = gm.x, gm.y, gm.tri
+    nods, nels = x.size, tri.shape[0]
+    idx = np.ascontiguousarray((tri + 1).ravel(), np.int32)
+    rg = interp.Regrid(idx, x, y)
+    # connectivity
+    nec, _ = dynamics.mesh_connectivity(idx, nods)
+    want_nec = np.where(np.isnan(nec), 0, nec).astype(np.int32) - 1
+    assert np.array_equal(rg.debug_table(2).reshape(nods, -1), want_nec)
+    ec = dynamics.mesh_element_connectivity(idx, nods)
+    assert np.array_equal(rg.debug_table(3).reshape(nels, 3), np.where(np.isnan(ec), 0, ec).astype(np.int32) - 1)
+    # bucket grid: bamg's integer plane (bbox + 5 %, 2^30 - 1 units, truncation), G x G cells, every triangle listed in the cells its bounding box touches, ascending
+    off, lst = rg.debug_table(0), rg.debug_table(1)
+    G = int(round(np.sqrt(off.size - 1)))
+    assert G * G + 1 == off.size and off[0] == 0 and off[-1] == lst.size and np.all(np.diff(off) >= 0)
+    px0, px1, py0, py1 = x.min(), x.max(), y.min(), y.max()
+    dx, dy = (px1 - px0) * 0.05, (py1 - py0) * 0.05
+    px0 -= dx; py0 -= dy; px1 += dx; py1 += dy
+    coef = 1073741823. / max(px1 - px0, py1 - py0)
+    ix = (coef * (x - px0)).astype(np.int64); iy = (coef * (y - py0)).astype(np.int64)
+    shift = 30 - int(np.log2(G))
+    cx0 = np.clip(ix[tri].min(1) >> shift, 0, G - 1); cx1 = np.clip(ix[tri].max(1) >> shift, 0, G - 1)
+    cy0 = np.clip(iy[tri].min(1) >> shift, 0, G - 1); cy1 = np.clip(iy[tri].max(1) >> shift, 0, G - 1)
+    assert lst.size == int(((cx1 - cx0 + 1) * (cy1 - cy0 + 1)).sum())
+    rng = np.random.default_rng(0)
+    for c in rng.integers(0, G * G, 400):
+        cy, cx = divmod(int(c), G)
+        want = np.flatnonzero((cx0 <= cx) & (cx <= cx1) & (cy0 <= cy) & (cy <= cy1))
+        assert np.array_equal(lst[off[c]:off[c + 1]], want), c
+    # one context, both calls of a regrid; then again with the data resident on the device
+    xn, yn, trin, ng = cases.rect_mesh(9, 3, L=0.5 * np.ptp(x), H=0.4 * np.ptp(y), x0=x.mean() - 0.25 * np.ptp(x), y0=y.mean() - 0.2 * np.ptp(y))
+    inside = np.ones(trin.shape[0], bool)
+    elem = rng.random((nels, 5)); nodal = rng.standard_normal((nods, 3))
+    a1 = rg.remap_elements(elem, trin + 1, xn, yn, np.zeros(xn.size), ng)
+    a2 = rg.interp_nodes(nodal, xn, yn, False, 0.0)
+    b1 = interp.ConservativeRemappingMeshToMesh(elem, idx, x, y, trin + 1, xn, yn, np.zeros(xn.size), ng)
+    b2 = interp.InterpFromMeshToMesh2dx(idx, x, y, nodal, xn, yn, False, 0.0)
+    assert np.array_equal(a1, b1, equal_nan=True) and np.array_equal(a2, b2)
+    L = dynamics.load_library()
+    L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; L.hipFree.argtypes = [C.c_void_p]
+    L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    d_in, d_out = C.c_void_p(), C.c_void_p()
+    assert L.hipMalloc(C.byref(d_in), elem.nbytes) == 0 and L.hipMalloc(C.byref(d_out), a1.nbytes) == 0
+    assert L.hipMemcpy(d_in, elem.ctypes.data, elem.nbytes, 1) == 0
+    rg.remap_elements(None, trin + 1, xn, yn, np.zeros(xn.size), ng, in_device=(d_in.value, elem.shape[1]), out_device=d_out.value)
+    back = np.empty_like(a1)
+    assert L.hipMemcpy(back.ctypes.data, d_out, back.nbytes, 2) == 0
+    assert np.array_equal(back, a1, equal_nan=True)
+    L.hipFree(d_in); L.hipFree(d_out)
+    rg.close()
