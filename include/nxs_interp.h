@@ -132,6 +132,11 @@ NXS_INTERP_API int nxs_interp_last_info(int32_t *num_fill_triangles, int32_t *nu
 NXS_INTERP_API int nxs_mesh_convex_completion(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
                                               int32_t *num_fill, int32_t *fill_tri, int32_t cap_fill, int32_t *num_hull,
                                               int32_t *hull_edges, int32_t cap_hull);
+/* mode: 0 = as above (the pocket construction; where it does not apply -- several components, a boundary that pinches -- the general one: the
+ * constrained Delaunay triangulation of the boundary vertices minus the domain), 1 = the general construction, 2 = the pocket construction only */
+NXS_INTERP_API int nxs_mesh_convex_completion_mode(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
+                                              int32_t *num_fill, int32_t *fill_tri, int32_t cap_fill, int32_t *num_hull,
+                                              int32_t *hull_edges, int32_t cap_hull, int32_t mode);
 
 NXS_INTERP_API const char *nxs_interp_last_error(void);
 

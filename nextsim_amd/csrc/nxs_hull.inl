@@ -299,4 +299,265 @@ inline Completion complete(const int32_t *index, const int *ix, const int *iy, i
     return out;
 }
 
+// ------------------------------------------------------------------------------------------------
+// The general case: a mesh with several components, or whose boundary pinches (a vertex with more than one outgoing boundary edge), has no
+// "outer loop with pockets".  What bamg builds there is still the same object -- the Delaunay triangulation of the boundary vertices with every
+// boundary edge forced, minus the triangles inside the domain (Mesh.cpp:3262-3328) -- so it is built that way: incremental Delaunay in
+// lexicographic order (every new vertex lies outside the hull of the earlier ones: each hull edge it sees gets a triangle, Lawson flips
+// restore the empty-circle property), the boundary edges that are missing recovered by flipping the edges they cross (Sloan), the free edges
+// made Delaunay again, and a flood fill from the boundary edges (the domain is on the left of each) that tells the fill triangles from the
+// domain's.  Exact integer predicates throughout.  On the meshes the pocket construction above covers both give the same triangles (tested).
+struct CDT {
+    typedef std::pair<int, int> E;
+    const Pts &P;
+    std::vector<int> t;        // 3 per triangle, counter-clockwise
+    std::map<E, int> half;     // directed edge -> 3 * triangle + position of its first vertex
+    std::map<E, char> fixed;   // forced edges, as (min, max)
+    explicit CDT(const Pts &p) : P(p) {}
+    static E und(int a, int b) { return a < b ? E{a, b} : E{b, a}; }
+    int add(int a, int b, int c) {
+        const int i = (int)t.size() / 3;
+        t.push_back(a); t.push_back(b); t.push_back(c);
+        half[{a, b}] = 3 * i; half[{b, c}] = 3 * i + 1; half[{c, a}] = 3 * i + 2;
+        return i;
+    }
+    // flips the edge {a, b} when both triangles exist and their quadrilateral is strictly convex; the new diagonal is (c, d)
+    bool flip(int a, int b, int &c, int &d) {
+        const auto h = half.find({a, b}), o = half.find({b, a});
+        if (h == half.end() || o == half.end()) return false;
+        const int i = h->second / 3, ki = h->second % 3, j = o->second / 3, kj = o->second % 3;
+        c = t[3 * i + (ki + 2) % 3]; d = t[3 * j + (kj + 2) % 3];  // a, b, c and b, a, d
+        if (P.orient(c, a, d) <= 0 || P.orient(d, b, c) <= 0) return false;
+        half.erase({a, b}); half.erase({b, a});
+        t[3 * i] = c; t[3 * i + 1] = a; t[3 * i + 2] = d;
+        t[3 * j] = d; t[3 * j + 1] = b; t[3 * j + 2] = c;
+        half[{c, a}] = 3 * i; half[{a, d}] = 3 * i + 1; half[{d, c}] = 3 * i + 2;
+        half[{d, b}] = 3 * j; half[{b, c}] = 3 * j + 1; half[{c, d}] = 3 * j + 2;
+        return true;
+    }
+    // Lawson: flips the listed free edges (and what the flips disturb) until each is locally Delaunay
+    bool lawson(std::vector<E> &work) {
+        long long guard = 64ll * (long long)(t.size() / 3 + 16) * 64;
+        while (!work.empty()) {
+            if (guard-- <= 0) return false;
+            const E e = work.back();
+            work.pop_back();
+            if (fixed.count(und(e.first, e.second))) continue;
+            const auto h = half.find({e.first, e.second}), o = half.find({e.second, e.first});
+            if (h == half.end() || o == half.end()) continue;
+            const int a = e.first, b = e.second;
+            const int c = t[3 * (h->second / 3) + (h->second % 3 + 2) % 3], d = t[3 * (o->second / 3) + (o->second % 3 + 2) % 3];
+            if (!P.in_circle(a, b, c, d)) continue;
+            int c2, d2;
+            if (!flip(a, b, c2, d2)) continue;
+            work.push_back({c, a}); work.push_back({a, d}); work.push_back({d, b}); work.push_back({b, c});
+        }
+        return true;
+    }
+};
+
+// index: 1-based triangles; the general construction (see above).  Same output as complete().
+inline Completion complete_general(const int32_t *index, const int *ix, const int *iy, int nods, int nels) {
+    Completion out;
+    const Pts P{ix, iy};
+    typedef CDT::E E;
+    static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+    std::vector<int> bnd;
+    if (!find_boundary_edges(index, nods, nels, bnd)) { out.why = "an edge belongs to more than two triangles"; return out; }
+    if (bnd.size() < 3) { out.why = "no boundary"; return out; }
+    std::map<E, int> etri;  // directed boundary edge p -> q (domain on its left) -> 3 * triangle + k
+    std::vector<int> pts;
+    {
+        std::vector<char> isb(nods, 0);
+        for (int be : bnd) {
+            const int e = be / 3, k = be % 3;
+            const int p = index[3 * e + VOTE[k][0]] - 1, q = index[3 * e + VOTE[k][1]] - 1;
+            etri[{p, q}] = be;
+            isb[p] = isb[q] = 1;
+        }
+        for (int i = 0; i < nods; ++i) if (isb[i]) pts.push_back(i);
+    }
+    std::sort(pts.begin(), pts.end(), [&](int p, int q) { return ix[p] != ix[q] ? ix[p] < ix[q] : iy[p] < iy[q]; });
+    for (size_t i = 1; i < pts.size(); ++i)
+        if (ix[pts[i]] == ix[pts[i - 1]] && iy[pts[i]] == iy[pts[i - 1]]) { out.why = "two boundary vertices share one integer point"; return out; }
+    const int n = (int)pts.size();
+    // ---- incremental Delaunay of the boundary vertices in lexicographic order
+    CDT T(P);
+    int apex = 2;  // the first vertex not collinear with pts[0], pts[1]
+    while (apex < n && P.orient(pts[0], pts[1], pts[apex]) == 0) ++apex;
+    if (apex >= n) { out.why = "every boundary vertex lies on one line"; return out; }
+    std::vector<int> hnext(n, -1), hprev(n, -1);  // the hull, counter-clockwise, as a circular list over the positions in pts
+    {
+        // the collinear run pts[0 .. apex-1] (ascending along its line) and the apex: a fan of triangles
+        const bool left = P.orient(pts[0], pts[1], pts[apex]) > 0;
+        for (int i = 0; i + 1 < apex; ++i) { if (left) T.add(pts[i], pts[i + 1], pts[apex]); else T.add(pts[i + 1], pts[i], pts[apex]); }
+        std::vector<int> cyc;
+        if (left) { for (int i = 0; i < apex; ++i) cyc.push_back(i); }
+        else { for (int i = apex - 1; i >= 0; --i) cyc.push_back(i); }
+        cyc.push_back(apex);
+        const int m = (int)cyc.size();
+        for (int i = 0; i < m; ++i) { hnext[cyc[i]] = cyc[(i + 1) % m]; hprev[cyc[(i + 1) % m]] = cyc[i]; }
+    }
+    std::vector<E> work;
+    int last = apex;  // the newest vertex: always on the hull, and a new vertex always sees an edge next to it or beyond
+    for (int i = apex + 1; i < n; ++i) {
+        const int p = pts[i];
+        auto visible = [&](int h) { return P.orient(pts[h], pts[hnext[h]], p) < 0; };
+        int e0 = -1, steps = 0;
+        for (int h = hprev[last]; steps <= n + 1; h = hnext[h], ++steps) if (visible(h)) { e0 = h; break; }
+        if (e0 < 0) { out.why = "internal: no hull edge visible from a new boundary vertex"; return out; }
+        int lo = e0, hi = e0;  // the strictly visible edges are one chain lo .. hi
+        while (hprev[lo] != hi && visible(hprev[lo])) lo = hprev[lo];
+        while (hnext[hi] != lo && visible(hnext[hi])) hi = hnext[hi];
+        const int end = hnext[hi];
+        for (int h = lo; h != end;) {
+            const int nx = hnext[h];
+            T.add(pts[nx], pts[h], p);   // (b, a, p) for the hull edge a -> b: counter-clockwise
+            work.push_back({pts[h], pts[nx]});
+            if (h != lo) { hnext[h] = -1; hprev[h] = -1; }
+            h = nx;
+        }
+        hnext[lo] = i; hprev[i] = lo; hnext[i] = end; hprev[end] = i;
+        last = i;
+        if (!T.lawson(work)) { out.why = "internal: Delaunay flips do not terminate"; return out; }
+    }
+    // ---- force the boundary edges (Sloan: flip what crosses a missing edge until it appears)
+    std::vector<E> loosened;
+    for (const auto &kv : etri) {
+        const int p = kv.first.first, q = kv.first.second;
+        long long guard = 8ll * n + 64;
+        while (!T.half.count({p, q}) && !T.half.count({q, p})) {
+            if (guard-- <= 0) { out.why = "a boundary edge could not be recovered in the triangulation of the boundary vertices (crossing boundary edges?)"; return out; }
+            // the triangle at p the segment p -> q leaves through: (p, x, y) with x strictly left of p -> q ... no: x right, y left of it
+            int x = -1, y = -1;
+            for (auto it = T.half.lower_bound({p, -1}); it != T.half.end() && it->first.first == p; ++it) {
+                const int tri = it->second / 3, k = it->second % 3;
+                const int a = T.t[3 * tri + (k + 1) % 3], b = T.t[3 * tri + (k + 2) % 3];  // triangle (p, a, b), counter-clockwise
+                const i64 oa = P.orient(p, q, a), ob = P.orient(p, q, b);
+                if (oa == 0 && ((i64)ix[a] - ix[p]) * ((i64)ix[q] - ix[p]) + ((i64)iy[a] - iy[p]) * ((i64)iy[q] - iy[p]) > 0) { out.why = "a boundary vertex lies on another boundary edge"; return out; }
+                if (oa < 0 && ob > 0) { x = a; y = b; break; }  // a on the right, b on the left: the segment crosses a - b
+            }
+            if (x < 0) { out.why = "internal: a missing boundary edge leaves its vertex through no triangle"; return out; }
+            // walk along p -> q flipping the first flippable crossed edge
+            bool flipped = false;
+            int r = x, l = y;  // the crossed edge: r on the right, l on the left; it is the directed edge r -> l of the triangle on p's side
+            for (long long w = 0; w < 8ll * n + 64 && !flipped; ++w) {
+                int c, d;
+                if (!T.fixed.count(CDT::und(r, l)) && T.flip(r, l, c, d)) {
+                    flipped = true;
+                    // (the new diagonal may still cross p -> q: the outer loop looks again)
+                    if (!((c == p && d == q) || (c == q && d == p))) loosened.push_back(CDT::und(c, d));
+                    break;
+                }
+                if (T.fixed.count(CDT::und(r, l))) { out.why = "two boundary edges cross"; return out; }
+                // not convex here: go on to the next crossed edge, across r -> l
+                const auto o = T.half.find({l, r});
+                if (o == T.half.end()) { out.why = "internal: a missing boundary edge leaves the hull"; return out; }
+                const int z = T.t[3 * (o->second / 3) + (o->second % 3 + 2) % 3];
+                if (z == q) break;
+                const i64 oz = P.orient(p, q, z);
+                if (oz == 0) { out.why = "a boundary vertex lies on another boundary edge"; return out; }
+                if (oz > 0) l = z; else r = z;
+            }
+            if (!flipped) {
+                // every crossed edge sits in a non-convex quadrilateral right now: flip them from the far end (the last one is always convex towards q)
+                // -- rare; fall back to trying every crossed edge in reverse order
+                std::vector<E> crossed;
+                int rr = x, ll = y;
+                for (long long w = 0; w < 8ll * n + 64; ++w) {
+                    crossed.push_back({rr, ll});
+                    const auto o = T.half.find({ll, rr});
+                    if (o == T.half.end()) break;
+                    const int z = T.t[3 * (o->second / 3) + (o->second % 3 + 2) % 3];
+                    if (z == q) break;
+                    if (P.orient(p, q, z) > 0) ll = z; else rr = z;
+                }
+                for (size_t k = crossed.size(); k-- > 0 && !flipped;) {
+                    int c, d;
+                    if (!T.fixed.count(CDT::und(crossed[k].first, crossed[k].second)) && T.flip(crossed[k].first, crossed[k].second, c, d)) {
+                        flipped = true;
+                        if (!((c == p && d == q) || (c == q && d == p))) loosened.push_back(CDT::und(c, d));
+                    }
+                }
+                if (!flipped) { out.why = "a boundary edge could not be recovered (no crossed edge can be flipped)"; return out; }
+            }
+        }
+        T.fixed[CDT::und(p, q)] = 1;
+    }
+    // ---- the free edges Delaunay again (all of them: the recovery flips were not Delaunay flips)
+    {
+        std::vector<E> all;
+        for (const auto &kv : T.half) if (kv.first.first < kv.first.second) all.push_back(kv.first);
+        if (!T.lawson(all)) { out.why = "internal: constrained Delaunay flips do not terminate"; return out; }
+    }
+    // ---- which triangles are the domain's: flood fill from the boundary edges, never across one
+    const int nt = (int)T.t.size() / 3;
+    std::vector<signed char> side(nt, 0);  // +1 inside the domain, -1 outside (fill)
+    std::vector<int> stack;
+    for (const auto &kv : etri) {
+        const auto in = T.half.find({kv.first.first, kv.first.second});
+        if (in == T.half.end()) { out.why = "internal: a forced boundary edge has no triangle on the domain's side"; return out; }
+        if (side[in->second / 3] == -1) { out.why = "the boundary edges do not bound a consistent domain"; return out; }
+        if (side[in->second / 3] == 0) { side[in->second / 3] = 1; stack.push_back(in->second / 3); }
+        const auto ot = T.half.find({kv.first.second, kv.first.first});
+        if (ot != T.half.end() && !etri.count({kv.first.second, kv.first.first})) {
+            if (side[ot->second / 3] == 1) { out.why = "the boundary edges do not bound a consistent domain"; return out; }
+            if (side[ot->second / 3] == 0) { side[ot->second / 3] = -1; stack.push_back(ot->second / 3); }
+        }
+    }
+    while (!stack.empty()) {
+        const int i = stack.back();
+        stack.pop_back();
+        for (int k = 0; k < 3; ++k) {
+            const int a = T.t[3 * i + k], b = T.t[3 * i + (k + 1) % 3];
+            if (T.fixed.count(CDT::und(a, b))) continue;
+            const auto o = T.half.find({b, a});
+            if (o == T.half.end()) continue;
+            const int j = o->second / 3;
+            if (side[j] == 0) { side[j] = side[i]; stack.push_back(j); }
+            else if (side[j] != side[i]) { out.why = "the boundary edges do not bound a consistent domain"; return out; }
+        }
+    }
+    std::vector<int> fill_no(nt, -1);
+    for (int i = 0; i < nt; ++i) {
+        if (side[i] > 0) continue;  // (0: a region no boundary edge touches cannot exist inside the hull of the boundary vertices; taken as outside)
+        fill_no[i] = (int)out.fill.size() / 3;
+        out.fill.push_back(T.t[3 * i]); out.fill.push_back(T.t[3 * i + 1]); out.fill.push_back(T.t[3 * i + 2]);
+    }
+    // ---- hull edges, counter-clockwise, with the triangle inside each
+    {
+        int start = last, steps = 0;
+        for (int h = start; steps <= n; ++steps) {
+            const int a = pts[h], b = pts[hnext[h]];
+            HullEdge he{a, b, -1, -1};
+            const auto in = T.half.find({a, b});
+            if (in == T.half.end()) { out.why = "internal: a hull edge has no triangle behind it"; out.fill.clear(); out.hull.clear(); return out; }
+            const int i = in->second / 3;
+            if (side[i] > 0) {
+                const auto m = etri.find({a, b});
+                if (m == etri.end()) { out.why = "internal: a domain triangle on the hull without a boundary edge"; out.fill.clear(); out.hull.clear(); return out; }
+                he.tri = m->second / 3; he.k = m->second % 3;
+            } else {
+                const int pos = in->second % 3;         // a is the vertex at `pos`, b the next: they are VOTE[k] = ((k+1)%3, (k+2)%3) for k = (pos + 2) % 3
+                he.tri = nels + fill_no[i]; he.k = (pos + 2) % 3;
+            }
+            out.hull.push_back(he);
+            h = hnext[h];
+            if (h == start) break;
+        }
+    }
+    out.ok = true;
+    return out;
+}
+
+// complete(), and where it does not apply (several components, a pinching boundary) the general construction
+inline Completion complete_any(const int32_t *index, const int *ix, const int *iy, int nods, int nels, int mode = 0) {
+    if (mode == 1) return complete_general(index, ix, iy, nods, nels);
+    Completion c = complete(index, ix, iy, nods, nels);
+    if (c.ok || mode == 2) return c;
+    Completion g = complete_general(index, ix, iy, nods, nels);
+    if (!g.ok) g.why = c.why + "; general construction: " + g.why;
+    return g;
+}
+
 }  // namespace nxs_hull

@@ -386,7 +386,7 @@ struct Locator {
         std::vector<int> fill3;  // AoS, 0-based
         if (need_boundary_edges) {
             Tick tk(2);
-            comp = ready ? *ready : nxs_hull::complete(index_data, ix.data(), iy.data(), nods, nels);
+            comp = ready ? *ready : nxs_hull::complete_any(index_data, ix.data(), iy.data(), nods, nels);
             with_completion = true;
             if (comp.ok) {
                 fill3 = comp.fill;
@@ -682,7 +682,7 @@ extern "C" int nxs_regrid_create(const int32_t *index_old, const double *x_old, 
             std::vector<int> ix, iy;
             double coef = 0., px = 0., py = 0.;
             if (!nxs_hull::int_plane(q->x.data(), q->y.data(), q->nods, ix, iy, coef, px, py)) { nxs_hull::Completion c; c.why = "coefIcoor should be positive"; return c; }
-            return nxs_hull::complete(q->index.data(), ix.data(), iy.data(), q->nods, q->nels);
+            return nxs_hull::complete_any(q->index.data(), ix.data(), iy.data(), q->nods, q->nels);
         });
     } catch (const std::system_error &) { }
     *out = r.release();
@@ -788,9 +788,10 @@ extern "C" int nxs_interp_last_info(int32_t *num_fill_triangles, int32_t *num_hu
 } catch (...) { return entry_caught("nxs_interp_last_info"); }
 
 // Host only: bamg's convex completion of a mesh (see nxs_hull.inl) -- what tests compare with the real bamg.
-extern "C" int nxs_mesh_convex_completion(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
+// mode 0: the pocket construction, and the general one (constrained Delaunay of the boundary vertices) where that does not apply; 1: the general one; 2: pockets only
+extern "C" int nxs_mesh_convex_completion_mode(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
                                           int32_t *num_fill, int32_t *fill_tri, int32_t cap_fill, int32_t *num_hull, int32_t *hull_edges,
-                                          int32_t cap_hull) try {
+                                          int32_t cap_hull, int32_t mode) try {
     if (!index || !x || !y || nods < 3 || nels < 1 || !num_fill || !num_hull) return fail(NXS_ERR_INVALID, "bad arguments");
     for (int64_t i = 0; i < 3ll * nels; ++i)
         if (index[i] < 1 || index[i] > nods) return fail(NXS_ERR_INVALID, "index[%lld] out of range", (long long)i);
@@ -798,7 +799,7 @@ extern "C" int nxs_mesh_convex_completion(const int32_t *index, const double *x,
     double coef = 0., pminx = 0., pminy = 0.;
     std::vector<int> ix, iy;
     if (!nxs_hull::int_plane(x, y, nods, ix, iy, coef, pminx, pminy)) return fail(NXS_ERR_INVALID, "coefIcoor should be positive");
-    const nxs_hull::Completion c = nxs_hull::complete(index, ix.data(), iy.data(), nods, nels);
+    const nxs_hull::Completion c = nxs_hull::complete_any(index, ix.data(), iy.data(), nods, nels, mode);
     if (!c.ok) return fail(NXS_ERR_INVALID, "no convex completion: %s", c.why.c_str());
     *num_fill = (int)c.fill.size() / 3; *num_hull = (int)c.hull.size();
     if (fill_tri) { if (cap_fill < *num_fill) return fail(NXS_ERR_INVALID, "fill_tri too small"); for (size_t i = 0; i < c.fill.size(); ++i) fill_tri[i] = c.fill[i] + 1; }
@@ -807,6 +808,12 @@ extern "C" int nxs_mesh_convex_completion(const int32_t *index, const double *x,
         for (size_t i = 0; i < c.hull.size(); ++i) { hull_edges[2 * i] = c.hull[i].a + 1; hull_edges[2 * i + 1] = c.hull[i].b + 1; }
     }
     return NXS_OK;
+} catch (...) { return entry_caught("nxs_mesh_convex_completion_mode"); }
+
+extern "C" int nxs_mesh_convex_completion(const int32_t *index, const double *x, const double *y, int32_t nods, int32_t nels,
+                                          int32_t *num_fill, int32_t *fill_tri, int32_t cap_fill, int32_t *num_hull, int32_t *hull_edges,
+                                          int32_t cap_hull) try {
+    return nxs_mesh_convex_completion_mode(index, x, y, nods, nels, num_fill, fill_tri, cap_fill, num_hull, hull_edges, cap_hull, 0);
 } catch (...) { return entry_caught("nxs_mesh_convex_completion"); }
 
 // ---------------------------------------------------------------------------------------------------------

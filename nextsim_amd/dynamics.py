@@ -113,7 +113,7 @@ EXPORTS = (
     "nxs_dyn_debug_array", "nxs_dyn_get_branch_trace", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
 )
 INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_mesh_to_grid_device", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
-                  "nxs_interp_last_error", "nxs_interp_last_info", "nxs_mesh_convex_completion", "nxs_regrid_create", "nxs_regrid_destroy",
+                  "nxs_interp_last_error", "nxs_interp_last_info", "nxs_mesh_convex_completion", "nxs_mesh_convex_completion_mode", "nxs_regrid_create", "nxs_regrid_destroy",
                   "nxs_regrid_interp_nodes", "nxs_regrid_remap_elements", "nxs_interp_last_timing", "nxs_regrid_debug_tables")
 
 

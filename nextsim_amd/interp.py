@@ -28,8 +28,8 @@ def _lib():
         L.nxs_interp_last_error.restype = C.c_char_p
         I = C.POINTER(C.c_int32)
         L.nxs_interp_last_info.argtypes = [I, I, I, I, I, I, C.POINTER(C.c_char_p)]
-        L.nxs_mesh_convex_completion.argtypes = [_abi.c_int32_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_int32, I, _abi.c_int32_p,
-                                                 C.c_int32, I, _abi.c_int32_p, C.c_int32]
+        L.nxs_mesh_convex_completion_mode.argtypes = [_abi.c_int32_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_int32, I, _abi.c_int32_p,
+                                                      C.c_int32, I, _abi.c_int32_p, C.c_int32, C.c_int32]
         _declared = True
     return L
 
@@ -46,19 +46,20 @@ def last_info() -> dict:
     return out
 
 
-def convex_completion(index, x, y):
+def convex_completion(index, x, y, mode=0):
     """bamg's convex completion of a mesh (index 1-based): (fill triangles [n, 3], hull edges [m, 2]), 1-based, counter-clockwise.
-    Host code of the product library (csrc/nxs_hull.inl)."""
+    Host code of the product library (csrc/nxs_hull.inl).  mode 0: automatic, 1: the general construction (constrained Delaunay of the boundary
+    vertices), 2: the pocket construction only."""
     L = _lib()
     index = np.ascontiguousarray(index, np.int32).ravel()
     x = np.ascontiguousarray(x, np.float64); y = np.ascontiguousarray(y, np.float64)
     nf, nh = C.c_int32(0), C.c_int32(0)
-    rc = L.nxs_mesh_convex_completion(_abi.iptr(index), _abi.dptr(x), _abi.dptr(y), x.size, index.size // 3, C.byref(nf), None, 0, C.byref(nh), None, 0)
+    rc = L.nxs_mesh_convex_completion_mode(_abi.iptr(index), _abi.dptr(x), _abi.dptr(y), x.size, index.size // 3, C.byref(nf), None, 0, C.byref(nh), None, 0, mode)
     if rc:
         raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
     fill = np.zeros((max(nf.value, 1), 3), np.int32); hull = np.zeros((max(nh.value, 1), 2), np.int32)
-    rc = L.nxs_mesh_convex_completion(_abi.iptr(index), _abi.dptr(x), _abi.dptr(y), x.size, index.size // 3, C.byref(nf), _abi.iptr(fill), nf.value,
-                                      C.byref(nh), _abi.iptr(hull), nh.value)
+    rc = L.nxs_mesh_convex_completion_mode(_abi.iptr(index), _abi.dptr(x), _abi.dptr(y), x.size, index.size // 3, C.byref(nf), _abi.iptr(fill), nf.value,
+                                           C.byref(nh), _abi.iptr(hull), nh.value, mode)
     if rc:
         raise NxsError(rc, (L.nxs_interp_last_error() or b"").decode())
     return fill[:nf.value], hull[:nh.value]

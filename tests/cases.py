@@ -54,6 +54,54 @@ def mesh_with_holes(kind="small", holes=((0.25, -0.1, 0.12), (-0.3, 0.3, 0.07)))
     return gm.x[used].copy(), gm.y[used].copy(), np.ascontiguousarray(new[tri], np.int32)
 
 
+def awkward_meshes():
+    """Meshes whose boundary is not "one outer loop + holes": name -> (x, y, tri 0-based).  Several components (a disc and the toy box; three
+    of them; a lake inside an island of another mesh) and boundaries that PINCH (two triangular holes meeting at an interior vertex; a hole
+    that touches the coast at one vertex) -- real coastlines do all of it."""
+    sm, toy = global_mesh("small"), global_mesh("toy")
+
+    def join(parts):
+        xs, ys, ts, off = [], [], [], 0
+        for x, y, t in parts:
+            xs.append(x); ys.append(y); ts.append(t + off); off += x.size
+        return np.concatenate(xs), np.concatenate(ys), np.ascontiguousarray(np.concatenate(ts), np.int32)
+    out = {"two_components": join([(sm.x, sm.y, sm.tri), (toy.x * 8 + 4.0e6, toy.y * 8 - 1e6, toy.tri)])}
+    xh, yh, th = mesh_with_holes("small")
+    out["three_components"] = join([(sm.x, sm.y, sm.tri), (toy.x * 8 + 4.0e6, toy.y * 8 - 1e6, toy.tri), (xh * 0.7 - 1e6, yh * 0.7 + 6.5e6, th)])
+    xi, yi, ti = mesh_with_holes("40km", holes=((0.0, 0.0, 0.45),))
+    out["lake_in_island"] = join([(xi, yi, ti), (sm.x * 0.25, sm.y * 0.25, sm.tri)])
+    tri = sm.tri
+    edges = {}
+    for t in tri.tolist():
+        for a, b in ((t[0], t[1]), (t[1], t[2]), (t[2], t[0])):
+            edges[(min(a, b), max(a, b))] = edges.get((min(a, b), max(a, b)), 0) + 1
+    bndv = {v for e, c in edges.items() if c == 1 for v in e}
+    deg = np.bincount(tri.ravel(), minlength=sm.num_nodes)
+    for v in range(sm.num_nodes):            # two opposite triangles of an interior vertex's fan of six removed: two holes that meet at that vertex
+        if deg[v] != 6 or v in bndv:
+            continue
+        fan = [i for i, t in enumerate(tri.tolist()) if v in t]
+        rest = {i: set(tri[i].tolist()) - {v} for i in fan}
+        if any(u in bndv for i in fan for u in rest[i]):
+            continue
+        order = [fan[0]]
+        while len(order) < 6:
+            nxt = [i for i in fan if i not in order and len(rest[i] & rest[order[-1]]) == 1]
+            if not nxt:
+                break
+            order.append(nxt[0])
+        if len(order) == 6:
+            keep = np.ones(tri.shape[0], bool); keep[order[0]] = False; keep[order[3]] = False
+            out["pinch_inside"] = (sm.x, sm.y, np.ascontiguousarray(tri[keep]))
+            break
+    for i, t in enumerate(tri.tolist()):     # a triangle with exactly one coast vertex removed: a hole that touches the coast at that vertex
+        if sum(u in bndv for u in t) == 1:
+            keep = np.ones(tri.shape[0], bool); keep[i] = False
+            out["pinch_at_the_coast"] = (sm.x, sm.y, np.ascontiguousarray(tri[keep]))
+            break
+    return out
+
+
 def rel_err(a, b):
     """max |a-b| / max|b| (fields here have a natural scale; pointwise relative error is meaningless
     near zero crossings)."""

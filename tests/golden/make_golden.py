@@ -219,6 +219,9 @@ def completion_cases():
         out[kind + "_holes"] = cases.mesh_with_holes(kind)
     gm = cases.global_mesh("toy")
     out["toy"] = (gm.x, gm.y, gm.tri)
+    # round 3: what the pocket construction refuses and the general one (constrained Delaunay of the boundary vertices) covers --
+    # several components, a component inside a hole of another, boundaries that pinch
+    out.update(cases.awkward_meshes())
     return out
 
 

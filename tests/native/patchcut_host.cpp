@@ -264,13 +264,13 @@ int pc_hilbert(const double *x, const double *y, int n, int32_t *order_out, char
 
 // bamg's convex completion (nxs_hull.inl).  out: [0] ok, [1] fill triangles, [2] hull edges.  When it is built: the fill triangles are
 // counter-clockwise and, with the mesh, cover the hull polygon exactly (integer areas).
-int pc_hull(const int32_t *index, const double *x, const double *y, int nods, int nels, int64_t *out, char *msg, int msg_cap) try {
+int pc_hull(const int32_t *index, const double *x, const double *y, int nods, int nels, int mode, int64_t *out, char *msg, int msg_cap) try {
     put_msg(msg, msg_cap, "");
     out[0] = out[1] = out[2] = 0;
     std::vector<int> ix, iy;
     double coef, px, py;
     if (!nxs_hull::int_plane(x, y, nods, ix, iy, coef, px, py)) { put_msg(msg, msg_cap, "coefIcoor should be positive"); return 2; }
-    const nxs_hull::Completion c = nxs_hull::complete(index, ix.data(), iy.data(), nods, nels);
+    const nxs_hull::Completion c = nxs_hull::complete_any(index, ix.data(), iy.data(), nods, nels, mode);
     out[0] = c.ok;
     if (!c.ok) { put_msg(msg, msg_cap, c.why); return 0; }
     out[1] = (int64_t)c.fill.size() / 3; out[2] = (int64_t)c.hull.size();
@@ -278,6 +278,15 @@ int pc_hull(const int32_t *index, const double *x, const double *y, int nods, in
     typedef __int128 i128;
     i128 area_mesh = 0, area_fill = 0, area_hull = 0;
     for (int e = 0; e < nels; ++e) area_mesh += P.orient(index[3 * e] - 1, index[3 * e + 1] - 1, index[3 * e + 2] - 1);
+    {   // every hull edge names the triangle behind it and the local edge (vertices VOTE[k]) that IS the hull edge
+        static const int VOTE[3][2] = {{1, 2}, {2, 0}, {0, 1}};
+        for (const auto &h : c.hull) {
+            int tv[3];
+            if (h.tri < nels) { for (int k = 0; k < 3; ++k) tv[k] = index[3 * h.tri + k] - 1; }
+            else { REQUIRE(h.tri - nels < (int)c.fill.size() / 3, "hull edge names fill triangle %d", h.tri - nels); for (int k = 0; k < 3; ++k) tv[k] = c.fill[3 * (size_t)(h.tri - nels) + k]; }
+            REQUIRE(h.k >= 0 && h.k < 3 && tv[VOTE[h.k][0]] == h.a && tv[VOTE[h.k][1]] == h.b, "hull edge %d -> %d is not edge %d of triangle %d", h.a, h.b, h.k, h.tri);
+        }
+    }
     for (size_t i = 0; i + 2 < c.fill.size(); i += 3) {
         const long long a = P.orient(c.fill[i], c.fill[i + 1], c.fill[i + 2]);
         REQUIRE(a > 0, "fill triangle %zu is not counter-clockwise", i / 3);

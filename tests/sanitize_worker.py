@@ -142,7 +142,7 @@ from nextsim_amd import mesh as M  # noqa: E402
 U8 = C.POINTER(C.c_uint8); I64 = C.POINTER(C.c_int64)
 cut.pc_run.argtypes = [IP, U8, D, D] + [C.c_int] * 8 + [IP, IP, C.c_int, IP, IP, C.c_int, IP, IP] + [C.c_int] * 3 + [I64, C.c_char_p, C.c_int]
 cut.pc_hilbert.argtypes = [D, D, C.c_int, IP, C.c_char_p, C.c_int]
-cut.pc_hull.argtypes = [IP, D, D, C.c_int, C.c_int, I64, C.c_char_p, C.c_int]
+cut.pc_hull.argtypes = [IP, D, D, C.c_int, C.c_int, C.c_int, I64, C.c_char_p, C.c_int]
 cut.pc_guard_selftest.argtypes = [C.c_int, C.c_char_p, C.c_int]
 
 
@@ -226,17 +226,32 @@ for xs, ys in ((np.array([0., np.nan, 1., np.inf, -np.inf, 2.]), np.array([np.na
                (np.array([3.]), np.array([4.])), (np.zeros(0), np.zeros(0)), (np.array([1e308, -1e308, 0.]), np.array([-1e308, 1e308, 0.]))):
     out = np.zeros(max(xs.size, 1), np.int32)
     assert cut.pc_hilbert(_abi.dptr(np.ascontiguousarray(xs)), _abi.dptr(np.ascontiguousarray(ys)), xs.size, _abi.iptr(out), msg, 256) == 0, msg.value
-# 4f. bamg's convex completion: the disc with its irregular coast, with islands, the toy box; meshes it refuses say why
+# 4f. bamg's convex completion: the disc with its irregular coast, with islands, the toy box -- by the pocket construction and by the general one
+#     (constrained Delaunay of the boundary vertices); several components, a lake inside an island, pinching boundaries (general only);
+#     what is no mesh says why
 hs = np.zeros(3, np.int64)
-for xk, yk, tk in ((sm.x, sm.y, sm.tri), cases.mesh_with_holes("small"), (cases.global_mesh("toy").x, cases.global_mesh("toy").y, cases.global_mesh("toy").tri),
-                   cases.mesh_with_holes("40km")):
+toy_ = cases.global_mesh("toy")
+hull_cases = [(sm.x, sm.y, sm.tri), cases.mesh_with_holes("small"), (toy_.x, toy_.y, toy_.tri), cases.mesh_with_holes("40km")]
+for xk, yk, tk in hull_cases:
     ti = i32((tk + 1).ravel())
-    assert cut.pc_hull(_abi.iptr(ti), _abi.dptr(np.ascontiguousarray(xk)), _abi.dptr(np.ascontiguousarray(yk)), xk.size, tk.shape[0], hs.ctypes.data_as(I64), msg, 256) == 0, msg.value
-    assert hs[0] == 1 and hs[2] >= 3, (hs, msg.value)
-two = np.concatenate([sm.tri, sm.tri + sm.num_nodes])   # two components
-assert cut.pc_hull(_abi.iptr(i32((two + 1).ravel())), _abi.dptr(np.concatenate([sm.x, sm.x + 1e7])), _abi.dptr(np.concatenate([sm.y, sm.y])), 2 * sm.num_nodes,
-                   two.shape[0], hs.ctypes.data_as(I64), msg, 256) == 0
-print("two components:", int(hs[0]), msg.value.decode())
+    sizes = []
+    for mode in (0, 1, 2):
+        assert cut.pc_hull(_abi.iptr(ti), _abi.dptr(np.ascontiguousarray(xk)), _abi.dptr(np.ascontiguousarray(yk)), xk.size, tk.shape[0], mode, hs.ctypes.data_as(I64), msg, 256) == 0, msg.value
+        assert hs[0] == 1 and hs[2] >= 3, (hs, msg.value)
+        sizes.append((int(hs[1]), int(hs[2])))
+    assert sizes[0] == sizes[1] == sizes[2], sizes
+for name, (xk, yk, tk) in cases.awkward_meshes().items():
+    ti = i32((tk + 1).ravel())
+    for mode in (0, 1):
+        assert cut.pc_hull(_abi.iptr(ti), _abi.dptr(np.ascontiguousarray(xk)), _abi.dptr(np.ascontiguousarray(yk)), xk.size, tk.shape[0], mode, hs.ctypes.data_as(I64), msg, 256) == 0, (name, msg.value)
+        assert hs[0] == 1 and hs[1] > 0, (name, hs, msg.value)
+    assert cut.pc_hull(_abi.iptr(ti), _abi.dptr(np.ascontiguousarray(xk)), _abi.dptr(np.ascontiguousarray(yk)), xk.size, tk.shape[0], 2, hs.ctypes.data_as(I64), msg, 256) == 0
+    assert hs[0] == 0 and msg.value, name          # the pocket construction alone refuses them, with a reason
+bad_t = i32(np.array([1, 2, 3, 2, 1, 4, 1, 2, 5]))  # one edge in three triangles
+assert cut.pc_hull(_abi.iptr(bad_t), _abi.dptr(np.array([0., 1., 0., 1., 0.5])), _abi.dptr(np.array([0., 0., 1., 1., -1.])), 5, 3, 0, hs.ctypes.data_as(I64), msg, 256) == 0 and hs[0] == 0
+line_t = i32(np.array([1, 2, 3]))                   # a degenerate triangle: every boundary vertex on one line
+cut.pc_hull(_abi.iptr(line_t), _abi.dptr(np.array([0., 1., 2.])), _abi.dptr(np.array([0., 1., 2.])), 3, 1, 1, hs.ctypes.data_as(I64), msg, 256)
+assert hs[0] == 0
 # 4g. the guard of the ABI (nxs_guard.hpp): length_error / bad_alloc -> NXS_ERR_NOMEM, anything else -> NXS_ERR_INTERNAL, with a text
 assert cut.pc_guard_selftest(0, msg, 256) == -6 and b"length_error" in msg.value
 assert cut.pc_guard_selftest(1, msg, 256) == -6 and b"bad_alloc" in msg.value
