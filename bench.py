@@ -145,7 +145,15 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
     transport = "none"
     halo = {"transport": "none"}
     if world > 1:
-        transport, halo = setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn)
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)       # (librccl's banner, should the RCCL transport be initialised: stdout carries the one JSON line only)
+        try:
+            transport, halo = setup_halo_transport(fe, lm, rank, world, dist, torch, unique_id_fn)
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     fe.put_state(f)
     fe.set_forcing(f)
     if transport.startswith("device-direct"):
@@ -771,7 +779,16 @@ def main():
             elif os.environ.get("NXS_BENCH_SKIP_RCCL") == "1":
                 out["aux_rccl"] = {"status": "skipped (NXS_BENCH_SKIP_RCCL=1)"}
             else:
-                out["aux_rccl"] = aux_rccl(args.mesh, args, rank, world, local_rank, dist, torch, unique_id_fn, out["ms_per_step"])
+                # librccl announces itself ("RCCL version : ...") on stdout from C: keep stdout for the one JSON line
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    out["aux_rccl"] = aux_rccl(args.mesh, args, rank, world, local_rank, dist, torch, unique_id_fn, out["ms_per_step"])
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
         except Exception as e:  # noqa: BLE001 -- never lose the main line over it
             out["aux_rccl"] = {"status": "failed", "error": repr(e)[:300]}
     if rank == 0 and not args.no_cpu_baseline:   # (at every N: rank 0's host is the same host)
