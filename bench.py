@@ -166,6 +166,8 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
         if world > 1:
             dist.barrier()
 
+    fe.set_option("prepare", 1)   # (lazily built tables now: ranks that share a device must not free device memory under each other's first step)
+    barrier()
     for _ in range(args.warmup):
         fe.step()
     fe.synchronize()

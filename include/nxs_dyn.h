@@ -284,6 +284,9 @@ NXS_API int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local);
 
 NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
 /* Options (none changes a bit of the results; the tests assert that):
+ *   "prepare"      1 = build NOW what the first step would build lazily (tables of the exchange inside the kernels, of the resident loop): hosts that
+ *                  run several ranks of one process on ONE device call it before their start barrier (building frees device memory, which waits for the
+ *                  whole device -- including a neighbour rank's kernel that is already waiting for this rank); harmless anywhere else
  *   "graph"        1 = sub-step loop replayed from a hipGraph (default); 0 = plain launches
  *   "timing"       1 = record the per-phase events (default); "timing_reset": zero the averages
  *   "fused"        3 = automatic (default): several sub-steps per launch on single-rank meshes small enough for one patch

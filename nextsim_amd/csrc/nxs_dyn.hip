@@ -613,6 +613,30 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         if (!h->res_ready) return fail(h, NXS_ERR_INVALID, "the resident sub-step loop cannot run this partition (NXS_DEBUG_PATCHES=1 says why)");
         return NXS_OK;
     }
+    if (!std::strcmp(key, "prepare")) {
+        // Everything the first step would otherwise build lazily and that FREES device memory while doing so (the patch arrays re-uploaded boundary
+        // first for the exchange inside the kernels, the resident loop's tables): a hipFree synchronises the whole device, and where several ranks
+        // of one process share a device (tests, rehearsals) a rank that is already spinning for its neighbour's first exchange would keep that
+        // neighbour's hipFree -- and with it the exchange -- from ever happening.  Hosts call it after set_halo / the transport set-up, before a barrier.
+        if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "prepare needs set_mesh");
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        const bool mr = multi_rank(h);
+        const bool device_halo = mr && h->have_halo && h->ipc_ready && !h->halo_fn;
+        int rc = NXS_OK;
+        if (device_halo && h->halo_fused && !h->hf_ready && (rc = build_halo_fused(h))) return rc;
+        if (h->fused == 4 && (!mr || (device_halo && h->halo_fused)) && !h->res_ready && !h->res_failed && h->dp.dynamics_type != NXS_DYN_MEVP) {
+            if ((rc = build_resident(h))) return rc;
+            if (h->res_failed && h->cut_big && !h->no_big_cut) {
+                release_graph(h);
+                h->no_big_cut = true;
+                if ((rc = upload_patches(h))) return rc;
+                h->res_failed = true;
+                if (device_halo && h->halo_fused && !h->hf_ready && (rc = build_halo_fused(h))) return rc;
+            }
+        }
+        return NXS_OK;
+    }
     if (!std::strcmp(key, "resident_wide")) {
         h->res_wide = value != 0; h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;
     }
@@ -1484,15 +1508,18 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
 int setup_ring(nxs_dyn_handle *h, int K) {
     const int R = K + 1;
     if (h->ring.R == R) return NXS_OK;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
-    free_pool(h->ring_allocs);
-    h->ring = VTRing{};
+    // Buffers are only ever ADDED (they go with the mesh): a hipFree synchronises the whole device, and on a device that another handle of this
+    // process shares (the several-ranks-per-process tests and rehearsals) that other rank's kernels may be spinning for THIS rank's next launch --
+    // freeing here, inside a step, deadlocked such runs until the 10 s guard fired whenever a run switched from the long ring to the short one
+    // (round 3: found in the kernel statistics of a two-rank run, one k_halo_pull of 10 s).
     h->ring.slot[0] = h->ds.VT;
     h->ring.slot[1] = h->ds.VT2;
     for (int i = 2; i < R; ++i) {
+        if (i - 2 < (int)h->ring_allocs.size()) { h->ring.slot[i] = static_cast<double *>(h->ring_allocs[i - 2]); continue; }
         int rc = dev_alloc(h, h->ring_allocs, &h->ring.slot[i], 2 * (size_t)h->dm.Nn);
         if (rc) return rc;
     }
+    for (int i = R; i < NXS_MAX_RING; ++i) h->ring.slot[i] = nullptr;
     h->ring.R = R;
     return NXS_OK;
 }

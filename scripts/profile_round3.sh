@@ -12,7 +12,7 @@ TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 OUT=$GRAFT_REPO_ROOT/gpurun_out/${TAG}_prof
 mkdir -p $OUT
-run() { echo "== $1"; shift; timeout -k 10 600 "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping"; exit 1; fi; return $rc; }
+run() { echo "== $1" >&2; shift; timeout -k 10 600 "$@"; rc=$?; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "timed out: stopping"; exit 1; fi; return $rc; }
 run bench python3 bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err || exit 1
 run stats rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-aux --no-live-pmc > $OUT/bench_under_prof.json 2> $OUT/bench_under_prof.err || exit 1
 run fetch rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc/FETCH_SIZE -o f -- python3 scripts/run_steps.py --mesh 2km --steps 1 --graph 0 > $OUT/fetch.log 2>&1 || exit 1

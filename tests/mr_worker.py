@@ -86,6 +86,7 @@ def run_rank(li, report):
     if transport == "ipc_sep":
         fe.set_option("halo_fused", 0)      # k_halo_push / k_halo_pull as separate kernels
     fe.put_state(fields[rank]); fe.set_forcing(fields[rank])
+    fe.set_option("prepare", 1)             # the lazily built tables now: building them frees device memory, which synchronises the SHARED device
     all_gather(0)                           # nobody steps before every rank's state is resident
     for i in range(nsteps):
         if i == 2 and nsteps > 4:            # rehearsals time the steps after the warm-up ones (graph capture, lazily built tables)
@@ -102,6 +103,7 @@ def run_rank(li, report):
         all_gather(0)
         fe.set_option("halo_fused", 0)
         fe.put_state(fields[rank]); fe.set_forcing(fields[rank])
+        fe.set_option("prepare", 1)
         all_gather(0)
         for _ in range(nsteps):
             fe.step()
