@@ -295,8 +295,11 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  number of sub-steps); 1 = one patch kernel per sub-step; 0 = one kernel per reference loop;
  *                  4 = the whole sub-step loop in ONE resident launch whose workgroups wait for their neighbouring patches only
  *                  (one rank, or several with the device-direct mailboxes and "halo_fused" 1: the exchange between ranks then happens
- *                  inside that launch too; not mEVP; one element per thread and every workgroup resident at once -- checked, else
- *                  as 1): for a device the handle has to itself -- one rank of eight of a 1.5 M-triangle mesh: 0.85 instead of 1.3 ms
+ *                  inside that launch too; not mEVP; every workgroup resident at once -- checked, also against the other resident grids this
+ *                  process runs on the device, else as 1): for a device the handle has to itself.  Partitions of up to ~200 k triangles run two
+ *                  workgroups per CU with one element per thread (a rank of eight of a 1.5 M-triangle mesh: 0.85 instead of 1.3 ms per step),
+ *                  partitions of 200 k - 400 k ONE workgroup per CU with four elements and two nodes per thread (a rank of four: 1.4 instead of
+ *                  2.2 ms).  The option decides how the mesh is cut: setting or clearing it on a live mesh cuts the mesh again (same bits)
  *   "resident_dryrun"  (an action, not a setting) builds the tables of the resident loop for the mesh and halo lists set so far -- no transport,
  *                  no neighbours needed -- and fails with NXS_ERR_INVALID when this partition cannot run it (a patch with more elements than
  *                  threads, more than one round of workgroups, LDS, > 24 neighbouring patches): a partition can be checked on its own

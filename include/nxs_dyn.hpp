@@ -50,6 +50,13 @@ public:
         check(nxs_dyn_check_fields_fast(h_, &crash), "checkFieldsFast");
         if (crash) throw std::runtime_error("FiniteElement::checkFieldsFast: Check failed");
     }
+    // FE.cpp:7860-7905: the element diagnostics of checkOutputs() / exportResults().  Host arrays of `d` that are not NULL are filled; the return value
+    // is the DEVICE address of the same diagnostics as [Ne][NXS_ICE_DIAG_FIELDS] rows (what nxs_interp_mesh_to_grid_device samples for a Moorings record).
+    const double *updateIceDiagnostics(nxs_dyn_ice_diag *d = nullptr) {
+        const double *rows = nullptr;
+        check(nxs_dyn_ice_diagnostics(h_, d, &rows), "updateIceDiagnostics");
+        return rows;
+    }
     nxs_dyn_handle *handle() { return h_; }
 
 private:

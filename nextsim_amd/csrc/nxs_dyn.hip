@@ -600,7 +600,16 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }  // -1 = automatic
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
-        h->fused = (int)value; h->res_failed = false; h->no_big_cut = false; release_graph(h); return NXS_OK;
+        const bool was_resident = h->fused == 4, now_resident = value == 4;
+        h->fused = (int)value; h->res_failed = false; h->no_big_cut = false; release_graph(h);
+        // the resident loop has a cut of its own (one round of workgroups; one LARGE patch per CU for partitions of 200 k - 400 k triangles, which is not what
+        // the one-launch-per-sub-step kernel wants): asking for it or giving it up on a live mesh cuts the mesh again -- any cut gives the same bits
+        if (h->have_mesh && was_resident != now_resident) {
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            return upload_patches(h);
+        }
+        return NXS_OK;
     }
     if (!std::strcmp(key, "resident_dryrun")) {  // builds the tables of the resident loop now (mesh and, on several ranks, halo lists set; no
         // transport needed) and says whether this partition can run it: checks a rank's partition without its neighbours

@@ -431,7 +431,7 @@ inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_re
             // of the 2 km mesh: 512 patches of ~360 nodes)
             int Pr = (int)(((long long)m.No + 2 * cus - 1) / (2 * cus));
             if (Pr < 100) Pr = (int)(((long long)m.No + cus - 1) / cus);
-            Pr = std::max(32, (Pr + 3) & ~3);
+            Pr = std::max(64, (Pr + 3) & ~3);  // (tiny partitions: 64-node patches as the one-launch-per-sub-step kernel takes -- fewer, fuller workgroups)
             for (int it = 0; it < 4 && Pr <= 208 && !done; ++it, Pr += 4) {  // orphan patches (multi-rank) may add a few workgroups
                 if (!build(Pr)) break;
                 done = hp.Emax <= 512 * res_ept && hp.nP <= 2 * cus && out.fused_lds <= 80 * 1024;

@@ -291,3 +291,35 @@ def test_resident_loop_in_the_build_with_all_its_registers(world, kind, over, tm
         assert r["crash"] == 0
         for k, e in r["errs"].items():
             assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
+
+
+def test_bench_line_of_a_two_rank_run_is_one_json_line_with_every_structured_field(tmp_path):
+    """bench.py as the driver launches it at N = 2 (torch.distributed.run, one rank per "GPU"; here both ranks share device 0, so the figures only
+    bound the protocol): stdout is ONE JSON line (RCCL's and gloo's banners stay on stderr), it carries the contract's keys, the structured
+    transport / variant report (config.halo), the slowest rank's phases, aux_rccl (RCCL refuses two ranks on one device: a recorded failure, not a
+    lost line) and the CPU baseline of rank 0's host."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+           os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--mesh", "40km"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["ranks_share_device"] is True and d["scaling"] == "strong" and d["value"] > 0 and d["fields_ok"] is True
+    halo = d["config"]["halo"]
+    assert halo["transport"] == "device-direct mailboxes" and halo["mailbox_selftest"].startswith("passed")
+    assert halo["kept_variant"] in ("inkernel", "separate", "resident", "resident_overlap")
+    assert halo["variants"]["separate"]["status"] == "ran" and halo["variants"]["separate"]["bit_identical_to_separate_kernels"] is True
+    assert halo["variants"]["inkernel"]["status"] in ("ran", "failed") and "ms_per_step" in halo["variants"]["separate"]
+    assert set(d["phases_ms"]) == {"prep_ms", "substeps_ms", "smoother_ms", "update_ms", "total_ms"} and d["phases_ms"]["total_ms"] >= d["phases_ms_rank0"]["total_ms"] - 1e-9
+    assert d["aux_rccl"]["status"] in ("ran", "failed") and ("error" in d["aux_rccl"] or "ms_per_step" in d["aux_rccl"])
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["host_cores"] >= cb["cores"] >= 1 and cb["cpu_model"] and cb["thread_counts_tried"]
