@@ -298,7 +298,7 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  inside that launch too; not mEVP; every workgroup resident at once -- checked, also against the other resident grids this
  *                  process runs on the device, else as 1): for a device the handle has to itself.  Partitions of up to ~200 k triangles run two
  *                  workgroups per CU with one element per thread (a rank of eight of a 1.5 M-triangle mesh: 0.85 instead of 1.3 ms per step),
- *                  partitions of 200 k - 400 k ONE workgroup per CU with four elements and two nodes per thread (a rank of four: 1.4 instead of
+ *                  partitions of 200 k - 400 k ONE workgroup per CU with four elements and two nodes per thread (a rank of four: 1.3 instead of
  *                  2.2 ms).  The option decides how the mesh is cut: setting or clearing it on a live mesh cuts the mesh again (same bits)
  *   "resident_dryrun"  (an action, not a setting) builds the tables of the resident loop for the mesh and halo lists set so far -- no transport,
  *                  no neighbours needed -- and fails with NXS_ERR_INVALID when this partition cannot run it (a patch with more elements than
@@ -306,9 +306,11 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *   "resident_wide"  with "fused" 4 on several ranks, a device that is this handle's alone and a partition that one workgroup per CU covers:
  *                  1 = the build of the resident kernel compiled for two waves per SIMD (no register limit to speak of: 15 % faster there);
  *                  default 0, because one such workgroup fills a CU and ranks sharing a device would no longer be resident side by side
- *   "resident_overlap"  with "fused" 4 on several ranks: 1 = the interior elements of every patch (no corner is a halo node) run one exchange
- *                  ahead -- their next update is computed while the exchange of the sub-step is awaited; default 0 (inside one GPU the wait is
- *                  filled by the other workgroup of the CU anyway; between GPUs it is a round trip over xGMI: bench.py times both and keeps one)
+ *   "resident_overlap"  with "fused" 4: 1 = the interior elements of every patch (no corner is a halo node) run one exchange ahead -- their next
+ *                  update is computed while the exchange of the sub-step is awaited; 0 = never; -1 (default) = where it is known to pay: the
+ *                  large patches of a 200 k - 400 k partition (one workgroup per CU, nothing else fills its wait: 4 % faster), not the
+ *                  one-element-per-thread patches (inside one GPU the wait is filled by the other workgroup of the CU; between GPUs it is a
+ *                  round trip over xGMI: bench.py times both and keeps one).  The same bits either way
  *   "smooth_depth" sweeps of the open-water smoother per launch on its own node-ring patches (single rank): 5, 10 or 25; 0 = automatic
  *                  (10 where ten rings of neighbours fit the LDS, else 5; sweep by sweep where neither fits)
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)

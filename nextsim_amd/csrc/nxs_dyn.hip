@@ -151,7 +151,9 @@ struct nxs_dyn_handle {
     bool no_big_cut = false;
     int res_substeps = 0; // the number of sub-steps the tables (the ghosts' ring) were sized for
     int res_wpe = 4;      // waves per SIMD of the resident kernel build in use (2 on several ranks where one workgroup per CU covers the partition)
-    int res_overlap = 0;  // option resident_overlap (several ranks): interior elements of the next sub-step computed while the exchange is awaited
+    int res_overlap = -1; // option resident_overlap: interior elements of the next sub-step computed while the exchange is awaited; -1 = where it pays
+                          // (the large patches of k_substep_resident_big: one workgroup per CU, nothing else fills its wait), 0 never, 1 wherever built
+    bool res_ovl = false; // what the tables of the resident loop were built for
     size_t res_lds = 0;
     double *d_vt3 = nullptr;
     double *d_icediag = nullptr;           // [Ne][NXS_ICE_DIAG_FIELDS] rows of nxs_dyn_ice_diagnostics (state pool: goes with the mesh)
@@ -650,7 +652,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         h->res_wide = value != 0; h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "resident_overlap")) {
-        h->res_overlap = value != 0; h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;
+        h->res_overlap = value < 0 ? -1 : (value != 0); h->res_ready = false; h->res_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "smooth_depth")) {
         if (value != 0 && value != 5 && value != 10 && value != 25) return fail(h, NXS_ERR_INVALID, "smooth_depth must be 0 (auto), 5, 10 or 25");
@@ -1538,8 +1540,10 @@ int setup_ring(nxs_dyn_handle *h, int K) {
 const void *resident_kernel(const nxs_dyn_handle *h, bool mr, bool ovl) {
     const bool p4 = h->res_pow4;
     if (h->res_big) {  // one large patch per CU, four elements and two own nodes per thread
-        if (mr) return p4 ? (const void *)k_substep_resident_big<true, true> : (const void *)k_substep_resident_big<false, true>;
-        return p4 ? (const void *)k_substep_resident_big<true, false> : (const void *)k_substep_resident_big<false, false>;
+        if (mr && ovl) return p4 ? (const void *)k_substep_resident_big<true, true, true> : (const void *)k_substep_resident_big<false, true, true>;
+        if (mr) return p4 ? (const void *)k_substep_resident_big<true, true, false> : (const void *)k_substep_resident_big<false, true, false>;
+        if (ovl) return p4 ? (const void *)k_substep_resident_big<true, false, true> : (const void *)k_substep_resident_big<false, false, true>;
+        return p4 ? (const void *)k_substep_resident_big<true, false, false> : (const void *)k_substep_resident_big<false, false, false>;
     }
     if (mr && h->res_wpe == 2 && p4) return ovl ? (const void *)k_substep_resident<512, true, true, true, 2> : (const void *)k_substep_resident<512, true, true, false, 2>;
     if (mr && ovl) return p4 ? (const void *)k_substep_resident<512, true, true, true> : (const void *)k_substep_resident<512, false, true, true>;
@@ -1634,7 +1638,8 @@ int build_resident(nxs_dyn_handle *h) {
     const int nP = hp.nP, No = h->dm.No, Nn = h->dm.Nn, S = h->dp.substeps;
     const bool mr = multi_rank(h);
     const bool big = nxs_cut::resident_is_big(hp);
-    const bool ovl = mr && h->res_overlap && !big;
+    const bool ovl = big ? h->res_overlap != 0 : (mr && h->res_overlap == 1);
+    h->res_ovl = ovl;
     auto refuse = [&](const char *why) {
         if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d resident kernel not possible: %s\n", h->rank, why);
         h->res_failed = true;
@@ -1812,7 +1817,7 @@ int run_substeps(nxs_dyn_handle *h) {
                 const HaloFused *hfp = mr ? h->d_hf : nullptr;
                 int nb = mr ? h->hf.n_boundary : 0;
                 void *args[] = {&h->dm, &h->dpch, &h->ds, &h->dw, &pdev, &h->res, &Sc, &Sn, &mdt, &hfp, &nb};
-                HIPCHK(h, hipLaunchKernel(resident_kernel(h, mr, mr && h->res_overlap), dim3(h->dpch.nP), dim3(512), args, h->res_lds, h->stream));
+                HIPCHK(h, hipLaunchKernel(resident_kernel(h, mr, h->res_ovl), dim3(h->dpch.nP), dim3(512), args, h->res_lds, h->stream));
             }
             if (mr) {
                 // the ghosts' mesh moves of all sub-steps but the last, from the ring the launch filled ...

@@ -1668,7 +1668,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE
 // launch per sub-step (tests/test_gpu_parity.py::test_resident_sub_step_loop_does_not_change_a_bit).
 #define NXS_RESB_EPT 4
 #define NXS_RESB_NPT 2
-template <bool POW4, bool HALO>
+template <bool POW4, bool HALO, bool OVL>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_substep_resident_big(DevMesh m, DevPatches pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, DevResident r,
                                                         const double *__restrict__ Sc, double *__restrict__ Sn, double move_dt,
                                                         const HaloFused *__restrict__ hfp, int n_boundary) {
@@ -1703,6 +1703,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int t = threadIdx.x, Nn = m.Nn, S = p0.substeps;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk], nNb = r.pnbr_cnt[blk];
     const int *pn = pp.pnodes + (size_t)blk * Mmax;
+    // OVL: the element list with the interior elements first (nxs_cut::plan_resident); slices j < JE of it (whole slices of T elements) hold
+    // interior elements only, and their next update is computed while the patch waits for its neighbours
+    const int *pel = (OVL ? r.pelem : pp.pelem) + (size_t)blk * Emax;
+    const ushort4 *ptr4 = reinterpret_cast<const ushort4 *>(OVL ? r.ptri : pp.ptri) + (size_t)blk * Emax;
+    const int JE = OVL ? r.ecut[blk] / T : 0, JA = (JE + 1) / 2;
     const bool bbm = p0.dynamics_type == NXS_DYN_BBM;
     if (t == 0) { lerr = 0; lF2[ZIDX] = d2{0., 0.}; }
 
@@ -1726,8 +1731,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
         for (int k = 0; k < 6; ++k) dxN[j][k] = 0.;
         if (l < nE) {
-            const int eraw = pp.pelem[(size_t)blk * Emax + l];
-            const ushort4 tr = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + l];
+            const int eraw = pel[l];
+            const ushort4 tr = ptr4[l];
             trp[j] = (unsigned)tr.x | ((unsigned)tr.y << 10) | ((unsigned)tr.z << 20);
             const bool writer = eraw >= 0;
             e[j] = writer ? eraw : ~eraw;
@@ -1743,7 +1748,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     unsigned nfl = 0u;            // per node i: bits 8 i .. 8 i + 7 the node flags, bit 24 + i has a node
     double um[NPT][4];            // the running M_UM (u, v) and M_UT (u, v) of the own nodes
     unsigned sinfo[NPT];          // HALO: where the own node is sent (see k_substep_resident)
-    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
+    const unsigned short *pf = (OVL ? r.pfan : pp.pfan) + (size_t)blk * pp.Wp * Pmax;
 #pragma unroll
     for (int i = 0; i < NPT; ++i) {
         const int sl = t + T * i;
@@ -1793,15 +1798,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
     __syncthreads();  // (sx / sy are read; lF may be written from here on)
 
-    for (int ss = 0; ss < S; ++ss) {
-        // the parameters are re-read where they are used (scalar loads that hit the constant cache), not held across the loop
-        const DevParams *pl = pdev;
-        asm volatile("" : "+s"(pl));
-        const DevParams &p = *pl;
-        // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467)
+    // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467); which: 0 every element of this thread, 1 the interior
+    // slices (j < JE), 2 the others, 3 / 4 the interior slices in two parts (j < JA, JA <= j < JE)
+    auto element_phase = [&](const DevParams &p, const int which) {
 #pragma unroll
         for (int j = 0; j < EPT; ++j) {
-            if (!(eflags & (1u << j))) continue;
+            if (!(eflags & (1u << j)) || (which == 1 && j >= JE) || (which == 2 && j < JE) || (which == 3 && j >= JA) || (which == 4 && (j < JA || j >= JE))) continue;
             const int l = t + T * j;
             double c_expC, volume, c_pmax, c_heal, c_coh, c_dxs = 1.;
             {   // the element constants: one 48-byte record, re-read every sub-step (it stays in the L2)
@@ -1826,6 +1828,19 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
             for (int k = 0; k < 3; ++k) lF2[(size_t)k * Emax + l] = d2{F[k], F[k + 3]};
         }
+    };
+    if (OVL) {  // the interior elements' first update
+        const DevParams *pl = pdev;
+        asm volatile("" : "+s"(pl));
+        element_phase(*pl, 1);
+    }
+    for (int ss = 0; ss < S; ++ss) {
+        // the parameters are re-read where they are used (scalar loads that hit the constant cache), not held across the loop
+        const DevParams *pl = pdev;
+        asm volatile("" : "+s"(pl));
+        const DevParams &p = *pl;
+        RSTAMP(0);
+        element_phase(p, OVL ? 2 : 0);
         // the nodal inputs of this thread's own nodes (80-byte records, from the L2): issued ahead of the barrier
         d2 nr[NPT][5];
 #pragma unroll
@@ -1839,6 +1854,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         __syncthreads();
+        RSTAMP(1);
         const DevParams *pq = pdev;
         asm volatile("" : "+s"(pq));
         const DevParams &q = *pq;
@@ -1890,9 +1906,11 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
             }
         }
+        RSTAMP(2);
         if (!HALO && ss == S - 1) break;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // every wave's stores have left; the corner forces have been read
+        RSTAMP(3);
         if (ss < S - 1 && t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (HALO && boundary && t == 0) {  // the last boundary patch to finish this sub-step publishes it to the neighbour ranks, in sub-step order
             if (atomicAdd(r.cnt + ss, 1u) == (unsigned)n_boundary - 1u) {
@@ -1909,6 +1927,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         if (ss == S - 1) break;
+        if (OVL) element_phase(p, 3);  // sub-step ss + 1 of the interior elements: own nodes only, all solved (the barrier above)
         if (HALO && boundary && t >= 64 && t < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
             const int k = t - 64;
             const long long t0 = wall_clock64();
@@ -1927,30 +1946,49 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         __syncthreads();
+        RSTAMP(4);
         if (lerr) break;
-        {   // the halo nodes' new velocities, past the caches
+        {   // the halo nodes' new velocities, past the caches; OVL: the first T of them travel while the second part of the interior elements is computed
             const double *X = (ss & 1) ? r.X1 : r.X0;
+            const double *mb = nullptr;
+            double *gr = nullptr;
             if (HALO) {
-                const double *mb = hfp->ipc.mailbox + ((x0 + (unsigned long long)ss) & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr;
-                double *gr = r.gring + (size_t)ss * 2 * (size_t)r.NG;
-                for (int i = nO + t; i < nM; i += T) {
-                    const int4 hv = lH[i - nO];
-                    if (hv.y >= 0) {
-                        const double gu = sys_load(mb + hv.x), gv = sys_load(mb + hv.x + hv.y);
-                        lu[i] = gu; lv[i] = gv;
-                        if (move_dt != 0.) { gr[hv.z] = gu; gr[r.NG + hv.z] = gv; }
-                    } else {
-                        lu[i] = ld_agent(X + hv.x); lv[i] = ld_agent(X + hv.x + Nn);
-                    }
-                }
-            } else {
-                for (int i = nO + t; i < nM; i += T) {
+                mb = hfp->ipc.mailbox + ((x0 + (unsigned long long)ss) & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr;
+                gr = r.gring + (size_t)ss * 2 * (size_t)r.NG;
+            }
+            auto halo_load = [&](const int i, double &hu, double &hv, int &ghost) {
+                ghost = -1;
+                if (HALO) {
+                    const int4 hv4 = lH[i - nO];
+                    if (hv4.y >= 0) { hu = sys_load(mb + hv4.x); hv = sys_load(mb + hv4.x + hv4.y); ghost = hv4.z; }
+                    else { hu = ld_agent(X + hv4.x); hv = ld_agent(X + hv4.x + Nn); }
+                } else {
                     const int g = pn[i];
-                    lu[i] = ld_agent(X + g); lv[i] = ld_agent(X + g + Nn);
+                    hu = ld_agent(X + g); hv = ld_agent(X + g + Nn);
                 }
+            };
+            auto halo_keep = [&](const int i, const double hu, const double hv, const int ghost) {
+                lu[i] = hu; lv[i] = hv;
+                if (HALO && ghost >= 0 && move_dt != 0.) { gr[ghost] = hu; gr[r.NG + ghost] = hv; }
+            };
+            int i0 = nO + t;
+            if (OVL) {
+                double hu = 0., hv = 0.;
+                int ghost = -1;
+                if (i0 < nM) halo_load(i0, hu, hv, ghost);
+                element_phase(p, 4);
+                if (i0 < nM) halo_keep(i0, hu, hv, ghost);
+                i0 += T;
+            }
+            for (int i = i0; i < nM; i += T) {
+                double hu, hv;
+                int ghost;
+                halo_load(i, hu, hv, ghost);
+                halo_keep(i, hu, hv, ghost);
             }
         }
         __syncthreads();
+        RSTAMP(5);
     }
     // ---- once per step: the element state and the moved mesh go back -- unless a wait timed out (see k_substep_resident)
     __syncthreads();

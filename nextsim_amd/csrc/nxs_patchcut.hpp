@@ -733,7 +733,6 @@ inline void plan_resident(const HostPatches &hp, int Nn, int No, bool multi_rank
         snprintf(msg, sizeof msg, "a patch holds %d elements / %d own nodes / %d staged nodes (at most %d / %d / 1024)", hp.Emax, hp.Pmax, hp.Mmax, 512 * NXS_CUT_RESB_EPT, 512 * NXS_CUT_RESB_NPT);
         return refuse(msg);
     }
-    if (big && overlap) return refuse("the overlap variant exists for patches of one element per thread only");
     std::vector<int> owner(Nn, -1);
     for (int q = 0; q < nP; ++q)
         for (int i = 0; i < hp.own_cnt[q]; ++i) owner[hp.pnodes[(size_t)q * hp.Mmax + i]] = q;
@@ -762,7 +761,8 @@ inline void plan_resident(const HostPatches &hp, int Nn, int No, bool multi_rank
     if (overlap) {
         // Interior elements first: an element none of whose corners is a halo node of its patch needs nothing from outside, so its next
         // update can be computed while the patch waits for the exchange.  A stable partition of every patch's element list (whole
-        // wavefronts of interior elements only: ecut is a multiple of 64); the fan entries keep their (ascending global element) order and
+        // wavefronts of interior elements only: ecut is a multiple of 64 -- of 512, whole slices of one element per thread, for the large patches of
+        // k_substep_resident_big); the fan entries keep their (ascending global element) order and
         // only name the new slots, so the additions of the gather stay the reference's.
         out.rpelem.assign(hp.pelem.size(), 0); out.ecut.assign(nP, 0);
         out.rptri.assign(hp.ptri.size(), 0); out.rpfan.assign(hp.pfan.size(), 0xFFFF);
@@ -785,7 +785,7 @@ inline void plan_resident(const HostPatches &hp, int Nn, int No, bool multi_rank
                 const unsigned short ent = hp.pfan[i];
                 out.rpfan[i] = ent == 0xFFFF ? ent : (unsigned short)((newslot[ent >> 3] << 3) | (ent & 7));
             }
-            out.ecut[q] = (nint / 64) * 64;
+            out.ecut[q] = big ? (nint / 512) * 512 : (nint / 64) * 64;
             tot_early += out.ecut[q]; tot_e += nE;
         }
         out.early_fraction = (double)tot_early / (double)std::max(1ll, tot_e);

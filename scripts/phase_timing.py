@@ -5,7 +5,7 @@
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true"); ap.add_argument("--resident", action="store_true")
+ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true"); ap.add_argument("--resident", action="store_true"); ap.add_argument("--opt", action="append", default=[], help="key=value for set_option (before set_mesh)")
 a = ap.parse_args()
 csrc = os.path.join(ROOT, "nextsim_amd", "csrc")
 if a.build:
@@ -22,6 +22,7 @@ g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
 lm = M.localize(gm, 1)[0]; f = F.localize_fields(g, lm, gm.num_nodes)
 fe = dynamics.FiniteElementDynamics(p); fe.set_option("graph", 0)
 if a.resident: fe.set_option("fused", 4)
+for kv in a.opt: fe.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
 fe.step(); fe.step(); fe.synchronize()
 t = fe.debug_array("phase_times")

@@ -2,7 +2,8 @@
 (two threads, two handles, in-process mailboxes), both cut into the 180-node patches a rank of eight has (a mesh of 173 k triangles, so that 2 x 245 workgroups fit the 512 slots together) a rank of eight has -- 2 x 256 workgroups, i.e. every CU holds
 two resident patches exactly as on the real machine, and the exchange between the ranks runs inside the resident launch (minus xGMI: both ranks
 share the device).  Prints each rank's per-step timing for the resident launch (plain and with the interior elements under the exchange) and checks
-the bits against the separate kernels and the oracle.        python3 scripts/rehearse_rank_of_eight.py [steps]"""
+the bits against the separate kernels and the oracle.        python3 scripts/rehearse_rank_of_eight.py [steps]
+NXS_PN=360: the same partition as 2 x 123 patches of 360 nodes, one 512-thread workgroup per CU with several elements per thread (k_substep_resident_big)."""
 import json, os, sys, tempfile, pathlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -11,7 +12,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 KIND = sys.argv[2] if len(sys.argv) > 2 else "h16000"   # 173 k triangles: two ranks of ~245 patches of 180 nodes fit the 512 slots together
 for overlap in (0, 1):
     with tempfile.TemporaryDirectory() as d:
-        reps = T._run(2, KIND, steps, pathlib.Path(d), "ipc", over={"options": {"fused": 4, "patch_nodes": 180, "resident_overlap": overlap, "resident_wide": int(os.environ.get("NXS_WIDE", "0"))}}, ranks_per_proc=int(os.environ.get("NXS_RPP", "2")))
+        reps = T._run(2, KIND, steps, pathlib.Path(d), "ipc", over={"options": {"fused": 4, "patch_nodes": int(os.environ.get("NXS_PN", "180")), "resident_overlap": overlap, "resident_wide": int(os.environ.get("NXS_WIDE", "0"))}}, ranks_per_proc=int(os.environ.get("NXS_RPP", "2")))
     for r in reps:
         tm = r.get("timing", {})
         if not r["ok"]: print("   ", {k: v for k, v in r.items() if k not in ("timing",)})

@@ -160,7 +160,7 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     std::vector<int> pet;
     pack_pet(hp, pet);
     REQUIRE(pet.size() == 2 * (size_t)hp.nP * hp.Emax, "pet size");
-    stats[16] = plan.cut_big; stats[0] = hp.nP; stats[1] = hp.Pmax; stats[2] = hp.Emax; stats[3] = hp.Mmax; stats[4] = hp.Wp; stats[5] = hp.used_hilbert; stats[6] = (int64_t)plan.fused_lds; stats[7] = plan.P;
+    stats[16] = plan.cut_big; for (int q = 0; q < hp.nP; ++q) { stats[17] += hp.elem_cnt[q]; stats[18] += (hp.elem_cnt[q] + 63) / 64 > 24; stats[19] = std::max<int64_t>(stats[19], hp.node_cnt[q] - hp.own_cnt[q]); } stats[0] = hp.nP; stats[1] = hp.Pmax; stats[2] = hp.Emax; stats[3] = hp.Mmax; stats[4] = hp.Wp; stats[5] = hp.used_hilbert; stats[6] = (int64_t)plan.fused_lds; stats[7] = plan.P;
     const bool mr = ns > 0 || nr > 0 || No < Nn;
     if (mr) {
         const std::vector<int> so(send_offsets, send_offsets + ns + 1), ro(recv_offsets, recv_offsets + nr + 1);
@@ -196,18 +196,19 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     }
     {
         ResidentPlan rp;
-        plan_resident(hp, Nn, No, mr, ns, overlap != 0 && mr && !resident_is_big(hp), rp);
+        const bool big = resident_is_big(hp), ovl = overlap != 0 && (mr || big);
+        plan_resident(hp, Nn, No, mr, ns, ovl, rp);
         stats[8] = rp.ok; stats[9] = rp.max_nbr;
         if (rp.ok) {
             for (int q = 0; q < hp.nP; ++q) {
                 REQUIRE(rp.cnt[q] >= 0 && rp.cnt[q] <= NXS_CUT_RES_NBR, "patch %d waits for %d patches", q, rp.cnt[q]);
                 for (int k = 0; k < rp.cnt[q]; ++k) { const int o = rp.nbr[(size_t)q * NXS_CUT_RES_NBR + k]; REQUIRE(o >= 0 && o < hp.nP && o != q, "patch %d neighbour %d", q, o); }
             }
-            if (overlap && mr && !resident_is_big(hp)) {  // the overlap variant's lists are a permutation of the patch's with interior elements first
+            if (ovl) {  // the overlap variant's lists are a permutation of the patch's with interior elements first
                 HostPatches alt = hp;
                 alt.pelem = rp.rpelem; alt.ptri = rp.rptri; alt.pfan = rp.rpfan;
                 for (int q = 0; q < hp.nP; ++q) {
-                    REQUIRE(rp.ecut[q] % 64 == 0 && rp.ecut[q] <= hp.elem_cnt[q], "patch %d: ecut=%d", q, rp.ecut[q]);
+                    REQUIRE(rp.ecut[q] % (big ? 512 : 64) == 0 && rp.ecut[q] <= hp.elem_cnt[q], "patch %d: ecut=%d", q, rp.ecut[q]);
                     std::vector<int> a(hp.pelem.begin() + (size_t)q * hp.Emax, hp.pelem.begin() + (size_t)q * hp.Emax + hp.elem_cnt[q]);
                     std::vector<int> b(rp.rpelem.begin() + (size_t)q * hp.Emax, rp.rpelem.begin() + (size_t)q * hp.Emax + hp.elem_cnt[q]);
                     std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());

@@ -166,7 +166,7 @@ def run_cut(lm, patch_nodes=0, want_resident=0, overlap=0, cus=256, res_ept=1, t
                     W2, depth_multi, depth_smooth, stats.ctypes.data_as(I64), msg, 512)
     assert rc == expect, (rc, msg.value.decode())
     return dict(zip(("nP", "Pmax", "Emax", "Mmax", "Wp", "hilbert", "lds", "P", "res_ok", "res_nbr", "n_boundary", "reordered", "m_nP", "m_EDmax",
-                     "s_nP", "s_NDmax", "cut_big"), stats.tolist()))
+                     "s_nP", "s_NDmax", "cut_big", "sum_elem", "over_24_passes", "max_halo"), stats.tolist()))
 
 
 def shuffled(gm, seed):
@@ -218,7 +218,7 @@ for kind in ("10km", "2km"):
         r = run_cut(lm_p, want_resident=1)
         assert r["res_ok"] == 1 and r["Emax"] <= 512 and r["nP"] <= 512 and r["cut_big"] == 0, (kind, lm_p.rank, r)
 for lm_p in M.localize(M.make_mesh("2km"), 4):     # ... and the four parts of a 4-GPU run: one large patch per CU (k_substep_resident_big)
-    r = run_cut(lm_p, want_resident=1)
+    r = run_cut(lm_p, want_resident=1, overlap=1)   # (with the interior-first lists: whole slices of 512 elements)
     assert r["res_ok"] == 1 and r["cut_big"] == 1 and r["nP"] <= 256, (lm_p.rank, r)
 # 4e. the Hilbert order on coordinates nobody should pass: NaN, infinities, one point, all equal, empty
 msg = C.create_string_buffer(256)

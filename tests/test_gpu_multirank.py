@@ -238,7 +238,8 @@ def test_ipc_connect_checks_its_tables_against_what_the_neighbour_published():
                                                          (8, "10km", 2, {}, 0), (2, "small", 1, {}, 1), (3, "small", 1, {"ragged_seed": 1, "dynamics_type": 3}, 1),
                                                          (8, "10km", 2, {}, 1), (2, "40km", 1, {}, 1),
                                                          # overlap = 600: patches of 600 nodes asked for (cut to ~450: more than one element per thread) -> k_substep_resident_big
-                                                         (2, "40km", 2, {}, 600), (3, "40km", 1, {"ragged_seed": 3, "dynamics_type": 3}, 600)])
+                                                         # (there the interior elements run ahead by default; -600: without)
+                                                         (2, "40km", 2, {}, 600), (3, "40km", 1, {"ragged_seed": 3, "dynamics_type": 3}, 600), (2, "40km", 2, {}, -600)])
 def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rpp, over, overlap, tmp_path):
     """Option fused = 4 on several ranks: ONE launch per rank for the whole sub-step loop; boundary patches send into the
     neighbour ranks' mailboxes and read their ghosts from their own once per sub-step, the last boundary patch of a sub-step
@@ -247,7 +248,8 @@ def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rp
     1e-10 of the multi-rank oracle.  (The meshes are small enough for every rank's workgroups to be resident on ONE device.)
     overlap = 1: option resident_overlap -- the interior elements of every patch run one exchange ahead (their next update is computed
     while the exchange is awaited): the same bits."""
-    options = {"fused": 4, "resident_overlap": overlap} if overlap <= 1 else {"patch_nodes": overlap, "fused": 4}
+    options = {"fused": 4, "resident_overlap": overlap} if 0 <= overlap <= 1 else {"patch_nodes": abs(overlap), "fused": 4}
+    if overlap < 0: options["resident_overlap"] = 0
     reps = _run(world, kind, 1, tmp_path, "ipc", over=dict(over, options=options), ranks_per_proc=rpp)
     for r in reps:
         assert r["ok"], r

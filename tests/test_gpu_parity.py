@@ -607,14 +607,15 @@ def test_resident_sub_step_loop_does_not_change_a_bit(kind, over):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("kind,over,opts", [("h11000", {}, {}), ("40km", {}, {"patch_nodes": 600}), ("40km", {"dynamics_type": 3}, {"patch_nodes": 1000}),
+@pytest.mark.parametrize("kind,over,opts", [("h11000", {}, {}), ("h11000", {}, {"resident_overlap": 0}), ("40km", {}, {"patch_nodes": 600}),
+                                            ("40km", {"dynamics_type": 3}, {"patch_nodes": 1000}), ("40km", {"dynamics_type": 3}, {"patch_nodes": 1000, "resident_overlap": 0}),
                                             ("small", {"substeps": 7, "dtime_step": 200. * 7 / 120}, {"patch_nodes": 700})])
 def test_resident_sub_step_loop_on_one_large_patch_per_cu_does_not_change_a_bit(kind, over, opts):
     """k_substep_resident_big: where a partition is too large for one element per thread (367 k triangles, a rank of four of the 2 km mesh, cut
     automatically into 256 patches of ~720 nodes when fused = 4 is set before set_mesh; or patches of 600 - 1000 nodes asked for explicitly) the
     resident loop runs ONE 512-thread workgroup per CU with four elements and two own nodes per thread -- stress, damage, shape coefficients and the
     moving mesh in registers, element constants and nodal inputs re-read from L2 -- and gives the bits of one launch per sub-step: BBM, EVP, an
-    odd number of sub-steps."""
+    odd number of sub-steps; with (the default here) and without the interior elements' next update computed under the wait for the neighbours."""
     a, _, _ = _pair(kind, 2, options=dict(opts, fused=1), **over)
     b, _, _ = _pair(kind, 2, options=dict({"fused": 4}, **opts), **over)
     sa, sb = a.get_state(), b.get_state()
