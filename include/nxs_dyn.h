@@ -311,6 +311,9 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  large patches of a 200 k - 400 k partition (one workgroup per CU, nothing else fills its wait: 4 % faster), not the
  *                  one-element-per-thread patches (inside one GPU the wait is filled by the other workgroup of the CU; between GPUs it is a
  *                  round trip over xGMI: bench.py times both and keeps one).  The same bits either way
+ *   "prep_fused"   single rank: prep elements + prep nodes (FE.cpp:10235-10416) as ONE launch over the sub-step kernel's node patches, the elements'
+ *                  values reaching their nodes through LDS (k_prep_fused: 2 km mesh 203 -> 113 us per step, the same bits): -1 (default) =
+ *                  on meshes of 250 k triangles and more, 0 = never, 1 = wherever its tables exist
  *   "smooth_depth" sweeps of the open-water smoother per launch on its own node-ring patches (single rank): 5, 10 or 25; 0 = automatic
  *                  (10 where ten rings of neighbours fit the LDS, else 5; sweep by sweep where neither fits)
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)

@@ -105,6 +105,9 @@ struct nxs_dyn_handle {
     size_t fused_lds = 0;
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
     std::vector<int> h_n2n, h_n2n_cnt;     // NodalConnectivity rows [W2][Nn] + counts (for the blocked smoother's tables)
+    std::vector<int> h_n2e;                // NodalElementConnectivity rows [W1][Nn], -1 = pad (for k_prep_fused's rows in patch slots)
+    size_t prep_lds = 0;                   // LDS of k_prep_fused for the current patches; 0: the two separate prep kernels run
+    int prep_fused = -1;                   // option "prep_fused": -1 where it pays (single rank, records only, >= 250 k triangles), 0 never, 1 wherever it can run
     size_t smooth_lds = 0;
     // node-ring patches for the smoother alone (single rank, meshes on the one-sub-step-per-launch kernels): D sweeps per launch
     DevPatches2 dsm{};
@@ -666,7 +669,8 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         if (value != 0 && (value < 16 || value > 512)) return fail(h, NXS_ERR_INVALID, "pair_nodes must be 0 (auto) or in [16,512]");
         h->pair_nodes = (int)value; h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
-    if (!std::strcmp(key, "work_arrays")) { h->work_arrays = value != 0; return NXS_OK; }
+    if (!std::strcmp(key, "work_arrays")) { h->work_arrays = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "prep_fused")) { h->prep_fused = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "shape_mem")) {
         if (value < -1 || value > 1) return fail(h, NXS_ERR_INVALID, "shape_mem must be -1 (auto), 0 or 1");
         h->shape_mem = (int)value; release_graph(h);
@@ -840,7 +844,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
         if ((rc = dev_upload(h, h->mesh_allocs, &d.n2e, n2e))) return rc;
         if ((rc = dev_upload(h, h->mesh_allocs, &d.n2n, n2n))) return rc;
         if ((rc = dev_upload(h, h->mesh_allocs, &d.n2n_cnt, cnt))) return rc;
-        h->h_n2n = std::move(n2n); h->h_n2n_cnt = std::move(cnt);
+        h->h_n2n = std::move(n2n); h->h_n2n_cnt = std::move(cnt); h->h_n2e = std::move(n2e);
     }
 
     // state + work arrays
@@ -1390,6 +1394,20 @@ int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_
             HIPCHK(h, hipStreamSynchronize(h->stream));
             return NXS_OK;
         }
+    {   // what the fused path does fill: the records of the sub-step kernels and the prep kernels' other outputs (explicit_solve leaves them as the
+        // prep kernels wrote them; step() goes on to update(), which renews M_surface)
+        struct { const char *nm; const double *p; int64_t len; } rec[] = {
+            {"erec", h->dw.erec, 6 * Ne}, {"nrec", h->dw.nrec, 10 * Nn}, {"xy", h->dw.xy, 2 * Nn}, {"delta_x", h->dw.delta_x, Ne},
+            {"surface", h->dw.surface, Ne}, {"tau_a", h->dw.D_tau_a, 2 * Nn},
+        };
+        for (auto &t : rec)
+            if (!std::strcmp(t.nm, name)) {
+                if (n != t.len) return fail(h, NXS_ERR_INVALID, "debug_array %s has %lld entries, caller asked %lld", name, (long long)t.len, (long long)n);
+                HIPCHK(h, hipMemcpyAsync(out, t.p, n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+                HIPCHK(h, hipStreamSynchronize(h->stream));
+                return NXS_OK;
+            }
+    }
 #ifdef NXS_PHASE_TIMING
     if (!std::strcmp(name, "phase_times")) {  // [8192][8] timestamps (100 MHz) of the last fused launch, as doubles
         std::vector<long long> t(8 * 8192);
@@ -1922,7 +1940,13 @@ int explicit_solve(nxs_dyn_handle *h) {
         h->dp_dirty = false;
     }
     // the fused kernels read records only: the per-quantity work vectors (v1 kernels, debug door) are filled on request
-    if (eff_fused(h) != 0 && !h->work_arrays) {
+    // (automatic: meshes that stream from HBM; on cache-resident ones the two small kernels are as fast: 10 km 24.7 vs 27.4 us)
+    if (eff_fused(h) != 0 && !h->work_arrays && (h->prep_fused == 1 || (h->prep_fused < 0 && m.Ne >= 250000)) && h->prep_lds > 0 && h->dpch.prow && h->dpch.nP > 0 && !multi_rank(h)) {
+        // one launch over the sub-step kernel's patches: the elements' values reach their nodes through LDS (k_prep_fused)
+        HIPCHK(h, hipMemsetAsync(h->dw.open_blk, 0, (size_t)nblocks(m.Nn), h->stream));  // (k_prep_elements' first lines)
+        hipLaunchKernelGGL(k_prep_fused, dim3(h->dpch.nP), dim3(512), h->prep_lds, h->stream, m, h->dpch, h->ds, h->dw, h->dp);
+        HIPCHK(h, hipGetLastError());
+    } else if (eff_fused(h) != 0 && !h->work_arrays) {
         LAUNCH(h, k_prep_elements<true>, m.Ne, m, h->ds, h->dw, h->dp);
         LAUNCH(h, k_prep_nodes<true>, m.Nn, m, h->ds, h->dw, h->dp);
     } else {

@@ -69,6 +69,8 @@ struct DevPatches {
     const unsigned short *ptri;   // [nP][Emax][4] patch-local node slots of the 3 corners (+ pad)
     const unsigned short *pfan;   // [nP][Wp][Pmax] (element slot << 3 | ghost << 2 | corner), 0xFFFF pad
     const int2 *pet;              // [nP][Emax] {pelem, the three corner slots in 10 bits each} -- what k_substep_fused reads: 8 bytes per element instead of 12
+    const unsigned short *prow;   // [nP][W1][Pmax] NodalElementConnectivity of the own nodes in patch element slots, bamg row order, 0xFFFF = none (k_prep_fused; nullptr: not built)
+    int W1;
 };
 
 // Patches of the several-sub-steps-per-launch kernel (k_substep_multi): D rings of halo around the own nodes.
@@ -372,6 +374,229 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
         const size_t base = (size_t)blk * BLOCK * 10;
         const int count = min(BLOCK, Nn - blk * BLOCK) * 10;
         for (int i = threadIdx.x; i < count; i += BLOCK) w.nrec[base + i] = rec[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1a + K1b + K2 in ONE launch over the node patches of the fused sub-step kernel (single rank, LEAN): k_prep_elements' per-element values are
+// formed by the patch that needs them and handed to its own nodes through LDS instead of through 72-byte records in memory that every corner
+// node gathers again (k_prep_nodes reads 596 MB on the 2 km mesh, three times the records' size).  A patch computes every element that touches
+// an own node (x 1.12 at 476-node patches) and keeps of it what the nodal loops take: mass x area and C_bu (FE.cpp:10314-10317), area and
+// drag x area (FE.cpp:10383-10390), and -- instead of the six ssh-gradient products -- the Jacobian and the corner slots: the node side forms
+// (vy[kp1] - vy[kp2]) / jac * m_g_A3rd * ssh[j] again from the staged coordinates (the same operations on the same values, so the same bits;
+// 48 bytes of LDS per element instead of 96, which is what lets two workgroups share a CU).  The element that a patch WRITES (pelem >= 0; every
+// element has one writer) also gets its M_delta_x, M_surface and the 48-byte record of sub-step constants.  Operand for operand the two
+// kernels above: tests/test_gpu_parity.py::test_fused_prep_kernel_does_not_change_a_bit.
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_prep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p) {
+    constexpr int T = 512;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int Mmax = pp.Mmax, Emax = pp.Emax, Pmax = pp.Pmax, Mp = (Mmax + 1) & ~1, Nn = m.Nn;
+    double *lx = lds, *ly = lx + Mp, *ls = ly + Mp;
+    d2 *lA = reinterpret_cast<d2 *>(ls + Mp), *lB = lA + Emax;
+    double *lJ = reinterpret_cast<double *>(lB + Emax);
+    ushort4 *lT = reinterpret_cast<ushort4 *>(lJ + Emax);
+    int blk;
+    {
+        const int nb = (int)gridDim.x, pos = (int)blockIdx.x, q = nb >> 3, r = nb & 7, x = pos & 7;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
+    }
+    const int t = threadIdx.x;
+    const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
+    const int *pn = pp.pnodes + (size_t)blk * Mmax;
+    for (int i = t; i < nM; i += T) {  // GmshMesh::vertices(indices, um, 1.) per node (load_vertices' expression), and the ssh the elements average
+        const int g = pn[i];
+        const double x = m.x0[g] + 1. * s.UM[g], y = m.y0[g] + 1. * s.UM[g + Nn];
+        lx[i] = x; ly[i] = y; ls[i] = s.ssh[g];
+        if (i < nO) reinterpret_cast<d2 *>(w.xy)[g] = d2{x, y};
+    }
+    __syncthreads();
+    // ---- k_prep_elements (FE.cpp:10235-10308), two elements of this thread at a time: their indices, then all their fields, then the arithmetic --
+    // element by element the two dependent load levels would be paid once per element
+    constexpr int NB = 2;
+    for (int l0 = t; l0 < nE; l0 += NB * T) {
+        int eraw[NB];
+        ushort4 trs[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int l = l0 + j * T;
+            eraw[j] = 0; trs[j] = make_ushort4(0, 0, 0, 0);
+            if (l < nE) { eraw[j] = pp.pelem[(size_t)blk * Emax + l]; trs[j] = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + l]; }
+        }
+        double f_conc[NB], f_thick[NB], f_snow[NB], f_cy[NB], f_hy[NB], f_hsy[NB], f_depth[NB], f_drag[NB], f_dragy[NB], f_theal[NB], f_coh[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int l = l0 + j * T;
+            const int e = eraw[j] >= 0 ? eraw[j] : ~eraw[j];
+            f_conc[j] = f_thick[j] = f_snow[j] = f_cy[j] = f_hy[j] = f_hsy[j] = f_depth[j] = f_drag[j] = f_dragy[j] = 0.; f_theal[j] = 1.; f_coh[j] = 0.;
+            if (l < nE) {
+                f_conc[j] = s.conc[e]; f_thick[j] = s.thick[e]; f_snow[j] = s.snow[e]; f_depth[j] = s.depth[e]; f_drag[j] = s.drag_ui[e];
+                if (p.young_cat) { f_cy[j] = s.cyoung[e]; f_hy[j] = s.hyoung[e]; f_hsy[j] = s.hsyoung[e]; f_dragy[j] = s.drag_ui_young[e]; }
+                if (eraw[j] >= 0) { f_coh[j] = s.cohesion[e]; if (p.dynamics_type == NXS_DYN_BBM) f_theal[j] = s.theal[e]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+        const int l = l0 + j * T;
+        if (l >= nE) continue;
+        const bool writer = eraw[j] >= 0;
+        const int e = writer ? eraw[j] : ~eraw[j];
+        const ushort4 tr = trs[j];
+        const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
+        const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
+        const double jac = jacobian(vx, vy);
+        const double surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
+        const double conc = f_conc[j], thick = f_thick[j];
+        double total_concentration = conc, total_thickness = thick, total_snow = f_snow[j];
+        if (p.young_cat) {
+            total_concentration += f_cy[j];
+            total_thickness += f_hy[j];
+            total_snow += f_hsy[j];
+        }
+        double element_mass = 0.;
+        if (total_concentration > 0.)
+            element_mass = (NXS_RHOI * total_thickness + NXS_RHOS * total_snow) / total_concentration;
+        double element_ssh = 0;
+        element_ssh += ls[tr.x];
+        element_ssh += ls[tr.y];
+        element_ssh += ls[tr.z];
+        element_ssh /= 3.;
+        const double max_keel_depth = 28;
+        const double min_water_depth = 2.;
+        const double depth_eff = STD_MAX(0., element_ssh + STD_MAX(min_water_depth, f_depth[j]));
+        double critical_h = 0., critical_h_mod = 0.;
+        if (p.basal_stress_type == NXS_BASAL_LEMIEUX) {
+            double mean_keel_depth = p.k1 * thick;
+            mean_keel_depth = STD_MIN(mean_keel_depth, conc * max_keel_depth);
+            critical_h = conc * depth_eff / p.k1;
+            critical_h_mod = mean_keel_depth / p.k1;
+        }
+        const double ecbu = p.k2 * STD_MAX(0., critical_h_mod - critical_h) * exp(-p.Cb * (1. - conc));
+        const double meA = element_mass * surface;           // FE.cpp:10314
+        double dragp = f_drag[j];                             // FE.cpp:10585-10596
+        if (p.young_cat) {
+            const double cy = f_cy[j];
+            if (conc + cy > 0.) dragp = (f_drag[j] * conc + f_dragy[j] * cy) / (conc + cy);
+        }
+        lA[l] = d2{meA, ecbu};
+        lB[l] = d2{surface, dragp * surface};
+        lJ[l] = jac;
+        lT[l] = tr;
+        if (!writer) continue;
+        // Q1 (FE.cpp:10239): int accumulator, then unsigned integer division by 3
+        const double side0 = hypot(vx[1] - vx[0], vy[1] - vy[0]);
+        const double side1 = hypot(vx[2] - vx[1], vy[2] - vy[1]);
+        const double side2 = hypot(vx[2] - vx[0], vy[2] - vy[0]);
+        int acc = 0;
+        acc = (int)(acc + side0);
+        acc = (int)(acc + side1);
+        acc = (int)(acc + side2);
+        const int acc_div3 = (int)((unsigned long)acc / 3ul);
+        w.delta_x[e] = (double)((unsigned long)acc / 3ul);
+        w.surface[e] = surface;
+        if (w.srec) {
+            double sc[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {  // FE.cpp:1956-1962
+                const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+                sc[k] = (vy[kp1] - vy[kp2]) / jac;
+                sc[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+            }
+            d2 *r = reinterpret_cast<d2 *>(w.srec) + 3 * (size_t)e;
+            r[0] = d2{sc[0], sc[1]}; r[1] = d2{sc[2], sc[3]}; r[2] = d2{sc[4], sc[5]};
+        }
+        double c_expC, c_pmax = 0., c_heal = 0.;
+        int c_dxi = 0, c_skip;
+        if (p.dynamics_type == NXS_DYN_BBM) {
+            c_expC = exp(p.compaction_param * (1. - conc));                        // FE.cpp:4185
+            c_pmax = pow(thick, p.ecf) * p.compression_factor * c_expC;            // FE.cpp:4192
+            c_heal = p.dte / f_theal[j] * c_expC;                                  // FE.cpp:4257
+            c_skip = (conc <= 0.1) ? 1 : 0;                                        // Q5, FE.cpp:4146-4151
+            c_dxi = (conc <= 0.1) ? ~acc_div3 : acc_div3;
+        } else {
+            c_expC = p.evp_Pstar * exp(-p.evp_C * (1. - conc));                    // FE.cpp:10684 (P)
+            c_skip = (thick == 0.) ? 1 : 0;                                        // FE.cpp:10656
+        }
+        const double c_vol = thick * surface;                                      // FE.cpp:10450
+        d2 *r = reinterpret_cast<d2 *>(w.erec) + 3 * (size_t)e;
+        r[0] = d2{c_expC, c_vol}; r[1] = d2{c_pmax, c_heal};
+        r[2] = d2{f_coh[j], __longlong_as_double(((long long)c_skip << 32) | (long long)(unsigned int)c_dxi)};
+    }
+    }
+    __syncthreads();
+    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
+    const unsigned short *pr = pp.prow + (size_t)blk * pp.W1 * Pmax;
+    for (int sl = t; sl < nO; sl += T) {  // ---- k_prep_nodes (FE.cpp:10309-10416)
+        const int n = pn[sl];
+        // every load of this node is issued before anything is used (the fan loop below ends at the first pad: fetched entry by entry it is a chain
+        // of up to Wp dependent global loads per node)
+        unsigned ents[8], rows[10];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) ents[k] = k < pp.Wp ? pf[(size_t)k * Pmax + sl] : 0xFFFFu;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) rows[j] = j < pp.W1 ? pr[(size_t)j * Pmax + sl] : 0xFFFFu;
+        const bool dirichlet = m.nflags[n] & NF_DIRICHLET;
+        const double vt_u = s.VT[n], vt_v = s.VT[n + Nn], wu = s.wind[n], wv = s.wind[n + Nn], latn = m.lat[n], ocu = s.ocean[n], ocv = s.ocean[n + Nn];
+        double rl = 0., nm = 0., cb = 0., gu = 0., gv = 0.;
+        auto fan_entry = [&](const unsigned ent) {
+            const unsigned slot = ent >> 3;
+            const d2 A = lA[slot];
+            rl += lB[slot].x;                              // FE.cpp:10313
+            nm += A.x;                                     // FE.cpp:10314
+            cb = STD_MAX(cb, A.y);                         // FE.cpp:10317
+            // Q7: the skip test sees node_mass as accumulated so far (elements <= e)
+            if (dirichlet || nm == 0. || (ent & 4u)) return;
+            const ushort4 tr = lT[slot];
+            const double jac = lJ[slot];
+            const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
+            const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
+            const double sshn[3] = {ls[tr.x], ls[tr.y], ls[tr.z]};
+            const double m_g_A3rd = A.x * (NXS_GRAVITY / 3.);    // FE.cpp:10321
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {                  // FE.cpp:10334-10339
+                const int kp1 = (j + 1) % 3, kp2 = (j + 2) % 3;
+                gu -= (vy[kp1] - vy[kp2]) / jac * m_g_A3rd * sshn[j];
+                gv -= (vx[kp2] - vx[kp1]) / jac * m_g_A3rd * sshn[j];
+            }
+        };
+        bool more = true;  // (the fan ends at its first pad)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            more = more && ents[k] != 0xFFFFu;
+            if (more) fan_entry(ents[k]);
+        }
+        for (int k = 8; more && k < pp.Wp; ++k) {
+            const unsigned ent = pf[(size_t)k * Pmax + sl];
+            if (ent == 0xFFFFu) break;
+            fan_entry(ent);
+        }
+        // prep nodes, FE.cpp:10356-10416
+        double vu = vt_u, vv = vt_v;
+        if (nm == 0.) { vu = 0.; vv = 0.; s.VT[n] = 0.; s.VT[n + Nn] = 0.; }
+        double drag = 0., surface = 0;
+        auto row_entry = [&](const unsigned se) {          // bamg row order (summation order!)
+            if (se == 0xFFFFu) return;                     // Q2
+            const d2 B = lB[se];
+            drag += B.y;                                   // dragp * surface
+            surface += B.x;
+        };
+#pragma unroll
+        for (int j = 0; j < 10; ++j) row_entry(rows[j]);
+        for (int j = 10; j < pp.W1; ++j) row_entry(pr[(size_t)j * Pmax + sl]);
+        drag *= NXS_RHOA * hypot(wu, wv) / surface;        // Q6
+        const double tax = drag * wu, tay = drag * wv;
+        w.D_tau_a[n] = tax;
+        w.D_tau_a[n + Nn] = tay;
+        const double fc = 2 * NXS_OMEGA * sin(latn * NXS_PI / 180.);
+        rl = 1. / rl;                                      // FE.cpp:10400-10402
+        nm *= rl;
+        rl *= 3.;
+        w.node_mass[n] = nm;
+        if (n < m.No && !dirichlet && nm == 0.) w.open_blk[n / BLOCK] = 1;
+        w.VTM[n] = vu;
+        w.VTM[n + Nn] = vv;
+        d2 *r = reinterpret_cast<d2 *>(w.nrec) + 5 * (size_t)n;
+        r[0] = d2{nm, gu}; r[1] = d2{gv, rl}; r[2] = d2{cb, fc}; r[3] = d2{tax, tay}; r[4] = d2{ocu, ocv};
     }
 }
 

@@ -484,6 +484,37 @@ inline void pack_pet(const HostPatches &hp, std::vector<int> &pet_xy) {
     }
 }
 
+// The bamg-order rows of k_prep_fused: NodalElementConnectivity of every own node of every patch with the elements named by their patch slots
+// ([nP][W1][Pmax], 0xFFFF = no element: NaN pad, Q2).  n2e: [W1][Nn] global element numbers, -1 = pad.  Every element of an own node's row is in
+// the patch (a patch holds all elements that touch its own nodes); a row that names an element outside it -- a caller-supplied table that does not
+// belong to this mesh -- makes the function return false, and the caller keeps the two separate kernels.
+inline bool build_prep_rows(const HostPatches &hp, const int *n2e, int W1, int Nn, std::vector<unsigned short> &rows) {
+    rows.assign((size_t)hp.nP * W1 * hp.Pmax, 0xFFFF);
+    std::vector<std::pair<int, int>> byid;
+    for (int q = 0; q < hp.nP; ++q) {
+        const int nE = hp.elem_cnt[q];
+        byid.resize(nE);
+        for (int l = 0; l < nE; ++l) { const int raw = hp.pelem[(size_t)q * hp.Emax + l]; byid[l] = {raw >= 0 ? raw : ~raw, l}; }
+        std::sort(byid.begin(), byid.end());
+        for (int i = 0; i < hp.own_cnt[q]; ++i) {
+            const int n = hp.pnodes[(size_t)q * hp.Mmax + i];
+            if (n < 0 || n >= Nn) return false;
+            for (int j = 0; j < W1; ++j) {
+                const int e = n2e[(size_t)j * Nn + n];
+                if (e < 0) continue;
+                auto it = std::lower_bound(byid.begin(), byid.end(), std::make_pair(e, -1));
+                if (it == byid.end() || it->first != e) return false;
+                rows[((size_t)q * W1 + j) * hp.Pmax + i] = (unsigned short)it->second;
+            }
+        }
+    }
+    return true;
+}
+// LDS of k_prep_fused: displaced coordinates and ssh of the staged nodes; per patch element (mass x area, C_bu), (area, drag x area), the Jacobian, the corner slots
+inline size_t prep_fused_lds_of(const HostPatches &hp) {
+    return 3 * (size_t)((hp.Mmax + 1) & ~1) * sizeof(double) + (size_t)hp.Emax * (16 + 16 + 8 + 8);
+}
+
 // ------------------------------------------------------------------------------------------------
 // The D-ring patches of k_substep_multi and the NodalConnectivity rows of their solved nodes in patch-local slots (k_smooth_multi).
 struct Patch2Plan {

@@ -162,6 +162,41 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     REQUIRE(pet.size() == 2 * (size_t)hp.nP * hp.Emax, "pet size");
     stats[16] = plan.cut_big; for (int q = 0; q < hp.nP; ++q) { stats[17] += hp.elem_cnt[q]; stats[18] += (hp.elem_cnt[q] + 63) / 64 > 24; stats[19] = std::max<int64_t>(stats[19], hp.node_cnt[q] - hp.own_cnt[q]); } stats[0] = hp.nP; stats[1] = hp.Pmax; stats[2] = hp.Emax; stats[3] = hp.Mmax; stats[4] = hp.Wp; stats[5] = hp.used_hilbert; stats[6] = (int64_t)plan.fused_lds; stats[7] = plan.P;
     const bool mr = ns > 0 || nr > 0 || No < Nn;
+    if (!mr) {  // the rows of k_prep_fused: every node's elements in an order of its own (descending here; bamg's is a chained list's) -> patch slots
+        std::vector<std::vector<int>> fan(Nn);
+        for (int e = Ne - 1; e >= 0; --e) for (int k = 0; k < 3; ++k) fan[indices[3 * e + k] - 1].push_back(e);
+        int W1 = 1;
+        for (const auto &f : fan) W1 = std::max(W1, (int)f.size());
+        W1 += 1;  // (a pad column, as bamg's table has NaNs)
+        std::vector<int> n2e((size_t)W1 * Nn, -1);
+        for (int n = 0; n < Nn; ++n) for (size_t j = 0; j < fan[n].size(); ++j) n2e[j * Nn + n] = fan[n][j];
+        std::vector<unsigned short> rows;
+        REQUIRE(build_prep_rows(hp, n2e.data(), W1, Nn, rows), "build_prep_rows refused a table of this mesh%s", "");
+        REQUIRE(rows.size() == (size_t)hp.nP * W1 * hp.Pmax, "rows size");
+        for (int q = 0; q < hp.nP; ++q)
+            for (int i = 0; i < hp.own_cnt[q]; ++i) {
+                const int n = hp.pnodes[(size_t)q * hp.Mmax + i];
+                for (int j = 0; j < W1; ++j) {
+                    const unsigned short sl = rows[((size_t)q * W1 + j) * hp.Pmax + i];
+                    const int want = n2e[(size_t)j * Nn + n];
+                    if (want < 0) { REQUIRE(sl == 0xFFFF, "patch %d node %d row %d: a slot for a pad", q, n, j); continue; }
+                    REQUIRE(sl < hp.elem_cnt[q], "patch %d node %d row %d: slot %d", q, n, j, (int)sl);
+                    const int raw = hp.pelem[(size_t)q * hp.Emax + sl];
+                    REQUIRE((raw >= 0 ? raw : ~raw) == want, "patch %d node %d row %d: element %d, not %d", q, n, j, raw >= 0 ? raw : ~raw, want);
+                }
+            }
+        REQUIRE(prep_fused_lds_of(hp) >= 48 * (size_t)hp.Emax, "prep lds");
+        if (Ne >= 2 && hp.nP >= 1 && hp.own_cnt[0] >= 1) {  // a row that names an element that does not touch the node: refused, not mapped
+            const int n0 = hp.pnodes[0];
+            int far = -1;
+            for (int e = 0; e < Ne && far < 0; ++e) {
+                bool in0 = false;
+                for (int l = 0; l < hp.elem_cnt[0]; ++l) { const int raw = hp.pelem[l]; in0 = in0 || (raw >= 0 ? raw : ~raw) == e; }
+                if (!in0) far = e;
+            }
+            if (far >= 0) { n2e[(size_t)(W1 - 1) * Nn + n0] = far; REQUIRE(!build_prep_rows(hp, n2e.data(), W1, Nn, rows), "a foreign element was accepted%s", ""); }
+        }
+    }
     if (mr) {
         const std::vector<int> so(send_offsets, send_offsets + ns + 1), ro(recv_offsets, recv_offsets + nr + 1);
         const std::vector<int> si(send_index, send_index + so[ns]), ri(recv_index, recv_index + ro[nr]);

@@ -625,6 +625,52 @@ def test_resident_sub_step_loop_on_one_large_patch_per_cu_does_not_change_a_bit(
     a.close(); b.close()
 
 
+def _shuffled_case(kind="small", seed=7):
+    """The mesh `kind` with node and element numbers permuted at random (no locality left): params, local mesh, fields."""
+    from nextsim_amd import forcing as F, mesh as M
+    gm = cases.global_mesh(kind)
+    rng = np.random.default_rng(seed)
+    pn = rng.permutation(gm.num_nodes); pe = rng.permutation(gm.num_elements)
+    inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
+    g2 = M.GlobalMesh(x=gm.x[pn].copy(), y=gm.y[pn].copy(), tri=np.ascontiguousarray(inv[gm.tri][pe].astype(np.int32)),
+                      dirichlet=gm.dirichlet[pn].copy(), neumann=gm.neumann[pn].copy(), lat=gm.lat[pn].copy(), name="shuffled")
+    p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), g2, alea_factor=0.33)
+    g = F.global_fields(g2, p, "arctic", C_fix, C_alea)
+    lm = M.localize(g2, 1)[0]
+    return p, lm, F.localize_fields(g, lm, g2.num_nodes)
+
+
+@pytest.mark.parametrize("kind,over,opts", [("small", {}, {}), ("40km", {}, {}), ("40km", {"dynamics_type": 3}, {"fused": 2}), ("h15600", {}, {"fused": 4}),
+                                            ("small", {"ice_cat_type": 0, "basal_stress_type": 0}, {"patch_nodes": 300}), ("toy", {}, {}), ("shuffled", {}, {})])
+def test_fused_prep_kernel_does_not_change_a_bit(kind, over, opts):
+    """k_prep_fused (single rank): prep elements + the nodal side of prep elements + prep nodes (FE.cpp:10235-10416) in ONE launch over the sub-step
+    kernel's patches -- the elements' values reach their nodes through LDS, the six ssh-gradient products are formed again at the node from the
+    Jacobian and the staged coordinates.  Every array the two separate kernels leave behind (the 48-byte element records, the 80-byte nodal
+    records, the displaced coordinates, M_delta_x, M_surface, D_tau_a, VTM, node_mass) has the same bits after explicitSolve, and the state after
+    two steps is the same; with and without young ice and basal stress, EVP, patches of any size, a numbering without locality, the resident
+    loop's patches."""
+    from nextsim_amd import dynamics
+    outs = []
+    for pf in (0, 1):
+        if kind == "shuffled": p, lm, f = _shuffled_case()
+        else:
+            _, p, _, lms, fields = cases.make_case(kind, **over)
+            lm, f = lms[0], fields[0]
+        fe = dynamics.FiniteElementDynamics(p)
+        for k, v in dict(opts, prep_fused=pf).items(): fe.set_option(k, v)
+        fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+        fe.explicitSolve(); fe.synchronize()
+        recs = {nm: fe.debug_array(nm).view(np.uint64).copy() for nm in ("erec", "nrec", "xy", "delta_x", "surface", "tau_a", "VTM", "node_mass")}
+        fe.update(); fe.step(); fe.synchronize()
+        outs.append((recs, fe.get_state()))
+        fe.close()
+    (ra, sa), (rb, sb) = outs
+    for nm in ra:
+        assert np.array_equal(ra[nm], rb[nm]), (nm, int((ra[nm] != rb[nm]).sum()))
+    for k in STATE_KEYS:
+        assert np.array_equal(sa[k], sb[k]), k
+
+
 def test_resident_sub_step_loop_falls_back_where_it_cannot_run():
     """mEVP (its sub-steps need the velocity of the step's start) and meshes whose patches do not fit one round of resident
     workgroups run one kernel per sub-step although fused = 4 was asked for -- same results, no error."""
@@ -677,18 +723,9 @@ def test_resident_loop_survives_a_remesh_a_change_of_sub_steps_and_a_second_hand
 def test_shuffled_numbering_still_matches_the_oracle():
     """A mesh whose node/element numbering has no locality (random permutation): patches are then cut
     along a Morton curve through the coordinates; results must still match the oracle on that mesh."""
-    from nextsim_amd import dynamics, forcing as F, mesh as M
+    from nextsim_amd import dynamics
     from oracle import pyoracle as O
-    gm = cases.global_mesh("small")
-    rng = np.random.default_rng(7)
-    pn = rng.permutation(gm.num_nodes); pe = rng.permutation(gm.num_elements)
-    inv = np.empty_like(pn); inv[pn] = np.arange(pn.size)
-    g2 = M.GlobalMesh(x=gm.x[pn].copy(), y=gm.y[pn].copy(), tri=np.ascontiguousarray(inv[gm.tri][pe].astype(np.int32)),
-                      dirichlet=gm.dirichlet[pn].copy(), neumann=gm.neumann[pn].copy(), lat=gm.lat[pn].copy(), name="shuffled")
-    p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), g2, alea_factor=0.33)
-    g = F.global_fields(g2, p, "arctic", C_fix, C_alea)
-    lm = M.localize(g2, 1)[0]
-    f = F.localize_fields(g, lm, g2.num_nodes)
+    p, lm, f = _shuffled_case()
     fe = dynamics.FiniteElementDynamics(p); fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
     ref = O.OracleRank(lm, p, f)
     fe.step(); ref.step(); fe.synchronize()
