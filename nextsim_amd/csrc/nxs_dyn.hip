@@ -1416,6 +1416,13 @@ int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_
         for (int64_t i = 0; i < n && i < (int64_t)t.size(); ++i) out[i] = (double)t[i];
         return NXS_OK;
     }
+    if (!std::strcmp(name, "phase_times_prep")) {  // the same of the last k_prep_fused
+        std::vector<long long> t(8 * 8192);
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_phase_p), t.size() * sizeof(long long)));
+        for (int64_t i = 0; i < n && i < (int64_t)t.size(); ++i) out[i] = (double)t[i];
+        return NXS_OK;
+    }
 #endif
     return fail(h, NXS_ERR_INVALID, "unknown debug array '%s'", name);
 } catch (...) { return dyn_caught(h, "nxs_dyn_debug_array"); }

@@ -387,6 +387,12 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
 // 48 bytes of LDS per element instead of 96, which is what lets two workgroups share a CU).  The element that a patch WRITES (pelem >= 0; every
 // element has one writer) also gets its M_delta_x, M_surface and the 48-byte record of sub-step constants.  Operand for operand the two
 // kernels above: tests/test_gpu_parity.py::test_fused_prep_kernel_does_not_change_a_bit.
+#ifdef NXS_PHASE_TIMING  // kernel microscope (scripts/phase_timing.py --prep)
+__device__ long long g_phase_p[8 * 8192];
+#define PSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_phase_p[8 * blockIdx.x + (k)] = wall_clock64(); } while (0)
+#else
+#define PSTAMP(k) do { } while (0)
+#endif
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) k_prep_fused(DevMesh m, DevPatches pp, DevState s, DevWork w, DevParams p) {
     constexpr int T = 512;
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -404,6 +410,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int t = threadIdx.x;
     const int nM = pp.node_cnt[blk], nE = pp.elem_cnt[blk], nO = pp.own_cnt[blk];
     const int *pn = pp.pnodes + (size_t)blk * Mmax;
+    PSTAMP(0);
     for (int i = t; i < nM; i += T) {  // GmshMesh::vertices(indices, um, 1.) per node (load_vertices' expression), and the ssh the elements average
         const int g = pn[i];
         const double x = m.x0[g] + 1. * s.UM[g], y = m.y0[g] + 1. * s.UM[g + Nn];
@@ -411,6 +418,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         if (i < nO) reinterpret_cast<d2 *>(w.xy)[g] = d2{x, y};
     }
     __syncthreads();
+    PSTAMP(1);
     // ---- k_prep_elements (FE.cpp:10235-10308), two elements of this thread at a time: their indices, then all their fields, then the arithmetic --
     // element by element the two dependent load levels would be paid once per element
     constexpr int NB = 2;
@@ -523,7 +531,9 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         r[2] = d2{f_coh[j], __longlong_as_double(((long long)c_skip << 32) | (long long)(unsigned int)c_dxi)};
     }
     }
+    PSTAMP(2);
     __syncthreads();
+    PSTAMP(3);
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * Pmax;
     const unsigned short *pr = pp.prow + (size_t)blk * pp.W1 * Pmax;
     for (int sl = t; sl < nO; sl += T) {  // ---- k_prep_nodes (FE.cpp:10309-10416)
@@ -598,6 +608,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         d2 *r = reinterpret_cast<d2 *>(w.nrec) + 5 * (size_t)n;
         r[0] = d2{nm, gu}; r[1] = d2{gv, rl}; r[2] = d2{cb, fc}; r[3] = d2{tax, tay}; r[4] = d2{ocu, ocv};
     }
+    PSTAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------

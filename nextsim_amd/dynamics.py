@@ -354,7 +354,7 @@ class FiniteElementDynamics:
         n = {"rlmass": Nn, "node_mass": Nn, "C_bu": Nn, "grad_ssh": 2 * Nn, "fcor": Nn, "VTM": 2 * Nn,
              "shape": 6 * Ne, "emass": Ne, "ecbu": Ne, "force": 6 * Ne, "volume": Ne, "expC": Ne,
              "erec": 6 * Ne, "nrec": 10 * Nn, "xy": 2 * Nn, "delta_x": Ne, "surface": Ne, "tau_a": 2 * Nn,
-             "phase_times": 8 * 8192}[name]
+             "phase_times": 8 * 8192, "phase_times_prep": 8 * 8192}[name]
         out = np.empty(n)
         self._chk(self.L.nxs_dyn_debug_array(self.h, name.encode(), _abi.dptr(out), n))
         return out

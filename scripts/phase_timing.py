@@ -5,7 +5,7 @@
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true"); ap.add_argument("--resident", action="store_true"); ap.add_argument("--opt", action="append", default=[], help="key=value for set_option (before set_mesh)")
+ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true"); ap.add_argument("--resident", action="store_true"); ap.add_argument("--prep", action="store_true"); ap.add_argument("--opt", action="append", default=[], help="key=value for set_option (before set_mesh)")
 a = ap.parse_args()
 csrc = os.path.join(ROOT, "nextsim_amd", "csrc")
 if a.build:
@@ -25,6 +25,16 @@ if a.resident: fe.set_option("fused", 4)
 for kv in a.opt: fe.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
 fe.step(); fe.step(); fe.synchronize()
+if a.prep:  # k_prep_fused: start, nodes staged + barrier, elements done, barrier, nodes done
+    t = fe.debug_array("phase_times_prep").reshape(8192, 8)[:, :5]
+    t = t[t[:, 0] > 0]
+    k0 = t[:, 0].min()
+    d = np.diff(t, axis=1) * 10e-3
+    print(f"{gm.num_elements} triangles, {t.shape[0]} workgroups; kernel span {(t[:, 4].max() - k0) * 10e-3:.2f} us")
+    for nm, col in zip(("staging (to barrier 1)", "element phase", "wait at barrier 2", "node phase"), d.T):
+        print(f"  {nm:38s} mean {col.mean():6.2f} us   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
+    print(f"  workgroup total                        mean {(t[:, 4] - t[:, 0]).mean() * 10e-3:6.2f} us; start of the last workgroup {(t[:, 0].max() - k0) * 10e-3:.2f} us after the first")
+    fe.close(); sys.exit(0)
 t = fe.debug_array("phase_times")
 if a.resident:  # k_substep_resident, sub-step 60 of the launch: start of the element phase, barrier 1, end of the node phase, stores drained + barrier, neighbours' counters seen, halo loaded
     t = t.reshape(8192, 8)[:, :6]
