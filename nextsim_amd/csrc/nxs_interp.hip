@@ -676,13 +676,38 @@ extern "C" int nxs_regrid_create(const int32_t *index_old, const double *x_old, 
     r->device = device; r->nods = nods_old; r->nels = nels_old;
     r->index.assign(index_old, index_old + 3 * (size_t)nels_old);
     r->x.assign(x_old, x_old + nods_old); r->y.assign(y_old, y_old + nods_old);
+    // The two connectivity tables are built on the device right away (2 ms at 1.5 M triangles): the conservative remapping walks them, and the
+    // boundary edges bamg's convex completion starts from are the entries of ElementConnectivity without a neighbour -- a few thousand numbers to
+    // copy back instead of a host pass over every triangle.  A mesh the device tables cannot describe (an edge in three triangles, inconsistent
+    // orientation) is left to the host code, which says what is wrong with it when the completion is asked for.
+    std::vector<int> bnd;
+    bool have_bnd = false;
+    if (regrid_connectivity(r.get(), nullptr, 0, nullptr) == 0) {
+        DevBuf<int> cnt, list;
+        const int cap = 3 * nels_old;
+        if (!cnt.alloc(2) && !list.alloc((size_t)cap) && hipMemsetAsync(cnt.p, 0, 2 * sizeof(int), S()) == hipSuccess) {
+            hipLaunchKernelGGL(regrid_tables::k_boundary_list, dim3((3 * nels_old + 255) / 256), dim3(256), 0, S(), nels_old, (const int *)r->dtrio.p, (const int *)r->dec.p,
+                               cnt.p, list.p, cap, cnt.p + 1);
+            int c2[2] = {0, 0};
+            if (copy_sync(c2, cnt.p, sizeof c2, hipMemcpyDeviceToHost) == hipSuccess && c2[1] == 0 && c2[0] >= 0 && c2[0] <= cap) {
+                bnd.resize((size_t)c2[0]);
+                if (c2[0] == 0 || copy_sync(bnd.data(), list.p, bnd.size() * sizeof(int), hipMemcpyDeviceToHost) == hipSuccess) {
+                    std::sort(bnd.begin(), bnd.end());
+                    have_bnd = true;
+                }
+            }
+        }
+    } else {
+        (void)hipGetLastError();
+        g_err.clear();   // (not this call's failure: the remapping reports it if it is asked for)
+    }
     try {   // bamg's convex completion on a host thread, from now on (pure host work on this context's own copies); without a thread it is made when asked for
         nxs_regrid *q = r.get();
-        r->completion = std::async(std::launch::async, [q]() {
+        r->completion = std::async(std::launch::async, [q, have_bnd, bnd = std::move(bnd)]() {
             std::vector<int> ix, iy;
             double coef = 0., px = 0., py = 0.;
             if (!nxs_hull::int_plane(q->x.data(), q->y.data(), q->nods, ix, iy, coef, px, py)) { nxs_hull::Completion c; c.why = "coefIcoor should be positive"; return c; }
-            return nxs_hull::complete_any(q->index.data(), ix.data(), iy.data(), q->nods, q->nels);
+            return nxs_hull::complete_any(q->index.data(), ix.data(), iy.data(), q->nods, q->nels, 0, have_bnd ? &bnd : nullptr);
         });
     } catch (const std::system_error &) { }
     *out = r.release();

@@ -160,4 +160,22 @@ __global__ void __launch_bounds__(256) k_elem_conn(int nels, const int *tri, con
     ec[i] = mate;
 }
 
+// The boundary edges of the mesh out of its ElementConnectivity: every local edge i = 3 t + j without a neighbour is appended to `list` (any order:
+// the host sorts the few thousand of them).  A neighbour that runs along the shared edge in the SAME direction (an inconsistently oriented mesh)
+// raises `bad`: the host's own pass over the triangles (nxs_hull::find_boundary_edges) then decides, as before.
+__global__ void __launch_bounds__(256) k_boundary_list(int nels, const int *tri, const int *ec, int *count, int *list, int cap, int *bad) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 3 * nels) return;
+    const int t = i / 3, j = i % 3, e = ec[i];
+    if (e < 0) {
+        const int pos = atomicAdd(count, 1);
+        if (pos < cap) list[pos] = i;
+        return;
+    }
+    const int p = tri[3 * t + (j + 1) % 3], q = tri[3 * t + (j + 2) % 3];  // this triangle runs p -> q along the edge: its neighbour must run q -> p
+    bool reversed = false;
+    for (int k = 0; k < 3; ++k) reversed = reversed || (tri[3 * e + k] == q && tri[3 * e + (k + 1) % 3] == p);
+    if (!reversed) atomicAdd(bad, 1);
+}
+
 }  // namespace regrid_tables

@@ -185,6 +185,15 @@ def last_timing() -> dict:
     return {k: float(v[i]) for i, k in enumerate(keys)}
 
 
+def _result_array(out, shape):
+    """A caller-supplied result array (C-contiguous float64 of exactly `shape`) or a fresh one."""
+    if out is None:
+        return np.empty(shape)
+    if not (isinstance(out, np.ndarray) and out.dtype == np.float64 and out.flags.c_contiguous and out.flags.writeable and out.shape == tuple(shape)):
+        raise ValueError(f"out must be a writeable C-contiguous float64 array of shape {tuple(shape)}")
+    return out
+
+
 class Regrid:
     """A regrid's context (include/nxs_interp.h, nxs_regrid_*): the OLD mesh's search tables -- integer plane, bucket grid, convex completion,
     the two connectivity tables -- built once, on the device, and shared by interpFields' two interpolation calls (FE.cpp:3071-3154)."""
@@ -226,7 +235,7 @@ class Regrid:
         if rc:
             raise NxsError(rc, (self.L.nxs_interp_last_error() or b"").decode())
 
-    def interp_nodes(self, data, x_interp, y_interp, isdefault=False, defaultvalue=1e-24, data_device=None, out_device=None, return_info=False):
+    def interp_nodes(self, data, x_interp, y_interp, isdefault=False, defaultvalue=1e-24, data_device=None, out_device=None, return_info=False, out=None):
         """InterpFromMeshToMesh2dx.  data_device = (device pointer, M_data, N_data) instead of `data`; out_device = a device pointer for the result."""
         x_interp = np.ascontiguousarray(x_interp, np.float64); y_interp = np.ascontiguousarray(y_interp, np.float64)
         flags = 0
@@ -239,11 +248,11 @@ class Regrid:
                 data = data[:, None]
             M, N = data.shape
             src = C.c_void_p(data.ctypes.data)
-        out = None
         if out_device is not None:
+            out = None
             dst = C.c_void_p(out_device); flags |= self.OUT_DEVICE
         else:
-            out = np.empty((x_interp.size, N))
+            out = _result_array(out, (x_interp.size, N))
             dst = C.c_void_p(out.ctypes.data)
         next_, ms = C.c_int32(0), C.c_double(0.0)
         self._chk(self.L.nxs_regrid_interp_nodes(self.h, dst, src, M, N, _abi.dptr(x_interp), _abi.dptr(y_interp), x_interp.size, int(bool(isdefault)),
@@ -253,8 +262,9 @@ class Regrid:
         return out
 
     def remap_elements(self, interp_in, index_new, x_new, y_new, previous_numbering=None, n_geom_vertices=0, nec_old=None, ec_old=None,
-                       in_device=None, out_device=None, return_info=False):
-        """ConservativeRemappingMeshToMesh.  in_device = (device pointer, nb_var) instead of `interp_in`; out_device = a device pointer for the result."""
+                       in_device=None, out_device=None, return_info=False, out=None):
+        """ConservativeRemappingMeshToMesh.  out = an array of the result's shape to fill (a caller that regrids repeatedly keeps it: a fresh
+        370 MB array costs its page faults inside the copy back).  in_device = (device pointer, nb_var) instead of `interp_in`; out_device = a device pointer for the result."""
         f64 = lambda a: np.ascontiguousarray(a, np.float64)  # noqa: E731
         index_new = np.ascontiguousarray(index_new, np.int32).ravel()
         x_new, y_new = f64(x_new), f64(y_new)
@@ -269,11 +279,11 @@ class Regrid:
             nv = interp_in.shape[1]
             src = C.c_void_p(interp_in.ctypes.data)
         ne_new = index_new.size // 3
-        out = None
         if out_device is not None:
+            out = None
             dst = C.c_void_p(out_device); flags |= self.OUT_DEVICE
         else:
-            out = np.empty((ne_new, nv))
+            out = _result_array(out, (ne_new, nv))
             dst = C.c_void_p(out.ctypes.data)
         visits = np.zeros(ne_new, np.int32)
         prev = None if previous_numbering is None else f64(previous_numbering)

@@ -292,6 +292,14 @@ def test_device_built_regrid_tables_equal_the_host_built_ones_and_a_context_serv
     b1 = interp.ConservativeRemappingMeshToMesh(elem, idx, x, y, trin + 1, xn, yn, np.zeros(xn.size), ng)
     b2 = interp.InterpFromMeshToMesh2dx(idx, x, y, nodal, xn, yn, False, 0.0)
     assert np.array_equal(a1, b1, equal_nan=True) and np.array_equal(a2, b2)
+    # results into arrays the caller keeps (out=): the same object comes back, filled with the same bits; an array of another shape, dtype or
+    # layout is refused, not silently replaced by a fresh one
+    k1, k2 = np.full_like(a1, -7.), np.full_like(a2, -7.)
+    assert rg.remap_elements(elem, trin + 1, xn, yn, np.zeros(xn.size), ng, out=k1) is k1 and np.array_equal(k1, a1, equal_nan=True)
+    assert rg.interp_nodes(nodal, xn, yn, False, 0.0, out=k2) is k2 and np.array_equal(k2, a2)
+    for bad in (np.empty((a1.shape[0] + 1, a1.shape[1])), np.empty(a1.shape, np.float32), np.empty(a1.shape[::-1]).T):
+        with pytest.raises(ValueError):
+            rg.remap_elements(elem, trin + 1, xn, yn, np.zeros(xn.size), ng, out=bad)
     L = dynamics.load_library()
     L.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]; L.hipFree.argtypes = [C.c_void_p]
     L.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
