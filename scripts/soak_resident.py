@@ -6,7 +6,8 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from nextsim_amd import dynamics, forcing as F, mesh as M
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
-for h_edge in (15600., 17000., 19000., 22000., 27600., 46000.):
+# (11 000 m, 12 500 m, 14 000 m: 367 k - 227 k triangles, the large-patch kernel with the interior elements one exchange ahead)
+for h_edge in (11000., 12500., 14000., 15600., 17000., 19000., 22000., 27600., 46000.):
     gm = M.make_disc_mesh(h_edge, seed=M.SEED, name="custom")
     p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
     g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
