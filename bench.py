@@ -46,10 +46,10 @@ def parse():
     return ap.parse_args()
 
 
-PMC_PROFILES = ("profiles/r02_pmc_traffic.json", "profiles/r01_v2_pmc_traffic.json")
+PMC_PROFILES = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_v2_pmc_traffic.json")
 
 
-def pmc_traffic(mesh, launches_per_substep, world):
+def pmc_traffic(mesh, launches_per_substep, world, kernel="k_substep_fused"):
     """(HBM bytes per launch of the sub-step kernel, the file they come from): the committed rocprofv3 --pmc passes
     (FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes, same command, same kernel, same mesh -- corrected as
     MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside this process, so this is a
@@ -60,14 +60,14 @@ def pmc_traffic(mesh, launches_per_substep, world):
         try:
             prof = json.load(open(os.path.join(ROOT, rel)))
             for k, v in prof["kernels"].items():
-                if k.startswith("k_substep_fused"):
+                if k.startswith(kernel):
                     return v["hbm_bytes_per_launch"], rel
         except Exception:  # noqa: BLE001
             continue
     return None, None
 
 
-def pmc_traffic_live(mesh, launches_per_substep, world, timeout_s=240):
+def pmc_traffic_live(mesh, launches_per_substep, world, timeout_s=240, kernel="k_substep_fused"):
     """(HBM bytes per launch of the sub-step kernel MEASURED NOW, how): two child runs of one step of the same mesh
     (scripts/run_steps.py) under `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` -- separate passes, counters only, no
     tracing beside them -- reduced as scripts/make_pmc_profile.py does: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over the launches of
@@ -94,15 +94,15 @@ def pmc_traffic_live(mesh, launches_per_substep, world, timeout_s=240):
             acc, n = 0.0, 0
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter and r["Kernel_Name"].split("(")[0].replace("void ", "").startswith("k_substep_fused"):
+                    if r["Counter_Name"] == counter and r["Kernel_Name"].split("(")[0].replace("void ", "").startswith(kernel):
                         acc += float(r["Counter_Value"]); n += 1
             if n == 0:
-                return None, f"no {counter} rows for k_substep_fused"
+                return None, f"no {counter} rows for {kernel}"
             vals[counter] = (acc / n, n)
         b = int((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024)
         return b, (f"MEASURED IN THIS RUN: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate, counters only) over one step of "
                    f"the same mesh (scripts/run_steps.py --mesh {mesh} --steps 1 --graph 0), (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over "
-                   f"{vals['FETCH_SIZE'][1]} launches of k_substep_fused (gfx950 reports half of the coalesced streaming reads, "
+                   f"{vals['FETCH_SIZE'][1]} launches of {kernel} (gfx950 reports half of the coalesced streaming reads, "
                    f"MI355X_MICROARCH.md); FETCH_SIZE {vals['FETCH_SIZE'][0]:.1f} KiB, WRITE_SIZE {vals['WRITE_SIZE'][0]:.1f} KiB per launch")
     except Exception as e:  # noqa: BLE001 -- the bench line survives without it (the committed profile is replayed instead)
         return None, "failed: " + repr(e)[:200]
@@ -741,11 +741,15 @@ def main():
 
     # roofline of the dominant kernel(s): the sub-step loop (sigma/damage + assembly + nodal solve)
     launches_per_substep = max(tm["substep_launches"] // S, 1)
-    substep_ms = tm["substeps_ms"] / S                      # HIP events on the kernel's stream, avg over timed steps
-    bytes_per_substep = BYTES_PER_ELEMENT * lm.num_elements + BYTES_PER_NODE * lm.num_nodes
+    # one launch of the dominant kernel advances D sub-steps (1: k_substep_fused; 2: k_substep_pair; S: the resident loop): everything below is PER LAUNCH --
+    # SURVEY 8d's algorithmic bytes per sub-step x D over the event-timed duration of one launch (what rocprofv3's kernel statistics list per call)
+    D_launch = max(S // max(tm["substep_launches"], 1), 1) if tm["substep_launches"] <= S else 1
+    kernel_name = "k_substep_resident" if tm["substep_launches"] == 1 else "k_substep_pair" if (D_launch == 2 and world == 1) else "k_substep_multi" if D_launch > 1 else "k_substep_fused"
+    substep_ms = tm["substeps_ms"] / S * D_launch           # HIP events on the kernel's stream, avg over timed steps: one launch (group)
+    bytes_per_substep = (BYTES_PER_ELEMENT * lm.num_elements + BYTES_PER_NODE * lm.num_nodes) * D_launch
     achieved = bytes_per_substep / (substep_ms * 1e-3) / 1e9
-    traffic_profile, profile_file = pmc_traffic(args.mesh, launches_per_substep, world)
-    traffic, traffic_source = (None, "skipped (--no-live-pmc)") if (args.no_live_pmc or rank != 0) else pmc_traffic_live(args.mesh, launches_per_substep, world)
+    traffic_profile, profile_file = pmc_traffic(args.mesh, launches_per_substep, world, kernel_name)
+    traffic, traffic_source = (None, "skipped (--no-live-pmc)") if (args.no_live_pmc or rank != 0) else pmc_traffic_live(args.mesh, launches_per_substep, world, kernel=kernel_name)
     traffic_live = traffic is not None
     if not traffic_live:   # replay of the committed profile, labelled as such
         why = traffic_source
@@ -778,6 +782,7 @@ def main():
         "roofline": {
             "bound": "hbm",
             "kernel": "k_substep_resident (ONE launch per step: the fused sub-step loop, patches waiting for their neighbours only)" if tm["substep_launches"] == 1
+                      else "k_substep_pair (TWO sub-steps per launch on patches with two rings of halo, the stresses between them in registers: stress/damage + assembly + nodal solve, twice)" if kernel_name == "k_substep_pair"
                       else f"k_substep_multi ({S // max(tm['substep_launches'], 1)} sub-steps per launch on patches with that many rings of halo)" if tm["substep_launches"] < S
                       else "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve + mesh move)" if launches_per_substep == 1 else f"sub-step loop ({launches_per_substep} launches per sub-step incl. halo pack/unpack)",
             "achieved": achieved,
@@ -790,12 +795,14 @@ def main():
             "traffic_committed_profile": {"bytes": traffic_profile, "file": profile_file} if traffic_profile else None,
             "achieved_counter": achieved_counter,
             "frac_counter": achieved_counter / HBM_PEAK_GBS if achieved_counter else None,
+            "substeps_per_launch": D_launch,
             "bytes_per_launch_group": bytes_per_substep,
             "avg_ms_per_launch_group": substep_ms,
-            "note": "rank-0 partition. achieved / frac = ALGORITHMIC bytes (SURVEY 8d: 172 B/element + 217 B/node per sub-step) over the "
-                    "event-timed launch; the kernel moves fewer bytes than that model (shape coefficients rebuilt from staged coordinates, "
-                    "M_UM / M_UT streamed once per step), so frac can exceed what HBM delivers (~6.3 TB/s = 0.79): achieved_counter / "
-                    "frac_counter = the counter bytes over the same time is the real HBM rate",
+            "note": "rank-0 partition. achieved / frac = ALGORITHMIC bytes (SURVEY 8d: 172 B/element + 217 B/node per sub-step, x the sub-steps one launch "
+                    "advances) over the event-timed launch; the kernel moves fewer bytes than that model (shape coefficients rebuilt from staged coordinates, "
+                    "M_UM / M_UT streamed once per step, and with two sub-steps per launch stress, damage, element constants and nodal inputs cross HBM once "
+                    "per TWO sub-steps), so frac can exceed what HBM delivers (~6.3 TB/s = 0.79) and even 1: achieved_counter / frac_counter = the counter "
+                    "bytes over the same time is the real HBM rate",
         },
         "phases_ms": res["phases_max"],   # (N > 1: the slowest rank's figure for every phase)
         "phases_ms_rank0": {k: tm[k] for k in ("prep_ms", "substeps_ms", "smoother_ms", "update_ms", "total_ms")},

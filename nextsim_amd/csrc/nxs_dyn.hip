@@ -106,7 +106,11 @@ struct nxs_dyn_handle {
     std::vector<int> h_t[3];               // kept for rebuilding patches when patch_nodes changes
     std::vector<int> h_n2n, h_n2n_cnt;     // NodalConnectivity rows [W2][Nn] + counts (for the blocked smoother's tables)
     std::vector<int> h_n2e;                // NodalElementConnectivity rows [W1][Nn], -1 = pad (for k_prep_fused's rows in patch slots)
+    int pair_own_max = 0;                  // most own nodes of a multi-sub-step patch
     size_t prep_lds = 0;                   // LDS of k_prep_fused for the current patches; 0: the two separate prep kernels run
+    int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
+                                           // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
+    bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
     int prep_fused = -1;                   // option "prep_fused": -1 where it pays (single rank, records only, >= 250 k triangles), 0 never, 1 wherever it can run
     size_t smooth_lds = 0;
     // node-ring patches for the smoother alone (single rank, meshes on the one-sub-step-per-launch kernels): D sweeps per launch
@@ -666,10 +670,11 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         h->pair_depth = (int)value; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "pair_nodes")) {
-        if (value != 0 && (value < 16 || value > 512)) return fail(h, NXS_ERR_INVALID, "pair_nodes must be 0 (auto) or in [16,512]");
+        if (value != 0 && (value < 16 || value > 1024)) return fail(h, NXS_ERR_INVALID, "pair_nodes must be 0 (auto) or in [16,1024]");
         h->pair_nodes = (int)value; h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "work_arrays")) { h->work_arrays = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "pair_regs")) { h->pair_regs = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "prep_fused")) { h->prep_fused = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "shape_mem")) {
         if (value < -1 || value > 1) return fail(h, NXS_ERR_INVALID, "shape_mem must be -1 (auto), 0 or 1");
@@ -1532,6 +1537,11 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
     for (int k = 0; k < D; ++k) vo.slot[k] = h->ring.slot[(sidx + 1 + k) % R];
     const dim3 grid(h->dpch2.nP);
     const bool pow4 = h->dp.ers_int == 4;
+    if (h->pair_kernel) {  // (D == 2: upload_patches2 cut the patches for it)
+        if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo);
+        else hipLaunchKernelGGL((k_substep_pair<512, false, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo);
+        return;
+    }
 #define MULTI(TT, PP, NN) hipLaunchKernelGGL((k_substep_multi<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, (const DevParams *)h->d_dp, b, vo)
 // no non-temporal hints: this kernel runs where the mesh lives in the caches (58 k triangles: 0.768 ms/step with them, 0.750 without; 111 k: 0.927 / 0.90)
 #define MULTI_T(TT) do { if (pow4) MULTI(TT, true, 0); else MULTI(TT, false, 0); } while (0)
@@ -1747,10 +1757,22 @@ int choose_depth(nxs_dyn_handle *h) {
     int D = 1;
     // Automatic (fused == 3): only where ONE round of one patch per CU covers the mesh (<= 256 own nodes per patch: 65 k nodes, 130 k
     // triangles on 256 CUs) -- 111 k triangles: 1.47 (v2) -> 0.97 ms/step; 182 k triangles, two patches per CU: 1.65 -> 1.90-2.31.
-    if ((eff_fused(h) == 2 || (eff_fused(h) == 3 && (long long)h->dm.Nn <= 256ll * 1024)) && !multi_rank(h) && move_dt != 0. && S >= 2 && !h->pair_failed) {
+    // ... and on meshes that STREAM from HBM (fused == 3, >= 400 k triangles, an even number of sub-steps) two sub-steps per launch with the
+    // stresses between them in registers and two workgroups per CU (k_substep_pair): 2 km 6.3 -> 5.7 ms of sub-steps.
+    const bool single = !multi_rank(h) && move_dt != 0. && S >= 2 && !h->pair_failed;
+    // (automatic: every mesh too large for one k_substep_multi patch per CU, i.e. above 65 k nodes)
+    const bool streaming_pair = single && eff_fused(h) == 3 && h->pair_regs != 0 && (long long)h->dm.Nn > 256ll * 256 && S % 2 == 0 && (h->pair_depth == 0 || h->pair_depth == 2);
+    if (streaming_pair) {
+        D = 2;
+        if ((!h->pair_ready || h->pair_depth_built != 2 || !h->pair_kernel) && upload_patches2(h, 2, false, true) != NXS_OK) {
+            h->pair_failed = true;  // (a numbering without any locality, huge fans): one sub-step per launch
+            D = 1;
+        }
+    } else if ((eff_fused(h) == 2 || (eff_fused(h) == 3 && (long long)h->dm.Nn <= 256ll * 256)) && single) {
         D = std::min(h->pair_depth > 0 ? h->pair_depth : 4, std::min(S, NXS_MAX_DEPTH));
         while (D > 1 && S % D != 0) --D;
-        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D) && upload_patches2(h, D, eff_fused(h) == 3) != NXS_OK) {
+        const bool want_pair = D == 2 && h->pair_regs == 1;   // (forced depth 2 with option pair_regs = 1: k_substep_pair at any size)
+        if (D >= 2 && (!h->pair_ready || h->pair_depth_built != D || h->pair_kernel != want_pair) && upload_patches2(h, D, eff_fused(h) == 3, want_pair) != NXS_OK) {
             h->pair_failed = true;  // no patch size fits (a numbering without any locality, huge fans): one sub-step per launch
             D = 1;
         }

@@ -1444,6 +1444,211 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// v3b  TWO sub-steps per launch on meshes that stream from HBM (single rank, deferred mesh move): k_substep_multi's temporal blocking at
+// depth 2 in the shape k_substep_fused has -- 512 threads, 128 registers, two workgroups per CU -- so that patches of ~400 own nodes fit
+// (k_substep_multi keeps the stresses between its sub-steps in LDS and takes 170 registers: one workgroup per CU, or patches of 200
+// nodes whose two rings cost more arithmetic than the traffic they save: 2 km 8.4-10.6 ms of sub-steps against 6.3).  Here the stress and
+// damage of an element stay in the REGISTERS of the thread that updates it in both sub-steps (the element list names E_1 first, so slot
+// l is the same element in both), LDS holds the staged velocities / frozen coordinates of N_2 and the corner forces only.  Sub-step 0
+// updates E_2 (every element touching N_1) and solves N_1, sub-step 1 updates E_1 and solves the own nodes: sigma / damage, the element
+// constants and the nodal inputs cross HBM once per two sub-steps (the second reads hit the L2), at +11 % element and +24 % node
+// arithmetic (400-node patches).  Same operations in the same order as k_substep_fused: bit-identical.
+// Limits (the host checks them): E_2 <= 3 T, E_1 <= 2 T, N_1 <= 2 T, own nodes <= T.
+template <int T, bool POW4, int NTM>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int NDm = pp.NDmax, EDm = pp.EDmax;
+    double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm;
+    d2 *lF2 = reinterpret_cast<d2 *>(ly + NDm);  // [3][EDm] + a pair of zeros
+    const unsigned ZIDX = 3u * (unsigned)EDm;
+    int blk;
+    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
+        const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, r = n & 7, x = pos & 7;
+        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
+    }
+    const int t = threadIdx.x, Nn = m.Nn;
+    if (t == 0) lF2[ZIDX] = d2{0., 0.};
+    const int *ncnt = pp.ncnt + (size_t)blk * 3, *ecnt = pp.ecnt + (size_t)blk * 2;
+    const int nO = ncnt[0], nN1 = ncnt[1], nN2 = ncnt[2], nE1 = ecnt[0], nE2 = ecnt[1];
+    const int *pn = pp.pnodes + (size_t)blk * NDm;
+    const int *pe = pp.pelem + (size_t)blk * EDm;
+    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * EDm;
+    const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
+    const bool bbm = p.dynamics_type == NXS_DYN_BBM;
+    constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
+    // index rows are padded: these loads depend on the launch arguments only
+    const int my_node = (t < NDm) ? pn[t] : 0, my_node2 = (t + T < NDm) ? pn[t + T] : 0;
+    int eraw[3];
+    ushort4 tr[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        eraw[r] = 0; tr[r] = make_ushort4(0, 0, 0, 0);
+        if (t + r * T < EDm) { eraw[r] = pe[t + r * T]; tr[r] = pt[t + r * T]; }
+    }
+    auto stage = [&](const int i, const int g) {
+        lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
+        const d2 c = reinterpret_cast<const d2 *>(w.xy)[g];
+        lx[i] = c.x; ly[i] = c.y;
+    };
+    if (t < nN2) stage(t, my_node);
+    if (t + T < nN2) stage(t + T, my_node2);
+    for (int i = t + 2 * T; i < nN2; i += T) stage(i, pn[i]);
+
+    double ks[2][4];  // sigma0, sigma1, sigma2, damage of this thread's E_1 elements between the two sub-steps
+#pragma unroll
+    for (int r = 0; r < 2; ++r) ks[r][0] = ks[r][1] = ks[r][2] = ks[r][3] = 0.;
+
+    // one element update (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467) from the staged velocities
+    auto update_element = [&](const int l, const ushort4 trl, double sig[3], double &damage, const d2 r0, const d2 r1, const d2 r2) {
+        const double c_expC = r0.x, volume = r0.y, c_pmax = r1.x, c_heal = r1.y, c_coh = r2.x;
+        const int dxi = (int)(__double_as_longlong(r2.y) & 0xffffffffll);
+        bool skip = bbm ? dxi < 0 : (__double_as_longlong(r2.y) >> 32) != 0;
+        double c_dxs = 1.;
+        if (bbm) c_dxs = (double)(skip ? ~dxi : dxi) * p.sqrt_nu_rhoi;  // FE.cpp:4232
+        double dxN[6];
+        {   // shapeCoeff (FE.cpp:1951-1964) from the staged frozen coordinates, as k_substep_fused
+            const double vx[3] = {lx[trl.x], lx[trl.y], lx[trl.z]};
+            const double vy[3] = {ly[trl.x], ly[trl.y], ly[trl.z]};
+            const double jac = jacobian(vx, vy);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+                dxN[k] = (vy[kp1] - vy[kp2]) / jac;
+                dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+            }
+        }
+        if (skip) {
+            sig[0] = sig[1] = sig[2] = 0.;
+            damage = 0.;
+        } else {
+            const double u[3] = {lu[trl.x], lu[trl.y], lu[trl.z]};
+            const double v[3] = {lv[trl.x], lv[trl.y], lv[trl.z]};
+            if (bbm) bbm_stress<POW4>(p, dxN, u, v, sig, damage, c_expC, c_pmax, c_heal, c_dxs, c_coh);
+            else vp_stress(p, dxN, u, v, sig, c_expC);
+        }
+        double F[6];
+        corner_forces(volume, sig, dxN, F);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) lF2[(size_t)k * EDm + l] = d2{F[k], F[k + 3]};
+    };
+    // one node (FE.cpp:10472-10529): its loads, then (behind the barrier) the fan gather in ascending element order and the 2x2 solve
+    struct NodeIn { unsigned char nf; d2 r[5]; unsigned fw[4]; };
+    auto load_node = [&](const int i, const int n) {
+        NodeIn in;
+        in.nf = m.nflags[n];
+        const d2 *q = reinterpret_cast<const d2 *>(w.nrec) + 5 * (size_t)n;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) in.r[k] = q[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {  // pad entries and ghost corners (ghostNodes[i], FE.cpp:10456) name the pair of zeros
+            const unsigned e0 = (2 * k < pp.Wp) ? pf[(size_t)(2 * k) * pp.NSmax + i] : 0xFFFFu;
+            const unsigned e1 = (2 * k + 1 < pp.Wp) ? pf[(size_t)(2 * k + 1) * pp.NSmax + i] : 0xFFFFu;
+            const unsigned i0 = (e0 == 0xFFFFu || (e0 & 4u)) ? ZIDX : (e0 & 3u) * (unsigned)EDm + (e0 >> 3);
+            const unsigned i1 = (e1 == 0xFFFFu || (e1 & 4u)) ? ZIDX : (e1 & 3u) * (unsigned)EDm + (e1 >> 3);
+            in.fw[k] = i0 | (i1 << 16);
+        }
+        return in;
+    };
+    auto solve_node = [&](const int i, const NodeIn &in, double &uice, double &vice) {
+        uice = lu[i]; vice = lv[i];
+        const double node_mass = in.r[0].x;
+        if ((in.nf & NF_DIRICHLET) || node_mass == 0.) return;
+        double gx = in.r[0].y, gy = in.r[1].x;
+        {
+            d2 f[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) f[k] = lF2[(in.fw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { gx -= f[k].x; gy -= f[k].y; }
+        }
+        for (int k = 8; k < pp.Wp; ++k) {  // (fans of more than eight elements)
+            const unsigned ent = pf[(size_t)k * pp.NSmax + i];
+            if (ent == 0xFFFFu) break;
+            if (ent & 4u) continue;
+            const d2 f = lF2[(ent & 3u) * (unsigned)EDm + (ent >> 3)];
+            gx -= f.x; gy -= f.y;
+        }
+        nodal_solve(p, gx, gy, uice, vice, node_mass, in.r[1].y, in.r[2].x, in.r[2].y, (in.nf & NF_LAT_NEG) ? -1. : 1., in.r[3].x, in.r[3].y, in.r[4].x, in.r[4].y, 0., 0.);
+    };
+
+    // ---- sub-step 0: elements E_2 (three rounds of the block), state from HBM
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int l = t + r * T;
+        const bool active = l < nE2;
+        const int e = eraw[r] >= 0 ? eraw[r] : ~eraw[r];
+        d2 a = d2{0., 0.}, c2 = d2{0., 0.}, r0 = d2{0., 0.}, r1 = d2{0., 0.}, r2 = d2{0., 0.};
+        if (active) {
+            const d2 *S = reinterpret_cast<const d2 *>(b.Sc) + 2 * (size_t)e;
+            if (NT_S) { a = __builtin_nontemporal_load(S); c2 = __builtin_nontemporal_load(S + 1); } else { a = S[0]; c2 = S[1]; }
+            const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;  // (read again by sub-step 1: no streaming hint)
+            r0 = q[0]; r1 = q[1]; r2 = q[2];
+        }
+        if (r == 0) __syncthreads();  // staged velocities / coordinates visible
+        if (active) {
+            double sig[3] = {a.x, a.y, c2.x}, damage = c2.y;
+            update_element(l, tr[r], sig, damage, r0, r1, r2);
+            if (r < 2) { ks[r][0] = sig[0]; ks[r][1] = sig[1]; ks[r][2] = sig[2]; ks[r][3] = damage; }
+        }
+    }
+    // ---- sub-step 0: nodes N_1 (two rounds)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = t + r * T;
+        const bool active = i < nN1;
+        const int n = r == 0 ? my_node : my_node2;
+        NodeIn in{};
+        if (active) in = load_node(i, n);
+        if (r == 0) __syncthreads();  // corner forces of sub-step 0 visible
+        if (active) {
+            double u1, v1;
+            solve_node(i, in, u1, v1);
+            if (i < nO) { vout.slot[0][n] = u1; vout.slot[0][n + Nn] = v1; }
+            lu[i] = u1; lv[i] = v1;  // (a node's solve reads only its own staged velocity: in place)
+        }
+    }
+    // ---- sub-step 1: elements E_1 (two rounds), state from the registers, result to HBM (by the element's writer); the constants of the first
+    // round are asked for ahead of the barrier
+    d2 c0 = d2{0., 0.}, c1 = d2{0., 0.}, c2r = d2{0., 0.};
+    auto load_constants = [&](const int e, d2 &r0, d2 &r1, d2 &r2) {
+        const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
+        if (NT_C) { r0 = __builtin_nontemporal_load(q); r1 = __builtin_nontemporal_load(q + 1); r2 = __builtin_nontemporal_load(q + 2); }
+        else { r0 = q[0]; r1 = q[1]; r2 = q[2]; }
+    };
+    if (t < nE1) load_constants(eraw[0] >= 0 ? eraw[0] : ~eraw[0], c0, c1, c2r);
+    __syncthreads();  // the velocities of sub-step 0 on N_1; the corner forces have been consumed
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int l = t + r * T;
+        if (l >= nE1) continue;
+        const bool writer = eraw[r] >= 0;
+        const int e = writer ? eraw[r] : ~eraw[r];
+        d2 r0 = c0, r1 = c1, r2 = c2r;
+        if (r > 0) load_constants(e, r0, r1, r2);
+        double sig[3] = {ks[r][0], ks[r][1], ks[r][2]}, damage = ks[r][3];
+        update_element(l, tr[r], sig, damage, r0, r1, r2);
+        if (writer) {
+            d2 *S = reinterpret_cast<d2 *>(b.Sn) + 2 * (size_t)e;
+            const d2 a = {sig[0], sig[1]}, c2 = {sig[2], damage};
+            if (NT_S) { __builtin_nontemporal_store(a, S); __builtin_nontemporal_store(c2, S + 1); } else { S[0] = a; S[1] = c2; }
+        }
+    }
+    // ---- sub-step 1: the own nodes
+    {
+        const bool active = t < nO;
+        NodeIn in{};
+        if (active) in = load_node(t, my_node);
+        __syncthreads();  // corner forces of sub-step 1 visible
+        if (active) {
+            double u1, v1;
+            solve_node(t, in, u1, v1);
+            vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // v4  The whole sub-step loop in ONE launch: a patch stays on its CU for all the sub-steps and waits for its NEIGHBOURING
 // patches only (FE.cpp:10425-10553 as k_substep_fused; same operations in the same order, same bits).
 // Where one round of resident workgroups covers the partition the sub-step of k_substep_fused is a latency chain -- launch,

@@ -519,17 +519,23 @@ inline size_t prep_fused_lds_of(const HostPatches &hp) {
 // The D-ring patches of k_substep_multi and the NodalConnectivity rows of their solved nodes in patch-local slots (k_smooth_multi).
 struct Patch2Plan {
     HostPatches2 hp;
+    bool pair_kernel = false;  // cut for k_substep_pair (depth 2, two workgroups per CU)
     int P = 0, threads = 512;
     size_t lds = 0, smooth_lds = 0;
     std::vector<unsigned short> pnbr;  // [nP][W2][NSmax], empty when a caller-supplied row reaches beyond its patch
 };
 
 inline size_t multi_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 2 + 4 * (size_t)x.ESmax) * sizeof(double); }
+// k_substep_pair (two sub-steps per launch, the stresses between them in registers): staged nodes and corner forces only; its 512-thread block
+// takes the elements of the first sub-step in three rounds, those of the second and the nodes of the first in two, the own nodes in one
+inline size_t pair_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 2) * sizeof(double); }
+inline bool pair_kernel_fits(const HostPatches2 &x, int own_max) { return x.D == 2 && x.EDmax <= 3 * 512 && x.ESmax <= 2 * 512 && x.NSmax <= 2 * 512 && own_max <= 512; }
 
 // n2n: [W2][Nn] neighbour rows (bamg order), n2n_cnt: [Nn]
 inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_nodes, int D, bool single_round_only, int cus,
-                                 const std::vector<int> &n2n, const std::vector<int> &n2n_cnt, int W2, Patch2Plan &out) {
+                                 const std::vector<int> &n2n, const std::vector<int> &n2n_cnt, int W2, Patch2Plan &out, bool for_pair_kernel = false) {
     char msg[160];
+    out.pair_kernel = false;
     if (m.No != m.Nn) return "multi-sub-step patches need a single-rank mesh";
     if (D < 2 || D > 8) return "multi-sub-step patches: depth out of range";
     std::vector<int> order(m.Nn);
@@ -539,7 +545,34 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
     HostPatches2 &hp = out.hp;
     int P = 0;
     cus = std::max(cus, 1);
-    if (pair_nodes > 0) {
+    auto own_max = [&]() { int v = 0; for (int q = 0; q < hp.nP; ++q) v = std::max(v, hp.ncnt[(size_t)q * (D + 1)]); return v; };
+    if (for_pair_kernel) {
+        // k_substep_pair on a mesh that streams from HBM: the LARGEST patches two workgroups per CU have the LDS for (80 KB each) -- the rings
+        // of a large patch are relatively thin, and what a launch saves in traffic is paid for in ring arithmetic (2 km: 5.72 ms of sub-steps
+        // at 408 nodes, 5.96 at 400 where one more wave of patches is started, 6.07 at 300; 6.7 at 420, where only one workgroup fits a CU)
+        if (D != 2) return "k_substep_pair runs two sub-steps per launch";
+        const size_t cap = 80 * 1024;
+        auto fits = [&](int PP) {
+            if (!build_patches2(m.t, m.ghost3, m.Nn, m.Ne, PP, D, order, hp)) return false;
+            return pair_lds_of(hp) <= cap && pair_kernel_fits(hp, own_max());
+        };
+        if (pair_nodes > 0) {
+            P = pair_nodes;
+            if (!fits(P)) { snprintf(msg, sizeof msg, "patches of %d nodes do not fit k_substep_pair (80 KB of LDS, three rounds of elements)", P); return msg; }
+        } else {
+            // (a mesh too small to give every CU two such patches takes smaller ones: one full round of 2 x cus workgroups)
+            int lo = 64, hi = std::min(512, std::max(68, (int)((((long long)m.Nn + 2 * cus - 1) / (2 * cus) + 3) & ~3ll) + 4));
+            if (!fits(lo)) return "no patch size fits k_substep_pair (node numbering without locality?)";
+            while (hi - lo > 4) {
+                const int mid = ((lo + hi) / 2 + 3) & ~3;
+                if (mid >= hi) break;
+                if (fits(mid)) lo = mid; else hi = mid;
+            }
+            P = lo;
+            if (!fits(P)) return "no patch size fits k_substep_pair";
+        }
+        out.pair_kernel = true;
+    } else if (pair_nodes > 0) {
         P = pair_nodes;
         if (!build_patches2(m.t, m.ghost3, m.Nn, m.Ne, P, D, order, hp)) { snprintf(msg, sizeof msg, "multi-sub-step patch construction failed (pair_nodes=%d)", P); return msg; }
     } else {
@@ -557,11 +590,11 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
         if (!done) return single_round_only ? "the mesh does not fit one multi-sub-step patch per CU" : "no multi-sub-step patch size fits (node numbering without locality?)";
     }
     out.P = P;
-    out.lds = multi_lds_of(hp);
+    out.lds = out.pair_kernel ? pair_lds_of(hp) : multi_lds_of(hp);
     if (out.lds > 160 * 1024) { snprintf(msg, sizeof msg, "multi-sub-step patches need %zu B of LDS", out.lds); return msg; }
     // one patch per CU: 768 threads when a level does not fit 512 (10 km, D = 4: 0.98 -> 0.93 ms/step; 1 024 threads would force
     // 128 VGPRs + 40 spilled: 1.53); several patches per CU: 512, the outer levels take a second round of the block
-    out.threads = hp.EDmax <= 256 ? 256 : (hp.EDmax <= 512 || hp.nP > cus) ? 512 : 768;
+    out.threads = out.pair_kernel ? 512 : hp.EDmax <= 256 ? 256 : (hp.EDmax <= 512 || hp.nP > cus) ? 512 : 768;
     {   // NodalConnectivity rows in patch-local slots, for D smoother sweeps per launch (k_smooth_multi)
         const int Nn = m.Nn;
         out.pnbr.assign((size_t)hp.nP * W2 * hp.NSmax, 0xFFFF);

@@ -32,7 +32,11 @@ print(f"shape_mem={a.shape_mem} ring={a.ring} nt={a.nt} fused={a.fused} patch_no
 if a.compare_fused >= 0:
     import numpy as np
     fe2 = dynamics.FiniteElementDynamics(p); fe2.set_option("fused", a.compare_fused); fe2.set_mesh(lm); fe2.put_state(f); fe2.set_forcing(f)
-    fe3 = dynamics.FiniteElementDynamics(p); fe3.set_option("fused", a.fused); [fe3.set_option(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.opt]; fe3.set_mesh(lm); fe3.put_state(f); fe3.set_forcing(f)
+    fe3 = dynamics.FiniteElementDynamics(p); fe3.set_option("fused", a.fused); [fe3.set_option(kv.split("=")[0], int(kv.split("=")[1])) for kv in a.opt]
+    if a.patch_nodes: fe3.set_option("patch_nodes", a.patch_nodes)
+    if a.pair_nodes: fe3.set_option("pair_nodes", a.pair_nodes)
+    if a.depth: fe3.set_option("substeps_per_launch", a.depth)
+    fe3.set_mesh(lm); fe3.put_state(f); fe3.set_forcing(f)
     for _ in range(2): fe3.step()
     fe3.synchronize()          # (one after the other: the resident kernel needs the device to itself)
     for _ in range(2): fe2.step()

@@ -265,6 +265,19 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
                 stats[12] = p2.hp.nP; stats[13] = p2.hp.EDmax;
             }
         }
+        {   // the same mesh cut for k_substep_pair (depth 2, two workgroups per CU): the largest patches that fit, or one full round of smaller ones
+            Patch2Plan pk;
+            const std::string w5 = plan_patches2(m.view(), hp.used_hilbert, 0, 2, false, cus, vn, vc, W2, pk, true);
+            if (w5.empty()) {
+                check_patches2(m, pk.hp);
+                int own_max = 0;
+                for (int q = 0; q < pk.hp.nP; ++q) own_max = std::max(own_max, pk.hp.ncnt[(size_t)q * 3]);
+                REQUIRE(pk.pair_kernel && pk.threads == 512 && pk.lds == pair_lds_of(pk.hp) && pk.lds <= 80 * 1024 && pair_kernel_fits(pk.hp, own_max),
+                        "pair plan: P=%d lds=%zu EDmax=%d ESmax=%d NSmax=%d own=%d", pk.P, pk.lds, pk.hp.EDmax, pk.hp.ESmax, pk.hp.NSmax, own_max);
+            }
+            Patch2Plan bad;   // patches of 1 000 nodes cannot fit it: refused with a reason, never cut
+            REQUIRE(Nn < 1000 || !plan_patches2(m.view(), hp.used_hilbert, 1000, 2, false, cus, vn, vc, W2, bad, true).empty(), "1 000-node patches accepted%s", "");
+        }
         if (depth_smooth >= 1) {
             SmoothPlan sp;
             const std::string w4 = plan_smooth_patches(m.view(), hp.used_hilbert, depth_smooth, vn, vc, W2, sp);

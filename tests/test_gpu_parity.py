@@ -365,12 +365,13 @@ def test_full_size_10km_invariants_and_rigid_state():
     fe.close()
 
 
-@pytest.mark.parametrize("kind,state,options,expect_launches", [("2km", "arctic", {}, 120), ("2km", "arctic_ow", {}, 120), ("h15600", "arctic", {"fused": 4}, 1),
-                                                                 ("10km", "arctic_ow", {}, 30)])
+@pytest.mark.parametrize("kind,state,options,expect_launches", [("2km", "arctic", {}, 60), ("2km", "arctic_ow", {}, 60), ("2km", "arctic", {"pair_regs": 0}, 120),
+                                                                 ("h15600", "arctic", {"fused": 4}, 1), ("10km", "arctic_ow", {}, 30)])
 def test_the_bench_workloads_themselves_against_the_oracle(kind, state, options, expect_launches):
     """What bench.py times, tied to the oracle DIRECTLY (not through the per-loop kernels): the 2 km mesh (BASELINE's headline configuration,
-    1.46 M triangles) on a single rank with the library's automatic kernel choice -- streaming hints, 476-node patches in three element rounds,
-    the once-per-step ring flush, ten smoother sweeps per launch -- with bench.py's two states ('arctic' and 'arctic_ow': 29 % of the triangles
+    1.46 M triangles) on a single rank with the library's automatic kernel choice -- two sub-steps per launch on 428-node patches with the stresses
+    in registers (k_substep_pair), the fused prep kernel, the once-per-step ring flush, ten smoother sweeps per launch; and with one launch per
+    sub-step (pair_regs = 0: streaming hints, 476-node patches in three element rounds) -- with bench.py's two states ('arctic' and 'arctic_ow': 29 % of the triangles
     ice free, 4 % in the 0 < A <= 0.1 band); the 182 k-triangle partition of aux_partition_floor in ONE resident launch (fused = 4); the 10 km
     mesh of aux_10km on the several-sub-steps kernel.  One full step (120 BBM sub-steps + 50 sweeps + update), every state array <= 1e-10 of
     the serial oracle (which takes ~9 s at 2 km and runs in a thread beside the GPU)."""
@@ -511,6 +512,41 @@ def test_several_sub_steps_per_launch_do_not_change_a_bit(dyn, substeps, opts):
         assert np.array_equal(outs[0][k], outs[1][k]), k
     if dyn != "mevp":
         assert launches[0] == substeps // _depth(substeps, opts.get("substeps_per_launch", 4))
+
+
+@pytest.mark.parametrize("kind,over,opts,launches", [
+    ("small", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}, 60),                       # the planner's own patch size
+    ("40km", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "pair_nodes": 150}, 60),
+    ("40km", {"dynamics_type": 3}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "pair_nodes": 64}, 60),   # EVP
+    ("small", {"substeps": 10, "dtime_step": 200. * 10 / 120}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "um_ring": 4}, 5),
+    ("shuffled", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}, 60),                    # patches along the Hilbert curve
+    ("h15600", {}, {}, 60),                                                                          # the default above 65 k nodes
+    ("h15600", {"substeps": 7, "dtime_step": 200. * 7 / 120}, {}, 7),                                 # an odd count: one sub-step per launch
+    ("40km", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "pair_nodes": 1000}, 120),   # patches too large for it: refused, one sub-step per launch
+])
+def test_two_sub_steps_per_launch_with_the_stresses_in_registers_do_not_change_a_bit(kind, over, opts, launches):
+    """k_substep_pair: temporal blocking at depth 2 for meshes that stream from HBM -- sub-step 0 updates every element touching the patch's
+    first ring of nodes and solves that ring, sub-step 1 updates the patch's own elements and solves its own nodes; stress and damage stay in the
+    registers of the thread that updates the element in both sub-steps, LDS holds staged velocities, frozen coordinates and corner forces only, two
+    workgroups share a CU.  The bits of one launch per sub-step: BBM and EVP, the planner's patch size and explicit ones, a short ring, a
+    numbering without locality; the default for single-rank meshes above 65 k nodes; odd sub-step counts and patches too large for it fall back."""
+    from nextsim_amd import dynamics
+    states = []
+    for options in (opts, {"fused": 1}):
+        if kind == "shuffled": p, lm, f = _shuffled_case()
+        else:
+            _, p, _, lms, fields = cases.make_case(kind, **over)
+            lm, f = lms[0], fields[0]
+        fe = dynamics.FiniteElementDynamics(p)
+        for k, v in options.items(): fe.set_option(k, v)
+        fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+        fe.step(); fe.step(); fe.synchronize()
+        states.append((fe.get_state(), fe.timing()["substep_launches"]))
+        fe.close()
+    (sa, la), (sb, lb) = states
+    for k in STATE_KEYS:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert la == launches and lb == over.get("substeps", 120)
 
 
 def test_automatic_choice_of_the_sub_step_kernel():
