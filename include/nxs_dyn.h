@@ -318,7 +318,11 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  (10 where ten rings of neighbours fit the LDS, else 5; sweep by sweep where neither fits)
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)
  *   "patch_nodes"  own nodes per patch of the fused kernel, 64..1024; 0 = automatic (whole rounds of resident workgroups)
- *   "pair_nodes"   the same for the several-sub-steps kernel, 16..512; 0 = automatic
+ *   "pair_nodes"   the same for the several-sub-steps kernels, 16..1024; 0 = automatic
+ *   "pair_regs"    single rank, not mEVP, an even number of sub-steps: TWO sub-steps per launch with the stresses between them in registers and two
+ *                  workgroups per CU (k_substep_pair: stress, damage, element constants and nodal inputs cross HBM once per two sub-steps; 2 km
+ *                  mesh 6.62 -> 5.54 ms per step, the same bits): -1 (default) = on meshes of more than 65 k nodes (smaller ones run four
+ *                  sub-steps per launch, one patch per CU), 0 = never, 1 = wherever "fused" 2 runs at depth 2
  *   "um_ring"      apply M_UM/M_UT += dt*M_VT every n sub-steps from a ring of velocity buffers, 1..128;
  *                  0 = automatic (once per step on meshes that stream from HBM, every sub-step on cache-resident ones)
  *   "nt_mask"      non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants); -1 = automatic

@@ -1959,7 +1959,8 @@ int explicit_solve(nxs_dyn_handle *h) {
     const DevMesh &m = h->dm;
     if (timed) HIPCHK(h, hipEventRecord(h->cur[0], h->stream));
     {
-        double *want = (choose_depth(h) >= 2 && h->shape_mem != 0) ? h->d_srec : nullptr;
+        // (the per-step shape-coefficient records are read by k_substep_multi only: k_substep_pair rebuilds the coefficients from the staged coordinates)
+        double *want = (choose_depth(h) >= 2 && !h->pair_kernel && h->shape_mem != 0) ? h->d_srec : nullptr;
         if (want != h->dw.srec) { h->dw.srec = want; release_graph(h); }  // (kernel arguments are baked into the graphs)
     }
     if (h->dp_dirty) {  // (outside any stream capture)
