@@ -111,6 +111,7 @@ struct nxs_dyn_handle {
     int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
                                            // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
     bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
+    int pair_hint = 0;                     // the patch size the planner kept for the previous mesh (tried first after a regrid)
     int prep_fused = -1;                   // option "prep_fused": -1 where it pays (single rank, records only, >= 250 k triangles), 0 never, 1 wherever it can run
     size_t smooth_lds = 0;
     // node-ring patches for the smoother alone (single rank, meshes on the one-sub-step-per-launch kernels): D sweeps per launch

@@ -533,7 +533,8 @@ inline bool pair_kernel_fits(const HostPatches2 &x, int own_max) { return x.D ==
 
 // n2n: [W2][Nn] neighbour rows (bamg order), n2n_cnt: [Nn]
 inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_nodes, int D, bool single_round_only, int cus,
-                                 const std::vector<int> &n2n, const std::vector<int> &n2n_cnt, int W2, Patch2Plan &out, bool for_pair_kernel = false) {
+                                 const std::vector<int> &n2n, const std::vector<int> &n2n_cnt, int W2, Patch2Plan &out, bool for_pair_kernel = false,
+                                 int pair_hint = 0 /* the size kept for the previous mesh of this handle: after a regrid it usually still fits */) {
     char msg[160];
     out.pair_kernel = false;
     if (m.No != m.Nn) return "multi-sub-step patches need a single-rank mesh";
@@ -561,15 +562,24 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
             if (!fits(P)) { snprintf(msg, sizeof msg, "patches of %d nodes do not fit k_substep_pair (80 KB of LDS, three rounds of elements)", P); return msg; }
         } else {
             // (a mesh too small to give every CU two such patches takes smaller ones: one full round of 2 x cus workgroups)
-            int lo = 64, hi = std::min(512, std::max(68, (int)((((long long)m.Nn + 2 * cus - 1) / (2 * cus) + 3) & ~3ll) + 4));
-            if (!fits(lo)) return "no patch size fits k_substep_pair (node numbering without locality?)";
-            while (hi - lo > 4) {
-                const int mid = ((lo + hi) / 2 + 3) & ~3;
-                if (mid >= hi) break;
-                if (fits(mid)) lo = mid; else hi = mid;
+            const int hi0 = std::min(512, std::max(68, (int)((((long long)m.Nn + 2 * cus - 1) / (2 * cus) + 3) & ~3ll) + 4));
+            int lo = 64, hi = hi0;
+            // every trial cuts the whole mesh (135 ms at 1.5 M triangles): the size the previous mesh of this handle took is tried first and kept if it
+            // still fits (one cut per regrid instead of nine), else the search goes on below it
+            if (pair_hint >= 64 && pair_hint < hi0 && fits(pair_hint)) { P = pair_hint; lo = hi = 0; }
+            else if (pair_hint >= 68 && pair_hint < hi0) hi = pair_hint;
+            if (hi > 0) {
+                if (!fits(lo)) return "no patch size fits k_substep_pair (node numbering without locality?)";
+                int last_built = lo;
+                while (hi - lo > 4) {   // bisection on the patch size (the need grows with it)
+                    const int mid = ((lo + hi) / 2 + 3) & ~3;
+                    if (mid >= hi) break;
+                    last_built = mid;
+                    if (fits(mid)) lo = mid; else hi = mid;
+                }
+                P = lo;
+                if (last_built != P && !fits(P)) return "no patch size fits k_substep_pair";
             }
-            P = lo;
-            if (!fits(P)) return "no patch size fits k_substep_pair";
         }
         out.pair_kernel = true;
     } else if (pair_nodes > 0) {

@@ -275,6 +275,14 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
                 REQUIRE(pk.pair_kernel && pk.threads == 512 && pk.lds == pair_lds_of(pk.hp) && pk.lds <= 80 * 1024 && pair_kernel_fits(pk.hp, own_max),
                         "pair plan: P=%d lds=%zu EDmax=%d ESmax=%d NSmax=%d own=%d", pk.P, pk.lds, pk.hp.EDmax, pk.hp.ESmax, pk.hp.NSmax, own_max);
             }
+            if (w5.empty()) {   // after a regrid: the size kept before is tried first (kept if it fits; a hint that no longer fits is searched below)
+                Patch2Plan again, above;
+                REQUIRE(plan_patches2(m.view(), hp.used_hilbert, 0, 2, false, cus, vn, vc, W2, again, true, pk.P).empty() && again.P == pk.P && again.pair_kernel, "hint %d -> %d", pk.P, again.P);
+                check_patches2(m, again.hp);
+                REQUIRE(plan_patches2(m.view(), hp.used_hilbert, 0, 2, false, cus, vn, vc, W2, above, true, pk.P + 40).empty() && above.pair_kernel && above.lds <= 80 * 1024,
+                        "hint %d -> %d", pk.P + 40, above.P);
+                check_patches2(m, above.hp);
+            }
             Patch2Plan bad;   // patches of 1 000 nodes cannot fit it: refused with a reason, never cut
             REQUIRE(Nn < 1000 || !plan_patches2(m.view(), hp.used_hilbert, 1000, 2, false, cus, vn, vc, W2, bad, true).empty(), "1 000-node patches accepted%s", "");
         }
