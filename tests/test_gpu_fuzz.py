@@ -43,12 +43,14 @@ def random_mesh(rng, n_pts, hubs):
     return M.GlobalMesh(x=x, y=y, tri=tri, dirichlet=dirichlet, neumann=neumann, lat=lat, name="fuzz")
 
 
-def random_case(seed):
+def random_case(seed, substeps=None, dynamics_type=None):
     rng = np.random.default_rng(1000 + seed)
     gm = random_mesh(rng, int(rng.integers(150, 900)), int(rng.integers(1, 4)))
     over = {"dynamics_type": [_abi.NXS_DYN_BBM, _abi.NXS_DYN_BBM, _abi.NXS_DYN_MEVP, _abi.NXS_DYN_EVP][seed % 4],
             "substeps": int(rng.integers(1, 6)), "ice_cat_type": int(rng.integers(0, 2)),
             "basal_stress_type": int(rng.integers(0, 2))}
+    if substeps is not None: over["substeps"] = substeps
+    if dynamics_type is not None: over["dynamics_type"] = dynamics_type
     over["dtime_step"] = 200.0 * over["substeps"] / 120.0                  # the reference's dte
     p = F.default_params(**over)
     p, C_fix, C_alea = F.scale_params_to_mesh(p, gm, alea_factor=0.33)
@@ -107,3 +109,38 @@ def test_random_case_matches_the_oracle(seed):
     fe.close()
     bad = {k: v for k, v in worst.items() if not (v <= 1e-11)}
     assert not bad, (seed, over, bad)
+
+
+ROUND3 = {"pair": {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1},        # k_substep_pair: two sub-steps per launch, stresses in registers
+          "prep_fused": {"fused": 1, "prep_fused": 1},                            # k_prep_fused: prep elements + prep nodes through LDS
+          "resident": {"fused": 4},                                               # k_substep_resident
+          "resident_big": {"fused": 4, "patch_nodes": 600},                       # k_substep_resident_big, interior elements one exchange ahead
+          "resident_big_plain": {"fused": 4, "patch_nodes": 600, "resident_overlap": 0}}
+
+
+@pytest.mark.parametrize("variant", sorted(ROUND3))
+@pytest.mark.parametrize("seed", range(8))
+def test_random_case_on_the_kernels_of_round_3_matches_the_oracle(seed, variant):
+    """The same random meshes (hubs of valence 10-16: the fan loops beyond eight entries, the bamg rows beyond ten), states and parameters through
+    the kernels round 3 added, each forced by its option: one step against the oracle to 1e-11, and the kernel that ran is the one asked for."""
+    from nextsim_amd import dynamics
+    substeps = [2, 4, 6][seed % 3]                                         # (even: what k_substep_pair needs; the others do not mind)
+    dyn = [_abi.NXS_DYN_BBM, _abi.NXS_DYN_EVP][seed % 2]                   # (no mEVP: its sub-steps need the step's first velocity -- one kernel per sub-step)
+    gm, p, lm, f, over = random_case(seed, substeps, dyn)
+    r = O.OracleRank(lm, p, f)
+    r.step()
+    fe = dynamics.FiniteElementDynamics(p)
+    for k, v in ROUND3[variant].items(): fe.set_option(k, v)
+    fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+    fe.step(); fe.synchronize()
+    got = fe.get_state()
+    launches = fe.timing()["substep_launches"]
+    assert launches == {"pair": substeps // 2, "prep_fused": substeps}.get(variant, 1), (variant, launches)
+    crashed = r.check_fields_fast() != 0
+    assert (fe.checkFieldsFast() != 0) == crashed
+    fe.close()
+    if crashed:
+        return
+    bad = {k: cases.rel_err(got[k], r.arr[k]) for k in KEYS}
+    bad = {k: v for k, v in bad.items() if not (v <= 1e-11)}
+    assert not bad, (seed, variant, over, bad)
