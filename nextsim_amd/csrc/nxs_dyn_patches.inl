@@ -27,7 +27,7 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
     h->pair_lds = plan.lds;
     h->pair_threads = plan.threads;
     h->pair_kernel = plan.pair_kernel;
-    if (plan.pair_kernel && h->pair_nodes == 0) h->pair_hint = plan.P;
+    if (plan.pair_kernel && h->pair_nodes == 0) h->pair_hint = plan.P_fit;
     h->pair_own_max = 0;
     for (int q = 0; q < hp.nP; ++q) h->pair_own_max = std::max(h->pair_own_max, hp.ncnt[(size_t)q * (D + 1)]);
     if (getenv("NXS_DEBUG_PATCHES")) {

@@ -520,6 +520,7 @@ inline size_t prep_fused_lds_of(const HostPatches &hp) {
 struct Patch2Plan {
     HostPatches2 hp;
     bool pair_kernel = false;  // cut for k_substep_pair (depth 2, two workgroups per CU)
+    int P_fit = 0;             // k_substep_pair: the largest patch size that fits (the hint for the next mesh of the handle; P may be smaller: whole rounds)
     int P = 0, threads = 512;
     size_t lds = 0, smooth_lds = 0;
     std::vector<unsigned short> pnbr;  // [nP][W2][NSmax], empty when a caller-supplied row reaches beyond its patch
@@ -579,6 +580,21 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
                 }
                 P = lo;
                 if (last_built != P && !fits(P)) return "no patch size fits k_substep_pair";
+            }
+            out.P_fit = P;
+            // One or two rounds of workgroups: whole rounds (a round that is a fraction full costs almost a full one -- 492 k triangles: 583
+            // patches of 424 nodes 2.43 ms of sub-steps, 1 013 of 244 nodes 2.26; 730 k: 864 of 424 3.15, 1 018 of 360 3.00).  From three rounds
+            // on the largest patches win (1.08 M triangles: 1 270 of 428 4.14, 1 494-1 527 of 356-364 4.32-4.35; 2 km likewise).
+            const int slots = 2 * cus, k = (hp.nP + slots - 1) / slots;
+            if (k <= 2 && hp.nP > 0 && hp.nP != k * slots) {
+                int Pr = (int)((((long long)m.Nn + (long long)k * slots - 1) / ((long long)k * slots) + 3) & ~3ll);
+                Pr = std::max(64, Pr);
+                bool tried = false;
+                for (int it = 0; it < 6 && Pr < P; ++it, Pr += 4) {   // (patches closed early add a few: a size or two up until they fit the rounds)
+                    tried = true;
+                    if (fits(Pr) && hp.nP <= k * slots) { P = Pr; break; }
+                }
+                if (tried && P == out.P_fit && !fits(P)) return "no patch size fits k_substep_pair";   // (the trials rebuilt hp: back to the size kept)
             }
         }
         out.pair_kernel = true;
