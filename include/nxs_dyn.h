@@ -311,6 +311,10 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  large patches of a 200 k - 400 k partition (one workgroup per CU, nothing else fills its wait: 4 % faster), not the
  *                  one-element-per-thread patches (inside one GPU the wait is filled by the other workgroup of the CU; between GPUs it is a
  *                  round trip over xGMI: bench.py times both and keeps one).  The same bits either way
+ *   "band_patch_nodes"  several ranks with "fused" 4 (one element per thread): the nodes this rank sends -- its own nodes along the partition boundary --
+ *                  are cut into small patches of their own: a boundary patch pays the exchange between ranks in every sub-step of the resident
+ *                  loop, so it gets a shorter compute phase (two ranks of 87 k triangles rehearsed on one GPU: 0.985 -> 0.89-0.91 ms of
+ *                  sub-steps).  16..512 nodes; 0 = off; -1 (default) = 48.  The cut does not change a bit of the results
  *   "prep_fused"   single rank: prep elements + prep nodes (FE.cpp:10235-10416) as ONE launch over the sub-step kernel's node patches, the elements'
  *                  values reaching their nodes through LDS (k_prep_fused: 2 km mesh 203 -> 113 us per step, the same bits): -1 (default) =
  *                  on meshes of 250 k triangles and more, 0 = never, 1 = wherever its tables exist

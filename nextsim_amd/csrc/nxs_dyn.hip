@@ -108,6 +108,7 @@ struct nxs_dyn_handle {
     std::vector<int> h_n2e;                // NodalElementConnectivity rows [W1][Nn], -1 = pad (for k_prep_fused's rows in patch slots)
     int pair_own_max = 0;                  // most own nodes of a multi-sub-step patch
     size_t prep_lds = 0;                   // LDS of k_prep_fused for the current patches; 0: the two separate prep kernels run
+    int band_nodes = -1;                   // option "band_patch_nodes": several ranks, resident loop: the sent nodes in patches of their own of this size; -1 = 48, 0 = off
     int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
                                            // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
     bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
@@ -675,6 +676,12 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         h->pair_nodes = (int)value; h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "work_arrays")) { h->work_arrays = value != 0; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "band_patch_nodes")) {
+        if (value > 0 && (value < 16 || value > 512)) return fail(h, NXS_ERR_INVALID, "band_patch_nodes must be -1 (automatic), 0 (off) or in [16,512]");
+        h->band_nodes = value < 0 ? -1 : (int)value;
+        if (h->have_mesh) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipStreamSynchronize(h->stream)); release_graph(h); return upload_patches(h); }
+        return NXS_OK;
+    }
     if (!std::strcmp(key, "pair_regs")) { h->pair_regs = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "prep_fused")) { h->prep_fused = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "shape_mem")) {

@@ -106,7 +106,7 @@ int upload_patches(nxs_dyn_handle *h) {
     h->hf_ready = false;
     const DevMesh &m = h->dm;
     nxs_cut::PatchPlan plan;
-    const std::string why = nxs_cut::plan_patches(mesh_view(h), h->patch_nodes, h->fused == 4, device_cus(h), plan, NXS_CUT_RES_EPT, !h->no_big_cut);
+    const std::string why = nxs_cut::plan_patches(mesh_view(h), h->patch_nodes, h->fused == 4, device_cus(h), plan, NXS_CUT_RES_EPT, !h->no_big_cut, h->band_nodes < 0 ? 48 : h->band_nodes);
     if (!why.empty()) return fail(h, NXS_ERR_INVALID, "%s", why.c_str());
     h->fused_lds = plan.fused_lds;
     h->cut_big = plan.cut_big;

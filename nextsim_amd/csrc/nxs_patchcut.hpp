@@ -62,15 +62,20 @@ inline void node_fans(const std::vector<int> t[3], int Nn, int Ne, std::vector<i
 // Ecap > 0: a patch is closed early when one more own node would take it past Ecap elements (the resident kernel holds a fixed number of
 // elements per thread; a partition whose own nodes are not contiguous along the numbering -- an RCB part of a Hilbert-numbered mesh --
 // otherwise has a few patches of two distant blobs with 1.5 times the elements of the others, and the whole round waits for them).
+// n_first > 0: the first n_first nodes of `order` are cut into patches of P_first nodes, the others into patches of P (several ranks: the nodes
+// along the partition boundary in small patches of their own -- a boundary patch pays the longer exchange between ranks every sub-step of the
+// resident loop, so it gets a shorter compute phase; see plan_patches)
 inline bool build_patches_from_order(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int No, int P,
-                                     const std::vector<int> &order, HostPatches &out, int Ecap = 0, int Mcap = 0) {
+                                     const std::vector<int> &order, HostPatches &out, int Ecap = 0, int Mcap = 0, int n_first = 0, int P_first = 0) {
     if (P < 1 || No < 0 || No > Nn || (int)order.size() < No) return false;
+    if (n_first <= 0 || P_first < 1 || n_first > No) { n_first = 0; P_first = P; }
     std::vector<int> off, adj;
     node_fans(t, Nn, Ne, off, adj);
 
     std::vector<int> pstart;  // patch q owns order[pstart[q] .. pstart[q + 1])
     if (Ecap <= 0) {
-        for (int a = 0; a < No; a += P) pstart.push_back(a);
+        for (int a = 0; a < n_first; a += P_first) pstart.push_back(a);
+        for (int a = n_first; a < No; a += P) pstart.push_back(a);
     } else {
         // Mcap > 0: ... or past Mcap staged nodes (own + halo; the large-patch resident kernel names a corner's slot in ten bits)
         std::vector<int> seen(Ne, -1), seen_n, trial_n;
@@ -96,7 +101,8 @@ inline bool build_patches_from_order(const std::vector<int> t[3], const unsigned
             int fresh = 0;
             for (int j = off[n]; j < off[n + 1]; ++j) fresh += seen[adj[j]] != q ? 1 : 0;
             int fresh_m = fresh_nodes(n);
-            if (cnt_n > 0 && (cnt_n == P || cnt_e + fresh > Ecap || (Mcap > 0 && cnt_m + fresh_m > Mcap))) {  // close the patch before this node
+            // close the patch before this node: it is full (of the size its part of the order takes), the small patches end here, or a cap would be passed
+            if (cnt_n > 0 && (cnt_n >= (i < n_first ? P_first : P) || (n_first > 0 && i == n_first) || cnt_e + fresh > Ecap || (Mcap > 0 && cnt_m + fresh_m > Mcap))) {
                 pstart.push_back(i);
                 ++q; cnt_n = 0; cnt_e = 0; cnt_m = 0;
                 fresh = off[n + 1] - off[n];
@@ -254,18 +260,33 @@ inline void hilbert_order(const double *x0, const double *y0, int n_nodes, std::
     std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
 }
 
+// band_P > 0 (several ranks): the own nodes that share an element with a ghost node -- on a partitioner's partitions the nodes this rank sends --
+// lead the order and are cut into patches of band_P nodes
 inline bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
-                          int No, int P, HostPatches &out, int Ecap = 0, int Mcap = 0) {
+                          int No, int P, HostPatches &out, int Ecap = 0, int Mcap = 0, int band_P = 0) {
     // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
     std::vector<int> order(No);
     for (int i = 0; i < No; ++i) order[i] = i;
-    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out, Ecap, Mcap);
-    if (ok && out.avg_elems_per_own_node <= 3.0) return true;
+    std::vector<char> band;
+    int n_band = 0;
+    if (band_P > 0 && No < Nn) {
+        band.assign(No, 0);
+        for (int e = 0; e < Ne; ++e) {
+            const int v[3] = {t[0][e], t[1][e], t[2][e]};
+            if (v[0] < No && v[1] < No && v[2] < No) continue;
+            for (int k = 0; k < 3; ++k) if (v[k] < No) band[v[k]] = 1;
+        }
+        for (int i = 0; i < No; ++i) n_band += band[i];
+        std::stable_partition(order.begin(), order.end(), [&](int n) { return band[n] != 0; });
+    }
+    bool ok = build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, out, Ecap, Mcap, n_band, band_P);
+    if (ok && out.avg_elems_per_own_node <= 3.0 + (n_band > 0 ? 0.5 : 0.)) return true;
     // numbering without locality: cut patches along a Hilbert curve through the node coordinates
     // (consecutive runs of a Hilbert curve are compact blobs: small halos)
     hilbert_order(x0, y0, No, order);
+    if (n_band > 0) std::stable_partition(order.begin(), order.end(), [&](int n) { return band[n] != 0; });
     HostPatches alt;
-    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt, Ecap, Mcap) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
+    if (build_patches_from_order(t, ghost3, Nn, Ne, No, P, order, alt, Ecap, Mcap, n_band, band_P) && (!ok || alt.avg_elems_per_own_node < out.avg_elems_per_own_node)) {
         out = std::move(alt);
         out.used_hilbert = true;
         return true;
@@ -393,7 +414,8 @@ inline bool resident_is_big(const HostPatches &hp) { return hp.Emax > 512 * NXS_
 // patch_nodes > 0: the caller's size (shrunk until it fits); else automatic.  want_resident: option fused = 4 was set before set_mesh (the mesh is
 // then cut for ONE round of resident 512-thread workgroups where that is possible), res_ept: elements per thread the resident kernel holds.
 // cus: compute units of the device.  Returns "" or the reason it failed.
-inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_resident, int cus, PatchPlan &out, int res_ept = NXS_CUT_RES_EPT, bool allow_big = true) {
+inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_resident, int cus, PatchPlan &out, int res_ept = NXS_CUT_RES_EPT, bool allow_big = true,
+                                int band_nodes = 0 /* several ranks, resident loop: the nodes along the partition boundary in patches of this size (0: like the others) */) {
     char msg[160];
     HostPatches &hp = out.hp;
     int P = 0;
@@ -402,7 +424,7 @@ inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_re
         // patches of up to ~200 nodes hold one element per thread of a 512-thread workgroup (k_substep_resident requires it, and one round
         // of the one-launch-per-sub-step kernel is as slow as its largest patch): none may exceed 480 elements
         const int Ecap = Ecap_big > 0 ? Ecap_big : (PP > NXS_CUT_T256_MAXP && PP <= 208) ? 480 : 0;
-        if (!build_patches(m.t, m.ghost3, m.x0, m.y0, m.Nn, m.Ne, m.No, PP, hp, Ecap, Ecap_big > 0 ? 1000 : 0)) return false;
+        if (!build_patches(m.t, m.ghost3, m.x0, m.y0, m.Nn, m.Ne, m.No, PP, hp, Ecap, Ecap_big > 0 ? 1000 : 0, (want_resident && Ecap_big == 0 && band_nodes < PP) ? band_nodes : 0)) return false;
         out.fused_lds = fused_lds_of(hp);
         return true;
     };

@@ -139,7 +139,11 @@ int caught(char *msg, int cap) {
 
 }  // namespace
 
+static int g_band_nodes = 0;   // pc_set_band: the size of the patches along the partition boundary in the cuts that follow (0: like the others)
+
 extern "C" {
+
+void pc_set_band(int band_nodes) { g_band_nodes = band_nodes; }
 
 // One rank's mesh through everything nxs_dyn_set_mesh / set_halo / the first step build on the host.  stats (int64[20]): nP, Pmax, Emax,
 // Mmax, Wp, used_hilbert, fused_lds, P, resident ok, resident max neighbours, n_boundary, reordered, multi nP, multi EDmax, smoother nP, smoother NDmax, cut for the large-patch resident kernel.
@@ -152,7 +156,7 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     for (int i = 0; i < 20; ++i) stats[i] = 0;
     const Mesh m = make_mesh(indices, ghost3, x, y, Nn, Ne, No);
     PatchPlan plan;
-    const std::string why = plan_patches(m.view(), patch_nodes, want_resident != 0, cus, plan, res_ept);
+    const std::string why = plan_patches(m.view(), patch_nodes, want_resident != 0, cus, plan, res_ept, true, g_band_nodes);
     if (!why.empty()) { put_msg(msg, msg_cap, why); return 2; }
     HostPatches &hp = plan.hp;
     check_patches(m, hp);
@@ -162,6 +166,21 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     REQUIRE(pet.size() == 2 * (size_t)hp.nP * hp.Emax, "pet size");
     stats[16] = plan.cut_big; for (int q = 0; q < hp.nP; ++q) { stats[17] += hp.elem_cnt[q]; stats[18] += (hp.elem_cnt[q] + 63) / 64 > 24; stats[19] = std::max<int64_t>(stats[19], hp.node_cnt[q] - hp.own_cnt[q]); } stats[0] = hp.nP; stats[1] = hp.Pmax; stats[2] = hp.Emax; stats[3] = hp.Mmax; stats[4] = hp.Wp; stats[5] = hp.used_hilbert; stats[6] = (int64_t)plan.fused_lds; stats[7] = plan.P;
     const bool mr = ns > 0 || nr > 0 || No < Nn;
+    if (mr && g_band_nodes > 0 && want_resident && !plan.cut_big && g_band_nodes < plan.P) {
+        // the own nodes that share an element with a ghost (on the partitions a mesh partitioner makes: the nodes this rank sends; a ragged element
+        // partition also sends nodes whose neighbours' elements it does not hold) sit in patches of their own, of at most g_band_nodes nodes
+        std::vector<char> band(No, 0);
+        for (int e = 0; e < Ne; ++e) {
+            bool has_ghost = false;
+            for (int k = 0; k < 3; ++k) has_ghost = has_ghost || indices[3 * e + k] - 1 >= No;
+            if (has_ghost) for (int k = 0; k < 3; ++k) if (indices[3 * e + k] - 1 < No) band[indices[3 * e + k] - 1] = 1;
+        }
+        for (int q = 0; q < hp.nP; ++q) {
+            int nb = 0;
+            for (int i = 0; i < hp.own_cnt[q]; ++i) nb += band[hp.pnodes[(size_t)q * hp.Mmax + i]];
+            REQUIRE(nb == 0 || (nb == hp.own_cnt[q] && nb <= g_band_nodes), "patch %d mixes %d boundary nodes with %d others", q, nb, hp.own_cnt[q] - nb);
+        }
+    }
     if (!mr) {  // the rows of k_prep_fused: every node's elements in an order of its own (descending here; bamg's is a chained list's) -> patch slots
         std::vector<std::vector<int>> fan(Nn);
         for (int e = Ne - 1; e >= 0; --e) for (int k = 0; k < 3; ++k) fan[indices[3 * e + k] - 1].push_back(e);

@@ -208,6 +208,7 @@ for kind, nparts, seed in (("toy", 3, 11), ("toy", 4, 12), ("small", 3, 13), ("s
     gmk = cases.global_mesh(kind)
     for lm_r in M.localize(gmk, nparts, elem_part=cases.ragged_partition(gmk, nparts, seed)):
         r0 = run_cut(lm_r); r1 = run_cut(lm_r, want_resident=1, overlap=1); run_cut(lm_r, patch_nodes=64, overlap=1)
+        cut.pc_set_band(16); run_cut(lm_r, want_resident=1, overlap=1); run_cut(lm_r, patch_nodes=200, want_resident=1); cut.pc_set_band(0)
         assert r0["n_boundary"] >= 1 and r1["n_boundary"] >= 1, (r0, r1)
 for lm_r in M.localize(sm, 2):
     run_cut(lm_r, want_resident=1, overlap=1)
@@ -217,6 +218,10 @@ for kind in ("10km", "2km"):
     for lm_p in M.localize(M.make_mesh(kind), 8):
         r = run_cut(lm_p, want_resident=1)
         assert r["res_ok"] == 1 and r["Emax"] <= 512 and r["nP"] <= 512 and r["cut_big"] == 0, (kind, lm_p.rank, r)
+        cut.pc_set_band(48)            # ... and with the sent nodes in patches of 48 of their own (what the resident loop of several ranks takes)
+        rb = run_cut(lm_p, want_resident=1, overlap=1)
+        cut.pc_set_band(0)
+        assert rb["res_ok"] == 1 and rb["Emax"] <= 512 and rb["nP"] <= 512 and rb["cut_big"] == 0 and rb["n_boundary"] >= 1, (kind, lm_p.rank, r, rb)
 for lm_p in M.localize(M.make_mesh("2km"), 4):     # ... and the four parts of a 4-GPU run: one large patch per CU (k_substep_resident_big)
     r = run_cut(lm_p, want_resident=1, overlap=1)   # (with the interior-first lists: whole slices of 512 elements)
     assert r["res_ok"] == 1 and r["cut_big"] == 1 and r["nP"] <= 256, (lm_p.rank, r)
