@@ -12,7 +12,7 @@ steps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 KIND = sys.argv[2] if len(sys.argv) > 2 else "h16000"   # 173 k triangles: two ranks of ~245 patches of 180 nodes fit the 512 slots together
 for overlap in (0, 1):
     with tempfile.TemporaryDirectory() as d:
-        reps = T._run(2, KIND, steps, pathlib.Path(d), "ipc", over={"options": {"fused": 4, "patch_nodes": int(os.environ.get("NXS_PN", "180")), "band_patch_nodes": int(os.environ.get("NXS_BAND", "0")), "resident_overlap": overlap, "resident_wide": int(os.environ.get("NXS_WIDE", "0"))}}, ranks_per_proc=int(os.environ.get("NXS_RPP", "2")))
+        reps = T._run(2, KIND, steps, pathlib.Path(d), "ipc", over={"options": {"fused": 4, "patch_nodes": int(os.environ.get("NXS_PN", "180")), "band_patch_nodes": int(os.environ.get("NXS_BAND", "-1")), "resident_overlap": overlap, "resident_wide": int(os.environ.get("NXS_WIDE", "0"))}}, ranks_per_proc=int(os.environ.get("NXS_RPP", "2")))
     for r in reps:
         tm = r.get("timing", {})
         if not r["ok"]: print("   ", {k: v for k, v in r.items() if k not in ("timing",)})
