@@ -289,8 +289,9 @@ NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
  *                  whole device -- including a neighbour rank's kernel that is already waiting for this rank); harmless anywhere else
  *   "graph"        1 = sub-step loop replayed from a hipGraph (default); 0 = plain launches
  *   "timing"       1 = record the per-phase events (default); "timing_reset": zero the averages
- *   "fused"        3 = automatic (default): several sub-steps per launch on single-rank meshes small enough for one patch
- *                  per CU (<= 256 nodes each, patches with that many rings of halo), one patch kernel per sub-step otherwise;
+ *   "fused"        3 = automatic (default): on a single rank several sub-steps per launch -- four on meshes small enough for one patch per CU
+ *                  (<= 256 nodes each, patches with that many rings of halo), two with the stresses in registers on larger ones (see
+ *                  "pair_regs") --, one patch kernel per sub-step otherwise (several ranks, mEVP, a sub-step count the depth does not divide);
  *                  2 = several sub-steps per launch wherever possible (single rank, not mEVP, a depth that divides the
  *                  number of sub-steps); 1 = one patch kernel per sub-step; 0 = one kernel per reference loop;
  *                  4 = the whole sub-step loop in ONE resident launch whose workgroups wait for their neighbouring patches only
