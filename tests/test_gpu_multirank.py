@@ -260,6 +260,20 @@ def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rp
             assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
 
 
+@pytest.mark.parametrize("world,kind,rpp,over,band", [(2, "40km", 2, {}, 0), (2, "40km", 2, {}, 16), (3, "40km", 1, {"ragged_seed": 3}, 24), (4, "10km", 2, {"dynamics_type": 3}, 32)])
+def test_small_patches_along_the_partition_boundary_do_not_change_a_bit(world, kind, rpp, over, band, tmp_path):
+    """Option band_patch_nodes (default 48): in the cut for the resident loop of several ranks the own nodes that share an element with a ghost node
+    lead the cutter's order and get patches of their own -- the patches that pay the exchange between ranks every sub-step then have a short compute
+    phase.  A different cut, the same bits: explicit sizes and none at all (0) against the separate kernels and the multi-rank oracle, regular and
+    ragged partitions (where a rank also sends nodes that touch no ghost of its own mesh: those stay in ordinary patches), EVP."""
+    reps = _run(world, kind, 1, tmp_path, "ipc", over=dict(over, options={"fused": 4, "band_patch_nodes": band}), ranks_per_proc=rpp)
+    for r in reps:
+        assert r["ok"], r
+        assert r["fused_equals_separate"] is True and r["launches_fused"] == 1 and r["crash"] == 0, r
+        for k, e in r["errs"].items():
+            assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
+
+
 @pytest.mark.parametrize("kind,world", [("2km", 8), ("10km", 8)])
 def test_every_partition_of_the_baseline_configurations_can_run_the_resident_loop(kind, world):
     """BASELINE configs 3 and 4 on eight GPUs are meant to run the whole sub-step loop of a rank as ONE resident launch (option fused = 4).
