@@ -1468,6 +1468,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
     }
     const int t = threadIdx.x, Nn = m.Nn;
+    NXS_STAMP(0);
     if (t == 0) lF2[ZIDX] = d2{0., 0.};
     const int *ncnt = pp.ncnt + (size_t)blk * 3, *ecnt = pp.ecnt + (size_t)blk * 2;
     const int nO = ncnt[0], nN1 = ncnt[1], nN2 = ncnt[2], nE1 = ecnt[0], nE2 = ecnt[1];
@@ -1618,6 +1619,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     };
     if (t < nE1) load_constants(eraw[0] >= 0 ? eraw[0] : ~eraw[0], c0, c1, c2r);
     __syncthreads();  // the velocities of sub-step 0 on N_1; the corner forces have been consumed
+    NXS_STAMP(2);
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int l = t + r * T;
@@ -1646,6 +1648,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1;
         }
     }
+    NXS_STAMP(4);
 }
 
 // ------------------------------------------------------------------------------------------------

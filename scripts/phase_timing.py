@@ -5,7 +5,7 @@
 import argparse, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true"); ap.add_argument("--resident", action="store_true"); ap.add_argument("--prep", action="store_true"); ap.add_argument("--opt", action="append", default=[], help="key=value for set_option (before set_mesh)")
+ap = argparse.ArgumentParser(); ap.add_argument("--build", action="store_true"); ap.add_argument("--mesh", default="2km"); ap.add_argument("--h", type=float, default=0.); ap.add_argument("--multi", action="store_true"); ap.add_argument("--resident", action="store_true"); ap.add_argument("--prep", action="store_true"); ap.add_argument("--pair", action="store_true"); ap.add_argument("--opt", action="append", default=[], help="key=value for set_option (before set_mesh)")
 a = ap.parse_args()
 csrc = os.path.join(ROOT, "nextsim_amd", "csrc")
 if a.build:
@@ -25,6 +25,16 @@ if a.resident: fe.set_option("fused", 4)
 for kv in a.opt: fe.set_option(kv.split("=")[0], float(kv.split("=")[1]))
 fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
 fe.step(); fe.step(); fe.synchronize()
+if a.pair:  # k_substep_pair (the last launch of the step): start, end of sub-step 0, end -- and how many workgroups run at a time
+    t = fe.debug_array("phase_times").reshape(8192, 8)[:, [0, 2, 4]]
+    t = t[t[:, 0] > 0]
+    k0, k1 = t[:, 0].min(), t[:, 2].max()
+    print(f"{gm.num_elements} triangles, {t.shape[0]} workgroups; kernel span {(k1 - k0) * 10e-3:.2f} us; a workgroup takes {((t[:, 2] - t[:, 0]).mean()) * 10e-3:.2f} us "
+          f"(sub-step 0: {((t[:, 1] - t[:, 0]).mean()) * 10e-3:.2f}); started in the last quarter of the span: {(t[:, 0] > k0 + 0.75 * (k1 - k0)).sum()}")
+    for f0 in np.linspace(0.05, 0.95, 10):
+        x = k0 + f0 * (k1 - k0)
+        print(f"  at {100 * f0:3.0f} % of the span: {((t[:, 0] <= x) & (t[:, 2] > x)).sum():4d} workgroups running")
+    fe.close(); sys.exit(0)
 if a.prep:  # k_prep_fused: start, nodes staged + barrier, elements done, barrier, nodes done
     t = fe.debug_array("phase_times_prep").reshape(8192, 8)[:, :5]
     t = t[t[:, 0] > 0]
