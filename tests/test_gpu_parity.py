@@ -549,6 +549,34 @@ def test_two_sub_steps_per_launch_with_the_stresses_in_registers_do_not_change_a
     assert la == launches and lb == over.get("substeps", 120)
 
 
+def test_two_sub_steps_per_launch_survive_a_change_of_sub_steps_and_a_remesh():
+    """What k_substep_pair's patches and ring are tied to may change under it: nxs_dyn_set_params with an odd number of sub-steps (one launch per
+    sub-step from then on), back to an even one (pairs again, another ring length), nxs_dyn_set_mesh with another mesh (the planner starts from
+    the patch size it kept).  Always the bits of one launch per sub-step doing the same."""
+    from nextsim_amd import dynamics
+    _, p1, _, lms1, f1 = cases.make_case("h15600")
+    _, p2, _, lms2, f2 = cases.make_case("h19000", dtime_step=200. * 10 / 120, substeps=10)
+
+    def run(opts):
+        fe = dynamics.FiniteElementDynamics(p1)
+        for k, v in opts.items(): fe.set_option(k, v)
+        fe.set_mesh(lms1[0]); fe.put_state(f1[0]); fe.set_forcing(f1[0]); fe.step()
+        launches = [fe.timing()["substep_launches"]]
+        q = p1.copy(); q.substeps = 7; q.dtime_step = 200. * 7 / 120
+        fe.set_params(q); fe.step(); fe.synchronize(); launches.append(fe.timing()["substep_launches"])
+        q = p1.copy(); q.substeps = 10; q.dtime_step = 200. * 10 / 120
+        fe.set_params(q); fe.step(); fe.synchronize(); launches.append(fe.timing()["substep_launches"])
+        fe.set_params(p2); fe.set_mesh(lms2[0]); fe.put_state(f2[0]); fe.set_forcing(f2[0]); fe.step(); fe.synchronize()
+        launches.append(fe.timing()["substep_launches"])
+        return fe, launches
+    (a, la), (b, lb) = run({"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}), run({"fused": 1})
+    sa, sb = a.get_state(), b.get_state()
+    for k in STATE_KEYS:
+        assert np.array_equal(sa[k], sb[k]), k
+    assert la == [60, 7, 5, 5] and lb == [120, 7, 10, 10], (la, lb)
+    a.close(); b.close()
+
+
 def test_automatic_choice_of_the_sub_step_kernel():
     """Default (fused = 3): four sub-steps per launch on a single-rank mesh that lives in the caches, one per launch when the
     pairing is impossible (odd count) -- and the same bits either way."""
