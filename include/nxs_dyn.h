@@ -208,6 +208,12 @@ NXS_API int nxs_dyn_abi_version(void);
 NXS_API const char *nxs_dyn_last_error(const nxs_dyn_handle *h); /* h may be NULL: last create() error */
 
 NXS_API int nxs_dyn_default_params(nxs_dyn_params *p); /* model/options.cpp defaults, bbm */
+/* The physical constants compiled into the kernels, in the order NXS_CONST_* names them: physical::rhoi, rhow, rhos, rhoa, gravity, omega
+ * (model/constants.hpp:56-87), PI (contrib/bamg/include/OppositeAngle.h:4), days_in_sec (model/finiteelement.hpp:549).  Host only; lets a
+ * caller (and tests/test_reference_constants.py, against values printed by a translation unit that includes the reference's headers) check
+ * that library and model agree before the first step. */
+enum { NXS_CONST_RHOI = 0, NXS_CONST_RHOW, NXS_CONST_RHOS, NXS_CONST_RHOA, NXS_CONST_GRAVITY, NXS_CONST_OMEGA, NXS_CONST_PI, NXS_CONST_DAYS_IN_SEC, NXS_CONST_COUNT };
+NXS_API int nxs_dyn_physical_constants(double *out, int32_t count);
 NXS_API int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out);
 NXS_API int nxs_dyn_destroy(nxs_dyn_handle *h);
 NXS_API int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p);

@@ -514,6 +514,13 @@ int nxs_dyn_default_params(nxs_dyn_params *p) try {  // model/options.cpp:43,80,
     return NXS_OK;
 } catch (...) { return dyn_caught(nullptr, "nxs_dyn_default_params"); }
 
+int nxs_dyn_physical_constants(double *out, int32_t count) try {  // model/constants.hpp:56-87, OppositeAngle.h:4, finiteelement.hpp:549
+    if (!out || count < 0) return NXS_ERR_INVALID;
+    const double c[NXS_CONST_COUNT] = {NXS_RHOI, NXS_RHOW, NXS_RHOS, NXS_RHOA, NXS_GRAVITY, NXS_OMEGA, NXS_PI, NXS_DAYS_IN_SEC};
+    for (int i = 0; i < count && i < NXS_CONST_COUNT; ++i) out[i] = c[i];
+    return NXS_OK;
+} catch (...) { return dyn_caught(nullptr, "nxs_dyn_physical_constants"); }
+
 int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) try {
     if (!out) return fail(nullptr, NXS_ERR_INVALID, "out is NULL");
     *out = nullptr;

@@ -85,6 +85,10 @@ void ref_work_destroy(ref_work *w) {
 }
 
 /* model/options.cpp:43,80,111,109,314-376,397,545,547 ; FE.cpp:1167-1172 (turning angle) */
+void ref_physical_constants(double out[8]) { /* the constants above, in include/nxs_dyn.h's NXS_CONST_* order */
+    out[0] = RHOI; out[1] = RHOW; out[2] = RHOS; out[3] = RHOA; out[4] = GRAVITY; out[5] = OMEGA; out[6] = PI_; out[7] = DAYS_IN_SEC;
+}
+
 void ref_default_params(nxs_dyn_params *p) {
     memset(p, 0, sizeof(*p));
     p->dtime_step = 200.;

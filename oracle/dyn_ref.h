@@ -63,6 +63,7 @@ void ref_work_destroy(ref_work *w);
 int ref_work_enable_trace(ref_work *w);   /* allocates and zeroes w->trace; 0 on success */
 
 void ref_default_params(nxs_dyn_params *p);
+void ref_physical_constants(double out[8]); /* rhoi, rhow, rhos, rhoa, gravity, omega, PI, days_in_sec as this file uses them */
 
 /* phases of explicitSolve(), split where the reference calls updateGhosts() */
 void ref_prep(const nxs_dyn_mesh *m, const nxs_dyn_params *p, nxs_dyn_state *s,

@@ -53,15 +53,7 @@ def test_ctypes_layouts_match_the_header(tmp_path):
     assert vals == expect
 
 
-def test_default_params_match_options_cpp():
-    L = dynamics.load_library()
-    p = _abi.Params()
-    assert L.nxs_dyn_default_params(C.byref(p)) == 0
-    from nextsim_amd.forcing import default_params
-    q = default_params()
-    for name, _ in _abi.Params._fields_:
-        assert getattr(p, name) == getattr(q, name), name
-    assert (p.dtime_step, p.substeps, p.young, p.compaction_param) == (200.0, 120, 5.9605e8, -20.0)
+# (the default parameters, the physical constants and the enums are compared with the REFERENCE's values in tests/test_reference_constants.py)
 
 
 def _has_gpu():
