@@ -46,15 +46,14 @@ def parse():
     return ap.parse_args()
 
 
-PMC_PROFILES = ("profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_v2_pmc_traffic.json")
+PMC_PROFILES = ("profiles/r04_pmc_traffic.json", "profiles/r03_pmc_traffic.json", "profiles/r02_pmc_traffic.json", "profiles/r01_v2_pmc_traffic.json")
 
 
-def pmc_traffic(mesh, launches_per_substep, world, kernel="k_substep_fused"):
-    """(HBM bytes per launch of the sub-step kernel, the file they come from): the committed rocprofv3 --pmc passes
-    (FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes, same command, same kernel, same mesh -- corrected as
-    MI355X_MICROARCH.md prescribes for gfx950).  PMC counters cannot be read from inside this process, so this is a
-    REPLAY of the committed profile, labelled as such in the JSON line; (None, None) when no profile applies to this run."""
-    if mesh != "2km" or launches_per_substep != 1 or world != 1:
+def pmc_traffic(mesh, world, kernel):
+    """(HBM bytes per launch of `kernel`, the file they come from) from the COMMITTED rocprofv3 --pmc passes of the single-GPU 2 km run (FETCH_SIZE x2 +
+    WRITE_SIZE, KiB, separate passes -- corrected as MI355X_MICROARCH.md prescribes for gfx950).  Only a stand-in when the live measurement below cannot
+    run, and labelled as a replay in the JSON line; (None, None) when no profile applies to this run."""
+    if mesh != "2km" or world != 1:
         return None, None
     for rel in PMC_PROFILES:
         try:
@@ -67,45 +66,55 @@ def pmc_traffic(mesh, launches_per_substep, world, kernel="k_substep_fused"):
     return None, None
 
 
-def pmc_traffic_live(mesh, launches_per_substep, world, timeout_s=240, kernel="k_substep_fused"):
-    """(HBM bytes per launch of the sub-step kernel MEASURED NOW, how): two child runs of one step of the same mesh
-    (scripts/run_steps.py) under `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` -- separate passes, counters only, no
-    tracing beside them -- reduced as scripts/make_pmc_profile.py does: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over the launches of
-    k_substep_fused (gfx950 counts half of the coalesced streaming reads: MI355X_MICROARCH.md; calibrated in
-    profiles/r01_v1_pmc_traffic.json).  (None, reason) when it cannot be done here (no rocprofv3, already under a profiler, a failure)."""
+def pmc_traffic_live(mesh, world, rank, kernels, options=(), timeout_s=300):
+    """({kernel prefix: HBM bytes per launch MEASURED NOW}, how): two child runs of one step of THIS RANK'S partition (scripts/run_steps.py) under
+    `rocprofv3 --pmc FETCH_SIZE` and `rocprofv3 --pmc WRITE_SIZE` -- separate passes, counters only, no tracing beside them, the program directly behind
+    `--` -- reduced as scripts/make_pmc_profile.py does: (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over the launches of each kernel (gfx950 counts half of
+    the coalesced streaming reads: MI355X_MICROARCH.md; calibrated in profiles/r01_v1_pmc_traffic.json).  world > 1: the child runs the rank's partition ALONE
+    on its device, its mailboxes connected to themselves (`--loopback`: every wait of the exchange inside the kernels is then satisfied by the rank's own
+    stores -- counter collection serialises the kernels of a device, so two ranks waiting for each other could not be profiled -- the ghosts receive
+    meaningless velocities, the launches walk the same tables and move the same bytes).  ({}, reason) when it cannot be done here."""
     import csv, glob, shutil, subprocess, tempfile
-    if mesh != "2km" or launches_per_substep != 1 or world != 1:
-        return None, "not the single-GPU one-launch-per-sub-step workload"
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
-        return None, "this run is itself under a profiler"
+        return {}, "this run is itself under a profiler"
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
-        return None, "rocprofv3 not found"
+        return {}, "rocprofv3 not found"
     out = tempfile.mkdtemp(prefix="nxs_pmc_", dir="/tmp")
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NXS_DYN_LIBRARY")}
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "NXS_DYN_LIBRARY", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK",
+                                                              "LOCAL_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
     env["TMPDIR"] = "/tmp"
+    child = [sys.executable, os.path.join(ROOT, "scripts", "run_steps.py"), "--mesh", mesh, "--steps", "1", "--graph", "0"]
+    if world > 1:
+        child += ["--nparts", str(world), "--rank", str(rank), "--loopback"]
+    for kv in options:
+        child += ["--opt", kv]
     vals = {}
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(out, counter)
-            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
-                   os.path.join(ROOT, "scripts", "run_steps.py"), "--mesh", mesh, "--steps", "1", "--graph", "0"]
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--"] + child
             subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s, check=True)
-            acc, n = 0.0, 0
+            acc, n = {k: 0.0 for k in kernels}, {k: 0 for k in kernels}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if r["Counter_Name"] == counter and r["Kernel_Name"].split("(")[0].replace("void ", "").startswith(kernel):
-                        acc += float(r["Counter_Value"]); n += 1
-            if n == 0:
-                return None, f"no {counter} rows for {kernel}"
-            vals[counter] = (acc / n, n)
-        b = int((2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024)
-        return b, (f"MEASURED IN THIS RUN: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate, counters only) over one step of "
-                   f"the same mesh (scripts/run_steps.py --mesh {mesh} --steps 1 --graph 0), (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged over "
-                   f"{vals['FETCH_SIZE'][1]} launches of {kernel} (gfx950 reports half of the coalesced streaming reads, "
-                   f"MI355X_MICROARCH.md); FETCH_SIZE {vals['FETCH_SIZE'][0]:.1f} KiB, WRITE_SIZE {vals['WRITE_SIZE'][0]:.1f} KiB per launch")
-    except Exception as e:  # noqa: BLE001 -- the bench line survives without it (the committed profile is replayed instead)
-        return None, "failed: " + repr(e)[:200]
+                    if r["Counter_Name"] != counter:
+                        continue
+                    name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                    for k in kernels:
+                        if name.startswith(k):
+                            acc[k] += float(r["Counter_Value"]); n[k] += 1
+            vals[counter] = {k: (acc[k] / n[k], n[k]) for k in kernels if n[k] > 0}
+        got = {k: int((2.0 * vals["FETCH_SIZE"][k][0] + vals["WRITE_SIZE"][k][0]) * 1024) for k in kernels if k in vals["FETCH_SIZE"] and k in vals["WRITE_SIZE"]}
+        if not got:
+            return {}, "no counter rows for " + ", ".join(kernels)
+        detail = "; ".join(f"{k}: FETCH_SIZE {vals['FETCH_SIZE'][k][0]:.1f} KiB, WRITE_SIZE {vals['WRITE_SIZE'][k][0]:.1f} KiB over {vals['FETCH_SIZE'][k][1]} launches" for k in got)
+        return got, ("MEASURED IN THIS RUN: two child passes `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate, counters only) over one step of "
+                     + ("the same mesh" if world == 1 else f"rank {rank}'s partition of {world}, alone on the device with its mailboxes looped back to itself")
+                     + f" (`{' '.join(child[1:])}`), (2 x FETCH_SIZE + WRITE_SIZE) KiB averaged per kernel (gfx950 reports half of the coalesced streaming reads, "
+                     f"MI355X_MICROARCH.md); {detail}")
+    except Exception as e:  # noqa: BLE001 -- the bench line survives without it
+        return {}, "failed: " + repr(e)[:200]
     finally:
         shutil.rmtree(out, ignore_errors=True)
 
@@ -183,6 +192,9 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     tm = fe.timing()
+    traffic = fe.traffic_model()
+    step_ms = fe.step_times()
+    options_used = dict(getattr(fe, "_bench_options", {}))
     crash = fe.checkFieldsFast()
     fe.close()
     phases = {k: tm[k] for k in ("prep_ms", "substeps_ms", "smoother_ms", "update_ms", "total_ms")}
@@ -193,7 +205,8 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
         crash = int(t[-1])
     else:
         phases_max = dict(phases)
-    return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash, transport=transport, halo=halo, phases_max=phases_max)  # (f: rank-local fields)
+    return dict(gm=gm, p=p, lm=lm, f=f, dt=dt, timing=tm, crash=crash, transport=transport, halo=halo, phases_max=phases_max,  # (f: rank-local fields)
+                traffic=traffic, step_ms=step_ms, options=options_used)
 
 
 def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
@@ -209,9 +222,11 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
                 "separate": (3, 0, ", separate push/pull kernels")}
 
     def select(name):
-        fe.set_option("resident_wide", 1 if own_device else 0)   # (only matters where one workgroup per CU covers a rank's partition)
-        fe.set_option("resident_overlap", 1 if name == "resident_overlap" else 0)
-        fe.set_option("fused", variants[name][0]); fe.set_option("halo_fused", variants[name][1])
+        opts = {"resident_wide": 1 if own_device else 0,   # (only matters where one workgroup per CU covers a rank's partition)
+                "resident_overlap": 1 if name == "resident_overlap" else 0, "fused": variants[name][0], "halo_fused": variants[name][1]}
+        for k in ("resident_wide", "resident_overlap", "fused", "halo_fused"):
+            fe.set_option(k, opts[k])
+        fe._bench_options = opts   # (what the PMC child run of this partition is given)
 
     force = os.environ.get("NXS_HALO_VARIANT")
     if force in variants:
@@ -269,6 +284,7 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
     fe.set_option("fused", 3)
     if "separate" not in results:
         fe.set_option("halo_fused", 0)
+        fe._bench_options = {"fused": 3, "halo_fused": 0}
         return (", separate push/pull kernels (its own check step failed on some rank: see stderr)",
                 {"kept_variant": "separate", "forced": False, "variants": report, "note": "the check step of the separate kernels failed on some rank"})
     ref = results["separate"][0]
@@ -739,24 +755,52 @@ def main():
     S = p.substeps
     value = gm.num_elements * S * args.steps / res["dt"]
 
-    # roofline of the dominant kernel(s): the sub-step loop (sigma/damage + assembly + nodal solve)
-    launches_per_substep = max(tm["substep_launches"] // S, 1)
-    # one launch of the dominant kernel advances D sub-steps (1: k_substep_fused; 2: k_substep_pair; S: the resident loop): everything below is PER LAUNCH --
-    # SURVEY 8d's algorithmic bytes per sub-step x D over the event-timed duration of one launch (what rocprofv3's kernel statistics list per call)
-    D_launch = max(S // max(tm["substep_launches"], 1), 1) if tm["substep_launches"] <= S else 1
-    kernel_name = "k_substep_resident" if tm["substep_launches"] == 1 else "k_substep_pair" if (D_launch == 2 and world == 1) else "k_substep_multi" if D_launch > 1 else "k_substep_fused"
-    substep_ms = tm["substeps_ms"] / S * D_launch           # HIP events on the kernel's stream, avg over timed steps: one launch (group)
-    bytes_per_substep = (BYTES_PER_ELEMENT * lm.num_elements + BYTES_PER_NODE * lm.num_nodes) * D_launch
-    achieved = bytes_per_substep / (substep_ms * 1e-3) / 1e9
-    traffic_profile, profile_file = pmc_traffic(args.mesh, launches_per_substep, world, kernel_name)
-    traffic, traffic_source = (None, "skipped (--no-live-pmc)") if (args.no_live_pmc or rank != 0) else pmc_traffic_live(args.mesh, launches_per_substep, world, kernel=kernel_name)
+    # ---- roofline of the dominant kernel (the sub-step loop) and of the once-per-step kernels.  Everything is PER LAUNCH: the bytes the launch must move,
+    # from the patch tables it walks (nxs_dyn_get_traffic_model), over the HIP-event time of the launch on the library's stream.
+    tr = res["traffic"]
+    kernel_name = tr["substep_kernel_name"]
+    D_launch = max(int(tr["substeps_per_launch"]), 1)
+    n_launches = max(S // D_launch, 1)                                   # launches of the dominant kernel per step
+    loop_ms = tm["substeps_ms"] - tm.get("ring_flush_ms", 0.0)           # the sub-step launches alone (the deferred mesh move is timed apart)
+    launch_ms = loop_ms / n_launches
+    def rate(nbytes, ms):
+        return nbytes / (ms * 1e-3) / 1e9 if (nbytes and ms and ms > 0) else None
+    def frac(r):
+        return r / HBM_PEAK_GBS if r is not None else None
+    achieved = rate(tr["substep_scheme_bytes"], launch_ms)
+    want = [kernel_name.split(" ")[0]] + (["k_move_ring"] if tr["move_ring_slots"] else []) + {3: ["k_prep_fused"], 2: ["k_prep_elements", "k_prep_nodes"], 1: ["k_prep_elements", "k_prep_nodes"]}.get(tr["prep_kernel"], []) + ["k_update"]
+    if args.no_live_pmc or rank != 0:
+        counted, traffic_source = {}, "skipped (--no-live-pmc)" if args.no_live_pmc else "rank 0 measures"
+    else:
+        counted, traffic_source = pmc_traffic_live(args.mesh, world, rank, want, options=[f"{k}={v}" for k, v in res["options"].items()])
+    traffic = counted.get(want[0])
     traffic_live = traffic is not None
-    if not traffic_live:   # replay of the committed profile, labelled as such
-        why = traffic_source
-        traffic, traffic_source = traffic_profile, (
-            (profile_file + " -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; REPLAYED here, not measured in this run ("
-             + why + ")") if profile_file else None)
-    achieved_counter = traffic / (substep_ms * 1e-3) / 1e9 if traffic else None
+    traffic_profile, profile_file = pmc_traffic(args.mesh, world, want[0])
+    if not traffic_live and traffic_profile:   # replay of the committed profile, labelled as such
+        traffic, traffic_source = traffic_profile, (profile_file + " -- rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, committed; REPLAYED here, not "
+                                                    "measured in this run (" + str(traffic_source) + ")")
+    achieved_counter = rate(traffic, launch_ms)
+    def kernel_row(name, scheme, unique, ms, what):
+        c = counted.get(name)
+        return {"what": what, "bytes_per_launch": scheme, "unique_bytes_per_launch": unique, "avg_ms_per_launch": ms, "achieved": rate(scheme, ms), "frac": frac(rate(scheme, ms)),
+                "traffic": c, "achieved_counter": rate(c, ms), "frac_counter": frac(rate(c, ms))}
+    other = {}
+    if tr["move_ring_slots"]:
+        other["k_move_ring"] = kernel_row("k_move_ring", tr["move_ring_bytes"], tr["move_ring_bytes"], tm.get("ring_flush_ms", 0.0),
+                                          f"the deferred mesh move M_UM / M_UT += dt * M_VT (FE.cpp:10543-10550) of {tr['move_ring_slots']} sub-steps from the velocity ring, once per step")
+    if tr["prep_kernel"] == 3:
+        other["k_prep_fused"] = kernel_row("k_prep_fused", tr["prep_scheme_bytes"], tr["prep_unique_bytes"], tm["prep_ms"], "prep elements + prep nodes (FE.cpp:10235-10416), one launch per step")
+    elif tr["prep_kernel"] in (1, 2):
+        c = (counted.get("k_prep_elements") or 0) + (counted.get("k_prep_nodes") or 0)
+        other["k_prep_elements + k_prep_nodes"] = kernel_row("", tr["prep_scheme_bytes"], tr["prep_unique_bytes"], tm["prep_ms"], "prep elements, prep nodes (FE.cpp:10235-10416), two launches per step")
+        if c:
+            other["k_prep_elements + k_prep_nodes"].update(traffic=c, achieved_counter=rate(c, tm["prep_ms"]), frac_counter=frac(rate(c, tm["prep_ms"])))
+    other["k_update"] = kernel_row("k_update", tr["update_bytes"], tr["update_bytes"], tm["update_ms"], "update() (FE.cpp:3946-4131), one launch per step")
+    sm = sorted(float(x) for x in res["step_ms"])
+    step_stats = None
+    if sm:
+        step_stats = {"n": len(sm), "median": sm[len(sm) // 2] if len(sm) % 2 else 0.5 * (sm[len(sm) // 2 - 1] + sm[len(sm) // 2]), "mean": sum(sm) / len(sm), "min": sm[0], "max": sm[-1],
+                      "what": "device time of every timed step of rank 0 (HIP events on the library's stream around each nxs_dyn_step; the steps stay asynchronous)"}
     out = {
         "metric": "element-updates/sec per dynamics step",
         "value": value,
@@ -781,29 +825,42 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_substep_resident (ONE launch per step: the fused sub-step loop, patches waiting for their neighbours only)" if tm["substep_launches"] == 1
-                      else "k_substep_pair (TWO sub-steps per launch on patches with two rings of halo, the stresses between them in registers: stress/damage + assembly + nodal solve, twice)" if kernel_name == "k_substep_pair"
-                      else f"k_substep_multi ({S // max(tm['substep_launches'], 1)} sub-steps per launch on patches with that many rings of halo)" if tm["substep_launches"] < S
-                      else "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve + mesh move)" if launches_per_substep == 1 else f"sub-step loop ({launches_per_substep} launches per sub-step incl. halo pack/unpack)",
+            "kernel": {"k_substep_resident": "k_substep_resident (ONE launch per step: the fused sub-step loop, patches waiting for their neighbours only)",
+                       "k_substep_resident_big": "k_substep_resident_big (ONE launch per step, one large patch per CU: four elements and two own nodes per thread)",
+                       "k_substep_pair": "k_substep_pair (TWO sub-steps per launch on patches with two rings of halo, the stresses between them in registers: stress/damage + assembly + nodal solve, twice)",
+                       "k_substep_multi": f"k_substep_multi ({D_launch} sub-steps per launch on patches with that many rings of halo)",
+                       "k_substep_fused": "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve" + (" + updateGhosts through the peer mailboxes" if tr["halo_in_kernel"] else "") + ")",
+                       }.get(kernel_name, kernel_name),
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
+            "frac": frac(achieved),
             "traffic": traffic,
             "traffic_source": traffic_source,
             "traffic_measured_in_this_run": traffic_live,
-            "traffic_committed_profile": {"bytes": traffic_profile, "file": profile_file} if traffic_profile else None,
             "achieved_counter": achieved_counter,
-            "frac_counter": achieved_counter / HBM_PEAK_GBS if achieved_counter else None,
+            "frac_counter": frac(achieved_counter),
             "substeps_per_launch": D_launch,
-            "bytes_per_launch_group": bytes_per_substep,
-            "avg_ms_per_launch_group": substep_ms,
-            "note": "rank-0 partition. achieved / frac = ALGORITHMIC bytes (SURVEY 8d: 172 B/element + 217 B/node per sub-step, x the sub-steps one launch "
-                    "advances) over the event-timed launch; the kernel moves fewer bytes than that model (shape coefficients rebuilt from staged coordinates, "
-                    "M_UM / M_UT streamed once per step, and with two sub-steps per launch stress, damage, element constants and nodal inputs cross HBM once "
-                    "per TWO sub-steps), so frac can exceed what HBM delivers (~6.3 TB/s = 0.79) and even 1: achieved_counter / frac_counter = the counter "
-                    "bytes over the same time is the real HBM rate",
+            "launches_per_step": n_launches,
+            "bytes_per_launch": tr["substep_scheme_bytes"],
+            "reread_bytes_per_launch": tr["substep_reread_bytes"],
+            "unique_bytes_per_launch": tr["substep_unique_bytes"],
+            "frac_unique": frac(rate(tr["substep_unique_bytes"], launch_ms)),
+            "avg_ms_per_launch": launch_ms,
+            "algorithmic_equivalent": {"bytes_per_launch": tr["survey_model_bytes"], "achieved": rate(tr["survey_model_bytes"], launch_ms), "frac": frac(rate(tr["survey_model_bytes"], launch_ms)),
+                                       "note": "SURVEY 8d's model, 172 B per element + 217 B per node per sub-step x the sub-steps one launch advances: what a kernel that streamed every "
+                                               "array of the reference loop once per sub-step would move.  NOT a bandwidth of this kernel (shape coefficients rebuilt on chip, M_UM / M_UT "
+                                               "once per step, state and records once per TWO sub-steps): it may exceed the peak; kept for comparison with rounds 1-3"},
+            "other_kernels": other,
+            "note": "rank-0 partition, per launch.  bytes_per_launch (-> achieved, frac) = what this blocking scheme MUST move: every list a workgroup reads, once, plus what "
+                    "it writes, summed over the workgroups from the patch tables (halo rings counted; nxs_dyn_get_traffic_model, include/nxs_dyn.h) -- a lower bound of the "
+                    "launch's HBM traffic, so frac <= frac_counter <= ~0.79 (a copy reaches ~6.3 TB/s).  traffic (-> achieved_counter, frac_counter) = counted bytes (2 x FETCH_SIZE "
+                    "+ WRITE_SIZE) of the same launch: bytes_per_launch + what of reread_bytes_per_launch (a workgroup's second read of a record) the L2 did not serve.  "
+                    "unique_bytes_per_launch (frac_unique) = every array entry once: the floor of ANY kernel with this many sub-steps per launch.  avg_ms_per_launch = HIP events "
+                    "around the sub-step graph on the library's stream / launches (the deferred mesh move is timed apart: other_kernels.k_move_ring)",
         },
+        "step_times_ms": step_stats,
+        "value_at_median_step": (gm.num_elements * S / (step_stats["median"] * 1e-3)) if (step_stats and world == 1) else None,
         "phases_ms": res["phases_max"],   # (N > 1: the slowest rank's figure for every phase)
         "phases_ms_rank0": {k: tm[k] for k in ("prep_ms", "substeps_ms", "smoother_ms", "update_ms", "total_ms")},
         "fields_ok": res["crash"] == 0,

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define NXS_DYN_ABI_VERSION 1
+#define NXS_DYN_ABI_VERSION 2
 
 /* error codes */
 #define NXS_OK 0
@@ -194,6 +194,8 @@ typedef struct nxs_dyn_timing {
     double total_ms;       /* "dynamics" */
     int32_t substep_launches; /* kernel launches inside substeps_ms */
     int32_t steps_averaged;   /* number of steps the averages cover */
+    double ring_flush_ms;     /* (ABI 2) the part of substeps_ms spent in the step's last k_move_ring -- the deferred M_UM / M_UT += dt * M_VT of FE.cpp:10543-10550
+                               * for all the sub-steps the velocity ring holds; 0 where the mesh move is inside the sub-step kernel */
 } nxs_dyn_timing;
 
 typedef struct nxs_dyn_handle nxs_dyn_handle;
@@ -289,6 +291,37 @@ NXS_API int nxs_dyn_check_regridding(nxs_dyn_handle *h, double *min_angle, int32
 NXS_API int nxs_dyn_check_fields_fast(nxs_dyn_handle *h, int32_t *crash_local);
 
 NXS_API int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t);
+/* Device time [ms] of every single nxs_dyn_step since the last "timing_reset" (HIP events on the handle's stream, steps stay asynchronous; at most 4096
+ * are kept): ms[0 .. min(*count, capacity)) are filled, *count = steps recorded.  SURVEY 8d quotes the metric on the MEDIAN step. */
+NXS_API int nxs_dyn_get_step_times(nxs_dyn_handle *h, double *ms, int32_t capacity, int32_t *count);
+
+/* The bytes the kernels of the LAST step had to move, per launch, computed on the host from the tables the launches really walk (the patch
+ * lists of nxs_dyn_set_mesh) -- the roofline model bench.py prices the event-timed launches with (SURVEY 8d asks for algorithmic bytes per
+ * launch; with temporal blocking its per-sub-step figure is no longer a lower bound, this one is):
+ *   *_scheme_bytes  every list a workgroup reads, once, plus what it writes, summed over the workgroups of one launch: the halo rings of the
+ *                   blocking scheme count (several workgroups must read them), a workgroup's SECOND read of a record does not
+ *   *_reread_bytes  those second reads (the caches may or may not serve them: the hardware counters say)
+ *   *_unique_bytes  every array entry the launch touches, once: the floor of ANY kernel that advances this many sub-steps per launch
+ * so unique <= scheme <= scheme + reread, and counted HBM traffic (rocprofv3 --pmc) should land between scheme and scheme + reread. */
+enum { NXS_KERNEL_NONE = 0, NXS_KERNEL_PER_LOOP = 1 /* k_sigma_* + k_solve_move */, NXS_KERNEL_FUSED = 2 /* k_substep_fused */,
+       NXS_KERNEL_MULTI = 3 /* k_substep_multi */, NXS_KERNEL_PAIR = 4 /* k_substep_pair */, NXS_KERNEL_RESIDENT = 5 /* k_substep_resident */,
+       NXS_KERNEL_RESIDENT_BIG = 6 /* k_substep_resident_big */ };
+enum { NXS_PREP_NONE = 0, NXS_PREP_FULL = 1 /* k_prep_elements + k_prep_nodes with the work arrays */, NXS_PREP_LEAN = 2 /* the same, records only */,
+       NXS_PREP_FUSED = 3 /* k_prep_fused */ };
+typedef struct nxs_dyn_traffic {
+    int32_t substep_kernel;          /* NXS_KERNEL_*: the kernel the sub-step loop of the last step ran on */
+    int32_t substeps_per_launch;     /* sub-steps one launch of it advances (the resident kernels: all of them) */
+    int32_t halo_in_kernel;          /* != 0: the launch also performs updateGhosts through the device-direct mailboxes */
+    int32_t prep_kernel;             /* NXS_PREP_* */
+    double substep_scheme_bytes, substep_reread_bytes, substep_unique_bytes;   /* per launch of the sub-step kernel */
+    double survey_model_bytes;       /* SURVEY 8d's 172 B per element + 217 B per node, x substeps_per_launch (the "algorithmic equivalent") */
+    int32_t move_ring_slots;         /* velocity slots one k_move_ring launch applies (0: the mesh move is inside the sub-step kernel) */
+    int32_t reserved0;
+    double move_ring_bytes;          /* per k_move_ring launch */
+    double prep_scheme_bytes, prep_unique_bytes;   /* per step: the prep kernel(s) */
+    double update_bytes;             /* per step: k_update */
+} nxs_dyn_traffic;
+NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
 /* Options (none changes a bit of the results; the tests assert that):
  *   "prepare"      1 = build NOW what the first step would build lazily (tables of the exchange inside the kernels, of the resident loop): hosts that
  *                  run several ranks of one process on ONE device call it before their start barrier (building frees device memory, which waits for the

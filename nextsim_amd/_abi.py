@@ -140,7 +140,14 @@ class IceDiag(C.Structure):
 class Timing(C.Structure):
     _fields_ = [("prep_ms", C.c_double), ("substeps_ms", C.c_double), ("smoother_ms", C.c_double),
                 ("update_ms", C.c_double), ("total_ms", C.c_double),
-                ("substep_launches", C.c_int32), ("steps_averaged", C.c_int32)]
+                ("substep_launches", C.c_int32), ("steps_averaged", C.c_int32), ("ring_flush_ms", C.c_double)]
+
+
+class Traffic(C.Structure):   # nxs_dyn_traffic
+    _fields_ = [("substep_kernel", C.c_int32), ("substeps_per_launch", C.c_int32), ("halo_in_kernel", C.c_int32), ("prep_kernel", C.c_int32),
+                ("substep_scheme_bytes", C.c_double), ("substep_reread_bytes", C.c_double), ("substep_unique_bytes", C.c_double),
+                ("survey_model_bytes", C.c_double), ("move_ring_slots", C.c_int32), ("reserved0", C.c_int32), ("move_ring_bytes", C.c_double),
+                ("prep_scheme_bytes", C.c_double), ("prep_unique_bytes", C.c_double), ("update_bytes", C.c_double)]
 
 
 # ---- numpy helpers --------------------------------------------------------------------------

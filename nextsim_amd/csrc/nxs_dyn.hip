@@ -199,11 +199,20 @@ struct nxs_dyn_handle {
     // (its elapsed times added to the sums) when it is about to be reused or when timing is read
     static constexpr int NSETS = 8;
     hipEvent_t ev[NSETS][5] = {};
+    hipEvent_t ev_flush[NSETS][2] = {};   // around the last k_move_ring of a step (launched behind the sub-step graph so that it can be timed on its own)
+    bool flush_timed[NSETS] = {};
+    double sum_flush_ms = 0.;
     bool set_pending[NSETS] = {};
     int set_next = 0;
     double sum_ms[4] = {0, 0, 0, 0};
     int sum_steps = 0;
+    std::vector<float> step_ms;  // device time of every step since "timing_reset" (at most 4096 kept): nxs_dyn_get_step_times
     hipEvent_t *cur = nullptr;  // event set of the step being enqueued (nullptr: untimed)
+    // sums over the patch tables (filled where the tables are uploaded) and what the last step launched: nxs_dyn_get_traffic_model
+    struct PatchSums { double nP = 0, M = 0, E = 0, O = 0, W = 0; } sums1;                       // DevPatches: staged nodes, elements, own nodes, written elements
+    struct PatchSums2 { double nP = 0, W = 0; std::vector<double> N, E; } sums2;                 // DevPatches2: nodes per level N_0..N_D, elements per level E_1..E_D
+    int last_kernel = 0, last_ring_count = 0, last_prep = 0;                                     // NXS_KERNEL_* / slots of the last k_move_ring / NXS_PREP_*
+    bool last_deferred = false, last_halo_in_kernel = false;
     nxs_dyn_timing timing{};
     int timing_enabled = 1;
     std::string err;
@@ -331,11 +340,20 @@ int check_params(nxs_dyn_handle *h, const nxs_dyn_params *p) {
 int harvest(nxs_dyn_handle *h, int k) {
     if (!h->set_pending[k]) return NXS_OK;
     HIPCHK(h, hipEventSynchronize(h->ev[k][4]));
+    float whole = 0.f;
     for (int i = 0; i < 4; ++i) {
         float ms = 0.f;
         HIPCHK(h, hipEventElapsedTime(&ms, h->ev[k][i], h->ev[k][i + 1]));
         h->sum_ms[i] += ms;
+        whole += ms;
     }
+    if (h->flush_timed[k]) {
+        float ms = 0.f;
+        HIPCHK(h, hipEventElapsedTime(&ms, h->ev_flush[k][0], h->ev_flush[k][1]));
+        h->sum_flush_ms += ms;
+        h->flush_timed[k] = false;
+    }
+    if (h->step_ms.size() < 4096) h->step_ms.push_back(whole);
     h->sum_steps++;
     h->set_pending[k] = false;
     return NXS_OK;
@@ -547,6 +565,7 @@ int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) tr
     CREATE_CHK(hipSetDevice(device));
     CREATE_CHK(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto &set : h->ev) for (auto &ev : set) CREATE_CHK(hipEventCreate(&ev));
+    for (auto &set : h->ev_flush) for (auto &ev : set) CREATE_CHK(hipEventCreate(&ev));
     CREATE_CHK(hipMalloc((void **)&h->d_regrid, sizeof(RegridPartial)));
     CREATE_CHK(hipMalloc((void **)&h->d_crash, sizeof(int)));
 #undef CREATE_CHK
@@ -587,6 +606,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) try {
     if (h->d_crash) (void)hipFree(h->d_crash);
     if (h->d_dp) (void)hipFree(h->d_dp);
     for (auto &set : h->ev) for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
+    for (auto &set : h->ev_flush) for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NXS_OK;
@@ -720,6 +740,8 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         for (int k = 0; k < nxs_dyn_handle::NSETS; ++k) { int rc = harvest(h, k); if (rc) return rc; }
         for (double &x : h->sum_ms) x = 0.;
         h->sum_steps = 0;
+        h->sum_flush_ms = 0.;
+        h->step_ms.clear();
         return NXS_OK;
     }
     return fail(h, NXS_ERR_INVALID, "unknown option '%s'", key);
@@ -1868,6 +1890,20 @@ int run_substeps(nxs_dyn_handle *h) {
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,
                            h->d_recv_seg, h->d_recv_off, h->ipc, 0., 0, h->d_recv_procs, 1);
     };
+    // the LAST flush of the step is launched behind the graph (one plain launch per step) so that its own events can bracket it
+    const int final_count = (deferred && !resident) ? S - K * ((S - 1) / K) : 0;
+    auto flush = [&](int s, int pending) {
+        if (s == S - 1 && final_count > 0) return;   // (launched below)
+        LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, (double *)nullptr);
+    };
+    auto final_flush = [&]() -> int {
+        if (final_count <= 0) return NXS_OK;
+        const int k = h->cur ? (int)((h->cur - &h->ev[0][0]) / 5) : -1;
+        if (k >= 0) HIPCHK(h, hipEventRecord(h->ev_flush[k][0], h->stream));
+        LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (S - final_count + 1) % R, final_count, move_dt, vt_back);
+        if (k >= 0) { HIPCHK(h, hipEventRecord(h->ev_flush[k][1], h->stream)); h->flush_timed[k] = true; }
+        return NXS_OK;
+    };
     auto loop = [&]() -> int {
         if (resident) {  // the whole loop in one launch; the element state is read from and written back to S4a (each record by its one writer)
             HIPCHK(h, hipMemsetAsync(h->res.flag, 0, (32 * (size_t)h->dpch.nP + NXS_RES_MAXS + 32) * sizeof(unsigned int), h->stream));
@@ -1899,18 +1935,18 @@ int run_substeps(nxs_dyn_handle *h) {
                 s += D - 1;
                 pending += D;
                 if (pending == K || s == S - 1) {
-                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, s == S - 1 ? vt_back : (double *)nullptr);
+                    flush(s, pending);
                     pending = 0;
                 }
                 continue;
             }
             if (halo_in_kernel) {
                 launch_fused(h, s, 0., 1, s > 0);
-                const bool flush = deferred && (pending + 1 == K || s == S - 1);
-                if (flush || s == S - 1) pull_latest(h->ring.slot[(s + 1) % R]);  // the newest ghosts, for the move / the end of the step
-                if (flush) {
+                const bool flush_now = deferred && (pending + 1 == K || s == S - 1);
+                if (flush_now || s == S - 1) pull_latest(h->ring.slot[(s + 1) % R]);  // the newest ghosts, for the move / the end of the step
+                if (flush_now) {
                     ++pending;
-                    LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, s == S - 1 ? vt_back : (double *)nullptr);
+                    flush(s, pending);
                     pending = 0;
                 } else if (deferred) ++pending;
                 continue;
@@ -1923,7 +1959,7 @@ int run_substeps(nxs_dyn_handle *h) {
                 if (rc) return rc;
             }
             if (deferred && (++pending == K || s == S - 1)) {
-                LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, s == S - 1 ? vt_back : (double *)nullptr);
+                flush(s, pending);
                 pending = 0;
             }
         }
@@ -1941,7 +1977,10 @@ int run_substeps(nxs_dyn_handle *h) {
     if (!fused) ensure_arrays(h);
     if (fused) h->sig_loc = records_end_odd ? 0 : 1;
     h->timing.substep_launches = resident ? 1 : pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
-    if (!h->use_graph || (mr && !device_halo)) return loop();
+    h->last_kernel = resident ? (h->res_big ? NXS_KERNEL_RESIDENT_BIG : NXS_KERNEL_RESIDENT) : pair ? (h->pair_kernel ? NXS_KERNEL_PAIR : NXS_KERNEL_MULTI) : fused ? NXS_KERNEL_FUSED : NXS_KERNEL_PER_LOOP;
+    h->last_deferred = deferred; h->last_halo_in_kernel = halo_in_kernel || (resident && mr);
+    h->last_ring_count = (deferred && !resident) ? K : 0;
+    if (!h->use_graph || (mr && !device_halo)) { int lrc = loop(); return lrc ? lrc : final_flush(); }
     if (!h->graph_valid) {
         release_graph(h);
         hipGraph_t g = nullptr;
@@ -1955,7 +1994,7 @@ int run_substeps(nxs_dyn_handle *h) {
         h->graph_valid = true;
     }
     HIPCHK(h, hipGraphLaunch(h->substep_graph, h->stream));
-    return NXS_OK;
+    return final_flush();
 }
 
 int ready(nxs_dyn_handle *h) {
@@ -1991,10 +2030,13 @@ int explicit_solve(nxs_dyn_handle *h) {
         HIPCHK(h, hipMemsetAsync(h->dw.open_blk, 0, (size_t)nblocks(m.Nn), h->stream));  // (k_prep_elements' first lines)
         hipLaunchKernelGGL(k_prep_fused, dim3(h->dpch.nP), dim3(512), h->prep_lds, h->stream, m, h->dpch, h->ds, h->dw, h->dp);
         HIPCHK(h, hipGetLastError());
+        h->last_prep = NXS_PREP_FUSED;
     } else if (eff_fused(h) != 0 && !h->work_arrays) {
         LAUNCH(h, k_prep_elements<true>, m.Ne, m, h->ds, h->dw, h->dp);
         LAUNCH(h, k_prep_nodes<true>, m.Nn, m, h->ds, h->dw, h->dp);
+        h->last_prep = NXS_PREP_LEAN;
     } else {
+        h->last_prep = NXS_PREP_FULL;
         LAUNCH(h, k_prep_elements<false>, m.Ne, m, h->ds, h->dw, h->dp);
         LAUNCH(h, k_prep_nodes<false>, m.Nn, m, h->ds, h->dw, h->dp);
     }
@@ -2157,10 +2199,100 @@ int nxs_dyn_get_timing(nxs_dyn_handle *h, nxs_dyn_timing *t) try {
     h->timing.prep_ms = h->sum_ms[0] / n; h->timing.substeps_ms = h->sum_ms[1] / n;
     h->timing.smoother_ms = h->sum_ms[2] / n; h->timing.update_ms = h->sum_ms[3] / n;
     h->timing.total_ms = (h->sum_ms[0] + h->sum_ms[1] + h->sum_ms[2] + h->sum_ms[3]) / n;
+    h->timing.ring_flush_ms = h->sum_flush_ms / n;
     h->timing.steps_averaged = h->sum_steps;
     *t = h->timing;
     return NXS_OK;
 } catch (...) { return dyn_caught(h, "nxs_dyn_get_timing"); }
+
+int nxs_dyn_get_step_times(nxs_dyn_handle *h, double *ms, int32_t capacity, int32_t *count) try {
+    if (!h || !count || capacity < 0 || (capacity > 0 && !ms)) return NXS_ERR_INVALID;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int k = 0; k < nxs_dyn_handle::NSETS; ++k) { int rc = harvest(h, k); if (rc) return rc; }
+    const int n = (int)std::min<size_t>(h->step_ms.size(), (size_t)capacity);
+    for (int i = 0; i < n; ++i) ms[i] = h->step_ms[i];
+    *count = (int32_t)h->step_ms.size();
+    return NXS_OK;
+} catch (...) { return dyn_caught(h, "nxs_dyn_get_step_times"); }
+
+// The bytes the last step's kernels had to move (see include/nxs_dyn.h).  Every term below names the array it prices and is the width of the
+// access in the kernel text (nxs_dyn_kernels.inl); `fanw` = the fan entries a node loads up front (eight; longer fans are rare).
+int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
+    if (!h || !t) return NXS_ERR_INVALID;
+    if (!h->have_mesh) return fail(h, NXS_ERR_STATE, "get_traffic_model before set_mesh");
+    std::memset(t, 0, sizeof *t);
+    const double Ne = h->dm.Ne, Nn = h->dm.Nn, S = h->dp.substeps;
+    const bool young = h->dp.young_cat != 0, bbm = h->dp.dynamics_type == NXS_DYN_BBM;
+    t->substep_kernel = h->last_kernel;
+    t->halo_in_kernel = h->last_halo_in_kernel ? 1 : 0;
+    t->prep_kernel = h->last_prep;
+    const double node_in = 1. /*nflags*/ + 80. /*nrec*/;
+    const auto &s1 = h->sums1;
+    const auto &s2 = h->sums2;
+    switch (h->last_kernel) {
+    case NXS_KERNEL_PAIR: if (s2.N.size() == 3 && s2.E.size() == 2) {
+        const double fanw = 2. * std::min(h->dpch2.Wp, 8);
+        const double N0 = s2.N[0], N1 = s2.N[1], N2 = s2.N[2], E1 = s2.E[0], E2 = s2.E[1];
+        t->substeps_per_launch = 2;
+        t->substep_scheme_bytes = s2.nP * 20. /*ncnt, ecnt*/ + N2 * (4. /*pnodes*/ + 16. /*VT*/ + 16. /*xy*/) + E2 * (4. /*pelem*/ + 8. /*ptri*/ + 32. /*S in*/ + 48. /*erec*/)
+                                  + N1 * (node_in + fanw) + s2.W * 32. /*S out*/ + N0 * 2. * 16. /*two velocity slots*/;
+        t->substep_reread_bytes = E1 * 48. /*erec again*/ + N0 * (node_in + fanw);
+        t->substep_unique_bytes = Ne * (12. + 32. + 48. + 32.) + Nn * (4. + 16. + 16. + node_in + fanw + 32.);
+    } break;
+    case NXS_KERNEL_MULTI: if (!s2.N.empty() && s2.E.size() + 1 == s2.N.size()) {
+        const int D = (int)s2.E.size();
+        const double fanw = 2. * std::min(h->dpch2.Wp, 8), shape = h->dw.srec ? 48. : 0., xy = h->dw.srec ? 0. : 16.;
+        t->substeps_per_launch = D;
+        t->substep_scheme_bytes = s2.nP * 4. * (2 * D + 1) + s2.N[D] * (4. + 16. + xy) + s2.E[D - 1] * (12. + 32. + 48. + shape) + s2.N[D - 1] * (node_in + fanw)
+                                  + s2.W * 32. + s2.N[0] * D * 16.;
+        for (int k = 1; k < D; ++k) t->substep_reread_bytes += s2.E[D - 1 - k] * (48. + shape) + s2.N[D - 1 - k] * (node_in + fanw);
+        t->substep_unique_bytes = Ne * (12. + 32. + 48. + shape + 32.) + Nn * (4. + 16. + xy + node_in + fanw + D * 16.);
+    } break;
+    case NXS_KERNEL_FUSED: {
+        const double fanw = 2. * std::min(h->dpch.Wp, 8), move = h->last_deferred || h->dp.dynamics_type == NXS_DYN_MEVP ? 0. : 64. /*M_UM, M_UT read and written*/;
+        t->substeps_per_launch = 1;
+        t->substep_scheme_bytes = s1.nP * 12. + s1.M * (4. + 16. + 16.) + s1.E * (8. /*pet*/ + 32. + 48.) + s1.O * (node_in + fanw + 16. /*VT out*/ + move) + s1.W * 32.;
+        t->substep_unique_bytes = Ne * (8. + 32. + 48. + 32.) + Nn * (4. + 16. + 16.) + (double)h->dm.No * (node_in + fanw + 16. + move);
+    } break;
+    case NXS_KERNEL_RESIDENT: case NXS_KERNEL_RESIDENT_BIG: {
+        // once per step: indices, state in and out, element constants, nodal inputs, coordinates, M_UM / M_UT; per sub-step: the own nodes' velocity to the
+        // exchange buffer and the halo nodes' velocity back (the big kernel also re-reads the element constants and nodal inputs every sub-step, from L2)
+        const double fanw = 2. * std::min(h->dpch.Wp, 8);
+        const bool big = h->last_kernel == NXS_KERNEL_RESIDENT_BIG;
+        t->substeps_per_launch = (int)S;
+        t->substep_scheme_bytes = s1.M * (4. + 16. + 16.) + s1.E * (12. + 32. + 48.) + s1.O * (node_in + fanw + 64.) + s1.W * 32. + S * (s1.O * 16. + (s1.M - s1.O) * 16.);
+        t->substep_reread_bytes = big ? (S - 1.) * (s1.E * 48. + s1.O * 80.) : 0.;
+        t->substep_unique_bytes = Ne * (12. + 32. + 48. + 32.) + Nn * (4. + 16. + 16.) + (double)h->dm.No * (node_in + fanw + 64. + S * 16.);
+    } break;
+    case NXS_KERNEL_PER_LOOP:
+        t->substeps_per_launch = 1;   // two launches: k_sigma_* (13 B indices + flags, state in and out, constants, shape coefficients, corner forces out) + k_solve_move
+        t->substep_scheme_bytes = t->substep_unique_bytes = Ne * (13. + (bbm ? 64. : 48.) + 48. + 48. + 48.) + Nn * 32. + (double)h->dm.No * (4. * h->dm.W + 48. * 3. + 90. + 16. + 64.);
+        break;
+    default: break;
+    }
+    t->survey_model_bytes = (172. * Ne + 217. * Nn) * std::max(t->substeps_per_launch, 1);
+    t->move_ring_slots = h->last_ring_count;
+    if (h->last_ring_count > 0) t->move_ring_bytes = Nn * (1. /*nflags*/ + 32. /*UM, UT in*/ + 32. /*out*/ + 16. * h->last_ring_count /*the slots*/ + 16. /*M_VT back, last flush*/);
+    {   // prep: per element 9 state fields (5 without the young category) + cohesion and healing time by the writer, out: delta_x, surface, 48-byte record;
+        // per node x0, y0, UM, ssh in; VT, wind, ocean, lat, flags in; xy, tau_a, node_mass, VTM, 80-byte record out
+        const double efields = (young ? 9. : 5.) * 8., ewrite = 16. + (bbm ? 16. : 8.) + 48. + (h->dw.srec ? 48. : 0.);
+        const double nstage = 4. + 40., nin = 1. + 16. + 16. + 8. + 16., nout = 16. + 16. + 8. + 16. + 80.;
+        if (h->last_prep == NXS_PREP_FUSED) {
+            const double rows = 2. * (std::min(h->dpch.Wp, 8) + std::min(h->dpch.W1, 10));
+            t->prep_scheme_bytes = s1.M * nstage + s1.E * (12. + efields) + s1.W * ewrite + s1.O * (rows + nin + nout);
+            t->prep_unique_bytes = Nn * (nstage + rows + nin + nout) + Ne * (12. + efields + ewrite);
+        } else if (h->last_prep == NXS_PREP_LEAN || h->last_prep == NXS_PREP_FULL) {
+            // two kernels: the elements gather their corners' x0, y0, UM, ssh (40 B per node, once in the unique count, three times in the scheme) and leave a
+            // 64-byte record + drag x area per element that every corner node gathers again
+            const double full = h->last_prep == NXS_PREP_FULL ? 104. + 48. : 0.;
+            t->prep_scheme_bytes = Ne * (13. + 3. * 40. + efields + ewrite + 64. + 8. + full) + Nn * (4. * (h->dm.W + h->dm.W1) + nin + nout + 32.) + Ne * 3. * (64. + 8.);
+            t->prep_unique_bytes = Ne * (13. + efields + ewrite + 64. + 8. + full + 64. + 8.) + Nn * (40. + 4. * (h->dm.W + h->dm.W1) + nin + nout + 32.);
+        }
+    }
+    // update(): flags, corners, area in and out, six fields (+ three young) in and out, the stress record in and out, D_del out; the corners' x0, y0, UM gathered
+    t->update_bytes = Ne * (1. + 12. + 16. + (young ? 9. : 6.) * 16. + 64. + 8.) + Nn * 32.;
+    return NXS_OK;
+} catch (...) { return dyn_caught(h, "nxs_dyn_get_traffic_model"); }
 
 int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f) try {
     int rc;

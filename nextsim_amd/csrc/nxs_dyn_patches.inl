@@ -40,6 +40,16 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
         for (int i = 0; i <= D; ++i) fprintf(stderr, " %.3f", sn[i] / std::max(m.Nn, 1));
         fprintf(stderr, "\n");
     }
+    {   // sums over the tables, for nxs_dyn_get_traffic_model
+        auto &S2 = h->sums2;
+        S2 = nxs_dyn_handle::PatchSums2{};
+        S2.nP = hp.nP; S2.N.assign(D + 1, 0.); S2.E.assign(D, 0.);
+        for (int q = 0; q < hp.nP; ++q) {
+            for (int i = 0; i <= D; ++i) S2.N[i] += hp.ncnt[(size_t)q * (D + 1) + i];
+            for (int i = 0; i < D; ++i) S2.E[i] += hp.ecnt[(size_t)q * D + i];
+            for (int l = 0; l < hp.ecnt[(size_t)q * D]; ++l) S2.W += hp.pelem[(size_t)q * hp.EDmax + l] >= 0 ? 1. : 0.;
+        }
+    }
     DevPatches2 &d = h->dpch2;
     d.nP = hp.nP; d.D = D; d.NDmax = hp.NDmax; d.NSmax = hp.NSmax; d.EDmax = hp.EDmax; d.ESmax = hp.ESmax; d.Wp = hp.Wp;
     int rc;
@@ -64,6 +74,15 @@ int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
     free_pool(h->res_allocs);  // (the resident loop's tables describe the patches that go now)
     h->res = DevResident{};
     h->res_ready = false; h->res_failed = false;
+    {   // sums over the tables, for nxs_dyn_get_traffic_model
+        auto &S1 = h->sums1;
+        S1 = nxs_dyn_handle::PatchSums{};
+        S1.nP = hp.nP;
+        for (int q = 0; q < hp.nP; ++q) {
+            S1.M += hp.node_cnt[q]; S1.E += hp.elem_cnt[q]; S1.O += hp.own_cnt[q];
+            for (int l = 0; l < hp.elem_cnt[q]; ++l) S1.W += hp.pelem[(size_t)q * hp.Emax + l] >= 0 ? 1. : 0.;
+        }
+    }
     DevPatches &d = h->dpch;
     d = DevPatches{};
     if (hp.Mmax > 1024) return fail(h, NXS_ERR_INVALID, "a patch stages %d nodes (at most 1024: choose smaller patches)", hp.Mmax);

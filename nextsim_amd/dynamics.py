@@ -79,6 +79,9 @@ def load_library():
     L.nxs_dyn_check_regridding.argtypes = [H, P(C.c_double), P(C.c_int32), P(C.c_int32)]
     L.nxs_dyn_check_fields_fast.argtypes = [H, P(C.c_int32)]
     L.nxs_dyn_get_timing.argtypes = [H, P(_abi.Timing)]
+    L.nxs_dyn_get_step_times.argtypes = [H, _abi.c_double_p, C.c_int32, P(C.c_int32)]
+    L.nxs_dyn_get_traffic_model.argtypes = [H, P(_abi.Traffic)]
+    L.nxs_dyn_physical_constants.argtypes = [P(C.c_double), C.c_int32]
     L.nxs_dyn_set_option.argtypes = [H, C.c_char_p, C.c_int64]
     L.nxs_dyn_debug_array.argtypes = [H, C.c_char_p, _abi.c_double_p, C.c_int64]
     L.nxs_dyn_get_branch_trace.argtypes = [H, C.POINTER(C.c_uint64), C.c_int64]
@@ -91,7 +94,7 @@ def load_library():
         if name not in ("nxs_dyn_last_error",):
             getattr(L, name).restype = C.c_int
     L.nxs_dyn_last_error.restype = C.c_char_p
-    if L.nxs_dyn_abi_version() != 1:
+    if L.nxs_dyn_abi_version() != 2:
         raise NxsError(-1, "libnxsdyn.so ABI version mismatch")
     _LIB = L
     return L
@@ -109,7 +112,7 @@ EXPORTS = (
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_set_forcing_pair", "nxs_dyn_set_forcing_time",
     "nxs_dyn_get_diag", "nxs_dyn_ice_diagnostics", "nxs_dyn_step",
     "nxs_dyn_explicit_solve", "nxs_dyn_update", "nxs_dyn_synchronize", "nxs_dyn_step_host",
-    "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_set_option",
+    "nxs_dyn_check_regridding", "nxs_dyn_check_fields_fast", "nxs_dyn_get_timing", "nxs_dyn_get_step_times", "nxs_dyn_get_traffic_model", "nxs_dyn_set_option",
     "nxs_dyn_debug_array", "nxs_dyn_get_branch_trace", "nxs_mesh_connectivity", "nxs_mesh_element_connectivity", "nxs_calc_cohesion",
 )
 INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_mesh_to_grid_device", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
@@ -271,6 +274,25 @@ class FiniteElementDynamics:
             self.L.nxs_dyn_set_halo(self.h, C.byref(_abi.halo_struct(lm)))
         return good
 
+    def ipc_loopback(self) -> bool:
+        """Profiling aid: the device-direct mailboxes of this handle connected to THEMSELVES, so that a rank's partition can be stepped alone on a device
+        with the exchange inside its kernels (every flag a kernel waits for is raised by the rank's own launches).  Rocprofv3's counter collection serialises
+        the kernels of a device: two ranks whose kernels wait for each other cannot be profiled together, a looped-back rank can.  The ghosts receive
+        meaningless velocities (results are NOT the model's); the launches walk the same tables and move the same bytes.  False when the partition's lists do
+        not allow it (fewer send than receive neighbours, a send segment longer than everything received)."""
+        lm = self.lm
+        ns, nr = len(lm.send_procs), len(lm.recv_procs)
+        tr = int(lm.recv_offsets[-1]) if nr else 0
+        seg = np.diff(lm.send_offsets) if ns else np.zeros(0, int)
+        if ns == 0 or ns < nr or (seg > tr).any():
+            return False
+        blob = C.create_string_buffer(IPC_BLOB_BYTES)
+        self._chk(self.L.nxs_dyn_ipc_export(self.h, blob))
+        bbuf = C.create_string_buffer(blob.raw * ns, IPC_BLOB_BYTES * ns)
+        a_off = np.zeros(ns, np.int32); a_tot = np.full(ns, tr, np.int32); a_slot = (np.arange(ns) % nr).astype(np.int32)
+        self._chk(self.L.nxs_dyn_ipc_connect(self.h, bbuf, _abi.iptr(a_off), _abi.iptr(a_tot), _abi.iptr(a_slot)))
+        return True
+
     @staticmethod
     def comm_unique_id() -> bytes:
         L = load_library()
@@ -387,3 +409,24 @@ class FiniteElementDynamics:
         t = _abi.Timing()
         self._chk(self.L.nxs_dyn_get_timing(self.h, C.byref(t)))
         return {k: getattr(t, k) for k, _ in _abi.Timing._fields_}
+
+    def step_times(self) -> np.ndarray:
+        """Device milliseconds of every step since the last "timing_reset" (nxs_dyn_get_step_times)."""
+        n = C.c_int32()
+        self._chk(self.L.nxs_dyn_get_step_times(self.h, None, 0, C.byref(n)))
+        out = np.zeros(max(n.value, 1), np.float64)
+        self._chk(self.L.nxs_dyn_get_step_times(self.h, _abi.dptr(out), n.value, C.byref(n)))
+        return out[:n.value]
+
+    KERNEL_NAMES = {0: "none", 1: "k_sigma + k_solve_move", 2: "k_substep_fused", 3: "k_substep_multi", 4: "k_substep_pair",
+                    5: "k_substep_resident", 6: "k_substep_resident_big"}
+    PREP_NAMES = {0: "none", 1: "k_prep_elements + k_prep_nodes (work arrays)", 2: "k_prep_elements + k_prep_nodes", 3: "k_prep_fused"}
+
+    def traffic_model(self) -> dict:
+        """Bytes per launch the kernels of the last step had to move (nxs_dyn_get_traffic_model; include/nxs_dyn.h says what each figure counts)."""
+        t = _abi.Traffic()
+        self._chk(self.L.nxs_dyn_get_traffic_model(self.h, C.byref(t)))
+        d = {k: getattr(t, k) for k, _ in _abi.Traffic._fields_ if k != "reserved0"}
+        d["substep_kernel_name"] = self.KERNEL_NAMES.get(t.substep_kernel, "?")
+        d["prep_kernel_name"] = self.PREP_NAMES.get(t.prep_kernel, "?")
+        return d

@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     L = dynamics.load_library()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.nxs_dyn_abi_version() == 1
+    assert L.nxs_dyn_abi_version() == 2
     itext = open(os.path.join(ROOT, "include", "nxs_interp.h")).read()
     ideclared = set(re.findall(r"NXS_INTERP_API\s+(?:const\s+char\s*\*|int)\s*(nxs_\w+)\s*\(", itext))
     assert ideclared == set(dynamics.INTERP_EXPORTS)
@@ -39,10 +39,10 @@ def test_ctypes_layouts_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
     structs = {"nxs_dyn_params": _abi.Params, "nxs_dyn_mesh": _abi.Mesh, "nxs_dyn_halo": _abi.Halo,
                "nxs_dyn_state": _abi.State, "nxs_dyn_forcing": _abi.Forcing, "nxs_dyn_diag": _abi.Diag,
-               "nxs_dyn_timing": _abi.Timing}
+               "nxs_dyn_timing": _abi.Timing, "nxs_dyn_traffic": _abi.Traffic}
     probes = [("nxs_dyn_params", "regrid_angle"), ("nxs_dyn_params", "young"), ("nxs_dyn_mesh", "nc_width"),
               ("nxs_dyn_mesh", "neumann_flags"), ("nxs_dyn_halo", "recv_index"), ("nxs_dyn_state", "drag_ui_young"),
-              ("nxs_dyn_state", "conc_young"), ("nxs_dyn_timing", "substep_launches")]
+              ("nxs_dyn_state", "conc_young"), ("nxs_dyn_timing", "substep_launches"), ("nxs_dyn_traffic", "move_ring_bytes"), ("nxs_dyn_traffic", "update_bytes")]
     body = "".join(f'printf("%zu\\n", sizeof({s}));' for s in structs)
     body += "".join(f'printf("%zu\\n", offsetof({s}, {f}));' for s, f in probes)
     src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "nxs_dyn.h"\nint main(void){{{body}return 0;}}\n')
