@@ -2234,10 +2234,10 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
         const double fanw = 2. * std::min(h->dpch2.Wp, 8);
         const double N0 = s2.N[0], N1 = s2.N[1], N2 = s2.N[2], E1 = s2.E[0], E2 = s2.E[1];
         t->substeps_per_launch = 2;
-        t->substep_scheme_bytes = s2.nP * 20. /*ncnt, ecnt*/ + N2 * (4. /*pnodes*/ + 16. /*VT*/ + 16. /*xy*/) + E2 * (4. /*pelem*/ + 8. /*ptri*/ + 32. /*S in*/ + 48. /*erec*/)
+        t->substep_scheme_bytes = s2.nP * 20. /*ncnt, ecnt*/ + N2 * (4. /*pnodes*/ + 16. /*VT*/ + 16. /*xy*/) + E2 * (8. /*pet*/ + 32. /*S in*/ + 48. /*erec*/)
                                   + N1 * (node_in + fanw) + s2.W * 32. /*S out*/ + N0 * 2. * 16. /*two velocity slots*/;
         t->substep_reread_bytes = E1 * 48. /*erec again*/ + N0 * (node_in + fanw);
-        t->substep_unique_bytes = Ne * (12. + 32. + 48. + 32.) + Nn * (4. + 16. + 16. + node_in + fanw + 32.);
+        t->substep_unique_bytes = Ne * (8. + 32. + 48. + 32.) + Nn * (4. + 16. + 16. + node_in + fanw + 32.);
     } break;
     case NXS_KERNEL_MULTI: if (!s2.N.empty() && s2.E.size() + 1 == s2.N.size()) {
         const int D = (int)s2.E.size();

@@ -88,6 +88,7 @@ struct DevPatches2 {
     const unsigned short *pfan;   // [nP][Wp][NSmax] fan of every solved node, ascending element id: (element slot << 3 | ghost << 2 | corner)
     const unsigned short *pnbr;   // [nP][W2][NSmax] NodalConnectivity row of every node of N_(D-1) in patch-local slots, bamg order (Q8), 0xFFFF pad;
     int W2;                       //                 NULL when a row leaves its patch (then the smoother runs sweep by sweep)
+    const int2 *pet;              // [nP][EDmax] {pelem, the three corner slots in 10 bits each}: what k_substep_pair reads (8 bytes per element instead of 12; NDmax <= 1024), else NULL
     int own_is_block;             // the own nodes of patch q are the nodes [256 q, 256 q + 256): k_prep_nodes' open-water flag of that block applies
 };
 struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
@@ -1473,8 +1474,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const int *ncnt = pp.ncnt + (size_t)blk * 3, *ecnt = pp.ecnt + (size_t)blk * 2;
     const int nO = ncnt[0], nN1 = ncnt[1], nN2 = ncnt[2], nE1 = ecnt[0], nE2 = ecnt[1];
     const int *pn = pp.pnodes + (size_t)blk * NDm;
-    const int *pe = pp.pelem + (size_t)blk * EDm;
-    const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * EDm;
+    const int2 *pet = pp.pet + (size_t)blk * EDm;   // {element, corner slots in ten bits each}: 8 bytes per element (as k_substep_fused)
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
     constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
@@ -1485,7 +1485,11 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         eraw[r] = 0; tr[r] = make_ushort4(0, 0, 0, 0);
-        if (t + r * T < EDm) { eraw[r] = pe[t + r * T]; tr[r] = pt[t + r * T]; }
+        if (t + r * T < EDm) {
+            const int2 et = pet[t + r * T];
+            eraw[r] = et.x;
+            tr[r] = make_ushort4((unsigned short)(et.y & 1023), (unsigned short)((et.y >> 10) & 1023), (unsigned short)((et.y >> 20) & 1023), 0);
+        }
     }
     auto stage = [&](const int i, const int g) {
         lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
@@ -1586,13 +1590,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;  // (read again by sub-step 1: no streaming hint)
             r0 = q[0]; r1 = q[1]; r2 = q[2];
         }
-        if (r == 0) __syncthreads();  // staged velocities / coordinates visible
+        if (r == 0) { __syncthreads(); NXS_STAMP(1); }  // staged velocities / coordinates visible
         if (active) {
             double sig[3] = {a.x, a.y, c2.x}, damage = c2.y;
             update_element(l, tr[r], sig, damage, r0, r1, r2);
             if (r < 2) { ks[r][0] = sig[0]; ks[r][1] = sig[1]; ks[r][2] = sig[2]; ks[r][3] = damage; }
         }
     }
+    NXS_STAMP(5);
     // ---- sub-step 0: nodes N_1 (two rounds)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -1601,7 +1606,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const int n = r == 0 ? my_node : my_node2;
         NodeIn in{};
         if (active) in = load_node(i, n);
-        if (r == 0) __syncthreads();  // corner forces of sub-step 0 visible
+        if (r == 0) { __syncthreads(); NXS_STAMP(6); }  // corner forces of sub-step 0 visible
         if (active) {
             double u1, v1;
             solve_node(i, in, u1, v1);
@@ -1636,12 +1641,14 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             if (NT_S) { __builtin_nontemporal_store(a, S); __builtin_nontemporal_store(c2, S + 1); } else { S[0] = a; S[1] = c2; }
         }
     }
+    NXS_STAMP(7);
     // ---- sub-step 1: the own nodes
     {
         const bool active = t < nO;
         NodeIn in{};
         if (active) in = load_node(t, my_node);
         __syncthreads();  // corner forces of sub-step 1 visible
+        NXS_STAMP(3);
         if (active) {
             double u1, v1;
             solve_node(t, in, u1, v1);

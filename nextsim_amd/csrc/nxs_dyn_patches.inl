@@ -59,6 +59,17 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
     if ((rc = dev_upload(h, h->pair_allocs, &d.pelem, hp.pelem))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.ptri, hp.ptri))) return rc;
     if ((rc = dev_upload(h, h->pair_allocs, &d.pfan, hp.pfan))) return rc;
+    d.pet = nullptr;
+    if (plan.pair_kernel) {   // {element, corner slots in ten bits each}: 8 bytes per element instead of 12 (pair_kernel_fits: at most 1024 staged nodes)
+        std::vector<int> pet(2 * hp.pelem.size());
+        for (size_t i = 0; i < hp.pelem.size(); ++i) {
+            pet[2 * i] = hp.pelem[i];
+            pet[2 * i + 1] = (int)hp.ptri[4 * i] | ((int)hp.ptri[4 * i + 1] << 10) | ((int)hp.ptri[4 * i + 2] << 20);
+        }
+        const int *dpet = nullptr;
+        if ((rc = dev_upload(h, h->pair_allocs, &dpet, pet))) return rc;
+        d.pet = reinterpret_cast<const int2 *>(dpet);
+    }
     // NodalConnectivity rows in patch-local slots, for D smoother sweeps per launch (k_smooth_multi)
     d.W2 = m.W2;
     d.pnbr = nullptr;

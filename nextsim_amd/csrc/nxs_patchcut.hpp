@@ -552,7 +552,7 @@ inline size_t multi_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax 
 // k_substep_pair (two sub-steps per launch, the stresses between them in registers): staged nodes and corner forces only; its 512-thread block
 // takes the elements of the first sub-step in three rounds, those of the second and the nodes of the first in two, the own nodes in one
 inline size_t pair_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 2) * sizeof(double); }
-inline bool pair_kernel_fits(const HostPatches2 &x, int own_max) { return x.D == 2 && x.EDmax <= 3 * 512 && x.ESmax <= 2 * 512 && x.NSmax <= 2 * 512 && own_max <= 512; }
+inline bool pair_kernel_fits(const HostPatches2 &x, int own_max) { return x.D == 2 && x.EDmax <= 3 * 512 && x.ESmax <= 2 * 512 && x.NSmax <= 2 * 512 && own_max <= 512 && x.NDmax <= 1024 /*corner slots travel in ten bits*/; }
 
 // n2n: [W2][Nn] neighbour rows (bamg order), n2n_cnt: [Nn]
 inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_nodes, int D, bool single_round_only, int cus,

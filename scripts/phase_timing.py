@@ -34,6 +34,13 @@ if a.pair:  # k_substep_pair (the last launch of the step): start, end of sub-st
     for f0 in np.linspace(0.05, 0.95, 10):
         x = k0 + f0 * (k1 - k0)
         print(f"  at {100 * f0:3.0f} % of the span: {((t[:, 0] <= x) & (t[:, 2] > x)).sum():4d} workgroups running")
+    # the phases of a workgroup (thread 0's clock): stamps 0 start, 1 staged (barrier), 5 elements of sub-step 0 done, 6 their forces visible (barrier; the loads of the
+    # first round of nodes were issued in front of it), 2 nodes of sub-step 0 done + barrier, 7 elements of sub-step 1 done, 3 barrier, 4 end
+    full = fe.debug_array("phase_times").reshape(8192, 8)
+    full = full[full[:, 0] > 0][:, [0, 1, 5, 6, 2, 7, 3, 4]]
+    d = np.diff(full, axis=1) * 10e-3
+    for nm, col in zip(("index hop + staging (to barrier 1)", "elements E_2, three rounds", "node loads + barrier 2", "solve N_1, two rounds (+ barrier 3)", "elements E_1, two rounds", "node loads + barrier 4", "solve the own nodes"), d.T):
+        print(f"  {nm:42s} mean {col.mean():6.2f} us   p10 {np.percentile(col, 10):6.2f}   p90 {np.percentile(col, 90):6.2f}")
     fe.close(); sys.exit(0)
 if a.prep:  # k_prep_fused: start, nodes staged + barrier, elements done, barrier, nodes done
     t = fe.debug_array("phase_times_prep").reshape(8192, 8)[:, :5]
