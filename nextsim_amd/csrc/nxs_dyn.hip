@@ -39,6 +39,7 @@
 #include "nxs_dyn.h"
 #include "nxs_guard.hpp"
 #include "nxs_patchcut.hpp"
+#include "nxs_resident_registry.hpp"
 
 #include "nxs_dyn_kernels.inl"
 
@@ -73,6 +74,7 @@ static_assert(NXS_CUT_BLOCK == BLOCK && NXS_CUT_T256_MAXP == NXS_T256_MAXP && NX
 
 struct nxs_dyn_handle {
     int device = 0;
+    std::string reg_key;    // the device's name in the registry of resident grids (its PCI bus id): nxs_resident_registry.hpp
     hipStream_t stream = nullptr;
     nxs_dyn_params params{};
     DevParams dp{};
@@ -125,6 +127,11 @@ struct nxs_dyn_handle {
     std::vector<double> h_x0, h_y0;
     std::vector<void *> patch_allocs;
     std::vector<void *> mesh_allocs, state_allocs;
+    // Device memory that a rebuild INSIDE a step lets go of is parked here and freed by the next call that is outside a step (set_mesh, set_params,
+    // set_option, put_state, destroy): a hipFree synchronises the whole device, and where ranks share one (tests, rehearsals, two MPI ranks per GPU) a
+    // neighbour rank's kernel may already be spinning for this rank's next launch -- the free would wait for it, the launch for the free.
+    std::vector<void *> retired;
+    bool in_step = false;
     // halo
     bool have_halo = false;
     int rank = 0, nranks = 1;
@@ -166,6 +173,7 @@ struct nxs_dyn_handle {
     size_t res_lds = 0;
     double *d_vt3 = nullptr;
     double *d_icediag = nullptr;           // [Ne][NXS_ICE_DIAG_FIELDS] rows of nxs_dyn_ice_diagnostics (state pool: goes with the mesh)
+    double *d_icediag_soa = nullptr;       // [NXS_ICE_DIAG_FIELDS][Ne] the same per field, made when the host asks for its vectors
     double *smooth_second = nullptr;       // the ring slot that equals M_VT after the sub-step loop (the smoother's second buffer), or NULL
     int sig_loc = 0;                       // where M_sigma / M_damage are current: 0 = the state arrays, 1 = the records in S4a (left there by
                                            // the fused sub-step loop; k_update works on them, the arrays follow on demand: ensure_arrays)
@@ -225,6 +233,7 @@ inline int eff_fused(const nxs_dyn_handle *h) { return h->trace_branches ? 0 : h
 int build_halo_fused(nxs_dyn_handle *h);  // (defined with the launch logic below)
 int build_resident(nxs_dyn_handle *h);
 void resident_registry_release(const nxs_dyn_handle *h);
+void release_resident(nxs_dyn_handle *h);
 bool multi_rank(const nxs_dyn_handle *h);
 
 int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
@@ -274,6 +283,20 @@ void free_pool(std::vector<void *> &pool) {
     for (void *p : pool) (void)hipFree(p);
     pool.clear();
 }
+// the same for a pool of a live handle: parked while a step is being enqueued (see nxs_dyn_handle::retired)
+void drop_pool(nxs_dyn_handle *h, std::vector<void *> &pool) {
+    if (!h->in_step) { free_pool(pool); return; }
+    h->retired.insert(h->retired.end(), pool.begin(), pool.end());
+    pool.clear();
+}
+void flush_retired(nxs_dyn_handle *h) {
+    if (!h->retired.empty() && !h->in_step) { (void)hipSetDevice(h->device); free_pool(h->retired); }
+}
+struct StepScope {  // marks "a step is being enqueued" for the length of an entry point
+    nxs_dyn_handle *h; bool was;
+    explicit StepScope(nxs_dyn_handle *hh) : h(hh), was(hh->in_step) { h->in_step = true; }
+    ~StepScope() { h->in_step = was; }
+};
 
 inline int nblocks(int n) { return n > 0 ? (n + BLOCK - 1) / BLOCK : 1; }
 
@@ -478,15 +501,15 @@ void release_graph(nxs_dyn_handle *h) {
 
 // the resident loop's tables and its claim on the device's workgroup slots
 void release_resident(nxs_dyn_handle *h) {
-    free_pool(h->res_allocs);
+    drop_pool(h, h->res_allocs);
     h->res = DevResident{};
     h->d_vt3 = nullptr;
     h->res_ready = false; h->res_failed = false;
     resident_registry_release(h);
 }
 
-// A resident launch that gave up (k_substep_resident's bounded waits) leaves the state of the step's start behind; whoever hands state to
-// the host next says so.  Call with the stream synchronised.
+// A resident launch that gave up (k_substep_resident's bounded waits) leaves a mixture of the step's start and its end behind (no patch writes after
+// it has seen the error, the ones that had finished before have written); whoever hands state to the host next says so.  Call with the stream synchronised.
 int resident_error(nxs_dyn_handle *h) {
     if (!h->res_ready) return NXS_OK;
     int err = 0;
@@ -500,8 +523,8 @@ int resident_error(nxs_dyn_handle *h) {
                      : err == 6 ? "the boundary patches' publishing order stalled for 10 s (an earlier sub-step was never published: a patch of this rank is missing)"
                      : err == 7 ? "a neighbour rank's flag did not arrive within 10 s (that rank started its step late, stopped, or its launch failed)"
                                 : "unknown wait";
-    return fail(h, NXS_ERR_HIP, "the resident sub-step launch gave up (code %d): %s; M_UM, M_UT, sigma and damage were not advanced by that step -- the step is lost, "
-                                "later steps run one kernel per sub-step", err, what);
+    return fail(h, NXS_ERR_HIP, "the resident sub-step launch gave up (code %d): %s; the step is lost and M_UM, M_UT, sigma and damage are undefined (patches that had finished "
+                                "before the time-out have written their result, the others have not): put the state again before going on; later steps run one kernel per sub-step", err, what);
 }
 
 }  // namespace
@@ -569,6 +592,12 @@ int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) tr
     CREATE_CHK(hipMalloc((void **)&h->d_regrid, sizeof(RegridPartial)));
     CREATE_CHK(hipMalloc((void **)&h->d_crash, sizeof(int)));
 #undef CREATE_CHK
+    {   // the handle is now a tenant of the device, for every process that looks (nxs_resident_registry.hpp)
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, device) != hipSuccess || !bus[0]) { (void)hipGetLastError(); snprintf(bus, sizeof bus, "device%d", device); }
+        h->reg_key = bus;
+        nxs_reg::table_for(h->reg_key).add((uint64_t)(uintptr_t)h);
+    }
     derive_params(h);
     *out = h;
     return NXS_OK;
@@ -579,6 +608,8 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) try {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     release_graph(h);
+    h->in_step = false;
+    flush_retired(h);
     if (h->comm && h->rccl.CommDestroy) h->rccl.CommDestroy(h->comm);
     ipc_release(h);
     free_pool(h->mesh_allocs);
@@ -586,6 +617,7 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) try {
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
     release_resident(h);
+    if (!h->reg_key.empty()) nxs_reg::table_for(h->reg_key).remove((uint64_t)(uintptr_t)h);
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
@@ -616,6 +648,7 @@ int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p) try {
     if (!h) return NXS_ERR_INVALID;
     int rc = check_params(h, p);
     if (rc) return rc;
+    flush_retired(h);
     if (h->sig_loc) {  // the records' damage slot belongs to the OLD dynamics type
         HIPCHK(h, hipSetDevice(h->device));
         ensure_arrays(h);
@@ -628,6 +661,7 @@ int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p) try {
 
 int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
     if (!h || !key) return NXS_ERR_INVALID;
+    if (std::strcmp(key, "timing_reset") && std::strcmp(key, "timing")) flush_retired(h);   // (not from the two a caller may use between steps of a timed run)
     if (!std::strcmp(key, "graph")) { h->use_graph = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "timing")) { h->timing_enabled = value != 0; return NXS_OK; }
     if (!std::strcmp(key, "um_ring")) {
@@ -678,8 +712,8 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
                 release_graph(h);
                 h->no_big_cut = true;
                 if ((rc = upload_patches(h))) return rc;
-                h->res_failed = true;
                 if (device_halo && h->halo_fused && !h->hf_ready && (rc = build_halo_fused(h))) return rc;
+                h->res_failed = true;   // (after the rebuilds: they give a fresh cut a fresh chance, this cut was made because the resident loop cannot run)
             }
         }
         return NXS_OK;
@@ -769,6 +803,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
 
     if (h->stream) HIPCHK(h, hipStreamSynchronize(h->stream));
     release_graph(h);
+    flush_retired(h);
     free_pool(h->mesh_allocs);
     free_pool(h->state_allocs);
     free_pool(h->halo_allocs);
@@ -893,7 +928,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     DevState &s = h->ds;
     DevWork &w = h->dw;
     s = DevState{}; w = DevWork{};
-    h->d_icediag = nullptr;
+    h->d_icediag = nullptr; h->d_icediag_soa = nullptr;
     auto &P = h->state_allocs;
     const size_t n2 = 2 * (size_t)Nn, ne = Ne;
 #define A(ptr, cnt) if ((rc = dev_alloc(h, P, &(ptr), (cnt)))) return rc
@@ -1394,10 +1429,16 @@ int nxs_dyn_ice_diagnostics(nxs_dyn_handle *h, nxs_dyn_ice_diag *dg, const doubl
     hipLaunchKernelGGL(k_ice_diagnostics, dim3(nblocks(h->dm.Ne)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, h->dp.young_cat ? 1 : 0,
                        h->sig_loc ? (const double *)h->ds.S4a : (const double *)nullptr, h->d_icediag);
     HIPCHK(h, hipGetLastError());
-    if (dg) {
+    if (dg) {   // the host's vectors from a field-major copy of the rows: six contiguous transfers (a strided copy of 8-byte rows moves one row per descriptor)
         double *dst[NXS_ICE_DIAG_FIELDS] = {dg->D_conc, dg->D_thick, dg->D_snow_thick, dg->D_sigma0, dg->D_sigma1, dg->D_divergence};
-        for (int k = 0; k < NXS_ICE_DIAG_FIELDS; ++k)
-            if (dst[k]) HIPCHK(h, hipMemcpy2DAsync(dst[k], sizeof(double), h->d_icediag + k, NXS_ICE_DIAG_FIELDS * sizeof(double), sizeof(double), Ne, hipMemcpyDeviceToHost, h->stream));
+        bool any = false;
+        for (double *q : dst) any = any || q;
+        if (any) {
+            if (!h->d_icediag_soa) { int rc = dev_alloc(h, h->state_allocs, &h->d_icediag_soa, NXS_ICE_DIAG_FIELDS * Ne); if (rc) return rc; }
+            hipLaunchKernelGGL(k_icediag_soa, dim3(nblocks(h->dm.Ne)), dim3(BLOCK), 0, h->stream, h->dm.Ne, (const double *)h->d_icediag, h->d_icediag_soa);
+            for (int k = 0; k < NXS_ICE_DIAG_FIELDS; ++k)
+                if (dst[k]) HIPCHK(h, hipMemcpyAsync(dst[k], h->d_icediag_soa + (size_t)k * Ne, Ne * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        }
     }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (device_rows) *device_rows = h->d_icediag;
@@ -1623,38 +1664,21 @@ const void *resident_kernel(const nxs_dyn_handle *h, bool mr, bool ovl) {
     return p4 ? (const void *)k_substep_resident<512, true, false> : (const void *)k_substep_resident<512, false, false>;
 }
 
-// The resident launch needs every workgroup of its grid on a CU at once, and its workgroups spin: two such grids on one device whose
-// sum does not fit keep each other's missing workgroups from ever starting (both then time out).  A handle therefore claims its
-// workgroup slots per device in this registry and gives them back when its tables go; a grid that would not fit beside the ones already
-// claimed is refused up front (the step then runs one kernel per sub-step).  Handles of OTHER processes on the same device cannot be
-// seen from here: option fused = 4 remains "this process has the device to itself".
-struct ResidentRegistry {
-    std::mutex mu;
-    std::map<int, std::map<const nxs_dyn_handle *, std::pair<int, int>>> claims;  // device -> handle -> (workgroups, the device's slots for that kernel build)
-};
-ResidentRegistry g_resident_registry;
+// The resident launch needs every workgroup of its grid on a CU at once, and its workgroups spin: a handle claims its workgroup slots in the device's
+// registry before it builds the loop and gives them back when its tables go; a claim that does not fit beside what is claimed already -- by handles
+// of this process or of any other process on the device, with headroom for the co-tenants' ordinary kernels where the device is shared -- is refused
+// up front and the step runs one kernel per sub-step (nxs_resident_registry.hpp has the rule and the evidence behind it).
 void resident_registry_release(const nxs_dyn_handle *h) {
-    ResidentRegistry &R = g_resident_registry;
-    std::lock_guard<std::mutex> lk(R.mu);
-    auto it = R.claims.find(h->device);
-    if (it != R.claims.end()) it->second.erase(h);
+    if (!h->reg_key.empty()) nxs_reg::table_for(h->reg_key).release((uint64_t)(uintptr_t)h);
 }
-bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots) {
-    ResidentRegistry &R = g_resident_registry;
-    std::lock_guard<std::mutex> lk(R.mu);
-    auto &dev = R.claims[h->device];
-    dev.erase(h);
-    // fractions of the device, because the builds differ in how many of their workgroups a CU holds
-    double used = (double)workgroups / std::max(slots, 1);
-    for (const auto &kv : dev) used += (double)kv.second.first / std::max(kv.second.second, 1);
-    if (used > 1.0 + 1e-9) return false;
-    dev[h] = std::make_pair(workgroups, slots);
-    return true;
+bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots, std::string *why) {
+    if (h->reg_key.empty()) { if (why) *why = "the handle is not registered on its device"; return false; }
+    return nxs_reg::table_for(h->reg_key).claim((uint64_t)(uintptr_t)h, workgroups, slots, multi_rank(h), why);
 }
 
 // tables of the halo exchange fused into the sub-step kernel (see HaloFused)
 int build_halo_fused(nxs_dyn_handle *h) {
-    free_pool(h->hf_allocs);
+    drop_pool(h, h->hf_allocs);
     h->hf = HaloFused{};
     h->hf_ready = false;
     const int Nn = h->dm.Nn, No = h->dm.No, nP = h->dpch.nP;
@@ -1702,7 +1726,7 @@ int build_halo_fused(nxs_dyn_handle *h) {
 // before it is rebuilt (options fused / resident_wide / resident_overlap / resident_dryrun, a change of parameters, a timed-out launch).
 int build_resident(nxs_dyn_handle *h) {
     h->res_ready = false;
-    free_pool(h->res_allocs);
+    drop_pool(h, h->res_allocs);
     h->res = DevResident{};
     h->d_vt3 = nullptr;
     if (!h->hp || h->hp->nP != h->dpch.nP) return NXS_OK;
@@ -1742,7 +1766,10 @@ int build_resident(nxs_dyn_handle *h) {
     }
     // the device's other resident grids (other handles of this process: the ranks a host drives from one process, the tests): all of them
     // together must fit, or the spinning workgroups of one keep the other's from ever starting
-    if (!resident_registry_claim(h, nP, per_cu * cus)) return refuse("the device's resident workgroup slots are taken by other handles of this process");
+    {
+        std::string why;
+        if (!resident_registry_claim(h, nP, per_cu * cus, &why)) return refuse(why.c_str());
+    }
     int rc;
     DevResident &r = h->res;
     if (ovl) {
@@ -1868,8 +1895,8 @@ int run_substeps(nxs_dyn_handle *h) {
             h->no_big_cut = true;
             int rcu = upload_patches(h);
             if (rcu) return rcu;
-            h->res_failed = true;
             if (mr && !h->hf_ready) { int rc = build_halo_fused(h); if (rc) return rc; }
+            h->res_failed = true;   // (after the rebuilds, which reset it: this cut exists because the resident loop cannot run)
         }
     }
     const bool resident = res_wanted && h->res_ready && !h->res_failed;
@@ -2132,6 +2159,7 @@ int nxs_dyn_explicit_solve(nxs_dyn_handle *h) try {
     int rc = ready(h);
     if (rc) return rc;
     h->cur = nullptr;
+    StepScope scope(h);
     return explicit_solve(h);
 } catch (...) { return dyn_caught(h, "nxs_dyn_explicit_solve"); }
 
@@ -2154,6 +2182,7 @@ int nxs_dyn_step(nxs_dyn_handle *h) try {  // FE.cpp:8197-8214
     if (type == NXS_DYN_NO_MOTION) return NXS_OK;
     int k = -1;
     h->cur = nullptr;
+    StepScope scope(h);
     if (h->timing_enabled) {
         k = h->set_next;
         if ((rc = harvest(h, k))) return rc;

@@ -2069,8 +2069,11 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
         __syncthreads();
         RSTAMP(5);
     }
-    // ---- once per step: the element state and the moved mesh go back -- unless a wait timed out: then nothing of this patch is written
-    // (M_UM, M_UT, sigma and damage keep their values of the step's start; nxs_dyn_synchronize and every call that hands state to the host report it)
+    // ---- once per step: the element state and the moved mesh go back -- unless a wait of this patch timed out or the error word is already set by another
+    // patch: then nothing of THIS patch is written.  Patches that finished all their sub-steps before the time-out elsewhere have written theirs (there is no
+    // barrier over the grid), so after an error the state is a mixture of the step's start and its end: nxs_dyn_synchronize and every call that hands state
+    // to the host report the lost step, and the caller restores the state (nxs_dyn_put_state) before it goes on
+    if (t == 0 && __hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lerr = 1;
     __syncthreads();
     if (lerr) return;
     if (has_elem && writer) {
@@ -2441,7 +2444,8 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();
         RSTAMP(5);
     }
-    // ---- once per step: the element state and the moved mesh go back -- unless a wait timed out (see k_substep_resident)
+    // ---- once per step: the element state and the moved mesh go back -- unless a wait timed out here or anywhere before (see k_substep_resident)
+    if (t == 0 && __hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) lerr = 1;
     __syncthreads();
     if (lerr) return;
 #pragma unroll
@@ -2526,6 +2530,14 @@ __global__ void __launch_bounds__(BLOCK) k_ice_diagnostics(DevMesh m, DevState s
 // VT buffers; every `count` sub-steps this kernel applies the same sequence of additions
 // M_UM += dte*M_VT, M_UT += dte*M_VT (FE.cpp:10543-10550) for all nodes, owned and ghost -- same
 // operations in the same order, but UM/UT are streamed once per `count` sub-steps instead of every one.
+// the interleaved rows of k_ice_diagnostics as one array per field ([NXS_ICE_DIAG_FIELDS][Ne]): what the host's six vectors are copied from, contiguously
+__global__ void __launch_bounds__(BLOCK) k_icediag_soa(int Ne, const double *__restrict__ rows, double *__restrict__ soa) {
+    const int e = blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= Ne) return;
+#pragma unroll
+    for (int k = 0; k < NXS_ICE_DIAG_FIELDS; ++k) soa[(size_t)k * Ne + e] = rows[(size_t)e * NXS_ICE_DIAG_FIELDS + k];
+}
+
 #define NXS_MAX_RING 129
 struct VTRing { double *slot[NXS_MAX_RING]; int R; };
 

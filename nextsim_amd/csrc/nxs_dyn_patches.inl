@@ -15,7 +15,7 @@ int device_cus(const nxs_dyn_handle *h) {
 }
 
 int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_pair_kernel = false) {
-    free_pool(h->pair_allocs);
+    drop_pool(h, h->pair_allocs);
     h->dpch2 = DevPatches2{};
     h->pair_ready = false;
     const DevMesh &m = h->dm;
@@ -81,10 +81,8 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
 }
 
 int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
-    free_pool(h->patch_allocs);
-    free_pool(h->res_allocs);  // (the resident loop's tables describe the patches that go now)
-    h->res = DevResident{};
-    h->res_ready = false; h->res_failed = false;
+    drop_pool(h, h->patch_allocs);
+    release_resident(h);  // (the resident loop's tables describe the patches that go now: the tables, the second exchange buffer, the claim on the device's slots)
     {   // sums over the tables, for nxs_dyn_get_traffic_model
         auto &S1 = h->sums1;
         S1 = nxs_dyn_handle::PatchSums{};
@@ -127,10 +125,8 @@ int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
 }
 
 int upload_patches(nxs_dyn_handle *h) {
-    free_pool(h->patch_allocs);
-    free_pool(h->res_allocs);
-    h->res = DevResident{};
-    h->res_ready = false; h->res_failed = false;
+    drop_pool(h, h->patch_allocs);
+    release_resident(h);
     h->dpch = DevPatches{};
     h->fused_lds = 0;
     h->hf_ready = false;
@@ -154,7 +150,7 @@ int upload_patches(nxs_dyn_handle *h) {
 
 // Node-ring patches for the open-water smoother alone (see nxs_cut::plan_smooth_patches).
 int build_smooth_patches(nxs_dyn_handle *h, int D) {
-    free_pool(h->sm_allocs);
+    drop_pool(h, h->sm_allocs);
     h->dsm = DevPatches2{};
     h->sm_ready = false;
     const DevMesh &m = h->dm;

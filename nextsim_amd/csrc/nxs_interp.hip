@@ -268,7 +268,10 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? 0 : -1; }
+    int alloc(size_t n) {   // (a buffer that is allocated again lets go of what it held)
+        if (p) { (void)hipFree(p); p = nullptr; }
+        return hipMalloc((void **)&p, std::max<size_t>(n, 1) * sizeof(T)) == hipSuccess ? 0 : -1;
+    }
     int upload(const T *src, size_t n) {
         Tick tk(3);
         if (alloc(n)) return -1;
@@ -660,8 +663,11 @@ int regrid_connectivity(nxs_regrid *r, const double *nec_old, int32_t nec_width,
 
 }  // namespace
 
-extern "C" int nxs_regrid_create(const int32_t *index_old, const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old, int32_t device,
-                                 nxs_regrid **out) try {
+namespace {
+// want_completion == false: the context of a one-shot call that will never look outside the mesh (the conservative remapping, the nodal interpolation
+// with a default value): no completion thread is started -- nxs_regrid_destroy would only wait for work nobody asked for
+int regrid_create(const int32_t *index_old, const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old, int32_t device,
+                  nxs_regrid **out, bool want_completion) {
     if (!out) return fail(NXS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (!index_old || !x_old || !y_old) return fail(NXS_ERR_INVALID, "NULL argument");
@@ -701,7 +707,7 @@ extern "C" int nxs_regrid_create(const int32_t *index_old, const double *x_old, 
         (void)hipGetLastError();
         g_err.clear();   // (not this call's failure: the remapping reports it if it is asked for)
     }
-    try {   // bamg's convex completion on a host thread, from now on (pure host work on this context's own copies); without a thread it is made when asked for
+    if (want_completion) try {   // bamg's convex completion on a host thread, from now on (pure host work on this context's own copies); without a thread it is made when asked for
         nxs_regrid *q = r.get();
         r->completion = std::async(std::launch::async, [q, have_bnd, bnd = std::move(bnd)]() {
             std::vector<int> ix, iy;
@@ -712,6 +718,12 @@ extern "C" int nxs_regrid_create(const int32_t *index_old, const double *x_old, 
     } catch (const std::system_error &) { }
     *out = r.release();
     return NXS_OK;
+}
+}  // namespace
+
+extern "C" int nxs_regrid_create(const int32_t *index_old, const double *x_old, const double *y_old, int32_t nods_old, int32_t nels_old, int32_t device,
+                                 nxs_regrid **out) try {
+    return regrid_create(index_old, x_old, y_old, nods_old, nels_old, device, out, true);
 } catch (...) { return entry_caught("nxs_regrid_create"); }
 
 extern "C" int nxs_regrid_destroy(nxs_regrid *r) try {
@@ -788,7 +800,7 @@ extern "C" int nxs_interp_mesh_to_mesh_2d(double *data_interp, const int32_t *in
     if (M_data != nods && M_data != nels)  // InterpFromMeshToMesh2dx.cpp:39-42
         return fail(NXS_ERR_INVALID, "data provided should have either %d or %d lines (not %d)", nods, nels, M_data);
     nxs_regrid *r = nullptr;
-    if (int rc = nxs_regrid_create(index_data, x_data, y_data, nods, nels, device, &r)) return rc;
+    if (int rc = regrid_create(index_data, x_data, y_data, nods, nels, device, &r, isdefault == 0)) return rc;
     const int rc = nxs_regrid_interp_nodes(r, data_interp, data, M_data, N_data, x_interp, y_interp, N_interp, isdefault, defaultvalue, 0, num_exterior, kernel_ms);
     (void)nxs_regrid_destroy(r);
     return rc;
@@ -1024,7 +1036,7 @@ extern "C" int nxs_interp_conservative_remap(double *interp_out, const double *i
     if (!interp_out || !interp_in || !index_old || !x_old || !y_old || !index_new || !x_new || !y_new) return fail(NXS_ERR_INVALID, "NULL argument");
     if (nb_var < 1 || nods_old < 3 || nels_old < 1 || nods_new < 3 || nels_new < 1) return fail(NXS_ERR_INVALID, "bad sizes");
     nxs_regrid *r = nullptr;
-    if (int rc = nxs_regrid_create(index_old, x_old, y_old, nods_old, nels_old, device, &r)) return rc;
+    if (int rc = regrid_create(index_old, x_old, y_old, nods_old, nels_old, device, &r, false)) return rc;
     const int rc = nxs_regrid_remap_elements(r, interp_out, interp_in, nb_var, nec_old, nec_width, ec_old, index_new, x_new, y_new, nods_new, nels_new,
                                              previous_numbering, n_geom_vertices, 0, num_failed, visits, kernel_ms);
     (void)nxs_regrid_destroy(r);
