@@ -18,12 +18,15 @@ From an evolved (damaged) state even ONE step of 120 sub-steps amplifies 1 ulp t
 section 8d's "1e-8 after 10 steps" cannot hold for ANY second implementation, including the reference
 rebuilt with another libm.
 """
+import os
+
 import numpy as np
 import pytest
 
 import cases
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 STATE_KEYS = ("VT", "UM", "UT", "sigma0", "sigma1", "sigma2", "damage", "conc", "thick", "snow_thick",
               "ridge_ratio", "conc_young", "h_young", "hs_young", "conc_myi", "thick_myi")
@@ -782,6 +785,35 @@ def test_resident_loop_survives_a_remesh_a_change_of_sub_steps_and_a_second_hand
     c.set_option("fused", 4); c.step(); c.synchronize()
     assert c.timing()["substep_launches"] == 1
     a.close(); c.close()
+
+
+def test_a_resident_grid_of_another_process_is_seen():
+    """The registry of resident grids is a POSIX shared-memory table named after the device (csrc/nxs_resident_registry.hpp): while THIS process holds 511 of
+    the device's 512 resident workgroup slots, a handle of ANOTHER process that asks for the resident loop is refused up front and steps with one kernel per
+    sub-step (same results, no spinning against each other until a time-out); when this process lets go, a new process gets the loop."""
+    import subprocess
+    import sys
+    from nextsim_amd import dynamics
+    gm1, p1, g1, lms1, f1 = cases.make_case("h15600")
+    b = dynamics.FiniteElementDynamics(p1); b.set_option("fused", 4)
+    b.set_mesh(lms1[0]); b.put_state(f1[0]); b.set_forcing(f1[0]); b.step(); b.synchronize()
+    assert b.timing()["substep_launches"] == 1
+    child = r'''
+import sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import cases
+from nextsim_amd import dynamics
+gm, p, g, lms, f = cases.make_case("small")
+c = dynamics.FiniteElementDynamics(p); c.set_option("fused", 4)
+c.set_mesh(lms[0]); c.put_state(f[0]); c.set_forcing(f[0]); c.step(); c.synchronize()
+print("launches", c.timing()["substep_launches"], "crash", c.checkFieldsFast())
+c.close()
+''' % (ROOT, os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "launches 120 crash 0" in r.stdout, (r.stdout, r.stderr[-2000:])
+    b.close()
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "launches 1 crash 0" in r.stdout, (r.stdout, r.stderr[-2000:])
 
 
 def test_shuffled_numbering_still_matches_the_oracle():
