@@ -642,14 +642,18 @@ def host_description():
     return os.cpu_count() or usable, usable, model
 
 
+# nominal memory bandwidth of hosts this has run on (GB/s, all sockets): the CPU leg's bytes/s is printed beside it
+HOST_MEMORY_GBS = {"AMD EPYC 9575F 64-Core Processor": ("2 sockets x 12 channels DDR5-6000", 1152.0)}
+
+
 def cpu_baseline(kind, nsteps=1, nsteps_threaded=3):
     """The restated reference CPU path (oracle/dyn_ref.c, -O3 -march=native) on the same mesh and forcing.
     (i) one core, the serial loops (nsteps steps); (ii) the cores this process may run on (sched_getaffinity -- on a GPU box that is the
     box's CPU share, not necessarily the host's core count; both are printed): one mesh partition per thread, all threads in lock-step
-    inside the oracle library (ref_multirank_steps: pthreads, barriers, shared-memory updateGhosts -- the CPU analogue of the reference's
-    MPI run), nsteps_threaded steps after an untimed one.  The path is memory-bound and its 170 exchanges per step are barriers, so
-    more threads is not always faster: EVERY usable core is tried, and fewer (1/2, 1/4, ... down to 16) while that is faster; the best
-    is `value`, all of them are listed.
+    inside the oracle library (ref_mr_*: the CPU analogue of the reference's MPI run) -- threads kept across the steps and PINNED (physical cores
+    first, the sockets in turn), every partition's arrays allocated and first touched by its own thread (NUMA-local, like the heap of an MPI rank),
+    spin barriers; nsteps_threaded steps after an untimed one.  Thread counts: every usable logical CPU, then half of that (the physical cores of an
+    SMT-2 host), a quarter, ... while fewer is faster; the best is `value`, all of them are listed.
     kind 'port': the reference binary itself cannot be built without Boost/Gmsh/NetCDF."""
     from nextsim_amd import forcing as F, mesh as M
     from oracle import pyoracle as O
@@ -660,9 +664,10 @@ def cpu_baseline(kind, nsteps=1, nsteps_threaded=3):
         r.step()
     dt1 = time.perf_counter() - t0
     single = gm.num_elements * p.substeps * nsteps / dt1
+    del r
     host_cores, usable, model = host_description()
     out = {"value": single, "cores": 1, "seconds": dt1, "single_core_value": single, "single_seconds": dt1, "single_steps": nsteps,
-           "host_cores": host_cores, "usable_cores": usable, "cpu_model": model, "threaded_steps": 0, "thread_counts_tried": {}}
+           "host_cores": host_cores, "usable_cores": usable, "cpu_model": model, "threaded_steps": 0, "thread_counts_tried": {}, "placement": None}
     if usable > 1:
         p2, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
         g = F.global_fields(gm, p2, "arctic", C_fix, C_alea)
@@ -674,22 +679,34 @@ def cpu_baseline(kind, nsteps=1, nsteps_threaded=3):
         for cores in counts:
             lms = M.localize(gm, cores)
             ranks = [O.OracleRank(l, p2, F.localize_fields(g, l, gm.num_nodes), fast=True) for l in lms]
-            O.multirank_steps_native(ranks, 1, cores)          # (untimed: first touch of every partition's arrays by its thread)
+            ctx = O.MultirankContext(ranks, nthreads=cores, pin=True)   # (every thread copies -- first touches -- its own partition here)
+            info = ctx.info()
+            ctx.run(1)                                                   # (untimed: the work arrays are touched by their threads)
             t0 = time.perf_counter()
-            O.multirank_steps_native(ranks, nsteps_threaded, cores)
+            ctx.run(nsteps_threaded)
             dtn = time.perf_counter() - t0
+            ctx.close(copy_back=False)
             v = gm.num_elements * p.substeps * nsteps_threaded / dtn
             out["thread_counts_tried"][str(cores)] = v
-            del ranks
-            if best is not None and v < best[0]:
-                break                                           # slower with fewer threads: the larger count was the best
+            del ranks, ctx
             if best is None or v > best[0]:
-                best = (v, cores, dtn)
-            if time.perf_counter() - budget_t0 > 60.:
+                best = (v, cores, dtn, info)
+            elif v < 0.9 * best[0]:
+                break                                           # clearly slower with fewer threads: the larger count was the best
+            if time.perf_counter() - budget_t0 > 90.:
                 break
         out["threaded_steps"] = nsteps_threaded
         if best and best[0] > single:
             out.update(value=best[0], cores=best[1], seconds=best[2])
+            info = best[3]
+            out["placement"] = {"threads": info["threads"], "pinned": all(c_ >= 0 for c_ in info["cpus"]), "sockets_used": info["sockets_used"],
+                                "distinct_cpus": len(set(info["cpus"])), "first_touch": "every partition's arrays allocated and copied in by its own thread",
+                                "barrier": "sense-reversing spin barrier, 340 per step"}
+    # SURVEY 8d's 172 B per element + 217 B per node per sub-step: what the figure means as a memory rate, beside the host's nominal bandwidth
+    bytes_per_update = (BYTES_PER_ELEMENT * gm.num_elements + BYTES_PER_NODE * gm.num_nodes) / gm.num_elements
+    out["model_GBps"] = out["value"] * bytes_per_update / 1e9
+    hm = HOST_MEMORY_GBS.get(model)
+    out["host_memory"] = {"what": hm[0], "nominal_GBps": hm[1], "fraction_used_by_the_model_bytes": out["model_GBps"] / hm[1]} if hm else None
     return out
 
 
@@ -893,10 +910,12 @@ def main():
                 "host_cores": cb["host_cores"], "usable_cores": cb["usable_cores"], "cpu_model": cb["cpu_model"],
                 "sample": f"full dynamics steps ({S} sub-steps each) of the same '{args.mesh}' mesh and forcing, oracle/dyn_ref.c -O3 -march=native: "
                           f"{cb['single_steps']} step on 1 core ({cb['single_seconds']:.1f} s, single_core_value); {cb['threaded_steps']} steps (after one untimed) with one "
-                          f"mesh partition per thread in lock-step, shared-memory halo exchange, at thread counts {list(cb['thread_counts_tried'])} (this process may run on "
-                          f"{cb['usable_cores']} of the host's {cb['host_cores']} logical CPUs, {cb['cpu_model']}; every usable core is tried first, fewer while that is faster): "
+                          f"mesh partition per PINNED thread in lock-step (threads kept, partitions first touched by their threads, spin barriers, shared-memory halo exchange), at "
+                          f"thread counts {list(cb['thread_counts_tried'])} (this process may run on "
+                          f"{cb['usable_cores']} of the host's {cb['host_cores']} logical CPUs, {cb['cpu_model']}; every usable CPU is tried first, fewer while that is not slower): "
                           f"the best, {cb['cores']} thread(s), is `value` ({cb['seconds']:.1f} s)",
-                "thread_counts_tried": cb["thread_counts_tried"],
+                "thread_counts_tried": cb["thread_counts_tried"], "placement": cb["placement"],
+                "model_GBps": cb["model_GBps"], "host_memory": cb["host_memory"],
             }
         except Exception as e:  # noqa: BLE001 -- the GPU line must survive a host-side failure of the baseline leg
             out["cpu_baseline"] = {"value": None, "unit": "element-updates/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}

@@ -1191,3 +1191,336 @@ int ref_multirank_steps(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_
     free(J.sendbuf); free(J.peer_seg); free(th); free(args);
     return rc;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* The same lock-step run as a PERSISTENT context that uses the host as an MPI run of the reference would (bench.py's cpu_baseline; SURVEY 8d
+ * "(ii) all physical cores"):
+ *   - the threads live as long as the context; thread t is pinned to one CPU (pthread_setaffinity_np), physical cores before their SMT siblings and the
+ *     sockets taken in turn, so that n threads use the memory controllers of every socket;
+ *   - every partition's arrays (mesh, state, forcing, halo lists, work) are ALLOCATED AND FIRST TOUCHED BY THE THREAD THAT OWNS THE PARTITION: its pages
+ *     lie on that thread's NUMA node, like the heap of an MPI rank (in round 3 the Python main thread had touched them all: one node served 256 threads);
+ *   - the phases meet at a sense-reversing spin barrier instead of a futex one (340 meetings per step).
+ * ref_mr_run's results are bit for bit those of ref_multirank_steps (tests/test_multirank_oracle.py); ref_mr_destroy copies the state back. */
+#include <sched.h>
+#include <stdatomic.h>
+#include <stdio.h>
+
+typedef struct ref_mr_rank {
+    nxs_dyn_mesh m; nxs_dyn_state s; nxs_dyn_forcing f; nxs_dyn_halo h; ref_work *w;
+    void **owned; int n_owned, cap_owned;   /* every array this context allocated for the rank */
+} ref_mr_rank;
+
+struct ref_mr_ctx {
+    int nranks, nthreads, pin;
+    nxs_dyn_params p;
+    const nxs_dyn_mesh *const *src_m; nxs_dyn_state *const *src_s; const nxs_dyn_forcing *const *src_f; const nxs_dyn_halo *const *src_h;
+    ref_mr_rank *rk;
+    ref_mr_job job;                /* the arrays of pointers mr_thread's phases read (m, s, f, w, h, sendbuf, peer_seg) */
+    const nxs_dyn_mesh **pm; nxs_dyn_state **ps; const nxs_dyn_forcing **pf; ref_work **pw; const nxs_dyn_halo **ph;
+    pthread_t *th;
+    int *cpu_of;                   /* [nthreads] the CPU thread t is pinned to, -1: not pinned */
+    int sockets_used, physical_cores_used;
+    /* command hand-off (idle threads sleep on the condition variable; inside a run they meet at the spin barrier) */
+    pthread_mutex_t mu; pthread_cond_t cv_go, cv_done;
+    int command, generation, done, failed;   /* command: 1 = set up (copy in), 2 = run, 3 = copy back, 4 = exit */
+    int nsteps;
+    atomic_int bar_count; atomic_int bar_sense;
+};
+typedef struct ref_mr_ctx ref_mr_ctx;
+typedef struct ref_mr_targ { ref_mr_ctx *c; int tid; } ref_mr_targ;
+
+static void mr_spin_barrier(ref_mr_ctx *c, int *local_sense) {
+    const int sense = !*local_sense;
+    *local_sense = sense;
+    if (atomic_fetch_add_explicit(&c->bar_count, 1, memory_order_acq_rel) == c->nthreads - 1) {
+        atomic_store_explicit(&c->bar_count, 0, memory_order_relaxed);
+        atomic_store_explicit(&c->bar_sense, sense, memory_order_release);
+    } else {
+        int spins = 0;
+        while (atomic_load_explicit(&c->bar_sense, memory_order_acquire) != sense) {
+#if defined(__x86_64__) || defined(__i386__)
+            __builtin_ia32_pause();
+#endif
+            if (++spins > 20000) { sched_yield(); spins = 0; }   /* (more threads than CPUs: let the others run) */
+        }
+    }
+}
+
+static void *mr_own(ref_mr_rank *r, const void *src, size_t bytes) {   /* a copy made -- and so first touched -- by the calling thread */
+    if (!src) return NULL;
+    void *p = malloc(bytes ? bytes : 1);
+    if (!p) return NULL;
+    if (bytes) memcpy(p, src, bytes);
+    if (r->n_owned == r->cap_owned) {
+        const int cap = r->cap_owned ? 2 * r->cap_owned : 64;
+        void **q = (void **)realloc(r->owned, (size_t)cap * sizeof(void *));
+        if (!q) { free(p); return NULL; }
+        r->owned = q; r->cap_owned = cap;
+    }
+    r->owned[r->n_owned++] = p;
+    return p;
+}
+
+static int mr_copy_in(ref_mr_ctx *c, int r) {
+    ref_mr_rank *k = &c->rk[r];
+    const nxs_dyn_mesh *m = c->src_m[r];
+    const nxs_dyn_state *s = c->src_s[r];
+    const nxs_dyn_forcing *f = c->src_f[r];
+    const nxs_dyn_halo *h = c->src_h[r];
+    const size_t Nn = (size_t)m->num_nodes, Ne = (size_t)m->num_elements, D = sizeof(double);
+    int bad = 0;
+#define OWN(dst, src, bytes) do { (dst) = mr_own(k, (src), (bytes)); if ((src) && !(dst)) bad = 1; } while (0)
+    k->m = *m;
+    OWN(k->m.indices, m->indices, 3 * Ne * sizeof(int32_t)); OWN(k->m.ghost_nodes, m->ghost_nodes, 3 * Ne);
+    OWN(k->m.coord_x, m->coord_x, Nn * D); OWN(k->m.coord_y, m->coord_y, Nn * D); OWN(k->m.lat, m->lat, Nn * D);
+    OWN(k->m.mask_dirichlet, m->mask_dirichlet, Nn); OWN(k->m.neumann_flags, m->neumann_flags, (size_t)m->num_neumann_flags * sizeof(int32_t));
+    OWN(k->m.nodal_element_connectivity, m->nodal_element_connectivity, Nn * (size_t)m->nec_width * D);
+    OWN(k->m.nodal_connectivity, m->nodal_connectivity, Nn * (size_t)m->nc_width * D);
+    k->s = *s;
+    OWN(k->s.VT, s->VT, 2 * Nn * D); OWN(k->s.UM, s->UM, 2 * Nn * D); OWN(k->s.UT, s->UT, 2 * Nn * D);
+    OWN(k->s.conc, s->conc, Ne * D); OWN(k->s.thick, s->thick, Ne * D); OWN(k->s.snow_thick, s->snow_thick, Ne * D);
+    OWN(k->s.damage, s->damage, Ne * D); OWN(k->s.ridge_ratio, s->ridge_ratio, Ne * D);
+    for (int i = 0; i < 3; i++) OWN(k->s.sigma[i], s->sigma[i], Ne * D);
+    OWN(k->s.conc_young, s->conc_young, Ne * D); OWN(k->s.h_young, s->h_young, Ne * D); OWN(k->s.hs_young, s->hs_young, Ne * D);
+    OWN(k->s.conc_myi, s->conc_myi, Ne * D); OWN(k->s.thick_myi, s->thick_myi, Ne * D);
+    OWN(k->s.cohesion, s->cohesion, Ne * D); OWN(k->s.time_relaxation_damage, s->time_relaxation_damage, Ne * D);
+    OWN(k->s.drag_ui, s->drag_ui, Ne * D); OWN(k->s.drag_ui_young, s->drag_ui_young, Ne * D);
+    k->f = *f;
+    OWN(k->f.wind, f->wind, 2 * Nn * D); OWN(k->f.ocean, f->ocean, 2 * Nn * D); OWN(k->f.ssh, f->ssh, Nn * D); OWN(k->f.element_depth, f->element_depth, Ne * D);
+    k->h = *h;
+    const size_t ns = (size_t)h->num_send_procs, nr = (size_t)h->num_recv_procs;
+    OWN(k->h.send_procs, h->send_procs, ns * sizeof(int32_t)); OWN(k->h.send_offsets, h->send_offsets, (ns + 1) * sizeof(int32_t));
+    OWN(k->h.send_index, h->send_index, (size_t)(ns ? h->send_offsets[ns] : 0) * sizeof(int32_t));
+    OWN(k->h.recv_procs, h->recv_procs, nr * sizeof(int32_t)); OWN(k->h.recv_offsets, h->recv_offsets, (nr + 1) * sizeof(int32_t));
+    OWN(k->h.recv_index, h->recv_index, (size_t)(nr ? h->recv_offsets[nr] : 0) * sizeof(int32_t));
+#undef OWN
+    k->w = ref_work_create(m->num_nodes, m->num_elements);   /* calloc: touched by this thread at its first step */
+    if (!k->w) bad = 1;
+    {   /* the exchange buffer of the rank (what ref_multirank_steps allocates on the caller's thread) */
+        const size_t n = 2 * (size_t)(ns ? h->send_offsets[ns] : 0) + 1;
+        c->job.sendbuf[r] = (double *)malloc(n * D);
+        if (c->job.sendbuf[r]) memset(c->job.sendbuf[r], 0, n * D); else bad = 1;
+    }
+    c->pm[r] = &k->m; c->ps[r] = &k->s; c->pf[r] = &k->f; c->pw[r] = k->w; c->ph[r] = &k->h;
+    return bad;
+}
+
+static void mr_copy_back(ref_mr_ctx *c, int r) {
+    ref_mr_rank *k = &c->rk[r];
+    nxs_dyn_state *s = c->src_s[r];
+    const size_t Nn = (size_t)k->m.num_nodes, Ne = (size_t)k->m.num_elements, D = sizeof(double);
+    memcpy(s->VT, k->s.VT, 2 * Nn * D); memcpy(s->UM, k->s.UM, 2 * Nn * D); memcpy(s->UT, k->s.UT, 2 * Nn * D);
+    double *dst[] = {s->conc, s->thick, s->snow_thick, s->damage, s->ridge_ratio, s->sigma[0], s->sigma[1], s->sigma[2], s->conc_young, s->h_young, s->hs_young, s->conc_myi, s->thick_myi};
+    double *src[] = {k->s.conc, k->s.thick, k->s.snow_thick, k->s.damage, k->s.ridge_ratio, k->s.sigma[0], k->s.sigma[1], k->s.sigma[2], k->s.conc_young, k->s.h_young, k->s.hs_young, k->s.conc_myi, k->s.thick_myi};
+    for (size_t i = 0; i < sizeof dst / sizeof dst[0]; i++) memcpy(dst[i], src[i], Ne * D);
+}
+
+/* the lock-step phases of mr_thread with the spin barrier */
+#define MRC_EACH(stmt) do { for (int r = tid; r < J->nranks; r += J->nthreads) { stmt; } mr_spin_barrier(c, &sense); } while (0)
+static void mr_run_steps(ref_mr_ctx *c, int tid, int nsteps) {
+    ref_mr_job *J = &c->job;
+    const nxs_dyn_params *p = &c->p;
+    const int S = p->substeps;
+    const double dte = p->dtime_step / (double)S;
+    int sense = atomic_load_explicit(&c->bar_sense, memory_order_acquire);
+    for (int it = 0; it < nsteps; it++) {
+        if (p->dynamics_type == NXS_DYN_NO_MOTION) break;
+        if (p->dynamics_type == NXS_DYN_FREE_DRIFT) { MRC_EACH(ref_free_drift(J->m[r], p, J->s[r], J->f[r])); continue; }
+        MRC_EACH(ref_prep(J->m[r], p, J->s[r], J->f[r], J->w[r]));
+        for (int ss = 0; ss < S; ss++) {
+            MRC_EACH(ref_substep_solve(J->m[r], p, J->s[r], J->f[r], J->w[r]); mr_pack(J, r));
+            if (p->dynamics_type != NXS_DYN_MEVP) MRC_EACH(mr_unpack(J, r); ref_move_mesh(J->m[r], J->s[r], J->w[r], dte));
+            else MRC_EACH(mr_unpack(J, r));
+        }
+        if (p->dynamics_type == NXS_DYN_MEVP) MRC_EACH(ref_move_mesh(J->m[r], J->s[r], J->w[r], p->dtime_step));
+        for (int nit = 0; nit < 50; nit++) {  /* Q9 */
+            MRC_EACH(ref_smoother_sweep(J->m[r], J->s[r], J->w[r]); mr_pack(J, r));
+            MRC_EACH(mr_unpack(J, r));
+        }
+        MRC_EACH(ref_ow_tail(J->m[r], p, J->s[r], J->f[r], J->w[r]); ref_update(J->m[r], p, J->s[r], J->w[r]));
+    }
+}
+
+static void *mr_ctx_thread(void *arg_) {
+    ref_mr_targ *a = (ref_mr_targ *)arg_;
+    ref_mr_ctx *c = a->c;
+    const int tid = a->tid;
+    free(a);
+    if (c->cpu_of[tid] >= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set); CPU_SET(c->cpu_of[tid], &set);
+        if (pthread_setaffinity_np(pthread_self(), sizeof set, &set) != 0) c->cpu_of[tid] = -1;
+    }
+    int seen = 0;
+    for (;;) {
+        pthread_mutex_lock(&c->mu);
+        while (c->generation == seen) pthread_cond_wait(&c->cv_go, &c->mu);
+        seen = c->generation;
+        const int cmd = c->command, nsteps = c->nsteps;
+        pthread_mutex_unlock(&c->mu);
+        int bad = 0;
+        if (cmd == 1) { for (int r = tid; r < c->nranks; r += c->nthreads) bad |= mr_copy_in(c, r); }
+        else if (cmd == 2) mr_run_steps(c, tid, nsteps);
+        else if (cmd == 3) { for (int r = tid; r < c->nranks; r += c->nthreads) mr_copy_back(c, r); }
+        pthread_mutex_lock(&c->mu);
+        if (bad) c->failed = 1;
+        if (++c->done == c->nthreads) pthread_cond_signal(&c->cv_done);
+        pthread_mutex_unlock(&c->mu);
+        if (cmd == 4) return NULL;
+    }
+}
+
+static void mr_command(ref_mr_ctx *c, int cmd, int nsteps) {
+    pthread_mutex_lock(&c->mu);
+    c->command = cmd; c->nsteps = nsteps; c->done = 0; c->generation++;
+    pthread_cond_broadcast(&c->cv_go);
+    while (c->done < c->nthreads) pthread_cond_wait(&c->cv_done, &c->mu);
+    pthread_mutex_unlock(&c->mu);
+}
+
+/* The CPUs this process may run on, ordered for pinning: physical cores (the first CPU of every thread_siblings_list) before their SMT siblings,
+ * and inside each class the sockets in turn -- n threads then sit on n different cores spread over all the sockets.  Returns the count. */
+static int mr_cpu_order(int *out, int cap, int *socket_of_out) {
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) != 0) return 0;
+    enum { MAXC = CPU_SETSIZE };
+    static int pkg[MAXC], primary[MAXC];
+    int maxpkg = 0, n = 0;
+    for (int cpu = 0; cpu < MAXC; cpu++) {
+        pkg[cpu] = -1; primary[cpu] = 1;
+        if (!CPU_ISSET(cpu, &set)) continue;
+        char path[128];
+        int v = 0;
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/physical_package_id", cpu);
+        FILE *f = fopen(path, "r");
+        if (f) { if (fscanf(f, "%d", &v) != 1) v = 0; fclose(f); }
+        pkg[cpu] = v < 0 ? 0 : v;
+        if (pkg[cpu] > maxpkg) maxpkg = pkg[cpu];
+        snprintf(path, sizeof path, "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+        f = fopen(path, "r");
+        if (f) { int first = cpu; if (fscanf(f, "%d", &first) == 1) primary[cpu] = (first == cpu); fclose(f); }
+    }
+    for (int cls = 1; cls >= 0; cls--) {            /* primary siblings first */
+        int cursor[64];
+        for (int s = 0; s <= maxpkg && s < 64; s++) cursor[s] = 0;
+        for (;;) {
+            int added = 0;
+            for (int s = 0; s <= maxpkg && s < 64; s++) {   /* one CPU of every socket per turn */
+                int cpu = cursor[s];
+                while (cpu < MAXC && !(pkg[cpu] == s && primary[cpu] == cls)) cpu++;
+                cursor[s] = cpu + 1;
+                if (cpu < MAXC && n < cap) { out[n] = cpu; if (socket_of_out) socket_of_out[n] = s; n++; added = 1; }
+            }
+            if (!added) break;
+        }
+    }
+    return n;
+}
+
+ref_mr_ctx *ref_mr_create(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_params *p, nxs_dyn_state *const *s, const nxs_dyn_forcing *const *f,
+                          const nxs_dyn_halo *const *h, int nthreads, int pin) {
+    if (nranks < 1 || !m || !p || !s || !f || !h) return NULL;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > nranks) nthreads = nranks;
+    ref_mr_ctx *c = (ref_mr_ctx *)calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->nranks = nranks; c->nthreads = nthreads; c->pin = pin; c->p = *p;
+    c->src_m = m; c->src_s = s; c->src_f = f; c->src_h = h;
+    c->rk = (ref_mr_rank *)calloc((size_t)nranks, sizeof(ref_mr_rank));
+    c->pm = (const nxs_dyn_mesh **)calloc((size_t)nranks, sizeof(void *)); c->ps = (nxs_dyn_state **)calloc((size_t)nranks, sizeof(void *));
+    c->pf = (const nxs_dyn_forcing **)calloc((size_t)nranks, sizeof(void *)); c->pw = (ref_work **)calloc((size_t)nranks, sizeof(void *));
+    c->ph = (const nxs_dyn_halo **)calloc((size_t)nranks, sizeof(void *));
+    c->th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
+    c->cpu_of = (int *)malloc((size_t)nthreads * sizeof(int));
+    ref_mr_job *J = &c->job;
+    J->nranks = nranks; J->nthreads = nthreads;
+    J->sendbuf = (double **)calloc((size_t)nranks, sizeof(double *));
+    J->peer_seg = (int **)calloc((size_t)nranks, sizeof(int *));
+    int ok = c->rk && c->pm && c->ps && c->pf && c->pw && c->ph && c->th && c->cpu_of && J->sendbuf && J->peer_seg;
+    for (int r = 0; r < nranks && ok; r++) {   /* who sends what to whom: checked on the caller's lists, as in ref_multirank_steps */
+        const nxs_dyn_halo *hr = h[r];
+        const int nr = hr->num_recv_procs;
+        J->peer_seg[r] = (int *)malloc(sizeof(int) * (size_t)(nr + 1));
+        if (!J->peer_seg[r]) { ok = 0; break; }
+        for (int k = 0; k < nr && ok; k++) {
+            const int q = hr->recv_procs[k];
+            if (q < 0 || q >= nranks) { ok = 0; break; }
+            int found = -1;
+            for (int kk = 0; kk < h[q]->num_send_procs; kk++) if (h[q]->send_procs[kk] == hr->rank) found = kk;
+            if (found < 0 || h[q]->send_offsets[found + 1] - h[q]->send_offsets[found] != hr->recv_offsets[k + 1] - hr->recv_offsets[k]) { ok = 0; break; }
+            J->peer_seg[r][k] = found;
+        }
+    }
+    if (ok) {
+        for (int t = 0; t < nthreads; t++) c->cpu_of[t] = -1;
+        if (pin) {
+            int *order = (int *)malloc(sizeof(int) * CPU_SETSIZE), *sock = (int *)malloc(sizeof(int) * CPU_SETSIZE);
+            const int n = (order && sock) ? mr_cpu_order(order, CPU_SETSIZE, sock) : 0;
+            int seen_sock[64] = {0};
+            for (int t = 0; t < nthreads && n > 0; t++) {
+                c->cpu_of[t] = order[t % n];
+                if (t < n && sock[t] >= 0 && sock[t] < 64 && !seen_sock[sock[t]]) { seen_sock[sock[t]] = 1; c->sockets_used++; }
+            }
+            free(order); free(sock);
+        }
+        pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->cv_go, NULL); pthread_cond_init(&c->cv_done, NULL);
+        atomic_init(&c->bar_count, 0); atomic_init(&c->bar_sense, 0);
+        int started = 0;
+        for (int t = 0; t < nthreads; t++) {
+            ref_mr_targ *a = (ref_mr_targ *)malloc(sizeof *a);
+            if (!a) break;
+            a->c = c; a->tid = t;
+            if (pthread_create(&c->th[t], NULL, mr_ctx_thread, a) != 0) { free(a); break; }
+            started++;
+        }
+        if (started != nthreads) {   /* cannot run with fewer: end the ones that started */
+            c->nthreads = started;
+            if (started) { mr_command(c, 4, 0); for (int t = 0; t < started; t++) pthread_join(c->th[t], NULL); }
+            c->nthreads = 0;
+            ok = 0;
+        }
+    }
+    if (ok) {
+        mr_command(c, 1, 0);   /* every thread copies its partitions in: first touch */
+        J->m = c->pm; J->p = &c->p; J->s = c->ps; J->f = c->pf; J->w = c->pw; J->h = c->ph;
+        if (c->failed) ok = 0;
+    }
+    if (!ok) { ref_mr_destroy(c, 0); return NULL; }
+    return c;
+}
+
+int ref_mr_run(ref_mr_ctx *c, int nsteps) {
+    if (!c || nsteps < 0 || c->nthreads < 1) return -1;
+    mr_command(c, 2, nsteps);
+    return 0;
+}
+
+/* threads, CPUs pinned (-1 where not), sockets the pinned threads sit on */
+int ref_mr_info(const ref_mr_ctx *c, int *nthreads, int *sockets_used, int *cpus, int cap) {
+    if (!c) return -1;
+    if (nthreads) *nthreads = c->nthreads;
+    if (sockets_used) *sockets_used = c->sockets_used;
+    for (int t = 0; cpus && t < c->nthreads && t < cap; t++) cpus[t] = c->cpu_of[t];
+    return 0;
+}
+
+void ref_mr_destroy(ref_mr_ctx *c, int copy_back) {
+    if (!c) return;
+    if (c->nthreads > 0 && c->th) {
+        if (copy_back && !c->failed) mr_command(c, 3, 0);
+        mr_command(c, 4, 0);
+        for (int t = 0; t < c->nthreads; t++) pthread_join(c->th[t], NULL);
+        pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->cv_go); pthread_cond_destroy(&c->cv_done);
+    }
+    for (int r = 0; c->rk && r < c->nranks; r++) {
+        for (int i = 0; i < c->rk[r].n_owned; i++) free(c->rk[r].owned[i]);
+        free(c->rk[r].owned);
+        ref_work_destroy(c->rk[r].w);
+        if (c->job.sendbuf) free(c->job.sendbuf[r]);
+        if (c->job.peer_seg) free(c->job.peer_seg[r]);
+    }
+    free(c->job.sendbuf); free(c->job.peer_seg);
+    free(c->rk); free(c->pm); free(c->ps); free(c->pf); free(c->pw); free(c->ph); free(c->th); free(c->cpu_of);
+    free(c);
+}

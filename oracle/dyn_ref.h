@@ -106,6 +106,16 @@ void ref_ghosts_unpack(const nxs_dyn_halo *h, int32_t Nn, double *vec, int k, co
 int ref_multirank_steps(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_params *p, nxs_dyn_state *const *s,
                         const nxs_dyn_forcing *const *f, ref_work *const *w, const nxs_dyn_halo *const *h, int nsteps, int nthreads);
 
+/* The same run as a persistent context that uses the host like an MPI run: threads kept across calls and pinned (pin != 0: physical cores first, the sockets
+ * in turn), every partition's arrays copied -- first touched -- by the thread that owns it, spin barriers.  ref_mr_run: nsteps lock-step steps (the part
+ * bench.py times); ref_mr_destroy(copy_back != 0) writes the state back into the caller's arrays.  Bit for bit ref_multirank_steps. */
+typedef struct ref_mr_ctx ref_mr_ctx;
+ref_mr_ctx *ref_mr_create(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_params *p, nxs_dyn_state *const *s, const nxs_dyn_forcing *const *f,
+                          const nxs_dyn_halo *const *h, int nthreads, int pin);
+int ref_mr_run(ref_mr_ctx *c, int nsteps);
+int ref_mr_info(const ref_mr_ctx *c, int *nthreads, int *sockets_used, int *cpus, int cap);
+void ref_mr_destroy(ref_mr_ctx *c, int copy_back);
+
 /* restatement of Mesh::WriteMesh's two connectivity tables (contrib/bamg/src/Mesh.cpp:514-543, 798-865) */
 int ref_mesh_connectivity(const int32_t *indices, int32_t num_nodes, int32_t num_elements,
                           int32_t *nec_width, double *nec, int32_t *nc_width, double *nc);

@@ -352,6 +352,43 @@ def multirank_steps_native(ranks: list, nsteps: int = 1, nthreads: int = 0) -> N
         raise RuntimeError(f"ref_multirank_steps failed ({rc})")
 
 
+class MultirankContext:
+    """ref_mr_create / ref_mr_run / ref_mr_destroy: the lock-step run of the in-process ranks on threads that are KEPT, PINNED (physical cores first, the
+    sockets in turn) and that have first touched their partitions' arrays -- the CPU baseline of bench.py as an MPI run of the reference would use the host.
+    run(n): n steps (what is timed); close(): the state back into the ranks' arrays.  Bit for bit multirank_steps_native."""
+
+    def __init__(self, ranks: list, nthreads: int = 0, pin: bool = True):
+        n = len(ranks)
+        P = C.POINTER
+        Mp, Sp, Fp, Hp = P(_abi.Mesh), P(_abi.State), P(_abi.Forcing), P(_abi.Halo)
+        self._keep = ranks   # (the context reads the ranks' structs while it is made and writes their arrays when it is closed)
+        self._m = (Mp * n)(*[C.pointer(r.mesh) for r in ranks]); self._s = (Sp * n)(*[C.pointer(r.state) for r in ranks])
+        self._f = (Fp * n)(*[C.pointer(r.forcing) for r in ranks]); self._h = (Hp * n)(*[C.pointer(r.halo) for r in ranks])
+        self.L = ranks[0].L
+        self.L.ref_mr_create.restype = C.c_void_p
+        self.L.ref_mr_create.argtypes = [C.c_int, P(Mp), P(_abi.Params), P(Sp), P(Fp), P(Hp), C.c_int, C.c_int]
+        self.L.ref_mr_run.argtypes = [C.c_void_p, C.c_int]; self.L.ref_mr_destroy.argtypes = [C.c_void_p, C.c_int]; self.L.ref_mr_destroy.restype = None
+        self.L.ref_mr_info.argtypes = [C.c_void_p, P(C.c_int), P(C.c_int), P(C.c_int), C.c_int]
+        self.ctx = self.L.ref_mr_create(n, self._m, C.byref(ranks[0].params), self._s, self._f, self._h, nthreads or n, 1 if pin else 0)
+        if not self.ctx:
+            raise RuntimeError("ref_mr_create failed (inconsistent halo lists, memory or threads)")
+
+    def run(self, nsteps: int = 1):
+        if self.L.ref_mr_run(self.ctx, nsteps) != 0:
+            raise RuntimeError("ref_mr_run failed")
+
+    def info(self) -> dict:
+        nt, so = C.c_int(), C.c_int()
+        cpus = (C.c_int * 1024)()
+        self.L.ref_mr_info(self.ctx, C.byref(nt), C.byref(so), cpus, 1024)
+        return {"threads": nt.value, "sockets_used": so.value, "cpus": [cpus[i] for i in range(min(nt.value, 1024))]}
+
+    def close(self, copy_back: bool = True):
+        if self.ctx:
+            self.L.ref_mr_destroy(self.ctx, 1 if copy_back else 0)
+            self.ctx = None
+
+
 def bamg_element_connectivity(indices, x, y):
     """bamgmesh->ElementConnectivity and ->Triangles of the REAL BamgConvertMeshx (doubles, NaN on the boundary)."""
     L = C.CDLL(os.path.join(HERE, "_ref", "libbamg_shim.so"))

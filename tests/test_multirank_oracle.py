@@ -97,3 +97,30 @@ def test_threaded_lock_step_in_the_library_equals_the_phase_by_phase_driver(kind
     for ra, rb in zip(a, b):
         for k in KEYS_N + KEYS_E:
             assert np.array_equal(ra.arr[k], rb.arr[k]), (ra.lm.rank, k)
+
+
+@pytest.mark.parametrize("kind,nparts,nthreads,pin,over", [("toy", 3, 2, True, {}), ("small", 5, 5, True, {}), ("small", 4, 3, False, {"dynamics_type": 4}),
+                                                          ("small", 3, 8, True, {"ragged_seed": 21}), ("toy", 2, 1, True, {"dynamics_type": 3})])
+def test_persistent_pinned_context_equals_the_phase_by_phase_driver(kind, nparts, nthreads, pin, over):
+    """ref_mr_create / ref_mr_run / ref_mr_destroy -- threads kept across calls and pinned, every partition's arrays copied (first touched) by the
+    thread that owns it, spin barriers: the form of the lock-step run that bench.py's cpu_baseline times -- gives, bit for bit, what the phase-by-phase
+    driver gives; two runs on one context (one step + one step) equal two steps; the ranks' own arrays change only when the context is closed."""
+    gm, p, g, lms, fields = cases.make_case(kind, nparts=nparts, **over)
+    a = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    b = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    for _ in range(2):
+        O.multirank_step(a)
+    before = b[0].arr["VT"].copy()
+    ctx = O.MultirankContext(b, nthreads=nthreads, pin=pin)
+    info = ctx.info()
+    assert info["threads"] == min(nthreads, nparts) and len(info["cpus"]) == info["threads"]
+    if pin:
+        assert all(c >= 0 for c in info["cpus"]) and info["sockets_used"] >= 1
+        import os
+        assert set(info["cpus"]) <= set(os.sched_getaffinity(0))
+    ctx.run(1); ctx.run(1)
+    assert np.array_equal(b[0].arr["VT"], before)
+    ctx.close()
+    for ra, rb in zip(a, b):
+        for k in KEYS_N + KEYS_E:
+            assert np.array_equal(ra.arr[k], rb.arr[k]), (ra.lm.rank, k)
