@@ -114,6 +114,8 @@ struct nxs_dyn_handle {
     int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
                                            // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
     bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
+    PairHalo pairh{};                      // several ranks: the patches' duties in the exchange inside k_substep_pair<HALO>, the ticket words
+    bool pair_claim = false;               // ... and their claim on the device's workgroup slots (nxs_resident_registry.hpp)
     int pair_hint = 0;                     // the patch size the planner kept for the previous mesh (tried first after a regrid)
     int prep_fused = -1;                   // option "prep_fused": -1 where it pays (single rank, records only, >= 250 k triangles), 0 never, 1 wherever it can run
     size_t smooth_lds = 0;
@@ -233,6 +235,7 @@ inline int eff_fused(const nxs_dyn_handle *h) { return h->trace_branches ? 0 : h
 int build_halo_fused(nxs_dyn_handle *h);  // (defined with the launch logic below)
 int build_resident(nxs_dyn_handle *h);
 void resident_registry_release(const nxs_dyn_handle *h);
+bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots, std::string *why);
 void release_resident(nxs_dyn_handle *h);
 bool multi_rank(const nxs_dyn_handle *h);
 
@@ -674,6 +677,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
         const bool was_resident = h->fused == 4, now_resident = value == 4;
         h->fused = (int)value; h->res_failed = false; h->no_big_cut = false; release_graph(h);
+        if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; h->pair_ready = false; }   // (the several-rank pair patches: cut again when they are wanted)
         // the resident loop has a cut of its own (one round of workgroups; one LARGE patch per CU for partitions of 200 k - 400 k triangles, which is not what
         // the one-launch-per-sub-step kernel wants): asking for it or giving it up on a live mesh cuts the mesh again -- any cut gives the same bits
         if (h->have_mesh && was_resident != now_resident) {
@@ -809,6 +813,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
     release_resident(h);
+    if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; }
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
@@ -988,6 +993,8 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
         if (off[n] > 0 && !(side ? halo->recv_index : halo->send_index)) return fail(h, NXS_ERR_INVALID, "%s_index is NULL", side ? "recv" : "send");
     }
     h->rank = halo->rank; h->nranks = halo->nranks;
+    if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; }
+    h->pair_ready = false; h->pair_failed = false;   // (the several-rank pair patches depend on the send lists)
     h->send_procs.assign(halo->send_procs, halo->send_procs + ns);
     h->recv_procs.assign(halo->recv_procs, halo->recv_procs + nr);
     if (ns > 0) h->send_offsets.assign(halo->send_offsets, halo->send_offsets + ns + 1); else h->send_offsets.assign(1, 0);
@@ -1606,7 +1613,7 @@ void launch_fused(nxs_dyn_handle *h, int sidx, double move_dt, int halo = 0, int
 }
 
 // sub-steps sidx .. sidx+D-1 in one launch (k_substep_multi): sigma/damage ping-pong per LAUNCH, velocities through the ring
-void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
+void launch_multi(nxs_dyn_handle *h, int sidx, int D, bool halo = false) {
     PingPong b = pingpong(h, (sidx / D) & 1);
     const int R = h->ring.R;
     b.VTc = h->ring.slot[sidx % R];
@@ -1615,9 +1622,16 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D) {
     for (int k = 0; k < D; ++k) vo.slot[k] = h->ring.slot[(sidx + 1 + k) % R];
     const dim3 grid(h->dpch2.nP);
     const bool pow4 = h->dp.ers_int == 4;
-    if (h->pair_kernel) {  // (D == 2: upload_patches2 cut the patches for it)
-        if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo);
-        else hipLaunchKernelGGL((k_substep_pair<512, false, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo);
+    if (h->pair_kernel) {  // (D == 2: upload_patches2 / upload_pair_patches_mr cut the patches for it)
+        if (halo) {        // several ranks: both exchanges inside the launch; the first launch of a step finds its ghosts in the velocity buffer
+            PairHalo ph = h->pairh;
+            ph.from_mailbox = sidx > 0 ? 1 : 0;
+            if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)h->d_hf, ph);
+            else hipLaunchKernelGGL((k_substep_pair<512, false, 3, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)h->d_hf, ph);
+            return;
+        }
+        if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
+        else hipLaunchKernelGGL((k_substep_pair<512, false, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
         return;
     }
 #define MULTI(TT, PP, NN) hipLaunchKernelGGL((k_substep_multi<TT, PP, NN>), grid, dim3(TT), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, (const DevParams *)h->d_dp, b, vo)
@@ -1824,6 +1838,17 @@ int choose_depth(nxs_dyn_handle *h) {
     // ... and on meshes that STREAM from HBM (fused == 3, >= 400 k triangles, an even number of sub-steps) two sub-steps per launch with the
     // stresses between them in registers and two workgroups per CU (k_substep_pair): 2 km 6.3 -> 5.7 ms of sub-steps.
     const bool single = !multi_rank(h) && move_dt != 0. && S >= 2 && !h->pair_failed;
+    // several ranks: two sub-steps per launch with BOTH exchanges inside it (k_substep_pair<HALO>: device-direct mailboxes, the exchange inside the kernels) --
+    // automatically where the partition streams from HBM (more than 65 k nodes: a rank of two of the 2 km mesh; smaller partitions run the resident loop where
+    // they have a device to themselves), with option pair_regs = 1 at any size
+    const bool mr_pair = multi_rank(h) && h->have_halo && h->ipc_ready && !h->halo_fn && h->halo_fused && eff_fused(h) == 3 && move_dt != 0. && S >= 2 && S % 2 == 0 &&
+                         !h->pair_failed && (h->pair_regs == 1 || (h->pair_regs < 0 && (long long)h->dm.Nn > 256ll * 256)) && (h->pair_depth == 0 || h->pair_depth == 2);
+    if (mr_pair) {
+        if (!h->hf_ready && build_halo_fused(h) != NXS_OK) { h->pair_failed = true; h->depth_now = 1; return 1; }
+        if ((!h->pair_ready || h->pair_depth_built != 2 || !h->pair_kernel) && upload_pair_patches_mr(h) != NXS_OK) h->pair_failed = true;
+        h->depth_now = (h->pair_ready && !h->pair_failed) ? 2 : 1;
+        return h->depth_now;
+    }
     // (automatic: every mesh too large for one k_substep_multi patch per CU, i.e. above 65 k nodes)
     const bool streaming_pair = single && eff_fused(h) == 3 && h->pair_regs != 0 && (long long)h->dm.Nn > 256ll * 256 && S % 2 == 0 && (h->pair_depth == 0 || h->pair_depth == 2);
     if (streaming_pair) {
@@ -1900,7 +1925,8 @@ int run_substeps(nxs_dyn_handle *h) {
         }
     }
     const bool resident = res_wanted && h->res_ready && !h->res_failed;
-    if ((halo_in_kernel || (resident && mr)) && h->d_hf_dirty) {  // (outside any stream capture)
+    const bool pair_halo = pair && mr;   // (choose_depth built the tables: device-direct mailboxes, the exchange inside the kernels)
+    if ((halo_in_kernel || (resident && mr) || pair_halo) && h->d_hf_dirty) {  // (outside any stream capture)
         HaloFused tmp = h->hf;
         tmp.ipc = h->ipc;
         HIPCHK(h, hipMemcpyAsync(h->d_hf, &tmp, sizeof tmp, hipMemcpyHostToDevice, h->stream));
@@ -1958,10 +1984,11 @@ int run_substeps(nxs_dyn_handle *h) {
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
         for (int s = 0; s < S; ++s) {
             if (pair) {
-                launch_multi(h, s, D);
+                launch_multi(h, s, D, pair_halo);
                 s += D - 1;
                 pending += D;
                 if (pending == K || s == S - 1) {
+                    if (pair_halo) pull_latest(h->ring.slot[(s + 1) % R]);  // the newest ghosts, for the move / the end of the step
                     flush(s, pending);
                     pending = 0;
                 }
@@ -2005,7 +2032,7 @@ int run_substeps(nxs_dyn_handle *h) {
     if (fused) h->sig_loc = records_end_odd ? 0 : 1;
     h->timing.substep_launches = resident ? 1 : pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
     h->last_kernel = resident ? (h->res_big ? NXS_KERNEL_RESIDENT_BIG : NXS_KERNEL_RESIDENT) : pair ? (h->pair_kernel ? NXS_KERNEL_PAIR : NXS_KERNEL_MULTI) : fused ? NXS_KERNEL_FUSED : NXS_KERNEL_PER_LOOP;
-    h->last_deferred = deferred; h->last_halo_in_kernel = halo_in_kernel || (resident && mr);
+    h->last_deferred = deferred; h->last_halo_in_kernel = halo_in_kernel || (resident && mr) || pair_halo;
     h->last_ring_count = (deferred && !resident) ? K : 0;
     if (!h->use_graph || (mr && !device_halo)) { int lrc = loop(); return lrc ? lrc : final_flush(); }
     if (!h->graph_valid) {

@@ -1455,8 +1455,26 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
 // constants and the nodal inputs cross HBM once per two sub-steps (the second reads hit the L2), at +11 % element and +24 % node
 // arithmetic (400-node patches).  Same operations in the same order as k_substep_fused: bit-identical.
 // Limits (the host checks them): E_2 <= 3 T, E_1 <= 2 T, N_1 <= 2 T, own nodes <= T.
-template <int T, bool POW4, int NTM>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout) {
+// HALO (several ranks, device-direct mailboxes): the two updateGhosts of the launch happen inside it.  A rank's patches are cut over its OWN nodes; the first
+// sub-step solves the own nodes of N_1 only -- a ghost node's fan is not complete on this rank -- and the ghosts of N_1 arrive from their owners instead:
+//   G patches (a ghost among the staged nodes N_2; they lead the grid) first wait until the exchange that ended the launch before has landed
+//     (flags >= x, x = *seq_push) and stage their ghosts from mailbox half (x-1)&1, copying them through to the velocity slot as k_substep_fused does;
+//   after the first solve the SENDER patches store their sent own nodes into the neighbours' half x&1; the last of the G patches to have staged (and, if it
+//     sends, stored) raises the flags to x+1 -- not before: the neighbours answer that flag by overwriting the half the G patches stage from;
+//   RECEIVER patches (a ghost in N_1: the band along the partition boundary, and the patches of elements without an own node) wait for the neighbours'
+//     flags >= x+1 and take the ghosts of N_1 from half x&1 (also into the first velocity slot: the ghosts' mesh move reads it);
+//   after the second solve the senders store into half (x+1)&1; the last band patch to finish raises the flags to x+2 and advances *seq_push by two.
+// Every other patch runs the single-rank body.  Same operations on the same values as one k_substep_fused<HALO> per sub-step: the same bits.
+// Needs every G patch of the rank on a CU at once (the host checks the count and claims them in the device's registry); every wait is bounded.
+struct PairHalo {
+    const unsigned char *pflags;   // [nP] bit 0: G (stages a ghost), bit 1: sends, bit 2: a ghost in N_1 (receives between the two sub-steps)
+    int nG, nBand;                 // patches [0, nBand) send or receive between the sub-steps, [0, nG) stage a ghost
+    int from_mailbox;              // 0: first launch of a step, the ghosts are in the velocity buffer
+    unsigned int *tickets;         // [0]: G patches past their first duty, [32]: band patches done, [64..65] (64 bits): the last sequence whose first exchange is published
+};
+template <int T, bool POW4, int NTM, bool HALO = false>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout,
+                                                                                                const HaloFused *__restrict__ hfp, PairHalo ph) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int NDm = pp.NDmax, EDm = pp.EDmax;
@@ -1464,13 +1482,60 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     d2 *lF2 = reinterpret_cast<d2 *>(ly + NDm);  // [3][EDm] + a pair of zeros
     const unsigned ZIDX = 3u * (unsigned)EDm;
     int blk;
-    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused)
-        const int n = (int)gridDim.x, pos = (int)blockIdx.x, q = n >> 3, r = n & 7, x = pos & 7;
-        blk = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3);
+    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused); several ranks: the G patches lead the grid, the remap acts inside each group
+        auto xcd_remap = [](const int pos, const int n) { const int q = n >> 3, r = n & 7, x = pos & 7; return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3); };
+        const int pos = (int)blockIdx.x, n = (int)gridDim.x;
+        if (HALO) blk = pos < ph.nG ? xcd_remap(pos, ph.nG) : ph.nG + xcd_remap(pos - ph.nG, n - ph.nG);
+        else blk = xcd_remap(pos, n);
     }
     const int t = threadIdx.x, Nn = m.Nn;
     NXS_STAMP(0);
     if (t == 0) lF2[ZIDX] = d2{0., 0.};
+    unsigned flg = 0u;                 // this patch's duties in the exchange (uniform over the workgroup)
+    unsigned long long xseq = 0ull;
+    if (HALO) {
+        flg = ph.pflags[blk];
+        if (flg & 1u) xseq = *hfp->ipc.seq_push;   // (interior patches never look at it: the last band patch advances it while they run)
+    }
+    // the neighbours' flags: one lane waits, bounded like every other wait of the transport
+    auto wait_flags = [&](const unsigned long long want) {
+        if (t == 0) {
+            const long long t0 = wall_clock64();  // 100 MHz
+            bool ok = true;
+            for (int k = 0; k < hfp->ipc.nr && ok; ++k)
+                while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (__hip_atomic_load(hfp->ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost
+                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hfp->ipc.error, 3); break; }  // 10 s
+                }
+        }
+        __syncthreads();   // (no acquire: the mailbox is uncached memory, read with system-scope loads -- see k_substep_fused)
+    };
+    // a G patch is past its first duty (staged; stored, if it sends): the last one tells the neighbours that exchange x is complete AND that half (x-1)&1 is free
+    auto ticket_first = [&]() {
+        if (t == 0 && atomicAdd(ph.tickets, 1u) == (unsigned)ph.nG - 1u) {
+            __threadfence_system();
+            const unsigned long long pub = ph.nBand > 0 ? xseq + 1ull : xseq + 2ull;   // (no band patch: nobody sends, both exchanges are empty)
+            for (int k = 0; k < hfp->ipc.ns; ++k) __hip_atomic_store(hfp->ipc.peer_flag[k], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *ph.tickets = 0u;
+            if (ph.nBand == 0) *hfp->ipc.seq_push = xseq + 2ull;
+            else __hip_atomic_store(reinterpret_cast<unsigned long long *>(ph.tickets + 64), xseq + 1ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // "the first exchange of sequence x is out"
+        }
+    };
+    auto send_node = [&](const int n, const double u1, const double v1, const unsigned long long x) {   // updateGhosts, sending side (FE.cpp:13967-13985)
+        for (int q = hfp->send_ptr[n]; q < hfp->send_ptr[n + 1]; ++q) {
+            const int k = hfp->send_k[q];
+            double *dst = hfp->ipc.peer_seg[k] + (x & 1ull) * hfp->ipc.peer_parity_stride[k] + hfp->send_pos[q];
+            sys_store(dst, u1);
+            sys_store(dst + (hfp->send_off[k + 1] - hfp->send_off[k]), v1);
+        }
+    };
+    auto ghost_from_mailbox = [&](const int g, const unsigned long long x, double &u1, double &v1) {
+        const double *src = hfp->ipc.mailbox + (x & 1ull) * 2ull * (unsigned long long)hfp->ipc.tr + hfp->ghost_off[g - m.No];
+        u1 = sys_load(src); v1 = sys_load(src + hfp->ghost_srl[g - m.No]);
+    };
+    const bool mailbox_ghosts = HALO && (flg & 1u) && ph.from_mailbox;
+    if (mailbox_ghosts) wait_flags(xseq);   // the exchange that ended the launch before (x - 1) has landed
     const int *ncnt = pp.ncnt + (size_t)blk * 3, *ecnt = pp.ecnt + (size_t)blk * 2;
     const int nO = ncnt[0], nN1 = ncnt[1], nN2 = ncnt[2], nE1 = ecnt[0], nE2 = ecnt[1];
     const int *pn = pp.pnodes + (size_t)blk * NDm;
@@ -1492,7 +1557,13 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
     }
     auto stage = [&](const int i, const int g) {
-        lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn];
+        if (mailbox_ghosts && g >= m.No) {
+            double u0, v0;
+            ghost_from_mailbox(g, xseq - 1ull, u0, v0);
+            lu[i] = u0; lv[i] = v0;
+            const_cast<double *>(b.VTc)[g] = u0;  // every patch that stages g writes the same two values (the ghosts' mesh move and the end of the step read them here)
+            const_cast<double *>(b.VTc)[g + Nn] = v0;
+        } else { lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn]; }
         const d2 c = reinterpret_cast<const d2 *>(w.xy)[g];
         lx[i] = c.x; ly[i] = c.y;
     };
@@ -1590,7 +1661,10 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;  // (read again by sub-step 1: no streaming hint)
             r0 = q[0]; r1 = q[1]; r2 = q[2];
         }
-        if (r == 0) { __syncthreads(); NXS_STAMP(1); }  // staged velocities / coordinates visible
+        if (r == 0) {
+            __syncthreads(); NXS_STAMP(1);  // staged velocities / coordinates visible
+            if (HALO && (flg & 1u) && !(flg & 2u)) ticket_first();   // (a G patch that sends nothing has read its mailbox half: that is all the neighbours wait for from it)
+        }
         if (active) {
             double sig[3] = {a.x, a.y, c2.x}, damage = c2.y;
             update_element(l, tr[r], sig, damage, r0, r1, r2);
@@ -1602,16 +1676,40 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = t + r * T;
-        const bool active = i < nN1;
         const int n = r == 0 ? my_node : my_node2;
+        const bool active = i < nN1 && !(HALO && n >= m.No);   // (several ranks: a ghost of N_1 is not solved here, it arrives below)
         NodeIn in{};
         if (active) in = load_node(i, n);
         if (r == 0) { __syncthreads(); NXS_STAMP(6); }  // corner forces of sub-step 0 visible
         if (active) {
             double u1, v1;
             solve_node(i, in, u1, v1);
-            if (i < nO) { vout.slot[0][n] = u1; vout.slot[0][n + Nn] = v1; }
+            if (i < nO) {
+                vout.slot[0][n] = u1; vout.slot[0][n + Nn] = v1;
+                if (HALO && (flg & 2u)) send_node(n, u1, v1, xseq);
+            }
             lu[i] = u1; lv[i] = v1;  // (a node's solve reads only its own staged velocity: in place)
+        }
+    }
+    if (HALO && (flg & 6u)) {   // ---- the exchange between the two sub-steps (band patches only)
+        if (flg & 2u) {         // every wave drains its stores into the neighbours' mailboxes, the barrier collects the waves, one lane takes the patch's ticket
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            ticket_first();
+        }
+        if (flg & 4u) {
+            wait_flags(xseq + 1ull);   // the neighbours' first velocities have landed in half x & 1
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int i = t + r * T;
+                const int g = r == 0 ? my_node : my_node2;
+                if (i >= nO && i < nN1 && g >= m.No) {
+                    double u1, v1;
+                    ghost_from_mailbox(g, xseq, u1, v1);
+                    lu[i] = u1; lv[i] = v1;
+                    vout.slot[0][g] = u1; vout.slot[0][g + Nn] = v1;   // (every patch that holds g in N_1 writes the same two values)
+                }
+            }
         }
     }
     // ---- sub-step 1: elements E_1 (two rounds), state from the registers, result to HBM (by the element's writer); the constants of the first
@@ -1653,6 +1751,28 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             double u1, v1;
             solve_node(t, in, u1, v1);
             vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1;
+            if (HALO && (flg & 2u)) send_node(my_node, u1, v1, xseq + 1ull);
+        }
+    }
+    if (HALO) {
+        if (flg & 6u) {   // publish the second exchange: the last band patch to finish raises the flags and advances the sequence
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (t == 0 && atomicAdd(ph.tickets + 32, 1u) == (unsigned)ph.nBand - 1u) {
+                // the flags count upwards: x + 1 (raised by the last G patch to have staged, which may be a patch that neither sends nor receives and started late) goes out
+                // before x + 2; and *seq_push may only move once every G patch has read it, which is what that first publication certifies
+                const long long t0 = wall_clock64();
+                while (__hip_atomic_load(reinterpret_cast<unsigned long long *>(ph.tickets + 64), __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < xseq + 1ull) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (wall_clock64() - t0 > 1000000000ll) { atomicExch(hfp->ipc.error, 3); break; }  // 10 s: a G patch of this rank never ran
+                }
+                __threadfence_system();
+                for (int k = 0; k < hfp->ipc.ns; ++k) __hip_atomic_store(hfp->ipc.peer_flag[k], xseq + 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                ph.tickets[32] = 0u;
+                *hfp->ipc.seq_push = xseq + 2ull;
+            }
+        } else if (ph.nG == 0 && blockIdx.x == 0 && t == 0) {
+            *hfp->ipc.seq_push += 2ull;             // a rank without neighbours: the sequence still counts the exchanges
         }
     }
     NXS_STAMP(4);

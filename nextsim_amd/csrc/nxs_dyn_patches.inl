@@ -80,6 +80,85 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
     return NXS_OK;
 }
 
+// Several ranks: the two-ring patches of k_substep_pair<HALO> over this rank's own nodes (nxs_cut::plan_pair_patches_mr), their duties in the exchange, the
+// ticket words -- and the claim on the device's workgroup slots for the patches that wait for a neighbour rank INSIDE the launch (they all have to be on
+// a CU at once; ranks that share a device share its slots: nxs_resident_registry.hpp).  NXS_OK with pair_ready == false: not possible here.
+int upload_pair_patches_mr(nxs_dyn_handle *h) {
+    drop_pool(h, h->pair_allocs);
+    h->dpch2 = DevPatches2{};
+    h->pair_ready = false;
+    h->pairh = PairHalo{};
+    if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; }
+    const DevMesh &m = h->dm;
+    std::vector<char> sent((size_t)std::max(m.No, 1), 0);
+    for (int n : h->h_send_index) if (n >= 0 && n < m.No) sent[n] = 1;
+    nxs_cut::PairHaloPlan plan;
+    const int cus = device_cus(h);
+    const std::string why = nxs_cut::plan_pair_patches_mr(mesh_view(h), h->hp && h->hp->used_hilbert, h->pair_nodes, cus, sent, plan, h->pair_hint);
+    auto refuse = [&](const char *w) {
+        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d: two sub-steps per launch not possible: %s\n", h->rank, w);
+        h->pair_failed = true;
+        return NXS_OK;
+    };
+    if (!why.empty()) return refuse(why.c_str());
+    const HostPatches2 &hp = plan.hp;
+    // every patch that takes part in the exchange may wait for a neighbour rank inside the launch: all of them resident at once, with room to spare
+    if (plan.nG > cus) return refuse("more patches along the partition boundary than half the device's workgroup slots");
+    {
+        std::string w2;
+        if (plan.nG > 0 && !resident_registry_claim(h, plan.nG, 2 * cus, &w2)) return refuse(w2.c_str());
+        h->pair_claim = plan.nG > 0;
+    }
+    if (h->pair_nodes == 0) h->pair_hint = plan.P;
+    h->pair_lds = plan.lds; h->pair_threads = 512; h->pair_kernel = true;
+    h->pair_own_max = 0;
+    for (int q = 0; q < hp.nP; ++q) h->pair_own_max = std::max(h->pair_own_max, hp.ncnt[(size_t)q * 3]);
+    {
+        auto &S2 = h->sums2;
+        S2 = nxs_dyn_handle::PatchSums2{};
+        S2.nP = hp.nP; S2.N.assign(3, 0.); S2.E.assign(2, 0.);
+        for (int q = 0; q < hp.nP; ++q) {
+            for (int i = 0; i <= 2; ++i) S2.N[i] += hp.ncnt[(size_t)q * 3 + i];
+            for (int i = 0; i < 2; ++i) S2.E[i] += hp.ecnt[(size_t)q * 2 + i];
+            for (int l = 0; l < hp.ecnt[(size_t)q * 2]; ++l) S2.W += hp.pelem[(size_t)q * hp.EDmax + l] >= 0 ? 1. : 0.;
+        }
+    }
+    if (getenv("NXS_DEBUG_PATCHES"))
+        fprintf(stderr, "[nxs] rank %d pair patches (several ranks): P=%d nP=%d (%d in the exchange, %d of them band) EDmax=%d ESmax=%d NDmax=%d NSmax=%d lds=%zu B; elements x %.3f / %.3f, nodes x %.3f / %.3f\n",
+                h->rank, plan.P, hp.nP, plan.nG, plan.nBand, hp.EDmax, hp.ESmax, hp.NDmax, hp.NSmax, plan.lds, h->sums2.E[0] / std::max(m.Ne, 1), h->sums2.E[1] / std::max(m.Ne, 1),
+                h->sums2.N[1] / std::max(m.No, 1), h->sums2.N[2] / std::max(m.No, 1));
+    DevPatches2 &d = h->dpch2;
+    d.nP = hp.nP; d.D = 2; d.NDmax = hp.NDmax; d.NSmax = hp.NSmax; d.EDmax = hp.EDmax; d.ESmax = hp.ESmax; d.Wp = hp.Wp;
+    int rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.ncnt, hp.ncnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.ecnt, hp.ecnt))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.pnodes, hp.pnodes))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.pelem, hp.pelem))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.ptri, hp.ptri))) return rc;
+    if ((rc = dev_upload(h, h->pair_allocs, &d.pfan, hp.pfan))) return rc;
+    {
+        std::vector<int> pet(2 * hp.pelem.size());
+        for (size_t i = 0; i < hp.pelem.size(); ++i) {
+            pet[2 * i] = hp.pelem[i];
+            pet[2 * i + 1] = (int)hp.ptri[4 * i] | ((int)hp.ptri[4 * i + 1] << 10) | ((int)hp.ptri[4 * i + 2] << 20);
+        }
+        const int *dpet = nullptr;
+        if ((rc = dev_upload(h, h->pair_allocs, &dpet, pet))) return rc;
+        d.pet = reinterpret_cast<const int2 *>(dpet);
+    }
+    d.W2 = m.W2; d.pnbr = nullptr;
+    if ((rc = dev_upload(h, h->pair_allocs, &h->pairh.pflags, plan.pflags))) return rc;
+    if ((rc = dev_alloc(h, h->pair_allocs, &h->pairh.tickets, 128))) return rc;
+    HIPCHK(h, hipMemsetAsync(h->pairh.tickets, 0, 128 * sizeof(unsigned int), h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->pairh.nG = plan.nG; h->pairh.nBand = plan.nBand; h->pairh.from_mailbox = 0;
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_substep_pair<512, true, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pair_lds));
+    HIPCHK(h, hipFuncSetAttribute(reinterpret_cast<const void *>(k_substep_pair<512, false, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pair_lds));
+    h->pair_ready = true;
+    h->pair_depth_built = 2;
+    return NXS_OK;
+}
+
 int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
     drop_pool(h, h->patch_allocs);
     release_resident(h);  // (the resident loop's tables describe the patches that go now: the tables, the second exchange buffer, the claim on the device's slots)

@@ -667,6 +667,185 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
 }
 
 // ------------------------------------------------------------------------------------------------
+// The two-ring patches of k_substep_pair<HALO>: a rank of SEVERAL (own nodes first, ghosts behind them, one layer of ghost elements).  The patches are
+// cut over the OWN nodes; a ghost node is never solved here (its fan is not complete on this rank), so
+//   E_1 = every element touching an own node of the patch,        N_1 = their nodes (own nodes of other patches, ghosts),
+//   E_2 = E_1 + every element touching an OWN node of N_1,        N_2 = their nodes,
+// and the elements without any own node (they exist in a rank's mesh and the reference updates them) form patches of their own without nodes to solve.
+// flags per patch: bit 0 = takes part in the exchange at all (a ghost among N_2, or it sends or receives), bit 1 = an own node of it is sent,
+// bit 2 = a ghost in N_1 (it receives between the two sub-steps).  The patches come out band first (bits 1 | 2), then the rest of bit 0, then the interior.
+struct PairHaloPlan {
+    HostPatches2 hp;
+    std::vector<unsigned char> pflags;
+    int nG = 0, nBand = 0, P = 0;
+    size_t lds = 0;
+};
+
+inline bool build_pair_patches_mr(const std::vector<int> t[3], const unsigned char *ghost3, int Nn, int Ne, int No, int P, const std::vector<int> &order,
+                                  const std::vector<char> &sent /*[No] != 0: the node is in a send list*/, PairHaloPlan &out) {
+    if (P < 1 || No < 0 || No > Nn || (int)order.size() < No || (int)sent.size() < No) return false;
+    const int D = 2;
+    std::vector<int> off, adj;
+    node_fans(t, Nn, Ne, off, adj);
+    const int nNodePatches = (No + P - 1) / P;
+    std::vector<int> patch_of(Nn, -1);
+    for (int i = 0; i < No; ++i) patch_of[order[i]] = i / P;
+    std::vector<int> writer(Ne, -1), orphans;
+    for (int e = 0; e < Ne; ++e) {
+        int wq = -1;
+        for (int k = 0; k < 3; ++k) { const int q = patch_of[t[k][e]]; if (q >= 0 && (wq < 0 || q < wq)) wq = q; }
+        writer[e] = wq;
+        if (wq < 0) orphans.push_back(e);
+    }
+    const int EORPH = 1024;   // (two rounds of the 512-thread block: the limit of E_1)
+    const int nOrph = ((int)orphans.size() + EORPH - 1) / EORPH, nP = nNodePatches + nOrph;
+    for (size_t i = 0; i < orphans.size(); ++i) writer[orphans[i]] = nNodePatches + (int)(i / EORPH);
+
+    std::vector<std::vector<int>> pel(nP), pnd(nP);
+    std::vector<std::vector<unsigned short>> tri_l(nP);
+    std::vector<std::vector<std::vector<unsigned short>>> fan_l(nP);
+    std::vector<int> ncnt((size_t)nP * (D + 1), 0), ecnt((size_t)nP * D, 0);
+    std::vector<unsigned char> flags(nP, 0);
+    std::vector<int> emark(Ne, -1), eslot(Ne, -1), slot_of(Nn, -1);
+    int NDmax = 0, NSmax = 0, EDmax = 0, ESmax = 0, Wp = 0;
+    for (int q = 0; q < nP; ++q) {
+        auto &nd = pnd[q];
+        auto &el = pel[q];
+        int *nc = ncnt.data() + (size_t)q * (D + 1), *ec = ecnt.data() + (size_t)q * D;
+        if (q < nNodePatches) {
+            const int a = q * P, bnd = std::min(No, a + P);
+            for (int i = a; i < bnd; ++i) { slot_of[order[i]] = (int)nd.size(); nd.push_back(order[i]); if (sent[order[i]]) flags[q] |= 2; }
+        }
+        nc[0] = (int)nd.size();
+        int n_prev = 0, e_prev = 0;
+        for (int lev = 1; lev <= D; ++lev) {
+            std::vector<int> add;
+            if (q >= nNodePatches && lev == 1) {   // a patch of elements without an own node
+                const int a = (q - nNodePatches) * EORPH, bnd = std::min((int)orphans.size(), a + EORPH);
+                for (int i = a; i < bnd; ++i) { emark[orphans[i]] = q; add.push_back(orphans[i]); }
+            } else {
+                for (int i = n_prev; i < nc[lev - 1]; ++i) {
+                    if (nd[i] >= No) continue;     // a ghost is not solved here: its other elements are not needed (and not all on this rank)
+                    for (int j = off[nd[i]]; j < off[nd[i] + 1]; ++j) {
+                        const int e = adj[j];
+                        if (emark[e] != q) { emark[e] = q; add.push_back(e); }
+                    }
+                }
+            }
+            std::sort(add.begin(), add.end());
+            el.insert(el.end(), add.begin(), add.end());
+            ec[lev - 1] = (int)el.size();
+            std::vector<int> addn;
+            for (int l = e_prev; l < ec[lev - 1]; ++l)
+                for (int k = 0; k < 3; ++k) {
+                    const int n = t[k][el[l]];
+                    if (slot_of[n] == -1) { slot_of[n] = -2; addn.push_back(n); }
+                }
+            std::sort(addn.begin(), addn.end());
+            for (int n : addn) { slot_of[n] = (int)nd.size(); nd.push_back(n); if (n >= No) flags[q] |= (lev == 1 ? 5 : 1); }
+            nc[lev] = (int)nd.size();
+            n_prev = nc[lev - 1]; e_prev = ec[lev - 1];
+        }
+        if (flags[q] & 6) flags[q] |= 1;
+        const bool too_big = nd.size() > 1024 || el.size() > 8191;
+        if (!too_big) {
+            for (size_t l = 0; l < el.size(); ++l) eslot[el[l]] = (int)l;
+            auto &tl = tri_l[q];
+            tl.assign(4 * el.size(), 0);
+            for (size_t l = 0; l < el.size(); ++l)
+                for (int k = 0; k < 3; ++k) tl[4 * l + k] = (unsigned short)slot_of[t[k][el[l]]];
+            auto &fl = fan_l[q];
+            fl.assign(nc[1], {});
+            for (int i = 0; i < nc[1]; ++i) {
+                const int n = nd[i];
+                if (n >= No) continue;             // (never solved here: its row stays empty)
+                for (int j = off[n]; j < off[n + 1]; ++j) {  // ascending element id = the order of the serial scatter
+                    const int e = adj[j];
+                    int k = 0;
+                    while (t[k][e] != n) ++k;
+                    fl[i].push_back((unsigned short)((eslot[e] << 3) | (ghost3[3 * (size_t)e + k] ? 4 : 0) | k));
+                }
+                Wp = std::max(Wp, (int)fl[i].size());
+            }
+        }
+        for (int n : nd) slot_of[n] = -1;
+        if (too_big) return false;
+        NDmax = std::max(NDmax, nc[D]); NSmax = std::max(NSmax, nc[1]);
+        EDmax = std::max(EDmax, ec[1]); ESmax = std::max(ESmax, ec[0]);
+    }
+    // band first, then the other patches that take part in the exchange, then the interior
+    std::vector<int> perm;
+    for (int q = 0; q < nP; ++q) if (flags[q] & 6) perm.push_back(q);
+    const int nBand = (int)perm.size();
+    for (int q = 0; q < nP; ++q) if ((flags[q] & 1) && !(flags[q] & 6)) perm.push_back(q);
+    const int nG = (int)perm.size();
+    for (int q = 0; q < nP; ++q) if (!(flags[q] & 1)) perm.push_back(q);
+
+    HostPatches2 &hp = out.hp;
+    hp = HostPatches2{};
+    hp.nP = nP; hp.D = D;
+    hp.NDmax = (NDmax + 1) & ~1; hp.NSmax = (NSmax + 1) & ~1; hp.EDmax = (EDmax + 1) & ~1; hp.ESmax = std::max(2, (ESmax + 1) & ~1); hp.Wp = std::max(Wp, 1);
+    hp.ncnt.assign((size_t)nP * (D + 1), 0); hp.ecnt.assign((size_t)nP * D, 0);
+    hp.pnodes.assign((size_t)nP * hp.NDmax, 0);
+    hp.pelem.assign((size_t)nP * hp.EDmax, 0);
+    hp.ptri.assign((size_t)nP * hp.EDmax * 4, 0);
+    hp.pfan.assign((size_t)nP * hp.Wp * hp.NSmax, 0xFFFF);
+    out.pflags.assign(nP, 0);
+    for (int qn = 0; qn < nP; ++qn) {
+        const int q = perm[qn];
+        for (int i = 0; i <= D; ++i) hp.ncnt[(size_t)qn * (D + 1) + i] = ncnt[(size_t)q * (D + 1) + i];
+        for (int i = 0; i < D; ++i) hp.ecnt[(size_t)qn * D + i] = ecnt[(size_t)q * D + i];
+        out.pflags[qn] = flags[q];
+        std::copy(pnd[q].begin(), pnd[q].end(), hp.pnodes.begin() + (size_t)qn * hp.NDmax);
+        for (size_t l = 0; l < pel[q].size(); ++l) { const int e = pel[q][l]; hp.pelem[(size_t)qn * hp.EDmax + l] = (writer[e] == q) ? e : ~e; }
+        std::copy(tri_l[q].begin(), tri_l[q].end(), hp.ptri.begin() + (size_t)qn * hp.EDmax * 4);
+        for (size_t i = 0; i < fan_l[q].size(); ++i)
+            for (size_t k = 0; k < fan_l[q][i].size(); ++k) hp.pfan[(size_t)qn * hp.Wp * hp.NSmax + k * hp.NSmax + i] = fan_l[q][i][k];
+    }
+    out.nG = nG; out.nBand = nBand; out.P = P;
+    out.lds = pair_lds_of(hp);
+    return true;
+}
+
+// which patch size: the largest whose patches fit k_substep_pair twice on a CU (as plan_patches2 does for one rank); `hint`: the size kept for the mesh before
+inline std::string plan_pair_patches_mr(const MeshView &m, bool used_hilbert, int pair_nodes, int cus, const std::vector<char> &sent, PairHaloPlan &out, int hint = 0) {
+    if (m.No <= 0) return "no own nodes";
+    std::vector<int> order(m.No);
+    for (int i = 0; i < m.No; ++i) order[i] = i;
+    if (used_hilbert) hilbert_order(m.x0, m.y0, m.No, order);
+    const size_t cap = 80 * 1024;
+    auto own_max = [&]() { int v = 0; for (int q = 0; q < out.hp.nP; ++q) v = std::max(v, out.hp.ncnt[(size_t)q * 3]); return v; };
+    auto fits = [&](int PP) { return build_pair_patches_mr(m.t, m.ghost3, m.Nn, m.Ne, m.No, PP, order, sent, out) && out.lds <= cap && pair_kernel_fits(out.hp, own_max()); };
+    cus = std::max(cus, 1);
+    if (pair_nodes > 0) return fits(pair_nodes) ? "" : "patches of that size do not fit k_substep_pair (80 KB of LDS, three rounds of elements)";
+    const int hi0 = std::min(512, std::max(68, (int)((((long long)m.No + 2 * cus - 1) / (2 * cus) + 3) & ~3ll) + 4));
+    int lo = 64, hi = hi0, P = 0;
+    if (hint >= 64 && hint < hi0 && fits(hint)) { P = hint; hi = 0; }
+    else if (hint >= 68 && hint < hi0) hi = hint;
+    if (hi > 0) {
+        if (!fits(lo)) return "no patch size fits k_substep_pair (node numbering without locality?)";
+        int last_built = lo;
+        while (hi - lo > 4) {
+            const int mid = ((lo + hi) / 2 + 3) & ~3;
+            if (mid >= hi) break;
+            last_built = mid;
+            if (fits(mid)) lo = mid; else hi = mid;
+        }
+        P = lo;
+        if (last_built != P && !fits(P)) return "no patch size fits k_substep_pair";
+    }
+    // whole rounds where the mesh is one or two rounds of workgroups (as plan_patches2)
+    const int slots = 2 * cus, k = (out.hp.nP + slots - 1) / slots, P_fit = P;
+    if (k <= 2 && out.hp.nP > 0 && out.hp.nP != k * slots) {
+        int Pr = std::max(64, (int)((((long long)m.No + (long long)k * slots - 1) / ((long long)k * slots) + 3) & ~3ll));
+        bool tried = false;
+        for (int it = 0; it < 6 && Pr < P; ++it, Pr += 4) { tried = true; if (fits(Pr) && out.hp.nP <= k * slots) { P = Pr; break; } }
+        if (tried && P == P_fit && !fits(P)) return "no patch size fits k_substep_pair";
+    }
+    return "";
+}
+
+// ------------------------------------------------------------------------------------------------
 // Node-ring patches for the open-water smoother alone (k_smooth_multi on meshes that do not use k_substep_multi): patches of 256
 // consecutive own nodes (or consecutive along the Hilbert curve the sub-step patches were cut along), D rings of neighbours through
 // the NodalConnectivity rows.  Only the node levels and the rows in patch-local slots are filled in.

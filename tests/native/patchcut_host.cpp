@@ -327,6 +327,85 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     return 0;
 } catch (...) { return caught(msg, msg_cap); }
 
+// The two-ring patches of k_substep_pair<HALO> (several ranks): nxs_cut::plan_pair_patches_mr on this rank's mesh and send list, and every invariant the kernel
+// and its exchange rely on.  out: [0] nP, [1] nG, [2] nBand, [3] P, [4] LDS bytes, [5] sum |E_2|, [6] sum |N_2|, [7] patches of elements without an own node.
+int pc_pair_mr(const int32_t *indices, const uint8_t *ghost3, const double *x, const double *y, int Nn, int Ne, int No, int pair_nodes, int cus,
+               const int32_t *send_index, int n_send, int hilbert, int64_t *out, char *msg, int msg_cap) try {
+    put_msg(msg, msg_cap, "");
+    const Mesh m = make_mesh(indices, ghost3, x, y, Nn, Ne, No);
+    std::vector<char> sent((size_t)std::max(No, 1), 0);
+    for (int i = 0; i < n_send; ++i) { REQUIRE(send_index[i] >= 0 && send_index[i] < No, "send_index[%d]", i); sent[send_index[i]] = 1; }
+    PairHaloPlan plan;
+    const std::string why = plan_pair_patches_mr(m.view(), hilbert != 0, pair_nodes, cus, sent, plan);
+    if (!why.empty()) { put_msg(msg, msg_cap, why); return 1; }
+    const HostPatches2 &hp = plan.hp;
+    const int nP = hp.nP;
+    REQUIRE(hp.D == 2 && (int)plan.pflags.size() == nP && plan.nBand <= plan.nG && plan.nG <= nP, "counts: nP=%d nG=%d nBand=%d", nP, plan.nG, plan.nBand);
+    REQUIRE(plan.lds <= 80 * 1024 && hp.EDmax <= 3 * 512 && hp.ESmax <= 2 * 512 && hp.NSmax <= 2 * 512 && hp.NDmax <= 1024, "limits: lds=%zu EDmax=%d ESmax=%d NSmax=%d NDmax=%d", plan.lds, hp.EDmax, hp.ESmax, hp.NSmax, hp.NDmax);
+    REQUIRE(hp.pnodes.size() == (size_t)nP * hp.NDmax && hp.pelem.size() == (size_t)nP * hp.EDmax && hp.ptri.size() == (size_t)nP * hp.EDmax * 4 && hp.pfan.size() == (size_t)nP * hp.Wp * hp.NSmax, "array sizes");
+    std::vector<int> off, adj;
+    node_fans(m.t, m.Nn, m.Ne, off, adj);
+    std::vector<int> own(Nn, 0), written(Ne, 0), noted(Nn, 0), slot(Nn, -1);
+    long long sumE2 = 0, sumN2 = 0;
+    int orphan_patches = 0;
+    for (int q = 0; q < nP; ++q) {
+        const int *nc = hp.ncnt.data() + (size_t)q * 3, *ec = hp.ecnt.data() + (size_t)q * 2;
+        const int *pn = hp.pnodes.data() + (size_t)q * hp.NDmax;
+        const unsigned fl = plan.pflags[q];
+        REQUIRE(nc[0] <= 512 && nc[0] <= nc[1] && nc[1] <= nc[2] && ec[0] <= ec[1] && nc[2] <= hp.NDmax && nc[1] <= hp.NSmax && ec[1] <= hp.EDmax && ec[0] <= hp.ESmax, "patch %d: levels", q);
+        REQUIRE((q < plan.nBand) == ((fl & 6u) != 0) && (q < plan.nG) == ((fl & 1u) != 0), "patch %d: flags %u out of order (nBand=%d nG=%d)", q, fl, plan.nBand, plan.nG);
+        if (nc[0] == 0) ++orphan_patches;
+        sumE2 += ec[1]; sumN2 += nc[2];
+        bool sends = false, ghost1 = false, ghost2 = false;
+        for (int i = 0; i < nc[2]; ++i) {
+            const int n = pn[i];
+            REQUIRE(n >= 0 && n < Nn && slot[n] == -1, "patch %d slot %d: node %d (twice?)", q, i, n);
+            slot[n] = i;
+            if (i < nc[0]) { REQUIRE(n < No, "patch %d solves ghost %d as its own", q, n); own[n]++; sends = sends || sent[n]; }
+            if (n >= No) { if (i < nc[1]) { ghost1 = true; noted[n]++; } ghost2 = true; }
+        }
+        REQUIRE(((fl & 2u) != 0) == sends && ((fl & 4u) != 0) == ghost1 && ((fl & 1u) != 0) == (ghost2 || sends), "patch %d: flags %u but sends=%d ghost in N_1=%d in N_2=%d", q, fl, sends, ghost1, ghost2);
+        std::vector<char> in1(Ne, 0);   // (small meshes only: the test meshes)
+        for (int l = 0; l < ec[1]; ++l) {
+            const int raw = hp.pelem[(size_t)q * hp.EDmax + l], e = raw >= 0 ? raw : ~raw;
+            REQUIRE(e >= 0 && e < Ne, "patch %d: element %d", q, e);
+            if (l < ec[0]) { if (raw >= 0) written[e]++; in1[e] = 1; }
+            else REQUIRE(true, "-");
+            if (l > 0 && l != ec[0]) { const int rp = hp.pelem[(size_t)q * hp.EDmax + l - 1]; REQUIRE((rp >= 0 ? rp : ~rp) < e, "patch %d: level not ascending at slot %d", q, l); }
+            bool touches_own_of_patch = false;
+            for (int k = 0; k < 3; ++k) {
+                const int sl = hp.ptri[((size_t)q * hp.EDmax + l) * 4 + k];
+                REQUIRE(sl < nc[l < ec[0] ? 1 : 2] && pn[sl] == m.t[k][e], "patch %d element %d corner %d: slot %d", q, e, k, sl);
+                touches_own_of_patch = touches_own_of_patch || sl < nc[0];
+            }
+            if (nc[0] > 0) REQUIRE((l < ec[0]) == touches_own_of_patch, "patch %d: element %d in the wrong level", q, e);
+            else { bool any_own = false; for (int k = 0; k < 3; ++k) any_own = any_own || m.t[k][e] < No; REQUIRE(!any_own && l < ec[0], "patch %d (no own nodes) holds element %d with an own node", q, e); }
+        }
+        for (int i = 0; i < nc[1]; ++i) {   // own nodes of N_1: the complete fan, ascending, inside E_2 (E_1 for the patch's own nodes); ghosts: no row
+            const int n = pn[i];
+            int k = 0;
+            if (n < No)
+                for (int j = off[n]; j < off[n + 1]; ++j, ++k) {
+                    REQUIRE(k < hp.Wp, "patch %d node %d: fan longer than Wp", q, n);
+                    const unsigned ent = hp.pfan[(size_t)q * hp.Wp * hp.NSmax + (size_t)k * hp.NSmax + i];
+                    REQUIRE(ent != 0xFFFFu && (int)(ent >> 3) < (i < nc[0] ? ec[0] : ec[1]), "patch %d node %d: fan entry %d", q, n, k);
+                    const int raw = hp.pelem[(size_t)q * hp.EDmax + (ent >> 3)], e = adj[j], c = (int)(ent & 3u);
+                    REQUIRE((raw >= 0 ? raw : ~raw) == e && c < 3 && m.t[c][e] == n, "patch %d node %d: fan entry %d is not element %d", q, n, k, e);
+                    REQUIRE(((ent & 4u) != 0) == (m.ghost3[3 * (size_t)e + c] != 0), "patch %d node %d: ghost flag of element %d", q, n, e);
+                }
+            for (; k < hp.Wp; ++k) REQUIRE(hp.pfan[(size_t)q * hp.Wp * hp.NSmax + (size_t)k * hp.NSmax + i] == 0xFFFFu, "patch %d node %d: stale fan entry %d", q, n, k);
+        }
+        for (int i = 0; i < nc[0]; ++i)    // E_1 holds EVERY element of an own node
+            for (int j = off[pn[i]]; j < off[pn[i] + 1]; ++j) REQUIRE(in1[adj[j]], "patch %d: element %d of own node %d is not in E_1", q, adj[j], pn[i]);
+        for (int i = 0; i < nc[2]; ++i) slot[pn[i]] = -1;
+    }
+    for (int n = 0; n < No; ++n) REQUIRE(own[n] == 1, "own node %d is solved by %d patches", n, own[n]);
+    for (int n = No; n < Nn; ++n) REQUIRE(noted[n] >= 1, "ghost node %d is in no patch's N_1: nobody would note its velocity between the sub-steps", n);
+    for (int e = 0; e < Ne; ++e) REQUIRE(written[e] == 1, "element %d is written by %d patches", e, written[e]);
+    out[0] = nP; out[1] = plan.nG; out[2] = plan.nBand; out[3] = plan.P; out[4] = (int64_t)plan.lds; out[5] = sumE2; out[6] = sumN2; out[7] = orphan_patches;
+    return 0;
+} catch (...) { return caught(msg, msg_cap); }
+
 // The Hilbert order alone: any coordinates (NaN, infinities, all equal) must give a permutation
 int pc_hilbert(const double *x, const double *y, int n, int32_t *order_out, char *msg, int msg_cap) try {
     std::vector<int> order;

@@ -225,6 +225,31 @@ for kind in ("10km", "2km"):
 for lm_p in M.localize(M.make_mesh("2km"), 4):     # ... and the four parts of a 4-GPU run: one large patch per CU (k_substep_resident_big)
     r = run_cut(lm_p, want_resident=1, overlap=1)   # (with the interior-first lists: whole slices of 512 elements)
     assert r["res_ok"] == 1 and r["cut_big"] == 1 and r["nP"] <= 256, (lm_p.rank, r)
+# 4f. the two-ring patches of k_substep_pair<HALO> (two sub-steps per launch on several ranks): regular and ragged partitions (ghost elements without an own
+#     node -> patches of their own, corner nodes sent to several ranks, sent nodes that touch no ghost), explicit sizes, a numbering without locality
+cut.pc_pair_mr.argtypes = [IP, U8, D, D] + [C.c_int] * 5 + [IP, C.c_int, C.c_int, I64, C.c_char_p, C.c_int]
+
+
+def run_pair_mr(lm, pair_nodes=0, cus=256, hilbert=0, expect=0):
+    idx = i32(lm.indices); g3 = np.ascontiguousarray(lm.ghost_nodes, np.uint8)
+    x = np.ascontiguousarray(lm.coord_x, np.float64); y = np.ascontiguousarray(lm.coord_y, np.float64)
+    si = i32(lm.send_index)
+    st = np.zeros(8, np.int64); m_ = C.create_string_buffer(512)
+    rc = cut.pc_pair_mr(_abi.iptr(idx), g3.ctypes.data_as(U8), _abi.dptr(x), _abi.dptr(y), lm.num_nodes, lm.num_elements, lm.local_ndof, pair_nodes, cus,
+                        _abi.iptr(si) if si.size else None, si.size, hilbert, st.ctypes.data_as(I64), m_, 512)
+    assert rc == expect, (rc, m_.value.decode())
+    return dict(zip(("nP", "nG", "nBand", "P", "lds", "sumE2", "sumN2", "orphan_patches"), st.tolist()))
+
+
+for kind, nparts, seed in (("toy", 3, 11), ("toy", 4, 12), ("small", 3, 13), ("small", 4, 14), ("40km", 4, 15)):
+    gmk = cases.global_mesh(kind)
+    for lm_r in M.localize(gmk, nparts, elem_part=cases.ragged_partition(gmk, nparts, seed)):
+        r = run_pair_mr(lm_r); run_pair_mr(lm_r, pair_nodes=64); run_pair_mr(lm_r, pair_nodes=200, hilbert=1); run_pair_mr(lm_r, cus=8)
+        assert r["nBand"] >= 1 and r["nG"] >= r["nBand"], r
+for nparts in (2, 3, 8):
+    for lm_r in M.localize(cases.global_mesh("10km"), nparts):
+        r = run_pair_mr(lm_r)
+        assert 1 <= r["nBand"] <= r["nG"] < r["nP"], r
 # 4e. the Hilbert order on coordinates nobody should pass: NaN, infinities, one point, all equal, empty
 msg = C.create_string_buffer(256)
 for xs, ys in ((np.array([0., np.nan, 1., np.inf, -np.inf, 2.]), np.array([np.nan, 0., 1., 5., -5., np.inf])), (np.zeros(7), np.zeros(7)),

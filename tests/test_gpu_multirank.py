@@ -264,6 +264,25 @@ def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rp
             assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
 
 
+@pytest.mark.parametrize("world,kind,rpp,nsteps,over", [(2, "small", 1, 1, {}), (3, "small", 1, 1, {"ragged_seed": 1}), (2, "40km", 2, 2, {"dynamics_type": 3}),
+                                                        (3, "small", 1, 1, {"ragged_seed": 5, "dynamics_type": 3}), (4, "10km", 2, 2, {}), (3, "toy", 1, 1, {"ragged_seed": 7})])
+def test_two_sub_steps_per_launch_on_several_ranks(world, kind, rpp, nsteps, over, tmp_path):
+    """k_substep_pair<HALO> (option pair_regs = 1 forces it on these small partitions; automatic above 65 k nodes per rank): a rank's sub-step loop is 60
+    launches of TWO sub-steps, the stresses between them in registers, BOTH updateGhosts of a launch inside it -- the patches along the partition boundary
+    store their first velocities into the neighbours' mailboxes, wait for the neighbours' and go on; every other patch runs the single-rank body.  Bitwise
+    equal to one kernel per sub-step with separate push / pull kernels, and within 1e-10 of the multi-rank oracle: regular and ragged partitions (ghost
+    elements without an own node, sent nodes that touch no ghost, every rank a neighbour of every other), BBM and EVP, one and two steps (the second starts
+    from the velocity buffer again), two ranks per process."""
+    reps = _run(world, kind, nsteps, tmp_path, "ipc", over=dict(over, options={"pair_regs": 1}), ranks_per_proc=rpp)
+    for r in reps:
+        assert r["ok"], r
+        assert r["fused_equals_separate"] is True, r
+        assert r["launches_fused"] == 60 and r["launches_separate"] > 120, r
+        assert r["crash"] == 0
+        for k, e in r["errs"].items():
+            assert e <= 1e-9 if over.get("dynamics_type") else e <= 1e-10, (r["rank"], k, e)
+
+
 @pytest.mark.parametrize("world,kind,rpp,over,band", [(2, "40km", 2, {}, 0), (2, "40km", 2, {}, 16), (3, "40km", 1, {"ragged_seed": 3}, 24), (4, "10km", 2, {"dynamics_type": 3}, 32)])
 def test_small_patches_along_the_partition_boundary_do_not_change_a_bit(world, kind, rpp, over, band, tmp_path):
     """Option band_patch_nodes (default 48): in the cut for the resident loop of several ranks the own nodes that share an element with a ghost node
