@@ -1697,8 +1697,12 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
             __syncthreads();
             ticket_first();
         }
+        // EVERY band patch waits for the neighbours' flags >= x + 1 before it goes on: a receiver because its ghosts arrive with them -- and a patch that only sends
+        // (its sent nodes touch no ghost of this rank: they are ghosts of a neighbour through an element none of whose nodes the neighbour owns) because its second
+        // store goes into the half (x+1)&1 = (x-1)&1 of the neighbour's mailbox, which the neighbour's G patches stage from (and its k_halo_pull at the end of a
+        // step reads) until that flag says they are done with it
+        wait_flags(xseq + 1ull);
         if (flg & 4u) {
-            wait_flags(xseq + 1ull);   // the neighbours' first velocities have landed in half x & 1
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int i = t + r * T;
