@@ -587,41 +587,50 @@ def aux_regrid(gm, with_cpu=True):
 
 
 def aux_partition_floor(args, local_rank, torch, S):
-    """The compute floor of strong scaling, measured on THIS one GPU: single-rank meshes of 1/2, 1/4 and 1/8 of the 2 km mesh's triangles (what
-    a rank holds on 2 / 4 / 8 GPUs), no halo exchange.  The 1/8 mesh is one round of resident workgroups: the whole sub-step loop runs as one
-    launch (option fused = 4) when the device is free, else one launch per sub-step."""
-    from nextsim_amd import dynamics, forcing as F, mesh as M
+    """The compute floor of strong scaling, measured on THIS one GPU with the SEVERAL-RANK builds of the kernels: rank 0's partition of the 2 km mesh as
+    `bench.py --gpus N` cuts it (N = 2, 4, 8: own nodes + one layer of ghosts), alone on the device, its mailboxes connected to themselves
+    (dynamics.ipc_loopback: every wait of the exchange inside the kernels is satisfied by the rank's own stores -- no neighbour, no xGMI; the ghosts receive
+    meaningless velocities, so only times are taken from these runs).  Two ways to run the sub-step loop: the exchange inside one launch per one or two
+    sub-steps (option fused = 3: k_substep_pair<HALO> above 65 k nodes per rank, else k_substep_fused<HALO>) and the whole loop as ONE resident launch
+    (fused = 4) where the partition fits one round of workgroups."""
+    from nextsim_amd import dynamics
     out = []
-    for share, h_edge in ((2, 7800.), (4, 11000.), (8, 15600.)):
-        gm = M.make_disc_mesh(h_edge, seed=M.SEED, name="custom")
-        p, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
-        g = F.global_fields(gm, p, "arctic", C_fix, C_alea)
-        lm = M.localize(gm, 1)[0]
-        f = F.localize_fields(g, lm, gm.num_nodes)
-        row = {"share_of_2km_mesh": f"1/{share}", "elements": gm.num_elements}
-        for name, fused in (("one_launch_per_substep", 1), ("resident_one_launch_per_step", 4)):
+    for share in (2, 4, 8):
+        gm, p, lm, f = build_case("2km", share, 0)
+        row = {"share_of_2km_mesh": f"1/{share}", "elements": int(lm.num_elements), "own_nodes": int(lm.local_ndof), "ghost_nodes": int(lm.num_nodes - lm.local_ndof)}
+        for name, opts in (("exchange_inside_the_substep_kernels", {"fused": 3, "halo_fused": 1}), ("resident_one_launch_per_step", {"resident_wide": 1, "fused": 4, "halo_fused": 1})):
             fe = dynamics.FiniteElementDynamics(p, device=local_rank)
-            fe.set_option("fused", fused)
-            fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
-            for _ in range(3):
-                fe.step()
-            fe.synchronize(); fe.set_option("timing_reset", 1)
-            n = 40 if share > 2 else 20
-            torch.cuda.synchronize(); t0 = time.perf_counter()
-            for _ in range(n):
-                fe.step()
-            fe.synchronize(); torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            launches = fe.timing()["substep_launches"]
-            ok = fe.checkFieldsFast() == 0
-            fe.close()
-            if fused == 4 and launches != 1:
-                row[name] = None   # the partition does not fit one round of resident workgroups
-                continue
-            row[name] = {"ms_per_step": dt / n * 1e3, "value": gm.num_elements * S * n / dt, "unit": "element-updates/s", "fields_ok": ok}
+            try:
+                fe.set_mesh(lm)
+                if not fe.ipc_loopback():
+                    row[name] = {"error": "this partition's halo lists cannot be looped back"}
+                    continue
+                for k, v in opts.items():
+                    fe.set_option(k, v)
+                fe.set_option("prepare", 1)
+                fe.put_state(f); fe.set_forcing(f)
+                for _ in range(2):
+                    fe.step()
+                fe.synchronize(); fe.put_state(f); fe.set_option("timing_reset", 1)
+                n = 10
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(n):
+                    fe.step()
+                fe.synchronize(); torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+                tm, tr = fe.timing(), fe.traffic_model()
+                if opts["fused"] == 4 and tm["substep_launches"] != 1:
+                    row[name] = None   # the partition does not fit one round of resident workgroups
+                    continue
+                row[name] = {"ms_per_step": dt / n * 1e3, "value": gm.num_elements / share * S * n / dt, "unit": "element-updates/s of this rank's share", "kernel": tr["substep_kernel_name"],
+                             "substeps_per_launch": tr["substeps_per_launch"], "substeps_ms": tm["substeps_ms"], "smoother_ms": tm["smoother_ms"], "prep_ms": tm["prep_ms"], "update_ms": tm["update_ms"]}
+            except dynamics.NxsError as e:
+                row[name] = {"error": str(e)[:300]}
+            finally:
+                fe.close()
         out.append(row)
-    return {"workload": "single-rank disc meshes with 1/2, 1/4 and 1/8 of the 2 km mesh's triangles, same state and forcing, no halo exchange: what "
-                        "one rank of 2 / 4 / 8 computes per step -- the ceiling of strong scaling is (ms_per_step of the whole mesh) / (this)",
+    return {"workload": "rank 0's partition of the 2 km mesh for 2 / 4 / 8 ranks, the several-rank kernels with the mailboxes looped back (no neighbour, no xGMI): what one rank "
+                        "computes per step -- the ceiling of strong scaling is (ms_per_step of the whole mesh) / (this)",
             "meshes": out}
 
 
