@@ -216,22 +216,24 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
     rank, the bits of (c), and the fastest of those is used (NXS_HALO_VARIANT=resident|inkernel|separate forces one)."""
     import numpy as np
     from nextsim_amd import dynamics
-    variants = {"resident": (4, 1, " + exchange inside ONE resident launch per step"),
-                "resident_overlap": (4, 1, " + exchange inside ONE resident launch per step, interior elements computed under the exchange"),
-                "inkernel": (3, 1, " + exchange inside the sub-step kernel"),
-                "separate": (3, 0, ", separate push/pull kernels")}
+    # name: (fused, halo_fused, pair_regs, text)
+    variants = {"resident": (4, 1, -1, " + exchange inside ONE resident launch per step"),
+                "resident_overlap": (4, 1, -1, " + exchange inside ONE resident launch per step, interior elements computed under the exchange"),
+                "inkernel_pair": (3, 1, 1, " + both exchanges of TWO sub-steps inside one launch (k_substep_pair<HALO>)"),
+                "inkernel": (3, 1, 0, " + exchange inside the sub-step kernel (one launch per sub-step)"),
+                "separate": (3, 0, 0, ", separate push/pull kernels")}
 
     def select(name):
         opts = {"resident_wide": 1 if own_device else 0,   # (only matters where one workgroup per CU covers a rank's partition)
-                "resident_overlap": 1 if name == "resident_overlap" else 0, "fused": variants[name][0], "halo_fused": variants[name][1]}
-        for k in ("resident_wide", "resident_overlap", "fused", "halo_fused"):
+                "resident_overlap": 1 if name == "resident_overlap" else 0, "fused": variants[name][0], "halo_fused": variants[name][1], "pair_regs": variants[name][2]}
+        for k in ("resident_wide", "resident_overlap", "pair_regs", "fused", "halo_fused"):
             fe.set_option(k, opts[k])
         fe._bench_options = opts   # (what the PMC child run of this partition is given)
 
     force = os.environ.get("NXS_HALO_VARIANT")
     if force in variants:
         select(force)
-        return variants[force][2] + " (forced)", {"kept_variant": force, "forced": True, "variants": {}}
+        return variants[force][3] + " (forced)", {"kept_variant": force, "forced": True, "variants": {}}
 
     def agree(flag):   # every rank calls this the same number of times, whatever happened to it
         t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64)
@@ -244,7 +246,7 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
         return out
 
     # (NXS_BENCH_TRY_RESIDENT=1: rehearsal on a shared device with a mesh small enough for every rank's workgroups to be resident)
-    order = (["resident", "resident_overlap"] if (own_device or os.environ.get("NXS_BENCH_TRY_RESIDENT") == "1") else []) + ["inkernel", "separate"]
+    order = (["resident", "resident_overlap"] if (own_device or os.environ.get("NXS_BENCH_TRY_RESIDENT") == "1") else []) + ["inkernel_pair", "inkernel", "separate"]
     results = {}
     report = {n: {"status": "not tried"} for n in variants}   # -> the JSON line (config.halo): per variant ms/step, bits, errors
     for name in order:
@@ -263,6 +265,9 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
             if name.startswith("resident") and fe.timing()["substep_launches"] != 1:
                 mine = False                       # the library fell back (partition too large for one round of workgroups)
                 err_text = "the library fell back to one kernel per sub-step (partition does not fit one round of resident workgroups, or the device's slots are taken)"
+            if name == "inkernel_pair" and fe.traffic_model()["substep_kernel_name"] != "k_substep_pair":
+                mine = False                       # (an odd number of sub-steps, patches that do not fit, the device's slots taken: it ran as "inkernel")
+                err_text = "the library fell back to one kernel per sub-step (two sub-steps per launch not possible on this partition, or the device's slots are taken)"
         except dynamics.NxsError as e:
             print(f"[bench rank {rank}] halo variant {name}: {e}", file=sys.stderr, flush=True)
             mine = False
@@ -283,8 +288,8 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
                 print(f"[bench rank {rank}] re-connecting the mailboxes after {name}: {e}", file=sys.stderr, flush=True)
     fe.set_option("fused", 3)
     if "separate" not in results:
-        fe.set_option("halo_fused", 0)
-        fe._bench_options = {"fused": 3, "halo_fused": 0}
+        fe.set_option("halo_fused", 0); fe.set_option("pair_regs", 0)
+        fe._bench_options = {"fused": 3, "halo_fused": 0, "pair_regs": 0}
         return (", separate push/pull kernels (its own check step failed on some rank: see stderr)",
                 {"kept_variant": "separate", "forced": False, "variants": report, "note": "the check step of the separate kernels failed on some rank"})
     ref = results["separate"][0]
@@ -298,7 +303,7 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
     select(best)
     note = "; ".join(f"{n} {results[n][1] * 500:.2f} ms/step" + ("" if ok[n] else " (bits differ: rejected)") for n in order if n in results)
     dropped = [n for n in order if n not in results]
-    return (variants[best][2] + f" (kept variants bit-identical to the separate kernels; {note}" + (f"; failed: {', '.join(dropped)}" if dropped else "") + ")",
+    return (variants[best][3] + f" (kept variants bit-identical to the separate kernels; {note}" + (f"; failed: {', '.join(dropped)}" if dropped else "") + ")",
             {"kept_variant": best, "forced": False, "variants": report})
 
 
@@ -590,15 +595,16 @@ def aux_partition_floor(args, local_rank, torch, S):
     """The compute floor of strong scaling, measured on THIS one GPU with the SEVERAL-RANK builds of the kernels: rank 0's partition of the 2 km mesh as
     `bench.py --gpus N` cuts it (N = 2, 4, 8: own nodes + one layer of ghosts), alone on the device, its mailboxes connected to themselves
     (dynamics.ipc_loopback: every wait of the exchange inside the kernels is satisfied by the rank's own stores -- no neighbour, no xGMI; the ghosts receive
-    meaningless velocities, so only times are taken from these runs).  Two ways to run the sub-step loop: the exchange inside one launch per one or two
-    sub-steps (option fused = 3: k_substep_pair<HALO> above 65 k nodes per rank, else k_substep_fused<HALO>) and the whole loop as ONE resident launch
-    (fused = 4) where the partition fits one round of workgroups."""
+    meaningless velocities, so only times are taken from these runs).  Three ways to run the sub-step loop: both exchanges of two sub-steps inside one launch
+    (k_substep_pair<HALO>), one launch per sub-step with its exchange inside (k_substep_fused<HALO>), and the whole loop as ONE resident launch (fused = 4)
+    where the partition fits one round of workgroups -- the candidates bench.py --gpus N times on the real machine."""
     from nextsim_amd import dynamics
     out = []
     for share in (2, 4, 8):
         gm, p, lm, f = build_case("2km", share, 0)
         row = {"share_of_2km_mesh": f"1/{share}", "elements": int(lm.num_elements), "own_nodes": int(lm.local_ndof), "ghost_nodes": int(lm.num_nodes - lm.local_ndof)}
-        for name, opts in (("exchange_inside_the_substep_kernels", {"fused": 3, "halo_fused": 1}), ("resident_one_launch_per_step", {"resident_wide": 1, "fused": 4, "halo_fused": 1})):
+        for name, opts in (("two_substeps_per_launch", {"pair_regs": 1, "fused": 3, "halo_fused": 1}), ("one_launch_per_substep", {"pair_regs": 0, "fused": 3, "halo_fused": 1}),
+                           ("resident_one_launch_per_step", {"resident_wide": 1, "fused": 4, "halo_fused": 1})):
             fe = dynamics.FiniteElementDynamics(p, device=local_rank)
             try:
                 fe.set_mesh(lm)
@@ -632,6 +638,21 @@ def aux_partition_floor(args, local_rank, torch, S):
     return {"workload": "rank 0's partition of the 2 km mesh for 2 / 4 / 8 ranks, the several-rank kernels with the mailboxes looped back (no neighbour, no xGMI): what one rank "
                         "computes per step -- the ceiling of strong scaling is (ms_per_step of the whole mesh) / (this)",
             "meshes": out}
+
+
+def cpu_quota():
+    """CPUs' worth of time the container may use (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: a GPU box shows all the host's CPUs in its affinity
+    mask but may only burn a share of them -- threads beyond the quota do not add throughput, and spinning ones take it away from the working ones."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def host_description():
@@ -676,12 +697,16 @@ def cpu_baseline(kind, nsteps=1, nsteps_threaded=3):
     del r
     host_cores, usable, model = host_description()
     out = {"value": single, "cores": 1, "seconds": dt1, "single_core_value": single, "single_seconds": dt1, "single_steps": nsteps,
-           "host_cores": host_cores, "usable_cores": usable, "cpu_model": model, "threaded_steps": 0, "thread_counts_tried": {}, "placement": None}
+           "host_cores": host_cores, "usable_cores": usable, "cpu_model": model, "threaded_steps": 0, "thread_counts_tried": {}, "placement": None, "cpu_quota_cores": None}
     if usable > 1:
         p2, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
         g = F.global_fields(gm, p2, "arctic", C_fix, C_alea)
-        counts, c = [], min(usable, 512)
-        while c >= 2 and (not counts or c >= 16):
+        quota = cpu_quota()
+        out["cpu_quota_cores"] = quota
+        # every usable CPU first -- or, where the container has a CPU quota below that, twice the quota (SMT siblings / a little oversubscription) -- then halves
+        top = min(usable, 512) if not quota else max(2, min(usable, 512, int(2 * quota + 0.5)))
+        counts, c = [], top
+        while c >= 2 and (not counts or c >= 8):
             counts.append(c); c //= 2
         best = None
         budget_t0 = time.perf_counter()
@@ -923,7 +948,7 @@ def main():
                           f"thread counts {list(cb['thread_counts_tried'])} (this process may run on "
                           f"{cb['usable_cores']} of the host's {cb['host_cores']} logical CPUs, {cb['cpu_model']}; every usable CPU is tried first, fewer while that is not slower): "
                           f"the best, {cb['cores']} thread(s), is `value` ({cb['seconds']:.1f} s)",
-                "thread_counts_tried": cb["thread_counts_tried"], "placement": cb["placement"],
+                "thread_counts_tried": cb["thread_counts_tried"], "placement": cb["placement"], "cpu_quota_cores": cb.get("cpu_quota_cores"),
                 "model_GBps": cb["model_GBps"], "host_memory": cb["host_memory"],
             }
         except Exception as e:  # noqa: BLE001 -- the GPU line must survive a host-side failure of the baseline leg

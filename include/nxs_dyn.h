@@ -363,10 +363,12 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)
  *   "patch_nodes"  own nodes per patch of the fused kernel, 64..1024; 0 = automatic (whole rounds of resident workgroups)
  *   "pair_nodes"   the same for the several-sub-steps kernels, 16..1024; 0 = automatic
- *   "pair_regs"    single rank, not mEVP, an even number of sub-steps: TWO sub-steps per launch with the stresses between them in registers and two
+ *   "pair_regs"    not mEVP, an even number of sub-steps: TWO sub-steps per launch with the stresses between them in registers and two
  *                  workgroups per CU (k_substep_pair: stress, damage, element constants and nodal inputs cross HBM once per two sub-steps; 2 km
- *                  mesh 6.62 -> 5.54 ms per step, the same bits): -1 (default) = on meshes of more than 65 k nodes (smaller ones run four
- *                  sub-steps per launch, one patch per CU), 0 = never, 1 = wherever "fused" 2 runs at depth 2
+ *                  mesh 6.62 -> 5.5 ms per step, the same bits).  Several ranks (device-direct mailboxes, "halo_fused" 1): both updateGhosts of a launch
+ *                  happen inside it -- the patches along the partition boundary store their first velocities into the neighbours' mailboxes, wait for
+ *                  the neighbours' and go on, every other patch runs the single-rank body.  -1 (default) = on meshes / partitions of more than 65 k nodes
+ *                  (smaller single-rank meshes run four sub-steps per launch, one patch per CU), 0 = never, 1 = wherever it can run
  *   "um_ring"      apply M_UM/M_UT += dt*M_VT every n sub-steps from a ring of velocity buffers, 1..128;
  *                  0 = automatic (once per step on meshes that stream from HBM, every sub-step on cache-resident ones)
  *   "nt_mask"      non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants); -1 = automatic
@@ -381,7 +383,9 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  element constants, rlmass, C_bu, grad_ssh, fcor) that only the fused = 0 kernels and nxs_dyn_debug_array read;
  *                  default 0: with fused != 0 the step writes its records only
  *   "halo_fused"   device-direct transport only: 1 = updateGhosts inside the fused sub-step kernel (default),
- *                  0 = separate push / pull kernels */
+ *                  0 = separate push / pull kernels
+ *   "ipc_pad"      before nxs_dyn_ipc_export: the mailbox gets room for at least this many received nodes (profiling aid: a rank whose mailbox is connected
+ *                  to itself stores its own, possibly longer, send segments into it) */
 NXS_API int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);
 
 /* Test door: copies a named internal work array (rlmass, node_mass, C_bu, grad_ssh, fcor, VTM, shape,

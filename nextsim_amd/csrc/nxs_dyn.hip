@@ -150,6 +150,7 @@ struct nxs_dyn_handle {
     void *ipc_block = nullptr;             // my mailbox allocation (exported)
     size_t ipc_block_bytes = 0;
     bool ipc_uncached = false;             // the mailbox is MTYPE_UC memory (what the fence-less in-kernel exchange relies on)
+    int ipc_pad = 0, ipc_cap = 0;          // option "ipc_pad" / the number of received nodes the exported mailbox has room for
     std::vector<void *> ipc_peer_base;     // opened peer mailboxes (to close)
     std::vector<void *> ipc_local_peers;   // mailboxes of other handles of THIS process this handle stores through (counted in g_mailboxes)
     std::vector<void *> ipc_allocs;
@@ -765,6 +766,10 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         }
         return NXS_OK;
     }
+    if (!std::strcmp(key, "ipc_pad")) {   // before nxs_dyn_ipc_export: room for at least this many received nodes (dynamics.ipc_loopback: a rank's send segments stored into its own mailbox)
+        if (value < 0 || value > (1 << 28)) return fail(h, NXS_ERR_INVALID, "ipc_pad out of range");
+        h->ipc_pad = (int)value; return NXS_OK;
+    }
     if (!std::strcmp(key, "pin_host")) { h->pin_host = value != 0; if (!h->pin_host) unpin_all(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_fused")) { h->halo_fused = value != 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "patch_nodes")) {
@@ -1142,7 +1147,9 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) try {
     release_graph(h);
     ipc_release(h);
     const int nr = (int)h->recv_procs.size();
-    const size_t tr = (size_t)h->recv_offsets[nr];
+    // (option "ipc_pad": a mailbox for at least that many received nodes -- the looped-back profiling set-up stores its own send segments into it)
+    const size_t tr = std::max((size_t)h->recv_offsets[nr], (size_t)std::max(h->ipc_pad, 0));
+    h->ipc_cap = (int)tr;
     const size_t bytes = ipc_layout(tr, nr).total * sizeof(double);
     // uncached (MTYPE_UC) device memory: neither my L2 nor a neighbour's can hold a stale copy of a mailbox line or a flag.
     // The kernels rely on that: a receiver takes no acquire after its flag wait and a sender releases once per launch.  With
@@ -1242,7 +1249,7 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
         sseg[k] = mb + pl.slots + 2 * (size_t)peer_recv_offset[k];
     }
     IpcDev &d = h->ipc;
-    const size_t tr = (size_t)h->recv_offsets[nr];
+    const size_t tr = (size_t)h->ipc_cap;   // the capacity the mailbox was exported with (the received nodes, or option "ipc_pad" if that is more)
     const IpcLayout ml = ipc_layout(tr, nr);
     d.mailbox = static_cast<double *>(h->ipc_block);
     d.flags = reinterpret_cast<unsigned long long *>(d.mailbox + ml.flags);

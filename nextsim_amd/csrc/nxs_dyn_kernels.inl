@@ -1472,31 +1472,20 @@ struct PairHalo {
     int from_mailbox;              // 0: first launch of a step, the ghosts are in the velocity buffer
     unsigned int *tickets;         // [0]: G patches past their first duty, [32]: band patches done, [64..65] (64 bits): the last sequence whose first exchange is published
 };
-template <int T, bool POW4, int NTM, bool HALO = false>
-__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout,
-                                                                                                const HaloFused *__restrict__ hfp, PairHalo ph) {
+template <int T, bool POW4, int NTM, bool HALO>
+__device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &pp, const DevState &s, const DevWork &w, const DevParams &p, const PingPong &b, const VTOut &vout,
+                                          const HaloFused *__restrict__ hfp, const PairHalo &ph, const int blk, const unsigned flg) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int NDm = pp.NDmax, EDm = pp.EDmax;
     double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm;
     d2 *lF2 = reinterpret_cast<d2 *>(ly + NDm);  // [3][EDm] + a pair of zeros
     const unsigned ZIDX = 3u * (unsigned)EDm;
-    int blk;
-    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused); several ranks: the G patches lead the grid, the remap acts inside each group
-        auto xcd_remap = [](const int pos, const int n) { const int q = n >> 3, r = n & 7, x = pos & 7; return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3); };
-        const int pos = (int)blockIdx.x, n = (int)gridDim.x;
-        if (HALO) blk = pos < ph.nG ? xcd_remap(pos, ph.nG) : ph.nG + xcd_remap(pos - ph.nG, n - ph.nG);
-        else blk = xcd_remap(pos, n);
-    }
     const int t = threadIdx.x, Nn = m.Nn;
     NXS_STAMP(0);
     if (t == 0) lF2[ZIDX] = d2{0., 0.};
-    unsigned flg = 0u;                 // this patch's duties in the exchange (uniform over the workgroup)
     unsigned long long xseq = 0ull;
-    if (HALO) {
-        flg = ph.pflags[blk];
-        if (flg & 1u) xseq = *hfp->ipc.seq_push;   // (interior patches never look at it: the last band patch advances it while they run)
-    }
+    if (HALO && (flg & 1u)) xseq = *hfp->ipc.seq_push;   // (interior patches never look at it: the last band patch advances it while they run)
     // the neighbours' flags: one lane waits, bounded like every other wait of the transport
     auto wait_flags = [&](const unsigned long long want) {
         if (t == 0) {
@@ -1780,6 +1769,26 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         }
     }
     NXS_STAMP(4);
+}
+
+
+// the kernel: which patch, and -- several ranks -- whether it takes part in the exchange: the patches that do not (all but the few along the partition boundary)
+// run the single-rank body, so the exchange's tables and tickets cost them no register (the resident kernels branch the same way)
+template <int T, bool POW4, int NTM, bool HALO = false>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout,
+                                                                                                const HaloFused *__restrict__ hfp, PairHalo ph) {
+    int blk;
+    {   // consecutive patches are neighbours in space: keep them on one XCD (see k_substep_fused); several ranks: the G patches lead the grid, the remap acts inside each group
+        auto xcd_remap = [](const int pos, const int n) { const int q = n >> 3, r = n & 7, x = pos & 7; return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (pos >> 3); };
+        const int pos = (int)blockIdx.x, n = (int)gridDim.x;
+        if (HALO) blk = pos < ph.nG ? xcd_remap(pos, ph.nG) : ph.nG + xcd_remap(pos - ph.nG, n - ph.nG);
+        else blk = xcd_remap(pos, n);
+    }
+    if (HALO) {
+        const unsigned flg = ph.pflags[blk];   // this patch's duties in the exchange (uniform over the workgroup)
+        if (flg & 1u) { pair_body<T, POW4, NTM, true>(m, pp, s, w, p, b, vout, hfp, ph, blk, flg); return; }
+    }
+    pair_body<T, POW4, NTM, false>(m, pp, s, w, p, b, vout, hfp, ph, blk, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -284,8 +284,10 @@ class FiniteElementDynamics:
         ns, nr = len(lm.send_procs), len(lm.recv_procs)
         tr = int(lm.recv_offsets[-1]) if nr else 0
         seg = np.diff(lm.send_offsets) if ns else np.zeros(0, int)
-        if ns == 0 or ns < nr or (seg > tr).any():
+        if ns == 0 or ns < nr:
             return False
+        tr = max(tr, int(seg.max()))          # (every send segment is stored at offset 0 of the looped-back mailbox: room for the longest)
+        self.set_option("ipc_pad", tr)
         blob = C.create_string_buffer(IPC_BLOB_BYTES)
         self._chk(self.L.nxs_dyn_ipc_export(self.h, blob))
         bbuf = C.create_string_buffer(blob.raw * ns, IPC_BLOB_BYTES * ns)
