@@ -422,16 +422,28 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     PSTAMP(1);
     // ---- k_prep_elements (FE.cpp:10235-10308), two elements of this thread at a time: their indices, then all their fields, then the arithmetic --
     // element by element the two dependent load levels would be paid once per element
-    constexpr int NB = 2;
+#ifndef NXS_PREP_NB
+#define NXS_PREP_NB 1   // elements of a thread in flight at a time: 2 spills (28 B of scratch per lane) and is no faster once the next round's indices are prefetched
+#endif
+    constexpr int NB = NXS_PREP_NB;
+    // (the indices of the round after this one are asked for before this round's fields: a round then starts with its field loads instead of an index hop)
+    int eraw_next[NB];
+    ushort4 trs_next[NB];
+    auto load_indices = [&](const int l0) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int l = l0 + j * T;
+            eraw_next[j] = 0; trs_next[j] = make_ushort4(0, 0, 0, 0);
+            if (l < nE) { eraw_next[j] = pp.pelem[(size_t)blk * Emax + l]; trs_next[j] = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + l]; }
+        }
+    };
+    load_indices(t);
     for (int l0 = t; l0 < nE; l0 += NB * T) {
         int eraw[NB];
         ushort4 trs[NB];
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int l = l0 + j * T;
-            eraw[j] = 0; trs[j] = make_ushort4(0, 0, 0, 0);
-            if (l < nE) { eraw[j] = pp.pelem[(size_t)blk * Emax + l]; trs[j] = reinterpret_cast<const ushort4 *>(pp.ptri)[(size_t)blk * Emax + l]; }
-        }
+        for (int j = 0; j < NB; ++j) { eraw[j] = eraw_next[j]; trs[j] = trs_next[j]; }
+        if (l0 + NB * T < nE) load_indices(l0 + NB * T);
         double f_conc[NB], f_thick[NB], f_snow[NB], f_cy[NB], f_hy[NB], f_hsy[NB], f_depth[NB], f_drag[NB], f_dragy[NB], f_theal[NB], f_coh[NB];
 #pragma unroll
         for (int j = 0; j < NB; ++j) {

@@ -10,4 +10,4 @@ for lib in "$@"; do
   NXS_DYN_LIBRARY=$GRAFT_REPO_ROOT/nextsim_amd/csrc/$lib timeout -k 10 300 python3 scripts/run_steps.py --mesh 2km --steps $STEPS ${AB_ARGS} >> gpurun_out/${TAG}.log 2>&1 || exit 1
 done
 done
-grep -E "^==|ms/step" gpurun_out/${TAG}.log | sed -E 's/, timing.*substeps_ms.: ([0-9.]+).*ring_flush_ms.: ([0-9.]+).*/ substeps \1 flush \2/' | cut -c1-200
+grep -E "^==|ms/step" gpurun_out/${TAG}.log | sed -E "s/shape_mem.*triangles, //; s/element-updates.*prep_ms.: ([0-9.]+).*substeps_ms.: ([0-9.]+).*ring_flush_ms.: ([0-9.]+).*/prep \1 substeps \2 flush \3/" | cut -c1-200
