@@ -369,6 +369,9 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  happen inside it -- the patches along the partition boundary store their first velocities into the neighbours' mailboxes, wait for
  *                  the neighbours' and go on, every other patch runs the single-rank body.  -1 (default) = on meshes / partitions of more than 65 k nodes
  *                  (smaller single-rank meshes run four sub-steps per launch, one patch per CU), 0 = never, 1 = wherever it can run
+ *   "pair_threads" single rank: threads of a k_substep_pair workgroup, 512 (default: two workgroups per CU, patches of ~430 nodes at 2 km) or 256 (four per CU,
+ *                  patches of ~180 nodes: measured slower, 5.67 against 5.30 ms of sub-steps at 2 km -- the thicker rings cost more than four independent
+ *                  workgroups per CU hide); set before nxs_dyn_set_mesh or the next step cuts the mesh again
  *   "um_ring"      apply M_UM/M_UT += dt*M_VT every n sub-steps from a ring of velocity buffers, 1..128;
  *                  0 = automatic (once per step on meshes that stream from HBM, every sub-step on cache-resident ones)
  *   "nt_mask"      non-temporal access classes of the fused kernel (1 sigma/damage, 2 UM/UT, 4 element constants); -1 = automatic

@@ -114,6 +114,7 @@ struct nxs_dyn_handle {
     int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
                                            // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
     bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
+    int pair_T = 512;                      // option "pair_threads": threads of a k_substep_pair workgroup on a single rank (512: two per CU; 256: four per CU, smaller patches)
     PairHalo pairh{};                      // several ranks: the patches' duties in the exchange inside k_substep_pair<HALO>, the ticket words
     bool pair_claim = false;               // ... and their claim on the device's workgroup slots (nxs_resident_registry.hpp)
     int pair_hint = 0;                     // the patch size the planner kept for the previous mesh (tried first after a regrid)
@@ -747,6 +748,10 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         h->band_nodes = value < 0 ? -1 : (int)value;
         if (h->have_mesh) { HIPCHK(h, hipSetDevice(h->device)); HIPCHK(h, hipStreamSynchronize(h->stream)); release_graph(h); return upload_patches(h); }
         return NXS_OK;
+    }
+    if (!std::strcmp(key, "pair_threads")) {
+        if (value != 256 && value != 512) return fail(h, NXS_ERR_INVALID, "pair_threads must be 256 or 512");
+        h->pair_T = (int)value; h->pair_ready = false; h->pair_failed = false; h->pair_hint = 0; release_graph(h); return NXS_OK;
     }
     if (!std::strcmp(key, "pair_regs")) { h->pair_regs = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "prep_fused")) { h->prep_fused = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
@@ -1635,6 +1640,11 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D, bool halo = false) {
             ph.from_mailbox = sidx > 0 ? 1 : 0;
             if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)h->d_hf, ph);
             else hipLaunchKernelGGL((k_substep_pair<512, false, 3, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)h->d_hf, ph);
+            return;
+        }
+        if (h->pair_threads == 256) {
+            if (pow4) hipLaunchKernelGGL((k_substep_pair<256, true, 3>), grid, dim3(256), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
+            else hipLaunchKernelGGL((k_substep_pair<256, false, 3>), grid, dim3(256), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
             return;
         }
         if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});

@@ -552,12 +552,13 @@ inline size_t multi_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax 
 // k_substep_pair (two sub-steps per launch, the stresses between them in registers): staged nodes and corner forces only; its 512-thread block
 // takes the elements of the first sub-step in three rounds, those of the second and the nodes of the first in two, the own nodes in one
 inline size_t pair_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 2) * sizeof(double); }
-inline bool pair_kernel_fits(const HostPatches2 &x, int own_max) { return x.D == 2 && x.EDmax <= 3 * 512 && x.ESmax <= 2 * 512 && x.NSmax <= 2 * 512 && own_max <= 512 && x.NDmax <= 1024 /*corner slots travel in ten bits*/; }
+inline bool pair_kernel_fits(const HostPatches2 &x, int own_max, int T = 512) { return x.D == 2 && x.EDmax <= 3 * T && x.ESmax <= 2 * T && x.NSmax <= 2 * T && own_max <= T && x.NDmax <= 1024 /*corner slots travel in ten bits*/; }
 
 // n2n: [W2][Nn] neighbour rows (bamg order), n2n_cnt: [Nn]
 inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_nodes, int D, bool single_round_only, int cus,
                                  const std::vector<int> &n2n, const std::vector<int> &n2n_cnt, int W2, Patch2Plan &out, bool for_pair_kernel = false,
-                                 int pair_hint = 0 /* the size kept for the previous mesh of this handle: after a regrid it usually still fits */) {
+                                 int pair_hint = 0 /* the size kept for the previous mesh of this handle: after a regrid it usually still fits */,
+                                 int pair_T = 512 /* threads of a k_substep_pair workgroup: 512 (two per CU) or 256 (four per CU) */) {
     char msg[160];
     out.pair_kernel = false;
     if (m.No != m.Nn) return "multi-sub-step patches need a single-rank mesh";
@@ -575,17 +576,18 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
         // of a large patch are relatively thin, and what a launch saves in traffic is paid for in ring arithmetic (2 km: 5.72 ms of sub-steps
         // at 408 nodes, 5.96 at 400 where one more wave of patches is started, 6.07 at 300; 6.7 at 420, where only one workgroup fits a CU)
         if (D != 2) return "k_substep_pair runs two sub-steps per launch";
-        const size_t cap = 80 * 1024;
+        const size_t cap = (size_t)80 * 1024 * pair_T / 512;
         auto fits = [&](int PP) {
             if (!build_patches2(m.t, m.ghost3, m.Nn, m.Ne, PP, D, order, hp)) return false;
-            return pair_lds_of(hp) <= cap && pair_kernel_fits(hp, own_max());
+            return pair_lds_of(hp) <= cap && pair_kernel_fits(hp, own_max(), pair_T);
         };
         if (pair_nodes > 0) {
             P = pair_nodes;
             if (!fits(P)) { snprintf(msg, sizeof msg, "patches of %d nodes do not fit k_substep_pair (80 KB of LDS, three rounds of elements)", P); return msg; }
         } else {
             // (a mesh too small to give every CU two such patches takes smaller ones: one full round of 2 x cus workgroups)
-            const int hi0 = std::min(512, std::max(68, (int)((((long long)m.Nn + 2 * cus - 1) / (2 * cus) + 3) & ~3ll) + 4));
+            const int wg_per_cu = 2 * 512 / pair_T;
+            const int hi0 = std::min(pair_T, std::max(68, (int)((((long long)m.Nn + wg_per_cu * cus - 1) / (wg_per_cu * cus) + 3) & ~3ll) + 4));
             int lo = 64, hi = hi0;
             // every trial cuts the whole mesh (135 ms at 1.5 M triangles): the size the previous mesh of this handle took is tried first and kept if it
             // still fits (one cut per regrid instead of nine), else the search goes on below it
@@ -607,7 +609,7 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
             // One or two rounds of workgroups: whole rounds (a round that is a fraction full costs almost a full one -- 492 k triangles: 583
             // patches of 424 nodes 2.43 ms of sub-steps, 1 013 of 244 nodes 2.26; 730 k: 864 of 424 3.15, 1 018 of 360 3.00).  From three rounds
             // on the largest patches win (1.08 M triangles: 1 270 of 428 4.14, 1 494-1 527 of 356-364 4.32-4.35; 2 km likewise).
-            const int slots = 2 * cus, k = (hp.nP + slots - 1) / slots;
+            const int slots = wg_per_cu * cus, k = (hp.nP + slots - 1) / slots;
             if (k <= 2 && hp.nP > 0 && hp.nP != k * slots) {
                 int Pr = (int)((((long long)m.Nn + (long long)k * slots - 1) / ((long long)k * slots) + 3) & ~3ll);
                 Pr = std::max(64, Pr);
@@ -642,7 +644,7 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
     if (out.lds > 160 * 1024) { snprintf(msg, sizeof msg, "multi-sub-step patches need %zu B of LDS", out.lds); return msg; }
     // one patch per CU: 768 threads when a level does not fit 512 (10 km, D = 4: 0.98 -> 0.93 ms/step; 1 024 threads would force
     // 128 VGPRs + 40 spilled: 1.53); several patches per CU: 512, the outer levels take a second round of the block
-    out.threads = out.pair_kernel ? 512 : hp.EDmax <= 256 ? 256 : (hp.EDmax <= 512 || hp.nP > cus) ? 512 : 768;
+    out.threads = out.pair_kernel ? pair_T : hp.EDmax <= 256 ? 256 : (hp.EDmax <= 512 || hp.nP > cus) ? 512 : 768;
     {   // NodalConnectivity rows in patch-local slots, for D smoother sweeps per launch (k_smooth_multi)
         const int Nn = m.Nn;
         out.pnbr.assign((size_t)hp.nP * W2 * hp.NSmax, 0xFFFF);

@@ -787,6 +787,41 @@ def test_resident_loop_survives_a_remesh_a_change_of_sub_steps_and_a_second_hand
     a.close(); c.close()
 
 
+@pytest.mark.parametrize("kind,opts,kernel,D", [("small", {"fused": 1}, "k_substep_fused", 1), ("small", {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}, "k_substep_pair", 2),
+                                                  ("small", {"fused": 2, "substeps_per_launch": 4}, "k_substep_multi", 4), ("small", {"fused": 4}, "k_substep_resident", 120)])
+def test_traffic_model_and_step_times(kind, opts, kernel, D):
+    """nxs_dyn_get_traffic_model names the kernel the last step ran on and prices a launch from the patch tables: unique <= scheme (the halo rings are the
+    difference), rereads only where a workgroup reads a record twice, the survey's model scaled by the sub-steps a launch advances; the mesh move, prep and
+    update figures scale with the mesh.  nxs_dyn_get_step_times returns one device time per step since the reset, and the last ring flush is part of the
+    sub-step phase."""
+    from nextsim_amd import dynamics
+    _, p, _, lms, fields = cases.make_case(kind)
+    lm, f = lms[0], fields[0]
+    fe = dynamics.FiniteElementDynamics(p)
+    for k, v in opts.items():
+        fe.set_option(k, v)
+    fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+    fe.step(); fe.synchronize(); fe.set_option("timing_reset", 1)
+    for _ in range(3):
+        fe.step()
+    fe.synchronize()
+    t = fe.traffic_model()
+    assert t["substep_kernel_name"] == kernel and t["substeps_per_launch"] == D and t["halo_in_kernel"] == 0, t
+    assert 0 < t["substep_unique_bytes"] <= t["substep_scheme_bytes"], t
+    assert (t["substep_reread_bytes"] > 0) == (kernel in ("k_substep_pair", "k_substep_multi")), t
+    Ne, Nn = lm.num_elements, lm.num_nodes
+    assert abs(t["survey_model_bytes"] - (172. * Ne + 217. * Nn) * D) < 1.
+    assert t["substep_unique_bytes"] >= D * 16. * Nn and t["substep_unique_bytes"] >= 112. * Ne    # at least: every velocity out, state in + out + constants
+    assert t["update_bytes"] > 100. * Ne and t["prep_unique_bytes"] > 100. * Ne and t["prep_scheme_bytes"] >= t["prep_unique_bytes"]
+    if t["move_ring_slots"]:
+        assert t["move_ring_bytes"] >= 16. * t["move_ring_slots"] * Nn
+    st = fe.step_times()
+    tm = fe.timing()
+    assert st.shape == (3,) and (st > 0).all() and abs(st.mean() - tm["total_ms"]) < 1e-6 * max(1., tm["total_ms"])
+    assert 0. <= tm["ring_flush_ms"] <= tm["substeps_ms"] and (tm["ring_flush_ms"] > 0) == (t["move_ring_slots"] > 0)
+    fe.close()
+
+
 def test_a_resident_grid_of_another_process_is_seen():
     """The registry of resident grids is a POSIX shared-memory table named after the device (csrc/nxs_resident_registry.hpp): while THIS process holds 511 of
     the device's 512 resident workgroup slots, a handle of ANOTHER process that asks for the resident loop is refused up front and steps with one kernel per
