@@ -1650,8 +1650,13 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     };
 
     // ---- sub-step 0: elements E_2 (three rounds of the block), state from HBM
+    // The rounds run from the LAST to the first: sub-step 1 reads the 48-byte constants of the E_1 elements a second time, and the ones it takes first (round 0)
+    // were then read last, ~7 us before -- inside the ~6-8 us a line survives in an XCD's 4 MB L2 at this kernel's rate (0.7 MB per us and XCD); in ascending order every
+    // second read missed (round 4: 5.29 -> 5.21 ms of sub-steps at 2 km; reversing the node rounds as well, or sub-step 1's rounds, or touching round 1's lines to renew
+    // them, all lose: gpurun_out/r4_ab5.log, r4_ab6.log).  No operand changes.
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
+    for (int rr = 0; rr < 3; ++rr) {
+        const int r = 2 - rr;
         const int l = t + r * T;
         const bool active = l < nE2;
         const int e = eraw[r] >= 0 ? eraw[r] : ~eraw[r];
@@ -1662,7 +1667,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;  // (read again by sub-step 1: no streaming hint)
             r0 = q[0]; r1 = q[1]; r2 = q[2];
         }
-        if (r == 0) {
+        if (rr == 0) {
             __syncthreads(); NXS_STAMP(1);  // staged velocities / coordinates visible
             if (HALO && (flg & 1u) && !(flg & 2u)) ticket_first();   // (a G patch that sends nothing has read its mailbox half: that is all the neighbours wait for from it)
         }
@@ -1675,13 +1680,14 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     NXS_STAMP(5);
     // ---- sub-step 0: nodes N_1 (two rounds)
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = rr;
         const int i = t + r * T;
         const int n = r == 0 ? my_node : my_node2;
         const bool active = i < nN1 && !(HALO && n >= m.No);   // (several ranks: a ghost of N_1 is not solved here, it arrives below)
         NodeIn in{};
         if (active) in = load_node(i, n);
-        if (r == 0) { __syncthreads(); NXS_STAMP(6); }  // corner forces of sub-step 0 visible
+        if (rr == 0) { __syncthreads(); NXS_STAMP(6); }  // corner forces of sub-step 0 visible
         if (active) {
             double u1, v1;
             solve_node(i, in, u1, v1);
@@ -1725,17 +1731,19 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         if (NT_C) { r0 = __builtin_nontemporal_load(q); r1 = __builtin_nontemporal_load(q + 1); r2 = __builtin_nontemporal_load(q + 2); }
         else { r0 = q[0]; r1 = q[1]; r2 = q[2]; }
     };
-    if (t < nE1) load_constants(eraw[0] >= 0 ? eraw[0] : ~eraw[0], c0, c1, c2r);
+    constexpr int PB0 = 0;   // the round sub-step 1 takes first
+    if (t + PB0 * T < nE1) load_constants(eraw[PB0] >= 0 ? eraw[PB0] : ~eraw[PB0], c0, c1, c2r);
     __syncthreads();  // the velocities of sub-step 0 on N_1; the corner forces have been consumed
     NXS_STAMP(2);
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = rr == 0 ? PB0 : 1 - PB0;
         const int l = t + r * T;
         if (l >= nE1) continue;
         const bool writer = eraw[r] >= 0;
         const int e = writer ? eraw[r] : ~eraw[r];
         d2 r0 = c0, r1 = c1, r2 = c2r;
-        if (r > 0) load_constants(e, r0, r1, r2);
+        if (rr > 0) load_constants(e, r0, r1, r2);
         double sig[3] = {ks[r][0], ks[r][1], ks[r][2]}, damage = ks[r][3];
         update_element(l, tr[r], sig, damage, r0, r1, r2);
         if (writer) {
