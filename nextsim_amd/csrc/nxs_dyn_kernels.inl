@@ -1654,6 +1654,8 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     // were then read last, ~7 us before -- inside the ~6-8 us a line survives in an XCD's 4 MB L2 at this kernel's rate (0.7 MB per us and XCD); in ascending order every
     // second read missed (round 4: 5.29 -> 5.21 ms of sub-steps at 2 km; reversing the node rounds as well, or sub-step 1's rounds, or touching round 1's lines to renew
     // them, all lose: gpurun_out/r4_ab5.log, r4_ab6.log).  No operand changes.
+    // (asking for a round's state and constants one round ahead fits the registers in this order -- 126 VGPRs, no scratch -- and LOSES, 5.27 against 5.07 ms: it moves the
+    // first read of the constants 2.8 us further away from the second)
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
         const int r = 2 - rr;
@@ -1723,29 +1725,30 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             }
         }
     }
-    // ---- sub-step 1: elements E_1 (two rounds), state from the registers, result to HBM (by the element's writer); the constants of the first
-    // round are asked for ahead of the barrier
-    d2 c0 = d2{0., 0.}, c1 = d2{0., 0.}, c2r = d2{0., 0.};
+    // ---- sub-step 1: elements E_1 (two rounds), state from the registers, result to HBM (by the element's writer).  Every load of this sub-step is asked for one
+    // phase ahead of its use (round 4; phase B has registers to spare, 122 VGPRs, where the first sub-step has none): the constants of the first round ahead of the
+    // barrier, those of the second round in front of the first round's arithmetic, the own nodes' inputs in front of the second round's -- the 2.2 us the node loads
+    // used to be waited for in front of barrier 4 are gone (2 km: 5.19 -> 5.10 ms of sub-steps), and the second reads come sooner after the first (L2)
+    d2 c0 = d2{0., 0.}, c1 = d2{0., 0.}, c2r = d2{0., 0.}, d0 = d2{0., 0.}, d1 = d2{0., 0.}, d2r = d2{0., 0.};
     auto load_constants = [&](const int e, d2 &r0, d2 &r1, d2 &r2) {
         const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
         if (NT_C) { r0 = __builtin_nontemporal_load(q); r1 = __builtin_nontemporal_load(q + 1); r2 = __builtin_nontemporal_load(q + 2); }
         else { r0 = q[0]; r1 = q[1]; r2 = q[2]; }
     };
-    constexpr int PB0 = 0;   // the round sub-step 1 takes first
-    if (t + PB0 * T < nE1) load_constants(eraw[PB0] >= 0 ? eraw[PB0] : ~eraw[PB0], c0, c1, c2r);
+    if (t < nE1) load_constants(eraw[0] >= 0 ? eraw[0] : ~eraw[0], c0, c1, c2r);
     __syncthreads();  // the velocities of sub-step 0 on N_1; the corner forces have been consumed
     NXS_STAMP(2);
+    NodeIn nin{};
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-        const int r = rr == 0 ? PB0 : 1 - PB0;
+    for (int r = 0; r < 2; ++r) {
         const int l = t + r * T;
+        if (r == 0 && t + T < nE1) load_constants(eraw[1] >= 0 ? eraw[1] : ~eraw[1], d0, d1, d2r);
+        if (r == 1 && t < nO) nin = load_node(t, my_node);
         if (l >= nE1) continue;
         const bool writer = eraw[r] >= 0;
         const int e = writer ? eraw[r] : ~eraw[r];
-        d2 r0 = c0, r1 = c1, r2 = c2r;
-        if (rr > 0) load_constants(e, r0, r1, r2);
         double sig[3] = {ks[r][0], ks[r][1], ks[r][2]}, damage = ks[r][3];
-        update_element(l, tr[r], sig, damage, r0, r1, r2);
+        update_element(l, tr[r], sig, damage, r == 0 ? c0 : d0, r == 0 ? c1 : d1, r == 0 ? c2r : d2r);
         if (writer) {
             d2 *S = reinterpret_cast<d2 *>(b.Sn) + 2 * (size_t)e;
             const d2 a = {sig[0], sig[1]}, c2 = {sig[2], damage};
@@ -1756,13 +1759,11 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     // ---- sub-step 1: the own nodes
     {
         const bool active = t < nO;
-        NodeIn in{};
-        if (active) in = load_node(t, my_node);
         __syncthreads();  // corner forces of sub-step 1 visible
         NXS_STAMP(3);
         if (active) {
             double u1, v1;
-            solve_node(t, in, u1, v1);
+            solve_node(t, nin, u1, v1);
             vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1;
             if (HALO && (flg & 2u)) send_node(my_node, u1, v1, xseq + 1ull);
         }
