@@ -222,7 +222,7 @@ struct nxs_dyn_handle {
     hipEvent_t *cur = nullptr;  // event set of the step being enqueued (nullptr: untimed)
     // sums over the patch tables (filled where the tables are uploaded) and what the last step launched: nxs_dyn_get_traffic_model
     struct PatchSums { double nP = 0, M = 0, E = 0, O = 0, W = 0; } sums1;                       // DevPatches: staged nodes, elements, own nodes, written elements
-    struct PatchSums2 { double nP = 0, W = 0; std::vector<double> N, E; } sums2;                 // DevPatches2: nodes per level N_0..N_D, elements per level E_1..E_D
+    struct PatchSums2 { double nP = 0, W = 0, E1_second_round = 0; std::vector<double> N, E; } sums2;   // DevPatches2: nodes per level N_0..N_D, elements per level E_1..E_D; elements of E_1 beyond the first 512 of their patch
     int last_kernel = 0, last_ring_count = 0, last_prep = 0;                                     // NXS_KERNEL_* / slots of the last k_move_ring / NXS_PREP_*
     bool last_deferred = false, last_halo_in_kernel = false;
     nxs_dyn_timing timing{};
@@ -2305,11 +2305,11 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
     switch (h->last_kernel) {
     case NXS_KERNEL_PAIR: if (s2.N.size() == 3 && s2.E.size() == 2) {
         const double fanw = 2. * std::min(h->dpch2.Wp, 8);
-        const double N0 = s2.N[0], N1 = s2.N[1], N2 = s2.N[2], E1 = s2.E[0], E2 = s2.E[1];
+        const double N0 = s2.N[0], N1 = s2.N[1], N2 = s2.N[2], E2 = s2.E[1];
         t->substeps_per_launch = 2;
         t->substep_scheme_bytes = s2.nP * 20. /*ncnt, ecnt*/ + N2 * (4. /*pnodes*/ + 16. /*VT*/ + 16. /*xy*/) + E2 * (8. /*pet*/ + 32. /*S in*/ + 48. /*erec*/)
                                   + N1 * (node_in + fanw) + s2.W * 32. /*S out*/ + N0 * 2. * 16. /*two velocity slots*/;
-        t->substep_reread_bytes = E1 * 48. /*erec again*/ + N0 * (node_in + fanw);
+        t->substep_reread_bytes = s2.E1_second_round * 48. /*the constants of sub-step 1's second round, read again 3-6 us after the first time (the first round's stay in registers)*/ + N0 * (node_in + fanw);
         t->substep_unique_bytes = Ne * (8. + 32. + 48. + 32.) + Nn * (4. + 16. + 16. + node_in + fanw + 32.);
     } break;
     case NXS_KERNEL_MULTI: if (!s2.N.empty() && s2.E.size() + 1 == s2.N.size()) {

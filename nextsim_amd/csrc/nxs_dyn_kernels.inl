@@ -1543,7 +1543,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     const int2 *pet = pp.pet + (size_t)blk * EDm;   // {element, corner slots in ten bits each}: 8 bytes per element (as k_substep_fused)
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
-    constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
+    constexpr bool NT_S = NTM & 1;
     // index rows are padded: these loads depend on the launch arguments only
     const int my_node = (t < NDm) ? pn[t] : 0, my_node2 = (t + T < NDm) ? pn[t + T] : 0;
     int eraw[3];
@@ -1632,12 +1632,15 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         const double node_mass = in.r[0].x;
         if ((in.nf & NF_DIRICHLET) || node_mass == 0.) return;
         double gx = in.r[0].y, gy = in.r[1].x;
-        {
-            d2 f[8];
+        // (eight 16-byte reads in two halves of four, then the reference's subtractions in the reference's order, x - (+0) == x bit for bit: half the registers of one
+        // gather of eight -- they are what lets the elements' constants stay in registers across this phase, see the first sub-step)
 #pragma unroll
-            for (int k = 0; k < 8; ++k) f[k] = lF2[(in.fw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+        for (int h2 = 0; h2 < 2; ++h2) {
+            d2 f[4];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) { gx -= f[k].x; gy -= f[k].y; }
+            for (int k = 0; k < 4; ++k) f[k] = lF2[(in.fw[(4 * h2 + k) >> 1] >> (16 * (k & 1))) & 0xFFFFu];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { gx -= f[k].x; gy -= f[k].y; }
         }
         for (int k = 8; k < pp.Wp; ++k) {  // (fans of more than eight elements)
             const unsigned ent = pf[(size_t)k * pp.NSmax + i];
@@ -1650,12 +1653,15 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     };
 
     // ---- sub-step 0: elements E_2 (three rounds of the block), state from HBM
-    // The rounds run from the LAST to the first: sub-step 1 reads the 48-byte constants of the E_1 elements a second time, and the ones it takes first (round 0)
-    // were then read last, ~7 us before -- inside the ~6-8 us a line survives in an XCD's 4 MB L2 at this kernel's rate (0.7 MB per us and XCD); in ascending order every
-    // second read missed (round 4: 5.29 -> 5.21 ms of sub-steps at 2 km; reversing the node rounds as well, or sub-step 1's rounds, or touching round 1's lines to renew
-    // them, all lose: gpurun_out/r4_ab5.log, r4_ab6.log).  No operand changes.
-    // (asking for a round's state and constants one round ahead fits the registers in this order -- 126 VGPRs, no scratch -- and LOSES, 5.27 against 5.07 ms: it moves the
-    // first read of the constants 2.8 us further away from the second)
+    // Round 4, the second reads of the 48-byte element constants (sub-step 1 needs those of the E_1 elements again) are gone: a line survives ~6-8 us in an XCD's 4 MB
+    // L2 at this kernel's rate, the second read used to come ~12 us after the first and missed.  The rounds now run from the LAST to the first, so the constants of
+    // round 0 are the last ones loaded and simply STAY in their registers (kc0); those of round 1 are read again right behind this loop -- 3-6 us after their first
+    // read: an L2 hit -- and held across the node phase (kc1).  24 registers across the node phase fit since its fan gather runs in two halves of four (122 VGPRs, no
+    // scratch); held from their first read they would cross this loop's last round, the kernel's register peak, and spill.  2 km: 5.29 -> 5.05 ms of sub-steps with
+    // the early loads of sub-step 1 below, counted traffic 443 -> ~400 MB per launch; same operands, same bits.  What loses: reversing the node rounds as well,
+    // asking for a round's state and constants one round ahead (fits, 126 VGPRs, but delays the re-read: 5.27 against 5.07 ms), touching lines to renew them
+    // (gpurun_out/r4_ab5.log, r4_ab6.log, r4_ab10.log).
+    d2 kc0[3] = {d2{0., 0.}, d2{0., 0.}, d2{0., 0.}}, kc1[3] = {d2{0., 0.}, d2{0., 0.}, d2{0., 0.}};
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
         const int r = 2 - rr;
@@ -1666,7 +1672,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         if (active) {
             const d2 *S = reinterpret_cast<const d2 *>(b.Sc) + 2 * (size_t)e;
             if (NT_S) { a = __builtin_nontemporal_load(S); c2 = __builtin_nontemporal_load(S + 1); } else { a = S[0]; c2 = S[1]; }
-            const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;  // (read again by sub-step 1: no streaming hint)
+            const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
             r0 = q[0]; r1 = q[1]; r2 = q[2];
         }
         if (rr == 0) {
@@ -1678,6 +1684,11 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             update_element(l, tr[r], sig, damage, r0, r1, r2);
             if (r < 2) { ks[r][0] = sig[0]; ks[r][1] = sig[1]; ks[r][2] = sig[2]; ks[r][3] = damage; }
         }
+        if (r == 0) { kc0[0] = r0; kc0[1] = r1; kc0[2] = r2; }
+    }
+    if (t + T < nE1) {
+        const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)(eraw[1] >= 0 ? eraw[1] : ~eraw[1]);
+        kc1[0] = q[0]; kc1[1] = q[1]; kc1[2] = q[2];
     }
     NXS_STAMP(5);
     // ---- sub-step 0: nodes N_1 (two rounds)
@@ -1725,30 +1736,20 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             }
         }
     }
-    // ---- sub-step 1: elements E_1 (two rounds), state from the registers, result to HBM (by the element's writer).  Every load of this sub-step is asked for one
-    // phase ahead of its use (round 4; phase B has registers to spare, 122 VGPRs, where the first sub-step has none): the constants of the first round ahead of the
-    // barrier, those of the second round in front of the first round's arithmetic, the own nodes' inputs in front of the second round's -- the 2.2 us the node loads
-    // used to be waited for in front of barrier 4 are gone (2 km: 5.19 -> 5.10 ms of sub-steps), and the second reads come sooner after the first (L2)
-    d2 c0 = d2{0., 0.}, c1 = d2{0., 0.}, c2r = d2{0., 0.}, d0 = d2{0., 0.}, d1 = d2{0., 0.}, d2r = d2{0., 0.};
-    auto load_constants = [&](const int e, d2 &r0, d2 &r1, d2 &r2) {
-        const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
-        if (NT_C) { r0 = __builtin_nontemporal_load(q); r1 = __builtin_nontemporal_load(q + 1); r2 = __builtin_nontemporal_load(q + 2); }
-        else { r0 = q[0]; r1 = q[1]; r2 = q[2]; }
-    };
-    if (t < nE1) load_constants(eraw[0] >= 0 ? eraw[0] : ~eraw[0], c0, c1, c2r);
+    // ---- sub-step 1: elements E_1 (two rounds), state AND constants from the registers, result to HBM (by the element's writer); the own nodes' inputs are asked
+    // for in front of the second round's arithmetic (they were waited for 2.2 us in front of the last barrier: 1.1 now)
     __syncthreads();  // the velocities of sub-step 0 on N_1; the corner forces have been consumed
     NXS_STAMP(2);
     NodeIn nin{};
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int l = t + r * T;
-        if (r == 0 && t + T < nE1) load_constants(eraw[1] >= 0 ? eraw[1] : ~eraw[1], d0, d1, d2r);
         if (r == 1 && t < nO) nin = load_node(t, my_node);
         if (l >= nE1) continue;
         const bool writer = eraw[r] >= 0;
         const int e = writer ? eraw[r] : ~eraw[r];
         double sig[3] = {ks[r][0], ks[r][1], ks[r][2]}, damage = ks[r][3];
-        update_element(l, tr[r], sig, damage, r == 0 ? c0 : d0, r == 0 ? c1 : d1, r == 0 ? c2r : d2r);
+        update_element(l, tr[r], sig, damage, r == 0 ? kc0[0] : kc1[0], r == 0 ? kc0[1] : kc1[1], r == 0 ? kc0[2] : kc1[2]);
         if (writer) {
             d2 *S = reinterpret_cast<d2 *>(b.Sn) + 2 * (size_t)e;
             const d2 a = {sig[0], sig[1]}, c2 = {sig[2], damage};

@@ -47,6 +47,7 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
         for (int q = 0; q < hp.nP; ++q) {
             for (int i = 0; i <= D; ++i) S2.N[i] += hp.ncnt[(size_t)q * (D + 1) + i];
             for (int i = 0; i < D; ++i) S2.E[i] += hp.ecnt[(size_t)q * D + i];
+            S2.E1_second_round += std::max(0, hp.ecnt[(size_t)q * D] - 512);
             for (int l = 0; l < hp.ecnt[(size_t)q * D]; ++l) S2.W += hp.pelem[(size_t)q * hp.EDmax + l] >= 0 ? 1. : 0.;
         }
     }
@@ -120,6 +121,7 @@ int upload_pair_patches_mr(nxs_dyn_handle *h) {
         for (int q = 0; q < hp.nP; ++q) {
             for (int i = 0; i <= 2; ++i) S2.N[i] += hp.ncnt[(size_t)q * 3 + i];
             for (int i = 0; i < 2; ++i) S2.E[i] += hp.ecnt[(size_t)q * 2 + i];
+            S2.E1_second_round += std::max(0, hp.ecnt[(size_t)q * 2] - 512);
             for (int l = 0; l < hp.ecnt[(size_t)q * 2]; ++l) S2.W += hp.pelem[(size_t)q * hp.EDmax + l] >= 0 ? 1. : 0.;
         }
     }
