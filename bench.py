@@ -818,7 +818,11 @@ def main():
         return nbytes / (ms * 1e-3) / 1e9 if (nbytes and ms and ms > 0) else None
     def frac(r):
         return r / HBM_PEAK_GBS if r is not None else None
-    achieved = rate(tr["substep_scheme_bytes"], launch_ms)
+    # the roofline's numerator is the launch's UNIQUE bytes -- every array entry it touches, once: the floor of its HBM traffic whatever the caches do.  (Until the
+    # middle of round 4 it was the scheme's bytes -- every list a workgroup reads, rings included; since the element constants stay in registers the COUNTED traffic of
+    # k_substep_pair, 361 MB, is below those 372 MB: the L2 serves part of the rings neighbouring patches share, so the scheme's bytes bound what the workgroups pull
+    # through the L2, not what crosses to memory.  unique <= counted always holds.)
+    achieved = rate(tr["substep_unique_bytes"], launch_ms)
     want = [kernel_name.split(" ")[0]] + (["k_move_ring"] if tr["move_ring_slots"] else []) + {3: ["k_prep_fused"], 2: ["k_prep_elements", "k_prep_nodes"], 1: ["k_prep_elements", "k_prep_nodes"]}.get(tr["prep_kernel"], []) + ["k_update"]
     if args.no_live_pmc or rank != 0:
         counted, traffic_source = {}, "skipped (--no-live-pmc)" if args.no_live_pmc else "rank 0 measures"
@@ -833,8 +837,8 @@ def main():
     achieved_counter = rate(traffic, launch_ms)
     def kernel_row(name, scheme, unique, ms, what):
         c = counted.get(name)
-        return {"what": what, "bytes_per_launch": scheme, "unique_bytes_per_launch": unique, "avg_ms_per_launch": ms, "achieved": rate(scheme, ms), "frac": frac(rate(scheme, ms)),
-                "traffic": c, "achieved_counter": rate(c, ms), "frac_counter": frac(rate(c, ms))}
+        return {"what": what, "bytes_per_launch": unique, "scheme_bytes_per_launch": scheme, "avg_ms_per_launch": ms, "achieved": rate(unique, ms), "frac": frac(rate(unique, ms)),
+                "frac_scheme": frac(rate(scheme, ms)), "traffic": c, "achieved_counter": rate(c, ms), "frac_counter": frac(rate(c, ms))}
     other = {}
     if tr["move_ring_slots"]:
         other["k_move_ring"] = kernel_row("k_move_ring", tr["move_ring_bytes"], tr["move_ring_bytes"], tm.get("ring_flush_ms", 0.0),
@@ -893,22 +897,22 @@ def main():
             "frac_counter": frac(achieved_counter),
             "substeps_per_launch": D_launch,
             "launches_per_step": n_launches,
-            "bytes_per_launch": tr["substep_scheme_bytes"],
+            "bytes_per_launch": tr["substep_unique_bytes"],
+            "scheme_bytes_per_launch": tr["substep_scheme_bytes"],
+            "frac_scheme": frac(rate(tr["substep_scheme_bytes"], launch_ms)),
             "reread_bytes_per_launch": tr["substep_reread_bytes"],
-            "unique_bytes_per_launch": tr["substep_unique_bytes"],
-            "frac_unique": frac(rate(tr["substep_unique_bytes"], launch_ms)),
             "avg_ms_per_launch": launch_ms,
             "algorithmic_equivalent": {"bytes_per_launch": tr["survey_model_bytes"], "achieved": rate(tr["survey_model_bytes"], launch_ms), "frac": frac(rate(tr["survey_model_bytes"], launch_ms)),
                                        "note": "SURVEY 8d's model, 172 B per element + 217 B per node per sub-step x the sub-steps one launch advances: what a kernel that streamed every "
                                                "array of the reference loop once per sub-step would move.  NOT a bandwidth of this kernel (shape coefficients rebuilt on chip, M_UM / M_UT "
                                                "once per step, state and records once per TWO sub-steps): it may exceed the peak; kept for comparison with rounds 1-3"},
             "other_kernels": other,
-            "note": "rank-0 partition, per launch.  bytes_per_launch (-> achieved, frac) = what this blocking scheme MUST move: every list a workgroup reads, once, plus what "
-                    "it writes, summed over the workgroups from the patch tables (halo rings counted; nxs_dyn_get_traffic_model, include/nxs_dyn.h) -- a lower bound of the "
-                    "launch's HBM traffic, so frac <= frac_counter <= ~0.79 (a copy reaches ~6.3 TB/s).  traffic (-> achieved_counter, frac_counter) = counted bytes (2 x FETCH_SIZE "
-                    "+ WRITE_SIZE) of the same launch: bytes_per_launch + what of reread_bytes_per_launch (a workgroup's second read of a record) the L2 did not serve.  "
-                    "unique_bytes_per_launch (frac_unique) = every array entry once: the floor of ANY kernel with this many sub-steps per launch.  avg_ms_per_launch = HIP events "
-                    "around the sub-step graph on the library's stream / launches (the deferred mesh move is timed apart: other_kernels.k_move_ring)",
+            "note": "rank-0 partition, per launch.  bytes_per_launch (-> achieved, frac) = the launch's UNIQUE bytes: every array entry it touches, once, from the patch tables "
+                    "(nxs_dyn_get_traffic_model, include/nxs_dyn.h) -- the floor of its HBM traffic whatever the caches do, so frac <= frac_counter <= ~0.79 (a copy reaches ~6.3 TB/s).  "
+                    "traffic (-> achieved_counter, frac_counter) = counted bytes (2 x FETCH_SIZE + WRITE_SIZE) of the same launch.  scheme_bytes_per_launch (frac_scheme) = every list "
+                    "a workgroup reads, once, plus what it writes, summed over the workgroups (the halo rings of the blocking counted): what the workgroups pull through the L2 -- the "
+                    "counted traffic can be BELOW it where the L2 serves rings that neighbouring patches share; reread_bytes_per_launch = a workgroup's second reads on top of that.  "
+                    "avg_ms_per_launch = HIP events around the sub-step graph on the library's stream / launches (the deferred mesh move is timed apart: other_kernels.k_move_ring)",
         },
         "step_times_ms": step_stats,
         "value_at_median_step": (gm.num_elements * S / (step_stats["median"] * 1e-3)) if (step_stats and world == 1) else None,
