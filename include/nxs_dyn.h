@@ -302,10 +302,11 @@ NXS_API int nxs_dyn_get_step_times(nxs_dyn_handle *h, double *ms, int32_t capaci
  *                   blocking scheme count (several workgroups must read them), a workgroup's SECOND read of a record does not
  *   *_reread_bytes  those second reads (the caches may or may not serve them: the hardware counters say)
  *   *_unique_bytes  every array entry the launch touches, once: the floor of ANY kernel that advances this many sub-steps per launch
- * so unique <= scheme <= scheme + reread, and counted HBM traffic (rocprofv3 --pmc) should land between scheme and scheme + reread. */
+ * so unique <= scheme <= scheme + reread, and counted HBM traffic (rocprofv3 --pmc) lands between unique and scheme + reread (below scheme where the L2 serves
+ * rings that neighbouring workgroups share). */
 enum { NXS_KERNEL_NONE = 0, NXS_KERNEL_PER_LOOP = 1 /* k_sigma_* + k_solve_move */, NXS_KERNEL_FUSED = 2 /* k_substep_fused */,
        NXS_KERNEL_MULTI = 3 /* k_substep_multi */, NXS_KERNEL_PAIR = 4 /* k_substep_pair */, NXS_KERNEL_RESIDENT = 5 /* k_substep_resident */,
-       NXS_KERNEL_RESIDENT_BIG = 6 /* k_substep_resident_big */ };
+       NXS_KERNEL_RESIDENT_BIG = 6 /* k_substep_resident_big */, NXS_KERNEL_PAIR_FLOW = 7 /* k_substep_flow: k_substep_pair's patches, one data-flow launch per step */ };
 enum { NXS_PREP_NONE = 0, NXS_PREP_FULL = 1 /* k_prep_elements + k_prep_nodes with the work arrays */, NXS_PREP_LEAN = 2 /* the same, records only */,
        NXS_PREP_FUSED = 3 /* k_prep_fused */ };
 typedef struct nxs_dyn_traffic {
@@ -369,6 +370,11 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  happen inside it -- the patches along the partition boundary store their first velocities into the neighbours' mailboxes, wait for
  *                  the neighbours' and go on, every other patch runs the single-rank body.  -1 (default) = on meshes / partitions of more than 65 k nodes
  *                  (smaller single-rank meshes run four sub-steps per launch, one patch per CU), 0 = never, 1 = wherever it can run
+ *   "pair_flow"    single rank, where k_substep_pair runs with 512 threads and the whole step fits the velocity ring: 1 = every pair of sub-steps of a step in ONE
+ *                  data-flow launch (k_substep_flow) whose workgroups take (pair, patch) tasks from queues and wait for the patches around theirs only
+ *                  (per-patch counters; what patches hand each other is stored write-through and read past the L1) -- no launch drains the device 60
+ *                  times a step; the same bits.  MEASURED SLOWER at 2 km (7.5 against 5.05 ms of sub-steps: the write-through traffic and the
+ *                  software hand-over between tasks cost more than the part-empty last round of a launch), so 0 / -1 (default) = one launch per pair
  *   "pair_threads" single rank: threads of a k_substep_pair workgroup, 512 (default: two workgroups per CU, patches of ~430 nodes at 2 km) or 256 (four per CU,
  *                  patches of ~180 nodes: measured slower, 5.67 against 5.30 ms of sub-steps at 2 km -- the thicker rings cost more than four independent
  *                  workgroups per CU hide); set before nxs_dyn_set_mesh or the next step cuts the mesh again

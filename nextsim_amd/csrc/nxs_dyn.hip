@@ -114,6 +114,12 @@ struct nxs_dyn_handle {
     int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
                                            // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
     bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
+    int pair_flow = -1;                    // option "pair_flow": the pairs of sub-steps of a step as ONE data-flow launch (k_substep_flow): -1 = wherever k_substep_pair runs on a
+                                           // single rank with 512 threads, 0 = never (one launch per pair), 1 = the same as -1
+    bool flow_ready = false, flow_failed = false;
+    PairFlow flow{};                       // its dependency lists, queues and counters (they go with the patches)
+    size_t flow_words = 0;                 // ... the words zeroed before every launch
+    int flow_grid = 0;
     int pair_T = 512;                      // option "pair_threads": threads of a k_substep_pair workgroup on a single rank (512: two per CU; 256: four per CU, smaller patches)
     PairHalo pairh{};                      // several ranks: the patches' duties in the exchange inside k_substep_pair<HALO>, the ticket words
     bool pair_claim = false;               // ... and their claim on the device's workgroup slots (nxs_resident_registry.hpp)
@@ -387,6 +393,12 @@ int harvest(nxs_dyn_handle *h, int k) {
     return NXS_OK;
 }
 
+// option "pair_flow": 1 = on, 0 = off, -1 = automatic
+bool flow_wanted(const nxs_dyn_handle *h) { return h->pair_flow == 1; }
+// the data-flow build of k_substep_pair for this handle's parameters: one place for the occupancy query and the launch
+const void *flow_kernel(const nxs_dyn_handle *h) {
+    return h->dp.ers_int == 4 ? (const void *)k_substep_flow<512, true, 3> : (const void *)k_substep_flow<512, false, 3>;
+}
 
 #include "nxs_dyn_patches.inl"
 
@@ -516,6 +528,18 @@ void release_resident(nxs_dyn_handle *h) {
 // A resident launch that gave up (k_substep_resident's bounded waits) leaves a mixture of the step's start and its end behind (no patch writes after
 // it has seen the error, the ones that had finished before have written); whoever hands state to the host next says so.  Call with the stream synchronised.
 int resident_error(nxs_dyn_handle *h) {
+    if (h->flow_ready && h->flow.error) {   // the data-flow launch of k_substep_pair's patches: the same contract
+        int ferr = 0;
+        HIPCHK(h, hipMemcpyAsync(&ferr, h->flow.error, sizeof ferr, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        if (ferr) {
+            HIPCHK(h, hipMemsetAsync(h->flow.error, 0, sizeof(int), h->stream));
+            h->flow_failed = true; h->flow_ready = false; release_graph(h);
+            return fail(h, NXS_ERR_HIP, "the data-flow sub-step launch gave up (code %d): a patch waited 10 s for the patches around it (is the device shared with a process that "
+                                        "holds it?); the step is lost and M_UM, M_UT, sigma and damage are undefined: put the state again before going on; later steps run one "
+                                        "launch per pair of sub-steps", ferr);
+        }
+    }
     if (!h->res_ready) return NXS_OK;
     int err = 0;
     HIPCHK(h, hipMemcpyAsync(&err, h->res.error, sizeof err, hipMemcpyDeviceToHost, h->stream));
@@ -753,6 +777,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         if (value != 256 && value != 512) return fail(h, NXS_ERR_INVALID, "pair_threads must be 256 or 512");
         h->pair_T = (int)value; h->pair_ready = false; h->pair_failed = false; h->pair_hint = 0; release_graph(h); return NXS_OK;
     }
+    if (!std::strcmp(key, "pair_flow")) { h->pair_flow = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; h->flow_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "pair_regs")) { h->pair_regs = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "prep_fused")) { h->prep_fused = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "shape_mem")) {
@@ -1371,7 +1396,7 @@ int nxs_dyn_get_state(nxs_dyn_handle *h, nxs_dyn_state *s) try {
         {s->conc_young, d.cyoung, ne}, {s->h_young, d.hyoung, ne}, {s->hs_young, d.hsyoung, ne},
         {s->conc_myi, d.cmyi, ne}, {s->thick_myi, d.tmyi, ne},
     };
-    if (h->res_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); int rc = resident_error(h); if (rc) return rc; }  // never a half-made step without an error
+    if (h->res_ready || h->flow_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); int rc = resident_error(h); if (rc) return rc; }  // never a half-made step without an error
     if (s->damage || s->sigma[0] || s->sigma[1] || s->sigma[2]) ensure_arrays(h);
     for (auto &c : cp) if (c.dst) pin_host_buffer(h, c.dst, c.bytes);
     for (auto &c : cp) if (c.dst) HIPCHK(h, hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyDeviceToHost, h->stream));
@@ -1443,7 +1468,7 @@ int nxs_dyn_ice_diagnostics(nxs_dyn_handle *h, nxs_dyn_ice_diag *dg, const doubl
     if (!h->have_mesh || !h->have_state) return fail(h, NXS_ERR_STATE, "ice_diagnostics needs set_mesh and put_state");
     HIPCHK(h, hipSetDevice(h->device));
     const size_t Ne = (size_t)h->dm.Ne;
-    if (h->res_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); int rc = resident_error(h); if (rc) return rc; }
+    if (h->res_ready || h->flow_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); int rc = resident_error(h); if (rc) return rc; }
     if (!h->d_icediag) { int rc = dev_alloc(h, h->state_allocs, &h->d_icediag, NXS_ICE_DIAG_FIELDS * Ne); if (rc) return rc; }
     hipLaunchKernelGGL(k_ice_diagnostics, dim3(nblocks(h->dm.Ne)), dim3(BLOCK), 0, h->stream, h->dm, h->ds, h->dp.young_cat ? 1 : 0,
                        h->sig_loc ? (const double *)h->ds.S4a : (const double *)nullptr, h->d_icediag);
@@ -1943,6 +1968,8 @@ int run_substeps(nxs_dyn_handle *h) {
     }
     const bool resident = res_wanted && h->res_ready && !h->res_failed;
     const bool pair_halo = pair && mr;   // (choose_depth built the tables: device-direct mailboxes, the exchange inside the kernels)
+    // ... single rank: all the pairs of a step in one data-flow launch (needs the whole step in the ring: one flush, behind the launch)
+    const bool flow = pair && !mr && D == 2 && h->pair_kernel && h->flow_ready && !h->flow_failed && flow_wanted(h) && !h->trace_branches && deferred && K == S && S % 2 == 0;
     if ((halo_in_kernel || (resident && mr) || pair_halo) && h->d_hf_dirty) {  // (outside any stream capture)
         HaloFused tmp = h->hf;
         tmp.ipc = h->ipc;
@@ -1998,6 +2025,17 @@ int run_substeps(nxs_dyn_handle *h) {
             }
             return NXS_OK;
         }
+        if (flow) {   // every pair of sub-steps of the step in ONE data-flow launch over the patches of k_substep_pair; the ring is flushed behind it (final_flush)
+            HIPCHK(h, hipMemsetAsync(h->flow.queue, 0, h->flow_words * sizeof(unsigned int), h->stream));
+            PairFlow f = h->flow;
+            f.K = S / 2;
+            f.S[0] = h->ds.S4a; f.S[1] = h->ds.S4b;
+            const DevParams *pdev = h->d_dp;   // (explicit_solve keeps the device copy current)
+            void *args[] = {&h->dm, &h->dpch2, &h->ds, &h->dw, &pdev, &h->ring, &f};
+            HIPCHK(h, hipLaunchKernel(flow_kernel(h), dim3(h->flow_grid), dim3(512), args, h->pair_lds, h->stream));
+            if (records_end_odd) LAUNCH(h, k_unpack_state, h->dm.Ne, h->dm, h->ds, bbm, (const double *)h->ds.S4b);
+            return NXS_OK;
+        }
         int pending = 0;  // sub-steps whose velocity still has to be applied to UM/UT
         for (int s = 0; s < S; ++s) {
             if (pair) {
@@ -2047,8 +2085,8 @@ int run_substeps(nxs_dyn_handle *h) {
     if (fused && h->sig_loc == 0) LAUNCH(h, k_pack_state, h->dm.Ne, h->dm, h->ds, bbm, h->ds.S4a);
     if (!fused) ensure_arrays(h);
     if (fused) h->sig_loc = records_end_odd ? 0 : 1;
-    h->timing.substep_launches = resident ? 1 : pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
-    h->last_kernel = resident ? (h->res_big ? NXS_KERNEL_RESIDENT_BIG : NXS_KERNEL_RESIDENT) : pair ? (h->pair_kernel ? NXS_KERNEL_PAIR : NXS_KERNEL_MULTI) : fused ? NXS_KERNEL_FUSED : NXS_KERNEL_PER_LOOP;
+    h->timing.substep_launches = (resident || flow) ? 1 : pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
+    h->last_kernel = resident ? (h->res_big ? NXS_KERNEL_RESIDENT_BIG : NXS_KERNEL_RESIDENT) : flow ? NXS_KERNEL_PAIR_FLOW : pair ? (h->pair_kernel ? NXS_KERNEL_PAIR : NXS_KERNEL_MULTI) : fused ? NXS_KERNEL_FUSED : NXS_KERNEL_PER_LOOP;
     h->last_deferred = deferred; h->last_halo_in_kernel = halo_in_kernel || (resident && mr) || pair_halo;
     h->last_ring_count = (deferred && !resident) ? K : 0;
     if (!h->use_graph || (mr && !device_halo)) { int lrc = loop(); return lrc ? lrc : final_flush(); }
@@ -2303,7 +2341,7 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
     const auto &s1 = h->sums1;
     const auto &s2 = h->sums2;
     switch (h->last_kernel) {
-    case NXS_KERNEL_PAIR: if (s2.N.size() == 3 && s2.E.size() == 2) {
+    case NXS_KERNEL_PAIR: case NXS_KERNEL_PAIR_FLOW: if (s2.N.size() == 3 && s2.E.size() == 2) {
         const double fanw = 2. * std::min(h->dpch2.Wp, 8);
         const double N0 = s2.N[0], N1 = s2.N[1], N2 = s2.N[2], E2 = s2.E[1];
         t->substeps_per_launch = 2;
@@ -2311,6 +2349,11 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
                                   + N1 * (node_in + fanw) + s2.W * 32. /*S out*/ + N0 * 2. * 16. /*two velocity slots*/;
         t->substep_reread_bytes = s2.E1_second_round * 48. /*the constants of sub-step 1's second round, read again 3-6 us after the first time (the first round's stay in registers)*/ + N0 * (node_in + fanw);
         t->substep_unique_bytes = Ne * (8. + 32. + 48. + 32.) + Nn * (4. + 16. + 16. + node_in + fanw + 32.);
+        if (h->last_kernel == NXS_KERNEL_PAIR_FLOW) {   // ONE launch runs every pair of sub-steps of the step over the same tables
+            const double pairs = std::floor(S / 2.);
+            t->substeps_per_launch = (int)S;
+            t->substep_scheme_bytes *= pairs; t->substep_reread_bytes *= pairs; t->substep_unique_bytes *= pairs;
+        }
     } break;
     case NXS_KERNEL_MULTI: if (!s2.N.empty() && s2.E.size() + 1 == s2.N.size()) {
         const int D = (int)s2.E.size();

@@ -92,6 +92,8 @@ struct DevPatches2 {
     int own_is_block;             // the own nodes of patch q are the nodes [256 q, 256 q + 256): k_prep_nodes' open-water flag of that block applies
 };
 struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
+#define NXS_MAX_RING 129
+struct VTRing { double *slot[NXS_MAX_RING]; int R; };  // the ring of velocity buffers of the deferred mesh move (k_move_ring)
 
 struct PingPong {  // buffers a fused sub-step reads (c) and writes (n)
     const double *VTc, *Sc;  // Sc, Sn: [Ne][4] records (sigma0, sigma1, sigma2, damage), see k_pack_state
@@ -913,6 +915,30 @@ struct IpcDev {
 };
 #define NXS_SMOOTH_SWEEPS 50  // FE.cpp:10580 (Q9: hard-coded in the reference)
 
+// agent scope (sc1): written through to memory / read past this CU's L1 -- what workgroups of ONE launch hand each other (MI355X_MICROARCH.md, inter-workgroup visibility)
+__device__ __forceinline__ void st_agent(double *p, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_agent(const double *p) {
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+// the same for 16-byte records: a buffer resource over the array, byte offsets per lane (buffer_load/store_dwordx4 ... offen sc1)
+typedef unsigned int nxs_u4 __attribute__((ext_vector_type(4)));
+typedef double nxs_d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t agent_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000 /*gfx9 raw buffer: DATA_FORMAT 32*/);
+}
+__device__ __forceinline__ nxs_d2 ld_agent16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const nxs_u4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16 /*sc1*/);
+    nxs_d2 o;
+    __builtin_memcpy(&o, &v, 16);
+    return o;
+}
+__device__ __forceinline__ void st_agent16(__amdgpu_buffer_rsrc_t r, unsigned byte_off, nxs_d2 x) {
+    nxs_u4 v;
+    __builtin_memcpy(&v, &x, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, (int)byte_off, 0, 16 /*sc1*/);
+}
 __device__ __forceinline__ void sys_store(double *p, double v) {
     __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1484,16 +1510,21 @@ struct PairHalo {
     int from_mailbox;              // 0: first launch of a step, the ghosts are in the velocity buffer
     unsigned int *tickets;         // [0]: G patches past their first duty, [32]: band patches done, [64..65] (64 bits): the last sequence whose first exchange is published
 };
-template <int T, bool POW4, int NTM, bool HALO>
+// FLOW (k_substep_flow): the workgroups of ONE launch hand each other velocities and element state -- what a patch stores for the patches around it is written
+// through (sc1) and read past the L1 (sc1), everything else as in the launch-per-pair kernel.
+template <int T, bool POW4, int NTM, bool HALO, bool FLOW = false>
 __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &pp, const DevState &s, const DevWork &w, const DevParams &p, const PingPong &b, const VTOut &vout,
-                                          const HaloFused *__restrict__ hfp, const PairHalo &ph, const int blk, const unsigned flg) {
+                                          const HaloFused *__restrict__ hfp, const PairHalo &ph, const int blk, const unsigned flg, const int t_in = 0) {
     typedef double d2 __attribute__((ext_vector_type(2)));
+    static_assert(!(HALO && FLOW), "the flow kernel is a single-rank kernel");
+    // (FLOW: the two state buffers as buffer resources, for 16-byte sc1 accesses; unused otherwise)
+    const __amdgpu_buffer_rsrc_t rSc = agent_rsrc(b.Sc, FLOW ? 32u * (unsigned)m.Ne : 0u), rSn = agent_rsrc(b.Sn, FLOW ? 32u * (unsigned)m.Ne : 0u);
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int NDm = pp.NDmax, EDm = pp.EDmax;
     double *lu = lds, *lv = lu + NDm, *lx = lv + NDm, *ly = lx + NDm;
     d2 *lF2 = reinterpret_cast<d2 *>(ly + NDm);  // [3][EDm] + a pair of zeros
     const unsigned ZIDX = 3u * (unsigned)EDm;
-    const int t = threadIdx.x, Nn = m.Nn;
+    const int t = FLOW ? t_in : (int)threadIdx.x, Nn = m.Nn;   // (FLOW: the task loop hands the thread number over as a value the compiler cannot hoist address arithmetic out of the loop with)
     NXS_STAMP(0);
     if (t == 0) lF2[ZIDX] = d2{0., 0.};
     unsigned long long xseq = 0ull;
@@ -1564,7 +1595,8 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             lu[i] = u0; lv[i] = v0;
             const_cast<double *>(b.VTc)[g] = u0;  // every patch that stages g writes the same two values (the ghosts' mesh move and the end of the step read them here)
             const_cast<double *>(b.VTc)[g + Nn] = v0;
-        } else { lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn]; }
+        } else if (FLOW) { lu[i] = ld_agent(b.VTc + g); lv[i] = ld_agent(b.VTc + g + Nn); }
+        else { lu[i] = b.VTc[g]; lv[i] = b.VTc[g + Nn]; }
         const d2 c = reinterpret_cast<const d2 *>(w.xy)[g];
         lx[i] = c.x; ly[i] = c.y;
     };
@@ -1671,7 +1703,8 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         d2 a = d2{0., 0.}, c2 = d2{0., 0.}, r0 = d2{0., 0.}, r1 = d2{0., 0.}, r2 = d2{0., 0.};
         if (active) {
             const d2 *S = reinterpret_cast<const d2 *>(b.Sc) + 2 * (size_t)e;
-            if (NT_S) { a = __builtin_nontemporal_load(S); c2 = __builtin_nontemporal_load(S + 1); } else { a = S[0]; c2 = S[1]; }
+            if (FLOW) { a = ld_agent16(rSc, 32u * (unsigned)e); c2 = ld_agent16(rSc, 32u * (unsigned)e + 16u); }
+            else if (NT_S) { a = __builtin_nontemporal_load(S); c2 = __builtin_nontemporal_load(S + 1); } else { a = S[0]; c2 = S[1]; }
             const d2 *q = reinterpret_cast<const d2 *>(w.erec) + 3 * (size_t)e;
             r0 = q[0]; r1 = q[1]; r2 = q[2];
         }
@@ -1705,7 +1738,8 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             double u1, v1;
             solve_node(i, in, u1, v1);
             if (i < nO) {
-                vout.slot[0][n] = u1; vout.slot[0][n + Nn] = v1;
+                if (FLOW) { st_agent(vout.slot[0] + n, u1); st_agent(vout.slot[0] + n + Nn, v1); }
+                else { vout.slot[0][n] = u1; vout.slot[0][n + Nn] = v1; }
                 if (HALO && (flg & 2u)) send_node(n, u1, v1, xseq);
             }
             lu[i] = u1; lv[i] = v1;  // (a node's solve reads only its own staged velocity: in place)
@@ -1753,7 +1787,8 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         if (writer) {
             d2 *S = reinterpret_cast<d2 *>(b.Sn) + 2 * (size_t)e;
             const d2 a = {sig[0], sig[1]}, c2 = {sig[2], damage};
-            if (NT_S) { __builtin_nontemporal_store(a, S); __builtin_nontemporal_store(c2, S + 1); } else { S[0] = a; S[1] = c2; }
+            if (FLOW) { st_agent16(rSn, 32u * (unsigned)e, a); st_agent16(rSn, 32u * (unsigned)e + 16u, c2); }
+            else if (NT_S) { __builtin_nontemporal_store(a, S); __builtin_nontemporal_store(c2, S + 1); } else { S[0] = a; S[1] = c2; }
         }
     }
     NXS_STAMP(7);
@@ -1765,7 +1800,8 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         if (active) {
             double u1, v1;
             solve_node(t, nin, u1, v1);
-            vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1;
+            if (FLOW) { st_agent(vout.slot[1] + my_node, u1); st_agent(vout.slot[1] + my_node + Nn, v1); }
+            else { vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1; }
             if (HALO && (flg & 2u)) send_node(my_node, u1, v1, xseq + 1ull);
         }
     }
@@ -1814,6 +1850,92 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// v3c  k_substep_pair as a DATA-FLOW launch (single rank, round 4): ONE launch per step whose workgroups take (pair of sub-steps, patch) tasks from
+// queues -- a task starts as soon as the patches it reads from have finished the pair of sub-steps before (per-patch counters), not when a whole launch has.
+// Why: a launch of k_substep_pair is 3.33 rounds of the 512 workgroups the device holds at 2 km, so the last third of every launch runs on a part-empty
+// device (16 % of its slot-time), and 60 launches a step start and drain 60 times.  Here the device stays full from the first task of the step to the last.
+//   tasks      queue x (x = blockIdx & 7: the workgroups the dispatcher deals to one XCD) owns a contiguous range of the patches -- neighbours in space -- and
+//              hands out tickets in order: ticket -> (pair-step k, patch) with k = ticket / patches of the queue.
+//   waits      task (k, p) waits until done[q] >= k for every q in dep(p): the writers of the elements p reads, the owners of the nodes it stages, the same
+//              relation the other way round (p overwrites the state buffer those patches read one pair-step earlier) and p itself (nxs_cut::build_flow_deps).
+//   no deadlock, whatever number of workgroups is resident: tickets leave a queue in order, so every task another one waits for is already in the hands of a
+//              running workgroup (or finished); a workgroup publishes a finished task BEFORE it waits for its next one.  Every wait is bounded all the same.
+//   visibility what patches hand each other (velocities, sigma / damage) is stored write-through and loaded past the L1 (pair_body<FLOW>); a patch's counter
+//              is raised by one lane behind every wave's s_waitcnt vmcnt(0) and the workgroup's barrier; the waiting lanes poll it with sc1 loads and the
+//              workgroup's barrier stands between the poll and the first load (MI355X_MICROARCH.md, inter-workgroup visibility: the first row of the table).
+// Same operations on the same values as k_substep_pair: the same bits (tests/test_gpu_parity.py).
+// MEASURED (2 km, gpurun_out/r4_flow1.log, r4_flow_ab1.log, r4_flow2.log): it LOSES -- 7.5-7.8 ms of sub-steps against 5.03-5.09 with one launch per pair; a task takes
+// 37 us where a workgroup of the launch takes 22.7.  With plain loads / stores and without the waits (wrong results, timing only) still 5.97: the loop itself costs 7 us a
+// task (drain + two barriers + ticket between tasks where the hardware's dispatcher overlaps the end of one workgroup with the start of the next; the parameters read
+// from memory; 128 VGPRs, 3 spilled), the write-through stores and L1-bypassing loads another 7.5 (1.5 ms a step).  The 16 % of a launch's slot-time the part-empty
+// last round leaves idle do not pay for either.  Kept behind option "pair_flow" = 1 (default: one launch per pair of sub-steps); DESIGN section 4.1.
+struct PairFlow {
+    unsigned int *queue;      // [8][32] the queues' ticket counters, one per 128-byte line (zeroed before the launch, with done)
+    unsigned int *done;       // [nP][16] pair-steps a patch has finished, one per 64-byte line
+    const int *dep_ptr;       // [nP + 1]
+    const int *dep;           // the patches a patch waits for (itself among them)
+    int qstart[9];            // the queues' patch ranges
+    int K;                    // pair-steps of the launch (sub-steps / 2)
+    int *error;               // != 0: a wait timed out, the step is lost (8)
+    double *S[2];             // the element state's two buffers: pair-step k reads S[k & 1] and writes S[(k + 1) & 1]
+};
+// The rheology parameters (DevParams: ~120 scalar registers' worth) are read from device memory INSIDE the task loop, through a pointer the compiler cannot see
+// through: as a kernel argument their scalar loads were hoisted in front of the loop and kept alive across it (93 spilled SGPRs, 36 spilled VGPRs, 84 B of
+// scratch per lane).  (Everything that holds POINTERS stays a kernel argument: read from memory they would be generic pointers and every load a flat load.)
+template <int T, bool POW4, int NTM>
+__global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_flow(DevMesh m, DevPatches2 pp, DevState s, DevWork w, const DevParams *__restrict__ pdev, VTRing ring, PairFlow f) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    unsigned int *ctl = reinterpret_cast<unsigned int *>(reinterpret_cast<d2 *>(lds + 4 * (size_t)pp.NDmax) + 3 * (size_t)pp.EDmax + 1);  // behind the pair of zeros: {next ticket, stop}
+    const int t = threadIdx.x;
+    const int qx = (int)(blockIdx.x & 7u);
+    const int q0 = f.qstart[qx], nq = f.qstart[qx + 1] - q0;
+    if (nq <= 0) return;
+    unsigned int *qc = f.queue + 32 * qx;
+    if (t == 0) { ctl[0] = atomicAdd(qc, 1u); ctl[1] = 0u; }
+    __syncthreads();
+    unsigned int tk = ctl[0];
+    const int R = ring.R;
+    for (;;) {
+        const int k = (int)(tk / (unsigned)nq);
+        if (k >= f.K) break;
+        const int blk = q0 + (int)(tk - (unsigned)k * (unsigned)nq);
+        const DevParams *pp_ = pdev;
+        asm volatile("" : "+s"(pp_));
+        if (t < 64) {   // one wave waits for the patches this task reads from (a lane each), bounded like every other wait of the library
+            const int d1 = f.dep_ptr[blk + 1];
+            const long long t0 = wall_clock64();  // 100 MHz
+            bool ok = true;
+            for (int j = f.dep_ptr[blk] + t; j < d1 && ok; j += 64) {
+                const unsigned int *flag = f.done + 16 * (size_t)f.dep[j];
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)k) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (__hip_atomic_load(f.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost
+                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(f.error, 8); break; }  // 10 s
+                }
+            }
+            if (!ok) ctl[1] = 1u;
+        }
+        unsigned int nxt = 0u;
+        if (t == 0) nxt = atomicAdd(qc, 1u);   // the next ticket: its answer is not needed before this task ends
+        __syncthreads();   // the poll stands before every load of this task; the LDS of the task before is free
+        if (ctl[1] != 0u) break;
+        PingPong b;
+        b.Sc = f.S[k & 1]; b.Sn = f.S[(k + 1) & 1]; b.VTc = ring.slot[(2 * k) % R]; b.VTn = nullptr;
+        VTOut vo{};
+        vo.slot[0] = ring.slot[(2 * k + 1) % R]; vo.slot[1] = ring.slot[(2 * k + 2) % R];
+        int tt = t;
+        asm volatile("" : "+v"(tt));   // (address arithmetic on the thread number stays inside the task: hoisted out of the loop it costs the registers the task needs)
+        pair_body<T, POW4, NTM, false, true>(m, pp, s, w, *pp_, b, vo, nullptr, PairHalo{}, blk, 0u, tt);
+        if (t == 0) ctl[0] = nxt;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave drains its write-through stores ...
+        __syncthreads();                                    // ... the barrier collects the waves (and the last LDS reads of this patch) ...
+        if (t == 0) __hip_atomic_store(f.done + 16 * (size_t)blk, (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... one lane says so
+        tk = ctl[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // v4  The whole sub-step loop in ONE launch: a patch stays on its CU for all the sub-steps and waits for its NEIGHBOURING
 // patches only (FE.cpp:10425-10553 as k_substep_fused; same operations in the same order, same bits).
 // Where one round of resident workgroups covers the partition the sub-step of k_substep_fused is a latency chain -- launch,
@@ -1854,12 +1976,6 @@ struct DevResident {
 #define NXS_RES_MAXS 512
 #define NXS_RES_MAXNB 16  // neighbour ranks whose mailbox addresses the several-rank variant keeps in LDS
 
-__device__ __forceinline__ void st_agent(double *p, double v) {
-    __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double ld_agent(const double *p) {
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
 
 // element phase of the resident kernel for this thread's element (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467);
 // the OVL variant calls it from three places, the plain variant keeps its own copy in line
@@ -2693,8 +2809,6 @@ __global__ void __launch_bounds__(BLOCK) k_icediag_soa(int Ne, const double *__r
     for (int k = 0; k < NXS_ICE_DIAG_FIELDS; ++k) soa[(size_t)k * Ne + e] = rows[(size_t)e * NXS_ICE_DIAG_FIELDS + k];
 }
 
-#define NXS_MAX_RING 129
-struct VTRing { double *slot[NXS_MAX_RING]; int R; };
 
 // vt_out != NULL (the last flush of a step): the newest velocity also goes back into M_VT -- the flush has just read it
 __global__ void __launch_bounds__(BLOCK) k_move_ring(DevMesh m, DevState s, VTRing ring, int first, int count, double dt, double *__restrict__ vt_out) {

@@ -78,6 +78,35 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
     h->smooth_lds = plan.smooth_lds;
     h->pair_ready = true;
     h->pair_depth_built = D;
+    // the same patches as ONE data-flow launch per step (k_substep_flow): what each patch waits for, the queues, the counters
+    h->flow = PairFlow{};
+    h->flow_ready = false;
+    if (plan.pair_kernel && plan.threads == 512 && flow_wanted(h) && !h->flow_failed) {
+        std::vector<int> ptr, dep;
+        auto refuse = [&](const char *w) { if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] one data-flow launch per step not possible: %s\n", w); return NXS_OK; };
+        if (!nxs_cut::build_flow_deps(hp, m.Nn, m.Ne, ptr, dep)) return refuse("a node without an owner or an element without a writer among the patches");
+        if (32ull * (unsigned long long)m.Ne >= (1ull << 32)) return refuse("the element state does not fit a 32-bit buffer offset");
+        PairFlow &f = h->flow;
+        if ((rc = dev_upload(h, h->pair_allocs, &f.dep_ptr, ptr))) return rc;
+        if ((rc = dev_upload(h, h->pair_allocs, &f.dep, dep))) return rc;
+        h->flow_words = 8 * 32 + 16 * (size_t)hp.nP;
+        if ((rc = dev_alloc(h, h->pair_allocs, &f.queue, h->flow_words))) return rc;
+        f.done = f.queue + 8 * 32;
+        if ((rc = dev_alloc(h, h->pair_allocs, &f.error, 1))) return rc;
+        HIPCHK(h, hipMemsetAsync(f.error, 0, sizeof(int), h->stream));
+        nxs_cut::flow_queues(hp.nP, f.qstart);
+        const void *kern = flow_kernel(h);
+        HIPCHK(h, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->pair_lds));
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, h->pair_lds) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); return refuse("the kernel does not fit a CU"); }
+        // as many workgroups as the device holds at once (a multiple of eight: every queue gets the same number), never more than there are patches
+        h->flow_grid = std::max(8, std::min(per_cu * device_cus(h), hp.nP) & ~7);
+        int max_dep = 0;
+        for (int q = 0; q < hp.nP; ++q) max_dep = std::max(max_dep, ptr[q + 1] - ptr[q]);
+        if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] data-flow launch: %d workgroups (%d per CU) over %d patches in 8 queues, a patch waits for %.1f patches (at most %d)\n",
+                                                 h->flow_grid, per_cu, hp.nP, (double)dep.size() / hp.nP, max_dep);
+        h->flow_ready = true;
+    }
     return NXS_OK;
 }
 

@@ -551,8 +551,73 @@ struct Patch2Plan {
 inline size_t multi_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 2 + 4 * (size_t)x.ESmax) * sizeof(double); }
 // k_substep_pair (two sub-steps per launch, the stresses between them in registers): staged nodes and corner forces only; its 512-thread block
 // takes the elements of the first sub-step in three rounds, those of the second and the nodes of the first in two, the own nodes in one
-inline size_t pair_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 2) * sizeof(double); }
+// (+ 4: the pair of zeros pad fan entries name, and 16 bytes of control words for k_substep_flow)
+inline size_t pair_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 4) * sizeof(double); }
 inline bool pair_kernel_fits(const HostPatches2 &x, int own_max, int T = 512) { return x.D == 2 && x.EDmax <= 3 * T && x.ESmax <= 2 * T && x.NSmax <= 2 * T && own_max <= T && x.NDmax <= 1024 /*corner slots travel in ten bits*/; }
+
+// k_substep_flow (one launch per step, tasks = (pair of sub-steps, patch)): which patches must have finished pair-step k - 1 before patch q may start pair-step k.
+//   q READS the state of the elements of its outer level from the buffer their WRITERS filled in the pair-step before, and the velocities of the nodes it stages
+//   from the slot their OWNERS filled;
+//   q OVERWRITES, for the elements it writes, the buffer that the patches holding those elements in their outer level read in the pair-step before (the state
+//   ping-pongs between two buffers): the same relation the other way round;
+//   q itself (another workgroup may have run its pair-step before).
+// CSR over the patches, ascending.  Returns false when a node has no owner or an element no writer (not a single-rank cut).
+inline bool build_flow_deps(const HostPatches2 &hp, int Nn, int Ne, std::vector<int> &ptr, std::vector<int> &dep) {
+    const int nP = hp.nP, D = hp.D;
+    ptr.assign((size_t)nP + 1, 0);
+    dep.clear();
+    if (nP <= 0 || D < 1) return false;
+    std::vector<int> owner((size_t)Nn, -1), writer((size_t)Ne, -1);
+    for (int q = 0; q < nP; ++q) {
+        for (int i = 0; i < hp.ncnt[(size_t)q * (D + 1)]; ++i) {
+            const int n = hp.pnodes[(size_t)q * hp.NDmax + i];
+            if (n < 0 || n >= Nn || owner[n] >= 0) return false;
+            owner[n] = q;
+        }
+        for (int l = 0; l < hp.ecnt[(size_t)q * D + (D - 1)]; ++l) {
+            const int e = hp.pelem[(size_t)q * hp.EDmax + l];
+            if (e < 0) continue;
+            if (e >= Ne || writer[e] >= 0) return false;
+            writer[e] = q;
+        }
+    }
+    std::vector<std::vector<int>> R((size_t)nP);
+    for (int q = 0; q < nP; ++q) {
+        std::vector<int> &r = R[q];
+        r.push_back(q);
+        for (int i = 0; i < hp.ncnt[(size_t)q * (D + 1) + D]; ++i) {
+            const int n = hp.pnodes[(size_t)q * hp.NDmax + i];
+            if (n < 0 || n >= Nn || owner[n] < 0) return false;
+            r.push_back(owner[n]);
+        }
+        for (int l = 0; l < hp.ecnt[(size_t)q * D + (D - 1)]; ++l) {
+            int e = hp.pelem[(size_t)q * hp.EDmax + l];
+            if (e < 0) e = ~e;
+            if (e >= Ne || writer[e] < 0) return false;
+            r.push_back(writer[e]);
+        }
+        std::sort(r.begin(), r.end());
+        r.erase(std::unique(r.begin(), r.end()), r.end());
+    }
+    std::vector<std::vector<int>> back((size_t)nP);
+    for (int q = 0; q < nP; ++q) for (int r : R[q]) if (r != q) back[r].push_back(q);
+    for (int q = 0; q < nP; ++q) {
+        std::vector<int> &r = R[q];
+        r.insert(r.end(), back[q].begin(), back[q].end());
+        std::sort(r.begin(), r.end());
+        r.erase(std::unique(r.begin(), r.end()), r.end());
+        ptr[q + 1] = ptr[q] + (int)r.size();
+        dep.insert(dep.end(), r.begin(), r.end());
+    }
+    return true;
+}
+// the queues of k_substep_flow: queue x serves the patches [qstart[x], qstart[x + 1]) -- the split k_substep_pair's XCD remap makes (consecutive patches are
+// neighbours in space; the workgroups blockIdx = x mod 8 are dealt to one XCD)
+inline void flow_queues(int nP, int qstart[9]) {
+    const int q = nP >> 3, r = nP & 7;
+    qstart[0] = 0;
+    for (int x = 0; x < 8; ++x) qstart[x + 1] = qstart[x] + (x < r ? q + 1 : q);
+}
 
 // n2n: [W2][Nn] neighbour rows (bamg order), n2n_cnt: [Nn]
 inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_nodes, int D, bool single_round_only, int cus,

@@ -421,7 +421,7 @@ class FiniteElementDynamics:
         return out[:n.value]
 
     KERNEL_NAMES = {0: "none", 1: "k_sigma + k_solve_move", 2: "k_substep_fused", 3: "k_substep_multi", 4: "k_substep_pair",
-                    5: "k_substep_resident", 6: "k_substep_resident_big"}
+                    5: "k_substep_resident", 6: "k_substep_resident_big", 7: "k_substep_flow"}
     PREP_NAMES = {0: "none", 1: "k_prep_elements + k_prep_nodes (work arrays)", 2: "k_prep_elements + k_prep_nodes", 3: "k_prep_fused"}
 
     def traffic_model(self) -> dict:

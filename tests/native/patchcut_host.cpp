@@ -294,6 +294,38 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
                 REQUIRE(pk.pair_kernel && pk.threads == 512 && pk.lds == pair_lds_of(pk.hp) && pk.lds <= 80 * 1024 && pair_kernel_fits(pk.hp, own_max),
                         "pair plan: P=%d lds=%zu EDmax=%d ESmax=%d NSmax=%d own=%d", pk.P, pk.lds, pk.hp.EDmax, pk.hp.ESmax, pk.hp.NSmax, own_max);
             }
+            if (w5.empty()) {   // k_substep_flow: what a patch waits for -- the writers of its outer elements, the owners of its staged nodes, the reverse relation, itself
+                const HostPatches2 &x = pk.hp;
+                std::vector<int> ptr, dep;
+                REQUIRE(build_flow_deps(x, Nn, Ne, ptr, dep), "build_flow_deps refused a single-rank cut%s", "");
+                REQUIRE((int)ptr.size() == x.nP + 1 && ptr[0] == 0 && ptr[x.nP] == (int)dep.size(), "flow deps: CSR shape%s", "");
+                std::vector<int> owner(Nn, -1), writer(Ne, -1);
+                for (int q = 0; q < x.nP; ++q) {
+                    for (int i = 0; i < x.ncnt[(size_t)q * 3]; ++i) owner[x.pnodes[(size_t)q * x.NDmax + i]] = q;
+                    for (int l = 0; l < x.ecnt[(size_t)q * 2 + 1]; ++l) if (x.pelem[(size_t)q * x.EDmax + l] >= 0) writer[x.pelem[(size_t)q * x.EDmax + l]] = q;
+                }
+                auto has = [&](int q, int r) { return std::binary_search(dep.begin() + ptr[q], dep.begin() + ptr[q + 1], r); };
+                for (int q = 0; q < x.nP; ++q) {
+                    REQUIRE(std::is_sorted(dep.begin() + ptr[q], dep.begin() + ptr[q + 1]) && std::adjacent_find(dep.begin() + ptr[q], dep.begin() + ptr[q + 1]) == dep.begin() + ptr[q + 1],
+                            "flow deps of patch %d not strictly ascending", q);
+                    REQUIRE(has(q, q), "patch %d does not wait for itself", q);
+                    for (int i = 0; i < x.ncnt[(size_t)q * 3 + 2]; ++i) REQUIRE(has(q, owner[x.pnodes[(size_t)q * x.NDmax + i]]), "patch %d: the owner of staged node %d is missing", q, i);
+                    for (int l = 0; l < x.ecnt[(size_t)q * 2 + 1]; ++l) {
+                        int e = x.pelem[(size_t)q * x.EDmax + l];
+                        if (e < 0) e = ~e;
+                        REQUIRE(has(q, writer[e]), "patch %d: the writer of element slot %d is missing", q, l);
+                    }
+                    for (int j = ptr[q]; j < ptr[q + 1]; ++j) REQUIRE(dep[j] >= 0 && dep[j] < x.nP && has(dep[j], q), "flow deps not symmetric: %d -> %d", q, dep[j]);
+                }
+                int qs[9];
+                flow_queues(x.nP, qs);
+                REQUIRE(qs[0] == 0 && qs[8] == x.nP, "flow queues do not cover the patches%s", "");
+                for (int k = 0; k < 8; ++k) REQUIRE(qs[k + 1] - qs[k] == x.nP / 8 + (k < x.nP % 8 ? 1 : 0), "flow queue %d has %d patches", k, qs[k + 1] - qs[k]);
+                HostPatches2 broken = x;   // an element without a writer: refused
+                bool cut = false;
+                for (size_t i = 0; i < broken.pelem.size() && !cut; ++i) if (broken.pelem[i] >= 0 && (int)(i % x.EDmax) < broken.ecnt[(i / x.EDmax) * 2 + 1]) { broken.pelem[i] = ~broken.pelem[i]; cut = true; }
+                REQUIRE(!cut || !build_flow_deps(broken, Nn, Ne, ptr, dep), "an element without a writer accepted%s", "");
+            }
             if (w5.empty()) {   // after a regrid: the size kept before is tried first (kept if it fits; a hint that no longer fits is searched below)
                 Patch2Plan again, above;
                 REQUIRE(plan_patches2(m.view(), hp.used_hilbert, 0, 2, false, cus, vn, vc, W2, again, true, pk.P).empty() && again.P == pk.P && again.pair_kernel, "hint %d -> %d", pk.P, again.P);

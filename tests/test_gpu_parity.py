@@ -552,6 +552,39 @@ def test_two_sub_steps_per_launch_with_the_stresses_in_registers_do_not_change_a
     assert la == launches and lb == over.get("substeps", 120)
 
 
+@pytest.mark.parametrize("kind,over,opts", [
+    ("h15600", {}, {}),                                                                               # the planner's patches (more than one task per workgroup)
+    ("small", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}),                             # a mesh smaller than the device: fewer patches than workgroups
+    ("40km", {"dynamics_type": 3}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "pair_nodes": 64}),   # EVP, small patches: many tasks per workgroup, short ones
+    ("shuffled", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}),                          # patches along the Hilbert curve
+    ("h15600", {"substeps": 10, "dtime_step": 200. * 10 / 120}, {}),
+])
+def test_the_pairs_of_a_step_in_one_data_flow_launch_do_not_change_a_bit(kind, over, opts):
+    """k_substep_flow (option pair_flow = 1): the patches of k_substep_pair, every pair of sub-steps of the step in ONE launch whose workgroups take (pair, patch)
+    tasks from queues and wait for the patches around theirs only -- the device stays full from the first task to the last instead of draining 60 times a step.
+    What the patches hand each other crosses memory inside the launch (write-through stores, loads past the L1, per-patch counters).  Three steps, every
+    prognostic array the bits of one launch per pair and of one launch per sub-step; the kernel reports itself; one launch per step."""
+    from nextsim_amd import dynamics
+    states = []
+    for extra in ({"pair_flow": 1}, {"pair_flow": 0}, None):
+        if kind == "shuffled": p, lm, f = _shuffled_case()
+        else:
+            _, p, _, lms, fields = cases.make_case(kind, **over)
+            lm, f = lms[0], fields[0]
+        fe = dynamics.FiniteElementDynamics(p)
+        for k, v in (dict(opts, **extra) if extra is not None else {"fused": 1}).items(): fe.set_option(k, v)
+        fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+        fe.step(); fe.step(); fe.step(); fe.synchronize()
+        states.append((fe.get_state(), fe.timing()["substep_launches"], fe.traffic_model()["substep_kernel_name"], fe.checkFieldsFast()))
+        fe.close()
+    S = over.get("substeps", 120)
+    assert [s[1] for s in states] == [1, S // 2, S] and [s[2] for s in states] == ["k_substep_flow", "k_substep_pair", "k_substep_fused"], [s[1:] for s in states]
+    assert all(s[3] == 0 for s in states)
+    for k in STATE_KEYS:
+        assert np.array_equal(states[0][0][k], states[1][0][k]), k
+        assert np.array_equal(states[0][0][k], states[2][0][k]), k
+
+
 def test_two_sub_steps_per_launch_survive_a_change_of_sub_steps_and_a_remesh():
     """What k_substep_pair's patches and ring are tied to may change under it: nxs_dyn_set_params with an odd number of sub-steps (one launch per
     sub-step from then on), back to an even one (pairs again, another ring length), nxs_dyn_set_mesh with another mesh (the planner starts from
