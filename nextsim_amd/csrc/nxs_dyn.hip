@@ -114,6 +114,9 @@ struct nxs_dyn_handle {
     int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
                                            // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
     bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
+    int pair_move = -1;                    // option "pair_move": k_substep_pair on a single rank applies the mesh move of its two sub-steps itself (no ring of velocity slots, no
+                                           // k_move_ring): -1 = automatic, 0 = never (the move deferred to one flush per step), 1 = wherever that kernel runs on one rank
+    bool move_now = false, last_move_in_pair = false;                 // ... decided for the step being built (run_substeps), read by launch_multi
     int pair_flow = -1;                    // option "pair_flow": the pairs of sub-steps of a step as ONE data-flow launch (k_substep_flow): -1 = wherever k_substep_pair runs on a
                                            // single rank with 512 threads, 0 = never (one launch per pair), 1 = the same as -1
     bool flow_ready = false, flow_failed = false;
@@ -395,6 +398,8 @@ int harvest(nxs_dyn_handle *h, int k) {
 
 // option "pair_flow": 1 = on, 0 = off, -1 = automatic
 bool flow_wanted(const nxs_dyn_handle *h) { return h->pair_flow == 1; }
+// option "pair_move" = -1: wherever k_substep_pair runs on a single rank (2 km: 5.27 -> 5.17 ms per step -- the launch grows by 2.8 us, the 0.27 ms flush goes)
+bool pair_move_default(const nxs_dyn_handle *) { return true; }
 // the data-flow build of k_substep_pair for this handle's parameters: one place for the occupancy query and the launch
 const void *flow_kernel(const nxs_dyn_handle *h) {
     return h->dp.ers_int == 4 ? (const void *)k_substep_flow<512, true, 3> : (const void *)k_substep_flow<512, false, 3>;
@@ -777,6 +782,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         if (value != 256 && value != 512) return fail(h, NXS_ERR_INVALID, "pair_threads must be 256 or 512");
         h->pair_T = (int)value; h->pair_ready = false; h->pair_failed = false; h->pair_hint = 0; release_graph(h); return NXS_OK;
     }
+    if (!std::strcmp(key, "pair_move")) { h->pair_move = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "pair_flow")) { h->pair_flow = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; h->flow_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "pair_regs")) { h->pair_regs = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "prep_fused")) { h->prep_fused = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
@@ -1672,6 +1678,11 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D, bool halo = false) {
             else hipLaunchKernelGGL((k_substep_pair<256, false, 3>), grid, dim3(256), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
             return;
         }
+        if (h->move_now) {   // the mesh move of the two sub-steps inside the launch
+            if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3, false, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
+            else hipLaunchKernelGGL((k_substep_pair<512, false, 3, false, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
+            return;
+        }
         if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
         else hipLaunchKernelGGL((k_substep_pair<512, false, 3>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
         return;
@@ -1933,9 +1944,15 @@ int run_substeps(nxs_dyn_handle *h) {
     const int D = h->depth_now;  // decided by choose_depth() before the prep kernels (they fill the records the multi kernel reads)
     const bool pair = D >= 2;
     int K = (fused && move_dt != 0.) ? std::max(1, std::min(want_ring, S)) : 1;
+    // k_substep_pair on a single rank can apply the mesh move of its two sub-steps itself (M_UM / M_UT in and out once per launch): no ring beyond the three
+    // buffers a launch reads and writes, no k_move_ring
+    const bool move_in_pair = pair && !mr && D == 2 && h->pair_kernel && h->pair_threads == 512 && move_dt != 0. && !h->trace_branches && h->um_ring <= 0 &&
+                              (h->pair_move == 1 || (h->pair_move < 0 && pair_move_default(h))) && !flow_wanted(h);
+    h->move_now = move_in_pair;
     if (pair) {  // the ring is flushed between launches; by default once per step (a flush per launch costs 30 small launches at 10 km: 66 us of 0.88 ms)
         if (h->um_ring <= 0) K = std::min(S, NXS_MAX_RING - 1);
         K = std::max(D, K - K % D);
+        if (move_in_pair) K = D;
     }
     const bool deferred = K > 1;
     if (fused) { int rc = setup_ring(h, K); if (rc) return rc; }
@@ -1980,7 +1997,7 @@ int run_substeps(nxs_dyn_handle *h) {
     const bool records_end_odd = resident ? false : (pair ? ((S / D) & 1) : (S & 1));
     // with the deferred mesh move the last flush of the step reads the newest velocity anyway and puts it back into M_VT itself; the
     // ring slot it came from then equals M_VT and serves the smoother as its second buffer (no copy before the sweeps)
-    double *const vt_back = (deferred && !resident && (S % R) != 0) ? h->ds.VT : nullptr;
+    double *const vt_back = (deferred && !resident && !move_in_pair && (S % R) != 0) ? h->ds.VT : nullptr;
     h->smooth_second = vt_back ? h->ring.slot[S % R] : nullptr;
     auto pull_latest = [&](double *vec) {
         const int tr = h->recv_offsets[h->recv_procs.size()];
@@ -1988,8 +2005,9 @@ int run_substeps(nxs_dyn_handle *h) {
                            h->d_recv_seg, h->d_recv_off, h->ipc, 0., 0, h->d_recv_procs, 1);
     };
     // the LAST flush of the step is launched behind the graph (one plain launch per step) so that its own events can bracket it
-    const int final_count = (deferred && !resident) ? S - K * ((S - 1) / K) : 0;
+    const int final_count = (deferred && !resident && !move_in_pair) ? S - K * ((S - 1) / K) : 0;
     auto flush = [&](int s, int pending) {
+        if (move_in_pair) return;                    // (the launches have moved the mesh)
         if (s == S - 1 && final_count > 0) return;   // (launched below)
         LAUNCH(h, k_move_ring, h->dm.Nn, h->dm, h->ds, h->ring, (s + 1 - (pending - 1)) % R, pending, move_dt, (double *)nullptr);
     };
@@ -2088,7 +2106,8 @@ int run_substeps(nxs_dyn_handle *h) {
     h->timing.substep_launches = (resident || flow) ? 1 : pair ? S / D : halo_in_kernel ? S + (S + K - 1) / K : S * ((fused ? 1 : 2) + (mr ? 2 : 0));
     h->last_kernel = resident ? (h->res_big ? NXS_KERNEL_RESIDENT_BIG : NXS_KERNEL_RESIDENT) : flow ? NXS_KERNEL_PAIR_FLOW : pair ? (h->pair_kernel ? NXS_KERNEL_PAIR : NXS_KERNEL_MULTI) : fused ? NXS_KERNEL_FUSED : NXS_KERNEL_PER_LOOP;
     h->last_deferred = deferred; h->last_halo_in_kernel = halo_in_kernel || (resident && mr) || pair_halo;
-    h->last_ring_count = (deferred && !resident) ? K : 0;
+    h->last_ring_count = (deferred && !resident && !move_in_pair) ? K : 0;
+    h->last_move_in_pair = move_in_pair;
     if (!h->use_graph || (mr && !device_halo)) { int lrc = loop(); return lrc ? lrc : final_flush(); }
     if (!h->graph_valid) {
         release_graph(h);
@@ -2349,6 +2368,10 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
                                   + N1 * (node_in + fanw) + s2.W * 32. /*S out*/ + N0 * 2. * 16. /*two velocity slots*/;
         t->substep_reread_bytes = s2.E1_second_round * 48. /*the constants of sub-step 1's second round, read again 3-6 us after the first time (the first round's stay in registers)*/ + N0 * (node_in + fanw);
         t->substep_unique_bytes = Ne * (8. + 32. + 48. + 32.) + Nn * (4. + 16. + 16. + node_in + fanw + 32.);
+        if (h->last_move_in_pair) {   // M_UM, M_UT in and out, no first velocity slot
+            t->substep_scheme_bytes += N0 * (64. - 16.);
+            t->substep_unique_bytes += Nn * (64. - 16.);
+        }
         if (h->last_kernel == NXS_KERNEL_PAIR_FLOW) {   // ONE launch runs every pair of sub-steps of the step over the same tables
             const double pairs = std::floor(S / 2.);
             t->substeps_per_launch = (int)S;

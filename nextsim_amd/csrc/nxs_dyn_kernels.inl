@@ -1512,11 +1512,15 @@ struct PairHalo {
 };
 // FLOW (k_substep_flow): the workgroups of ONE launch hand each other velocities and element state -- what a patch stores for the patches around it is written
 // through (sc1) and read past the L1 (sc1), everything else as in the launch-per-pair kernel.
-template <int T, bool POW4, int NTM, bool HALO, bool FLOW = false>
+// MOVE (single rank, one launch per pair): the mesh move of both sub-steps (FE.cpp:10543-10550) is applied to the own nodes HERE -- M_UM / M_UT read and written
+// once per launch, the same two additions per component in the same order as k_move_ring makes them -- instead of once per step from a ring of 120 velocity
+// slots: no k_move_ring, no first velocity slot (nobody reads the first sub-step's velocity after the launch).
+template <int T, bool POW4, int NTM, bool HALO, bool FLOW = false, bool MOVE = false>
 __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &pp, const DevState &s, const DevWork &w, const DevParams &p, const PingPong &b, const VTOut &vout,
                                           const HaloFused *__restrict__ hfp, const PairHalo &ph, const int blk, const unsigned flg, const int t_in = 0) {
     typedef double d2 __attribute__((ext_vector_type(2)));
     static_assert(!(HALO && FLOW), "the flow kernel is a single-rank kernel");
+    static_assert(!(MOVE && (HALO || FLOW)), "the mesh move inside the launch: single rank, one launch per pair");
     // (FLOW: the two state buffers as buffer resources, for 16-byte sc1 accesses; unused otherwise)
     const __amdgpu_buffer_rsrc_t rSc = agent_rsrc(b.Sc, FLOW ? 32u * (unsigned)m.Ne : 0u), rSn = agent_rsrc(b.Sn, FLOW ? 32u * (unsigned)m.Ne : 0u);
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1737,7 +1741,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         if (active) {
             double u1, v1;
             solve_node(i, in, u1, v1);
-            if (i < nO) {
+            if (i < nO && !MOVE) {   // (MOVE: the first velocity stays in LDS, where the second solve and the move below find it)
                 if (FLOW) { st_agent(vout.slot[0] + n, u1); st_agent(vout.slot[0] + n + Nn, v1); }
                 else { vout.slot[0][n] = u1; vout.slot[0][n + Nn] = v1; }
                 if (HALO && (flg & 2u)) send_node(n, u1, v1, xseq);
@@ -1775,10 +1779,13 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     __syncthreads();  // the velocities of sub-step 0 on N_1; the corner forces have been consumed
     NXS_STAMP(2);
     NodeIn nin{};
+    double mv[4] = {0., 0., 0., 0.};   // MOVE: M_UM, M_UT of this thread's own node
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int l = t + r * T;
-        if (r == 1 && t < nO) nin = load_node(t, my_node);
+        if (r == 1 && t < nO) {
+            nin = load_node(t, my_node);
+        }
         if (l >= nE1) continue;
         const bool writer = eraw[r] >= 0;
         const int e = writer ? eraw[r] : ~eraw[r];
@@ -1795,13 +1802,27 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     // ---- sub-step 1: the own nodes
     {
         const bool active = t < nO;
+        // (MOVE: asked for behind the elements' arithmetic -- held across it they spill)
+        if (MOVE && active) { mv[0] = s.UM[my_node]; mv[1] = s.UM[my_node + Nn]; mv[2] = s.UT[my_node]; mv[3] = s.UT[my_node + Nn]; }
         __syncthreads();  // corner forces of sub-step 1 visible
         NXS_STAMP(3);
         if (active) {
             double u1, v1;
+            const double u0 = lu[t], v0 = lv[t];   // (MOVE) the first sub-step's velocity of this node
             solve_node(t, nin, u1, v1);
             if (FLOW) { st_agent(vout.slot[1] + my_node, u1); st_agent(vout.slot[1] + my_node + Nn, v1); }
             else { vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1; }
+            if (MOVE) {   // FE.cpp:10543-10550, twice: Neumann nodes keep M_UM (k_move_ring)
+                const double dt = p.dte;
+                if (!(nin.nf & NF_NEUMANN)) {
+                    mv[0] += dt * u0; mv[1] += dt * v0;
+                    mv[0] += dt * u1; mv[1] += dt * v1;
+                    s.UM[my_node] = mv[0]; s.UM[my_node + Nn] = mv[1];
+                }
+                mv[2] += dt * u0; mv[3] += dt * v0;
+                mv[2] += dt * u1; mv[3] += dt * v1;
+                s.UT[my_node] = mv[2]; s.UT[my_node + Nn] = mv[3];
+            }
             if (HALO && (flg & 2u)) send_node(my_node, u1, v1, xseq + 1ull);
         }
     }
@@ -1832,7 +1853,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
 
 // the kernel: which patch, and -- several ranks -- whether it takes part in the exchange: the patches that do not (all but the few along the partition boundary)
 // run the single-rank body, so the exchange's tables and tickets cost them no register (the resident kernels branch the same way)
-template <int T, bool POW4, int NTM, bool HALO = false>
+template <int T, bool POW4, int NTM, bool HALO = false, bool MOVE = false>
 __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) k_substep_pair(DevMesh m, DevPatches2 pp, DevState s, DevWork w, DevParams p, PingPong b, VTOut vout,
                                                                                                 const HaloFused *__restrict__ hfp, PairHalo ph) {
     int blk;
@@ -1846,7 +1867,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const unsigned flg = ph.pflags[blk];   // this patch's duties in the exchange (uniform over the workgroup)
         if (flg & 1u) { pair_body<T, POW4, NTM, true>(m, pp, s, w, p, b, vout, hfp, ph, blk, flg); return; }
     }
-    pair_body<T, POW4, NTM, false>(m, pp, s, w, p, b, vout, hfp, ph, blk, 0u);
+    pair_body<T, POW4, NTM, false, false, MOVE>(m, pp, s, w, p, b, vout, hfp, ph, blk, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -585,6 +585,41 @@ def test_the_pairs_of_a_step_in_one_data_flow_launch_do_not_change_a_bit(kind, o
         assert np.array_equal(states[0][0][k], states[2][0][k]), k
 
 
+@pytest.mark.parametrize("kind,over,opts", [
+    ("h15600", {}, {}),
+    ("small", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}),
+    ("40km", {"dynamics_type": 3}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "pair_nodes": 64}),   # EVP
+    ("shuffled", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}),
+    ("h15600", {"substeps": 10, "dtime_step": 200. * 10 / 120}, {}),                                   # ten sub-steps: the last velocity ends in a ring slot, not in M_VT
+    ("toy", {}, {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}),                               # open boundaries: Neumann nodes keep M_UM
+])
+def test_the_mesh_move_inside_the_pair_launch_does_not_change_a_bit(kind, over, opts):
+    """k_substep_pair<MOVE> (option pair_move = 1, single rank): the launch applies the mesh move of its two sub-steps to its own nodes itself -- M_UM and M_UT
+    read and written once per launch, the two additions per component in the order k_move_ring makes them -- so the step needs no ring of 120 velocity slots
+    and no flush.  Three steps: every prognostic array (M_UM and M_UT among them) the bits of the deferred move (pair_move = 0) and of one launch per sub-step."""
+    from nextsim_amd import dynamics
+    states = []
+    for extra in ({"pair_move": 1}, {"pair_move": 0}, None):
+        if kind == "shuffled": p, lm, f = _shuffled_case()
+        else:
+            _, p, _, lms, fields = cases.make_case(kind, **over)
+            lm, f = lms[0], fields[0]
+        fe = dynamics.FiniteElementDynamics(p)
+        for k, v in (dict(opts, **extra) if extra is not None else {"fused": 1}).items(): fe.set_option(k, v)
+        fe.set_mesh(lm); fe.put_state(f); fe.set_forcing(f)
+        fe.step(); fe.step(); fe.step(); fe.synchronize()
+        states.append((fe.get_state(), fe.timing(), fe.traffic_model(), fe.checkFieldsFast()))
+        fe.close()
+    S = over.get("substeps", 120)
+    assert [s[1]["substep_launches"] for s in states] == [S // 2, S // 2, S], [s[1] for s in states]
+    assert states[0][2]["move_ring_slots"] == 0 and states[1][2]["move_ring_slots"] == S and states[0][1]["ring_flush_ms"] == 0.
+    assert all(s[3] == 0 for s in states)
+    assert np.abs(states[0][0]["UM"]).max() > 0
+    for k in STATE_KEYS:
+        assert np.array_equal(states[0][0][k], states[1][0][k]), k
+        assert np.array_equal(states[0][0][k], states[2][0][k]), k
+
+
 def test_two_sub_steps_per_launch_survive_a_change_of_sub_steps_and_a_remesh():
     """What k_substep_pair's patches and ring are tied to may change under it: nxs_dyn_set_params with an odd number of sub-steps (one launch per
     sub-step from then on), back to an even one (pairs again, another ring length), nxs_dyn_set_mesh with another mesh (the planner starts from
