@@ -912,7 +912,8 @@ def main():
                     "traffic (-> achieved_counter, frac_counter) = counted bytes (2 x FETCH_SIZE + WRITE_SIZE) of the same launch.  scheme_bytes_per_launch (frac_scheme) = every list "
                     "a workgroup reads, once, plus what it writes, summed over the workgroups (the halo rings of the blocking counted): what the workgroups pull through the L2 -- the "
                     "counted traffic can be BELOW it where the L2 serves rings that neighbouring patches share; reread_bytes_per_launch = a workgroup's second reads on top of that.  "
-                    "avg_ms_per_launch = HIP events around the sub-step graph on the library's stream / launches (the deferred mesh move is timed apart: other_kernels.k_move_ring)",
+                    "avg_ms_per_launch = HIP events around the sub-step graph on the library's stream / launches (where the mesh move is deferred to one k_move_ring per step -- several "
+                    "ranks, one launch per sub-step -- that flush is timed apart: other_kernels.k_move_ring; k_substep_pair on a single rank moves the mesh inside its launches)",
         },
         "step_times_ms": step_stats,
         "value_at_median_step": (gm.num_elements * S / (step_stats["median"] * 1e-3)) if (step_stats and world == 1) else None,

@@ -370,6 +370,10 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  happen inside it -- the patches along the partition boundary store their first velocities into the neighbours' mailboxes, wait for
  *                  the neighbours' and go on, every other patch runs the single-rank body.  -1 (default) = on meshes / partitions of more than 65 k nodes
  *                  (smaller single-rank meshes run four sub-steps per launch, one patch per CU), 0 = never, 1 = wherever it can run
+ *   "pair_move"    single rank, k_substep_pair with 512 threads, no "um_ring": the launch applies the mesh move of its two sub-steps (FE.cpp:10543-10550) to its
+ *                  own nodes itself -- M_UM and M_UT read and written once per launch, the additions in the order the deferred flush makes them -- so the
+ *                  step needs no ring of one velocity buffer per sub-step (120 x 11.7 MB at 2 km) and no k_move_ring: 2 km 5.27 -> 5.17 ms per step, the
+ *                  same bits.  -1 (default) = wherever that kernel runs on one rank, 0 = never (one flush per step from the ring), 1 = as -1
  *   "pair_flow"    single rank, where k_substep_pair runs with 512 threads and the whole step fits the velocity ring: 1 = every pair of sub-steps of a step in ONE
  *                  data-flow launch (k_substep_flow) whose workgroups take (pair, patch) tasks from queues and wait for the patches around theirs only
  *                  (per-patch counters; what patches hand each other is stored write-through and read past the L1) -- no launch drains the device 60
