@@ -882,7 +882,8 @@ def main():
             "bound": "hbm",
             "kernel": {"k_substep_resident": "k_substep_resident (ONE launch per step: the fused sub-step loop, patches waiting for their neighbours only)",
                        "k_substep_resident_big": "k_substep_resident_big (ONE launch per step, one large patch per CU: four elements and two own nodes per thread)",
-                       "k_substep_pair": "k_substep_pair (TWO sub-steps per launch on patches with two rings of halo, the stresses between them in registers: stress/damage + assembly + nodal solve, twice)",
+                       "k_substep_pair": "k_substep_pair (TWO sub-steps per launch on patches with two rings of halo, the stresses between them in registers: stress/damage + assembly + nodal solve, twice" + ("" if tr["move_ring_slots"] else " + the mesh move of both") + ")",
+                       "k_substep_flow": "k_substep_flow (ONE data-flow launch per step over k_substep_pair's patches: option pair_flow)",
                        "k_substep_multi": f"k_substep_multi ({D_launch} sub-steps per launch on patches with that many rings of halo)",
                        "k_substep_fused": "k_substep_fused (one launch per sub-step: stress/damage + assembly + nodal solve" + (" + updateGhosts through the peer mailboxes" if tr["halo_in_kernel"] else "") + ")",
                        }.get(kernel_name, kernel_name),

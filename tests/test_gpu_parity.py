@@ -663,11 +663,12 @@ def test_automatic_choice_of_the_sub_step_kernel():
     a.close(); b.close(); c.close()
 
 
-@pytest.mark.parametrize("kind,nsteps", [("toy", 100), ("10km", 60)])
+@pytest.mark.parametrize("kind,nsteps", [("toy", 100), ("10km", 60), ("h15600", 40)])
 def test_long_free_run_default_kernels_equal_one_sub_step_per_launch_bit_for_bit(kind, nsteps):
     """A long free run (the mesh moves, damage localises, the toy case has an open-water strip for the smoother): the default
-    kernels of a small single-rank mesh (four sub-steps and four smoother sweeps per launch, one ring flush per step) against the
-    one-sub-step-per-launch kernels -- every prognostic array bit for bit after the last step."""
+    kernels of a small single-rank mesh (four sub-steps and four smoother sweeps per launch, one ring flush per step) -- and, h15600, of one above
+    65 k nodes (two sub-steps per launch with the stresses in registers and the mesh move inside the launch: what the 2 km headline runs on) --
+    against the one-sub-step-per-launch kernels: every prognostic array bit for bit after the last step."""
     from nextsim_amd import dynamics
     gm, p, g, lms, fields = cases.make_case(kind)
     lm, f = lms[0], fields[0]
@@ -679,7 +680,8 @@ def test_long_free_run_default_kernels_equal_one_sub_step_per_launch_bit_for_bit
         for _ in range(nsteps):
             fe.step()
         fe.synchronize()
-        assert fe.timing()["substep_launches"] == (30 if fused == 3 else 120)
+        assert fe.timing()["substep_launches"] == ((60 if kind == "h15600" else 30) if fused == 3 else 120)
+        if kind == "h15600" and fused == 3: assert fe.traffic_model()["substep_kernel_name"] == "k_substep_pair" and fe.traffic_model()["move_ring_slots"] == 0
         out.append(fe.get_state())
         fe.close()
     for k in STATE_KEYS:
