@@ -216,6 +216,13 @@ NXS_API int nxs_dyn_default_params(nxs_dyn_params *p); /* model/options.cpp defa
  * that library and model agree before the first step. */
 enum { NXS_CONST_RHOI = 0, NXS_CONST_RHOW, NXS_CONST_RHOS, NXS_CONST_RHOA, NXS_CONST_GRAVITY, NXS_CONST_OMEGA, NXS_CONST_PI, NXS_CONST_DAYS_IN_SEC, NXS_CONST_COUNT };
 NXS_API int nxs_dyn_physical_constants(double *out, int32_t count);
+/* Self-test of one arithmetic short-cut of the sub-step kernels (no reference call site).  The six shape coefficients of a triangle (FE.cpp:1951-1964) are six
+ * quotients by ONE divisor, the Jacobian; where every operand of a step lies in a range the prep kernels check once per step (|coordinate| zero or in
+ * [1e-100, 1e100], |Jacobian| in [1e-100, 1e100]) the kernels refine the divisor's reciprocal once and finish every quotient with the three operations the
+ * compiler's own division sequence ends in -- the same instructions on the same operands, hence the same bits as six divisions; outside that range they divide.
+ * This entry point computes n pseudo-random sextuples both ways on `device` and returns in *mismatches the number of quotients whose bits differ (0 expected):
+ * mode 0 = triangles of the size and position meshes have, mode 1 = operands spread over the whole admitted range, zeros among the numerators. */
+NXS_API int nxs_dyn_selftest_quotients(int32_t device, int64_t n, uint64_t seed, int32_t mode, int64_t *mismatches);
 NXS_API int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out);
 NXS_API int nxs_dyn_destroy(nxs_dyn_handle *h);
 NXS_API int nxs_dyn_set_params(nxs_dyn_handle *h, const nxs_dyn_params *p);

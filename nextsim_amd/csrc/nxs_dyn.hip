@@ -596,6 +596,26 @@ int nxs_dyn_physical_constants(double *out, int32_t count) try {  // model/const
     return NXS_OK;
 } catch (...) { return dyn_caught(nullptr, "nxs_dyn_physical_constants"); }
 
+int nxs_dyn_selftest_quotients(int32_t device, int64_t n, uint64_t seed, int32_t mode, int64_t *mismatches) try {
+    if (!mismatches || n < 0 || (mode != 0 && mode != 1)) return fail(nullptr, NXS_ERR_INVALID, "selftest_quotients: n >= 0, mode 0 or 1, a place for the count");
+    *mismatches = -1;
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, NXS_ERR_HIP, "selftest_quotients: no device %d", (int)device); }
+    unsigned long long *d = nullptr, host = 0ull;
+    if (hipMalloc((void **)&d, sizeof *d) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, NXS_ERR_HIP, "selftest_quotients: hipMalloc"); }
+    hipError_t e = hipMemset(d, 0, sizeof *d);
+    const long long chunk = 1ll << 28;   // (grid sizes stay well inside 2^31 blocks)
+    for (long long done = 0; done < (long long)n && e == hipSuccess; done += chunk) {
+        const long long m = std::min(chunk, (long long)n - done);
+        hipLaunchKernelGGL(k_selftest_quotients, dim3((unsigned)((m + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, 0, m, (unsigned long long)seed + 0x632be59bd9b4e019ull * (unsigned long long)done, (int)mode, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&host, d, sizeof host, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(nullptr, NXS_ERR_HIP, "selftest_quotients: %s", hipGetErrorString(e));
+    *mismatches = (int64_t)host;
+    return NXS_OK;
+} catch (...) { return dyn_caught(nullptr, "nxs_dyn_selftest_quotients"); }
+
 int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out) try {
     if (!out) return fail(nullptr, NXS_ERR_INVALID, "out is NULL");
     *out = nullptr;
@@ -986,7 +1006,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     A(s.cohesion, ne); A(s.theal, ne); A(s.drag_ui, ne); A(s.drag_ui_young, ne);
     A(s.wind, n2); A(s.ocean, n2); A(s.ssh, (size_t)Nn); A(s.depth, ne);
     A(w.delta_x, ne); A(w.surface, ne); A(w.shape, 6 * ne); A(w.emass, ne); A(w.ecbu, ne); A(w.prec, 8 * ne); A(w.dragsurf, ne);
-    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn)); A(w.erec, 6 * ne); A(w.nrec, 10 * (size_t)Nn);
+    A(w.expC, ne); A(w.pmax, ne); A(w.heal, ne); A(w.dxs, ne); A(w.volume, ne); A(w.eskip, ne); A(w.dxi, ne); A(w.open_blk, (size_t)nblocks(Nn)); A(w.shape_range, 1); A(w.erec, 6 * ne); A(w.nrec, 10 * (size_t)Nn);
     A(w.force, 6 * ne);
     A(h->d_srec, 6 * ne);
     w.srec = nullptr;  // (set per step: only the several-sub-steps kernel reads the records)
@@ -998,6 +1018,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     HIPCHK(h, hipMemsetAsync(w.D_tau_a, 0, n2 * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(w.D_tau_w, 0, n2 * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(w.D_del, 0, ne * sizeof(double), h->stream));
+    HIPCHK(h, hipMemsetAsync(w.shape_range, 0, sizeof(int), h->stream));
 
     if (h->d_partials) { (void)hipFree(h->d_partials); h->d_partials = nullptr; }
     h->n_partials = std::min(nblocks(Ne), 1024);
@@ -1540,6 +1561,14 @@ int nxs_dyn_debug_array(nxs_dyn_handle *h, const char *name, double *out, int64_
                 HIPCHK(h, hipStreamSynchronize(h->stream));
                 return NXS_OK;
             }
+    }
+    if (!std::strcmp(name, "shape_range")) {   // [1] the per-step range flag of the shared-reciprocal shape coefficients (raised by the prep kernels, lowered by k_update)
+        if (n != 1) return fail(h, NXS_ERR_INVALID, "debug_array shape_range has 1 entry");
+        int v = 0;
+        HIPCHK(h, hipMemcpyAsync(&v, h->dw.shape_range, sizeof v, hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        out[0] = (double)v;
+        return NXS_OK;
     }
 #ifdef NXS_PHASE_TIMING
     if (!std::strcmp(name, "phase_times")) {  // [8192][8] timestamps (100 MHz) of the last fused launch, as doubles

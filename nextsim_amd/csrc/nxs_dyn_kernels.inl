@@ -106,6 +106,8 @@ struct DevWork {
     double *dragsurf /*[Ne]: air drag coefficient x area, the other thing k_prep_nodes' bamg-order loop sums (FE.cpp:10383-10390)*/;
     double *expC, *pmax, *heal, *dxs, *volume;  // per-step element constants of the sub-step loop
     unsigned char *eskip;                        // conc <= 0.1 (BBM) / thick == 0 (EVP)
+    int *shape_range;                            // [1] != 0: a frozen coordinate or a Jacobian of this step lies outside the range in which six divisions by one divisor may share
+                                                 // its reciprocal (quotients_by_one_divisor): raised by the prep kernels, lowered by k_update
     unsigned char *open_blk;                     // [ceil(Nn/BLOCK)] != 0: the block of BLOCK nodes holds a node the open-water smoother changes (zeroed by k_prep_elements, set by k_prep_nodes)
     int *dxi;                                    // BBM, fused kernel: M_delta_x as the integer it is (Q1), ~M_delta_x when the element is skipped
     double *erec;                                // [Ne][6]: (expC, volume, pmax, heal, cohesion, {dxi, eskip}) -- the fused kernels' per-step element constants as one record
@@ -139,6 +141,91 @@ __device__ __forceinline__ double jacobian(const double vx[3], const double vy[3
     return jac;
 }
 
+// shapeCoeff (FE.cpp:1951-1964): six quotients with ONE divisor, the Jacobian.  The compiler's division is (gfx950, ROCm 7.2: v_div_scale x 2, v_rcp_f64, four FMAs
+// that refine the reciprocal, q = n r, one FMA for the remainder, v_div_fmas, v_div_fixup -- eleven instructions) a reciprocal refined from the DIVISOR alone and
+// three operations per numerator.  Where v_div_scale leaves both operands alone (no exponent near the ends of the range) and v_div_fixup has nothing to fix (a
+// finite, non-zero divisor) the six divisions can share that reciprocal: the same instructions on the same operands in the same order, 23 instead of 66, the same
+// bits as six divisions (nxs_dyn_selftest_quotients compares them bit for bit; tests/test_gpu_parity.py).  2 km: 4.93 -> 4.65 ms of sub-steps.
+// The range is checked ONCE PER STEP by the prep kernels, not per element (per-element guards cost what the shared reciprocal saves: gpurun_out/r4_ab16.log): every
+// frozen coordinate is zero or has a magnitude in [1e-100, 1e100] -- so every numerator, a difference of two of them, is zero or in [1e-116, 2e100] -- and every
+// |Jacobian| is in [1e-100, 1e100]; v_div_scale's thresholds (exponents 768 apart, quotients or reciprocals near the denormals, numerators below 2^-970) are then
+// hundreds of binades away.  One violation anywhere raises w.shape_range[0] and every sub-step kernel of the step divides six times (k_update lowers it again).
+__device__ __forceinline__ bool shape_value_in_range(const double c) { const double a = fabs(c); return a == 0. || (a >= 1e-100 && a <= 1e100); }
+__device__ __forceinline__ bool shape_jacobian_in_range(const double jac) { const double a = fabs(jac); return a >= 1e-100 && a <= 1e100; }
+__device__ __forceinline__ void quotients_by_one_divisor(const double num[6], const double jac, double q[6], const bool in_range /*uniform: w.shape_range[0] == 0*/) {
+#ifdef NXS_NO_SHARED_RCP
+    const bool fast = false;
+#else
+    const bool fast = in_range;
+#endif
+    if (fast) {
+        double r = __builtin_amdgcn_rcp(jac);
+        double e = __builtin_fma(-jac, r, 1.0);
+        r = __builtin_fma(r, e, r);
+        e = __builtin_fma(-jac, r, 1.0);
+        r = __builtin_fma(r, e, r);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double q0 = num[k] * r;
+            const double rem = __builtin_fma(-jac, q0, num[k]);
+            q[k] = __builtin_fma(rem, r, q0);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) q[k] = num[k] / jac;
+    }
+}
+
+// nxs_dyn_selftest_quotients: sextuples of numerators over one divisor, both ways, bit for bit.
+//   mode 0  triangles as meshes have them: a vertex anywhere within +-4e6 m, edges of 5e2 .. 2e4 m, the numerators and the Jacobian by the kernels' own expressions
+//   mode 1  operands spread over the whole range the per-step check admits: numerators zero (one in sixteen) or +-2^[-380, 330], divisors +-2^[-330, 330]
+__device__ __forceinline__ unsigned long long selftest_mix(unsigned long long z) {   // splitmix64
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+__global__ void __launch_bounds__(BLOCK) k_selftest_quotients(long long n, unsigned long long seed, int mode, unsigned long long *mismatches) {
+    const long long i = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    unsigned long long st = seed ^ (0xd1342543de82ef95ull * (unsigned long long)(i + 1));
+    auto next = [&]() { st = selftest_mix(st); return st; };
+    auto unit = [&]() { return (double)(next() >> 11) * (1. / 9007199254740992.); };   // [0, 1)
+    auto pow2 = [&](int lo, int hi) {   // +-2^e (1 + m), e uniform in [lo, hi]
+        const unsigned long long r = next();
+        const int e = lo + (int)(r % (unsigned long long)(hi - lo + 1));
+        const double v = ldexp(1. + unit(), e);
+        return (r >> 40) & 1ull ? -v : v;
+    };
+    double num[6], jac;
+    if (mode == 0) {
+        double vx[3], vy[3];
+        vx[0] = (unit() - .5) * 8e6; vy[0] = (unit() - .5) * 8e6;
+        const double h = 5e2 + unit() * 1.95e4, a0 = unit() * 6.283185307179586, a1 = a0 + .3 + unit() * 2.5;
+        vx[1] = vx[0] + h * cos(a0); vy[1] = vy[0] + h * sin(a0);
+        vx[2] = vx[0] + h * (.5 + unit()) * cos(a1); vy[2] = vy[0] + h * (.5 + unit()) * sin(a1);
+        jac = jacobian(vx, vy);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
+            num[k] = vy[kp1] - vy[kp2];
+            num[k + 3] = vx[kp2] - vx[kp1];
+        }
+        if (!shape_jacobian_in_range(jac)) return;
+    } else {
+        jac = pow2(-330, 330);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) num[k] = (next() & 15ull) == 0ull ? 0. : pow2(-380, 330);
+    }
+    double fast[6], slow[6];
+    quotients_by_one_divisor(num, jac, fast, true);
+    quotients_by_one_divisor(num, jac, slow, false);
+    unsigned bad = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) bad += __double_as_longlong(fast[k]) != __double_as_longlong(slow[k]) ? 1u : 0u;
+    if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1a  prep elements, FE.cpp:10235-10308
 // LEAN: only what the fused sub-step kernels, update() and the diagnostics read is written (records, M_surface, M_delta_x); the
@@ -165,6 +252,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_elements(DevMesh m, DevState s, 
     w.delta_x[e] = delta_x;
 
     const double jac = jacobian(vx, vy);
+    if (!shape_jacobian_in_range(jac)) w.shape_range[0] = 1;   // (see quotients_by_one_divisor)
     const double surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
     w.surface[e] = surface;
     if (!LEAN || w.srec) {
@@ -330,7 +418,9 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     // same expression as load_vertices(): the fused sub-step kernel rebuilds the shape coefficients from these
     {
         typedef double d2 __attribute__((ext_vector_type(2)));
-        reinterpret_cast<d2 *>(w.xy)[n] = d2{m.x0[n] + 1. * s.UM[n], m.y0[n] + 1. * s.UM[n + Nn]};
+        const d2 c = d2{m.x0[n] + 1. * s.UM[n], m.y0[n] + 1. * s.UM[n + Nn]};
+        reinterpret_cast<d2 *>(w.xy)[n] = c;
+        if (!shape_value_in_range(c.x) || !shape_value_in_range(c.y)) w.shape_range[0] = 1;   // (see quotients_by_one_divisor)
     }
     if (!LEAN) {
         w.C_bu[n] = cb;
@@ -418,7 +508,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         const int g = pn[i];
         const double x = m.x0[g] + 1. * s.UM[g], y = m.y0[g] + 1. * s.UM[g + Nn];
         lx[i] = x; ly[i] = y; ls[i] = s.ssh[g];
-        if (i < nO) reinterpret_cast<d2 *>(w.xy)[g] = d2{x, y};
+        if (i < nO) {
+            reinterpret_cast<d2 *>(w.xy)[g] = d2{x, y};
+            if (!shape_value_in_range(x) || !shape_value_in_range(y)) w.shape_range[0] = 1;   // (see quotients_by_one_divisor)
+        }
     }
     __syncthreads();
     PSTAMP(1);
@@ -468,6 +561,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
         const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
         const double jac = jacobian(vx, vy);
+        if (!shape_jacobian_in_range(jac)) w.shape_range[0] = 1;   // (see quotients_by_one_divisor)
         const double surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
         const double conc = f_conc[j], thick = f_thick[j];
         double total_concentration = conc, total_thickness = thick, total_snow = f_snow[j];
@@ -1020,6 +1114,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
     d2 *lF2 = reinterpret_cast<d2 *>(lF);
     const unsigned ZIDX = 3u * (unsigned)pp.Emax;
     if (threadIdx.x == 0) lF2[ZIDX] = d2{0., 0.};
+    const bool shape_in_range = w.shape_range[0] == 0;   // (uniform; see quotients_by_one_divisor)
     // consecutive patches are neighbours in space: keep them on one XCD (blocks are dealt round-robin
     // over the 8 XCDs) so that shared halo elements / nodes hit that XCD's L2.  Speed only.
     auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index, classes pos%8 -> contiguous index ranges
@@ -1146,12 +1241,14 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
                 const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
                 const double jac = jacobian(vx, vy);
+                double num[6];
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-                    dxN[k] = (vy[kp1] - vy[kp2]) / jac;
-                    dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+                    num[k] = vy[kp1] - vy[kp2];
+                    num[k + 3] = vx[kp2] - vx[kp1];
                 }
+                quotients_by_one_divisor(num, jac, dxN, shape_in_range);
             }
             if (skip) {
                 sig[0] = sig[1] = sig[2] = 0.;
@@ -1305,6 +1402,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     }
     const int t = threadIdx.x, Nn = m.Nn;
     NXS_STAMP(0);
+    const bool shape_in_range = w.shape_range[0] == 0;   // (uniform; see quotients_by_one_divisor)
     const int *ncnt = pp.ncnt + (size_t)blk * (D + 1), *ecnt = pp.ecnt + (size_t)blk * D;
     const int nO = ncnt[0], nD = ncnt[D];
     const int *pn = pp.pnodes + (size_t)blk * NDm;
@@ -1380,12 +1478,14 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
             const double vx[3] = {lx[tr.x], lx[tr.y], lx[tr.z]};
             const double vy[3] = {ly[tr.x], ly[tr.y], ly[tr.z]};
             const double jac = jacobian(vx, vy);
+            double num[6];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-                dxN[k] = (vy[kp1] - vy[kp2]) / jac;
-                dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+                num[k] = vy[kp1] - vy[kp2];
+                num[k + 3] = vx[kp2] - vx[kp1];
             }
+            quotients_by_one_divisor(num, jac, dxN, shape_in_range);
         }
         if (skip) {
             sig[0] = sig[1] = sig[2] = 0.;
@@ -1579,6 +1679,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
     constexpr bool NT_S = NTM & 1;
+    const bool shape_in_range = w.shape_range[0] == 0;   // (uniform; written by the prep kernels, before any launch of the loop)
     // index rows are padded: these loads depend on the launch arguments only
     const int my_node = (t < NDm) ? pn[t] : 0, my_node2 = (t + T < NDm) ? pn[t + T] : 0;
     int eraw[3];
@@ -1624,12 +1725,14 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             const double vx[3] = {lx[trl.x], lx[trl.y], lx[trl.z]};
             const double vy[3] = {ly[trl.x], ly[trl.y], ly[trl.z]};
             const double jac = jacobian(vx, vy);
+            double num[6];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int kp1 = (k + 1) % 3, kp2 = (k + 2) % 3;
-                dxN[k] = (vy[kp1] - vy[kp2]) / jac;
-                dxN[k + 3] = (vx[kp2] - vx[kp1]) / jac;
+                num[k] = vy[kp1] - vy[kp2];
+                num[k + 3] = vx[kp2] - vx[kp1];
             }
+            quotients_by_one_divisor(num, jac, dxN, shape_in_range);
         }
         if (skip) {
             sig[0] = sig[1] = sig[2] = 0.;
@@ -3298,6 +3401,7 @@ template <bool REC>
 __global__ void __launch_bounds__(BLOCK) k_update(DevMesh m, DevState s, DevWork w, DevParams p) {
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= m.Ne) return;
+    if (e == 0) w.shape_range[0] = 0;   // the step's sub-steps are over: the next step's prep kernels judge its own coordinates
     const bool to_be_updated = !(m.eflags[e] & EF_ON_NEUMANN);
     double D_del = 0.;
     const double surface_old = w.surface[e];

@@ -82,6 +82,7 @@ def load_library():
     L.nxs_dyn_get_step_times.argtypes = [H, _abi.c_double_p, C.c_int32, P(C.c_int32)]
     L.nxs_dyn_get_traffic_model.argtypes = [H, P(_abi.Traffic)]
     L.nxs_dyn_physical_constants.argtypes = [P(C.c_double), C.c_int32]
+    L.nxs_dyn_selftest_quotients.argtypes = [C.c_int32, C.c_int64, C.c_uint64, C.c_int32, P(C.c_int64)]
     L.nxs_dyn_set_option.argtypes = [H, C.c_char_p, C.c_int64]
     L.nxs_dyn_debug_array.argtypes = [H, C.c_char_p, _abi.c_double_p, C.c_int64]
     L.nxs_dyn_get_branch_trace.argtypes = [H, C.POINTER(C.c_uint64), C.c_int64]
@@ -107,7 +108,7 @@ IPC_BLOB_BYTES = 128
 
 EXPORTS = (
     "nxs_dyn_set_halo_exchange_fn", "nxs_dyn_ipc_export", "nxs_dyn_ipc_connect", "nxs_dyn_ipc_selftest",
-    "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_physical_constants", "nxs_dyn_create", "nxs_dyn_destroy",
+    "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_physical_constants", "nxs_dyn_selftest_quotients", "nxs_dyn_create", "nxs_dyn_destroy",
     "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init", "nxs_dyn_comm_selftest",
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_set_forcing_pair", "nxs_dyn_set_forcing_time",
     "nxs_dyn_get_diag", "nxs_dyn_ice_diagnostics", "nxs_dyn_step",
@@ -118,6 +119,17 @@ EXPORTS = (
 INTERP_EXPORTS = ("nxs_interp_mesh_to_mesh_2d", "nxs_interp_mesh_to_grid", "nxs_interp_mesh_to_grid_device", "nxs_interp_conservative_remap", "nxs_interp_grid_to_mesh",
                   "nxs_interp_last_error", "nxs_interp_last_info", "nxs_mesh_convex_completion", "nxs_mesh_convex_completion_mode", "nxs_regrid_create", "nxs_regrid_destroy",
                   "nxs_regrid_interp_nodes", "nxs_regrid_remap_elements", "nxs_interp_last_timing", "nxs_regrid_debug_tables")
+
+
+def selftest_quotients(n: int, seed: int = 1, mode: int = 0, device: int = 0) -> int:
+    """nxs_dyn_selftest_quotients: n sextuples of numerators over one divisor computed with the shared reciprocal and with six divisions on `device`;
+    the number of quotients whose bits differ."""
+    L = load_library()
+    bad = C.c_int64(-1)
+    rc = L.nxs_dyn_selftest_quotients(device, n, seed, mode, C.byref(bad))
+    if rc != 0:
+        raise NxsError(f"nxs_dyn_selftest_quotients returned {rc}: {L.nxs_dyn_last_error(None).decode(errors='replace')}")
+    return bad.value
 
 
 def mesh_connectivity(indices: np.ndarray, num_nodes: int):
@@ -378,7 +390,7 @@ class FiniteElementDynamics:
         n = {"rlmass": Nn, "node_mass": Nn, "C_bu": Nn, "grad_ssh": 2 * Nn, "fcor": Nn, "VTM": 2 * Nn,
              "shape": 6 * Ne, "emass": Ne, "ecbu": Ne, "force": 6 * Ne, "volume": Ne, "expC": Ne,
              "erec": 6 * Ne, "nrec": 10 * Nn, "xy": 2 * Nn, "delta_x": Ne, "surface": Ne, "tau_a": 2 * Nn,
-             "phase_times": 8 * 8192, "phase_times_prep": 8 * 8192}[name]
+             "phase_times": 8 * 8192, "phase_times_prep": 8 * 8192, "shape_range": 1}[name]
         out = np.empty(n)
         self._chk(self.L.nxs_dyn_debug_array(self.h, name.encode(), _abi.dptr(out), n))
         return out

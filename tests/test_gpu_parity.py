@@ -620,6 +620,50 @@ def test_the_mesh_move_inside_the_pair_launch_does_not_change_a_bit(kind, over, 
         assert np.array_equal(states[0][0][k], states[2][0][k]), k
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_quotients_by_one_divisor_are_the_divisions(mode):
+    """The six shape coefficients of a triangle are six quotients by its Jacobian; the sub-step kernels refine the Jacobian's reciprocal once and finish every
+    quotient with the three operations the compiler's division ends in (quotients_by_one_divisor) -- the same bits as six divisions wherever v_div_scale leaves
+    the operands alone.  2 x 10^8 sextuples per mode (triangles as meshes have them; operands over the whole range the per-step check admits, zeros among them)
+    computed both ways on the device: not one quotient differs in a bit."""
+    from nextsim_amd import dynamics
+    for seed in (1, 20261005):
+        assert dynamics.selftest_quotients(200_000_000, seed=seed, mode=mode) == 0
+
+
+def test_coordinates_outside_the_checked_range_fall_back_to_six_divisions():
+    """The range in which the quotients may share a reciprocal is checked once per step by the prep kernels; a single coordinate outside it (here: a node 1e-150 m
+    from the y axis) raises the flag for the step, every sub-step kernel divides six times, k_update lowers the flag again.  Same bits as the per-loop kernels
+    (which read shape coefficients formed by division) either way; an ordinary mesh leaves the flag down."""
+    from nextsim_amd import dynamics
+    import copy
+    _, p, _, lms, fields = cases.make_case("small")
+    lm0, f = lms[0], fields[0]
+    lm = copy.deepcopy(lm0)
+    k = int(np.argmin(np.abs(lm.coord_x)))
+    tri0 = lm.indices.reshape(-1, 3)[0] - 1
+    assert abs(lm.coord_x[k]) < 0.25 * np.hypot(lm.coord_x[tri0[1]] - lm.coord_x[tri0[0]], lm.coord_y[tri0[1]] - lm.coord_y[tri0[0]])   # (the mesh stays a mesh)
+    lm.coord_x = lm.coord_x.copy(); lm.coord_x[k] = 1e-150
+    flags, states = [], []
+    for mesh in (lm, lm0):
+        for opts in ({}, {"fused": 1}, {"fused": 0}):
+            fe = dynamics.FiniteElementDynamics(p)
+            for kk, v in opts.items(): fe.set_option(kk, v)
+            fe.set_mesh(mesh); fe.put_state(f); fe.set_forcing(f)
+            fe.explicitSolve(); fe.synchronize()
+            flags.append(fe.debug_array("shape_range")[0])
+            fe.update(); fe.synchronize()
+            assert fe.debug_array("shape_range")[0] == 0
+            fe.step(); fe.synchronize()
+            states.append(fe.get_state())
+            fe.close()
+    assert flags == [1, 1, 1, 0, 0, 0], flags
+    for base in (0, 3):
+        for k in STATE_KEYS:
+            assert np.array_equal(states[base][k], states[base + 2][k]), k
+            assert np.array_equal(states[base + 1][k], states[base + 2][k]), k
+
+
 def test_two_sub_steps_per_launch_survive_a_change_of_sub_steps_and_a_remesh():
     """What k_substep_pair's patches and ring are tied to may change under it: nxs_dyn_set_params with an odd number of sub-steps (one launch per
     sub-step from then on), back to an even one (pairs again, another ring length), nxs_dyn_set_mesh with another mesh (the planner starts from
