@@ -221,7 +221,10 @@ NXS_API int nxs_dyn_physical_constants(double *out, int32_t count);
  * [1e-100, 1e100], |Jacobian| in [1e-100, 1e100]) the kernels refine the divisor's reciprocal once and finish every quotient with the three operations the
  * compiler's own division sequence ends in -- the same instructions on the same operands, hence the same bits as six divisions; outside that range they divide.
  * This entry point computes n pseudo-random sextuples both ways on `device` and returns in *mismatches the number of quotients whose bits differ (0 expected):
- * mode 0 = triangles of the size and position meshes have, mode 1 = operands spread over the whole admitted range, zeros among the numerators. */
+ * mode 0 = triangles of the size and position meshes have, mode 1 = operands spread over the whole admitted range, zeros among the numerators.
+ * mode 2 tests the second short-cut: the strain-rate and stress-increment sums of updateSigmaDamage (FE.cpp:4167-4176, 4204-4210) are formed without the terms
+ * that are products with a LITERAL zero of M_B0T / M_Dunit (adding +-0 to a sum that cannot be -0 returns it unchanged); n random operand sets, zeros of both signs
+ * among the velocities and stresses, computed with and without those terms: *mismatches = values whose bits differ (0 expected). */
 NXS_API int nxs_dyn_selftest_quotients(int32_t device, int64_t n, uint64_t seed, int32_t mode, int64_t *mismatches);
 NXS_API int nxs_dyn_create(const nxs_dyn_params *p, int device, nxs_dyn_handle **out);
 NXS_API int nxs_dyn_destroy(nxs_dyn_handle *h);

@@ -597,7 +597,7 @@ int nxs_dyn_physical_constants(double *out, int32_t count) try {  // model/const
 } catch (...) { return dyn_caught(nullptr, "nxs_dyn_physical_constants"); }
 
 int nxs_dyn_selftest_quotients(int32_t device, int64_t n, uint64_t seed, int32_t mode, int64_t *mismatches) try {
-    if (!mismatches || n < 0 || (mode != 0 && mode != 1)) return fail(nullptr, NXS_ERR_INVALID, "selftest_quotients: n >= 0, mode 0 or 1, a place for the count");
+    if (!mismatches || n < 0 || mode < 0 || mode > 2) return fail(nullptr, NXS_ERR_INVALID, "selftest_quotients: n >= 0, mode 0, 1 or 2, a place for the count");
     *mismatches = -1;
     if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, NXS_ERR_HIP, "selftest_quotients: no device %d", (int)device); }
     unsigned long long *d = nullptr, host = 0ull;
@@ -2395,7 +2395,8 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
         t->substeps_per_launch = 2;
         t->substep_scheme_bytes = s2.nP * 20. /*ncnt, ecnt*/ + N2 * (4. /*pnodes*/ + 16. /*VT*/ + 16. /*xy*/) + E2 * (8. /*pet*/ + 32. /*S in*/ + 48. /*erec*/)
                                   + N1 * (node_in + fanw) + s2.W * 32. /*S out*/ + N0 * 2. * 16. /*two velocity slots*/;
-        t->substep_reread_bytes = s2.E1_second_round * 48. /*the constants of sub-step 1's second round, read again 3-6 us after the first time (the first round's stay in registers)*/ + N0 * (node_in + fanw);
+        t->substep_reread_bytes = s2.E1_second_round * 48. /*the constants of sub-step 1's second round, read again 3-6 us after the first time (the first round's stay in registers)*/
+                                  + ((h->last_halo_in_kernel || h->last_kernel == NXS_KERNEL_PAIR_FLOW) ? N0 * (node_in + fanw) : 0.) /*(the single-rank launch keeps the own nodes' inputs in registers between its two solves)*/;
         t->substep_unique_bytes = Ne * (8. + 32. + 48. + 32.) + Nn * (4. + 16. + 16. + node_in + fanw + 32.);
         if (h->last_move_in_pair) {   // M_UM, M_UT in and out, no first velocity slot
             t->substep_scheme_bytes += N0 * (64. - 16.);

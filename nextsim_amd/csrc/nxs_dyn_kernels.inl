@@ -113,7 +113,7 @@ struct DevWork {
     double *erec;                                // [Ne][6]: (expC, volume, pmax, heal, cohesion, {dxi, eskip}) -- the fused kernels' per-step element constants as one record
     double *srec;                                // [Ne][6] M_shape_coeff as one 48-byte record per element for k_substep_multi, or NULL: the coefficients
                                                  // are then rebuilt from the staged coordinates every sub-step, as k_substep_fused always does
-    double *nrec;                                // [Nn][10]: (node_mass, grad_ssh u, v, rlmass, C_bu, fcor, D_tau_a u, v, ocean u, v) -- their nodal inputs
+    double *nrec;                                // [Nn][10]: (dte / max(min_m, node_mass) -- 0 for a node without mass --, grad_ssh u, v, rlmass, C_bu, fcor, D_tau_a u, v, ocean u, v) -- their nodal inputs
     double *force /*[6][Ne]: fx0,fx1,fx2,fy0,fy1,fy2*/;
     double *rlmass, *node_mass, *C_bu, *grad_ssh /*[2Nn]*/, *fcor, *VTM /*[2Nn]*/;
     double *xy;       // [Nn][2] node coordinates (x, y) on the displaced mesh at step start (frozen over the sub-steps, Q4)
@@ -176,9 +176,13 @@ __device__ __forceinline__ void quotients_by_one_divisor(const double num[6], co
     }
 }
 
+template <bool ZEROS> __device__ __forceinline__ void strain_rates(const double dxN[6], const double u[3], const double v[3], double eps[3]);
+template <bool ZEROS> __device__ __forceinline__ void elastic_stress_increment(double sig[3], const double dtE, const double Da, const double Db, const double Dc, const double eps[3]);
 // nxs_dyn_selftest_quotients: sextuples of numerators over one divisor, both ways, bit for bit.
 //   mode 0  triangles as meshes have them: a vertex anywhere within +-4e6 m, edges of 5e2 .. 2e4 m, the numerators and the Jacobian by the kernels' own expressions
 //   mode 1  operands spread over the whole range the per-step check admits: numerators zero (one in sixteen) or +-2^[-380, 330], divisors +-2^[-330, 330]
+//   mode 2  not the quotients but the two sums of updateSigmaDamage with and without the reference's literal-zero terms (strain_rates, elastic_stress_increment):
+//           shape coefficients +-2^[-20, -8], velocities and stresses zero of either sign (one in eight each) or +-2^[-30, 10] / +-2^[-10, 20], dt E > 0
 __device__ __forceinline__ unsigned long long selftest_mix(unsigned long long z) {   // splitmix64
     z += 0x9e3779b97f4a7c15ull;
     z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
@@ -197,6 +201,24 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_quotients(long long n, unsig
         const double v = ldexp(1. + unit(), e);
         return (r >> 40) & 1ull ? -v : v;
     };
+    if (mode == 2) {
+        double dxN[6], u[3], v[3], sa[3], sb[3], ea[3], eb[3];
+        auto maybe_zero = [&](int lo, int hi) { const unsigned long long r = next(); return (r & 7ull) == 0ull ? ((r >> 8) & 1ull ? -0. : 0.) : pow2(lo, hi); };
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dxN[k] = pow2(-20, -8);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { u[k] = maybe_zero(-30, 10); v[k] = maybe_zero(-30, 10); sa[k] = sb[k] = maybe_zero(-10, 20); }
+        const double dtE = fabs(pow2(-5, 40)), Da = fabs(pow2(0, 1)), Db = fabs(pow2(-2, -1)), Dc = fabs(pow2(-2, -1));
+        strain_rates<true>(dxN, u, v, ea);
+        strain_rates<false>(dxN, u, v, eb);
+        elastic_stress_increment<true>(sa, dtE, Da, Db, Dc, ea);
+        elastic_stress_increment<false>(sb, dtE, Da, Db, Dc, eb);
+        unsigned bad = 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) bad += (__double_as_longlong(ea[k]) != __double_as_longlong(eb[k]) ? 1u : 0u) + (__double_as_longlong(sa[k]) != __double_as_longlong(sb[k]) ? 1u : 0u);
+        if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+        return;
+    }
     double num[6], jac;
     if (mode == 0) {
         double vx[3], vy[3];
@@ -224,6 +246,14 @@ __global__ void __launch_bounds__(BLOCK) k_selftest_quotients(long long n, unsig
 #pragma unroll
     for (int k = 0; k < 6; ++k) bad += __double_as_longlong(fast[k]) != __double_as_longlong(slow[k]) ? 1u : 0u;
     if (bad) atomicAdd(mismatches, (unsigned long long)bad);
+}
+
+// first entry of the 80-byte nodal record: the quotient the sub-solve forms from the nodal mass (FE.cpp:10495, nodal_solve), 0 for a node without mass (the solve
+// leaves such a node alone: node_mass == 0 <=> this entry == 0, the quotient itself is never 0)
+__device__ __forceinline__ double record_dte_over_mass(const DevParams &p, const double node_mass) {
+    if (node_mass == 0.) return 0.;
+    const double dtep = (p.dynamics_type == NXS_DYN_MEVP) ? p.dte / (p.mevp_beta + 1.) : p.dte;   // FE.cpp:10483-10493
+    return dtep / STD_MAX(p.min_m, node_mass);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -460,7 +490,7 @@ __global__ void __launch_bounds__(BLOCK) k_prep_nodes(DevMesh m, DevState s, Dev
     {   // the nodal inputs of the sub-step solve once more, as one 80-byte record per node (what the fused sub-step kernels read: one
         // base pointer, five 16-byte loads), staged through LDS so that the records leave the block as one contiguous stream
         double *r = rec + 10 * threadIdx.x;
-        r[0] = nm; r[1] = gu; r[2] = gv; r[3] = rl; r[4] = cb; r[5] = fc; r[6] = tax; r[7] = tay; r[8] = s.ocean[n]; r[9] = s.ocean[n + Nn];
+        r[0] = record_dte_over_mass(p, nm); r[1] = gu; r[2] = gv; r[3] = rl; r[4] = cb; r[5] = fc; r[6] = tax; r[7] = tay; r[8] = s.ocean[n]; r[9] = s.ocean[n + Nn];
     }
     __syncthreads();
     {
@@ -715,7 +745,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
         w.VTM[n] = vu;
         w.VTM[n + Nn] = vv;
         d2 *r = reinterpret_cast<d2 *>(w.nrec) + 5 * (size_t)n;
-        r[0] = d2{nm, gu}; r[1] = d2{gv, rl}; r[2] = d2{cb, fc}; r[3] = d2{tax, tay}; r[4] = d2{ocu, ocv};
+        r[0] = d2{record_dte_over_mass(p, nm), gu}; r[1] = d2{gv, rl}; r[2] = d2{cb, fc}; r[3] = d2{tax, tay}; r[4] = d2{ocu, ocv};
     }
     PSTAMP(4);
 }
@@ -724,32 +754,70 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
 // Arithmetic shared by the v1 kernels (one per reference loop) and the v2 fused sub-step kernel, so
 // that both perform literally the same operations in the same order.
 
+// The two sums of updateSigmaDamage that the reference forms with literal zeros among their terms.
+//   strain rates (FE.cpp:4167-4176): eighteen products of M_B0T with the corner velocities, six of them with a literal zero.  A product 0 * x of a finite x is
+//   +-0, and a sum that started at +0 and has only ever had products added to it is never -0 (+0 + -0 = +0, a + -a = +0), so adding +-0 returns it unchanged:
+//   the twelve remaining operations, in the reference's order, give the same bits for every finite velocity.
+//   stress increment (FE.cpp:4204-4210): nine terms dt E D_ij eps_j, four of them with a literal zero of M_Dunit ([[a, b, 0], [b, a, 0], [0, 0, c]] by construction,
+//   FE.cpp:1491-1507).  Each of those is +-0; the sum it is added to is -0 only if the stress component and both of its other terms are -0, which takes dt E == 0
+//   (damage == 1 exactly) on an exactly zero stress: there, and only there, a zero stress can come out as -0 where the reference has +0.
+// ZEROS = true performs every product and addition of the reference's loops (what rounds 1-3 ran); false leaves the literal zeros out: 24 instructions fewer per
+// element update and, in k_substep_pair, 16 registers fewer -- the room in which the own nodes' inputs now stay between the two solves.
+// nxs_dyn_selftest_quotients mode 2 forms both variants on random operands, zeros of both signs among the velocities and stresses: the same bits.
+template <bool ZEROS>
+__device__ __forceinline__ void strain_rates(const double dxN[6], const double u[3], const double v[3], double eps[3]) {
+    eps[0] = eps[1] = eps[2] = 0.;
+    if (ZEROS) {
+        double B0T[18];   // M_B0T (FE.cpp:10242-10249) rebuilt in registers
+#pragma unroll
+        for (int i = 0; i < 18; ++i) B0T[i] = 0.;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            B0T[2 * i] = dxN[i];
+            B0T[2 * i + 13] = dxN[i];
+            B0T[2 * i + 7] = dxN[i + 3];
+            B0T[2 * i + 12] = dxN[i + 3];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                eps[i] += B0T[i * 6 + 2 * j] * u[j];
+                eps[i] += B0T[i * 6 + 2 * j + 1] * v[j];
+            }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            eps[0] += dxN[j] * u[j];
+            eps[1] += dxN[j + 3] * v[j];
+            eps[2] += dxN[j + 3] * u[j];
+            eps[2] += dxN[j] * v[j];
+        }
+    }
+}
+template <bool ZEROS>
+__device__ __forceinline__ void elastic_stress_increment(double sig[3], const double dtE, const double Da, const double Db, const double Dc, const double eps[3]) {
+    const double Dm[9] = {Da, Db, 0., Db, Da, 0., 0., 0., Dc};
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            if (ZEROS || (i < 2) == (j < 2)) sig[i] += dtE * Dm[3 * i + j] * eps[j];
+}
+#ifdef NXS_KEEP_ZERO_TERMS
+#define NXS_ZERO_TERMS true
+#else
+#define NXS_ZERO_TERMS false
+#endif
+
 // updateSigmaDamage body for one element, FE.cpp:4161-4257 (the conc <= 0.1 early-out is the caller's)
 template <bool POW4>
 __device__ __forceinline__ void bbm_stress(const DevParams &p, const double dxN[6], const double u[3], const double v[3],
                                            double sig[3], double &damage, const double expC, const double Pmax,
                                            const double heal, const double dxs, const double cohesion, double *dcrit_out = nullptr) {
     const double dt = p.dte;
-    // M_B0T (FE.cpp:10242-10249) rebuilt in registers, zeros included so that the sums below are the
-    // reference's term for term (FE.cpp:4167-4176)
-    double B0T[18];
-#pragma unroll
-    for (int i = 0; i < 18; ++i) B0T[i] = 0.;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        B0T[2 * i] = dxN[i];
-        B0T[2 * i + 13] = dxN[i];
-        B0T[2 * i + 7] = dxN[i + 3];
-        B0T[2 * i + 12] = dxN[i + 3];
-    }
-    double eps[3] = {0., 0., 0.};
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            eps[i] += B0T[i * 6 + 2 * j] * u[j];
-            eps[i] += B0T[i * 6 + 2 * j + 1] * v[j];
-        }
+    double eps[3];
+    strain_rates<NXS_ZERO_TERMS>(dxN, u, v, eps);
     double sigma_n = (sig[0] + sig[1]) * 0.5;                                    // FE.cpp:4184
     // FE.cpp:4186: std::pow(x, exponent_relaxation_sigma - 1.).  For the default exponent (5 - 1 = 4) the
     // power is formed by two squarings: <= 1.5 ulp from the correctly rounded value, i.e. inside the error
@@ -769,23 +837,19 @@ __device__ __forceinline__ void bbm_stress(const DevParams &p, const double dxN[
     const double multiplicator = STD_MIN(1. - 1e-12, time_viscous / (time_viscous + dt * (1. - tildeP)));  // Q3
     const double elasticity = p.young * (1. - damage) * expC;                    // FE.cpp:4202
     // M_Dunit (FE.cpp:1491-1507) is [[a, b, 0], [b, a, 0], [0, 0, c]] by construction (nxs_dyn.hip fills p.D the same way): three
-    // uniform values instead of nine keep 12 SGPRs out of the hot loop, whose scalar registers spill into VGPR lanes; the zero
-    // entries stay in the sums as literal zeros, so every product and addition of the reference's triple loop is still performed
+    // uniform values instead of nine keep 12 SGPRs out of the hot loop, whose scalar registers spill into VGPR lanes
     const double Da = p.D[0], Db = p.D[1], Dc = p.D[8];
-    const double Dm[9] = {Da, Db, 0., Db, Da, 0., 0., 0., Dc};
+    elastic_stress_increment<NXS_ZERO_TERMS>(sig, dt * elasticity, Da, Db, Dc, eps);   // FE.cpp:4204-4210
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {                                                // FE.cpp:4204-4210
-#pragma unroll
-        for (int j = 0; j < 3; ++j) sig[i] += dt * elasticity * Dm[3 * i + j] * eps[j];
-        sig[i] *= multiplicator;
-    }
+    for (int i = 0; i < 3; ++i) sig[i] *= multiplicator;
     const double sigma_s = hypot((sig[0] - sig[1]) / 2., sig[2]);                // FE.cpp:4218
     sigma_n = (sig[0] + sig[1]) * 0.5;
-    double dcrit;
-    if (sigma_n < -p.compr_strength)
-        dcrit = -p.compr_strength / sigma_n;
-    else
-        dcrit = cohesion / (sigma_s + p.tan_phi * sigma_n);
+    // FE.cpp:4221-4227: one of two quotients -- the operands are chosen first, then ONE division forms it (lanes of a wave take different sides: as two branches
+    // both division sequences ran, 11 instructions each)
+    const bool crushed = sigma_n < -p.compr_strength;
+    const double dcrit_num = crushed ? -p.compr_strength : cohesion;
+    const double dcrit_den = crushed ? sigma_n : sigma_s + p.tan_phi * sigma_n;
+    const double dcrit = dcrit_num / dcrit_den;
     if (dcrit_out) *dcrit_out = dcrit;                                           // (branch trace only)
     if ((0. < dcrit) && (dcrit < 1.)) {                                          // FE.cpp:4229-4243
         const double rtd = sqrt(elasticity) / dxs;
@@ -829,6 +893,9 @@ __device__ __forceinline__ void corner_forces(const double volume, const double 
 }
 
 // "sub-solve" for one node, FE.cpp:10481-10528: (uice, vice) in -> new velocity out
+// DTM: the caller hands over dtep / max(min_m, node_mass) itself -- the nodal records hold that quotient (it does not change during the sub-steps of a step, so the
+// prep kernels divide once per node and step, by the same expression, instead of the solve once per node and sub-step) -- instead of the nodal mass.
+template <bool DTM = false>
 __device__ __forceinline__ void nodal_solve(const DevParams &p, const double gx, const double gy, double &uice, double &vice,
                                             const double node_mass, const double rlm, const double C_bu, const double fcor,
                                             const double lat, const double tau_ax, const double tau_ay, const double ou,
@@ -842,7 +909,7 @@ __device__ __forceinline__ void nodal_solve(const DevParams &p, const double gx,
     } else {
         delu = 0.; delv = 0.; dtep = p.dte;
     }
-    const double dte_over_mass = dtep / STD_MAX(p.min_m, node_mass);
+    const double dte_over_mass = DTM ? node_mass : dtep / STD_MAX(p.min_m, node_mass);
     const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
     const double tau_b = C_bu / (hypot(uice, vice) + p.u0);
     const double alpha = 1. + dte_over_mass * (c_prime * p.cos_ota + tau_b);
@@ -1336,7 +1403,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 const d2 f = lF2[(ent & 3u) * (unsigned)Emax + (ent >> 3)];
                 gx -= f.x; gy -= f.y;
             }
-            nodal_solve(q, gx, gy, uice, vice, node_mass, rlm, cbu, fcor, lat, tax, tay, ou, ov, vtmu, vtmv);
+            nodal_solve<true>(q, gx, gy, uice, vice, node_mass, rlm, cbu, fcor, lat, tax, tay, ou, ov, vtmu, vtmv);
         }
         b.VTn[n] = uice;
         b.VTn[n + Nn] = vice;
@@ -1545,7 +1612,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
             const d2 f = lF2[(ent & 3u) * (unsigned)EDm + (ent >> 3)];
             gx -= f.x; gy -= f.y;
         }
-        nodal_solve(p, gx, gy, uice, vice, in.node_mass, in.rlm, in.cbu, in.fcor, (in.nf & NF_LAT_NEG) ? -1. : 1., in.tax, in.tay, in.ou, in.ov, 0., 0.);
+        nodal_solve<true>(p, gx, gy, uice, vice, in.node_mass, in.rlm, in.cbu, in.fcor, (in.nf & NF_LAT_NEG) ? -1. : 1., in.tax, in.tay, in.ou, in.ov, 0., 0.);
     };
 
     for (int k = 0; k < D; ++k) {
@@ -1615,7 +1682,9 @@ struct PairHalo {
 // MOVE (single rank, one launch per pair): the mesh move of both sub-steps (FE.cpp:10543-10550) is applied to the own nodes HERE -- M_UM / M_UT read and written
 // once per launch, the same two additions per component in the same order as k_move_ring makes them -- instead of once per step from a ring of 120 velocity
 // slots: no k_move_ring, no first velocity slot (nobody reads the first sub-step's velocity after the launch).
-template <int T, bool POW4, int NTM, bool HALO, bool FLOW = false, bool MOVE = false>
+// KEEPN (the single-rank launch): the inputs of a thread's own node (25 registers) stay in registers from the first solve to the second -- no second read of the
+// 97 bytes per own node; the several-rank and the data-flow builds, short of registers, read them again ahead of the second sub-step's last element round.
+template <int T, bool POW4, int NTM, bool HALO, bool FLOW = false, bool MOVE = false, bool KEEPN = false>
 __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &pp, const DevState &s, const DevWork &w, const DevParams &p, const PingPong &b, const VTOut &vout,
                                           const HaloFused *__restrict__ hfp, const PairHalo &ph, const int blk, const unsigned flg, const int t_in = 0) {
     typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1788,7 +1857,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             const d2 f = lF2[(ent & 3u) * (unsigned)EDm + (ent >> 3)];
             gx -= f.x; gy -= f.y;
         }
-        nodal_solve(p, gx, gy, uice, vice, node_mass, in.r[1].y, in.r[2].x, in.r[2].y, (in.nf & NF_LAT_NEG) ? -1. : 1., in.r[3].x, in.r[3].y, in.r[4].x, in.r[4].y, 0., 0.);
+        nodal_solve<true>(p, gx, gy, uice, vice, node_mass, in.r[1].y, in.r[2].x, in.r[2].y, (in.nf & NF_LAT_NEG) ? -1. : 1., in.r[3].x, in.r[3].y, in.r[4].x, in.r[4].y, 0., 0.);
     };
 
     // ---- sub-step 0: elements E_2 (three rounds of the block), state from HBM
@@ -1801,6 +1870,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     // asking for a round's state and constants one round ahead (fits, 126 VGPRs, but delays the re-read: 5.27 against 5.07 ms), touching lines to renew them
     // (gpurun_out/r4_ab5.log, r4_ab6.log, r4_ab10.log).
     d2 kc0[3] = {d2{0., 0.}, d2{0., 0.}, d2{0., 0.}}, kc1[3] = {d2{0., 0.}, d2{0., 0.}, d2{0., 0.}};
+    NodeIn nin{};   // the inputs of this thread's own node, kept from the first solve for the second (the own nodes lead N_1: thread t solves node t in both)
 #pragma unroll
     for (int rr = 0; rr < 3; ++rr) {
         const int r = 2 - rr;
@@ -1840,6 +1910,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         const bool active = i < nN1 && !(HALO && n >= m.No);   // (several ranks: a ghost of N_1 is not solved here, it arrives below)
         NodeIn in{};
         if (active) in = load_node(i, n);
+        if (KEEPN && rr == 0) nin = in;   // (25 registers across the second sub-step's elements: they fit since the strain and stress sums lost their literal zeros, bbm_stress)
         if (rr == 0) { __syncthreads(); NXS_STAMP(6); }  // corner forces of sub-step 0 visible
         if (active) {
             double u1, v1;
@@ -1881,14 +1952,11 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     // for in front of the second round's arithmetic (they were waited for 2.2 us in front of the last barrier: 1.1 now)
     __syncthreads();  // the velocities of sub-step 0 on N_1; the corner forces have been consumed
     NXS_STAMP(2);
-    NodeIn nin{};
     double mv[4] = {0., 0., 0., 0.};   // MOVE: M_UM, M_UT of this thread's own node
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int l = t + r * T;
-        if (r == 1 && t < nO) {
-            nin = load_node(t, my_node);
-        }
+        if (!KEEPN && r == 1 && t < nO) nin = load_node(t, my_node);
         if (l >= nE1) continue;
         const bool writer = eraw[r] >= 0;
         const int e = writer ? eraw[r] : ~eraw[r];
@@ -1970,7 +2038,7 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         const unsigned flg = ph.pflags[blk];   // this patch's duties in the exchange (uniform over the workgroup)
         if (flg & 1u) { pair_body<T, POW4, NTM, true>(m, pp, s, w, p, b, vout, hfp, ph, blk, flg); return; }
     }
-    pair_body<T, POW4, NTM, false, false, MOVE>(m, pp, s, w, p, b, vout, hfp, ph, blk, 0u);
+    pair_body<T, POW4, NTM, false, false, MOVE, !HALO>(m, pp, s, w, p, b, vout, hfp, ph, blk, 0u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2341,7 +2409,7 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
                     const d2 f = lF2[(ent & 3u) * (unsigned)Emax + (ent >> 3)];
                     gx -= f.x; gy -= f.y;
                 }
-                nodal_solve(q, gx, gy, uice, vice, node_mass, lN[3 * (size_t)Pmax + tt], lN[4 * (size_t)Pmax + tt], lN[5 * (size_t)Pmax + tt],
+                nodal_solve<true>(q, gx, gy, uice, vice, node_mass, lN[3 * (size_t)Pmax + tt], lN[4 * (size_t)Pmax + tt], lN[5 * (size_t)Pmax + tt],
                             (nf & NF_LAT_NEG) ? -1. : 1., lN[6 * (size_t)Pmax + tt], lN[7 * (size_t)Pmax + tt], lN[8 * (size_t)Pmax + tt],
                             lN[9 * (size_t)Pmax + tt], 0., 0.);
             }
@@ -2733,7 +2801,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     const d2 f = lF2[(ent & 3u) * (unsigned)Emax + (ent >> 3)];
                     gx -= f.x; gy -= f.y;
                 }
-                nodal_solve(q, gx, gy, uice, vice, node_mass, nr[i][1].y, nr[i][2].x, nr[i][2].y, (nf & NF_LAT_NEG) ? -1. : 1., nr[i][3].x, nr[i][3].y, nr[i][4].x, nr[i][4].y, 0., 0.);
+                nodal_solve<true>(q, gx, gy, uice, vice, node_mass, nr[i][1].y, nr[i][2].x, nr[i][2].y, (nf & NF_LAT_NEG) ? -1. : 1., nr[i][3].x, nr[i][3].y, nr[i][4].x, nr[i][4].y, 0., 0.);
             }
             lu[sl] = uice; lv[sl] = vice;
             if (move_dt != 0.) {  // FE.cpp:10543-10550; Neumann nodes keep M_UM (restore == skip)

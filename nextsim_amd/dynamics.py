@@ -249,13 +249,16 @@ class FiniteElementDynamics:
         lm = self.lm
         blob = C.create_string_buffer(IPC_BLOB_BYTES)
         ok = 1
+        self._ipc_error = ""
         try:
             self._chk(self.L.nxs_dyn_ipc_export(self.h, blob))
-        except NxsError:
+        except NxsError as e:
+            self._ipc_error = f"rank {lm.rank}: export: {e}"
             ok = 0
         infos = all_gather({"ok": ok, "blob": blob.raw, "recv_procs": lm.recv_procs.tolist(),
-                            "recv_offsets": lm.recv_offsets.tolist()})
+                            "recv_offsets": lm.recv_offsets.tolist(), "err": self._ipc_error})
         if not all(i["ok"] for i in infos):
+            self._ipc_error = "; ".join(i["err"] for i in infos if i["err"])   # (every rank reports what any rank saw)
             return False
         blobs, off, tot, slot = b"", [], [], []
         for q in lm.send_procs.tolist():
@@ -270,19 +273,25 @@ class FiniteElementDynamics:
             self._chk(self.L.nxs_dyn_ipc_connect(self.h, bbuf, _abi.iptr(np.ascontiguousarray(a_off)),
                                                  _abi.iptr(np.ascontiguousarray(a_tot)), _abi.iptr(np.ascontiguousarray(a_slot))))
         except NxsError as e:
-            self._ipc_error = str(e)
+            self._ipc_error = f"rank {lm.rank}: connect: {e}"
             ok = 0
-        if not all(all_gather(ok)):
+        oks = all_gather((ok, self._ipc_error))
+        if not all(o for o, _ in oks):
+            self._ipc_error = "; ".join(m for _, m in oks if m)
             self.L.nxs_dyn_set_halo(self.h, C.byref(_abi.halo_struct(lm)))  # drops the half-made transport
             return False
         err = C.c_int32(0)
         try:
             self._chk(self.L.nxs_dyn_ipc_selftest(self.h, selftest_rounds, C.byref(err)))
         except NxsError as e:   # still take part in the gather below: the other ranks are waiting in it
-            self._ipc_error = str(e)
+            self._ipc_error = f"rank {lm.rank}: self-test: {e}"
             err.value = err.value or -1
-        good = all(e == 0 for e in all_gather(int(err.value)))
+        if err.value and not self._ipc_error:
+            self._ipc_error = f"rank {lm.rank}: self-test: {err.value} payload(s) wrong"
+        errs = all_gather((int(err.value), self._ipc_error))
+        good = all(e == 0 for e, _ in errs)
         if not good:
+            self._ipc_error = "; ".join(m for _, m in errs if m)
             self.L.nxs_dyn_set_halo(self.h, C.byref(_abi.halo_struct(lm)))
         return good
 

@@ -620,6 +620,15 @@ def test_the_mesh_move_inside_the_pair_launch_does_not_change_a_bit(kind, over, 
         assert np.array_equal(states[0][0][k], states[2][0][k]), k
 
 
+def test_sums_without_the_literal_zero_terms_are_the_reference_sums():
+    """updateSigmaDamage forms its strain rates and its stress increment with literal zeros of M_B0T and M_Dunit among the terms (FE.cpp:4167-4176, 4204-4210); the
+    kernels leave those products out (adding +-0 to a sum that cannot be -0 returns it unchanged).  4 x 10^8 random operand sets, zeros of both signs among the
+    velocities and the stresses, with and without the terms: the same bits."""
+    from nextsim_amd import dynamics
+    for seed in (3, 977):
+        assert dynamics.selftest_quotients(200_000_000, seed=seed, mode=2) == 0
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 def test_quotients_by_one_divisor_are_the_divisions(mode):
     """The six shape coefficients of a triangle are six quotients by its Jacobian; the sub-step kernels refine the Jacobian's reciprocal once and finish every
@@ -922,7 +931,9 @@ def test_traffic_model_and_step_times(kind, opts, kernel, D):
     t = fe.traffic_model()
     assert t["substep_kernel_name"] == kernel and t["substeps_per_launch"] == D and t["halo_in_kernel"] == 0, t
     assert 0 < t["substep_unique_bytes"] <= t["substep_scheme_bytes"], t
-    assert (t["substep_reread_bytes"] > 0) == (kernel in ("k_substep_pair", "k_substep_multi")), t
+    # second reads: the several-sub-steps kernel always has them; k_substep_pair on one rank only where a patch has a second round of E_1 elements (their constants)
+    assert t["substep_reread_bytes"] > 0 if kernel == "k_substep_multi" else t["substep_reread_bytes"] >= 0, t
+    if kernel not in ("k_substep_pair", "k_substep_multi"): assert t["substep_reread_bytes"] == 0, t
     Ne, Nn = lm.num_elements, lm.num_nodes
     assert abs(t["survey_model_bytes"] - (172. * Ne + 217. * Nn) * D) < 1.
     assert t["substep_unique_bytes"] >= D * 16. * Nn and t["substep_unique_bytes"] >= 112. * Ne    # at least: every velocity out, state in + out + constants
