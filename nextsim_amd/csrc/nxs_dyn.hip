@@ -2390,7 +2390,7 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
     const auto &s2 = h->sums2;
     switch (h->last_kernel) {
     case NXS_KERNEL_PAIR: case NXS_KERNEL_PAIR_FLOW: if (s2.N.size() == 3 && s2.E.size() == 2) {
-        const double fanw = 2. * std::min(h->dpch2.Wp, 8);
+        const double fanw = 16.;   // (four words of ready-made LDS indices per solved node: DevPatches2::pfan8)
         const double N0 = s2.N[0], N1 = s2.N[1], N2 = s2.N[2], E2 = s2.E[1];
         t->substeps_per_launch = 2;
         t->substep_scheme_bytes = s2.nP * 20. /*ncnt, ecnt*/ + N2 * (4. /*pnodes*/ + 16. /*VT*/ + 16. /*xy*/) + E2 * (8. /*pet*/ + 32. /*S in*/ + 48. /*erec*/)

@@ -89,6 +89,8 @@ struct DevPatches2 {
     const unsigned short *pnbr;   // [nP][W2][NSmax] NodalConnectivity row of every node of N_(D-1) in patch-local slots, bamg order (Q8), 0xFFFF pad;
     int W2;                       //                 NULL when a row leaves its patch (then the smoother runs sweep by sweep)
     const int2 *pet;              // [nP][EDmax] {pelem, the three corner slots in 10 bits each}: what k_substep_pair reads (8 bytes per element instead of 12; NDmax <= 1024), else NULL
+    const unsigned int *pfan8;    // [nP][4][NSmax] k_substep_pair: the first eight fan entries of every solved node as what the gather needs -- the LDS index of the corner's force
+                                  // (corner * EDmax + element slot; 3 * EDmax, the pair of zeros, for pads and ghost corners), two per word: decoded on the host, once
     int own_is_block;             // the own nodes of patch q are the nodes [256 q, 256 q + 256): k_prep_nodes' open-water flag of that block applies
 };
 struct VTOut { double *slot[NXS_MAX_DEPTH]; };  // ring slots of the D velocities a launch produces
@@ -1746,6 +1748,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     const int *pn = pp.pnodes + (size_t)blk * NDm;
     const int2 *pet = pp.pet + (size_t)blk * EDm;   // {element, corner slots in ten bits each}: 8 bytes per element (as k_substep_fused)
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
+    const unsigned int *pf8 = pp.pfan8 + (size_t)blk * 4 * pp.NSmax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
     constexpr bool NT_S = NTM & 1;
     const bool shape_in_range = w.shape_range[0] == 0;   // (uniform; written by the prep kernels, before any launch of the loop)
@@ -1825,14 +1828,10 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         const d2 *q = reinterpret_cast<const d2 *>(w.nrec) + 5 * (size_t)n;
 #pragma unroll
         for (int k = 0; k < 5; ++k) in.r[k] = q[k];
+        // the first eight fan entries as LDS indices, two per word (pad entries and ghost corners -- ghostNodes[i], FE.cpp:10456 -- name the pair of zeros): read ready-made
+        // (round 4: decoding them here cost ~45 integer instructions per solve)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // pad entries and ghost corners (ghostNodes[i], FE.cpp:10456) name the pair of zeros
-            const unsigned e0 = (2 * k < pp.Wp) ? pf[(size_t)(2 * k) * pp.NSmax + i] : 0xFFFFu;
-            const unsigned e1 = (2 * k + 1 < pp.Wp) ? pf[(size_t)(2 * k + 1) * pp.NSmax + i] : 0xFFFFu;
-            const unsigned i0 = (e0 == 0xFFFFu || (e0 & 4u)) ? ZIDX : (e0 & 3u) * (unsigned)EDm + (e0 >> 3);
-            const unsigned i1 = (e1 == 0xFFFFu || (e1 & 4u)) ? ZIDX : (e1 & 3u) * (unsigned)EDm + (e1 >> 3);
-            in.fw[k] = i0 | (i1 << 16);
-        }
+        for (int k = 0; k < 4; ++k) in.fw[k] = pf8[(size_t)k * pp.NSmax + i];
         return in;
     };
     auto solve_node = [&](const int i, const NodeIn &in, double &uice, double &vice) {

@@ -71,6 +71,12 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
         if ((rc = dev_upload(h, h->pair_allocs, &dpet, pet))) return rc;
         d.pet = reinterpret_cast<const int2 *>(dpet);
     }
+    d.pfan8 = nullptr;
+    if (plan.pair_kernel) {   // the first eight fan entries of every solved node, decoded: the LDS index of the corner's force, two per word (nxs_cut::decode_fan8)
+        std::vector<unsigned int> f8;
+        nxs_cut::decode_fan8(hp, f8);
+        if ((rc = dev_upload(h, h->pair_allocs, &d.pfan8, f8))) return rc;
+    }
     // NodalConnectivity rows in patch-local slots, for D smoother sweeps per launch (k_smooth_multi)
     d.W2 = m.W2;
     d.pnbr = nullptr;
@@ -176,6 +182,11 @@ int upload_pair_patches_mr(nxs_dyn_handle *h) {
         const int *dpet = nullptr;
         if ((rc = dev_upload(h, h->pair_allocs, &dpet, pet))) return rc;
         d.pet = reinterpret_cast<const int2 *>(dpet);
+    }
+    {
+        std::vector<unsigned int> f8;
+        nxs_cut::decode_fan8(hp, f8);
+        if ((rc = dev_upload(h, h->pair_allocs, &d.pfan8, f8))) return rc;
     }
     d.W2 = m.W2; d.pnbr = nullptr;
     if ((rc = dev_upload(h, h->pair_allocs, &h->pairh.pflags, plan.pflags))) return rc;

@@ -555,6 +555,25 @@ inline size_t multi_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax 
 inline size_t pair_lds_of(const HostPatches2 &x) { return (4 * (size_t)x.NDmax + 6 * (size_t)x.EDmax + 4) * sizeof(double); }
 inline bool pair_kernel_fits(const HostPatches2 &x, int own_max, int T = 512) { return x.D == 2 && x.EDmax <= 3 * T && x.ESmax <= 2 * T && x.NSmax <= 2 * T && own_max <= T && x.NDmax <= 1024 /*corner slots travel in ten bits*/; }
 
+// k_substep_pair's fan gather reads eight 16-byte corner forces per solved node from LDS: [3][EDmax] pairs, the pair of zeros behind them.  The first eight fan
+// entries of every solved node as the LDS indices themselves (corner * EDmax + element slot; 3 * EDmax for a pad entry or a ghost corner, FE.cpp:10456), two per
+// 32-bit word: out[(q * 4 + k) * NSmax + i] = index of entry 2k | index of entry 2k + 1 << 16.  (3 * EDmax + 1 <= 65 536: EDmax <= 3 * 512.)
+inline void decode_fan8(const HostPatches2 &hp, std::vector<unsigned int> &out) {
+    out.assign((size_t)hp.nP * 4 * hp.NSmax, 0u);
+    const unsigned zidx = 3u * (unsigned)hp.EDmax;
+    for (int q = 0; q < hp.nP; ++q)
+        for (int i = 0; i < hp.NSmax; ++i)
+            for (int k = 0; k < 4; ++k) {
+                unsigned idx[2];
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int row = 2 * k + h2;
+                    const unsigned ent = row < hp.Wp ? hp.pfan[((size_t)q * hp.Wp + row) * hp.NSmax + i] : 0xFFFFu;
+                    idx[h2] = (ent == 0xFFFFu || (ent & 4u)) ? zidx : (ent & 3u) * (unsigned)hp.EDmax + (ent >> 3);
+                }
+                out[((size_t)q * 4 + k) * hp.NSmax + i] = idx[0] | (idx[1] << 16);
+            }
+}
+
 // k_substep_flow (one launch per step, tasks = (pair of sub-steps, patch)): which patches must have finished pair-step k - 1 before patch q may start pair-step k.
 //   q READS the state of the elements of its outer level from the buffer their WRITERS filled in the pair-step before, and the velocities of the nodes it stages
 //   from the slot their OWNERS filled;
