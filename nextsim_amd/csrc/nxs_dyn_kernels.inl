@@ -913,7 +913,8 @@ __device__ __forceinline__ void nodal_solve(const DevParams &p, const double gx,
     }
     const double dte_over_mass = DTM ? node_mass : dtep / STD_MAX(p.min_m, node_mass);
     const double c_prime = NXS_RHOW * p.qdw * hypot(ou - uice, ov - vice);
-    const double tau_b = C_bu / (hypot(uice, vice) + p.u0);
+    // (FE.cpp:10498: where no ice is grounded C_bu is +0 and the quotient, over a positive denominator, +0 too: a wave without a grounded node skips the hypot and the division)
+    const double tau_b = (C_bu == 0. && p.u0 > 0.) ? 0. : C_bu / (hypot(uice, vice) + p.u0);
     const double alpha = 1. + dte_over_mass * (c_prime * p.cos_ota + tau_b);
     const double beta = dtep * fcor + dte_over_mass * c_prime * copysign(p.sin_ota, lat);
     const double rdenom = 1. / (alpha * alpha + beta * beta);
