@@ -1479,6 +1479,7 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
     const int *pe = pp.pelem + (size_t)blk * EDm;
     const ushort4 *pt = reinterpret_cast<const ushort4 *>(pp.ptri) + (size_t)blk * EDm;
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.NSmax;
+    const unsigned int *pf8 = pp.pfan8 + (size_t)blk * 4 * pp.NSmax;
     const bool bbm = p.dynamics_type == NXS_DYN_BBM;
     constexpr bool NT_S = NTM & 1, NT_C = NTM & 4;
 
@@ -1587,14 +1588,9 @@ __global__ void __launch_bounds__(T) k_substep_multi(DevMesh m, DevPatches2 pp, 
         const d2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4];
         in.node_mass = r0.x; in.gx = r0.y; in.gy = r1.x; in.rlm = r1.y; in.cbu = r2.x; in.fcor = r2.y;
         in.tax = r3.x; in.tay = r3.y; in.ou = r4.x; in.ov = r4.y;
+        // pad entries and ghost corners (ghostNodes[i], FE.cpp:10456) name the pair of zeros: ready-made LDS indices, two per word (DevPatches2::pfan8, as k_substep_pair)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {  // pad entries and ghost corners (ghostNodes[i], FE.cpp:10456) name the pair of zeros
-            const unsigned e0 = (2 * k < pp.Wp) ? pf[(size_t)(2 * k) * pp.NSmax + i] : 0xFFFFu;
-            const unsigned e1 = (2 * k + 1 < pp.Wp) ? pf[(size_t)(2 * k + 1) * pp.NSmax + i] : 0xFFFFu;
-            const unsigned i0 = (e0 == 0xFFFFu || (e0 & 4u)) ? ZIDX : (e0 & 3u) * (unsigned)EDm + (e0 >> 3);
-            const unsigned i1 = (e1 == 0xFFFFu || (e1 & 4u)) ? ZIDX : (e1 & 3u) * (unsigned)EDm + (e1 >> 3);
-            in.fw[k] = i0 | (i1 << 16);
-        }
+        for (int k = 0; k < 4; ++k) in.fw[k] = pf8[(size_t)k * pp.NSmax + i];
         return in;
     };
     auto solve_node = [&](const int i, NodeIn &in, double &uice, double &vice) {

@@ -72,7 +72,7 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
         d.pet = reinterpret_cast<const int2 *>(dpet);
     }
     d.pfan8 = nullptr;
-    if (plan.pair_kernel) {   // the first eight fan entries of every solved node, decoded: the LDS index of the corner's force, two per word (nxs_cut::decode_fan8)
+    {   // the first eight fan entries of every solved node, decoded: the LDS index of the corner's force, two per word (nxs_cut::decode_fan8)
         std::vector<unsigned int> f8;
         nxs_cut::decode_fan8(hp, f8);
         if ((rc = dev_upload(h, h->pair_allocs, &d.pfan8, f8))) return rc;
