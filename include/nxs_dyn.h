@@ -380,6 +380,9 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  happen inside it -- the patches along the partition boundary store their first velocities into the neighbours' mailboxes, wait for
  *                  the neighbours' and go on, every other patch runs the single-rank body.  -1 (default) = on meshes / partitions of more than 65 k nodes
  *                  (smaller single-rank meshes run four sub-steps per launch, one patch per CU), 0 = never, 1 = wherever it can run
+ *   "pair_hilbert" single rank: 1 = the two-ring patches are cut along a Hilbert curve even where the caller's numbering has locality (experiment: at 2 km the rings get
+ *                  THICKER -- nodes x 1.27 / 1.54 instead of x 1.25 / 1.51 -- and the own nodes of a patch are no longer contiguous: 4.51-4.77 against 4.30-4.42 ms of
+ *                  sub-steps); 0 (default) = only where the numbering has none
  *   "pair_move"    single rank, k_substep_pair with 512 threads, no "um_ring": the launch applies the mesh move of its two sub-steps (FE.cpp:10543-10550) to its
  *                  own nodes itself -- M_UM and M_UT read and written once per launch, the additions in the order the deferred flush makes them -- so the
  *                  step needs no ring of one velocity buffer per sub-step (120 x 11.7 MB at 2 km) and no k_move_ring: 2 km 5.27 -> 5.17 ms per step, the

@@ -114,6 +114,7 @@ struct nxs_dyn_handle {
     int pair_regs = -1;                    // option "pair_regs": two sub-steps per launch with the stresses between them in registers (k_substep_pair): -1 = on
                                            // single-rank meshes of more than 65 k nodes (an even number of sub-steps), 0 = never, 1 = wherever depth 2 runs
     bool pair_kernel = false;              // the multi-sub-step patches were cut for k_substep_pair
+    int pair_hilbert = 0;                  // option "pair_hilbert": 1 = the two-ring patches of a single rank are cut along a Hilbert curve even where the caller's numbering has locality
     int pair_move = -1;                    // option "pair_move": k_substep_pair on a single rank applies the mesh move of its two sub-steps itself (no ring of velocity slots, no
                                            // k_move_ring): -1 = automatic, 0 = never (the move deferred to one flush per step), 1 = wherever that kernel runs on one rank
     bool move_now = false, last_move_in_pair = false;                 // ... decided for the step being built (run_substeps), read by launch_multi
@@ -802,6 +803,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         if (value != 256 && value != 512) return fail(h, NXS_ERR_INVALID, "pair_threads must be 256 or 512");
         h->pair_T = (int)value; h->pair_ready = false; h->pair_failed = false; h->pair_hint = 0; release_graph(h); return NXS_OK;
     }
+    if (!std::strcmp(key, "pair_hilbert")) { h->pair_hilbert = value != 0; h->pair_ready = false; h->pair_failed = false; h->pair_hint = 0; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "pair_move")) { h->pair_move = value < 0 ? -1 : (value != 0); release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "pair_flow")) { h->pair_flow = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; h->flow_failed = false; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "pair_regs")) { h->pair_regs = value < 0 ? -1 : (value != 0); h->pair_ready = false; h->pair_failed = false; release_graph(h); return NXS_OK; }

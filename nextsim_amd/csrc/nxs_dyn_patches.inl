@@ -20,7 +20,7 @@ int upload_patches2(nxs_dyn_handle *h, int D, bool single_round_only, bool for_p
     h->pair_ready = false;
     const DevMesh &m = h->dm;
     nxs_cut::Patch2Plan plan;
-    const std::string why = nxs_cut::plan_patches2(mesh_view(h), h->hp && h->hp->used_hilbert, h->pair_nodes, D, single_round_only, device_cus(h),
+    const std::string why = nxs_cut::plan_patches2(mesh_view(h), (h->hp && h->hp->used_hilbert) || h->pair_hilbert == 1, h->pair_nodes, D, single_round_only, device_cus(h),
                                                    h->h_n2n, h->h_n2n_cnt, m.W2, plan, for_pair_kernel, h->pair_hint, h->pair_T);
     if (!why.empty()) return fail(h, m.No != m.Nn ? NXS_ERR_STATE : NXS_ERR_INVALID, "%s", why.c_str());
     const HostPatches2 &hp = plan.hp;
