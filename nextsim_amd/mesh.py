@@ -128,6 +128,35 @@ def _hilbert_key(ix: np.ndarray, iy: np.ndarray, order: int = 16) -> np.ndarray:
     return d
 
 
+def tile_numbering(x: np.ndarray, y: np.ndarray, tile: int, key: np.ndarray) -> np.ndarray:
+    """A node numbering made of compact TILES of exactly `tile` nodes (the last one fewer): the node set is bisected recursively, by count, across the longer
+    side of its bounding box, into parts that are whole multiples of `tile`; a part of one tile is numbered along `key` (a space-filling-curve key).  Returns
+    order with order[new] = old.  Runs of `tile` consecutive numbers are then near-square blocks -- what a patch kernel with two rings of halo wants: rings of
+    x 1.20 / x 1.42 nodes instead of the x 1.25 / x 1.51 of runs along a Hilbert curve."""
+    n = x.size
+    out = np.empty(n, np.int64)
+    stack = [(np.arange(n, dtype=np.int64), 0)]
+    while stack:
+        idx, start = stack.pop()
+        k = -(-idx.size // tile)
+        if k <= 1:
+            out[start:start + idx.size] = idx[np.argsort(key[idx], kind="stable")]
+            continue
+        xs, ys = x[idx], y[idx]
+        c = xs if (xs.max() - xs.min()) >= (ys.max() - ys.min()) else ys
+        o = np.argsort(c, kind="stable")
+        n1 = (k // 2) * tile
+        # which half comes first: the one that holds the smaller curve key, so that consecutive tiles stay neighbours in space as far as a bisection tree allows
+        left, right = idx[o[:n1]], idx[o[n1:]]
+        if key[left].min() > key[right].min():
+            # (the right part may hold the short last tile: it must stay LAST in its range, so only equal-multiple parts swap)
+            if right.size % tile == 0:
+                left, right = right, left
+        stack.append((right, start + left.size))
+        stack.append((left, start))
+    return out
+
+
 def _lattice_mesh(nx: int, ny: int, h: float, x0: float, y0: float, inside, jitter: float, seed: int,
                   open_boundary, name: str, reorder: bool = True) -> GlobalMesh:
     """Triangulate the (nx+1) x (ny+1) lattice of spacing h (rows offset by h/2: near-equilateral
@@ -172,8 +201,10 @@ def _lattice_mesh(nx: int, ny: int, h: float, x0: float, y0: float, inside, jitt
         # space-filling-curve numbering of nodes and elements: neighbours in space are neighbours in memory
         import os as _os
         curve = _os.environ.get("NXS_MESH_CURVE", "hilbert")
-        key = _hilbert_key(lat_i, lat_j) if curve == "hilbert" else _morton_key(lat_i, lat_j)
+        key = _hilbert_key(lat_i, lat_j) if curve in ("hilbert", "tiles") else _morton_key(lat_i, lat_j)
         order = np.argsort(key, kind="stable")
+        if curve == "tiles":   # compact tiles of NXS_MESH_TILE nodes (recursive bisection by node count), tiles and the nodes inside a tile along the Hilbert curve
+            order = tile_numbering(px, py, int(_os.environ.get("NXS_MESH_TILE", "428")), key)
         inv = np.empty(nn, np.int64); inv[order] = np.arange(nn)
         px, py, dirichlet, neumann = px[order], py[order], dirichlet[order], neumann[order]
         tri = inv[tri]
