@@ -1710,6 +1710,9 @@ void launch_multi(nxs_dyn_handle *h, int sidx, int D, bool halo = false) {
             return;
         }
         if (h->move_now) {   // the mesh move of the two sub-steps inside the launch
+            // (the first velocity slot is not written; the LAST launch of a step whose final velocity lands in M_VT itself writes it a second time there instead: the
+            // smoother wants two equal buffers and would otherwise copy one)
+            vo.slot[0] = (sidx + D == h->dp.substeps && (h->dp.substeps % R) == 0) ? h->ring.slot[(sidx + 1) % R] : nullptr;
             if (pow4) hipLaunchKernelGGL((k_substep_pair<512, true, 3, false, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
             else hipLaunchKernelGGL((k_substep_pair<512, false, 3, false, true>), grid, dim3(512), h->pair_lds, h->stream, h->dm, h->dpch2, h->ds, h->dw, h->dp, b, vo, (const HaloFused *)nullptr, PairHalo{});
             return;
@@ -2030,6 +2033,8 @@ int run_substeps(nxs_dyn_handle *h) {
     // ring slot it came from then equals M_VT and serves the smoother as its second buffer (no copy before the sweeps)
     double *const vt_back = (deferred && !resident && !move_in_pair && (S % R) != 0) ? h->ds.VT : nullptr;
     h->smooth_second = vt_back ? h->ring.slot[S % R] : nullptr;
+    if (move_in_pair)   // the final velocity: in a ring slot that k_pingpong_copy_back copies into M_VT, or in M_VT itself with a second copy in the last launch's free slot
+        h->smooth_second = (S % R) ? h->ring.slot[S % R] : h->ring.slot[(S - D + 1) % R];
     auto pull_latest = [&](double *vec) {
         const int tr = h->recv_offsets[h->recv_procs.size()];
         hipLaunchKernelGGL(k_halo_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, vec, h->dm, h->ds, tr, h->d_recv_index,

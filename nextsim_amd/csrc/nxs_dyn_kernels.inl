@@ -1979,6 +1979,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
             solve_node(t, nin, u1, v1);
             if (FLOW) { st_agent(vout.slot[1] + my_node, u1); st_agent(vout.slot[1] + my_node + Nn, v1); }
             else { vout.slot[1][my_node] = u1; vout.slot[1][my_node + Nn] = v1; }
+            if (MOVE && vout.slot[0]) { vout.slot[0][my_node] = u1; vout.slot[0][my_node + Nn] = v1; }   // (the last launch of a step: the smoother's second buffer)
             if (MOVE) {   // FE.cpp:10543-10550, twice: Neumann nodes keep M_UM (k_move_ring)
                 const double dt = p.dte;
                 if (!(nin.nf & NF_NEUMANN)) {
