@@ -1021,6 +1021,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     HIPCHK(h, hipMemsetAsync(w.D_tau_w, 0, n2 * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(w.D_del, 0, ne * sizeof(double), h->stream));
     HIPCHK(h, hipMemsetAsync(w.shape_range, 0, sizeof(int), h->stream));
+    HIPCHK(h, hipMemsetAsync(w.open_blk, 0, (size_t)nblocks(Nn), h->stream));
 
     if (h->d_partials) { (void)hipFree(h->d_partials); h->d_partials = nullptr; }
     h->n_partials = std::min(nblocks(Ne), 1024);
@@ -2191,7 +2192,8 @@ int explicit_solve(nxs_dyn_handle *h) {
     // (automatic: meshes that stream from HBM; on cache-resident ones the two small kernels are as fast: 10 km 24.7 vs 27.4 us)
     if (eff_fused(h) != 0 && !h->work_arrays && (h->prep_fused == 1 || (h->prep_fused < 0 && m.Ne >= 250000)) && h->prep_lds > 0 && h->dpch.prow && h->dpch.nP > 0 && !multi_rank(h)) {
         // one launch over the sub-step kernel's patches: the elements' values reach their nodes through LDS (k_prep_fused)
-        HIPCHK(h, hipMemsetAsync(h->dw.open_blk, 0, (size_t)nblocks(m.Nn), h->stream));  // (k_prep_elements' first lines)
+        // (the open-water flags of the node blocks are lowered by the step before -- k_update's first threads, as the range flag -- and at allocation: no memset per step;
+        // a step that ended without update() leaves them raised, which only costs the smoother some blocks it could have skipped)
         hipLaunchKernelGGL(k_prep_fused, dim3(h->dpch.nP), dim3(512), h->prep_lds, h->stream, m, h->dpch, h->ds, h->dw, h->dp);
         HIPCHK(h, hipGetLastError());
         h->last_prep = NXS_PREP_FUSED;

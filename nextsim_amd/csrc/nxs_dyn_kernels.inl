@@ -3467,6 +3467,7 @@ __global__ void __launch_bounds__(BLOCK) k_update(DevMesh m, DevState s, DevWork
     const int e = blockIdx.x * BLOCK + threadIdx.x;
     if (e >= m.Ne) return;
     if (e == 0) w.shape_range[0] = 0;   // the step's sub-steps are over: the next step's prep kernels judge its own coordinates
+    if (e < (m.Nn + BLOCK - 1) / BLOCK) w.open_blk[e] = 0;   // ... and raise the open-water flags of their node blocks anew (k_prep_fused; k_prep_elements lowers them itself)
     const bool to_be_updated = !(m.eflags[e] & EF_ON_NEUMANN);
     double D_del = 0.;
     const double surface_old = w.surface[e];
