@@ -294,6 +294,22 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
                 REQUIRE(pk.pair_kernel && pk.threads == 512 && pk.lds == pair_lds_of(pk.hp) && pk.lds <= 80 * 1024 && pair_kernel_fits(pk.hp, own_max),
                         "pair plan: P=%d lds=%zu EDmax=%d ESmax=%d NSmax=%d own=%d", pk.P, pk.lds, pk.hp.EDmax, pk.hp.ESmax, pk.hp.NSmax, own_max);
             }
+            if (w5.empty()) {   // the ready-made fan indices of k_substep_pair / k_substep_multi: every entry names a corner force of the patch or the pair of zeros
+                const HostPatches2 &x = pk.hp;
+                std::vector<unsigned int> f8;
+                decode_fan8(x, f8);
+                REQUIRE(f8.size() == (size_t)x.nP * 4 * x.NSmax, "decode_fan8 size%s", "");
+                const unsigned zidx = 3u * (unsigned)x.EDmax;
+                for (int q = 0; q < x.nP; ++q)
+                    for (int i = 0; i < x.ncnt[(size_t)q * 3 + 1]; ++i)
+                        for (int k = 0; k < 8; ++k) {
+                            const unsigned idx = (f8[((size_t)q * 4 + k / 2) * x.NSmax + i] >> (16 * (k & 1))) & 0xFFFFu;
+                            const unsigned ent = k < x.Wp ? x.pfan[((size_t)q * x.Wp + k) * x.NSmax + i] : 0xFFFFu;
+                            if (ent == 0xFFFFu || (ent & 4u)) REQUIRE(idx == zidx, "patch %d node %d entry %d: a pad or ghost corner must name the pair of zeros", q, i, k);
+                            else REQUIRE(idx == (ent & 3u) * (unsigned)x.EDmax + (ent >> 3) && (ent >> 3) < (unsigned)x.ecnt[(size_t)q * 2 + 1] && (ent & 3u) < 3u,
+                                         "patch %d node %d entry %d: index %u", q, i, k, idx);
+                        }
+            }
             if (w5.empty()) {   // k_substep_flow: what a patch waits for -- the writers of its outer elements, the owners of its staged nodes, the reverse relation, itself
                 const HostPatches2 &x = pk.hp;
                 std::vector<int> ptr, dep;
