@@ -251,7 +251,12 @@ NXS_API int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors);
  * the runtime refuses it, and the caller stays on RCCL or its own communicator.  Neighbour handles may live in other processes
  * (hipIpc) or in this one (a host that drives several GPUs from one process); ipc_connect checks the tables it is given against
  * what each neighbour published, and a second connect replaces the first.  The self-test pushes checked payloads through every
- * link with both publishing protocols the step can use (one release per block / one per launch). */
+ * link with both publishing protocols the step can use (one release per block / one per launch).
+ * NEIGHBOURS IN BOTH DIRECTIONS: a mailbox has two buffers per link, which is safe because "a neighbour cannot start exchange x + 2 before it has received my
+ * exchange x + 1, which I send only after my pull of exchange x" -- a hand-shake that needs every rank I send to to send to me as well.  A ragged partition can
+ * send a node to a rank it receives nothing from; the halo lists of nxs_dyn_set_halo must then name that rank in BOTH lists, the direction without nodes as an
+ * empty segment (offsets[k + 1] == offsets[k]; on both ranks).  ipc_connect returns NXS_ERR_INVALID for one-directional neighbours (round 4: found as one wrong
+ * payload in the self-test of a 4-rank mosaic; RCCL and the host-staged transport do not need the pairing, an empty segment is a message of no bytes to them). */
 #define NXS_IPC_BLOB_BYTES 128
 NXS_API int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob);
 NXS_API int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset,

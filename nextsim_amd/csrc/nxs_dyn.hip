@@ -1260,6 +1260,21 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     HIPCHK(h, hipSetDevice(h->device));
     const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
     if (ns > 0 && (!blobs || !peer_recv_offset || !peer_recv_total || !peer_flag_slot)) return fail(h, NXS_ERR_INVALID, "ipc_connect: NULL tables");
+    {   // Two buffers per link are safe only with a hand-shake: "a neighbour cannot start exchange x + 2 before it has received my exchange x + 1, which I send only
+        // after my pull of exchange x" (k_halo_push) holds when every rank I send to also sends to me.  A rank that sends to q without receiving from q could run two
+        // exchanges ahead of q and overwrite the half q still reads -- seen once in round 4 as a wrong payload in the self-test of a 4-rank mosaic whose rank 0 sends to
+        // rank 3 and receives nothing from it.  So the device-direct transport wants the two neighbour sets equal; a direction that carries no node is an EMPTY
+        // segment (its flag is still raised and waited for: that is the hand-shake).
+        std::vector<int> sp(h->send_procs.begin(), h->send_procs.end()), rp(h->recv_procs.begin(), h->recv_procs.end());
+        std::sort(sp.begin(), sp.end()); std::sort(rp.begin(), rp.end());
+        if (sp != rp) {
+            int odd = -1;
+            for (int q : sp) if (!std::binary_search(rp.begin(), rp.end(), q)) { odd = q; break; }
+            if (odd < 0) for (int q : rp) if (!std::binary_search(sp.begin(), sp.end(), q)) { odd = q; break; }
+            return fail(h, NXS_ERR_INVALID, "ipc_connect: rank %d exchanges with rank %d in one direction only; the device-direct mailboxes need every send neighbour to be a receive "
+                                            "neighbour and vice versa -- add the missing direction to nxs_dyn_set_halo as an empty segment (on both ranks)", h->rank, odd);
+        }
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     release_graph(h);
     ipc_disconnect(h);  // a second connect replaces the first: its peer mappings and tables go

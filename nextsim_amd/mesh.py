@@ -370,4 +370,21 @@ def localize(mesh: GlobalMesh, nparts: int = 1, elem_part: np.ndarray | None = N
             lm.send_procs = np.array(sp, np.int32)
             lm.send_offsets = np.array(so, np.int32)
             lm.send_index = np.ascontiguousarray(np.concatenate(si).astype(np.int32)) if si else np.zeros(0, np.int32)
+        # Every exchange partner is both a sender and a receiver: where a ragged partition sends to a rank it receives nothing from (a node of mine touches an
+        # element of yours, none of yours touches one of mine), the missing direction becomes an EMPTY segment.  The device-direct mailboxes need that hand-shake
+        # (two buffers per link: nxs_dyn_ipc_connect refuses one-directional neighbours); for every other transport an empty segment is a message of no bytes.
+        for lm in out:
+            partners = sorted(set(lm.send_procs.tolist()) | set(lm.recv_procs.tolist()))
+            for side in ("send", "recv"):
+                procs, offs = getattr(lm, side + "_procs").tolist(), getattr(lm, side + "_offsets").tolist()
+                if procs == partners:
+                    continue
+                new_offs, pos = [0], 0
+                for q in partners:
+                    if pos < len(procs) and procs[pos] == q:
+                        new_offs.append(new_offs[-1] + offs[pos + 1] - offs[pos]); pos += 1
+                    else:
+                        new_offs.append(new_offs[-1])
+                assert pos == len(procs) and new_offs[-1] == offs[-1]
+                setattr(lm, side + "_procs", np.array(partners, np.int32)); setattr(lm, side + "_offsets", np.array(new_offs, np.int32))
     return out

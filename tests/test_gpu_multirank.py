@@ -234,6 +234,33 @@ def test_ipc_connect_checks_its_tables_against_what_the_neighbour_published():
         fe.close()
 
 
+def test_ipc_connect_refuses_neighbours_in_one_direction_only():
+    """Two buffers per link are safe only with a hand-shake: a rank that sends to q without receiving from q could run two exchanges ahead of q and overwrite the
+    half q still reads (seen once in round 4 as a wrong payload in the self-test of the 4-rank mosaic of 'small', whose rank 0 sends two nodes to rank 3 and
+    receives nothing from it).  nextsim_amd.mesh.localize therefore gives every partner both directions, an empty segment where a direction carries no node; halo
+    lists without it are refused by nxs_dyn_ipc_connect with the rank named, before any table is read."""
+    import ctypes as C
+    import copy
+    import numpy as np
+    import cases
+    from nextsim_amd import _abi, dynamics
+    gm, p, g, lms, fields = cases.make_case("small", nparts=4)
+    lm = copy.deepcopy(lms[0])
+    k = lm.recv_procs.tolist().index(3)
+    assert lm.recv_offsets[k + 1] == lm.recv_offsets[k]          # the empty direction
+    lm.recv_procs = np.delete(lm.recv_procs, k); lm.recv_offsets = np.delete(lm.recv_offsets, k + 1)
+    fe = dynamics.FiniteElementDynamics(p)
+    fe.set_mesh(lm)
+    b = C.create_string_buffer(dynamics.IPC_BLOB_BYTES)
+    fe._chk(fe.L.nxs_dyn_ipc_export(fe.h, b))
+    ns = lm.send_procs.size
+    z = np.zeros(ns, np.int32)
+    rc = fe.L.nxs_dyn_ipc_connect(fe.h, C.create_string_buffer(ns * dynamics.IPC_BLOB_BYTES), _abi.iptr(z), _abi.iptr(z), _abi.iptr(z))
+    msg = (fe.L.nxs_dyn_last_error(fe.h) or b"").decode()
+    assert rc != 0 and "one direction only" in msg and "rank 3" in msg and "empty segment" in msg, (rc, msg)
+    fe.close()
+
+
 @pytest.mark.parametrize("world,kind,rpp,over,overlap", [(2, "small", 1, {}, 0), (3, "small", 1, {"ragged_seed": 1}, 0), (3, "small", 1, {"dynamics_type": 3}, 0),
                                                          (8, "10km", 2, {}, 0), (2, "small", 1, {}, 1), (3, "small", 1, {"ragged_seed": 1, "dynamics_type": 3}, 1),
                                                          (8, "10km", 2, {}, 1), (2, "40km", 1, {}, 1),

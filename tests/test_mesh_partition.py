@@ -7,7 +7,7 @@ import cases
 from nextsim_amd import mesh as M
 
 
-@pytest.mark.parametrize("kind,nparts", [("toy", 2), ("small", 3), ("small", 8), ("40km", 4)])
+@pytest.mark.parametrize("kind,nparts", [("toy", 2), ("small", 3), ("small", 4), ("small", 8), ("40km", 4)])
 def test_layout_contract(kind, nparts):
     gm = cases.global_mesh(kind)
     lms = M.localize(gm, nparts)
@@ -48,6 +48,12 @@ def test_layout_contract(kind, nparts):
             sent = lm.node_gid[lm.send_index[lm.send_offsets[k]:lm.send_offsets[k + 1]]]
             recv = other.node_gid[other.recv_index[other.recv_offsets[kk]:other.recv_offsets[kk + 1]]]
             assert np.array_equal(sent, recv) and np.all(np.diff(sent) > 0)
+        # every exchange partner is sender AND receiver (the hand-shake the device-direct mailboxes need; a direction without a node is an empty segment):
+        # the 4-rank mosaic of 'small' has one -- rank 0 sends two nodes to rank 3 and receives nothing from it
+        assert lm.send_procs.tolist() == lm.recv_procs.tolist() == sorted(set(lm.send_procs.tolist()))
+    if (kind, nparts) == ("small", 4):
+        k03 = lms[0].recv_procs.tolist().index(3)
+        assert lms[0].recv_offsets[k03 + 1] == lms[0].recv_offsets[k03] and lms[0].send_offsets[k03 + 1] > lms[0].send_offsets[k03]
 
 
 def test_generators_are_seeded_and_sane():
