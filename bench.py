@@ -960,8 +960,8 @@ def main():
         except Exception as e:  # noqa: BLE001 -- the GPU line must survive a host-side failure of the baseline leg
             out["cpu_baseline"] = {"value": None, "unit": "element-updates/s", "cores": 0, "kind": "port", "sample": "failed: " + repr(e)}
     if world == 1 and not args.no_aux and args.mesh != "10km":
-        # (a 0.55 ms step is enqueued by the host as fast as the device runs it: 20 steps measure the host's mood -- 0.59 to 0.80 ms in this round's records -- so 200)
-        aux_args = argparse.Namespace(**vars(args)); aux_args.steps = max(args.steps, 200); aux_args.warmup = max(args.warmup, 20)
+        # (a 0.55 ms step is enqueued by the host as fast as the device runs it: 20 steps measure the host's mood and the device's clocks after half a minute of idling -- 0.55 to 0.80 ms in this round's records)
+        aux_args = argparse.Namespace(**vars(args)); aux_args.steps = max(args.steps, 400); aux_args.warmup = max(args.warmup, 200)   # (the leg follows the CPU baseline: the device has idled for half a minute)
         try:
             r2 = run_gpu("10km", aux_args, 0, 1, local_rank, dist, torch, None)
             out["aux_10km"] = {
