@@ -5,6 +5,8 @@
 
 N > 1 is launched by the driver as one rank per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+or simply as `python bench.py --gpus N ...` (no WORLD_SIZE in the environment): bench.py then starts its N ranks itself, as child
+processes created before anything of torch or HIP is loaded (launch_ranks), and relays rank 0's line.
 A "step" is one pass of the hot path: FiniteElement::step()'s dynamics block (FE.cpp:8197-8214) =
 explicitSolve() with dynamics.substeps = 120 BBM sub-steps + 50 smoother sweeps + update(), on the
 synthetic pan-Arctic mesh with inputs resident in HBM.  The mesh is domain-decomposed over the N
@@ -744,14 +746,72 @@ def cpu_baseline(kind, nsteps=1, nsteps_threaded=3):
     return out
 
 
+def launch_ranks(nranks, worker_cmd, grace_s=20.0, poll_s=0.2):
+    """`python bench.py --gpus N` called WITHOUT a launcher (no WORLD_SIZE in the environment): start the N ranks here, one child process per GPU, with
+    the environment torch.distributed.run would give them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT on 127.0.0.1, a free port).  This
+    process never imports torch and never touches the GPU, so the children are ordinary fork + exec of a process without a HIP context (an exec from a
+    process that HAS initialised the GPU takes the machine down on this pool).  Rank 0's stdout -- the one JSON line -- is relayed to this process's
+    stdout; the other ranks' stdout goes to stderr.  Returns the exit code: 0 when every rank returned 0; otherwise the first failing rank's code, after
+    the remaining ranks were given `grace_s` seconds and then ended (by their own pids -- never by pattern)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(nranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nranks), LOCAL_WORLD_SIZE=str(nranks), GROUP_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), NXS_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen(list(worker_cmd), env=env, stdin=subprocess.DEVNULL, stdout=(subprocess.PIPE if r == 0 else sys.stderr.fileno())))
+    import threading
+    relayed = []
+
+    def relay():   # rank 0's stdout, line by line as it comes (a reader thread: a full pipe must never block rank 0)
+        for line in procs[0].stdout:
+            relayed.append(line)
+            sys.stdout.buffer.write(line)
+            sys.stdout.buffer.flush()
+    t = threading.Thread(target=relay, daemon=True)
+    t.start()
+    failed, deadline = None, None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad and failed is None:
+            failed, deadline = bad[0], time.monotonic() + grace_s
+            print(f"[bench launcher] rank {failed[0]} exited with code {failed[1]}; the other ranks get {grace_s:.0f} s", file=sys.stderr, flush=True)
+        if deadline is not None and time.monotonic() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            end = time.monotonic() + 5.0
+            while time.monotonic() < end and any(p.poll() is None for p in procs):
+                time.sleep(poll_s)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            deadline = None
+        time.sleep(poll_s)
+    t.join(timeout=10.0)
+    codes = [p.returncode for p in procs]
+    if failed is not None:
+        return failed[1] if failed[1] > 0 else 1
+    bad = [c for c in codes if c != 0]
+    return (bad[0] if bad[0] > 0 else 1) if bad else 0
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called like the single-GPU bench (`python bench.py --gpus N ...`): be the launcher, before anything of torch / HIP is in this process
+        sys.exit(launch_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
     # torch FIRST: it bundles its own libamdhip64.so.7 / libhsa-runtime64 and they must be the ones in

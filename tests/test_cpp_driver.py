@@ -93,7 +93,7 @@ def test_mpi_host_builds_and_refuses_a_foreign_case_file(tmp_path):
     exe = _build_mpi(tmp_path)
     gm, p, g, lms, fields = cases.make_case("tiny", nparts=2)
     casefile.write_case(str(tmp_path / "case_0.bin"), lms[1], p, fields[1])
-    r = subprocess.run([MPIEXEC, "-n", "1", exe, str(tmp_path / "case_%d.bin"), "1", str(tmp_path / "out_%d.bin")], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([MPIEXEC, "-n", "1", exe, str(tmp_path / "case_%d.bin"), "1", str(tmp_path / "out_%d.bin")], capture_output=True, text=True, timeout=120, stdin=subprocess.DEVNULL)
     assert r.returncode != 0 and "another rank" in r.stderr
 
 
@@ -111,7 +111,7 @@ def test_mpi_host_runs_a_partitioned_case_and_matches_the_multirank_oracle(world
         casefile.write_case(str(tmp_path / f"case_{r}.bin"), lms[r], p, fields[r])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     res = subprocess.run([MPIEXEC, "-n", str(world), exe, str(tmp_path / "case_%d.bin"), "2", str(tmp_path / "out_%d.bin")], capture_output=True, text=True,
-                         timeout=300, env=env)
+                         timeout=300, env=env, stdin=subprocess.DEVNULL)
     assert res.returncode == 0, (res.stdout[-1000:], res.stderr[-3000:])
     ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
     for _ in range(2):
