@@ -1,10 +1,11 @@
 // nextsim_mpi.cpp -- the multi-rank host in the reference's own terms: one MPI rank per GPU (the reference uses Boost.MPI over
 // the same MPI), the mesh partition and halo lists each rank got from distributedMeshProcessing / initUpdateGhosts, and
 // libnxsdyn.so under step().  The halo transport is the device-direct one (peer mailboxes mapped with hipIpc, exchange
-// inside the sub-step kernel); MPI only carries the 128-byte handles and the receive lists once, at set-up -- the
-// bookkeeping INTEGRATION.md section 3(a) describes, written out.  Host code is plain C++14 + MPI (no hipcc, no Python):
+// inside the sub-step kernel); MPI only carries one record per rank once, at set-up -- or, with
+// "host" as the last argument, the literal send / recv of FE.cpp:13981-13985 through MPI.  The halo lists go in VERBATIM, also
+// where a ragged partition sends to a rank it receives nothing from.  Host code is plain C++14 + MPI (no hipcc, no Python):
 //     mpicxx -std=c++14 -O2 -Iinclude examples/nextsim_mpi.cpp -Lnextsim_amd/csrc -lnxsdyn -Wl,-rpath,$PWD/nextsim_amd/csrc -o nextsim_mpi
-//     mpiexec -n 2 ./nextsim_mpi case_%d.bin 2 out_%d.bin      (%d = rank; case files from nextsim_amd/casefile.py)
+//     mpiexec -n 2 ./nextsim_mpi case_%d.bin 2 out_%d.bin [gpus_per_node [ipc|host]]     (%d = rank; case files from nextsim_amd/casefile.py)
 #include <mpi.h>
 
 #include <algorithm>
@@ -62,9 +63,10 @@ int main(int argc, char **argv) {
     MPI_Comm_rank(MPI_COMM_WORLD, &rank);
     MPI_Comm_size(MPI_COMM_WORLD, &nranks);
     try {
-        if (argc < 4) throw std::runtime_error("usage: nextsim_mpi case_%d.bin nsteps out_%d.bin [gpus_per_node]");
+        if (argc < 4) throw std::runtime_error("usage: nextsim_mpi case_%d.bin nsteps out_%d.bin [gpus_per_node [ipc|host]]");
         CaseFile c = read_case(with_rank(argv[1], rank));
         const int nsteps = std::atoi(argv[2]), gpus = argc > 4 ? std::atoi(argv[4]) : 1;
+        const std::string transport = argc > 5 ? argv[5] : "ipc";
         auto &D = c.dbl; auto &I = c.i32; auto &B = c.u8;
         if (I["halo_rank"][0] != rank || I["halo_rank"][1] != nranks) throw std::runtime_error("case file is for another rank / communicator size");
 
@@ -82,33 +84,43 @@ int main(int argc, char **argv) {
         nxs_dyn_halo hl{rank, nranks, ns, nr, I["send_procs"].data(), I["send_offsets"].data(), I["send_index"].data(),
                         I["recv_procs"].data(), I["recv_offsets"].data(), I["recv_index"].data()};
         FE.setHalo(hl);
-        std::vector<char> blob(NXS_IPC_BLOB_BYTES), blobs((size_t)NXS_IPC_BLOB_BYTES * nranks);
-        if (nxs_dyn_ipc_export(FE.handle(), blob.data())) throw std::runtime_error(nxs_dyn_last_error(FE.handle()));
-        MPI_Allgather(blob.data(), NXS_IPC_BLOB_BYTES, MPI_CHAR, blobs.data(), NXS_IPC_BLOB_BYTES, MPI_CHAR, MPI_COMM_WORLD);
-        // every rank's receive lists: (neighbour, offset) pairs, so that I can find MY segment in my neighbours' mailboxes
-        std::vector<int> nrecv(nranks), displ(nranks + 1, 0);
-        MPI_Allgather(&nr, 1, MPI_INT, nrecv.data(), 1, MPI_INT, MPI_COMM_WORLD);
-        for (int q = 0; q < nranks; ++q) displ[q + 1] = displ[q] + nrecv[q];
-        std::vector<int> all_procs(displ[nranks]), all_off(displ[nranks]), all_tot(nranks);
-        MPI_Allgatherv(I["recv_procs"].data(), nr, MPI_INT, all_procs.data(), nrecv.data(), displ.data(), MPI_INT, MPI_COMM_WORLD);
-        MPI_Allgatherv(I["recv_offsets"].data(), nr, MPI_INT, all_off.data(), nrecv.data(), displ.data(), MPI_INT, MPI_COMM_WORLD);
-        const int my_tot = I["recv_offsets"][nr];
-        MPI_Allgather(&my_tot, 1, MPI_INT, all_tot.data(), 1, MPI_INT, MPI_COMM_WORLD);
-        std::vector<char> nb_blobs((size_t)NXS_IPC_BLOB_BYTES * std::max(ns, 1));
-        std::vector<int32_t> off(ns), tot(ns), slot(ns);
-        for (int k = 0; k < ns; ++k) {
-            const int q = I["send_procs"][k];
-            const int *b = all_procs.data() + displ[q], *e = b + nrecv[q];
-            const int pos = (int)(std::find(b, e, rank) - b);
-            if (pos == nrecv[q]) throw std::runtime_error("halo lists are not symmetric");
-            std::memcpy(nb_blobs.data() + (size_t)k * NXS_IPC_BLOB_BYTES, blobs.data() + (size_t)q * NXS_IPC_BLOB_BYTES, NXS_IPC_BLOB_BYTES);
-            off[k] = all_off[displ[q] + pos]; tot[k] = all_tot[q]; slot[k] = pos;
+        struct HostHalo { CaseFile *c; int rank; } hh{&c, rank};
+        if (transport == "host") {
+            // the literal M_comm.send / M_comm.recv of FE.cpp:13981-13985 through the caller's communicator: the library hands over the packed segments
+            // (per neighbour k of MY lists, 2 * n_k doubles at 2 * send_offsets[k]) and takes the received ones back
+            FE.setHaloExchange([](void *ctx, const double *send, double *recv) -> int {
+                auto *h = static_cast<HostHalo *>(ctx);
+                auto &I = h->c->i32;
+                const int ns = (int)I["send_procs"].size(), nr = (int)I["recv_procs"].size();
+                std::vector<MPI_Request> rq;
+                rq.reserve(ns + nr);
+                for (int k = 0; k < nr; ++k) {
+                    const int n = 2 * (I["recv_offsets"][k + 1] - I["recv_offsets"][k]);
+                    rq.emplace_back();
+                    MPI_Irecv(recv + 2 * (size_t)I["recv_offsets"][k], n, MPI_DOUBLE, I["recv_procs"][k], 77, MPI_COMM_WORLD, &rq.back());
+                }
+                for (int k = 0; k < ns; ++k) {
+                    const int n = 2 * (I["send_offsets"][k + 1] - I["send_offsets"][k]);
+                    rq.emplace_back();
+                    MPI_Isend(const_cast<double *>(send) + 2 * (size_t)I["send_offsets"][k], n, MPI_DOUBLE, I["send_procs"][k], 77, MPI_COMM_WORLD, &rq.back());
+                }
+                return MPI_Waitall((int)rq.size(), rq.data(), MPI_STATUSES_IGNORE) == MPI_SUCCESS ? 0 : 1;
+            }, &hh);
+        } else {
+            // the device-direct mailboxes: every rank publishes ONE record (its mailbox handle + its receive lists as the library holds them -- the directions
+            // nxs_dyn_set_halo added on a ragged partition included), MPI carries the records once, the library finds its segments itself
+            int32_t nbytes = 0, stride = 0;
+            if (nxs_dyn_ipc_record_bytes(FE.handle(), &nbytes)) throw std::runtime_error(nxs_dyn_last_error(FE.handle()));
+            MPI_Allreduce(&nbytes, &stride, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+            std::vector<char> rec(stride), recs((size_t)stride * nranks);
+            if (nxs_dyn_ipc_export_record(FE.handle(), rec.data(), stride)) throw std::runtime_error(nxs_dyn_last_error(FE.handle()));
+            MPI_Allgather(rec.data(), stride, MPI_CHAR, recs.data(), stride, MPI_CHAR, MPI_COMM_WORLD);
+            if (nxs_dyn_ipc_connect_records(FE.handle(), recs.data(), stride, nranks)) throw std::runtime_error(nxs_dyn_last_error(FE.handle()));
+            int32_t err = 0, worst = 0;
+            if (nxs_dyn_ipc_selftest(FE.handle(), 32, &err)) throw std::runtime_error(nxs_dyn_last_error(FE.handle()));
+            MPI_Allreduce(&err, &worst, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+            if (worst) throw std::runtime_error("mailbox self-test failed on some rank");   // a production host falls back to RCCL / its own MPI here
         }
-        if (nxs_dyn_ipc_connect(FE.handle(), nb_blobs.data(), off.data(), tot.data(), slot.data())) throw std::runtime_error(nxs_dyn_last_error(FE.handle()));
-        int32_t err = 0, worst = 0;
-        if (nxs_dyn_ipc_selftest(FE.handle(), 32, &err)) throw std::runtime_error(nxs_dyn_last_error(FE.handle()));
-        MPI_Allreduce(&err, &worst, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
-        if (worst) throw std::runtime_error("mailbox self-test failed on some rank");   // a production host falls back to RCCL / its own MPI here
 
         nxs_dyn_state s{};
         s.VT = D["VT"].data(); s.UM = D["UM"].data(); s.UT = D["UT"].data();

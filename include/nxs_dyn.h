@@ -123,7 +123,11 @@ typedef struct nxs_dyn_mesh {
 } nxs_dyn_mesh;
 
 /* Halo lists of initUpdateGhosts() (FE.hpp:615-618), flattened CSR-style.
- * send_index = M_extract_local_index[q][], recv_index = M_local_ghosts_local_index[q][]. */
+ * send_index = M_extract_local_index[q][], recv_index = M_local_ghosts_local_index[q][]; send_procs = M_recipients_proc_id,
+ * recv_procs = M_local_ghosts_proc_id -- VERBATIM, as FE.cpp:14003-14088 leaves them.  On a ragged partition (Gmsh / METIS) a rank may send a node to a rank it
+ * receives nothing from; the device-direct mailboxes need every link in both directions (below), so nxs_dyn_set_halo itself adds the missing direction as an
+ * empty segment -- APPENDED behind the caller's neighbours, so that the caller's neighbour numbers k and its offsets (the layout of nxs_dyn_halo_fn's buffers)
+ * stay what they were.  Both ranks of such a link do the same without talking to each other: one has the link in its send list, the other in its receive list. */
 typedef struct nxs_dyn_halo {
     int32_t rank, nranks;
     int32_t num_send_procs;        /* M_recipients_proc_id.size() */
@@ -254,14 +258,55 @@ NXS_API int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors);
  * link with both publishing protocols the step can use (one release per block / one per launch).
  * NEIGHBOURS IN BOTH DIRECTIONS: a mailbox has two buffers per link, which is safe because "a neighbour cannot start exchange x + 2 before it has received my
  * exchange x + 1, which I send only after my pull of exchange x" -- a hand-shake that needs every rank I send to to send to me as well.  A ragged partition can
- * send a node to a rank it receives nothing from; the halo lists of nxs_dyn_set_halo must then name that rank in BOTH lists, the direction without nodes as an
- * empty segment (offsets[k + 1] == offsets[k]; on both ranks).  ipc_connect returns NXS_ERR_INVALID for one-directional neighbours (round 4: found as one wrong
- * payload in the self-test of a 4-rank mosaic; RCCL and the host-staged transport do not need the pairing, an empty segment is a message of no bytes to them). */
+ * send a node to a rank it receives nothing from: nxs_dyn_set_halo adds that direction itself as an empty segment (its flag is still raised and waited for: that
+ * is the hand-shake), on both ranks, without communication.  The LOW-LEVEL nxs_dyn_ipc_connect below takes tables for the caller's own send neighbours only, so on
+ * such a partition it returns NXS_ERR_INVALID and names the rank (round 4: found as one wrong payload in the self-test of a 4-rank mosaic): use the record form,
+ * which finds the added direction in the neighbours' records.  RCCL and the host-staged transport do not need the pairing; they skip segments without nodes. */
 #define NXS_IPC_BLOB_BYTES 128
 NXS_API int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob);
 NXS_API int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset,
                                 const int32_t *peer_recv_total, const int32_t *peer_flag_slot);
 NXS_API int nxs_dyn_ipc_selftest(nxs_dyn_handle *h, int rounds, int32_t *errors);
+/* The same set-up WITHOUT bookkeeping on the caller's side (round 5) -- what INTEGRATION.md section 3 shows, and the only form that works on a partition with
+ * one-directional neighbours (the direction nxs_dyn_set_halo added is not in any list the caller holds):
+ *   1. every rank: nxs_dyn_ipc_record_bytes(h, &n)         the size of its record: the blob of nxs_dyn_ipc_export + its receive lists as the library holds them
+ *   2. the launcher: stride = MPI_Allreduce(MAX) of n
+ *   3. every rank: nxs_dyn_ipc_export_record(h, rec, stride)   (exports the mailbox, like nxs_dyn_ipc_export; the tail of rec is zeroed)
+ *   4. the launcher: MPI_Allgather of the records, `stride` bytes each, in rank order
+ *   5. every rank: nxs_dyn_ipc_connect_records(h, records, stride, nranks)   finds its segment, the totals and its flag slot in every neighbour's record itself
+ *   6. every rank: nxs_dyn_ipc_selftest
+ * connect_records returns NXS_ERR_INVALID when the records disagree with this rank's lists (a neighbour that does not list this rank, a segment of another length). */
+NXS_API int nxs_dyn_ipc_record_bytes(nxs_dyn_handle *h, int32_t *bytes);
+NXS_API int nxs_dyn_ipc_export_record(nxs_dyn_handle *h, void *record, int32_t capacity);
+NXS_API int nxs_dyn_ipc_connect_records(nxs_dyn_handle *h, const void *records, int64_t stride, int32_t nranks);
+/* Profiling aid (no reference call site): the mailboxes of this handle connected to THEMSELVES, so that a rank's partition can be stepped alone on a device with the
+ * exchange inside its kernels -- every flag a kernel waits for is raised by the rank's own launches (rocprofv3's counter collection serialises the kernels of a
+ * device: two ranks whose kernels wait for each other cannot be profiled together, a looped-back rank can; bench.py's roofline.traffic at N > 1 and its
+ * aux_partition_floor).  The ghosts receive meaningless velocities -- results are NOT the model's --, the launches walk the same tables and move the same bytes.
+ * NXS_ERR_INVALID when the lists do not allow it (no neighbour). */
+NXS_API int nxs_dyn_ipc_loopback(nxs_dyn_handle *h);
+
+/* Test door "ipc_delay" (option of nxs_dyn_set_option; compiled in, off by default, no reference call site): ONE named rank sleeps at ONE named point of the exchange
+ * protocols -- value = rank << 16 | point << 8 | units, a unit = 10 us, units 1..255; 0 = off.  The blocking send / recv of the reference (FE.cpp:13981-13985) cannot
+ * reorder; the flag protocols of the device-direct transport can, in windows a few microseconds wide that a bitwise test only sees when the race is lost.  A delay at
+ * the right point makes the race lose every time: tests/test_gpu_protocol_delays.py walks (variant x point x delayed rank) on ragged 3- and 4-rank partitions and
+ * requires the bits of the undelayed separate kernels -- and, with the test door "halo_one_directional" (= 1 BEFORE nxs_dyn_set_halo: the lists are taken as given, no
+ * direction is added, nxs_dyn_ipc_connect does not refuse), shows round 4's defect fail deterministically. */
+enum { NXS_DELAY_NONE = 0,
+       NXS_DELAY_PULL_READ = 1,          /* k_halo_pull: flags seen, before the mailbox half is read */
+       NXS_DELAY_PUSH_STORE = 2,         /* k_halo_push: before the stores into the neighbours' mailboxes */
+       NXS_DELAY_PUSH_FLAG = 3,          /* k_halo_push: stores drained, before the flags are raised */
+       NXS_DELAY_STAGE_READ = 4,         /* k_substep_fused / k_substep_pair<HALO> / k_substep_resident*: flags seen, before the ghosts are staged from the mailbox half */
+       NXS_DELAY_SEND_STORE = 5,         /* the same kernels: before the (first) store of the sent nodes */
+       NXS_DELAY_PAIR_SECOND_STORE = 6,  /* k_substep_pair<HALO>: before the second sub-step's store */
+       NXS_DELAY_PUBLISH_FLAG = 7,       /* the same kernels: stores drained, before the (first) flag is raised */
+       NXS_DELAY_PAIR_MID_READ = 8,      /* k_substep_pair<HALO>: flags x + 1 seen, before the ghosts of N_1 are read */
+       NXS_DELAY_SMOOTH_READ = 9,        /* k_smooth_halo: flags seen, before the ghosts' slot is read */
+       NXS_DELAY_SMOOTH_STORE = 10,      /* k_smooth_halo: before a sweep's stores */
+       NXS_DELAY_SMOOTH_FLAG = 11,       /* k_smooth_halo: before a sweep's publication */
+       NXS_DELAY_SMOOTH_PULL_READ = 12,  /* k_smooth_pull: flags seen, before the last slot is read */
+       NXS_DELAY_PAIR_SECOND_FLAG = 13,  /* k_substep_pair<HALO>: before the second publication */
+       NXS_DELAY_POINTS = 14 };
 
 /* Alternative transport: host-staged exchange through the CALLER's communicator -- the literal
  * M_comm.send / M_comm.recv of FE.cpp:13981-13985.  send holds, per send neighbour k, 2*n_k doubles
@@ -416,7 +461,8 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *   "halo_fused"   device-direct transport only: 1 = updateGhosts inside the fused sub-step kernel (default),
  *                  0 = separate push / pull kernels
  *   "ipc_pad"      before nxs_dyn_ipc_export: the mailbox gets room for at least this many received nodes (profiling aid: a rank whose mailbox is connected
- *                  to itself stores its own, possibly longer, send segments into it) */
+ *                  to itself stores its own, possibly longer, send segments into it)
+ *   "ipc_delay", "halo_one_directional"   test doors of the exchange protocols, see NXS_DELAY_* above */
 NXS_API int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value);
 
 /* Test door: copies a named internal work array (rlmass, node_mass, C_bu, grad_ssh, fcor, VTM, shape,

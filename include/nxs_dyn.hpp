@@ -23,6 +23,7 @@ public:
 
     void setMesh(const nxs_dyn_mesh &m) { check(nxs_dyn_set_mesh(h_, &m), "set_mesh"); }      // distributedMeshProcessing, FE.cpp:50-143
     void setHalo(const nxs_dyn_halo &hl) { check(nxs_dyn_set_halo(h_, &hl), "set_halo"); }    // initUpdateGhosts, FE.cpp:14003-14088
+    void setHaloExchange(nxs_dyn_halo_fn fn, void *ctx) { check(nxs_dyn_set_halo_exchange_fn(h_, fn, ctx), "set_halo_exchange_fn"); }   // the caller's own M_comm.send / recv, FE.cpp:13981-13985
     void putState(const nxs_dyn_state &s) { check(nxs_dyn_put_state(h_, &s), "put_state"); }
     void getState(nxs_dyn_state &s) { check(nxs_dyn_get_state(h_, &s), "get_state"); }
     void setForcing(const nxs_dyn_forcing &f) { check(nxs_dyn_set_forcing(h_, &f), "set_forcing"); }

@@ -148,7 +148,10 @@ struct nxs_dyn_handle {
     // halo
     bool have_halo = false;
     int rank = 0, nranks = 1;
-    std::vector<int> send_procs, send_offsets, recv_procs, recv_offsets;
+    std::vector<int> send_procs, send_offsets, recv_procs, recv_offsets;   // as nxs_dyn_set_halo keeps them: the caller's neighbours, then the directions it added (empty segments)
+    int ns_caller = 0, nr_caller = 0;      // neighbours the caller's own lists named (the low-level nxs_dyn_ipc_connect takes tables for those)
+    int one_directional = 0;               // test door "halo_one_directional": 1 = set_halo takes the lists as given and ipc_connect does not refuse (round 4's defect, for the delay tests)
+    unsigned ipc_delay_opt = 0;            // test door "ipc_delay": rank << 16 | point << 8 | units (include/nxs_dyn.h)
     int *d_send_index = nullptr, *d_send_seg = nullptr, *d_send_off = nullptr;
     int *d_recv_index = nullptr, *d_recv_seg = nullptr, *d_recv_off = nullptr;
     double *d_send_buf = nullptr, *d_recv_buf = nullptr;
@@ -463,6 +466,12 @@ void mailbox_drop_locked(std::map<void *, MailboxRegistry::Entry>::iterator it) 
     g_mailboxes.boxes.erase(it);
 }
 
+// test door "ipc_delay": the word the kernels see -- point << 8 | units on the named rank, 0 on every other
+unsigned ipc_delay_word(const nxs_dyn_handle *h) {
+    const unsigned v = h->ipc_delay_opt;
+    return (v != 0u && (int)(v >> 16) == h->rank && (v & 0xffu) != 0u) ? (v & 0xffffu) : 0u;
+}
+
 void ipc_disconnect(nxs_dyn_handle *h) {  // the peer mappings and the tables of one nxs_dyn_ipc_connect
     for (void *p : h->ipc_peer_base) if (p) (void)hipIpcCloseMemHandle(p);
     h->ipc_peer_base.clear();
@@ -725,6 +734,16 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         return NXS_OK;
     }
     if (!std::strcmp(key, "nt_mask")) { h->nt_mask = (int)value; release_graph(h); return NXS_OK; }  // -1 = automatic
+    if (!std::strcmp(key, "ipc_delay")) {   // test door (include/nxs_dyn.h, NXS_DELAY_*): the kernels read it from IpcDev, by value in captured graphs and from the device copy of HaloFused
+        if (value < 0 || value > 0x7fffffffll || ((value >> 8) & 0xff) >= NXS_DELAY_POINTS) return fail(h, NXS_ERR_INVALID, "ipc_delay: rank << 16 | point << 8 | units, point < %d", NXS_DELAY_POINTS);
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        h->ipc_delay_opt = (unsigned)value;
+        h->ipc.delay = ipc_delay_word(h);
+        h->d_hf_dirty = true; release_graph(h);
+        return NXS_OK;
+    }
+    if (!std::strcmp(key, "halo_one_directional")) { h->one_directional = value != 0; return NXS_OK; }   // test door: before nxs_dyn_set_halo
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
         const bool was_resident = h->fused == 4, now_resident = value == 4;
@@ -1064,7 +1083,22 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
     h->recv_procs.assign(halo->recv_procs, halo->recv_procs + nr);
     if (ns > 0) h->send_offsets.assign(halo->send_offsets, halo->send_offsets + ns + 1); else h->send_offsets.assign(1, 0);
     if (nr > 0) h->recv_offsets.assign(halo->recv_offsets, halo->recv_offsets + nr + 1); else h->recv_offsets.assign(1, 0);
+    h->ns_caller = ns; h->nr_caller = nr;
     const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
+    for (int side = 0; side < 2; ++side) {   // a neighbour is named once per list (the padding below and the mailbox's flag slots rely on it)
+        std::vector<int> v(side ? h->recv_procs : h->send_procs);
+        std::sort(v.begin(), v.end());
+        const auto dup = std::adjacent_find(v.begin(), v.end());
+        if (dup != v.end()) return fail(h, NXS_ERR_INVALID, "%s_procs names rank %d twice", side ? "recv" : "send", *dup);
+    }
+    if (!h->one_directional) {
+        // NEIGHBOURS IN BOTH DIRECTIONS (include/nxs_dyn.h): M_recipients_proc_id and M_local_ghosts_proc_id of a ragged partition need not be the same set.  The
+        // direction that carries no node is added here as an empty segment, BEHIND the caller's neighbours (its numbers k and offsets stay valid); the rank at the
+        // other end does the same from its own lists, so both agree without communication.
+        const std::vector<int> sp0(h->send_procs), rp0(h->recv_procs);
+        for (int q : rp0) if (std::find(sp0.begin(), sp0.end(), q) == sp0.end()) { h->send_procs.push_back(q); h->send_offsets.push_back(ts); }
+        for (int q : sp0) if (std::find(rp0.begin(), rp0.end(), q) == rp0.end()) { h->recv_procs.push_back(q); h->recv_offsets.push_back(tr); }
+    }
     std::vector<int> sidx(halo->send_index, halo->send_index + ts), ridx(halo->recv_index, halo->recv_index + tr);
     h->h_send_index = sidx; h->h_recv_index = ridx;
     h->hf_ready = false;
@@ -1180,9 +1214,11 @@ int nxs_dyn_comm_selftest(nxs_dyn_handle *h, int32_t *errors) try {
     if (e == 0) e = h->rccl.Send(ds, (size_t)N, ncclDouble, h->rank, h->comm, h->stream);
     if (e == 0) e = h->rccl.Recv(dr, (size_t)N, ncclDouble, h->rank, h->comm, h->stream);
     for (int k = 0; k < ns && e == 0; ++k)
-        e = h->rccl.Send(h->d_send_buf + 2 * (size_t)h->send_offsets[k], 2 * (size_t)(h->send_offsets[k + 1] - h->send_offsets[k]), ncclDouble, h->send_procs[k], h->comm, h->stream);
+        if (h->send_offsets[k + 1] > h->send_offsets[k])
+            e = h->rccl.Send(h->d_send_buf + 2 * (size_t)h->send_offsets[k], 2 * (size_t)(h->send_offsets[k + 1] - h->send_offsets[k]), ncclDouble, h->send_procs[k], h->comm, h->stream);
     for (int k = 0; k < nr && e == 0; ++k)
-        e = h->rccl.Recv(h->d_recv_buf + 2 * (size_t)h->recv_offsets[k], 2 * (size_t)(h->recv_offsets[k + 1] - h->recv_offsets[k]), ncclDouble, h->recv_procs[k], h->comm, h->stream);
+        if (h->recv_offsets[k + 1] > h->recv_offsets[k])
+            e = h->rccl.Recv(h->d_recv_buf + 2 * (size_t)h->recv_offsets[k], 2 * (size_t)(h->recv_offsets[k + 1] - h->recv_offsets[k]), ncclDouble, h->recv_procs[k], h->comm, h->stream);
     const int e2 = h->rccl.GroupEnd();
     if (e == 0) e = e2;
     if (e != 0) return done(fail(h, NXS_ERR_COMM, "comm_selftest send/recv: %s", h->rccl.GetErrorString(e)));
@@ -1249,32 +1285,12 @@ int nxs_dyn_ipc_export(nxs_dyn_handle *h, void *blob) try {
     return NXS_OK;
 } catch (...) { return dyn_caught(h, "nxs_dyn_ipc_export"); }
 
-// Step 2: map the neighbours' mailboxes.  For send neighbour k (order of nxs_dyn_halo.send_procs):
+// Step 2: map the neighbours' mailboxes.  For send neighbour k (order of the handle's send_procs: the caller's neighbours, then the directions nxs_dyn_set_halo added):
 // blobs + k*NXS_IPC_BLOB_BYTES is its exported blob, peer_recv_offset[k] the offset (in nodes) of MY
 // segment inside its receive lists, peer_recv_total[k] its total number of received nodes and
 // peer_flag_slot[k] my position in its recv_procs.
-int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset, const int32_t *peer_recv_total,
-                        const int32_t *peer_flag_slot) try {
-    if (!h) return NXS_ERR_INVALID;
-    if (!h->ipc_block) return fail(h, NXS_ERR_STATE, "ipc_connect before ipc_export");
-    HIPCHK(h, hipSetDevice(h->device));
+static int ipc_connect_impl(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset, const int32_t *peer_recv_total, const int32_t *peer_flag_slot) {
     const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
-    if (ns > 0 && (!blobs || !peer_recv_offset || !peer_recv_total || !peer_flag_slot)) return fail(h, NXS_ERR_INVALID, "ipc_connect: NULL tables");
-    {   // Two buffers per link are safe only with a hand-shake: "a neighbour cannot start exchange x + 2 before it has received my exchange x + 1, which I send only
-        // after my pull of exchange x" (k_halo_push) holds when every rank I send to also sends to me.  A rank that sends to q without receiving from q could run two
-        // exchanges ahead of q and overwrite the half q still reads -- seen once in round 4 as a wrong payload in the self-test of a 4-rank mosaic whose rank 0 sends to
-        // rank 3 and receives nothing from it.  So the device-direct transport wants the two neighbour sets equal; a direction that carries no node is an EMPTY
-        // segment (its flag is still raised and waited for: that is the hand-shake).
-        std::vector<int> sp(h->send_procs.begin(), h->send_procs.end()), rp(h->recv_procs.begin(), h->recv_procs.end());
-        std::sort(sp.begin(), sp.end()); std::sort(rp.begin(), rp.end());
-        if (sp != rp) {
-            int odd = -1;
-            for (int q : sp) if (!std::binary_search(rp.begin(), rp.end(), q)) { odd = q; break; }
-            if (odd < 0) for (int q : rp) if (!std::binary_search(sp.begin(), sp.end(), q)) { odd = q; break; }
-            return fail(h, NXS_ERR_INVALID, "ipc_connect: rank %d exchanges with rank %d in one direction only; the device-direct mailboxes need every send neighbour to be a receive "
-                                            "neighbour and vice versa -- add the missing direction to nxs_dyn_set_halo as an empty segment (on both ranks)", h->rank, odd);
-        }
-    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
     release_graph(h);
     ipc_disconnect(h);  // a second connect replaces the first: its peer mappings and tables go
@@ -1332,6 +1348,7 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     d.sstatic = reinterpret_cast<unsigned long long *>(d.mailbox + ml.sstatic);
     d.smb = d.mailbox + ml.slots;
     d.tr = (int)tr; d.ns = ns; d.nr = nr;
+    d.delay = ipc_delay_word(h);
     int rc;
     unsigned long long *ctr = nullptr;
     if ((rc = dev_alloc(h, h->ipc_allocs, &ctr, 8))) return rc;
@@ -1365,7 +1382,107 @@ int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *pee
     h->d_hf_dirty = true;
     release_graph(h);
     return NXS_OK;
+}
+
+// The low-level form: tables for the CALLER's send neighbours, in the order of nxs_dyn_halo.send_procs.
+int nxs_dyn_ipc_connect(nxs_dyn_handle *h, const void *blobs, const int32_t *peer_recv_offset, const int32_t *peer_recv_total,
+                        const int32_t *peer_flag_slot) try {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->ipc_block) return fail(h, NXS_ERR_STATE, "ipc_connect before ipc_export");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
+    if (ns > 0 && (!blobs || !peer_recv_offset || !peer_recv_total || !peer_flag_slot)) return fail(h, NXS_ERR_INVALID, "ipc_connect: NULL tables");
+    if (!h->one_directional && (ns != h->ns_caller || nr != h->nr_caller)) {
+        // Two buffers per link are safe only with a hand-shake: "a neighbour cannot start exchange x + 2 before it has received my exchange x + 1, which I send only
+        // after my pull of exchange x" (k_halo_push) holds when every rank I send to also sends to me.  A rank that sends to q without receiving from q could run two
+        // exchanges ahead of q and overwrite the half q still reads -- seen once in round 4 as a wrong payload in the self-test of a 4-rank mosaic whose rank 0 sends to
+        // rank 3 and receives nothing from it (and made deterministic since: tests/test_gpu_protocol_delays.py).  nxs_dyn_set_halo has added the missing direction as
+        // an empty segment; the caller's tables do not know it, the neighbours' records do.
+        const int odd = ns != h->ns_caller ? h->send_procs[h->ns_caller] : h->recv_procs[h->nr_caller];
+        return fail(h, NXS_ERR_INVALID, "ipc_connect: rank %d exchanges with rank %d in one direction only; the device-direct mailboxes need every link in both directions, and "
+                                        "nxs_dyn_set_halo has added the missing one as an empty segment -- which these tables cannot describe: connect with "
+                                        "nxs_dyn_ipc_export_record / nxs_dyn_ipc_connect_records", h->rank, odd);
+    }
+    return ipc_connect_impl(h, blobs, peer_recv_offset, peer_recv_total, peer_flag_slot);
 } catch (...) { return dyn_caught(h, "nxs_dyn_ipc_connect"); }
+
+// The record form (include/nxs_dyn.h): a rank's record = its blob + its receive lists as this library holds them (the added directions included), so that every
+// neighbour finds its segment, the totals and its flag slot itself.
+namespace {
+constexpr int IPC_RECORD_MAGIC = 0x4e585231;   // 'NXR1'
+struct IpcRecordHead { int magic, rank, nr, reserved; };
+inline int ipc_record_size(int nr) { return NXS_IPC_BLOB_BYTES + (int)sizeof(IpcRecordHead) + 4 * nr + 4 * (nr + 1); }
+}  // namespace
+
+int nxs_dyn_ipc_record_bytes(nxs_dyn_handle *h, int32_t *bytes) try {
+    if (!h || !bytes) return NXS_ERR_INVALID;
+    if (!h->have_halo) return fail(h, NXS_ERR_STATE, "ipc_record_bytes before set_halo");
+    *bytes = ipc_record_size((int)h->recv_procs.size());
+    return NXS_OK;
+} catch (...) { return dyn_caught(h, "nxs_dyn_ipc_record_bytes"); }
+
+int nxs_dyn_ipc_export_record(nxs_dyn_handle *h, void *record, int32_t capacity) try {
+    if (!h || !record) return NXS_ERR_INVALID;
+    if (!h->have_halo) return fail(h, NXS_ERR_STATE, "ipc_export_record before set_halo");
+    const int nr = (int)h->recv_procs.size(), need = ipc_record_size(nr);
+    if (capacity < need) return fail(h, NXS_ERR_INVALID, "ipc_export_record: the record needs %d bytes, %d given", need, capacity);
+    std::memset(record, 0, (size_t)capacity);
+    const int rc = nxs_dyn_ipc_export(h, record);
+    if (rc) return rc;
+    char *p = static_cast<char *>(record) + NXS_IPC_BLOB_BYTES;
+    const IpcRecordHead hd{IPC_RECORD_MAGIC, h->rank, nr, 0};
+    std::memcpy(p, &hd, sizeof hd); p += sizeof hd;
+    if (nr > 0) std::memcpy(p, h->recv_procs.data(), 4 * (size_t)nr);
+    p += 4 * (size_t)nr;
+    std::memcpy(p, h->recv_offsets.data(), 4 * (size_t)(nr + 1));
+    return NXS_OK;
+} catch (...) { return dyn_caught(h, "nxs_dyn_ipc_export_record"); }
+
+int nxs_dyn_ipc_connect_records(nxs_dyn_handle *h, const void *records, int64_t stride, int32_t nranks) try {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->ipc_block) return fail(h, NXS_ERR_STATE, "ipc_connect_records before ipc_export_record");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int ns = (int)h->send_procs.size();
+    if (nranks != h->nranks) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: %d records, the halo lists were set for %d ranks", nranks, h->nranks);
+    if (!records || stride < ipc_record_size(0)) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: NULL records or a stride below %d bytes", ipc_record_size(0));
+    std::vector<char> blobs((size_t)std::max(ns, 1) * NXS_IPC_BLOB_BYTES);
+    std::vector<int32_t> off(std::max(ns, 1)), tot(std::max(ns, 1)), slot(std::max(ns, 1));
+    for (int k = 0; k < ns; ++k) {
+        const int q = h->send_procs[k], nseg = h->send_offsets[k + 1] - h->send_offsets[k];
+        const char *rec = static_cast<const char *>(records) + (size_t)q * (size_t)stride;
+        IpcRecordHead hd;
+        std::memcpy(&hd, rec + NXS_IPC_BLOB_BYTES, sizeof hd);
+        if (hd.magic != IPC_RECORD_MAGIC || hd.rank != q) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: record %d was not made by nxs_dyn_ipc_export_record on rank %d", q, q);
+        if (hd.nr < 0 || (int64_t)ipc_record_size(hd.nr) > stride) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: record %d names %d receive neighbours, more than the stride holds", q, hd.nr);
+        const int32_t *rp = reinterpret_cast<const int32_t *>(rec + NXS_IPC_BLOB_BYTES + sizeof hd), *ro = rp + hd.nr;
+        int me = -1;
+        for (int j = 0; j < hd.nr; ++j) if (rp[j] == h->rank) { me = j; break; }
+        if (me < 0) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: rank %d does not list rank %d among its receive neighbours (its halo lists and mine disagree)", q, h->rank);
+        if (ro[me + 1] - ro[me] != nseg)
+            return fail(h, NXS_ERR_INVALID, "ipc_connect_records: I send %d nodes to rank %d, which expects %d from me (its halo lists and mine disagree)", nseg, q, ro[me + 1] - ro[me]);
+        std::memcpy(blobs.data() + (size_t)k * NXS_IPC_BLOB_BYTES, rec, NXS_IPC_BLOB_BYTES);
+        off[k] = ro[me]; tot[k] = ro[hd.nr]; slot[k] = me;
+    }
+    return ipc_connect_impl(h, blobs.data(), off.data(), tot.data(), slot.data());
+} catch (...) { return dyn_caught(h, "nxs_dyn_ipc_connect_records"); }
+
+// Profiling aid (include/nxs_dyn.h): the mailboxes of this handle connected to THEMSELVES.
+int nxs_dyn_ipc_loopback(nxs_dyn_handle *h) try {
+    if (!h) return NXS_ERR_INVALID;
+    if (!h->have_halo) return fail(h, NXS_ERR_STATE, "ipc_loopback before set_halo");
+    const int ns = (int)h->send_procs.size(), nr = (int)h->recv_procs.size();
+    if (ns == 0 || nr == 0 || ns < nr) return fail(h, NXS_ERR_INVALID, "ipc_loopback: this partition's halo lists cannot be looped back (%d send, %d receive neighbours)", ns, nr);
+    int tr = h->recv_offsets[nr];
+    for (int k = 0; k < ns; ++k) tr = std::max(tr, h->send_offsets[k + 1] - h->send_offsets[k]);   // every send segment is stored at offset 0 of the mailbox: room for the longest
+    h->ipc_pad = tr;
+    char blob[NXS_IPC_BLOB_BYTES];
+    int rc = nxs_dyn_ipc_export(h, blob);
+    if (rc) return rc;
+    std::vector<char> blobs((size_t)ns * NXS_IPC_BLOB_BYTES);
+    std::vector<int32_t> off(ns, 0), tot(ns, tr), slot(ns);
+    for (int k = 0; k < ns; ++k) { std::memcpy(blobs.data() + (size_t)k * NXS_IPC_BLOB_BYTES, blob, NXS_IPC_BLOB_BYTES); slot[k] = k % nr; }
+    return ipc_connect_impl(h, blobs.data(), off.data(), tot.data(), slot.data());
+} catch (...) { return dyn_caught(h, "nxs_dyn_ipc_loopback"); }
 
 // Step 3 (collective): `rounds` exchanges of a synthetic pattern through the mailboxes; *errors gets
 // 0 when every value arrived intact and in time on this rank.
@@ -1645,12 +1762,14 @@ int halo_exchange(nxs_dyn_handle *h, double *vec, double move_dt) {
     }
     const int ncclDouble = 8;  // ncclFloat64
     int e = h->rccl.GroupStart();
-    for (int k = 0; k < ns && e == 0; ++k)
-        e = h->rccl.Send(h->d_send_buf + 2 * (size_t)h->send_offsets[k], 2 * (size_t)(h->send_offsets[k + 1] - h->send_offsets[k]),
-                         ncclDouble, h->send_procs[k], h->comm, h->stream);
+    for (int k = 0; k < ns && e == 0; ++k)   // (a segment without nodes -- a direction set_halo added -- is no message: both ends know it is empty)
+        if (h->send_offsets[k + 1] > h->send_offsets[k])
+            e = h->rccl.Send(h->d_send_buf + 2 * (size_t)h->send_offsets[k], 2 * (size_t)(h->send_offsets[k + 1] - h->send_offsets[k]),
+                             ncclDouble, h->send_procs[k], h->comm, h->stream);
     for (int k = 0; k < nr && e == 0; ++k)
-        e = h->rccl.Recv(h->d_recv_buf + 2 * (size_t)h->recv_offsets[k], 2 * (size_t)(h->recv_offsets[k + 1] - h->recv_offsets[k]),
-                         ncclDouble, h->recv_procs[k], h->comm, h->stream);
+        if (h->recv_offsets[k + 1] > h->recv_offsets[k])
+            e = h->rccl.Recv(h->d_recv_buf + 2 * (size_t)h->recv_offsets[k], 2 * (size_t)(h->recv_offsets[k + 1] - h->recv_offsets[k]),
+                             ncclDouble, h->recv_procs[k], h->comm, h->stream);
     int e2 = h->rccl.GroupEnd();
     if (e == 0) e = e2;
     if (e != 0) return fail(h, NXS_ERR_COMM, "halo send/recv: %s", h->rccl.GetErrorString(e));

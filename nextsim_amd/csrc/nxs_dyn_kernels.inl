@@ -1076,8 +1076,19 @@ struct IpcDev {
     unsigned long long *epoch;      // smoother passes completed by this rank (one per step; the ranks stay aligned)
     int *my_static;                 // [ns] 1 = nothing I send to neighbour k can change during this step's sweeps (reset to 1 by k_smooth_pull)
     int *peer_static;               // [nr] what neighbour k said about its sends to me (cached by sweep 1 for the later ones)
+    unsigned delay;                 // test door "ipc_delay" (include/nxs_dyn.h): point << 8 | units of 10 us, set on ONE rank; 0 (always, outside the protocol tests) = none
 };
 #define NXS_SMOOTH_SWEEPS 50  // FE.cpp:10580 (Q9: hard-coded in the reference)
+
+// Test door "ipc_delay": the named rank sleeps here when `point` is the named point -- a deterministic widening of one window of the exchange protocols, so that an
+// ordering the protocol does not enforce shows as wrong bits instead of depending on who wins a race of a few microseconds (tests/test_gpu_protocol_delays.py).
+// d is uniform (a kernel argument or a scalar load): one scalar compare per point where the option is off.
+__device__ __forceinline__ void nxs_delay_at(const unsigned d, const unsigned point) {
+    if (d != 0u && (d >> 8) == point) {
+        const long long t0 = wall_clock64(), ticks = (long long)(d & 0xffu) * 1000ll;  // wall_clock64 runs at 100 MHz: units of 10 us
+        while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+    }
+}
 
 // agent scope (sc1): written through to memory / read past this CU's L1 -- what workgroups of ONE launch hand each other (MI355X_MICROARCH.md, inter-workgroup visibility)
 __device__ __forceinline__ void st_agent(double *p, double v) {
@@ -1239,6 +1250,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
                 }
             // no acquire fence: the mailbox is uncached memory and every read of it below is a system-scope load that
             // bypasses the caches; a fence here would invalidate this XCD's caches once per boundary patch and sub-step
+            nxs_delay_at(hfp->ipc.delay, NXS_DELAY_STAGE_READ);
         }
         __syncthreads();
     }
@@ -1354,6 +1366,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         // fields the node phase needs instead of keeping every field it loaded for the staging phase alive -- and spilled into
         // VGPR lanes -- across the hot loop (166 v_readlane/v_writelane in that loop before, 12 in the kernel without the exchange)
         asm volatile("" : "+s"(hfp));
+        if (boundary) nxs_delay_at(hfp->ipc.delay, NXS_DELAY_SEND_STORE);
     }
     // node phase: issue this node's loads before barrier 2 so that they overlap the wait
     const unsigned short *pf = pp.pfan + (size_t)blk * pp.Wp * pp.Pmax;
@@ -1438,6 +1451,7 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (t == 0 && atomicAdd(hfp->ipc.done_push, 1u) == (unsigned)n_boundary - 1u) {
+                nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
                 __threadfence_system();  // the one release of the launch
                 for (int k = 0; k < hfp->ipc.ns; ++k)
                     __hip_atomic_store(hfp->ipc.peer_flag[k], xseq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above, once for all flags
@@ -1702,7 +1716,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
     unsigned long long xseq = 0ull;
     if (HALO && (flg & 1u)) xseq = *hfp->ipc.seq_push;   // (interior patches never look at it: the last band patch advances it while they run)
     // the neighbours' flags: one lane waits, bounded like every other wait of the transport
-    auto wait_flags = [&](const unsigned long long want) {
+    auto wait_flags = [&](const unsigned long long want, const unsigned point) {
         if (t == 0) {
             const long long t0 = wall_clock64();  // 100 MHz
             bool ok = true;
@@ -1712,12 +1726,14 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
                     if (__hip_atomic_load(hfp->ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost
                     if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hfp->ipc.error, 3); break; }  // 10 s
                 }
+            nxs_delay_at(hfp->ipc.delay, point);
         }
         __syncthreads();   // (no acquire: the mailbox is uncached memory, read with system-scope loads -- see k_substep_fused)
     };
     // a G patch is past its first duty (staged; stored, if it sends): the last one tells the neighbours that exchange x is complete AND that half (x-1)&1 is free
     auto ticket_first = [&]() {
         if (t == 0 && atomicAdd(ph.tickets, 1u) == (unsigned)ph.nG - 1u) {
+            nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
             __threadfence_system();
             const unsigned long long pub = ph.nBand > 0 ? xseq + 1ull : xseq + 2ull;   // (no band patch: nobody sends, both exchanges are empty)
             for (int k = 0; k < hfp->ipc.ns; ++k) __hip_atomic_store(hfp->ipc.peer_flag[k], pub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1739,7 +1755,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         u1 = sys_load(src); v1 = sys_load(src + hfp->ghost_srl[g - m.No]);
     };
     const bool mailbox_ghosts = HALO && (flg & 1u) && ph.from_mailbox;
-    if (mailbox_ghosts) wait_flags(xseq);   // the exchange that ended the launch before (x - 1) has landed
+    if (mailbox_ghosts) wait_flags(xseq, NXS_DELAY_STAGE_READ);   // the exchange that ended the launch before (x - 1) has landed
     const int *ncnt = pp.ncnt + (size_t)blk * 3, *ecnt = pp.ecnt + (size_t)blk * 2;
     const int nO = ncnt[0], nN1 = ncnt[1], nN2 = ncnt[2], nE1 = ecnt[0], nE2 = ecnt[1];
     const int *pn = pp.pnodes + (size_t)blk * NDm;
@@ -1897,6 +1913,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         kc1[0] = q[0]; kc1[1] = q[1]; kc1[2] = q[2];
     }
     NXS_STAMP(5);
+    if (HALO && (flg & 2u)) nxs_delay_at(hfp->ipc.delay, NXS_DELAY_SEND_STORE);
     // ---- sub-step 0: nodes N_1 (two rounds)
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
@@ -1929,7 +1946,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         // (its sent nodes touch no ghost of this rank: they are ghosts of a neighbour through an element none of whose nodes the neighbour owns) because its second
         // store goes into the half (x+1)&1 = (x-1)&1 of the neighbour's mailbox, which the neighbour's G patches stage from (and its k_halo_pull at the end of a
         // step reads) until that flag says they are done with it
-        wait_flags(xseq + 1ull);
+        wait_flags(xseq + 1ull, NXS_DELAY_PAIR_MID_READ);
         if (flg & 4u) {
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -1973,6 +1990,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         if (MOVE && active) { mv[0] = s.UM[my_node]; mv[1] = s.UM[my_node + Nn]; mv[2] = s.UT[my_node]; mv[3] = s.UT[my_node + Nn]; }
         __syncthreads();  // corner forces of sub-step 1 visible
         NXS_STAMP(3);
+        if (HALO && (flg & 2u)) nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PAIR_SECOND_STORE);
         if (active) {
             double u1, v1;
             const double u0 = lu[t], v0 = lv[t];   // (MOVE) the first sub-step's velocity of this node
@@ -2006,6 +2024,7 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
                     __builtin_amdgcn_s_sleep(2);
                     if (wall_clock64() - t0 > 1000000000ll) { atomicExch(hfp->ipc.error, 3); break; }  // 10 s: a G patch of this rank never ran
                 }
+                nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PAIR_SECOND_FLAG);
                 __threadfence_system();
                 for (int k = 0; k < hfp->ipc.ns; ++k) __hip_atomic_store(hfp->ipc.peer_flag[k], xseq + 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 ph.tickets[32] = 0u;
@@ -2384,6 +2403,7 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
         const DevParams *pq = pdev;
         asm volatile("" : "+s"(pq));
         const DevParams &q = *pq;
+        if (HALO) nxs_delay_at(hfp->ipc.delay, NXS_DELAY_SEND_STORE);
         // ---- node phase (FE.cpp:10445-10553): fan gather in ascending element order, 2x2 solve, mesh move, publish
         if (has_node) {
             double uice = lu[tt], vice = lv[tt];
@@ -2453,6 +2473,7 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
                     __builtin_amdgcn_s_sleep(1);
                     if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }  // 10 s, as every other inter-rank wait
                 }
+                nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
                 // the one release of the sub-step -- a RELEASE only: __threadfence_system() is an acquire as well, i.e. it also invalidates this
                 // XCD's L2, and every patch on the XCD then re-reads its element constants from memory instead of the L2, every sub-step
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
@@ -2491,6 +2512,7 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
         __syncthreads();
         RSTAMP(4);
         if (lerr) break;
+        if (HALO) nxs_delay_at(hfp->ipc.delay, NXS_DELAY_STAGE_READ);
         {   // the halo nodes' new velocities, past the caches
             const double *X = (ss & 1) ? r.X1 : r.X0;
             if (HALO) {
@@ -2772,6 +2794,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         const DevParams *pq = pdev;
         asm volatile("" : "+s"(pq));
         const DevParams &q = *pq;
+        if (HALO && boundary) nxs_delay_at(hfp->ipc.delay, NXS_DELAY_SEND_STORE);
         // ---- node phase (FE.cpp:10445-10553): fan gather in ascending element order, 2x2 solve, mesh move, publish
 #pragma unroll
         for (int i = 0; i < NPT; ++i) {
@@ -2833,6 +2856,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     __builtin_amdgcn_s_sleep(1);
                     if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
                 }
+                nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
                 for (int k = 0; k < hfp->ipc.ns; ++k)
                     __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2862,6 +2886,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         __syncthreads();
         RSTAMP(4);
         if (lerr) break;
+        if (HALO && boundary) nxs_delay_at(hfp->ipc.delay, NXS_DELAY_STAGE_READ);
         {   // the halo nodes' new velocities, past the caches; OVL: the first T of them travel while the second part of the interior elements is computed
             const double *X = (ss & 1) ? r.X1 : r.X0;
             const double *mb = nullptr;
@@ -3122,6 +3147,7 @@ __global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ 
                                                      int rank, int selftest) {
     const unsigned long long seq = *ipc.seq_push;
     const int j = blockIdx.x * BLOCK + threadIdx.x;
+    nxs_delay_at(ipc.delay, NXS_DELAY_PUSH_STORE);
     if (j < total) {
         const int k = seg_of[j];
         const int off = offsets[k], srl = offsets[k + 1] - off;
@@ -3145,6 +3171,7 @@ __global__ void __launch_bounds__(BLOCK) k_halo_push(const double *__restrict__ 
     if (threadIdx.x == 0) { if (selftest != 2) __threadfence_system(); last = (atomicAdd(ipc.done_push, 1u) == gridDim.x - 1); }
     __syncthreads();
     if (last) {
+        nxs_delay_at(ipc.delay, NXS_DELAY_PUSH_FLAG);
         __threadfence_system();
         for (int k = threadIdx.x; k < ipc.ns; k += BLOCK)
             __hip_atomic_store(ipc.peer_flag[k], seq + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);  // released by the fence above
@@ -3174,6 +3201,7 @@ __global__ void __launch_bounds__(BLOCK) k_halo_pull(double *__restrict__ vec, D
             }
             if (!ok) break;
         }
+        nxs_delay_at(ipc.delay, NXS_DELAY_PULL_READ);
     }
     __syncthreads();
     const int j = blockIdx.x * BLOCK + threadIdx.x;
@@ -3276,9 +3304,11 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
             if (scribe && ok)  // the neighbours' words came with their sweep 0; sweeps >= 2 read this cached copy
                 for (int k = 0; k < ipc.nr; ++k)
                     ipc.peer_static[k] = __hip_atomic_load(ipc.sstatic + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ((E << 1) | 1ull);
+            nxs_delay_at(ipc.delay, NXS_DELAY_SMOOTH_READ);
         }
         __syncthreads();
     }
+    if (publisher) nxs_delay_at(ipc.delay, NXS_DELAY_SMOOTH_STORE);
     const int n = blockIdx.x * BLOCK + threadIdx.x;
     if (n < No && (has_open || publisher)) {
         double u = src[n], v = src[n + Nn];
@@ -3329,6 +3359,7 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
         }
     }
     if (last) {
+        nxs_delay_at(ipc.delay, NXS_DELAY_SMOOTH_FLAG);
         if (sweep == 0)
             for (int k = 0; k < ipc.ns; ++k)
                 __hip_atomic_store(ipc.peer_sstatic[k], (E << 1) | (unsigned long long)(ipc.my_static[k] != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -3357,6 +3388,7 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_pull(double *__restrict__ vec,
                 if (wall_clock64() - t0 > 1000000000ll) { ok = 0; atomicExch(ipc.error, 4); break; }  // 10 s
             }
         }
+        nxs_delay_at(ipc.delay, NXS_DELAY_SMOOTH_PULL_READ);
     }
     __syncthreads();
     const int j = blockIdx.x * BLOCK + threadIdx.x;

@@ -64,6 +64,10 @@ def load_library():
     L.nxs_dyn_ipc_export.argtypes = [H, C.c_void_p]
     L.nxs_dyn_ipc_connect.argtypes = [H, C.c_void_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p]
     L.nxs_dyn_ipc_selftest.argtypes = [H, C.c_int, P(C.c_int32)]
+    L.nxs_dyn_ipc_record_bytes.argtypes = [H, P(C.c_int32)]
+    L.nxs_dyn_ipc_export_record.argtypes = [H, C.c_void_p, C.c_int32]
+    L.nxs_dyn_ipc_connect_records.argtypes = [H, C.c_void_p, C.c_int64, C.c_int32]
+    L.nxs_dyn_ipc_loopback.argtypes = [H]
     L.nxs_dyn_put_state.argtypes = [H, P(_abi.State)]
     L.nxs_dyn_get_state.argtypes = [H, P(_abi.State)]
     L.nxs_dyn_set_forcing.argtypes = [H, P(_abi.Forcing)]
@@ -108,6 +112,7 @@ IPC_BLOB_BYTES = 128
 
 EXPORTS = (
     "nxs_dyn_set_halo_exchange_fn", "nxs_dyn_ipc_export", "nxs_dyn_ipc_connect", "nxs_dyn_ipc_selftest",
+    "nxs_dyn_ipc_record_bytes", "nxs_dyn_ipc_export_record", "nxs_dyn_ipc_connect_records", "nxs_dyn_ipc_loopback",
     "nxs_dyn_abi_version", "nxs_dyn_last_error", "nxs_dyn_default_params", "nxs_dyn_physical_constants", "nxs_dyn_selftest_quotients", "nxs_dyn_create", "nxs_dyn_destroy",
     "nxs_dyn_set_params", "nxs_dyn_set_mesh", "nxs_dyn_set_halo", "nxs_dyn_comm_unique_id", "nxs_dyn_comm_init", "nxs_dyn_comm_selftest",
     "nxs_dyn_put_state", "nxs_dyn_get_state", "nxs_dyn_set_forcing", "nxs_dyn_set_forcing_pair", "nxs_dyn_set_forcing_time",
@@ -128,7 +133,7 @@ def selftest_quotients(n: int, seed: int = 1, mode: int = 0, device: int = 0) ->
     bad = C.c_int64(-1)
     rc = L.nxs_dyn_selftest_quotients(device, n, seed, mode, C.byref(bad))
     if rc != 0:
-        raise NxsError(f"nxs_dyn_selftest_quotients returned {rc}: {L.nxs_dyn_last_error(None).decode(errors='replace')}")
+        raise NxsError(rc, (L.nxs_dyn_last_error(None) or b"").decode(errors="replace"))
     return bad.value
 
 
@@ -241,37 +246,62 @@ class FiniteElementDynamics:
         self._halo_cb = HALO_FN(tramp)
         self._chk(self.L.nxs_dyn_set_halo_exchange_fn(self.h, self._halo_cb, None))
 
-    def ipc_setup(self, all_gather, selftest_rounds: int = 64) -> bool:
+    def ipc_setup(self, all_gather, selftest_rounds: int = 64, low_level: bool = False) -> bool:
         """Collective setup of the device-direct halo transport (peer-mapped mailboxes).
         all_gather(obj) -> list of every rank's obj (the launcher's communicator, e.g.
         torch.distributed.all_gather_object).  Returns True when the transport is connected and its
-        self-test passed on EVERY rank; otherwise the handle is left on its previous transport."""
+        self-test passed on EVERY rank; otherwise the handle is left on its previous transport.
+        Default: the record form (nxs_dyn_ipc_export_record / nxs_dyn_ipc_connect_records) -- the library finds every neighbour's segment, totals and
+        flag slot itself, also for the directions nxs_dyn_set_halo added on a ragged partition.  low_level: the caller's own bookkeeping through
+        nxs_dyn_ipc_connect (tables for the caller's send neighbours; refused by the library where a neighbour exists in one direction only)."""
         lm = self.lm
-        blob = C.create_string_buffer(IPC_BLOB_BYTES)
         ok = 1
         self._ipc_error = ""
-        try:
-            self._chk(self.L.nxs_dyn_ipc_export(self.h, blob))
-        except NxsError as e:
-            self._ipc_error = f"rank {lm.rank}: export: {e}"
-            ok = 0
-        infos = all_gather({"ok": ok, "blob": blob.raw, "recv_procs": lm.recv_procs.tolist(),
-                            "recv_offsets": lm.recv_offsets.tolist(), "err": self._ipc_error})
+        if low_level:
+            blob = C.create_string_buffer(IPC_BLOB_BYTES)
+            try:
+                self._chk(self.L.nxs_dyn_ipc_export(self.h, blob))
+            except NxsError as e:
+                self._ipc_error = f"rank {lm.rank}: export: {e}"
+                ok = 0
+            infos = all_gather({"ok": ok, "blob": blob.raw, "recv_procs": lm.recv_procs.tolist(),
+                                "recv_offsets": lm.recv_offsets.tolist(), "err": self._ipc_error})
+        else:
+            n = C.c_int32(0)
+            rec = b""
+            try:
+                self._chk(self.L.nxs_dyn_ipc_record_bytes(self.h, C.byref(n)))
+            except NxsError as e:
+                self._ipc_error = f"rank {lm.rank}: record: {e}"
+                ok = 0
+            stride = max(all_gather(int(n.value)))       # (the launcher's MPI_Allreduce(MAX))
+            if ok:
+                buf = C.create_string_buffer(stride)
+                try:
+                    self._chk(self.L.nxs_dyn_ipc_export_record(self.h, buf, stride))
+                    rec = buf.raw
+                except NxsError as e:
+                    self._ipc_error = f"rank {lm.rank}: export: {e}"
+                    ok = 0
+            infos = all_gather({"ok": ok, "rec": rec if ok else bytes(stride), "err": self._ipc_error})
         if not all(i["ok"] for i in infos):
             self._ipc_error = "; ".join(i["err"] for i in infos if i["err"])   # (every rank reports what any rank saw)
             return False
-        blobs, off, tot, slot = b"", [], [], []
-        for q in lm.send_procs.tolist():
-            inf = infos[q]
-            k = inf["recv_procs"].index(lm.rank)
-            blobs += inf["blob"]
-            off.append(inf["recv_offsets"][k]); tot.append(inf["recv_offsets"][-1]); slot.append(k)
-        a_off, a_tot, a_slot = (np.asarray(v, np.int32) for v in (off, tot, slot))
-        bbuf = C.create_string_buffer(blobs, max(len(blobs), 1))
         ok = 1
         try:
-            self._chk(self.L.nxs_dyn_ipc_connect(self.h, bbuf, _abi.iptr(np.ascontiguousarray(a_off)),
-                                                 _abi.iptr(np.ascontiguousarray(a_tot)), _abi.iptr(np.ascontiguousarray(a_slot))))
+            if low_level:
+                blobs, off, tot, slot = b"", [], [], []
+                for q in lm.send_procs.tolist():
+                    inf = infos[q]
+                    k = inf["recv_procs"].index(lm.rank)
+                    blobs += inf["blob"]
+                    off.append(inf["recv_offsets"][k]); tot.append(inf["recv_offsets"][-1]); slot.append(k)
+                a_off, a_tot, a_slot = (np.ascontiguousarray(np.asarray(v, np.int32)) for v in (off, tot, slot))
+                bbuf = C.create_string_buffer(blobs, max(len(blobs), 1))
+                self._chk(self.L.nxs_dyn_ipc_connect(self.h, bbuf, _abi.iptr(a_off), _abi.iptr(a_tot), _abi.iptr(a_slot)))
+            else:
+                recs = b"".join(i["rec"] for i in infos)
+                self._chk(self.L.nxs_dyn_ipc_connect_records(self.h, C.create_string_buffer(recs, len(recs)), stride, len(infos)))
         except NxsError as e:
             self._ipc_error = f"rank {lm.rank}: connect: {e}"
             ok = 0
@@ -296,24 +326,13 @@ class FiniteElementDynamics:
         return good
 
     def ipc_loopback(self) -> bool:
-        """Profiling aid: the device-direct mailboxes of this handle connected to THEMSELVES, so that a rank's partition can be stepped alone on a device
-        with the exchange inside its kernels (every flag a kernel waits for is raised by the rank's own launches).  Rocprofv3's counter collection serialises
-        the kernels of a device: two ranks whose kernels wait for each other cannot be profiled together, a looped-back rank can.  The ghosts receive
-        meaningless velocities (results are NOT the model's); the launches walk the same tables and move the same bytes.  False when the partition's lists do
-        not allow it (fewer send than receive neighbours, a send segment longer than everything received)."""
-        lm = self.lm
-        ns, nr = len(lm.send_procs), len(lm.recv_procs)
-        tr = int(lm.recv_offsets[-1]) if nr else 0
-        seg = np.diff(lm.send_offsets) if ns else np.zeros(0, int)
-        if ns == 0 or ns < nr:
+        """Profiling aid (nxs_dyn_ipc_loopback): the device-direct mailboxes of this handle connected to THEMSELVES, so that a rank's partition can be stepped
+        alone on a device with the exchange inside its kernels.  The ghosts receive meaningless velocities (results are NOT the model's); the launches walk
+        the same tables and move the same bytes.  False when the partition's lists do not allow it (no neighbour)."""
+        rc = self.L.nxs_dyn_ipc_loopback(self.h)
+        if rc == -1:
             return False
-        tr = max(tr, int(seg.max()))          # (every send segment is stored at offset 0 of the looped-back mailbox: room for the longest)
-        self.set_option("ipc_pad", tr)
-        blob = C.create_string_buffer(IPC_BLOB_BYTES)
-        self._chk(self.L.nxs_dyn_ipc_export(self.h, blob))
-        bbuf = C.create_string_buffer(blob.raw * ns, IPC_BLOB_BYTES * ns)
-        a_off = np.zeros(ns, np.int32); a_tot = np.full(ns, tr, np.int32); a_slot = (np.arange(ns) % nr).astype(np.int32)
-        self._chk(self.L.nxs_dyn_ipc_connect(self.h, bbuf, _abi.iptr(a_off), _abi.iptr(a_tot), _abi.iptr(a_slot)))
+        self._chk(rc)
         return True
 
     @staticmethod

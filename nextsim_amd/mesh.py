@@ -302,8 +302,11 @@ def partition_elements(mesh: GlobalMesh, nparts: int) -> np.ndarray:
     return part
 
 
-def localize(mesh: GlobalMesh, nparts: int = 1, elem_part: np.ndarray | None = None) -> list[LocalMesh]:
-    """Per-rank meshes in the reference layout (see module docstring)."""
+def localize(mesh: GlobalMesh, nparts: int = 1, elem_part: np.ndarray | None = None, symmetrise: bool = False) -> list[LocalMesh]:
+    """Per-rank meshes in the reference layout (see module docstring).  The halo lists are what initUpdateGhosts() (FE.cpp:14003-14088) leaves: a ragged
+    partition may send a node to a rank it receives nothing from -- nxs_dyn_set_halo adds the missing direction itself.  symmetrise = True does it here
+    instead (every partner in both lists, the direction without nodes as an empty segment, partners in ascending order): what a caller of the low-level
+    nxs_dyn_ipc_connect has to hand over."""
     Nn, Ne = mesh.num_nodes, mesh.num_elements
     tri = mesh.tri.astype(np.int64)
     if elem_part is None:
@@ -370,10 +373,10 @@ def localize(mesh: GlobalMesh, nparts: int = 1, elem_part: np.ndarray | None = N
             lm.send_procs = np.array(sp, np.int32)
             lm.send_offsets = np.array(so, np.int32)
             lm.send_index = np.ascontiguousarray(np.concatenate(si).astype(np.int32)) if si else np.zeros(0, np.int32)
-        # Every exchange partner is both a sender and a receiver: where a ragged partition sends to a rank it receives nothing from (a node of mine touches an
-        # element of yours, none of yours touches one of mine), the missing direction becomes an EMPTY segment.  The device-direct mailboxes need that hand-shake
-        # (two buffers per link: nxs_dyn_ipc_connect refuses one-directional neighbours); for every other transport an empty segment is a message of no bytes.
-        for lm in out:
+        # symmetrise: every exchange partner is both a sender and a receiver: where a ragged partition sends to a rank it receives nothing from (a node of mine
+        # touches an element of yours, none of yours touches one of mine), the missing direction becomes an EMPTY segment.  The device-direct mailboxes need that
+        # hand-shake (two buffers per link); nxs_dyn_set_halo adds it by itself, this is the same thing done on the caller's side.
+        for lm in (out if symmetrise else []):
             partners = sorted(set(lm.send_procs.tolist()) | set(lm.recv_procs.tolist()))
             for side in ("send", "recv"):
                 procs, offs = getattr(lm, side + "_procs").tolist(), getattr(lm, side + "_offsets").tolist()

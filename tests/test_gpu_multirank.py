@@ -234,31 +234,68 @@ def test_ipc_connect_checks_its_tables_against_what_the_neighbour_published():
         fe.close()
 
 
-def test_ipc_connect_refuses_neighbours_in_one_direction_only():
+def test_one_directional_neighbours_are_padded_behind_the_abi_and_the_low_level_connect_says_so():
     """Two buffers per link are safe only with a hand-shake: a rank that sends to q without receiving from q could run two exchanges ahead of q and overwrite the
-    half q still reads (seen once in round 4 as a wrong payload in the self-test of the 4-rank mosaic of 'small', whose rank 0 sends two nodes to rank 3 and
-    receives nothing from it).  nextsim_amd.mesh.localize therefore gives every partner both directions, an empty segment where a direction carries no node; halo
-    lists without it are refused by nxs_dyn_ipc_connect with the rank named, before any table is read."""
+    half q still reads (round 4; deterministic in tests/test_gpu_protocol_delays.py).  The 4-rank partition of 'small' has such a link (rank 0 -> rank 3), and its
+    halo lists go in VERBATIM: nxs_dyn_set_halo adds the missing direction as an empty segment behind the caller's neighbours, the record form connects all four
+    ranks (handles of ONE process here, mailboxes through plain pointers) and the self-test passes on every link; the low-level nxs_dyn_ipc_connect, whose tables
+    know only the caller's own neighbours, refuses with the rank named and points at the record form."""
     import ctypes as C
-    import copy
+    import threading
     import numpy as np
     import cases
     from nextsim_amd import _abi, dynamics
     gm, p, g, lms, fields = cases.make_case("small", nparts=4)
-    lm = copy.deepcopy(lms[0])
-    k = lm.recv_procs.tolist().index(3)
-    assert lm.recv_offsets[k + 1] == lm.recv_offsets[k]          # the empty direction
-    lm.recv_procs = np.delete(lm.recv_procs, k); lm.recv_offsets = np.delete(lm.recv_offsets, k + 1)
-    fe = dynamics.FiniteElementDynamics(p)
-    fe.set_mesh(lm)
-    b = C.create_string_buffer(dynamics.IPC_BLOB_BYTES)
-    fe._chk(fe.L.nxs_dyn_ipc_export(fe.h, b))
-    ns = lm.send_procs.size
-    z = np.zeros(ns, np.int32)
-    rc = fe.L.nxs_dyn_ipc_connect(fe.h, C.create_string_buffer(ns * dynamics.IPC_BLOB_BYTES), _abi.iptr(z), _abi.iptr(z), _abi.iptr(z))
-    msg = (fe.L.nxs_dyn_last_error(fe.h) or b"").decode()
-    assert rc != 0 and "one direction only" in msg and "rank 3" in msg and "empty segment" in msg, (rc, msg)
-    fe.close()
+    assert 3 in lms[0].send_procs.tolist() and 3 not in lms[0].recv_procs.tolist()
+    fes = [dynamics.FiniteElementDynamics(p) for _ in range(4)]
+    for fe, lm in zip(fes, lms):
+        fe.set_mesh(lm)
+    # low level: refused on the two ranks of the one-directional link, before any table is read
+    for r, other in ((0, 3), (3, 0)):
+        fe, lm = fes[r], lms[r]
+        b = C.create_string_buffer(dynamics.IPC_BLOB_BYTES)
+        fe._chk(fe.L.nxs_dyn_ipc_export(fe.h, b))
+        ns = max(lm.send_procs.size, 1)
+        z = np.zeros(ns, np.int32)
+        rc = fe.L.nxs_dyn_ipc_connect(fe.h, C.create_string_buffer(ns * dynamics.IPC_BLOB_BYTES), _abi.iptr(z), _abi.iptr(z), _abi.iptr(z))
+        msg = (fe.L.nxs_dyn_last_error(fe.h) or b"").decode()
+        assert rc != 0 and "one direction only" in msg and f"rank {other}" in msg and "nxs_dyn_ipc_connect_records" in msg, (rc, msg)
+    # the record form: sizes, records, connect -- what examples/nextsim_mpi.cpp does with MPI_Allreduce / MPI_Allgather
+    sizes = []
+    for fe in fes:
+        n = C.c_int32()
+        fe._chk(fe.L.nxs_dyn_ipc_record_bytes(fe.h, C.byref(n)))
+        sizes.append(n.value)
+    stride = max(sizes)
+    recs = b""
+    for fe, need in zip(fes, sizes):
+        buf = C.create_string_buffer(stride)
+        assert fe.L.nxs_dyn_ipc_export_record(fe.h, buf, need - 1) != 0          # a record that does not fit is refused, nothing is exported
+        fe._chk(fe.L.nxs_dyn_ipc_export_record(fe.h, buf, stride))
+        recs += buf.raw
+    rb = C.create_string_buffer(recs, len(recs))
+    assert fes[0].L.nxs_dyn_ipc_connect_records(fes[0].h, rb, stride, 3) != 0          # the wrong number of ranks
+    for fe in fes:
+        fe._chk(fe.L.nxs_dyn_ipc_connect_records(fe.h, rb, stride, 4))
+    errs = [C.c_int32(-1) for _ in fes]
+    th = [threading.Thread(target=lambda r=r: fes[r]._chk(fes[r].L.nxs_dyn_ipc_selftest(fes[r].h, 16, C.byref(errs[r])))) for r in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert [e.value for e in errs] == [0, 0, 0, 0]
+    # records that disagree with this rank's lists are refused: rank 3's record with rank 0 cut out of its receive neighbours
+    bad = bytearray(recs)
+    head = 3 * stride + dynamics.IPC_BLOB_BYTES
+    nr3 = int(np.frombuffer(bytes(bad[head + 8:head + 12]), np.int32)[0])
+    rp = np.frombuffer(bytes(bad[head + 16:head + 16 + 4 * nr3]), np.int32).copy()
+    assert 0 in rp.tolist()
+    rp[rp.tolist().index(0)] = 2 if 2 not in rp.tolist() else 1
+    bad[head + 16:head + 16 + 4 * nr3] = rp.tobytes()
+    rc = fes[0].L.nxs_dyn_ipc_connect_records(fes[0].h, C.create_string_buffer(bytes(bad), len(bad)), stride, 4)
+    assert rc != 0 and "does not list rank 0" in (fes[0].L.nxs_dyn_last_error(fes[0].h) or b"").decode()
+    for fe in fes:
+        fe.close()
 
 
 @pytest.mark.parametrize("world,kind,rpp,over,overlap", [(2, "small", 1, {}, 0), (3, "small", 1, {"ragged_seed": 1}, 0), (3, "small", 1, {"dynamics_type": 3}, 0),

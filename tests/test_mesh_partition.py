@@ -48,12 +48,24 @@ def test_layout_contract(kind, nparts):
             sent = lm.node_gid[lm.send_index[lm.send_offsets[k]:lm.send_offsets[k + 1]]]
             recv = other.node_gid[other.recv_index[other.recv_offsets[kk]:other.recv_offsets[kk + 1]]]
             assert np.array_equal(sent, recv) and np.all(np.diff(sent) > 0)
-        # every exchange partner is sender AND receiver (the hand-shake the device-direct mailboxes need; a direction without a node is an empty segment):
-        # the 4-rank mosaic of 'small' has one -- rank 0 sends two nodes to rank 3 and receives nothing from it
-        assert lm.send_procs.tolist() == lm.recv_procs.tolist() == sorted(set(lm.send_procs.tolist()))
+    # The lists are what initUpdateGhosts leaves -- NOT symmetric on a ragged partition: in the 4-rank partition of 'small' rank 0 sends two nodes to rank 3 and
+    # receives nothing from it.  nxs_dyn_set_halo adds the missing direction as an empty segment by itself (the hand-shake the device-direct mailboxes need);
+    # localize(symmetrise=True) is the same thing done on the caller's side: every partner in both lists, ascending, the same nodes.
+    sym = M.localize(gm, nparts, symmetrise=True)
+    for lm, ls in zip(lms, sym):
+        partners = sorted(set(lm.send_procs.tolist()) | set(lm.recv_procs.tolist()))
+        assert ls.send_procs.tolist() == ls.recv_procs.tolist() == partners
+        assert np.array_equal(ls.send_index, lm.send_index) and np.array_equal(ls.recv_index, lm.recv_index)
+        for side in ("send", "recv"):
+            po, oo = getattr(lm, side + "_procs").tolist(), getattr(lm, side + "_offsets")
+            ps, os_ = getattr(ls, side + "_procs").tolist(), getattr(ls, side + "_offsets")
+            for k, q in enumerate(ps):
+                n = os_[k + 1] - os_[k]
+                assert n == (oo[po.index(q) + 1] - oo[po.index(q)] if q in po else 0)
     if (kind, nparts) == ("small", 4):
-        k03 = lms[0].recv_procs.tolist().index(3)
-        assert lms[0].recv_offsets[k03 + 1] == lms[0].recv_offsets[k03] and lms[0].send_offsets[k03 + 1] > lms[0].send_offsets[k03]
+        assert 3 in lms[0].send_procs.tolist() and 3 not in lms[0].recv_procs.tolist()
+        k03 = sym[0].recv_procs.tolist().index(3)
+        assert sym[0].recv_offsets[k03 + 1] == sym[0].recv_offsets[k03] and sym[0].send_offsets[k03 + 1] > sym[0].send_offsets[k03]
 
 
 def test_generators_are_seeded_and_sane():
