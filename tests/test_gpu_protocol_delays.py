@@ -28,7 +28,7 @@ VARIANTS = {
     "pair": ({"fused": 3, "pair_regs": 1, "halo_fused": 1}, (STAGE_READ, SEND_STORE, PUBLISH_FLAG, PAIR_MID_READ, PAIR_SECOND_STORE, PAIR_SECOND_FLAG, PULL_READ)),
     "resident": ({"fused": 4, "halo_fused": 1}, (STAGE_READ, SEND_STORE, PUBLISH_FLAG)),
 }
-EXPECT_LAUNCHES = {"inkernel": 120, "pair": 60, "resident": 1}
+EXPECT_KERNEL = {"separate": "k_substep_fused", "inkernel": "k_substep_fused", "pair": "k_substep_pair", "resident": "k_substep_resident"}
 
 
 def _walk(world, units, variants=VARIANTS, mixed=True):
@@ -100,11 +100,12 @@ def test_every_protocol_point_delayed_on_every_rank_keeps_the_bits(world, seed, 
             if not c.get("equal") or c.get("error") or c.get("crash"):
                 bad.append((r["rank"], c))
             v = c["name"].split("/")[0]
-            if v in EXPECT_LAUNCHES:   # the variant named is the variant that ran
-                assert c["launches"] == EXPECT_LAUNCHES[v], (r["rank"], c)
+            if v in EXPECT_KERNEL:   # the variant named is the variant that ran
+                assert c["kernel"].startswith(EXPECT_KERNEL[v]), (r["rank"], c)
+                assert v != "resident" or c["launches"] == 1, (r["rank"], c)
             if v.startswith("mixed"):
                 want = [1, 0] if v == "mixed1" else [0, 1]
-                assert c["launches"] == (60 if want[r["rank"] % 2] else 120), (r["rank"], c)
+                assert c["kernel"] == ("k_substep_pair" if want[r["rank"] % 2] else "k_substep_fused"), (r["rank"], c)
     assert not bad, bad[:6]
 
 
