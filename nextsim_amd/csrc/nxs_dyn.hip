@@ -140,9 +140,10 @@ struct nxs_dyn_handle {
     std::vector<double> h_x0, h_y0;
     std::vector<void *> patch_allocs;
     std::vector<void *> mesh_allocs, state_allocs;
-    // Device memory that a rebuild INSIDE a step lets go of is parked here and freed by the next call that is outside a step (set_mesh, set_params,
-    // set_option, put_state, destroy): a hipFree synchronises the whole device, and where ranks share one (tests, rehearsals, two MPI ranks per GPU) a
-    // neighbour rank's kernel may already be spinning for this rank's next launch -- the free would wait for it, the launch for the free.
+    // Device memory that a rebuild INSIDE a step lets go of is parked here and freed by the next call that is outside a step AND outside the time loop (set_mesh,
+    // set_params, set_option, destroy -- NOT put_state / set_forcing, which a host with its thermodynamics on the CPU calls between any two steps): a hipFree
+    // synchronises the whole device, and where ranks share one (tests, rehearsals, two MPI ranks per GPU) a neighbour rank's kernel may already be spinning for this
+    // rank's next launch -- the free would wait for it, the launch for the free.
     std::vector<void *> retired;
     bool in_step = false;
     // halo
@@ -152,6 +153,8 @@ struct nxs_dyn_handle {
     int ns_caller = 0, nr_caller = 0;      // neighbours the caller's own lists named (the low-level nxs_dyn_ipc_connect takes tables for those)
     int one_directional = 0;               // test door "halo_one_directional": 1 = set_halo takes the lists as given and ipc_connect does not refuse (round 4's defect, for the delay tests)
     unsigned ipc_delay_opt = 0;            // test door "ipc_delay": rank << 16 | point << 8 | units (include/nxs_dyn.h)
+    int ord_blocks = 0, ord_slots = 0;     // the largest grid of blocks that may WAIT inside this handle's ordinary kernels, as registered on the device (nxs_resident_registry.hpp)
+    long long reg_touched = 0;             // when the registry entry was last touched (seconds)
     int *d_send_index = nullptr, *d_send_seg = nullptr, *d_send_off = nullptr;
     int *d_recv_index = nullptr, *d_recv_seg = nullptr, *d_recv_off = nullptr;
     double *d_send_buf = nullptr, *d_recv_buf = nullptr;
@@ -249,10 +252,12 @@ namespace {
 inline int eff_fused(const nxs_dyn_handle *h) { return h->trace_branches ? 0 : h->fused; }
 int build_halo_fused(nxs_dyn_handle *h);  // (defined with the launch logic below)
 int build_resident(nxs_dyn_handle *h);
-void resident_registry_release(const nxs_dyn_handle *h);
-bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots, std::string *why);
+void resident_registry_release(const nxs_dyn_handle *h, int kind);
+bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots, std::string *why, int kind);
 void release_resident(nxs_dyn_handle *h);
+void release_graph(nxs_dyn_handle *h);
 bool multi_rank(const nxs_dyn_handle *h);
+void register_waiting_grid(nxs_dyn_handle *h, int blocks, int slots, bool reset = false);
 
 int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -537,7 +542,7 @@ void release_resident(nxs_dyn_handle *h) {
     h->res = DevResident{};
     h->d_vt3 = nullptr;
     h->res_ready = false; h->res_failed = false;
-    resident_registry_release(h);
+    resident_registry_release(h, nxs_reg::KIND_RESIDENT);
 }
 
 // A resident launch that gave up (k_substep_resident's bounded waits) leaves a mixture of the step's start and its end behind (no patch writes after
@@ -562,7 +567,7 @@ int resident_error(nxs_dyn_handle *h) {
     if (!err) return NXS_OK;
     HIPCHK(h, hipMemsetAsync(h->res.error, 0, sizeof(int), h->stream));
     h->res_failed = true; h->res_ready = false; release_graph(h);
-    resident_registry_release(h);
+    resident_registry_release(h, nxs_reg::KIND_RESIDENT);
     const char *what = err == 5 ? "a patch waited 12 s for a neighbouring patch of its own rank: the workgroups of the grid were not all resident (is the device shared with another process?)"
                      : err == 6 ? "the boundary patches' publishing order stalled for 10 s (an earlier sub-step was never published: a patch of this rank is missing)"
                      : err == 7 ? "a neighbour rank's flag did not arrive within 10 s (that rank started its step late, stopped, or its launch failed)"
@@ -748,7 +753,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
         const bool was_resident = h->fused == 4, now_resident = value == 4;
         h->fused = (int)value; h->res_failed = false; h->no_big_cut = false; release_graph(h);
-        if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; h->pair_ready = false; }   // (the several-rank pair patches: cut again when they are wanted)
+        if (h->pair_claim) { resident_registry_release(h, nxs_reg::KIND_PAIR); h->pair_claim = false; h->pair_ready = false; }   // (the several-rank pair patches: cut again when they are wanted)
         // the resident loop has a cut of its own (one round of workgroups; one LARGE patch per CU for partitions of 200 k - 400 k triangles, which is not what
         // the one-launch-per-sub-step kernel wants): asking for it or giving it up on a live mesh cuts the mesh again -- any cut gives the same bits
         if (h->have_mesh && was_resident != now_resident) {
@@ -895,7 +900,7 @@ int nxs_dyn_set_mesh(nxs_dyn_handle *h, const nxs_dyn_mesh *m) try {
     free_pool(h->halo_allocs);
     free_pool(h->patch_allocs);
     release_resident(h);
-    if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; }
+    if (h->pair_claim) { resident_registry_release(h, nxs_reg::KIND_PAIR); h->pair_claim = false; }
     free_pool(h->pair_allocs);
     h->pair_ready = false;
     h->pair_failed = false;
@@ -1077,7 +1082,7 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
         if (off[n] > 0 && !(side ? halo->recv_index : halo->send_index)) return fail(h, NXS_ERR_INVALID, "%s_index is NULL", side ? "recv" : "send");
     }
     h->rank = halo->rank; h->nranks = halo->nranks;
-    if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; }
+    if (h->pair_claim) { resident_registry_release(h, nxs_reg::KIND_PAIR); h->pair_claim = false; }
     h->pair_ready = false; h->pair_failed = false;   // (the several-rank pair patches depend on the send lists)
     h->send_procs.assign(halo->send_procs, halo->send_procs + ns);
     h->recv_procs.assign(halo->recv_procs, halo->recv_procs + nr);
@@ -1137,6 +1142,11 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
     HIPCHK(h, hipHostMalloc((void **)&h->h_send, std::max<size_t>(2 * (size_t)ts, 1) * sizeof(double), hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void **)&h->h_recv, std::max<size_t>(2 * (size_t)tr, 1) * sizeof(double), hipHostMallocDefault));
     h->have_halo = true;
+    {   // k_smooth_halo's blocks (one per BLOCK own nodes) spin for a neighbour's sweep, k_halo_pull's (one per BLOCK ghosts) for its flags
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_smooth_halo, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+        register_waiting_grid(h, halo->nranks > 1 ? std::max(nblocks(No), nblocks(tr)) : 0, per_cu * device_cus(h), true);
+    }
     return NXS_OK;
 } catch (...) { return dyn_caught(h, "nxs_dyn_set_halo"); }
 
@@ -1904,12 +1914,23 @@ const void *resident_kernel(const nxs_dyn_handle *h, bool mr, bool ovl) {
 // registry before it builds the loop and gives them back when its tables go; a claim that does not fit beside what is claimed already -- by handles
 // of this process or of any other process on the device, with headroom for the co-tenants' ordinary kernels where the device is shared -- is refused
 // up front and the step runs one kernel per sub-step (nxs_resident_registry.hpp has the rule and the evidence behind it).
-void resident_registry_release(const nxs_dyn_handle *h) {
-    if (!h->reg_key.empty()) nxs_reg::table_for(h->reg_key).release((uint64_t)(uintptr_t)h);
+// (kind: nxs_reg::KIND_RESIDENT / KIND_PAIR -- one claim per handle, held by ONE of its two grids of waiting workgroups; a release names the grid that lets go,
+// so that the resident loop's tables going away do not take the pair patches' claim with them)
+void resident_registry_release(const nxs_dyn_handle *h, int kind) {
+    if (!h->reg_key.empty()) nxs_reg::table_for(h->reg_key).release((uint64_t)(uintptr_t)h, kind);
 }
-bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots, std::string *why) {
+bool resident_registry_claim(const nxs_dyn_handle *h, int workgroups, int slots, std::string *why, int kind) {
     if (h->reg_key.empty()) { if (why) *why = "the handle is not registered on its device"; return false; }
-    return nxs_reg::table_for(h->reg_key).claim((uint64_t)(uintptr_t)h, workgroups, slots, multi_rank(h), why);
+    return nxs_reg::table_for(h->reg_key).claim((uint64_t)(uintptr_t)h, workgroups, slots, multi_rank(h), why, kind);
+}
+
+// The blocks of this handle's ORDINARY kernels that may spin for a neighbour rank (k_smooth_halo, k_halo_pull, the boundary patches of k_substep_fused<HALO>): the
+// largest such grid, as a fraction of the device, is registered -- other handles' claims leave it room (nxs_resident_registry.hpp).  reset: start from nothing.
+void register_waiting_grid(nxs_dyn_handle *h, int blocks, int slots, bool reset) {
+    if (h->reg_key.empty()) return;
+    if (reset) { h->ord_blocks = 0; h->ord_slots = 0; }
+    if (blocks > 0 && slots > 0 && (h->ord_blocks == 0 || (double)blocks / slots > (double)h->ord_blocks / h->ord_slots)) { h->ord_blocks = blocks; h->ord_slots = slots; }
+    nxs_reg::table_for(h->reg_key).set_ordinary((uint64_t)(uintptr_t)h, h->ord_blocks, h->ord_slots);
 }
 
 // tables of the halo exchange fused into the sub-step kernel (see HaloFused)
@@ -1945,6 +1966,7 @@ int build_halo_fused(nxs_dyn_handle *h) {
     f.n_send_blocks = plan.n_send_blocks;
     f.send_off = h->d_send_off;
     f.n_boundary = plan.n_boundary;
+    register_waiting_grid(h, plan.n_boundary, 2 * device_cus(h));   // (two 512-thread workgroups of the fused kernel per CU)
     f.No = No;
     {
         unsigned long long *raw = nullptr;  // device copy of the struct itself (filled in by run_substeps once the mailboxes are connected)
@@ -2004,7 +2026,8 @@ int build_resident(nxs_dyn_handle *h) {
     // together must fit, or the spinning workgroups of one keep the other's from ever starting
     {
         std::string why;
-        if (!resident_registry_claim(h, nP, per_cu * cus, &why)) return refuse(why.c_str());
+        if (!resident_registry_claim(h, nP, per_cu * cus, &why, nxs_reg::KIND_RESIDENT)) return refuse(why.c_str());
+        if (h->pair_claim) { h->pair_claim = false; h->pair_ready = false; }   // (a handle holds ONE claim: the pair patches' went with it and are cut -- and claimed -- again if they are wanted)
     }
     int rc;
     DevResident &r = h->res;
@@ -2456,6 +2479,10 @@ int nxs_dyn_step(nxs_dyn_handle *h) try {  // FE.cpp:8197-8214
     int k = -1;
     h->cur = nullptr;
     StepScope scope(h);
+    if (!h->reg_key.empty()) {   // "still here" for the device's registry, at most every ten seconds (nxs_resident_registry.hpp: entries of other PID namespaces expire)
+        const long long now = (long long)nxs_reg::boot_seconds();
+        if (now - h->reg_touched >= 10) { nxs_reg::table_for(h->reg_key).touch((uint64_t)(uintptr_t)h); h->reg_touched = now; }
+    }
     if (h->timing_enabled) {
         k = h->set_next;
         if ((rc = harvest(h, k))) return rc;

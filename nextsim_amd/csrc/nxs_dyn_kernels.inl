@@ -2030,8 +2030,6 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
                 ph.tickets[32] = 0u;
                 *hfp->ipc.seq_push = xseq + 2ull;
             }
-        } else if (ph.nG == 0 && blockIdx.x == 0 && t == 0) {
-            *hfp->ipc.seq_push += 2ull;             // a rank without neighbours: the sequence still counts the exchanges
         }
     }
     NXS_STAMP(4);
@@ -2053,6 +2051,8 @@ __global__ void __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     if (HALO) {
         const unsigned flg = ph.pflags[blk];   // this patch's duties in the exchange (uniform over the workgroup)
         if (flg & 1u) { pair_body<T, POW4, NTM, true>(m, pp, s, w, p, b, vout, hfp, ph, blk, flg); return; }
+        // a rank whose mesh holds no ghost (no G patch: nobody runs the exchange's body, nobody reads the sequence): the sequence still counts the two exchanges
+        if (ph.nG == 0 && blockIdx.x == 0 && threadIdx.x == 0) *hfp->ipc.seq_push += 2ull;
     }
     pair_body<T, POW4, NTM, false, false, MOVE, !HALO>(m, pp, s, w, p, b, vout, hfp, ph, blk, 0u);
 }

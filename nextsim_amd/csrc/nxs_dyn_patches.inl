@@ -124,7 +124,7 @@ int upload_pair_patches_mr(nxs_dyn_handle *h) {
     h->dpch2 = DevPatches2{};
     h->pair_ready = false;
     h->pairh = PairHalo{};
-    if (h->pair_claim) { resident_registry_release(h); h->pair_claim = false; }
+    if (h->pair_claim) { resident_registry_release(h, nxs_reg::KIND_PAIR); h->pair_claim = false; }
     const DevMesh &m = h->dm;
     std::vector<char> sent((size_t)std::max(m.No, 1), 0);
     for (int n : h->h_send_index) if (n >= 0 && n < m.No) sent[n] = 1;
@@ -142,7 +142,8 @@ int upload_pair_patches_mr(nxs_dyn_handle *h) {
     if (plan.nG > cus) return refuse("more patches along the partition boundary than half the device's workgroup slots");
     {
         std::string w2;
-        if (plan.nG > 0 && !resident_registry_claim(h, plan.nG, 2 * cus, &w2)) return refuse(w2.c_str());
+        if (plan.nG > 0 && !resident_registry_claim(h, plan.nG, 2 * cus, &w2, nxs_reg::KIND_PAIR)) return refuse(w2.c_str());
+        if (plan.nG > 0 && h->res_ready) { h->res_ready = false; release_graph(h); }   // (a handle holds ONE claim: the resident loop's went with this one)
         h->pair_claim = plan.nG > 0;
     }
     if (h->pair_nodes == 0) h->pair_hint = plan.P;

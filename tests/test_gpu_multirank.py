@@ -238,10 +238,9 @@ def test_one_directional_neighbours_are_padded_behind_the_abi_and_the_low_level_
     """Two buffers per link are safe only with a hand-shake: a rank that sends to q without receiving from q could run two exchanges ahead of q and overwrite the
     half q still reads (round 4; deterministic in tests/test_gpu_protocol_delays.py).  The 4-rank partition of 'small' has such a link (rank 0 -> rank 3), and its
     halo lists go in VERBATIM: nxs_dyn_set_halo adds the missing direction as an empty segment behind the caller's neighbours, the record form connects all four
-    ranks (handles of ONE process here, mailboxes through plain pointers) and the self-test passes on every link; the low-level nxs_dyn_ipc_connect, whose tables
-    know only the caller's own neighbours, refuses with the rank named and points at the record form."""
+    ranks (handles of ONE process here, mailboxes through plain pointers); the low-level nxs_dyn_ipc_connect, whose tables know only the caller's own neighbours,
+    refuses with the rank named and points at the record form."""
     import ctypes as C
-    import threading
     import numpy as np
     import cases
     from nextsim_amd import _abi, dynamics
@@ -277,13 +276,9 @@ def test_one_directional_neighbours_are_padded_behind_the_abi_and_the_low_level_
     assert fes[0].L.nxs_dyn_ipc_connect_records(fes[0].h, rb, stride, 3) != 0          # the wrong number of ranks
     for fe in fes:
         fe._chk(fe.L.nxs_dyn_ipc_connect_records(fe.h, rb, stride, 4))
-    errs = [C.c_int32(-1) for _ in fes]
-    th = [threading.Thread(target=lambda r=r: fes[r]._chk(fes[r].L.nxs_dyn_ipc_selftest(fes[r].h, 16, C.byref(errs[r])))) for r in range(4)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join()
-    assert [e.value for e in errs] == [0, 0, 0, 0]
+    # (the self-test over these links, the steps and the delays run in tests/test_gpu_protocol_delays.py on this very partition, as 2 processes x 2 ranks: FOUR
+    # handles of one process whose kernels wait for each other exceed the hardware queues a process gets -- two streams share a queue and one's spinning kernel
+    # keeps the other's from starting)
     # records that disagree with this rank's lists are refused: rank 3's record with rank 0 cut out of its receive neighbours
     bad = bytearray(recs)
     head = 3 * stride + dynamics.IPC_BLOB_BYTES

@@ -910,7 +910,8 @@ def test_resident_loop_survives_a_remesh_a_change_of_sub_steps_and_a_second_hand
     a.close(); c.close()
 
 
-@pytest.mark.parametrize("kind,opts,kernel,D", [("small", {"fused": 1}, "k_substep_fused", 1), ("small", {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1}, "k_substep_pair", 2),
+@pytest.mark.parametrize("kind,opts,kernel,D", [("small", {"fused": 1}, "k_substep_fused", 1), ("small", {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "pair_nodes": 64}, "k_substep_pair", 2),
+                                                  ("small", {"fused": 2, "substeps_per_launch": 2, "pair_regs": 1, "pair_nodes": 400}, "k_substep_pair", 2),
                                                   ("small", {"fused": 2, "substeps_per_launch": 4}, "k_substep_multi", 4), ("small", {"fused": 4}, "k_substep_resident", 120)])
 def test_traffic_model_and_step_times(kind, opts, kernel, D):
     """nxs_dyn_get_traffic_model names the kernel the last step ran on and prices a launch from the patch tables: unique <= scheme (the halo rings are the
@@ -931,9 +932,15 @@ def test_traffic_model_and_step_times(kind, opts, kernel, D):
     t = fe.traffic_model()
     assert t["substep_kernel_name"] == kernel and t["substeps_per_launch"] == D and t["halo_in_kernel"] == 0, t
     assert 0 < t["substep_unique_bytes"] <= t["substep_scheme_bytes"], t
-    # second reads: the several-sub-steps kernel always has them; k_substep_pair on one rank only where a patch has a second round of E_1 elements (their constants)
-    assert t["substep_reread_bytes"] > 0 if kernel == "k_substep_multi" else t["substep_reread_bytes"] >= 0, t
-    if kernel not in ("k_substep_pair", "k_substep_multi"): assert t["substep_reread_bytes"] == 0, t
+    # second reads: the several-sub-steps kernel always has them; k_substep_pair on one rank reads again exactly the 48-byte constants of the E_1 elements beyond the
+    # first 512 of their patch (the second element round of sub-step 1; the first round's stay in registers): none in 64-node patches (E_1 ~ 170 elements), some -- whole
+    # records, fewer than the mesh has elements -- in 400-node patches (E_1 ~ 900).  (Round 4 relaxed this to a vacuous ">= 0" after a failure in suite 7 -- the
+    # automatic patch size of 'small' happens to have no second round; profiles/r04_experiments/r4_suite7_traffic_model_assertion.log.)
+    rr = t["substep_reread_bytes"]
+    if kernel == "k_substep_multi": assert rr > 0, t
+    elif kernel == "k_substep_pair" and opts["pair_nodes"] == 64: assert rr == 0, t
+    elif kernel == "k_substep_pair": assert rr > 0 and rr % 48 == 0 and rr / 48 < lm.num_elements, t
+    else: assert rr == 0, t
     Ne, Nn = lm.num_elements, lm.num_nodes
     assert abs(t["survey_model_bytes"] - (172. * Ne + 217. * Nn) * D) < 1.
     assert t["substep_unique_bytes"] >= D * 16. * Nn and t["substep_unique_bytes"] >= 112. * Ne    # at least: every velocity out, state in + out + constants
