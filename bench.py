@@ -678,14 +678,25 @@ def host_description():
 HOST_MEMORY_GBS = {"AMD EPYC 9575F 64-Core Processor": ("2 sockets x 12 channels DDR5-6000", 1152.0)}
 
 
-def cpu_baseline(kind, nsteps=1, nsteps_threaded=3):
+def cpu_pressure():
+    """/proc/pressure/cpu 'some avg10' (percent of the last ten seconds in which some task waited for a CPU), or None: how busy the shared host is beside this run."""
+    try:
+        for line in open("/proc/pressure/cpu"):
+            if line.startswith("some"):
+                return float(line.split("avg10=")[1].split()[0])
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
+def cpu_baseline(kind, nsteps=1, nsteps_threaded=2):
     """The restated reference CPU path (oracle/dyn_ref.c, -O3 -march=native) on the same mesh and forcing.
-    (i) one core, the serial loops (nsteps steps); (ii) the cores this process may run on (sched_getaffinity -- on a GPU box that is the
-    box's CPU share, not necessarily the host's core count; both are printed): one mesh partition per thread, all threads in lock-step
-    inside the oracle library (ref_mr_*: the CPU analogue of the reference's MPI run) -- threads kept across the steps and PINNED (physical cores
-    first, the sockets in turn), every partition's arrays allocated and first touched by its own thread (NUMA-local, like the heap of an MPI rank),
-    spin barriers; nsteps_threaded steps after an untimed one.  Thread counts: every usable logical CPU, then half of that (the physical cores of an
-    SMT-2 host), a quarter, ... while fewer is faster; the best is `value`, all of them are listed.
+    (i) one core, the serial loops (nsteps steps); (ii) the cores this process may run on: one mesh partition per thread, all threads in lock-step inside the oracle
+    library (ref_mr_*: the CPU analogue of the reference's MPI run), threads kept across the steps, every partition's arrays allocated and first touched by its own
+    thread (NUMA-local, like the heap of an MPI rank).  What the host gives depends on how the threads wait and where they sit -- under a CPU quota (cgroup cpu.max: a
+    GPU box shows all the host's CPUs and grants a share of their time) spinning threads burn the quota the working ones need, sleeping ones pay a futex per meeting --,
+    so EVERY combination is timed on the same partitions: thread counts {2 x quota, quota} (every usable CPU and half of it where there is no quota) x barrier {spin,
+    sleep} x {pinned, unpinned}, nsteps_threaded steps each after one untimed step per thread count; `value` is the fastest, the table goes into the line.
     kind 'port': the reference binary itself cannot be built without Boost/Gmsh/NetCDF."""
     from nextsim_amd import forcing as F, mesh as M
     from oracle import pyoracle as O
@@ -699,45 +710,46 @@ def cpu_baseline(kind, nsteps=1, nsteps_threaded=3):
     del r
     host_cores, usable, model = host_description()
     out = {"value": single, "cores": 1, "seconds": dt1, "single_core_value": single, "single_seconds": dt1, "single_steps": nsteps,
-           "host_cores": host_cores, "usable_cores": usable, "cpu_model": model, "threaded_steps": 0, "thread_counts_tried": {}, "placement": None, "cpu_quota_cores": None}
+           "host_cores": host_cores, "usable_cores": usable, "cpu_model": model, "threaded_steps": 0, "thread_counts_tried": {}, "table": [], "placement": None,
+           "cpu_quota_cores": None, "cpu_pressure_some_avg10": {"before": cpu_pressure()}}
     if usable > 1:
         p2, C_fix, C_alea = F.scale_params_to_mesh(F.default_params(), gm, alea_factor=0.33)
         g = F.global_fields(gm, p2, "arctic", C_fix, C_alea)
         quota = cpu_quota()
         out["cpu_quota_cores"] = quota
-        # every usable CPU first -- or, where the container has a CPU quota below that, twice the quota (SMT siblings / a little oversubscription) -- then halves
         top = min(usable, 512) if not quota else max(2, min(usable, 512, int(2 * quota + 0.5)))
-        counts, c = [], top
-        while c >= 2 and (not counts or c >= 8):
-            counts.append(c); c //= 2
+        counts = [c for c in (top, top // 2) if c >= 2]
         best = None
         budget_t0 = time.perf_counter()
         for cores in counts:
             lms = M.localize(gm, cores)
             ranks = [O.OracleRank(l, p2, F.localize_fields(g, l, gm.num_nodes), fast=True) for l in lms]
             ctx = O.MultirankContext(ranks, nthreads=cores, pin=True)   # (every thread copies -- first touches -- its own partition here)
-            info = ctx.info()
             ctx.run(1)                                                   # (untimed: the work arrays are touched by their threads)
-            t0 = time.perf_counter()
-            ctx.run(nsteps_threaded)
-            dtn = time.perf_counter() - t0
+            for barrier, pin in (("sleep", False), ("sleep", True), ("spin", True), ("spin", False)):
+                if time.perf_counter() - budget_t0 > 150.:
+                    break
+                ctx.configure(barrier, pin)
+                info = ctx.info()
+                t0 = time.perf_counter()
+                ctx.run(nsteps_threaded)
+                dtn = time.perf_counter() - t0
+                v = gm.num_elements * p.substeps * nsteps_threaded / dtn
+                out["table"].append({"threads": cores, "barrier": barrier, "pinned": pin, "value": v, "seconds": dtn})
+                key = str(cores)
+                out["thread_counts_tried"][key] = max(out["thread_counts_tried"].get(key, 0.), v)
+                if best is None or v > best[0]:
+                    best = (v, cores, dtn, info, barrier, pin)
             ctx.close(copy_back=False)
-            v = gm.num_elements * p.substeps * nsteps_threaded / dtn
-            out["thread_counts_tried"][str(cores)] = v
             del ranks, ctx
-            if best is None or v > best[0]:
-                best = (v, cores, dtn, info)
-            elif v < 0.9 * best[0]:
-                break                                           # clearly slower with fewer threads: the larger count was the best
-            if time.perf_counter() - budget_t0 > 90.:
-                break
         out["threaded_steps"] = nsteps_threaded
         if best and best[0] > single:
             out.update(value=best[0], cores=best[1], seconds=best[2])
             info = best[3]
-            out["placement"] = {"threads": info["threads"], "pinned": all(c_ >= 0 for c_ in info["cpus"]), "sockets_used": info["sockets_used"],
-                                "distinct_cpus": len(set(info["cpus"])), "first_touch": "every partition's arrays allocated and copied in by its own thread",
-                                "barrier": "sense-reversing spin barrier, 340 per step"}
+            out["placement"] = {"threads": info["threads"], "pinned": best[5], "sockets_used": info["sockets_used"] if best[5] else None,
+                                "distinct_cpus": len(set(info["cpus"])) if best[5] else None, "first_touch": "every partition's arrays allocated and copied in by its own thread",
+                                "barrier": {"spin": "sense-reversing spin barrier", "sleep": "pthread_barrier_t (the waiting threads sleep)"}[best[4]] + ", 340 meetings per step"}
+    out["cpu_pressure_some_avg10"]["after"] = cpu_pressure()
     # SURVEY 8d's 172 B per element + 217 B per node per sub-step: what the figure means as a memory rate, beside the host's nominal bandwidth
     bytes_per_update = (BYTES_PER_ELEMENT * gm.num_elements + BYTES_PER_NODE * gm.num_nodes) / gm.num_elements
     out["model_GBps"] = out["value"] * bytes_per_update / 1e9
@@ -1003,17 +1015,18 @@ def main():
             out["aux_rccl"] = {"status": "failed", "error": repr(e)[:300]}
     if rank == 0 and not args.no_cpu_baseline:   # (at every N: rank 0's host is the same host)
         try:
-            cb = cpu_baseline(args.mesh, 1, 3)
+            cb = cpu_baseline(args.mesh, 1, 2)
             out["cpu_baseline"] = {
                 "value": cb["value"], "unit": "element-updates/s", "cores": cb["cores"], "kind": "port",
                 "single_core_value": cb["single_core_value"],
                 "host_cores": cb["host_cores"], "usable_cores": cb["usable_cores"], "cpu_model": cb["cpu_model"],
                 "sample": f"full dynamics steps ({S} sub-steps each) of the same '{args.mesh}' mesh and forcing, oracle/dyn_ref.c -O3 -march=native: "
-                          f"{cb['single_steps']} step on 1 core ({cb['single_seconds']:.1f} s, single_core_value); {cb['threaded_steps']} steps (after one untimed) with one "
-                          f"mesh partition per PINNED thread in lock-step (threads kept, partitions first touched by their threads, spin barriers, shared-memory halo exchange), at "
-                          f"thread counts {list(cb['thread_counts_tried'])} (this process may run on "
-                          f"{cb['usable_cores']} of the host's {cb['host_cores']} logical CPUs, {cb['cpu_model']}; every usable CPU is tried first, fewer while that is not slower): "
-                          f"the best, {cb['cores']} thread(s), is `value` ({cb['seconds']:.1f} s)",
+                          f"{cb['single_steps']} step on 1 core ({cb['single_seconds']:.1f} s, single_core_value); {cb['threaded_steps']} steps (after one untimed per thread count) with "
+                          f"one mesh partition per thread in lock-step (threads kept, partitions first touched by their threads, shared-memory halo exchange), timed in EVERY "
+                          f"combination of thread count {list(cb['thread_counts_tried'])} x barrier (spin / sleeping) x (pinned / unpinned) -- `table` -- on a host where this process "
+                          f"may run on {cb['usable_cores']} of {cb['host_cores']} logical CPUs ({cb['cpu_model']}) within a quota of {cb.get('cpu_quota_cores')} CPUs' time: "
+                          f"the fastest, {cb['cores']} thread(s), is `value` ({cb['seconds']:.1f} s)",
+                "table": cb["table"], "cpu_pressure_some_avg10": cb["cpu_pressure_some_avg10"],
                 "thread_counts_tried": cb["thread_counts_tried"], "placement": cb["placement"], "cpu_quota_cores": cb.get("cpu_quota_cores"),
                 "model_GBps": cb["model_GBps"], "host_memory": cb["host_memory"],
             }

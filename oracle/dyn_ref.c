@@ -1219,6 +1219,11 @@ struct ref_mr_ctx {
     const nxs_dyn_mesh **pm; nxs_dyn_state **ps; const nxs_dyn_forcing **pf; ref_work **pw; const nxs_dyn_halo **ph;
     pthread_t *th;
     int *cpu_of;                   /* [nthreads] the CPU thread t is pinned to, -1: not pinned */
+    int *cpu_plan;                 /* [nthreads] the CPU thread t WOULD be pinned to (ref_mr_configure switches pinning on and off between runs) */
+    cpu_set_t all_cpus;            /* the affinity mask the process came with (what an unpinned thread runs on) */
+    int barrier_kind;              /* 0: sense-reversing spin barrier; 1: pthread_barrier_t (futex: the waiting threads sleep -- under a CPU quota spinning burns the
+                                    * quota the working threads need, round 4: 16 pinned spinning threads 1.8e8 against 2.85e8 for round 3's sleeping ones) */
+    pthread_barrier_t pbar;
     int sockets_used, physical_cores_used;
     /* command hand-off (idle threads sleep on the condition variable; inside a run they meet at the spin barrier) */
     pthread_mutex_t mu; pthread_cond_t cv_go, cv_done;
@@ -1230,6 +1235,7 @@ typedef struct ref_mr_ctx ref_mr_ctx;
 typedef struct ref_mr_targ { ref_mr_ctx *c; int tid; } ref_mr_targ;
 
 static void mr_spin_barrier(ref_mr_ctx *c, int *local_sense) {
+    if (c->barrier_kind == 1) { pthread_barrier_wait(&c->pbar); return; }
     const int sense = !*local_sense;
     *local_sense = sense;
     if (atomic_fetch_add_explicit(&c->bar_count, 1, memory_order_acq_rel) == c->nthreads - 1) {
@@ -1359,6 +1365,12 @@ static void *mr_ctx_thread(void *arg_) {
         const int cmd = c->command, nsteps = c->nsteps;
         pthread_mutex_unlock(&c->mu);
         int bad = 0;
+        if (cmd == 5) {   /* ref_mr_configure: pinned to the planned CPU, or free on the process's mask */
+            cpu_set_t set;
+            CPU_ZERO(&set);
+            if (c->pin && c->cpu_plan[tid] >= 0) CPU_SET(c->cpu_plan[tid], &set); else set = c->all_cpus;
+            c->cpu_of[tid] = (pthread_setaffinity_np(pthread_self(), sizeof set, &set) == 0 && c->pin) ? c->cpu_plan[tid] : -1;
+        }
         if (cmd == 1) { for (int r = tid; r < c->nranks; r += c->nthreads) bad |= mr_copy_in(c, r); }
         else if (cmd == 2) mr_run_steps(c, tid, nsteps);
         else if (cmd == 3) { for (int r = tid; r < c->nranks; r += c->nthreads) mr_copy_back(c, r); }
@@ -1433,11 +1445,14 @@ ref_mr_ctx *ref_mr_create(int nranks, const nxs_dyn_mesh *const *m, const nxs_dy
     c->ph = (const nxs_dyn_halo **)calloc((size_t)nranks, sizeof(void *));
     c->th = (pthread_t *)calloc((size_t)nthreads, sizeof(pthread_t));
     c->cpu_of = (int *)malloc((size_t)nthreads * sizeof(int));
+    c->cpu_plan = (int *)malloc((size_t)nthreads * sizeof(int));
+    CPU_ZERO(&c->all_cpus);
+    if (sched_getaffinity(0, sizeof c->all_cpus, &c->all_cpus) != 0) for (int i = 0; i < CPU_SETSIZE; i++) CPU_SET(i, &c->all_cpus);
     ref_mr_job *J = &c->job;
     J->nranks = nranks; J->nthreads = nthreads;
     J->sendbuf = (double **)calloc((size_t)nranks, sizeof(double *));
     J->peer_seg = (int **)calloc((size_t)nranks, sizeof(int *));
-    int ok = c->rk && c->pm && c->ps && c->pf && c->pw && c->ph && c->th && c->cpu_of && J->sendbuf && J->peer_seg;
+    int ok = c->rk && c->pm && c->ps && c->pf && c->pw && c->ph && c->th && c->cpu_of && c->cpu_plan && J->sendbuf && J->peer_seg;
     for (int r = 0; r < nranks && ok; r++) {   /* who sends what to whom: checked on the caller's lists, as in ref_multirank_steps */
         const nxs_dyn_halo *hr = h[r];
         const int nr = hr->num_recv_procs;
@@ -1453,17 +1468,19 @@ ref_mr_ctx *ref_mr_create(int nranks, const nxs_dyn_mesh *const *m, const nxs_dy
         }
     }
     if (ok) {
-        for (int t = 0; t < nthreads; t++) c->cpu_of[t] = -1;
-        if (pin) {
+        for (int t = 0; t < nthreads; t++) { c->cpu_of[t] = -1; c->cpu_plan[t] = -1; }
+        {
             int *order = (int *)malloc(sizeof(int) * CPU_SETSIZE), *sock = (int *)malloc(sizeof(int) * CPU_SETSIZE);
             const int n = (order && sock) ? mr_cpu_order(order, CPU_SETSIZE, sock) : 0;
             int seen_sock[64] = {0};
             for (int t = 0; t < nthreads && n > 0; t++) {
-                c->cpu_of[t] = order[t % n];
+                c->cpu_plan[t] = order[t % n];
+                if (pin) c->cpu_of[t] = c->cpu_plan[t];
                 if (t < n && sock[t] >= 0 && sock[t] < 64 && !seen_sock[sock[t]]) { seen_sock[sock[t]] = 1; c->sockets_used++; }
             }
             free(order); free(sock);
         }
+        pthread_barrier_init(&c->pbar, NULL, (unsigned)nthreads);
         pthread_mutex_init(&c->mu, NULL); pthread_cond_init(&c->cv_go, NULL); pthread_cond_init(&c->cv_done, NULL);
         atomic_init(&c->bar_count, 0); atomic_init(&c->bar_sense, 0);
         int started = 0;
@@ -1490,6 +1507,16 @@ ref_mr_ctx *ref_mr_create(int nranks, const nxs_dyn_mesh *const *m, const nxs_dy
     return c;
 }
 
+/* between runs: the barrier the phases meet at (0 spin, 1 sleeping) and whether the threads are pinned -- the same partitions, first touched as they were, so that
+ * bench.py can time every combination on ONE context and report the best the host gives */
+int ref_mr_configure(ref_mr_ctx *c, int barrier_kind, int pin) {
+    if (!c || c->nthreads < 1 || barrier_kind < 0 || barrier_kind > 1) return -1;
+    c->barrier_kind = barrier_kind;
+    c->pin = pin ? 1 : 0;
+    mr_command(c, 5, 0);
+    return 0;
+}
+
 int ref_mr_run(ref_mr_ctx *c, int nsteps) {
     if (!c || nsteps < 0 || c->nthreads < 1) return -1;
     mr_command(c, 2, nsteps);
@@ -1512,6 +1539,7 @@ void ref_mr_destroy(ref_mr_ctx *c, int copy_back) {
         mr_command(c, 4, 0);
         for (int t = 0; t < c->nthreads; t++) pthread_join(c->th[t], NULL);
         pthread_mutex_destroy(&c->mu); pthread_cond_destroy(&c->cv_go); pthread_cond_destroy(&c->cv_done);
+        pthread_barrier_destroy(&c->pbar);
     }
     for (int r = 0; c->rk && r < c->nranks; r++) {
         for (int i = 0; i < c->rk[r].n_owned; i++) free(c->rk[r].owned[i]);
@@ -1521,6 +1549,6 @@ void ref_mr_destroy(ref_mr_ctx *c, int copy_back) {
         if (c->job.peer_seg) free(c->job.peer_seg[r]);
     }
     free(c->job.sendbuf); free(c->job.peer_seg);
-    free(c->rk); free(c->pm); free(c->ps); free(c->pf); free(c->pw); free(c->ph); free(c->th); free(c->cpu_of);
+    free(c->rk); free(c->pm); free(c->ps); free(c->pf); free(c->pw); free(c->ph); free(c->th); free(c->cpu_of); free(c->cpu_plan);
     free(c);
 }

@@ -112,6 +112,7 @@ int ref_multirank_steps(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_
 typedef struct ref_mr_ctx ref_mr_ctx;
 ref_mr_ctx *ref_mr_create(int nranks, const nxs_dyn_mesh *const *m, const nxs_dyn_params *p, nxs_dyn_state *const *s, const nxs_dyn_forcing *const *f,
                           const nxs_dyn_halo *const *h, int nthreads, int pin);
+int ref_mr_configure(ref_mr_ctx *c, int barrier_kind /* 0 spin, 1 sleeping (pthread_barrier_t) */, int pin);   /* between runs */
 int ref_mr_run(ref_mr_ctx *c, int nsteps);
 int ref_mr_info(const ref_mr_ctx *c, int *nthreads, int *sockets_used, int *cpus, int cap);
 void ref_mr_destroy(ref_mr_ctx *c, int copy_back);

@@ -377,6 +377,13 @@ class MultirankContext:
         if self.L.ref_mr_run(self.ctx, nsteps) != 0:
             raise RuntimeError("ref_mr_run failed")
 
+    def configure(self, barrier: str = "spin", pin: bool = True):
+        """Between runs: the barrier the phases meet at ("spin": sense-reversing spin barrier; "sleep": pthread_barrier_t, the waiting threads sleep) and whether
+        the threads are pinned -- the same partitions, first touched as they were."""
+        self.L.ref_mr_configure.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        if self.L.ref_mr_configure(self.ctx, {"spin": 0, "sleep": 1}[barrier], 1 if pin else 0) != 0:
+            raise RuntimeError("ref_mr_configure failed")
+
     def info(self) -> dict:
         nt, so = C.c_int(), C.c_int()
         cpus = (C.c_int * 1024)()

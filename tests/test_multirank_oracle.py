@@ -124,3 +124,22 @@ def test_persistent_pinned_context_equals_the_phase_by_phase_driver(kind, nparts
     for ra, rb in zip(a, b):
         for k in KEYS_N + KEYS_E:
             assert np.array_equal(ra.arr[k], rb.arr[k]), (ra.lm.rank, k)
+
+
+def test_every_barrier_and_pinning_of_the_cpu_baseline_gives_the_same_bits():
+    """bench.py's cpu_baseline times ONE context in every combination of barrier (spin / sleeping) and pinning (ref_mr_configure between the runs) and reports the
+    fastest: four steps, one per combination, equal four steps of the phase-by-phase driver bit for bit; the info says what the threads are pinned to."""
+    gm, p, g, lms, fields = cases.make_case("small", nparts=4, ragged_seed=5)
+    a = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    b = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
+    for _ in range(4):
+        O.multirank_step(a)
+    ctx = O.MultirankContext(b, nthreads=3, pin=True)
+    for barrier, pin in (("sleep", False), ("sleep", True), ("spin", True), ("spin", False)):
+        ctx.configure(barrier, pin)
+        assert all((c >= 0) == pin for c in ctx.info()["cpus"])
+        ctx.run(1)
+    ctx.close()
+    for ra, rb in zip(a, b):
+        for k in KEYS_N + KEYS_E:
+            assert np.array_equal(ra.arr[k], rb.arr[k]), (ra.lm.rank, k)
