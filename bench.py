@@ -719,6 +719,8 @@ def cpu_baseline(kind, nsteps=1, nsteps_threaded=2):
         out["cpu_quota_cores"] = quota
         top = min(usable, 512) if not quota else max(2, min(usable, 512, int(2 * quota + 0.5)))
         counts = [c for c in (top, top // 2) if c >= 2]
+        if quota and 4 * quota <= usable:
+            counts.append(int(4 * quota + 0.5))   # (sleeping, unpinned only: waiting threads cost no quota, smaller partitions balance the lock-step better)
         best = None
         budget_t0 = time.perf_counter()
         for cores in counts:
@@ -726,7 +728,7 @@ def cpu_baseline(kind, nsteps=1, nsteps_threaded=2):
             ranks = [O.OracleRank(l, p2, F.localize_fields(g, l, gm.num_nodes), fast=True) for l in lms]
             ctx = O.MultirankContext(ranks, nthreads=cores, pin=True)   # (every thread copies -- first touches -- its own partition here)
             ctx.run(1)                                                   # (untimed: the work arrays are touched by their threads)
-            for barrier, pin in (("sleep", False), ("sleep", True), ("spin", True), ("spin", False)):
+            for barrier, pin in ((("sleep", False),) if (quota and cores > 2 * quota + 0.5) else (("sleep", False), ("sleep", True), ("spin", True), ("spin", False))):
                 if time.perf_counter() - budget_t0 > 150.:
                     break
                 ctx.configure(barrier, pin)
