@@ -153,6 +153,11 @@ def run_gpu(kind, args, rank, world, local_rank, dist, torch, unique_id_fn, stat
     fe.set_mesh(lm)
     if os.environ.get("NXS_BENCH_PATCH_NODES"):   # rehearsals: e.g. two ranks of 91 k triangles with the 180-node patches a rank of eight has
         fe.set_option("patch_nodes", int(os.environ["NXS_BENCH_PATCH_NODES"]))
+    if os.environ.get("NXS_BENCH_OPTIONS"):       # experiments (e.g. "pair_nodes=416" on a mesh numbered in tiles of 416 nodes): key=value,... ; they go to the counter passes too
+        fe._bench_options = dict(getattr(fe, "_bench_options", {}))
+        for kv in os.environ["NXS_BENCH_OPTIONS"].split(","):
+            k, v = kv.split("=")
+            fe.set_option(k, int(v)); fe._bench_options[k] = int(v)
     transport = "none"
     halo = {"transport": "none"}
     if world > 1:
