@@ -1169,11 +1169,18 @@ def test_partial_state_transfers():
     a.close(); b.close(); c.close()
 
 
-def test_pin_host_option_changes_nothing_but_the_copies():
+@pytest.mark.parametrize("over", [{}, {"ice_cat_type": 1}, {"dynamics_type": 3}])
+def test_pin_host_option_changes_nothing_but_the_copies(over):
+    """nxs_dyn_step_host with page-locked vectors moves what the kernels do not need yet / any more on a second stream beside them (round 5: the arrays only update()
+    reads go up while the sub-steps run, M_VT / M_UM / M_UT come down while update() runs, an unused young-ice trio does not come down at all): the same bits as the
+    plain put + set_forcing + step + get sequence, with and without the young-ice category (whose arrays are then needed FIRST, by prep), BBM and EVP."""
     import ctypes as C
     from nextsim_amd import _abi, dynamics
-    gm, p, g, lms, fields = cases.make_case("small")
+    gm, p, g, lms, fields = cases.make_case("small", **over)
     lm = lms[0]
+    if over.get("ice_cat_type"):   # a young-ice category that holds something
+        rng = np.random.default_rng(3)
+        fields[0]["conc_young"] = 0.05 * rng.random(lm.num_elements); fields[0]["h_young"] = 0.1 * rng.random(lm.num_elements); fields[0]["hs_young"] = 0.01 * rng.random(lm.num_elements)
     out = []
     for pin in (0, 1):
         f = {k: v.copy() for k, v in fields[0].items()}
