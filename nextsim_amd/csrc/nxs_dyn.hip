@@ -2680,18 +2680,24 @@ int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing
     std::vector<Cp> ytrio = {{d.cyoung, s->conc_young, ne}, {d.hyoung, s->h_young, ne}, {d.hsyoung, s->hs_young, ne}, {d.drag_ui_young, H(s->drag_ui_young), ne}};
     (young ? early : late).insert((young ? early : late).end(), ytrio.begin(), ytrio.end());
     for (auto *set : {&early, &late}) for (const Cp &c : *set) pin_host_buffer(h, c.host, c.bytes);
-    // (the kernels of the step before may still read the late arrays: the copy stream starts behind everything enqueued so far)
-    HIPCHK(h, hipEventRecord(h->ev_solved, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_solved, 0));
+    static const bool dbg = getenv("NXS_DEBUG_STEP_HOST") != nullptr;
+    hipEvent_t te[7] = {};
+    if (dbg) { for (auto &e : te) (void)hipEventCreate(&e); (void)hipEventRecord(te[0], h->stream); }
     h->sig_loc = 0;   // M_sigma and M_damage arrive as arrays (all four: nothing of the records is kept)
     for (const Cp &c : early) HIPCHK(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->stream));
+    // the late copies start BEHIND the early ones (both directions of a link are one copy engine each: side by side they would only delay what the kernels wait
+    // for) -- and so behind every kernel of the step before, which may still read those arrays
+    HIPCHK(h, hipEventRecord(h->ev_solved, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_solved, 0));
     for (const Cp &c : late) HIPCHK(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->copy_stream));
     HIPCHK(h, hipEventRecord(h->ev_late, h->copy_stream));
+    if (dbg) { (void)hipEventRecord(te[1], h->stream); (void)hipEventRecord(te[2], h->copy_stream); }
     h->have_state = true; h->have_forcing = true;
     h->wait_before_update = h->ev_late; h->record_after_solve = h->ev_solved;
     rc = nxs_dyn_step(h);
     h->wait_before_update = nullptr; h->record_after_solve = nullptr;
     if (rc) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); return rc; }
+    if (dbg) (void)hipEventRecord(te[3], h->stream);
     HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_solved, 0));
     for (const Cp &c : {Cp{d.VT, s->VT, n2}, Cp{d.UM, s->UM, n2}, Cp{d.UT, s->UT, n2}}) HIPCHK(h, hipMemcpyAsync(c.host, c.dev, c.bytes, hipMemcpyDeviceToHost, h->copy_stream));
     if (h->res_ready || h->flow_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); if ((rc = resident_error(h))) { (void)hipStreamSynchronize(h->copy_stream); return rc; } }
@@ -2700,8 +2706,15 @@ int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing
                             {d.s0, s->sigma[0], ne}, {d.s1, s->sigma[1], ne}, {d.s2, s->sigma[2], ne}, {d.cmyi, s->conc_myi, ne}, {d.tmyi, s->thick_myi, ne}};
     if (young) down.insert(down.end(), ytrio.begin(), ytrio.begin() + 3);
     for (const Cp &c : down) HIPCHK(h, hipMemcpyAsync(c.host, c.dev, c.bytes, hipMemcpyDeviceToHost, h->stream));
+    if (dbg) { (void)hipEventRecord(te[4], h->copy_stream); (void)hipEventRecord(te[5], h->stream); }
     HIPCHK(h, hipStreamSynchronize(h->copy_stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (dbg) {
+        float ms[6] = {};
+        for (int i = 1; i <= 5; ++i) (void)hipEventElapsedTime(&ms[i], te[0], te[i]);
+        fprintf(stderr, "[nxs] step_host: early uploads done %.2f ms, late uploads done %.2f, step done %.2f, nodal downloads done %.2f, all downloads done %.2f\n", ms[1], ms[2], ms[3], ms[4], ms[5]);
+        for (auto &e : te) (void)hipEventDestroy(e);
+    }
     return NXS_OK;
 } catch (...) { return dyn_caught(h, "nxs_dyn_step_host"); }
 
