@@ -460,6 +460,10 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  default 0: with fused != 0 the step writes its records only
  *   "halo_fused"   device-direct transport only: 1 = updateGhosts inside the fused sub-step kernel (default),
  *                  0 = separate push / pull kernels
+ *   "smooth_persist"  several ranks, device-direct mailboxes with the exchange inside the kernels: the 50 sweeps of the open-water smoother (FE.cpp:10578-10611) as ONE launch
+ *                  of at most 128 persistent workgroups that meet at a barrier of their own between the sweeps (k_smooth_persist) instead of 50 launches of one sweep each
+ *                  (0.12-0.16 ms per step saved on a rank of eight; a rank without ice-free own nodes whose exchanged nodes cannot change is done after one sweep); the same
+ *                  bits.  -1 (default) / 1 = on, 0 = one launch per sweep
  *   "ipc_pad"      before nxs_dyn_ipc_export: the mailbox gets room for at least this many received nodes (profiling aid: a rank whose mailbox is connected
  *                  to itself stores its own, possibly longer, send segments into it)
  *   "ipc_delay", "halo_one_directional"   test doors of the exchange protocols, see NXS_DELAY_* above */

@@ -210,6 +210,7 @@ struct nxs_dyn_handle {
     int pin_host = 0;                      // option "pin_host": page-lock the caller's state / forcing vectors on first use
     std::map<const void *, size_t> pinned; // what this handle has registered with hipHostRegister
     int halo_fused = 1;                    // option "halo_fused"
+    int smooth_persist = -1;               // option "smooth_persist": the 50 sweeps with the exchange inside as ONE launch of persistent workgroups (k_smooth_persist): -1 / 1 = on, 0 = 50 launches of k_smooth_halo
     bool hf_ready = false;
     HaloFused *d_hf = nullptr;  // device copy of hf with the mailbox addresses filled in (what k_substep_fused<.., HALO> reads)
     bool d_hf_dirty = true;
@@ -756,6 +757,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         h->d_hf_dirty = true; release_graph(h);
         return NXS_OK;
     }
+    if (!std::strcmp(key, "smooth_persist")) { h->smooth_persist = (int)value; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_one_directional")) { h->one_directional = value != 0; return NXS_OK; }   // test door: before nxs_dyn_set_halo
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
@@ -1967,8 +1969,8 @@ int build_halo_fused(nxs_dyn_handle *h) {
     if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_srl, plan.gsrl))) return rc;
     if ((rc = dev_upload(h, h->hf_allocs, &f.ghost_k, plan.gk))) return rc;
     unsigned int *ctr = nullptr;
-    if ((rc = dev_alloc(h, h->hf_allocs, &ctr, 32 * 17))) return rc;
-    HIPCHK(h, hipMemsetAsync(ctr, 0, 32 * 17 * sizeof(unsigned int), h->stream));
+    if ((rc = dev_alloc(h, h->hf_allocs, &ctr, 32 * 19))) return rc;   // [0] and [32 (g + 1)]: two-level tickets; [32 * 17]: the generation word of k_smooth_persist's barrier
+    HIPCHK(h, hipMemsetAsync(ctr, 0, 32 * 19 * sizeof(unsigned int), h->stream));
     f.done_all = ctr;
     if ((rc = dev_upload(h, h->hf_allocs, &f.send_block_rank, plan.send_block_rank))) return rc;  // k_smooth_halo: which blocks store into a mailbox
     f.n_send_blocks = plan.n_send_blocks;
@@ -2411,6 +2413,16 @@ int explicit_solve(nxs_dyn_handle *h) {
             if (ts > 0) LAUNCH(h, k_smooth_static, ts, ts, h->d_send_index, h->d_send_seg, m, h->dw, h->ipc.my_static);
         }
         static_assert(NXS_SMOOTH_SWEEPS == 50, "Q9: FE.cpp:10580 hard-codes 50 sweeps");
+        if (halo_in_kernel && h->smooth_persist != 0) {   // all 50 sweeps in ONE launch of persistent workgroups (k_smooth_persist); the result is back in `a` (50 is even)
+            HaloFused hf = h->hf;
+            hf.ipc = h->ipc;
+            const int nblk = nblocks(m.No), G = std::min(nblk, 128);
+            hipLaunchKernelGGL(k_smooth_persist, dim3(G), dim3(BLOCK), 0, h->stream, m, h->dw, a, b, hf, nblk);
+            const int tr = h->recv_offsets[h->recv_procs.size()];
+            hipLaunchKernelGGL(k_smooth_pull, dim3(nblocks(tr)), dim3(BLOCK), 0, h->stream, a, m.Nn, tr, h->d_recv_index, h->d_recv_seg, h->d_recv_off, h->ipc);
+            LAUNCH(h, k_ow_tail, m.Nn, m, h->ds, h->dw, h->dp);
+            return NXS_OK;
+        }
         for (int nit = 0; nit < 50; ++nit) {
             if (halo_in_kernel) {  // updateGhosts inside the sweep; the ghosts land in the array once, after the last sweep
                 HaloFused hf = h->hf;

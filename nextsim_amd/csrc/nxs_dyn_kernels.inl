@@ -1079,6 +1079,12 @@ struct IpcDev {
     unsigned delay;                 // test door "ipc_delay" (include/nxs_dyn.h): point << 8 | units of 10 us, set on ONE rank; 0 (always, outside the protocol tests) = none
 };
 #define NXS_SMOOTH_SWEEPS 50  // FE.cpp:10580 (Q9: hard-coded in the reference)
+// the one release in front of a sub-step's flags in the resident loops (an experiment build may leave it out to price it: scripts)
+#ifdef NXS_EXP_NOFENCE
+#define NXS_RESIDENT_RELEASE() do { } while (0)
+#else
+#define NXS_RESIDENT_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "")
+#endif
 
 // Test door "ipc_delay": the named rank sleeps here when `point` is the named point -- a deterministic widening of one window of the exchange protocols, so that an
 // ordering the protocol does not enforce shows as wrong bits instead of depending on who wins a race of a few microseconds (tests/test_gpu_protocol_delays.py).
@@ -2363,8 +2369,12 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
         const DevParams &p = *pl;
 #ifdef NXS_PHASE_TIMING
 #define RSTAMP(k) do { if (ss == 60 && threadIdx.x == 0 && blk < 8192 && r.rank == 0) g_phase_t[8 * blk + (k)] = wall_clock64(); } while (0)
+#define RSTAMP_ANY(k) do { if (ss == 60 && blk < 8192 && r.rank == 0) g_phase_t[8 * blk + (k)] = wall_clock64(); } while (0)   /* by whichever thread executes it */
+#define RSTAMP_PUB(k) do { if (ss == 60 && r.rank == 0) g_phase_t[8 * 8191 + (k)] = wall_clock64(); } while (0)   /* the publishing patch of the sub-step: row 8191 */
 #else
 #define RSTAMP(k) do { } while (0)
+#define RSTAMP_ANY(k) do { } while (0)
+#define RSTAMP_PUB(k) do { } while (0)
 #endif
         RSTAMP(0);
         // ---- element phase (FE.cpp:4137-4260 / 10649-10726 + the element half of 10445-10467)
@@ -2468,6 +2478,7 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
             // the last boundary patch to finish this sub-step publishes it to the neighbour ranks -- in sub-step order: patches far
             // apart may be several sub-steps apart, so the one that completes sub-step ss waits for ss - 1 to have been published
             if (atomicAdd(r.cnt + ss, 1u) == (unsigned)n_boundary - 1u) {
+                RSTAMP_PUB(1);   // (the last boundary patch of the sub-step: its ticket is back)
                 const long long t0 = wall_clock64();
                 while (__hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ss) {
                     __builtin_amdgcn_s_sleep(1);
@@ -2476,11 +2487,12 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
                 nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
                 // the one release of the sub-step -- a RELEASE only: __threadfence_system() is an acquire as well, i.e. it also invalidates this
                 // XCD's L2, and every patch on the XCD then re-reads its element constants from memory instead of the L2, every sub-step
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                NXS_RESIDENT_RELEASE();
                 for (int k = 0; k < hfp->ipc.ns; ++k)
                     __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (ss == S - 1) *hfp->ipc.seq_push = x0 + (unsigned long long)S;
                 __hip_atomic_store(r.raised, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                RSTAMP_PUB(2);   // (... its flags are stored)
             }
         }
         if (ss == S - 1) break;
@@ -2498,6 +2510,7 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
                 if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 7); break; }  // 10 s: the transport's bound (a neighbour rank may start its step late: output, a regrid, host thermodynamics)
             }
+            if (k == 0) RSTAMP_ANY(6);   // (phase microscope: this patch has seen neighbour rank 0's flag)
         }
         int nb = nbr;
         asm volatile("" : "+v"(nb));  // (its counter's address is formed here, not kept across the loop)
@@ -2857,7 +2870,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
                 }
                 nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+                NXS_RESIDENT_RELEASE();
                 for (int k = 0; k < hfp->ipc.ns; ++k)
                     __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (ss == S - 1) *hfp->ipc.seq_push = x0 + (unsigned long long)S;
@@ -3369,6 +3382,138 @@ __global__ void __launch_bounds__(BLOCK) k_smooth_halo(DevMesh m, DevWork w, con
                 __hip_atomic_store(ipc.peer_sflag[k], 64ull * E + (unsigned long long)sweep + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(hf.done_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+// ALL 50 sweeps with updateGhosts inside in ONE launch (round 5).  Fifty launches of k_smooth_halo cost a rank 0.12-0.16 ms per step -- 10-13 % of a
+// rank of eight's step -- although most of them find nothing to do: a launch that returns at once still takes its 2.4 us in the graph.  Here G PERSISTENT workgroups (at
+// most 128: all resident whatever else shares the device) walk the rank's blocks of BLOCK own nodes sweep after sweep -- workgroup p takes the blocks p, p + G, ... --
+// and meet at a barrier of their own between the sweeps (two-level tickets, a generation word; what a sweep stores for the other workgroups is written through and read
+// past the L1: the guide's drained-sc1 hand-off).  The exchange between RANKS is k_smooth_halo's, statement for statement: the workgroup whose ticket completes sweep j
+// raises the flags for it (that workgroup cannot reach the ticket of sweep j + 1 before it has done so: the flags count upwards), blocks with an ice-free node wait for
+// the neighbours' sweep j - 1 before they read a ghost.  A rank without an ice-free own node whose directions are all static is done after sweep 0.  Same operations on
+// the same values in the same (bamg row) order: the same bits as 50 launches.
+__global__ void __launch_bounds__(BLOCK) k_smooth_persist(DevMesh m, DevWork w, double *__restrict__ bufA, double *__restrict__ bufB, HaloFused hf, int nblk) {
+    const IpcDev &ipc = hf.ipc;
+    const int Nn = m.Nn, No = m.No, G = (int)gridDim.x, pid = (int)blockIdx.x, t = (int)threadIdx.x;
+    const unsigned long long E = *ipc.epoch;
+    unsigned int *gen = hf.done_all + 32u * 17u;
+    const unsigned g0 = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (read before this workgroup's first ticket: nobody can have raised it yet)
+    bool any_dynamic = false;
+    for (int k = 0; k < ipc.ns; ++k) any_dynamic |= !ipc.my_static[k];
+    int mine_open = 0, rank_open = 0;
+    for (int b = t; b < nblk; b += BLOCK) { const int o = w.open_blk[b] != 0; rank_open |= o; if (b % G == pid) mine_open |= o; }
+    rank_open = __syncthreads_or(rank_open);
+    mine_open = __syncthreads_or(mine_open);
+    const int sweeps = (rank_open || any_dynamic) ? NXS_SMOOTH_SWEEPS : 1;
+    __shared__ int s_err;
+    if (t == 0) s_err = 0;
+    __syncthreads();
+    // the neighbours' sweep `want - 1` has landed (flags >= 64 E + want) for every direction that still matters; the scribe notes what the neighbours said about theirs
+    auto wait_peers = [&](const int sweep, const bool scribe) {
+        if (t == 0) {
+            const long long t0 = wall_clock64();
+            bool ok = true;
+            for (int k = 0; k < ipc.nr && ok; ++k) {
+                if (sweep >= 2 && __hip_atomic_load(ipc.peer_static + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;  // its values are in slot 0 for good
+                while (__hip_atomic_load(ipc.sflags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < 64ull * E + (unsigned long long)sweep) {
+                    __builtin_amdgcn_s_sleep(4);
+                    if (__hip_atomic_load(ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }
+                    if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(ipc.error, 4); break; }  // 10 s
+                }
+            }
+            if (scribe && ok)
+                for (int k = 0; k < ipc.nr; ++k)
+                    __hip_atomic_store(ipc.peer_static + k, (int)(__hip_atomic_load(ipc.sstatic + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == ((E << 1) | 1ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!ok) s_err = 1;
+            nxs_delay_at(ipc.delay, NXS_DELAY_SMOOTH_READ);
+        }
+        __syncthreads();
+    };
+    for (int sweep = 0; sweep < sweeps; ++sweep) {
+        const double *src = (sweep & 1) ? bufB : bufA;
+        double *dst = (sweep & 1) ? bufA : bufB;
+        const bool scribe = sweep == 1 && pid == 0;
+        if (sweep >= 1 && (mine_open || scribe)) wait_peers(sweep, scribe);
+        if (s_err) break;
+        const bool publishing = sweep == 0 || any_dynamic;
+        if (publishing) nxs_delay_at(ipc.delay, NXS_DELAY_SMOOTH_STORE);
+        for (int b = pid; b < nblk; b += G) {
+            const bool has_open = w.open_blk[b] != 0, publisher = publishing && hf.send_block_rank[b] >= 0;
+            if (!has_open && !publisher) continue;
+            const int n = b * BLOCK + t;
+            if (n >= No) continue;
+            // (sweeps >= 1 read what other workgroups of this launch have written: past the L1)
+            double u = sweep ? ld_agent(src + n) : src[n], v = sweep ? ld_agent(src + n + Nn) : src[n + Nn];
+            if (has_open && !((m.nflags[n] & NF_DIRICHLET) || w.node_mass[n] != 0.)) {
+                u = 0.; v = 0.;
+                const int num_neighbours = m.n2n_cnt[n];
+                for (int j = 0; j < num_neighbours; ++j) {  // Q8: bamg row order
+                    const int nni = m.n2n[(size_t)j * Nn + n];
+                    if (sweep >= 1 && nni >= No) {
+                        const int slot = (sweep >= 2 && __hip_atomic_load(ipc.peer_static + hf.ghost_k[nni - No], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 0 : sweep - 1;
+                        const double *g = ipc.smb + (size_t)slot * 2 * (size_t)ipc.tr + hf.ghost_off[nni - No];
+                        u += sys_load(g);
+                        v += sys_load(g + hf.ghost_srl[nni - No]);
+                    } else if (sweep) {
+                        u += ld_agent(src + nni);
+                        v += ld_agent(src + nni + Nn);
+                    } else {
+                        u += src[nni];
+                        v += src[nni + Nn];
+                    }
+                }
+                u /= num_neighbours;
+                v /= num_neighbours;
+                st_agent(dst + n, u);
+                st_agent(dst + n + Nn, v);
+            }
+            if (publisher)
+                for (int q = hf.send_ptr[n]; q < hf.send_ptr[n + 1]; ++q) {
+                    const int k = hf.send_k[q];
+                    if (sweep >= 1 && ipc.my_static[k]) continue;  // slot 0 already holds this value, and the neighbour knows
+                    double *d = ipc.peer_smb[k] + (long long)sweep * ipc.peer_parity_stride[k] + hf.send_pos[q];
+                    sys_store(d, u);
+                    sys_store(d + (hf.send_off[k + 1] - hf.send_off[k]), v);
+                }
+        }
+        // the sweep's barrier: every wave drains its stores, the workgroup's barrier collects the waves, one lane takes the ticket (two-level: 16 group counters, then one)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) {
+            const unsigned want = g0 + (unsigned)sweep + 1u;
+            const unsigned int total = (unsigned)G, g = (unsigned)pid % 16u, members = (total - g + 15u) / 16u;
+            bool last = false;
+            if (__hip_atomic_fetch_add(hf.done_all + 32u * (g + 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1u) {
+                __hip_atomic_store(hf.done_all + 32u * (g + 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int groups = total < 16u ? total : 16u;
+                last = __hip_atomic_fetch_add(hf.done_all, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == groups - 1u;
+            }
+            if (last) {
+                __hip_atomic_store(hf.done_all, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(gen, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this rank's workgroups go on; the flags for the neighbour ranks follow
+                if (publishing) {
+                    nxs_delay_at(ipc.delay, NXS_DELAY_SMOOTH_FLAG);
+                    if (sweep == 0)
+                        for (int k = 0; k < ipc.ns; ++k)
+                            __hip_atomic_store(ipc.peer_sstatic[k], (E << 1) | (unsigned long long)(ipc.my_static[k] != 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    __threadfence_system();  // the one release of the sweep: data and words before the flags
+                    for (int k = 0; k < ipc.ns; ++k)
+                        if (sweep == 0 || !ipc.my_static[k])
+                            __hip_atomic_store(ipc.peer_sflag[k], 64ull * E + (unsigned long long)sweep + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            } else {
+                const long long t0 = wall_clock64();
+                while ((int)(__hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - want) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (wall_clock64() - t0 > 1000000000ll) { s_err = 1; atomicExch(ipc.error, 4); break; }  // 10 s: a workgroup of this launch never arrived
+                }
+            }
+        }
+        __syncthreads();
+        if (s_err) break;
+    }
+    // a rank that was done after sweep 0 still notes what the neighbours said about their directions (k_smooth_pull reads it)
+    if (sweeps == 1 && pid == 0 && !s_err) wait_peers(1, true);
 }
 
 // After the last sweep: the ghosts land in the array (FE.cpp:10609 does it after every sweep) from the last slot -- slot 0 for a
