@@ -217,6 +217,7 @@ struct nxs_dyn_handle {
     HaloFused hf{};
     std::vector<void *> hf_allocs;
     std::vector<int> h_send_index, h_recv_index;   // host copies of the halo lists
+    std::vector<char> h_sent;                      // [No] != 0: an own node this rank sends (the cut for the resident loop puts those in the small boundary patches)
     std::shared_ptr<HostPatches> hp;  // host copy of the patches (re-uploaded boundary-first for the fused halo)
     nxs_dyn_halo_fn halo_fn = nullptr;  // host-staged exchange through the caller's communicator
     void *halo_ctx = nullptr;
@@ -1076,6 +1077,7 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
     free_pool(h->halo_allocs);
     ipc_release(h);
     h->have_halo = false;
+    h->h_sent.clear();
     const int Nn = h->dm.Nn, No = h->dm.No;
     if (halo->nranks < 1 || halo->rank < 0 || halo->rank >= halo->nranks) return fail(h, NXS_ERR_INVALID, "rank/nranks invalid");
     const int ns = halo->num_send_procs, nr = halo->num_recv_procs;
@@ -1152,6 +1154,11 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
     HIPCHK(h, hipHostMalloc((void **)&h->h_send, std::max<size_t>(2 * (size_t)ts, 1) * sizeof(double), hipHostMallocDefault));
     HIPCHK(h, hipHostMalloc((void **)&h->h_recv, std::max<size_t>(2 * (size_t)tr, 1) * sizeof(double), hipHostMallocDefault));
     h->have_halo = true;
+    h->h_sent.assign((size_t)std::max(No, 1), 0);
+    for (int n : sidx) h->h_sent[n] = 1;
+    if (h->fused == 4 && halo->nranks > 1 && h->band_nodes != 0) {   // cut for the resident loop before the lists were known: again, with every sent node in the band
+        if ((rc = upload_patches(h))) return rc;
+    }
     {   // k_smooth_halo's blocks (one per BLOCK own nodes) spin for a neighbour's sweep, k_halo_pull's (one per BLOCK ghosts) for its flags
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_smooth_halo, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
@@ -1985,7 +1992,17 @@ int build_halo_fused(nxs_dyn_handle *h) {
         h->d_hf_dirty = true;
     }
     h->hf_ready = true;
-    if (getenv("NXS_DEBUG_PATCHES")) fprintf(stderr, "[nxs] rank %d fused halo: %d of %d patches on the boundary, %d sent nodes, %d ghosts\n", h->rank, plan.n_boundary, nP, plan.sptr[No], Nn - No);
+    if (getenv("NXS_DEBUG_PATCHES")) {
+        fprintf(stderr, "[nxs] rank %d fused halo: %d of %d patches on the boundary, %d sent nodes, %d ghosts\n", h->rank, plan.n_boundary, nP, plan.sptr[No], Nn - No);
+        std::string sizes;   // own nodes / elements / of them sent, of the boundary patches (they lead the arrays now)
+        for (int q = 0; q < plan.n_boundary && q < 80; ++q) {
+            int sent = 0, ghosts = 0;
+            const int *nd = h->hp->pnodes.data() + (size_t)q * h->hp->Mmax;
+            for (int i = 0; i < h->hp->node_cnt[q]; ++i) { if (nd[i] >= No) ++ghosts; else if (i < h->hp->own_cnt[q] && plan.sptr[nd[i] + 1] > plan.sptr[nd[i]]) ++sent; }
+            char b[64]; snprintf(b, sizeof b, " %d/%d/s%d/g%d", h->hp->own_cnt[q], h->hp->elem_cnt[q], sent, ghosts); sizes += b;
+        }
+        fprintf(stderr, "[nxs] rank %d boundary patches (own nodes / elements / sent / ghosts staged):%s\n", h->rank, sizes.c_str());
+    }
     return NXS_OK;
 }
 

@@ -5,7 +5,8 @@
 // ------------------------------------------------------------------------------------------------
 
 nxs_cut::MeshView mesh_view(const nxs_dyn_handle *h) {
-    return nxs_cut::MeshView{h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), h->dm.Nn, h->dm.Ne, h->dm.No};
+    return nxs_cut::MeshView{h->h_t, h->h_ghost.data(), h->h_x0.data(), h->h_y0.data(), h->dm.Nn, h->dm.Ne, h->dm.No,
+                             (h->have_halo && (int)h->h_sent.size() == h->dm.No && h->dm.No > 0) ? h->h_sent.data() : nullptr};
 }
 
 int device_cus(const nxs_dyn_handle *h) {

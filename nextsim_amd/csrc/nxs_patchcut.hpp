@@ -46,6 +46,7 @@ struct MeshView {
     const unsigned char *ghost3;    // [3 Ne]
     const double *x0, *y0;          // [Nn]
     int Nn, Ne, No;
+    const char *sent = nullptr;     // [No] several ranks, once the halo lists are known: != 0 = an own node this rank sends to a neighbour (else NULL)
 };
 
 // node -> elements CSR, ascending element number per node
@@ -260,10 +261,11 @@ inline void hilbert_order(const double *x0, const double *y0, int n_nodes, std::
     std::stable_sort(order.begin(), order.end(), [&](int a, int b2) { return key[a] < key[b2]; });
 }
 
-// band_P > 0 (several ranks): the own nodes that share an element with a ghost node -- on a partitioner's partitions the nodes this rank sends --
-// lead the order and are cut into patches of band_P nodes
+// band_P > 0 (several ranks): the own nodes that share an element with a ghost node AND the own nodes this rank sends (sent: known once the halo lists are; the
+// two sets differ -- a neighbour's OWNED element all of whose nodes are mine makes them its ghosts, and no ghost of mine is near: at 2 km / 8 ranks 123 of 914 sent
+// nodes, scattered over 37 ordinary patches that then sat in the exchange's critical path at full size) lead the order and are cut into patches of band_P nodes
 inline bool build_patches(const std::vector<int> t[3], const unsigned char *ghost3, const double *x0, const double *y0, int Nn, int Ne,
-                          int No, int P, HostPatches &out, int Ecap = 0, int Mcap = 0, int band_P = 0) {
+                          int No, int P, HostPatches &out, int Ecap = 0, int Mcap = 0, int band_P = 0, const char *sent = nullptr) {
     // 1st try: the caller's node numbering (keeps the patch's nodal accesses contiguous)
     std::vector<int> order(No);
     for (int i = 0; i < No; ++i) order[i] = i;
@@ -276,6 +278,7 @@ inline bool build_patches(const std::vector<int> t[3], const unsigned char *ghos
             if (v[0] < No && v[1] < No && v[2] < No) continue;
             for (int k = 0; k < 3; ++k) if (v[k] < No) band[v[k]] = 1;
         }
+        if (sent) for (int i = 0; i < No; ++i) if (sent[i]) band[i] = 1;
         for (int i = 0; i < No; ++i) n_band += band[i];
         std::stable_partition(order.begin(), order.end(), [&](int n) { return band[n] != 0; });
     }
@@ -424,7 +427,7 @@ inline std::string plan_patches(const MeshView &m, int patch_nodes, bool want_re
         // patches of up to ~200 nodes hold one element per thread of a 512-thread workgroup (k_substep_resident requires it, and one round
         // of the one-launch-per-sub-step kernel is as slow as its largest patch): none may exceed 480 elements
         const int Ecap = Ecap_big > 0 ? Ecap_big : (PP > NXS_CUT_T256_MAXP && PP <= 208) ? 480 : 0;
-        if (!build_patches(m.t, m.ghost3, m.x0, m.y0, m.Nn, m.Ne, m.No, PP, hp, Ecap, Ecap_big > 0 ? 1000 : 0, (want_resident && Ecap_big == 0 && band_nodes < PP) ? band_nodes : 0)) return false;
+        if (!build_patches(m.t, m.ghost3, m.x0, m.y0, m.Nn, m.Ne, m.No, PP, hp, Ecap, Ecap_big > 0 ? 1000 : 0, (want_resident && Ecap_big == 0 && band_nodes < PP) ? band_nodes : 0, m.sent)) return false;
         out.fused_lds = fused_lds_of(hp);
         return true;
     };

@@ -24,5 +24,5 @@ for band in bands:
     for _ in range(10): fe.step()
     fe.synchronize()
     tm, tr = fe.timing(), fe.traffic_model()
-    print(f"band_patch_nodes {band} {opts}: {tr['substep_kernel_name']} sub-steps {tm['substeps_ms']:.3f} ms ({tm['substep_launches']} launches), total {tm['total_ms']:.3f} ms", flush=True)
+    print(f"band_patch_nodes {band} {opts}: {tr['substep_kernel_name']} sub-steps {tm['substeps_ms']:.3f} ms ({tm['substep_launches']} launches), smoother {tm['smoother_ms']:.3f}, prep {tm['prep_ms']:.3f}, update {tm['update_ms']:.3f}, total {tm['total_ms']:.3f} ms", flush=True)
     fe.close()

@@ -156,7 +156,11 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
     for (int i = 0; i < 20; ++i) stats[i] = 0;
     const Mesh m = make_mesh(indices, ghost3, x, y, Nn, Ne, No);
     PatchPlan plan;
-    const std::string why = plan_patches(m.view(), patch_nodes, want_resident != 0, cus, plan, res_ept, true, g_band_nodes);
+    std::vector<char> sent((size_t)std::max(No, 1), 0);   // as nxs_dyn_set_halo hands it to the cutter: the own nodes this rank sends
+    for (int j = 0; send_index && ns > 0 && j < send_offsets[ns]; ++j) if (send_index[j] >= 0 && send_index[j] < No) sent[send_index[j]] = 1;
+    MeshView mv = m.view();
+    if (ns > 0) mv.sent = sent.data();
+    const std::string why = plan_patches(mv, patch_nodes, want_resident != 0, cus, plan, res_ept, true, g_band_nodes);
     if (!why.empty()) { put_msg(msg, msg_cap, why); return 2; }
     HostPatches &hp = plan.hp;
     check_patches(m, hp);
@@ -175,10 +179,15 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
             for (int k = 0; k < 3; ++k) has_ghost = has_ghost || indices[3 * e + k] - 1 >= No;
             if (has_ghost) for (int k = 0; k < 3; ++k) if (indices[3 * e + k] - 1 < No) band[indices[3 * e + k] - 1] = 1;
         }
+        if (ns > 0) for (int n = 0; n < No; ++n) if (sent[n]) band[n] = 1;   // (round 5: and every node this rank sends, ghost nearby or not)
         for (int q = 0; q < hp.nP; ++q) {
             int nb = 0;
             for (int i = 0; i < hp.own_cnt[q]; ++i) nb += band[hp.pnodes[(size_t)q * hp.Mmax + i]];
             REQUIRE(nb == 0 || (nb == hp.own_cnt[q] && nb <= g_band_nodes), "patch %d mixes %d boundary nodes with %d others", q, nb, hp.own_cnt[q] - nb);
+            // hence: a patch that takes part in the exchange between ranks (it sends, or it stages a ghost) is one of the SMALL ones
+            bool exch = false;
+            for (int i = 0; i < hp.node_cnt[q]; ++i) { const int n = hp.pnodes[(size_t)q * hp.Mmax + i]; exch = exch || n >= No || (i < hp.own_cnt[q] && ns > 0 && sent[n]); }
+            REQUIRE(!exch || hp.own_cnt[q] == 0 || hp.own_cnt[q] <= g_band_nodes, "patch %d of %d own nodes takes part in the exchange", q, hp.own_cnt[q]);
         }
     }
     if (!mr) {  // the rows of k_prep_fused: every node's elements in an order of its own (descending here; bamg's is a chained list's) -> patch slots
