@@ -226,14 +226,16 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
     # name: (fused, halo_fused, pair_regs, text)
     variants = {"resident": (4, 1, -1, " + exchange inside ONE resident launch per step"),
                 "resident_overlap": (4, 1, -1, " + exchange inside ONE resident launch per step, interior elements computed under the exchange"),
+                "resident_norelease": (4, 1, -1, " + exchange inside ONE resident launch per step, no release fence in front of a sub-step's flags (option resident_release 0)"),
                 "inkernel_pair": (3, 1, 1, " + both exchanges of TWO sub-steps inside one launch (k_substep_pair<HALO>)"),
                 "inkernel": (3, 1, 0, " + exchange inside the sub-step kernel (one launch per sub-step)"),
                 "separate": (3, 0, 0, ", separate push/pull kernels")}
 
     def select(name):
         opts = {"resident_wide": 1 if own_device else 0,   # (only matters where one workgroup per CU covers a rank's partition)
-                "resident_overlap": 1 if name == "resident_overlap" else 0, "fused": variants[name][0], "halo_fused": variants[name][1], "pair_regs": variants[name][2]}
-        for k in ("resident_wide", "resident_overlap", "pair_regs", "fused", "halo_fused"):
+                "resident_overlap": 1 if name == "resident_overlap" else 0, "resident_release": 0 if name == "resident_norelease" else 1,
+                "fused": variants[name][0], "halo_fused": variants[name][1], "pair_regs": variants[name][2]}
+        for k in ("resident_wide", "resident_overlap", "resident_release", "pair_regs", "fused", "halo_fused"):
             fe.set_option(k, opts[k])
         fe._bench_options = opts   # (what the PMC child run of this partition is given)
 
@@ -253,11 +255,11 @@ def choose_halo_kernels(fe, f, rank, world, dist, torch, own_device):
         return out
 
     # (NXS_BENCH_TRY_RESIDENT=1: rehearsal on a shared device with a mesh small enough for every rank's workgroups to be resident)
-    order = (["resident", "resident_overlap"] if (own_device or os.environ.get("NXS_BENCH_TRY_RESIDENT") == "1") else []) + ["inkernel_pair", "inkernel", "separate"]
+    order = (["resident", "resident_overlap", "resident_norelease"] if (own_device or os.environ.get("NXS_BENCH_TRY_RESIDENT") == "1") else []) + ["inkernel_pair", "inkernel", "separate"]
     results = {}
     report = {n: {"status": "not tried"} for n in variants}   # -> the JSON line (config.halo): per variant ms/step, bits, errors
     for name in order:
-        if name == "resident_overlap" and "resident" not in results:
+        if name in ("resident_overlap", "resident_norelease") and "resident" not in results:
             report[name] = {"status": "skipped: the plain resident launch did not run"}
             continue                               # (the same on every rank: `results` only holds what all ranks agreed on)
         mine, state, secs, err_text = True, None, 0.0, None
@@ -611,7 +613,8 @@ def aux_partition_floor(args, local_rank, torch, S):
         gm, p, lm, f = build_case("2km", share, 0)
         row = {"share_of_2km_mesh": f"1/{share}", "elements": int(lm.num_elements), "own_nodes": int(lm.local_ndof), "ghost_nodes": int(lm.num_nodes - lm.local_ndof)}
         for name, opts in (("two_substeps_per_launch", {"pair_regs": 1, "fused": 3, "halo_fused": 1}), ("one_launch_per_substep", {"pair_regs": 0, "fused": 3, "halo_fused": 1}),
-                           ("resident_one_launch_per_step", {"resident_wide": 1, "fused": 4, "halo_fused": 1})):
+                           ("resident_one_launch_per_step", {"resident_wide": 1, "fused": 4, "halo_fused": 1}),
+                           ("resident_without_the_release_fence", {"resident_wide": 1, "fused": 4, "halo_fused": 1, "resident_release": 0})):
             fe = dynamics.FiniteElementDynamics(p, device=local_rank)
             try:
                 fe.set_mesh(lm)

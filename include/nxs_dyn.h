@@ -460,6 +460,10 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  default 0: with fused != 0 the step writes its records only
  *   "halo_fused"   device-direct transport only: 1 = updateGhosts inside the fused sub-step kernel (default),
  *                  0 = separate push / pull kernels
+ *   "resident_release"  "fused" 4 on several ranks: 1 (default) = a system-scope release fence in front of every sub-step's flags; 0 = none -- the flags publish
+ *                  mailbox stores of other workgroups that were written through and drained before those workgroups took their tickets, which the publishing lane's
+ *                  fence does not reach: 0.65 us per sub-step (a rank of eight of the 2 km mesh, looped back: 1.03 -> 0.95 ms of sub-steps).  The same bits on one
+ *                  device; no run on several devices has told the two apart yet, hence the default; bench.py tries both and keeps 0 only if bit-identical
  *   "smooth_persist"  several ranks, device-direct mailboxes with the exchange inside the kernels: the 50 sweeps of the open-water smoother (FE.cpp:10578-10611) as ONE launch
  *                  of at most 128 persistent workgroups that meet at a barrier of their own between the sweeps (k_smooth_persist) instead of 50 launches of one sweep each
  *                  (0.12-0.16 ms per step saved on a rank of eight; a rank without ice-free own nodes whose exchanged nodes cannot change is done after one sweep); the same

@@ -210,6 +210,7 @@ struct nxs_dyn_handle {
     int pin_host = 0;                      // option "pin_host": page-lock the caller's state / forcing vectors on first use
     std::map<const void *, size_t> pinned; // what this handle has registered with hipHostRegister
     int halo_fused = 1;                    // option "halo_fused"
+    int res_no_release = 0;                // option "resident_release" = 0 (kept here: h->hf is rebuilt with the tables)
     int smooth_persist = -1;               // option "smooth_persist": the 50 sweeps with the exchange inside as ONE launch of persistent workgroups (k_smooth_persist): -1 / 1 = on, 0 = 50 launches of k_smooth_halo
     bool hf_ready = false;
     HaloFused *d_hf = nullptr;  // device copy of hf with the mailbox addresses filled in (what k_substep_fused<.., HALO> reads)
@@ -758,6 +759,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         h->d_hf_dirty = true; release_graph(h);
         return NXS_OK;
     }
+    if (!std::strcmp(key, "resident_release")) { h->hf.no_release = value == 0 ? 1 : 0; h->res_no_release = h->hf.no_release; h->d_hf_dirty = true; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "smooth_persist")) { h->smooth_persist = (int)value; release_graph(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_one_directional")) { h->one_directional = value != 0; return NXS_OK; }   // test door: before nxs_dyn_set_halo
     if (!std::strcmp(key, "fused")) {
@@ -1981,6 +1983,7 @@ int build_halo_fused(nxs_dyn_handle *h) {
     f.done_all = ctr;
     if ((rc = dev_upload(h, h->hf_allocs, &f.send_block_rank, plan.send_block_rank))) return rc;  // k_smooth_halo: which blocks store into a mailbox
     f.n_send_blocks = plan.n_send_blocks;
+    f.no_release = h->res_no_release;
     f.send_off = h->d_send_off;
     f.n_boundary = plan.n_boundary;
     register_waiting_grid(h, plan.n_boundary, 2 * device_cus(h));   // (two 512-thread workgroups of the fused kernel per CU)

@@ -1079,12 +1079,6 @@ struct IpcDev {
     unsigned delay;                 // test door "ipc_delay" (include/nxs_dyn.h): point << 8 | units of 10 us, set on ONE rank; 0 (always, outside the protocol tests) = none
 };
 #define NXS_SMOOTH_SWEEPS 50  // FE.cpp:10580 (Q9: hard-coded in the reference)
-// the one release in front of a sub-step's flags in the resident loops (an experiment build may leave it out to price it: scripts)
-#ifdef NXS_EXP_NOFENCE
-#define NXS_RESIDENT_RELEASE() do { } while (0)
-#else
-#define NXS_RESIDENT_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "")
-#endif
 
 // Test door "ipc_delay": the named rank sleeps here when `point` is the named point -- a deterministic widening of one window of the exchange protocols, so that an
 // ordering the protocol does not enforce shows as wrong bits instead of depending on who wins a race of a few microseconds (tests/test_gpu_protocol_delays.py).
@@ -1159,6 +1153,13 @@ struct HaloFused {
     unsigned int *done_all;            // k_smooth_halo: two-level ticket counters, [0] global, [32 (g+1)] group g
     const int *send_block_rank;        // k_smooth_halo: rank of block b among the blocks that send something, -1: sends nothing
     int n_send_blocks;
+    // Option "resident_release" = 0: the resident loops raise a sub-step's flags WITHOUT the system-scope release in front of them.  What the flags publish are the
+    // mailbox stores of OTHER workgroups -- write-through system-scope stores into uncached memory, each drained by its own wave (s_waitcnt vmcnt(0)) before that
+    // workgroup took its ticket; the publishing lane's fence (a write-back of ITS XCD's L2 and a wait for ITS wave's stores) reaches none of them, it only costs
+    // 0.65 us of the 2.5 us between the last boundary patch's barrier and the flags being seen, in every sub-step (a rank of eight: 1.03 -> 0.95 ms of sub-steps).
+    // The default keeps it: no run on more than one device has told the two apart yet; bench.py tries both where every rank has a device of its own and keeps the
+    // faster one only if it gives the bits of the separate kernels.
+    int no_release;
 };
 
 #ifdef NXS_PHASE_TIMING  // kernel microscope (scripts/phase_timing.py builds a variant of the library with it)
@@ -2487,7 +2488,7 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
                 nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
                 // the one release of the sub-step -- a RELEASE only: __threadfence_system() is an acquire as well, i.e. it also invalidates this
                 // XCD's L2, and every patch on the XCD then re-reads its element constants from memory instead of the L2, every sub-step
-                NXS_RESIDENT_RELEASE();
+                if (!hfp->no_release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // (option "resident_release" 0 leaves it out: see HaloFused::no_release)
                 for (int k = 0; k < hfp->ipc.ns; ++k)
                     __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (ss == S - 1) *hfp->ipc.seq_push = x0 + (unsigned long long)S;
@@ -2870,7 +2871,7 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                     if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
                 }
                 nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
-                NXS_RESIDENT_RELEASE();
+                if (!hfp->no_release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // (option "resident_release" 0 leaves it out: see HaloFused::no_release)
                 for (int k = 0; k < hfp->ipc.ns; ++k)
                     __hip_atomic_store(hfp->ipc.peer_flag[k], x0 + (unsigned long long)ss + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 if (ss == S - 1) *hfp->ipc.seq_push = x0 + (unsigned long long)S;

@@ -416,7 +416,7 @@ def test_bench_line_of_a_two_rank_run_is_one_json_line_with_every_structured_fie
     assert d["n_gpus"] == 2 and d["ranks_share_device"] is True and d["scaling"] == "strong" and d["value"] > 0 and d["fields_ok"] is True
     halo = d["config"]["halo"]
     assert halo["transport"] == "device-direct mailboxes" and halo["mailbox_selftest"].startswith("passed")
-    assert halo["kept_variant"] in ("inkernel", "inkernel_pair", "separate", "resident", "resident_overlap")
+    assert halo["kept_variant"] in ("inkernel", "inkernel_pair", "separate", "resident", "resident_overlap", "resident_norelease")
     assert halo["variants"]["inkernel_pair"]["status"] in ("ran", "failed")
     assert halo["variants"]["separate"]["status"] == "ran" and halo["variants"]["separate"]["bit_identical_to_separate_kernels"] is True
     assert halo["variants"]["inkernel"]["status"] in ("ran", "failed") and "ms_per_step" in halo["variants"]["separate"]
