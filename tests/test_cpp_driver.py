@@ -99,10 +99,12 @@ def test_mpi_host_builds_and_refuses_a_foreign_case_file(tmp_path):
 
 @needs_mpi
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
-def test_mpi_host_runs_a_partitioned_case_and_matches_the_multirank_oracle(world, tmp_path):
-    """mpiexec -n N ./nextsim_mpi: every rank creates its handle, exchanges mailbox handles and receive lists with
-    MPI_Allgather(v), runs the mailbox self-test and two steps with the halo exchange inside the sub-step kernel."""
+@pytest.mark.parametrize("world,transport", [(2, "ipc"), (3, "ipc"), (4, "ipc"), (4, "host")])
+def test_mpi_host_runs_a_partitioned_case_and_matches_the_multirank_oracle(world, transport, tmp_path):
+    """mpiexec -n N ./nextsim_mpi: every rank creates its handle, hands over its halo lists VERBATIM (the 4-rank partition of 'small' has a one-directional
+    neighbour: rank 0 sends to rank 3 and receives nothing from it -- nxs_dyn_set_halo adds the missing direction), publishes one record (MPI_Allreduce +
+    MPI_Allgather), runs the mailbox self-test and two steps with the halo exchange inside the sub-step kernel; or ("host") exchanges the ghosts through MPI
+    itself, the literal M_comm.send / recv of FE.cpp:13981-13985."""
     from nextsim_amd import casefile
     from oracle import pyoracle as O
     exe = _build_mpi(tmp_path)
@@ -110,7 +112,9 @@ def test_mpi_host_runs_a_partitioned_case_and_matches_the_multirank_oracle(world
     for r in range(world):
         casefile.write_case(str(tmp_path / f"case_{r}.bin"), lms[r], p, fields[r])
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    res = subprocess.run([MPIEXEC, "-n", str(world), exe, str(tmp_path / "case_%d.bin"), "2", str(tmp_path / "out_%d.bin")], capture_output=True, text=True,
+    if world == 4:
+        assert 3 in lms[0].send_procs.tolist() and 3 not in lms[0].recv_procs.tolist()      # (the case files hold the lists as initUpdateGhosts leaves them)
+    res = subprocess.run([MPIEXEC, "-n", str(world), exe, str(tmp_path / "case_%d.bin"), "2", str(tmp_path / "out_%d.bin"), "1", transport], capture_output=True, text=True,
                          timeout=300, env=env, stdin=subprocess.DEVNULL)
     assert res.returncode == 0, (res.stdout[-1000:], res.stderr[-3000:])
     ranks = [O.OracleRank(lm, p, f) for lm, f in zip(lms, fields)]
