@@ -111,6 +111,19 @@ def test_device_direct_halo_on_a_ragged_partition(world, seed, tmp_path):
             assert e <= 1e-10, (r["rank"], k, e)
 
 
+@pytest.mark.parametrize("world,kind,rpp,options", [(3, "small", 1, {}), (3, "small", 1, {"smooth_persist": 0}), (4, "40km", 2, {"fused": 4}), (2, "40km", 1, {"pair_regs": 1})])
+def test_open_water_across_the_partition_boundaries(world, kind, rpp, options, tmp_path):
+    """State 'arctic_ow' (29 % of the triangles ice free, half the rim): ice-free nodes on both sides of the partition boundaries, so the 50 smoother sweeps
+    exchange values that CHANGE from sweep to sweep (dynamic directions) -- in one launch of persistent workgroups (k_smooth_persist, the default), in 50 launches
+    of k_smooth_halo, under the resident loop and under two sub-steps per launch: bitwise the separate kernels, 1e-10 of the multi-rank oracle, two steps."""
+    reps = _run(world, kind, 2, tmp_path, "ipc", over={"forcing_kind": "arctic_ow", "options": options}, ranks_per_proc=rpp)
+    for r in reps:
+        assert r["ok"], r
+        assert r["fused_equals_separate"] is True and r["crash"] == 0, r
+        for k, e in r["errs"].items():
+            assert e <= 1e-10, (r["rank"], k, e)
+
+
 @pytest.mark.parametrize("dyn", ["mevp", "evp"])
 def test_in_kernel_halo_exchange_with_the_vp_rheologies(dyn, tmp_path):
     """mEVP moves the mesh once after the sub-step loop (no ring of velocity buffers: the ghosts are copied through

@@ -87,12 +87,13 @@ def _reference_against_the_oracle(kind, world, over, tmp_path):
     return lms
 
 
-@pytest.mark.parametrize("world,seed,rpp", [(3, 1, 1), (4, 2, 2)])
-def test_every_protocol_point_delayed_on_every_rank_keeps_the_bits(world, seed, rpp, tmp_path):
+@pytest.mark.parametrize("world,seed,rpp,state", [(3, 1, 1, "arctic_ow"), (4, 2, 2, "arctic")])
+def test_every_protocol_point_delayed_on_every_rank_keeps_the_bits(world, seed, rpp, state, tmp_path):
     """Ragged mosaics of 'small' (every rank a neighbour of every other, elements without an own node, nodes shared by three ranks), the halo lists VERBATIM
     (nextsim_amd.mesh.localize no longer symmetrises them: nxs_dyn_set_halo does), connected through the record form.  4 ranks = 2 processes x 2 ranks: links
     through hipIpc and through plain pointers."""
-    over = {"ragged_seed": seed}
+    # ('arctic_ow': half the rim ice free -- open water on both sides of the partition boundaries, so that the smoother's sweeps really exchange values that change)
+    over = {"ragged_seed": seed, "forcing_kind": state}
     spec = {"kind": "small", "over": over, "phases": [{"one_directional": 0, "cases": _walk(world, 50)}]}
     reps = _run(world, spec, tmp_path, ranks_per_proc=rpp)
     for r in reps:
