@@ -2377,11 +2377,12 @@ int explicit_solve(nxs_dyn_handle *h) {
     }
     // the fused kernels read records only: the per-quantity work vectors (v1 kernels, debug door) are filled on request
     // (automatic: meshes that stream from HBM; on cache-resident ones the two small kernels are as fast: 10 km 24.7 vs 27.4 us)
-    if (eff_fused(h) != 0 && !h->work_arrays && (h->prep_fused == 1 || (h->prep_fused < 0 && m.Ne >= 250000)) && h->prep_lds > 0 && h->dpch.prow && h->dpch.nP > 0 && !multi_rank(h)) {
+    if (eff_fused(h) != 0 && !h->work_arrays && (h->prep_fused == 1 || (h->prep_fused < 0 && m.Ne >= 250000)) && h->prep_lds > 0 && h->dpch.prow && h->dpch.nP > 0) {
         // one launch over the sub-step kernel's patches: the elements' values reach their nodes through LDS (k_prep_fused)
         // (the open-water flags of the node blocks are lowered by the step before -- k_update's first threads, as the range flag -- and at allocation: no memset per step;
         // a step that ended without update() leaves them raised, which only costs the smoother some blocks it could have skipped)
         hipLaunchKernelGGL(k_prep_fused, dim3(h->dpch.nP), dim3(512), h->prep_lds, h->stream, m, h->dpch, h->ds, h->dw, h->dp);
+        if (m.Nn > m.No) LAUNCH(h, k_prep_ghost_nodes, m.Nn - m.No, m, h->ds, h->dw, h->dp);   // several ranks: the ghost nodes' share of the nodal loops
         HIPCHK(h, hipGetLastError());
         h->last_prep = NXS_PREP_FUSED;
     } else if (eff_fused(h) != 0 && !h->work_arrays) {

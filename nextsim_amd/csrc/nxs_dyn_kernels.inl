@@ -752,6 +752,100 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))
     PSTAMP(4);
 }
 
+// Several ranks: k_prep_fused runs over the patches of a rank's OWN nodes (every element touching one is in its patch: the fans are complete); the reference's
+// loops also visit the GHOST nodes (FE.cpp:10309, 10356 run over M_num_nodes), whose local fans are partial -- their frozen coordinates are staged by the sub-step
+// kernels, their M_VT is zeroed where their local mass is, D_tau_a of all nodes goes to the coupler.  This pass does them: one thread per ghost node, the values of
+// the few elements around it formed again with k_prep_elements' expressions (a rank of eight of the 2 km mesh has 793 ghosts).  Operand for operand k_prep_nodes
+// on a ghost node: its grad_ssh sums stay zero (every corner a ghost holds is flagged ghostNodes[i], FE.cpp:10328).
+__global__ void __launch_bounds__(BLOCK) k_prep_ghost_nodes(DevMesh m, DevState s, DevWork w, DevParams p) {
+    const int n = m.No + blockIdx.x * BLOCK + (int)threadIdx.x;
+    if (n >= m.Nn) return;
+    const int Nn = m.Nn;
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    // what the nodal loops take from element e: its area, mass x area, C_bu and drag coefficient x area (k_prep_elements, FE.cpp:10235-10308)
+    auto element_values = [&](const int e, double &surface, double &meA, double &ecbu, double &dragsurf) {
+        double vx[3], vy[3];
+        load_vertices(m, s.UM, e, vx, vy);
+        const double jac = jacobian(vx, vy);
+        surface = (1. / 2) * fabs(jac);  // FE.cpp:1929-1933
+        const double conc = s.conc[e], thick = s.thick[e];
+        double total_concentration = conc, total_thickness = thick, total_snow = s.snow[e];
+        if (p.young_cat) {
+            total_concentration += s.cyoung[e];
+            total_thickness += s.hyoung[e];
+            total_snow += s.hsyoung[e];
+        }
+        double element_mass = 0.;
+        if (total_concentration > 0.)
+            element_mass = (NXS_RHOI * total_thickness + NXS_RHOS * total_snow) / total_concentration;
+        double element_ssh = 0;
+        element_ssh += s.ssh[m.t0[e]];
+        element_ssh += s.ssh[m.t1[e]];
+        element_ssh += s.ssh[m.t2[e]];
+        element_ssh /= 3.;
+        const double max_keel_depth = 28;
+        const double min_water_depth = 2.;
+        const double depth_eff = STD_MAX(0., element_ssh + STD_MAX(min_water_depth, s.depth[e]));
+        double critical_h = 0., critical_h_mod = 0.;
+        if (p.basal_stress_type == NXS_BASAL_LEMIEUX) {
+            double mean_keel_depth = p.k1 * thick;
+            mean_keel_depth = STD_MIN(mean_keel_depth, conc * max_keel_depth);
+            critical_h = conc * depth_eff / p.k1;
+            critical_h_mod = mean_keel_depth / p.k1;
+        }
+        ecbu = p.k2 * STD_MAX(0., critical_h_mod - critical_h) * exp(-p.Cb * (1. - conc));
+        meA = element_mass * surface;                        // FE.cpp:10314
+        double dragp = s.drag_ui[e];                          // FE.cpp:10585-10596
+        if (p.young_cat) {
+            const double cy = s.cyoung[e];
+            if (conc + cy > 0.) dragp = (s.drag_ui[e] * conc + s.drag_ui_young[e] * cy) / (conc + cy);
+        }
+        dragsurf = dragp * surface;
+    };
+    double rl = 0., nm = 0., cb = 0.;
+    const double gu = 0., gv = 0.;   // (ghost corners are skipped by the ssh-gradient scatter)
+    for (int slot = 0; slot < m.W; ++slot) {
+        const int ent = m.fan[(size_t)slot * Nn + n];
+        if (ent < 0) break;
+        double surface, meA, ecbu, dragsurf;
+        element_values(ent >> 3, surface, meA, ecbu, dragsurf);
+        rl += surface;                                 // FE.cpp:10313
+        nm += meA;                                     // FE.cpp:10314
+        cb = STD_MAX(cb, ecbu);                        // FE.cpp:10317
+    }
+    {
+        const d2 c = d2{m.x0[n] + 1. * s.UM[n], m.y0[n] + 1. * s.UM[n + Nn]};
+        reinterpret_cast<d2 *>(w.xy)[n] = c;
+        if (!shape_value_in_range(c.x) || !shape_value_in_range(c.y)) w.shape_range[0] = 1;   // (see quotients_by_one_divisor)
+    }
+    // prep nodes, FE.cpp:10356-10416
+    double vu = s.VT[n], vv = s.VT[n + Nn];
+    if (nm == 0.) { vu = 0.; vv = 0.; s.VT[n] = 0.; s.VT[n + Nn] = 0.; }
+    double drag = 0., surface_sum = 0;
+    for (int j = 0; j < m.W1; ++j) {                  // bamg row order (summation order!)
+        const int e = m.n2e[(size_t)j * Nn + n];
+        if (e < 0) continue;                           // Q2
+        double surface, meA, ecbu, dragsurf;
+        element_values(e, surface, meA, ecbu, dragsurf);
+        drag += dragsurf;
+        surface_sum += surface;
+    }
+    const double wu = s.wind[n], wv = s.wind[n + Nn];
+    drag *= NXS_RHOA * hypot(wu, wv) / surface_sum;   // Q6
+    const double tax = drag * wu, tay = drag * wv;
+    w.D_tau_a[n] = tax;
+    w.D_tau_a[n + Nn] = tay;
+    const double fc = 2 * NXS_OMEGA * sin(m.lat[n] * NXS_PI / 180.);
+    rl = 1. / rl;                                      // FE.cpp:10400-10402
+    nm *= rl;
+    rl *= 3.;
+    w.node_mass[n] = nm;
+    w.VTM[n] = vu;
+    w.VTM[n + Nn] = vv;
+    d2 *r = reinterpret_cast<d2 *>(w.nrec) + 5 * (size_t)n;
+    r[0] = d2{record_dte_over_mass(p, nm), gu}; r[1] = d2{gv, rl}; r[2] = d2{cb, fc}; r[3] = d2{tax, tay}; r[4] = d2{s.ocean[n], s.ocean[n + Nn]};
+}
+
 // ------------------------------------------------------------------------------------------------
 // Arithmetic shared by the v1 kernels (one per reference loop) and the v2 fused sub-step kernel, so
 // that both perform literally the same operations in the same order.

@@ -232,11 +232,11 @@ int upload_host_patches(nxs_dyn_handle *h, const HostPatches &hp) {
     const int *dpet = nullptr;
     if ((rc = dev_upload(h, h->patch_allocs, &dpet, pet))) return rc;
     d.pet = reinterpret_cast<const int2 *>(dpet);
-    // k_prep_fused (single rank): the bamg-order rows in patch slots; a table that does not fit this mesh, or patches too large for its LDS, leave
+    // k_prep_fused: the bamg-order rows in patch slots; a table that does not fit this mesh, or patches too large for its LDS, leave
     // the two separate prep kernels in place
     h->prep_lds = 0;
     d.prow = nullptr; d.W1 = h->dm.W1;
-    if (h->dm.No == h->dm.Nn && !h->h_n2e.empty() && nxs_cut::prep_fused_lds_of(hp) <= 160 * 1024) {
+    if (!h->h_n2e.empty() && nxs_cut::prep_fused_lds_of(hp) <= 160 * 1024) {   // (several ranks too, since round 5: the rows of the OWN nodes; the ghosts have a pass of their own)
         std::vector<unsigned short> rows;
         if (nxs_cut::build_prep_rows(hp, h->h_n2e.data(), h->dm.W1, h->dm.Nn, rows)) {
             if ((rc = dev_upload(h, h->patch_allocs, &d.prow, rows))) return rc;

@@ -90,7 +90,10 @@ def run_rank(li, report):
             except dynamics.NxsError as e:
                 res["error"] = str(e)
             got = fe.get_state()
+            for name in spec.get("debug_arrays", []):        # work arrays of the step too (the prep kernels' records, ghosts included)
+                got["debug:" + name] = fe.debug_array(name)
             res["launches"] = fe.timing()["substep_launches"]
+            res["prep"] = fe.traffic_model()["prep_kernel_name"]
             res["kernel"] = fe.traffic_model()["substep_kernel_name"]
             res["crash"] = fe.checkFieldsFast()
             if ref is None:
@@ -100,7 +103,7 @@ def run_rank(li, report):
             else:
                 res["equal"] = bool(all(np.array_equal(got[k], ref[k]) for k in got))
                 if not res["equal"]:
-                    res["worst"] = {k: float(cases.rel_err(got[k], ref[k])) for k in KEYS if not np.array_equal(got[k], ref[k])}
+                    res["worst"] = {k: float(cases.rel_err(got[k], ref[k])) for k in got if not np.array_equal(got[k], ref[k])}
             fe.set_option("ipc_delay", 0)
     report["ok"] = True
     all_gather(0)                               # keep every mailbox alive until all ranks are done

@@ -139,3 +139,27 @@ def test_the_one_directional_neighbour_of_round_4_fails_under_a_delay_and_the_pa
     r3 = [r for r in reps if r["rank"] == 3][0]      # phase 2: rank 3 reads what rank 0 has already overwritten
     red = {c["name"]: (not c["equal"]) if "equal" in c else c["selftest_errors"] != 0 for c in r3["phases"][1]["cases"]}
     assert all(red.values()), red
+
+
+@pytest.mark.parametrize("world,kind,rpp,over", [(3, "small", 1, {"ragged_seed": 4}), (2, "40km", 2, {}), (4, "small", 2, {"forcing_kind": "arctic_ow", "ice_cat_type": 1})])
+def test_fused_prep_kernel_on_several_ranks_does_not_change_a_bit(world, kind, rpp, over, tmp_path):
+    """Round 5: k_prep_fused (prep elements + prep nodes in one launch over the node patches, FE.cpp:10235-10416) also on a rank of several -- over the patches of
+    its OWN nodes, with k_prep_ghost_nodes for the ghosts' share of the nodal loops (partial fans, M_VT zeroed where the local mass is zero, D_tau_a, the frozen
+    coordinates).  Forced on these small partitions by option prep_fused 1 (automatic from 250 k triangles): the state after a step AND the prep kernels' own arrays --
+    the 80-byte nodal records, the frozen coordinates, D_tau_a, M_surface, M_delta_x, the 48-byte element records, ghosts and ghost elements included -- are bit for bit
+    those of the two separate kernels, under every kernel family of the sub-step loop (whose patch cuts differ)."""
+    base = {"fused": 3, "pair_regs": 0, "halo_fused": 1, "smooth_persist": 1, "resident_release": 1}
+    cases = [{"name": "reference", "options": dict(base, prep_fused=0)}]
+    for name, o in (("inkernel", {}), ("pair", {"pair_regs": 1}), ("resident", {"fused": 4}), ("separate", {"halo_fused": 0})):
+        cases.append({"name": f"{name}/two_kernels", "options": dict(base, prep_fused=0, **o)})
+        cases.append({"name": f"{name}/fused", "options": dict(base, prep_fused=1, **o)})
+    spec = {"kind": kind, "over": over, "debug_arrays": ["nrec", "xy", "tau_a", "surface", "delta_x", "erec"], "phases": [{"one_directional": 0, "cases": cases}]}
+    reps = _run(world, spec, tmp_path, ranks_per_proc=rpp)
+    for r in reps:
+        assert r["ok"], r.get("error", r)
+        for c in r["phases"][0]["cases"]:
+            assert c.get("equal") and not c.get("error") and not c.get("crash"), (r["rank"], c)
+            if c["name"].endswith("/fused"):
+                assert c["prep"] == "k_prep_fused", (r["rank"], c)
+            elif c["name"] != "reference":
+                assert c["prep"].startswith("k_prep_elements"), (r["rank"], c)
