@@ -416,9 +416,10 @@ NXS_API int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t);
  *                  are cut into small patches of their own: a boundary patch pays the exchange between ranks in every sub-step of the resident
  *                  loop, so it gets a shorter compute phase (two ranks of 87 k triangles rehearsed on one GPU: 0.985 -> 0.89-0.91 ms of
  *                  sub-steps).  16..512 nodes; 0 = off; -1 (default) = 48.  The cut does not change a bit of the results
- *   "prep_fused"   single rank: prep elements + prep nodes (FE.cpp:10235-10416) as ONE launch over the sub-step kernel's node patches, the elements'
- *                  values reaching their nodes through LDS (k_prep_fused: 2 km mesh 203 -> 113 us per step, the same bits): -1 (default) =
- *                  on meshes of 250 k triangles and more, 0 = never, 1 = wherever its tables exist
+ *   "prep_fused"   prep elements + prep nodes (FE.cpp:10235-10416) as ONE launch over the sub-step kernel's node patches, the elements'
+ *                  values reaching their nodes through LDS (k_prep_fused: 2 km mesh 203 -> 113 us per step, the same bits); on a rank of several over the
+ *                  patches of its own nodes, the ghost nodes' share of the nodal loops in a small pass of its own (k_prep_ghost_nodes): -1 (default) =
+ *                  on meshes of 250 k triangles and more (a rank of several: 500 k), 0 = never, 1 = wherever its tables exist
  *   "smooth_depth" sweeps of the open-water smoother per launch on its own node-ring patches (single rank): 5, 10 or 25; 0 = automatic
  *                  (10 where ten rings of neighbours fit the LDS, else 5; sweep by sweep where neither fits)
  *   "substeps_per_launch"  depth of that temporal blocking, 2..8; 0 = automatic (4, lowered until it divides the count)

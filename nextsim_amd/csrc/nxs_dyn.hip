@@ -2377,7 +2377,9 @@ int explicit_solve(nxs_dyn_handle *h) {
     }
     // the fused kernels read records only: the per-quantity work vectors (v1 kernels, debug door) are filled on request
     // (automatic: meshes that stream from HBM; on cache-resident ones the two small kernels are as fast: 10 km 24.7 vs 27.4 us)
-    if (eff_fused(h) != 0 && !h->work_arrays && (h->prep_fused == 1 || (h->prep_fused < 0 && m.Ne >= 250000)) && h->prep_lds > 0 && h->dpch.prow && h->dpch.nP > 0) {
+    // (automatic: from 250 k triangles on a single rank; on a rank of several from 500 k -- measured on rank 0's partitions of the 2 km mesh, looped back: 730 k
+    // 0.108 -> 0.086 ms, 366 k in the resident loop's large patches 0.046 -> 0.053, 184 k 0.033 -> 0.043: gpurun_out/r5_prepmr_ab.log)
+    if (eff_fused(h) != 0 && !h->work_arrays && (h->prep_fused == 1 || (h->prep_fused < 0 && m.Ne >= (multi_rank(h) ? 500000 : 250000))) && h->prep_lds > 0 && h->dpch.prow && h->dpch.nP > 0) {
         // one launch over the sub-step kernel's patches: the elements' values reach their nodes through LDS (k_prep_fused)
         // (the open-water flags of the node blocks are lowered by the step before -- k_update's first threads, as the range flag -- and at allocation: no memset per step;
         // a step that ended without update() leaves them raised, which only costs the smoother some blocks it could have skipped)
