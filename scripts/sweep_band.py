@@ -17,7 +17,7 @@ for band in bands:
     for k, v in opts.items(): fe.set_option(k, int(v))
     fe.set_mesh(lm)
     assert fe.ipc_loopback()
-    for k, v in {"fused": 4, "halo_fused": 1, "resident_wide": 1}.items(): fe.set_option(k, v)
+    for k, v in {"fused": 4, "halo_fused": 1, "resident_wide": 1, **{k2: int(v2) for k2, v2 in opts.items()}}.items(): fe.set_option(k, v)   # (the caller's options win)
     fe.set_option("prepare", 1); fe.put_state(f); fe.set_forcing(f)
     for _ in range(3): fe.step()
     fe.synchronize(); fe.put_state(f); fe.set_option("timing_reset", 1)

@@ -22,15 +22,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 PULL_READ, PUSH_STORE, PUSH_FLAG, STAGE_READ, SEND_STORE, PAIR_SECOND_STORE, PUBLISH_FLAG, PAIR_MID_READ, SMOOTH_READ, SMOOTH_STORE, SMOOTH_FLAG, SMOOTH_PULL_READ, PAIR_SECOND_FLAG = range(1, 14)
 POINT_NAMES = {1: "pull_read", 2: "push_store", 3: "push_flag", 4: "stage_read", 5: "send_store", 6: "pair_second_store", 7: "publish_flag", 8: "pair_mid_read",
                9: "smooth_read", 10: "smooth_store", 11: "smooth_flag", 12: "smooth_pull_read", 13: "pair_second_flag"}
+_BASE = {"fused": 3, "pair_regs": 0, "halo_fused": 1, "smooth_persist": 1, "resident_release": 1}
 VARIANTS = {   # (every variant names every option: the worker keeps ONE handle per rank for all cases)
-    "separate": ({"fused": 3, "pair_regs": 0, "halo_fused": 0, "smooth_persist": 1}, (PULL_READ, PUSH_STORE, PUSH_FLAG)),
-    "inkernel": ({"fused": 3, "pair_regs": 0, "halo_fused": 1, "smooth_persist": 1}, (STAGE_READ, SEND_STORE, PUBLISH_FLAG, PULL_READ, SMOOTH_READ, SMOOTH_STORE, SMOOTH_FLAG, SMOOTH_PULL_READ)),
+    "separate": (dict(_BASE, halo_fused=0), (PULL_READ, PUSH_STORE, PUSH_FLAG)),
+    "inkernel": (dict(_BASE), (STAGE_READ, SEND_STORE, PUBLISH_FLAG, PULL_READ, SMOOTH_READ, SMOOTH_STORE, SMOOTH_FLAG, SMOOTH_PULL_READ)),
     # the smoother as 50 launches of one sweep (k_smooth_halo) instead of one launch of persistent workgroups (k_smooth_persist, the default since round 5)
-    "sweeps": ({"fused": 3, "pair_regs": 0, "halo_fused": 1, "smooth_persist": 0}, (SMOOTH_READ, SMOOTH_STORE, SMOOTH_FLAG, SMOOTH_PULL_READ)),
-    "pair": ({"fused": 3, "pair_regs": 1, "halo_fused": 1, "smooth_persist": 1}, (STAGE_READ, SEND_STORE, PUBLISH_FLAG, PAIR_MID_READ, PAIR_SECOND_STORE, PAIR_SECOND_FLAG, PULL_READ)),
-    "resident": ({"fused": 4, "halo_fused": 1, "smooth_persist": 1, "resident_release": 1}, (STAGE_READ, SEND_STORE, PUBLISH_FLAG)),
+    "sweeps": (dict(_BASE, smooth_persist=0), (SMOOTH_READ, SMOOTH_STORE, SMOOTH_FLAG, SMOOTH_PULL_READ)),
+    "pair": (dict(_BASE, pair_regs=1), (STAGE_READ, SEND_STORE, PUBLISH_FLAG, PAIR_MID_READ, PAIR_SECOND_STORE, PAIR_SECOND_FLAG, PULL_READ)),
+    "resident": (dict(_BASE, fused=4), (STAGE_READ, SEND_STORE, PUBLISH_FLAG)),
     # the resident loop without the release fence in front of a sub-step's flags (option resident_release 0: what bench.py tries on machines with a device per rank)
-    "resident_norelease": ({"fused": 4, "halo_fused": 1, "smooth_persist": 1, "resident_release": 0}, (STAGE_READ, SEND_STORE, PUBLISH_FLAG)),
+    "resident_norelease": (dict(_BASE, fused=4, resident_release=0), (STAGE_READ, SEND_STORE, PUBLISH_FLAG)),
 }
 EXPECT_KERNEL = {"separate": "k_substep_fused", "inkernel": "k_substep_fused", "sweeps": "k_substep_fused", "pair": "k_substep_pair", "resident": "k_substep_resident", "resident_norelease": "k_substep_resident"}
 
@@ -44,7 +45,7 @@ def _walk(world, units, variants=VARIANTS, mixed=True):
                 cases.append({"name": f"{vname}/{POINT_NAMES[pt]}/rank{r}", "options": dict(opts), "delay": [r, pt, units]})
     if mixed:   # k_substep_pair<HALO> on some ranks against k_substep_fused<HALO> on their neighbours, through the same two-half mailbox
         for pat in ([1, 0], [0, 1]):
-            mopts = {"fused": 3, "halo_fused": 1, "smooth_persist": 1}
+            mopts = {k: v for k, v in _BASE.items() if k != "pair_regs"}
             cases.append({"name": f"mixed{pat[0]}/undelayed", "options": mopts, "rank_options": {"pair_regs": pat}})
             for pt in (STAGE_READ, PAIR_MID_READ, PAIR_SECOND_STORE, PUBLISH_FLAG, SEND_STORE):
                 for r in range(world):
@@ -148,7 +149,7 @@ def test_fused_prep_kernel_on_several_ranks_does_not_change_a_bit(world, kind, r
     coordinates).  Forced on these small partitions by option prep_fused 1 (automatic from 250 k triangles): the state after a step AND the prep kernels' own arrays --
     the 80-byte nodal records, the frozen coordinates, D_tau_a, M_surface, M_delta_x, the 48-byte element records, ghosts and ghost elements included -- are bit for bit
     those of the two separate kernels, under every kernel family of the sub-step loop (whose patch cuts differ)."""
-    base = {"fused": 3, "pair_regs": 0, "halo_fused": 1, "smooth_persist": 1, "resident_release": 1}
+    base = dict(_BASE)
     cases = [{"name": "reference", "options": dict(base, prep_fused=0)}]
     for name, o in (("inkernel", {}), ("pair", {"pair_regs": 1}), ("resident", {"fused": 4}), ("separate", {"halo_fused": 0})):
         cases.append({"name": f"{name}/two_kernels", "options": dict(base, prep_fused=0, **o)})
