@@ -153,11 +153,6 @@ struct nxs_dyn_handle {
     int ns_caller = 0, nr_caller = 0;      // neighbours the caller's own lists named (the low-level nxs_dyn_ipc_connect takes tables for those)
     int one_directional = 0;               // test door "halo_one_directional": 1 = set_halo takes the lists as given and ipc_connect does not refuse (round 4's defect, for the delay tests)
     unsigned ipc_delay_opt = 0;            // test door "ipc_delay": rank << 16 | point << 8 | units (include/nxs_dyn.h)
-    // nxs_dyn_step_host with option "pin_host": a second stream for the copies that need not wait for / be waited for by the kernels (the arrays only update() reads
-    // go up while the sub-steps run, M_VT / M_UM / M_UT come down while update() runs)
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_late = nullptr, ev_solved = nullptr;
-    hipEvent_t wait_before_update = nullptr, record_after_solve = nullptr;   // hooks nxs_dyn_step honours for ONE step (set and cleared by nxs_dyn_step_host)
     int ord_blocks = 0, ord_slots = 0;     // the largest grid of blocks that may WAIT inside this handle's ordinary kernels, as registered on the device (nxs_resident_registry.hpp)
     long long reg_touched = 0;             // when the registry entry was last touched (seconds)
     int *d_send_index = nullptr, *d_send_seg = nullptr, *d_send_off = nullptr;
@@ -716,9 +711,6 @@ int nxs_dyn_destroy(nxs_dyn_handle *h) try {
     if (h->d_dp) (void)hipFree(h->d_dp);
     for (auto &set : h->ev) for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
     for (auto &set : h->ev_flush) for (auto &ev : set) if (ev) (void)hipEventDestroy(ev);
-    if (h->copy_stream) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamDestroy(h->copy_stream); }
-    if (h->ev_late) (void)hipEventDestroy(h->ev_late);
-    if (h->ev_solved) (void)hipEventDestroy(h->ev_solved);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NXS_OK;
@@ -2533,8 +2525,6 @@ int nxs_dyn_step(nxs_dyn_handle *h) try {  // FE.cpp:8197-8214
     }
     rc = explicit_solve(h);
     if (rc) { h->cur = nullptr; return rc; }
-    if (h->record_after_solve) HIPCHK(h, hipEventRecord(h->record_after_solve, h->stream));   // (nxs_dyn_step_host: M_VT, M_UM, M_UT are final)
-    if (h->wait_before_update) HIPCHK(h, hipStreamWaitEvent(h->stream, h->wait_before_update, 0));   // (... the arrays only update() reads have arrived)
     if (h->sig_loc) LAUNCH(h, k_update<true>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     else LAUNCH(h, k_update<false>, h->dm.Ne, h->dm, h->ds, h->dw, h->dp);
     HIPCHK(h, hipGetLastError());
@@ -2681,12 +2671,13 @@ int nxs_dyn_get_traffic_model(nxs_dyn_handle *h, nxs_dyn_traffic *t) try {
 int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing *f) try {
     int rc;
     if (!h || !s || !f) return NXS_ERR_INVALID;
-    // The literal drop-in moves the whole state and forcing over PCIe every step (2 km: 275 MB up, 187 MB down at ~52 GB/s = 8.9 ms beside 4.6 ms of kernels).  With
-    // page-locked host vectors (option "pin_host") the copies are asynchronous, and what the kernels do not need yet / any more moves beside them on a second stream:
-    //   up, BEHIND the start of the step:  the arrays only update() reads (M_ridge_ratio, M_conc_myi, M_thick_myi; without the young-ice category also the young-ice
-    //       trio and M_drag_ui_young, which no kernel reads then) -- update() waits for them;
-    //   down, beside update():             M_VT, M_UM, M_UT, final when explicitSolve() is;
-    //   not down at all:                   the young-ice trio without the young-ice category (the step did not change it: the host's copy is the current one).
+    // The literal drop-in moves the whole state and forcing over PCIe every step (2 km: 275 MB up, 187 MB down at 50-54 GB/s = 8.9 ms beside 4.7 ms of kernels).
+    // With page-locked host vectors (option "pin_host") the copies are asynchronous: put, forcing, step and get become ONE queue without a synchronisation between
+    // them, and without the young-ice category the young-ice trio -- which no kernel reads or writes then -- is not brought down again (the step did not change it).
+    // Round 5 also tried, on a second stream: the arrays only update() reads going up beside the sub-steps, M_VT / M_UM / M_UT coming down beside update(), the arrays
+    // no kernel reads going up beside the downloads.  None of it pays (13.5-14.2 ms against 13.0-13.6: `profiles/r05_experiments/r5_copies*.log`): the two directions of
+    // the link slow each other down (downloads 54 -> 35 GB/s beside an upload), and the kernels run 11 % slower inside this call whatever the copies do (sub-steps 4.85 ms
+    // against 4.35 back to back: the device has idled through 5 ms of uploads) -- the floor of this API on this link is the sum of its parts.
     const bool moving = h->have_mesh && (h->dp.dynamics_type == NXS_DYN_BBM || h->dp.dynamics_type == NXS_DYN_EVP || h->dp.dynamics_type == NXS_DYN_MEVP);
     const bool complete = s->VT && s->UM && s->UT && s->conc && s->thick && s->snow_thick && s->damage && s->ridge_ratio && s->sigma[0] && s->sigma[1] && s->sigma[2] &&
                           s->conc_young && s->h_young && s->hs_young && s->conc_myi && s->thick_myi && s->cohesion && s->time_relaxation_damage && s->drag_ui && s->drag_ui_young &&
@@ -2698,58 +2689,28 @@ int nxs_dyn_step_host(nxs_dyn_handle *h, nxs_dyn_state *s, const nxs_dyn_forcing
         return nxs_dyn_get_state(h, s);
     }
     HIPCHK(h, hipSetDevice(h->device));
-    if (!h->copy_stream) {
-        HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_late, hipEventDisableTiming));
-        HIPCHK(h, hipEventCreateWithFlags(&h->ev_solved, hipEventDisableTiming));
-    }
     const size_t Nn = h->dm.Nn, Ne = h->dm.Ne, n2 = 2 * Nn * sizeof(double), n1 = Nn * sizeof(double), ne = Ne * sizeof(double);
     DevState &d = h->ds;
-    const bool young = h->dp.young_cat != 0;
     struct Cp { double *dev; double *host; size_t bytes; };
     const auto H = [](const double *p) { return const_cast<double *>(p); };
-    std::vector<Cp> early = {{d.VT, s->VT, n2}, {d.UM, s->UM, n2}, {d.wind, H(f->wind), n2}, {d.ocean, H(f->ocean), n2}, {d.ssh, H(f->ssh), n1}, {d.depth, H(f->element_depth), ne},
-                             {d.conc, s->conc, ne}, {d.thick, s->thick, ne}, {d.snow, s->snow_thick, ne}, {d.cohesion, H(s->cohesion), ne}, {d.theal, H(s->time_relaxation_damage), ne},
-                             {d.drag_ui, H(s->drag_ui), ne}, {d.UT, s->UT, n2}, {d.s0, s->sigma[0], ne}, {d.s1, s->sigma[1], ne}, {d.s2, s->sigma[2], ne}, {d.damage, s->damage, ne}};
-    std::vector<Cp> late = {{d.ridge, s->ridge_ratio, ne}, {d.cmyi, s->conc_myi, ne}, {d.tmyi, s->thick_myi, ne}};
-    std::vector<Cp> ytrio = {{d.cyoung, s->conc_young, ne}, {d.hyoung, s->h_young, ne}, {d.hsyoung, s->hs_young, ne}, {d.drag_ui_young, H(s->drag_ui_young), ne}};
-    (young ? early : late).insert((young ? early : late).end(), ytrio.begin(), ytrio.end());
-    for (auto *set : {&early, &late}) for (const Cp &c : *set) pin_host_buffer(h, c.host, c.bytes);
-    static const bool dbg = getenv("NXS_DEBUG_STEP_HOST") != nullptr;
-    hipEvent_t te[7] = {};
-    if (dbg) { for (auto &e : te) (void)hipEventCreate(&e); (void)hipEventRecord(te[0], h->stream); }
+    const Cp up[] = {{d.VT, s->VT, n2}, {d.UM, s->UM, n2}, {d.wind, H(f->wind), n2}, {d.ocean, H(f->ocean), n2}, {d.ssh, H(f->ssh), n1}, {d.depth, H(f->element_depth), ne},
+                     {d.conc, s->conc, ne}, {d.thick, s->thick, ne}, {d.snow, s->snow_thick, ne}, {d.cohesion, H(s->cohesion), ne}, {d.theal, H(s->time_relaxation_damage), ne},
+                     {d.drag_ui, H(s->drag_ui), ne}, {d.cyoung, s->conc_young, ne}, {d.hyoung, s->h_young, ne}, {d.hsyoung, s->hs_young, ne}, {d.drag_ui_young, H(s->drag_ui_young), ne},
+                     {d.UT, s->UT, n2}, {d.s0, s->sigma[0], ne}, {d.s1, s->sigma[1], ne}, {d.s2, s->sigma[2], ne}, {d.damage, s->damage, ne},
+                     {d.ridge, s->ridge_ratio, ne}, {d.cmyi, s->conc_myi, ne}, {d.tmyi, s->thick_myi, ne}};
+    for (const Cp &c : up) pin_host_buffer(h, c.host, c.bytes);
     h->sig_loc = 0;   // M_sigma and M_damage arrive as arrays (all four: nothing of the records is kept)
-    for (const Cp &c : early) HIPCHK(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->stream));
-    // the late copies start BEHIND the early ones (both directions of a link are one copy engine each: side by side they would only delay what the kernels wait
-    // for) -- and so behind every kernel of the step before, which may still read those arrays
-    HIPCHK(h, hipEventRecord(h->ev_solved, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_solved, 0));
-    for (const Cp &c : late) HIPCHK(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->copy_stream));
-    HIPCHK(h, hipEventRecord(h->ev_late, h->copy_stream));
-    if (dbg) { (void)hipEventRecord(te[1], h->stream); (void)hipEventRecord(te[2], h->copy_stream); }
+    for (const Cp &c : up) HIPCHK(h, hipMemcpyAsync(c.dev, c.host, c.bytes, hipMemcpyHostToDevice, h->stream));
     h->have_state = true; h->have_forcing = true;
-    h->wait_before_update = h->ev_late; h->record_after_solve = h->ev_solved;
-    rc = nxs_dyn_step(h);
-    h->wait_before_update = nullptr; h->record_after_solve = nullptr;
-    if (rc) { (void)hipStreamSynchronize(h->copy_stream); (void)hipStreamSynchronize(h->stream); return rc; }
-    if (dbg) (void)hipEventRecord(te[3], h->stream);
-    HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->ev_solved, 0));
-    for (const Cp &c : {Cp{d.VT, s->VT, n2}, Cp{d.UM, s->UM, n2}, Cp{d.UT, s->UT, n2}}) HIPCHK(h, hipMemcpyAsync(c.host, c.dev, c.bytes, hipMemcpyDeviceToHost, h->copy_stream));
-    if (h->res_ready || h->flow_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); if ((rc = resident_error(h))) { (void)hipStreamSynchronize(h->copy_stream); return rc; } }
+    if ((rc = nxs_dyn_step(h))) { (void)hipStreamSynchronize(h->stream); return rc; }
+    if (h->res_ready || h->flow_ready) { HIPCHK(h, hipStreamSynchronize(h->stream)); if ((rc = resident_error(h))) return rc; }
     ensure_arrays(h);
-    std::vector<Cp> down = {{d.conc, s->conc, ne}, {d.thick, s->thick, ne}, {d.snow, s->snow_thick, ne}, {d.damage, s->damage, ne}, {d.ridge, s->ridge_ratio, ne},
-                            {d.s0, s->sigma[0], ne}, {d.s1, s->sigma[1], ne}, {d.s2, s->sigma[2], ne}, {d.cmyi, s->conc_myi, ne}, {d.tmyi, s->thick_myi, ne}};
-    if (young) down.insert(down.end(), ytrio.begin(), ytrio.begin() + 3);
+    const Cp down[] = {{d.VT, s->VT, n2}, {d.UM, s->UM, n2}, {d.UT, s->UT, n2}, {d.conc, s->conc, ne}, {d.thick, s->thick, ne}, {d.snow, s->snow_thick, ne}, {d.damage, s->damage, ne},
+                       {d.ridge, s->ridge_ratio, ne}, {d.s0, s->sigma[0], ne}, {d.s1, s->sigma[1], ne}, {d.s2, s->sigma[2], ne}, {d.cmyi, s->conc_myi, ne}, {d.tmyi, s->thick_myi, ne}};
     for (const Cp &c : down) HIPCHK(h, hipMemcpyAsync(c.host, c.dev, c.bytes, hipMemcpyDeviceToHost, h->stream));
-    if (dbg) { (void)hipEventRecord(te[4], h->copy_stream); (void)hipEventRecord(te[5], h->stream); }
-    HIPCHK(h, hipStreamSynchronize(h->copy_stream));
+    if (h->dp.young_cat)   // (without the category update() leaves the trio alone: the host's copy is the current one)
+        for (const Cp &c : {Cp{d.cyoung, s->conc_young, ne}, Cp{d.hyoung, s->h_young, ne}, Cp{d.hsyoung, s->hs_young, ne}}) HIPCHK(h, hipMemcpyAsync(c.host, c.dev, c.bytes, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
-    if (dbg) {
-        float ms[6] = {};
-        for (int i = 1; i <= 5; ++i) (void)hipEventElapsedTime(&ms[i], te[0], te[i]);
-        fprintf(stderr, "[nxs] step_host: early uploads done %.2f ms, late uploads done %.2f, step done %.2f, nodal downloads done %.2f, all downloads done %.2f\n", ms[1], ms[2], ms[3], ms[4], ms[5]);
-        for (auto &e : te) (void)hipEventDestroy(e);
-    }
     return NXS_OK;
 } catch (...) { return dyn_caught(h, "nxs_dyn_step_host"); }
 

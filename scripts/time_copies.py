@@ -25,6 +25,9 @@ fe.step(); fe.synchronize()
 t = time.perf_counter()
 for _ in range(10): fe.step()
 fe.synchronize(); print(f"step: {(time.perf_counter() - t) / 10 * 1e3:.2f} ms")
+print("phases of the resident step:", {k: round(v, 3) for k, v in fe.timing().items() if k.endswith("_ms")})
+fe.set_option("timing_reset", 1)
 t = time.perf_counter()
 for _ in range(10): assert fe.L.nxs_dyn_step_host(fe.h, C.byref(ss), C.byref(fo)) == 0
 print(f"step_host: {(time.perf_counter() - t) / 10 * 1e3:.2f} ms")
+print("phases of the step inside step_host:", {k: round(v, 3) for k, v in fe.timing().items() if k.endswith("_ms")})
