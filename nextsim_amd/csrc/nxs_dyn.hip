@@ -261,6 +261,7 @@ void release_resident(nxs_dyn_handle *h);
 void release_graph(nxs_dyn_handle *h);
 bool multi_rank(const nxs_dyn_handle *h);
 void register_waiting_grid(nxs_dyn_handle *h, int blocks, int slots, bool reset = false);
+void register_smoother_grid(nxs_dyn_handle *h);
 
 int fail(nxs_dyn_handle *h, int code, const char *fmt, ...) {
     char buf[512];
@@ -752,7 +753,7 @@ int nxs_dyn_set_option(nxs_dyn_handle *h, const char *key, int64_t value) try {
         return NXS_OK;
     }
     if (!std::strcmp(key, "resident_release")) { h->hf.no_release = value == 0 ? 1 : 0; h->res_no_release = h->hf.no_release; h->d_hf_dirty = true; release_graph(h); return NXS_OK; }
-    if (!std::strcmp(key, "smooth_persist")) { h->smooth_persist = (int)value; release_graph(h); return NXS_OK; }
+    if (!std::strcmp(key, "smooth_persist")) { h->smooth_persist = (int)value; release_graph(h); HIPCHK(h, hipSetDevice(h->device)); register_smoother_grid(h); return NXS_OK; }
     if (!std::strcmp(key, "halo_one_directional")) { h->one_directional = value != 0; return NXS_OK; }   // test door: before nxs_dyn_set_halo
     if (!std::strcmp(key, "fused")) {
         if (value < 0 || value > 4) return fail(h, NXS_ERR_INVALID, "fused must be 0, 1, 2, 3 or 4");
@@ -1153,11 +1154,7 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
     if (h->fused == 4 && halo->nranks > 1 && h->band_nodes != 0) {   // cut for the resident loop before the lists were known: again, with every sent node in the band
         if ((rc = upload_patches(h))) return rc;
     }
-    {   // k_smooth_halo's blocks (one per BLOCK own nodes) spin for a neighbour's sweep, k_halo_pull's (one per BLOCK ghosts) for its flags
-        int per_cu = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_smooth_halo, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
-        register_waiting_grid(h, halo->nranks > 1 ? std::max(nblocks(No), nblocks(tr)) : 0, per_cu * device_cus(h), true);
-    }
+    register_smoother_grid(h);
     return NXS_OK;
 } catch (...) { return dyn_caught(h, "nxs_dyn_set_halo"); }
 
@@ -1942,6 +1939,19 @@ void register_waiting_grid(nxs_dyn_handle *h, int blocks, int slots, bool reset)
     if (reset) { h->ord_blocks = 0; h->ord_slots = 0; }
     if (blocks > 0 && slots > 0 && (h->ord_blocks == 0 || (double)blocks / slots > (double)h->ord_blocks / h->ord_slots)) { h->ord_blocks = blocks; h->ord_slots = slots; }
     nxs_reg::table_for(h->reg_key).set_ordinary((uint64_t)(uintptr_t)h, h->ord_blocks, h->ord_slots);
+}
+
+// ... the smoother's: k_smooth_persist runs at most 128 persistent workgroups that wait for each other and for the neighbour ranks; with option smooth_persist 0 every
+// block of k_smooth_halo (one per BLOCK own nodes) may spin for a neighbour's sweep; k_halo_pull's blocks (one per BLOCK ghosts) spin for its flags.  Called where the
+// halo lists are set and where the option changes.
+void register_smoother_grid(nxs_dyn_handle *h) {
+    if (!h->have_halo) return;
+    const int No = h->dm.No, tr = h->recv_offsets[h->recv_procs.size()];
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_smooth_halo, BLOCK, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+    const int sweeps = h->smooth_persist != 0 ? std::min(nblocks(No), 128) : nblocks(No);
+    register_waiting_grid(h, h->nranks > 1 ? std::max(sweeps, nblocks(tr)) : 0, per_cu * device_cus(h), true);
+    if (h->hf_ready) register_waiting_grid(h, h->hf.n_boundary, 2 * device_cus(h));   // (the boundary patches of k_substep_fused<HALO>, as build_halo_fused registers them)
 }
 
 // tables of the halo exchange fused into the sub-step kernel (see HaloFused)
