@@ -1097,19 +1097,11 @@ int nxs_dyn_set_halo(nxs_dyn_handle *h, const nxs_dyn_halo *halo) try {
     if (nr > 0) h->recv_offsets.assign(halo->recv_offsets, halo->recv_offsets + nr + 1); else h->recv_offsets.assign(1, 0);
     h->ns_caller = ns; h->nr_caller = nr;
     const int ts = h->send_offsets[ns], tr = h->recv_offsets[nr];
-    for (int side = 0; side < 2; ++side) {   // a neighbour is named once per list (the padding below and the mailbox's flag slots rely on it)
-        std::vector<int> v(side ? h->recv_procs : h->send_procs);
-        std::sort(v.begin(), v.end());
-        const auto dup = std::adjacent_find(v.begin(), v.end());
-        if (dup != v.end()) return fail(h, NXS_ERR_INVALID, "%s_procs names rank %d twice", side ? "recv" : "send", *dup);
-    }
-    if (!h->one_directional) {
-        // NEIGHBOURS IN BOTH DIRECTIONS (include/nxs_dyn.h): M_recipients_proc_id and M_local_ghosts_proc_id of a ragged partition need not be the same set.  The
-        // direction that carries no node is added here as an empty segment, BEHIND the caller's neighbours (its numbers k and offsets stay valid); the rank at the
-        // other end does the same from its own lists, so both agree without communication.
-        const std::vector<int> sp0(h->send_procs), rp0(h->recv_procs);
-        for (int q : rp0) if (std::find(sp0.begin(), sp0.end(), q) == sp0.end()) { h->send_procs.push_back(q); h->send_offsets.push_back(ts); }
-        for (int q : sp0) if (std::find(rp0.begin(), rp0.end(), q) == rp0.end()) { h->recv_procs.push_back(q); h->recv_offsets.push_back(tr); }
+    {   // NEIGHBOURS IN BOTH DIRECTIONS (include/nxs_dyn.h): a direction that carries no node is added as an empty segment BEHIND the caller's neighbours
+        std::vector<int> sp(h->send_procs), so(h->send_offsets), rp(h->recv_procs), ro(h->recv_offsets);
+        const std::string bad = nxs_cut::pad_halo_directions(sp, so, rp, ro);   // (also refuses a rank named twice)
+        if (!bad.empty()) return fail(h, NXS_ERR_INVALID, "%s", bad.c_str());
+        if (!h->one_directional) { h->send_procs = sp; h->send_offsets = so; h->recv_procs = rp; h->recv_offsets = ro; }
     }
     std::vector<int> sidx(halo->send_index, halo->send_index + ts), ridx(halo->recv_index, halo->recv_index + tr);
     h->h_send_index = sidx; h->h_recv_index = ridx;

@@ -49,6 +49,25 @@ struct MeshView {
     const char *sent = nullptr;     // [No] several ranks, once the halo lists are known: != 0 = an own node this rank sends to a neighbour (else NULL)
 };
 
+// initUpdateGhosts' neighbour lists made mutual (nxs_dyn_set_halo; FE.cpp:14003-14088 leaves M_recipients_proc_id and M_local_ghosts_proc_id as two sets that a
+// ragged partition makes differ): every rank of one list that is missing from the other is APPENDED there with an empty segment -- behind the caller's neighbours,
+// whose numbers and offsets stay what they were.  Both ranks of a one-directional link do this from their own lists and so agree without talking.  Returns "" or what
+// is wrong with the lists (a rank named twice; offsets that do not match).  Host only; tests/native/patchcut_host.cpp::pc_pad_halo.
+inline std::string pad_halo_directions(std::vector<int> &send_procs, std::vector<int> &send_offsets, std::vector<int> &recv_procs, std::vector<int> &recv_offsets) {
+    if (send_offsets.size() != send_procs.size() + 1 || recv_offsets.size() != recv_procs.size() + 1) return "offsets do not match the neighbour lists";
+    for (int side = 0; side < 2; ++side) {   // a neighbour is named once per list (the padding and the mailbox's flag slots rely on it)
+        std::vector<int> v(side ? recv_procs : send_procs);
+        std::sort(v.begin(), v.end());
+        const auto dup = std::adjacent_find(v.begin(), v.end());
+        if (dup != v.end()) return std::string(side ? "recv" : "send") + "_procs names rank " + std::to_string(*dup) + " twice";
+    }
+    const std::vector<int> sp0(send_procs), rp0(recv_procs);
+    const int ts = send_offsets.back(), tr = recv_offsets.back();
+    for (int q : rp0) if (std::find(sp0.begin(), sp0.end(), q) == sp0.end()) { send_procs.push_back(q); send_offsets.push_back(ts); }
+    for (int q : sp0) if (std::find(rp0.begin(), rp0.end(), q) == rp0.end()) { recv_procs.push_back(q); recv_offsets.push_back(tr); }
+    return "";
+}
+
 // node -> elements CSR, ascending element number per node
 inline void node_fans(const std::vector<int> t[3], int Nn, int Ne, std::vector<int> &off, std::vector<int> &adj) {
     off.assign((size_t)Nn + 1, 0);

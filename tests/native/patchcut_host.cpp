@@ -464,6 +464,26 @@ int pc_pair_mr(const int32_t *indices, const uint8_t *ghost3, const double *x, c
 } catch (...) { return caught(msg, msg_cap); }
 
 // The Hilbert order alone: any coordinates (NaN, infinities, all equal) must give a permutation
+// nxs_dyn_set_halo's padding of one-directional neighbours (nxs_cut::pad_halo_directions): lists in, padded lists out (capacity cap entries each); returns 0,
+// 1 (msg: what is wrong with the lists) or a guard code.  *ns / *nr are updated.
+int pc_pad_halo(int32_t *send_procs, int32_t *send_offsets, int *ns, int32_t *recv_procs, int32_t *recv_offsets, int *nr, int cap, char *msg, int msg_cap) try {
+    put_msg(msg, msg_cap, "");
+    std::vector<int> sp(send_procs, send_procs + *ns), so(send_offsets, send_offsets + *ns + 1), rp(recv_procs, recv_procs + *nr), ro(recv_offsets, recv_offsets + *nr + 1);
+    const std::vector<int> sp0(sp), so0(so), rp0(rp), ro0(ro);
+    const std::string bad = pad_halo_directions(sp, so, rp, ro);
+    if (!bad.empty()) { put_msg(msg, msg_cap, bad); return 1; }
+    // what set_halo relies on: the caller's entries untouched in front, every partner in both lists, the added segments empty, totals unchanged
+    REQUIRE(std::equal(sp0.begin(), sp0.end(), sp.begin()) && std::equal(so0.begin(), so0.end(), so.begin()), "the caller's send entries moved%s", "");
+    REQUIRE(std::equal(rp0.begin(), rp0.end(), rp.begin()) && std::equal(ro0.begin(), ro0.end(), ro.begin()), "the caller's receive entries moved%s", "");
+    { std::vector<int> a(sp), b(rp); std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end()); REQUIRE(a == b, "the two lists still differ%s", ""); }
+    for (size_t k = sp0.size(); k < sp.size(); ++k) REQUIRE(so[k + 1] == so[k] && so[k] == so0.back(), "added send segment %zu is not empty", k);
+    for (size_t k = rp0.size(); k < rp.size(); ++k) REQUIRE(ro[k + 1] == ro[k] && ro[k] == ro0.back(), "added receive segment %zu is not empty", k);
+    REQUIRE((int)sp.size() <= cap && (int)rp.size() <= cap, "capacity %d too small", cap);
+    std::copy(sp.begin(), sp.end(), send_procs); std::copy(so.begin(), so.end(), send_offsets); *ns = (int)sp.size();
+    std::copy(rp.begin(), rp.end(), recv_procs); std::copy(ro.begin(), ro.end(), recv_offsets); *nr = (int)rp.size();
+    return 0;
+} catch (...) { return caught(msg, msg_cap); }
+
 int pc_hilbert(const double *x, const double *y, int n, int32_t *order_out, char *msg, int msg_cap) try {
     std::vector<int> order;
     hilbert_order(x, y, n, order);

@@ -283,6 +283,32 @@ line_t = i32(np.array([1, 2, 3]))                   # a degenerate triangle: eve
 cut.pc_hull(_abi.iptr(line_t), _abi.dptr(np.array([0., 1., 2.])), _abi.dptr(np.array([0., 1., 2.])), 3, 1, 1, hs.ctypes.data_as(I64), msg, 256)
 assert hs[0] == 0
 # 4g. the guard of the ABI (nxs_guard.hpp): length_error / bad_alloc -> NXS_ERR_NOMEM, anything else -> NXS_ERR_INTERNAL, with a text
+# nxs_dyn_set_halo's padding of one-directional neighbours (nxs_cut::pad_halo_directions, the very text libnxsdyn.so includes): every partition of the test
+# meshes as initUpdateGhosts leaves its lists, hand-made lists (both directions missing, nothing missing, no neighbour at all), and lists it must refuse
+cut.pc_pad_halo.argtypes = [IP, IP, C.POINTER(C.c_int), IP, IP, C.POINTER(C.c_int), C.c_int, C.c_char_p, C.c_int]
+def pad(sp, so, rp, ro, expect=0):
+    cap = 64
+    a = [np.zeros(cap + 1, np.int32) for _ in range(4)]
+    for buf, v in zip(a, (sp, so, rp, ro)): buf[:len(v)] = v
+    ns, nr = C.c_int(len(sp)), C.c_int(len(rp))
+    rc = cut.pc_pad_halo(_abi.iptr(a[0]), _abi.iptr(a[1]), C.byref(ns), _abi.iptr(a[2]), _abi.iptr(a[3]), C.byref(nr), cap, msg, 256)
+    assert rc == expect, (rc, msg.value)
+    return a[0][:ns.value].tolist(), a[1][:ns.value + 1].tolist(), a[2][:nr.value].tolist(), a[3][:nr.value + 1].tolist()
+one_directional = 0
+for kind, nparts, seed in (("small", 4, None), ("small", 3, 1), ("small", 4, 2), ("small", 8, None), ("40km", 4, 3)):
+    lms_p = M.localize(cases.global_mesh(kind), nparts, elem_part=cases.ragged_partition(cases.global_mesh(kind), nparts, seed) if seed is not None else None)
+    padded = [pad(lm.send_procs.tolist(), lm.send_offsets.tolist(), lm.recv_procs.tolist(), lm.recv_offsets.tolist()) for lm in lms_p]
+    for r, (sp, so, rp, ro) in enumerate(padded):
+        one_directional += len(sp) != len(lms_p[r].send_procs) or len(rp) != len(lms_p[r].recv_procs)
+        for k, q in enumerate(sp):     # what I send to q is what q expects from me, the added directions included: both ends padded alike without talking
+            qsp, qso, qrp, qro = padded[q]
+            kk = qrp.index(r)
+            assert so[k + 1] - so[k] == qro[kk + 1] - qro[kk], (kind, nparts, r, q)
+assert one_directional > 0               # (the regular 4-rank partition of 'small' has one: rank 0 -> rank 3)
+assert pad([1, 2], [0, 3, 5], [3], [0, 4]) == ([1, 2, 3], [0, 3, 5, 5], [3, 1, 2], [0, 4, 4, 4])
+assert pad([2, 1], [0, 1, 2], [1, 2], [0, 5, 9]) == ([2, 1], [0, 1, 2], [1, 2], [0, 5, 9])
+assert pad([], [0], [], [0]) == ([], [0], [], [0])
+pad([1, 1], [0, 1, 2], [1], [0, 2], expect=1); assert b"twice" in msg.value
 assert cut.pc_guard_selftest(0, msg, 256) == -6 and b"length_error" in msg.value
 assert cut.pc_guard_selftest(1, msg, 256) == -6 and b"bad_alloc" in msg.value
 assert cut.pc_guard_selftest(2, msg, 256) == -7 and b"boom" in msg.value
