@@ -1464,7 +1464,9 @@ int nxs_dyn_ipc_connect_records(nxs_dyn_handle *h, const void *records, int64_t 
         std::memcpy(&hd, rec + NXS_IPC_BLOB_BYTES, sizeof hd);
         if (hd.magic != IPC_RECORD_MAGIC || hd.rank != q) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: record %d was not made by nxs_dyn_ipc_export_record on rank %d", q, q);
         if (hd.nr < 0 || (int64_t)ipc_record_size(hd.nr) > stride) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: record %d names %d receive neighbours, more than the stride holds", q, hd.nr);
-        const int32_t *rp = reinterpret_cast<const int32_t *>(rec + NXS_IPC_BLOB_BYTES + sizeof hd), *ro = rp + hd.nr;
+        std::vector<int32_t> lists(2 * (size_t)hd.nr + 1);   // (copied out: a caller's byte buffer owes no alignment)
+        std::memcpy(lists.data(), rec + NXS_IPC_BLOB_BYTES + sizeof hd, lists.size() * sizeof(int32_t));
+        const int32_t *rp = lists.data(), *ro = rp + hd.nr;
         int me = -1;
         for (int j = 0; j < hd.nr; ++j) if (rp[j] == h->rank) { me = j; break; }
         if (me < 0) return fail(h, NXS_ERR_INVALID, "ipc_connect_records: rank %d does not list rank %d among its receive neighbours (its halo lists and mine disagree)", q, h->rank);
