@@ -2414,21 +2414,27 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
     // HALO: where this thread's halo slot gets its velocity from, and where this thread's own node is sent to -- bit 31: it is sent somewhere;
     // bit 30: to more than one neighbour rank (a corner of the partition: the tables are walked as in k_substep_fused); else bits 29-26 the
     // neighbour, bits 25-0 the position in its segment
+    // A corner of the partition: bit 30 says "and to a second neighbour rank", whose word (same form) sits in the free lane of lH[t]; its bit 30: "and to more"
+    // -- only those walk the tables, from the third entry on (the walk is three dependent loads in front of the stores, on the exchange's critical path: the patch
+    // with a corner node used to finish its node phase 2 us after the others, every sub-step)
     unsigned sinfo = 0u;
     if (HALO) {
+        int second = 0;
+        if (boundary && has_node) {
+            const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
+            if (sq1 > sq0) sinfo = 0x80000000u | (sq1 - sq0 > 1 ? 0x40000000u : 0u) | ((unsigned)hfp->send_k[sq0] << 26) | (unsigned)hfp->send_pos[sq0];
+            if (sq1 - sq0 > 1) second = (int)(0x80000000u | (sq1 - sq0 > 2 ? 0x40000000u : 0u) | ((unsigned)hfp->send_k[sq0 + 1] << 26) | (unsigned)hfp->send_pos[sq0 + 1]);
+        }
         if (nO + t < nM) {
             const int g = pn[nO + t];
-            lH[t] = (g >= m.No) ? make_int4(hfp->ghost_off[g - m.No], hfp->ghost_srl[g - m.No], g - m.No, 0) : make_int4(g, -1, 0, 0);
+            lH[t] = (g >= m.No) ? make_int4(hfp->ghost_off[g - m.No], hfp->ghost_srl[g - m.No], g - m.No, second) : make_int4(g, -1, 0, second);
+        } else if (has_node) {
+            lH[t] = make_int4(0, -1, 0, second);
         }
         if (t < hfp->ipc.ns && t < NXS_RES_MAXNB) {
             lPeerSeg[t] = hfp->ipc.peer_seg[t];
             lPeerStride[t] = hfp->ipc.peer_parity_stride[t];
             lPeerVd[t] = hfp->send_off[t + 1] - hfp->send_off[t];
-        }
-        if (boundary && has_node) {
-            const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
-            if (sq1 - sq0 == 1) sinfo = 0x80000000u | ((unsigned)hfp->send_k[sq0] << 26) | (unsigned)hfp->send_pos[sq0];
-            else if (sq1 > sq0) sinfo = 0xC0000000u;
         }
     }
     __syncthreads();
@@ -2547,18 +2553,29 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
             }
             unsigned si = sinfo;
             if (HALO) asm volatile("" : "+v"(si));  // (decoded here every sub-step: hoisted out of the loop, neighbour, position and the LDS addresses would each hold a register across it)
-            if (HALO && (si & 0x80000000u) && !(si & 0x40000000u)) {  // updateGhosts, sending side: straight into the neighbour rank's mailbox
-                const unsigned k = (si >> 26) & 15u;
-                double *dst = lPeerSeg[k] + ((x0 + (unsigned long long)ss) & 1ull) * lPeerStride[k] + (si & 0x3FFFFFFu);
-                sys_store(dst, uice);
-                sys_store(dst + lPeerVd[k], vice);
-            } else if (HALO && (si & 0x40000000u)) {  // ... into several (as k_substep_fused)
-                const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
-                for (int qq = sq0; qq < sq1; ++qq) {
-                    const int k = hfp->send_k[qq];
-                    double *dst = hfp->ipc.peer_seg[k] + ((x0 + (unsigned long long)ss) & 1ull) * hfp->ipc.peer_parity_stride[k] + hfp->send_pos[qq];
+            if (HALO && (si & 0x80000000u)) {  // updateGhosts, sending side: straight into the neighbour rank's mailbox
+                const unsigned long long half = (x0 + (unsigned long long)ss) & 1ull;
+                {
+                    const unsigned k = (si >> 26) & 15u;
+                    double *dst = lPeerSeg[k] + half * lPeerStride[k] + (si & 0x3FFFFFFu);
                     sys_store(dst, uice);
-                    sys_store(dst + (hfp->send_off[k + 1] - hfp->send_off[k]), vice);
+                    sys_store(dst + lPeerVd[k], vice);
+                }
+                if (si & 0x40000000u) {  // ... a second one's
+                    const unsigned s2 = (unsigned)lH[tt].w;
+                    const unsigned k = (s2 >> 26) & 15u;
+                    double *dst = lPeerSeg[k] + half * lPeerStride[k] + (s2 & 0x3FFFFFFu);
+                    sys_store(dst, uice);
+                    sys_store(dst + lPeerVd[k], vice);
+                    if (s2 & 0x40000000u) {  // ... and more (as k_substep_fused, from the third entry)
+                        const int sq0 = hfp->send_ptr[n], sq1 = hfp->send_ptr[n + 1];
+                        for (int qq = sq0 + 2; qq < sq1; ++qq) {
+                            const int kk = hfp->send_k[qq];
+                            double *d3 = hfp->ipc.peer_seg[kk] + half * hfp->ipc.peer_parity_stride[kk] + hfp->send_pos[qq];
+                            sys_store(d3, uice);
+                            sys_store(d3 + (hfp->send_off[kk + 1] - hfp->send_off[kk]), vice);
+                        }
+                    }
                 }
             }
         }
@@ -2724,7 +2741,10 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
     double *lu = lds, *lv = lu + Mmax, *lF = lv + Mmax /*d2 [3][Emax] + 1*/;
     d2 *lF2 = reinterpret_cast<d2 *>(lF);
     uint4 *lFan4 = reinterpret_cast<uint4 *>(lF + 6 * (size_t)Emax + 2);  // [Pmax] the first eight fan entries of every own node as indices into lF2 (16 bits each)
-    int4 *lH = reinterpret_cast<int4 *>(lFan4 + Pmax);                    // HALO: [Mmax] halo slot i - nO: {node, -1, -, -} or, a ghost, {offset of u in a mailbox half, distance to v, ghost number, -}
+    int4 *lH = reinterpret_cast<int4 *>(lFan4 + Pmax);                    // HALO: [Mmax] halo slot i - nO: {node, -1, -, .} or, a ghost, {offset of u in a mailbox half, distance to v, ghost number, .}; fourth lane: see below
+    double **lPeerSeg = reinterpret_cast<double **>(lH + Mmax);           // HALO: [NXS_RES_MAXNB] the neighbour ranks' mailbox segments for my values,
+    long long *lPeerStride = reinterpret_cast<long long *>(lPeerSeg + NXS_RES_MAXNB);  // the distance of their second half,
+    int *lPeerVd = reinterpret_cast<int *>(lPeerStride + NXS_RES_MAXNB);                // and of the v-block inside a segment
     const unsigned ZIDX = 3u * (unsigned)Emax;
     __shared__ int lerr;
     auto xcd_remap = [](int pos, int n) {  // position in dispatch order -> index (see k_substep_fused)
@@ -2809,19 +2829,36 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             lFan4[sl] = make_uint4(idx[0] | (idx[1] << 16), idx[2] | (idx[3] << 16), idx[4] | (idx[5] << 16), idx[6] | (idx[7] << 16));
             um[i][0] = s.UM[n[i]]; um[i][1] = s.UM[n[i] + Nn]; um[i][2] = s.UT[n[i]]; um[i][3] = s.UT[n[i] + Nn];
-            if (HALO && boundary) {
+            if (HALO && boundary) {  // (bit 30: and to a second neighbour rank -- lH[sl].w, see k_substep_resident)
                 const int sq0 = hfp->send_ptr[n[i]], sq1 = hfp->send_ptr[n[i] + 1];
-                if (sq1 - sq0 == 1) sinfo[i] = 0x80000000u | ((unsigned)hfp->send_k[sq0] << 26) | (unsigned)hfp->send_pos[sq0];
-                else if (sq1 > sq0) sinfo[i] = 0xC0000000u;
+                if (sq1 > sq0) sinfo[i] = 0x80000000u | (sq1 - sq0 > 1 ? 0x40000000u : 0u) | ((unsigned)hfp->send_k[sq0] << 26) | (unsigned)hfp->send_pos[sq0];
             }
         }
     }
     int nbr = -1;
     if (t < nNb) nbr = r.pnbr[(size_t)blk * NXS_RES_NBR + t];
     if (HALO) {
-        for (int i = nO + t; i < nM; i += T) {
-            const int g = pn[i];
-            lH[i - nO] = (g >= m.No) ? make_int4(hfp->ghost_off[g - m.No], hfp->ghost_srl[g - m.No], g - m.No, 0) : make_int4(g, -1, 0, 0);
+        // entry j: halo slot nO + j -- {node, -1, -, .} or, a ghost, {offset of u in a mailbox half, distance to v, ghost number, .} -- and, in its fourth lane,
+        // the SECOND neighbour rank own node j is sent to (a corner of the partition; the form of sinfo, bit 30: "and to more": those walk the tables)
+        const int nH = nM - nO, top = nH > nO ? nH : nO;
+        for (int j = t; j < top; j += T) {
+            int second = 0;
+            if (boundary && j < nO) {
+                const int g = pn[j];
+                const int sq0 = hfp->send_ptr[g], sq1 = hfp->send_ptr[g + 1];
+                if (sq1 - sq0 > 1) second = (int)(0x80000000u | (sq1 - sq0 > 2 ? 0x40000000u : 0u) | ((unsigned)hfp->send_k[sq0 + 1] << 26) | (unsigned)hfp->send_pos[sq0 + 1]);
+            }
+            int4 hv = make_int4(0, -1, 0, second);
+            if (j < nH) {
+                const int g = pn[nO + j];
+                hv = (g >= m.No) ? make_int4(hfp->ghost_off[g - m.No], hfp->ghost_srl[g - m.No], g - m.No, second) : make_int4(g, -1, 0, second);
+            }
+            lH[j] = hv;
+        }
+        if (t < hfp->ipc.ns && t < NXS_RES_MAXNB) {
+            lPeerSeg[t] = hfp->ipc.peer_seg[t];
+            lPeerStride[t] = hfp->ipc.peer_parity_stride[t];
+            lPeerVd[t] = hfp->send_off[t + 1] - hfp->send_off[t];
         }
     }
     __syncthreads();
@@ -2941,13 +2978,29 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 double *X = (ss & 1) ? r.X1 : r.X0;
                 st_agent(X + n[i], uice); st_agent(X + n[i] + Nn, vice);
             }
-            if (HALO && (sinfo[i] & 0x80000000u)) {  // updateGhosts, sending side: straight into the neighbour ranks' mailboxes (as k_substep_fused)
-                const int sq0 = hfp->send_ptr[n[i]], sq1 = hfp->send_ptr[n[i] + 1];
-                for (int qq = sq0; qq < sq1; ++qq) {
-                    const int k = hfp->send_k[qq];
-                    double *dst = hfp->ipc.peer_seg[k] + ((x0 + (unsigned long long)ss) & 1ull) * hfp->ipc.peer_parity_stride[k] + hfp->send_pos[qq];
+            if (HALO && (sinfo[i] & 0x80000000u)) {  // updateGhosts, sending side: straight into the neighbour ranks' mailboxes, from what was looked up once
+                const unsigned long long half = (x0 + (unsigned long long)ss) & 1ull;
+                {
+                    const unsigned k = (sinfo[i] >> 26) & 15u;
+                    double *dst = lPeerSeg[k] + half * lPeerStride[k] + (sinfo[i] & 0x3FFFFFFu);
                     sys_store(dst, uice);
-                    sys_store(dst + (hfp->send_off[k + 1] - hfp->send_off[k]), vice);
+                    sys_store(dst + lPeerVd[k], vice);
+                }
+                if (sinfo[i] & 0x40000000u) {
+                    const unsigned s2 = (unsigned)lH[sl].w;
+                    const unsigned k = (s2 >> 26) & 15u;
+                    double *dst = lPeerSeg[k] + half * lPeerStride[k] + (s2 & 0x3FFFFFFu);
+                    sys_store(dst, uice);
+                    sys_store(dst + lPeerVd[k], vice);
+                    if (s2 & 0x40000000u) {  // more than two neighbour ranks share the node: the rest as k_substep_fused
+                        const int sq0 = hfp->send_ptr[n[i]], sq1 = hfp->send_ptr[n[i] + 1];
+                        for (int qq = sq0 + 2; qq < sq1; ++qq) {
+                            const int kk = hfp->send_k[qq];
+                            double *d3 = hfp->ipc.peer_seg[kk] + half * hfp->ipc.peer_parity_stride[kk] + hfp->send_pos[qq];
+                            sys_store(d3, uice);
+                            sys_store(d3 + (hfp->send_off[kk + 1] - hfp->send_off[kk]), vice);
+                        }
+                    }
                 }
             }
         }

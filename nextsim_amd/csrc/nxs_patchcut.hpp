@@ -429,7 +429,7 @@ inline size_t resident_lds_of(const HostPatches &hp, bool multi_rank) {
            (multi_rank ? 16 * (size_t)std::min(hp.Mmax, 512) + 20 * (size_t)NXS_CUT_RES_MAXNB : 0);
 }
 inline size_t resident_big_lds_of(const HostPatches &hp, bool multi_rank) {
-    return (2 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax + (multi_rank ? 16 * (size_t)hp.Mmax : 0);
+    return (2 * (size_t)hp.Mmax + 6 * (size_t)hp.Emax + 2) * sizeof(double) + 16 * (size_t)hp.Pmax + (multi_rank ? 16 * (size_t)hp.Mmax + 20 * (size_t)NXS_CUT_RES_MAXNB : 0);
 }
 inline bool resident_is_big(const HostPatches &hp) { return hp.Emax > 512 * NXS_CUT_RES_EPT || hp.Pmax > 512; }
 
