@@ -1343,9 +1343,11 @@ __global__ void __launch_bounds__(T) k_substep_fused(DevMesh m, DevPatches pp, D
         if (t == 0) {
             const long long t0 = wall_clock64();  // 100 MHz
             bool ok = true;
+            unsigned polls = 0u;
             for (int k = 0; k < hfp->ipc.nr && ok; ++k)
                 while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < xseq) {
-                    __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++polls & 31u) != 0u) continue;  // the error word is another round trip and the clock a few hundred cycles: every 32nd poll, so that a poll period is ONE round trip
                     if (__hip_atomic_load(hfp->ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost, do not wait again
                     if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hfp->ipc.error, 3); break; }  // 10 s
                 }
@@ -1821,9 +1823,11 @@ __device__ __forceinline__ void pair_body(const DevMesh &m, const DevPatches2 &p
         if (t == 0) {
             const long long t0 = wall_clock64();  // 100 MHz
             bool ok = true;
+            unsigned polls = 0u;
             for (int k = 0; k < hfp->ipc.nr && ok; ++k)
                 while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < want) {
-                    __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_s_sleep(2);
+                    if ((++polls & 31u) != 0u) continue;  // the error word is another round trip and the clock a few hundred cycles: every 32nd poll, so that a poll period is ONE round trip
                     if (__hip_atomic_load(hfp->ipc.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { ok = false; break; }  // a wait already timed out: the run is lost
                     if (wall_clock64() - t0 > 1000000000ll) { ok = false; atomicExch(hfp->ipc.error, 3); break; }  // 10 s
                 }
@@ -2589,11 +2593,13 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
         if (HALO && boundary && t == 0) {
             // the last boundary patch to finish this sub-step publishes it to the neighbour ranks -- in sub-step order: patches far
             // apart may be several sub-steps apart, so the one that completes sub-step ss waits for ss - 1 to have been published
+            unsigned raised = __hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (asked for together with the ticket: one round trip, not two; it only grows)
             if (atomicAdd(r.cnt + ss, 1u) == (unsigned)n_boundary - 1u) {
                 RSTAMP_PUB(1);   // (the last boundary patch of the sub-step: its ticket is back)
                 const long long t0 = wall_clock64();
-                while (__hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ss) {
+                while (raised < (unsigned)ss) {
                     __builtin_amdgcn_s_sleep(1);
+                    raised = __hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }  // 10 s, as every other inter-rank wait
                 }
                 nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
@@ -2617,8 +2623,10 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
         if (HALO && boundary && tt >= 64 && tt < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
             const int k = tt - 64;
             const long long t0 = wall_clock64();
+            unsigned polls = 0u;
             while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x0 + (unsigned long long)ss + 1ull) {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 31u) != 0u) continue;  // (error word and clock every 32nd poll: a poll period is one round trip, not two)
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
                 if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 7); break; }  // 10 s: the transport's bound (a neighbour rank may start its step late: output, a regrid, host thermodynamics)
             }
@@ -2628,8 +2636,10 @@ __device__ __forceinline__ void resident_body(const DevMesh &m, const DevPatches
         asm volatile("" : "+v"(nb));  // (its counter's address is formed here, not kept across the loop)
         if (nb >= 0) {
             const long long t0 = wall_clock64();  // 100 MHz
+            unsigned polls = 0u;
             while (__hip_atomic_load(r.flag + 32 * (size_t)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
                 __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 31u) != 0u) continue;  // (error word and clock every 32nd poll: a poll period is one round trip, not two)
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
                 if (wall_clock64() - t0 > 1200000000ll) { lerr = 1; atomicExch(r.error, 5); break; }  // 12 s: longer than the inter-rank waits, so that a late neighbour RANK is reported as that (7) by the patch that waits for it, not as a missing patch (5) by that patch's neighbours
             }
@@ -3011,10 +3021,12 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         RSTAMP(3);
         if (ss < S - 1 && t == 0) __hip_atomic_store(r.flag + 32 * (size_t)blk, (unsigned)(ss + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (HALO && boundary && t == 0) {  // the last boundary patch to finish this sub-step publishes it to the neighbour ranks, in sub-step order
+            unsigned raised = __hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (asked for together with the ticket, see k_substep_resident)
             if (atomicAdd(r.cnt + ss, 1u) == (unsigned)n_boundary - 1u) {
                 const long long t0 = wall_clock64();
-                while (__hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)ss) {
+                while (raised < (unsigned)ss) {
                     __builtin_amdgcn_s_sleep(1);
+                    raised = __hip_atomic_load(r.raised, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 6); break; }
                 }
                 nxs_delay_at(hfp->ipc.delay, NXS_DELAY_PUBLISH_FLAG);
@@ -3030,16 +3042,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
         if (HALO && boundary && t >= 64 && t < 64 + hfp->ipc.nr) {  // exchange x0 + ss of every neighbour rank must have landed
             const int k = t - 64;
             const long long t0 = wall_clock64();
+            unsigned polls = 0u;
             while (__hip_atomic_load(hfp->ipc.flags + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < x0 + (unsigned long long)ss + 1ull) {
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 31u) != 0u) continue;  // (error word and clock every 32nd poll: a poll period is one round trip, not two)
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
                 if (wall_clock64() - t0 > 1000000000ll) { lerr = 1; atomicExch(r.error, 7); break; }
             }
         }
         if (nbr >= 0) {
             const long long t0 = wall_clock64();  // 100 MHz
+            unsigned polls = 0u;
             while (__hip_atomic_load(r.flag + 32 * (size_t)nbr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(ss + 1)) {
                 __builtin_amdgcn_s_sleep(1);
+                if ((++polls & 31u) != 0u) continue;  // (error word and clock every 32nd poll: a poll period is one round trip, not two)
                 if (__hip_atomic_load(r.error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { lerr = 1; break; }
                 if (wall_clock64() - t0 > 1200000000ll) { lerr = 1; atomicExch(r.error, 5); break; }
             }
