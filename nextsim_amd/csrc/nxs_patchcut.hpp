@@ -942,9 +942,11 @@ inline std::string plan_pair_patches_mr(const MeshView &m, bool used_hilbert, in
         P = lo;
         if (last_built != P && !fits(P)) return "no patch size fits k_substep_pair";
     }
-    // whole rounds where the mesh is one or two rounds of workgroups (as plan_patches2)
+    // a whole round where the partition is ONE round of workgroups (as plan_patches2).  Two rounds keep the largest patches that fit: rank 0 of two of the 2 km
+    // mesh runs its 60 launches in 2.85-2.91 ms with 855-963 patches of 380-428 nodes and in 3.01 with 1 016 of 360 (two whole rounds: more ring for nothing,
+    // profiles/r05_experiments/r5_pairnodes.log)
     const int slots = 2 * cus, k = (out.hp.nP + slots - 1) / slots, P_fit = P;
-    if (k <= 2 && out.hp.nP > 0 && out.hp.nP != k * slots) {
+    if (k == 1 && out.hp.nP > 0 && out.hp.nP != k * slots) {
         int Pr = std::max(64, (int)((((long long)m.No + (long long)k * slots - 1) / ((long long)k * slots) + 3) & ~3ll));
         bool tried = false;
         for (int it = 0; it < 6 && Pr < P; ++it, Pr += 4) { tried = true; if (fits(Pr) && out.hp.nP <= k * slots) { P = Pr; break; } }

@@ -311,7 +311,9 @@ def test_one_directional_neighbours_are_padded_behind_the_abi_and_the_low_level_
                                                          (8, "10km", 2, {}, 1), (2, "40km", 1, {}, 1),
                                                          # overlap = 600: patches of 600 nodes asked for (cut to ~450: more than one element per thread) -> k_substep_resident_big
                                                          # (there the interior elements run ahead by default; -600: without)
-                                                         (2, "40km", 2, {}, 600), (3, "40km", 1, {"ragged_seed": 3, "dynamics_type": 3}, 600), (2, "40km", 2, {}, -600)])
+                                                         (2, "40km", 2, {}, 600), (3, "40km", 1, {"ragged_seed": 3, "dynamics_type": 3}, 600), (2, "40km", 2, {}, -600),
+                                                         # four ragged ranks: own nodes that three neighbour ranks hold as ghosts (the first two destinations looked up once, the third from the tables)
+                                                         (4, "40km", 2, {"ragged_seed": 3}, 600), (4, "small", 2, {}, 0)])
 def test_resident_sub_step_loop_with_the_mailbox_exchange_inside(world, kind, rpp, over, overlap, tmp_path):
     """Option fused = 4 on several ranks: ONE launch per rank for the whole sub-step loop; boundary patches send into the
     neighbour ranks' mailboxes and read their ghosts from their own once per sub-step, the last boundary patch of a sub-step
