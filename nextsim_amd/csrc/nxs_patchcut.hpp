@@ -725,6 +725,20 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
                     if (fits(Pr) && hp.nP <= k * slots) { P = Pr; break; }
                 }
                 if (tried && P == out.P_fit && !fits(P)) return "no patch size fits k_substep_pair";   // (the trials rebuilt hp: back to the size kept)
+            } else if (k >= 3) {
+                // Three rounds or more: the time of a launch steps up whenever the number of patches crosses a multiple of HALF a round (one workgroup per CU: a CU then
+                // runs one more patch behind the others), and falls slowly towards the next multiple (smaller patches, as many per CU).  2 km, sub-steps per step: 1 707
+                // patches of 428 nodes 4.28 ms, 1 756-1 773 of 416-412 4.22, 1 790 of 408 4.25 | 1 808 of 404 4.51 ... 2 029 of 360 4.40 | 2 123 of 344 4.62
+                // (profiles/r05_experiments/r5_pair_nodes_2km.log).  So: the smallest patches that stay under the multiple the largest ones are under, 1.5 % short of it.
+                const int unit = std::max(slots / 2, 1), hr = (hp.nP + unit - 1) / unit;
+                const long long target = (long long)(0.985 * (double)hr * unit);
+                int Pr = (int)((((long long)m.Nn + target - 1) / std::max(target, 1ll) + 3) & ~3ll);
+                bool tried = false, found = false;
+                for (int it = 0; it < 4 && Pr < P; ++it, Pr += 4) {
+                    tried = true;
+                    if (fits(Pr) && hp.nP <= hr * unit) { P = Pr; found = true; break; }
+                }
+                if (tried && !found && !fits(P)) return "no patch size fits k_substep_pair";   // (the trials rebuilt hp: back to the size kept)
             }
         }
         out.pair_kernel = true;
@@ -942,15 +956,23 @@ inline std::string plan_pair_patches_mr(const MeshView &m, bool used_hilbert, in
         P = lo;
         if (last_built != P && !fits(P)) return "no patch size fits k_substep_pair";
     }
-    // a whole round where the partition is ONE round of workgroups (as plan_patches2).  Two rounds keep the largest patches that fit: rank 0 of two of the 2 km
-    // mesh runs its 60 launches in 2.85-2.91 ms with 855-963 patches of 380-428 nodes and in 3.01 with 1 016 of 360 (two whole rounds: more ring for nothing,
-    // profiles/r05_experiments/r5_pairnodes.log)
+    // a whole round where the partition is ONE round of workgroups (as plan_patches2).  More: the smallest patches that stay under the multiple of HALF a round
+    // (one workgroup per CU) the largest ones are under -- as plan_patches2, but 7 % short of it (the band patches wait for the neighbour ranks: the rounds are
+    // less even).  Rank 0 of two of the 2 km mesh, 60 launches: 855 patches of 428 nodes 2.91 ms, 924-963 of 396-380 2.85-2.87, 1 016 of 360 (two whole rounds
+    // but for eight) 3.01 (profiles/r05_experiments/r5_pairnodes.log)
     const int slots = 2 * cus, k = (out.hp.nP + slots - 1) / slots, P_fit = P;
     if (k == 1 && out.hp.nP > 0 && out.hp.nP != k * slots) {
         int Pr = std::max(64, (int)((((long long)m.No + (long long)k * slots - 1) / ((long long)k * slots) + 3) & ~3ll));
         bool tried = false;
         for (int it = 0; it < 6 && Pr < P; ++it, Pr += 4) { tried = true; if (fits(Pr) && out.hp.nP <= k * slots) { P = Pr; break; } }
         if (tried && P == P_fit && !fits(P)) return "no patch size fits k_substep_pair";
+    } else if (k >= 2) {
+        const int unit = cus, hr = (out.hp.nP + unit - 1) / unit;
+        const long long target = (long long)(0.93 * (double)hr * unit);
+        int Pr = std::max(64, (int)((((long long)m.No + target - 1) / std::max(target, 1ll) + 3) & ~3ll));
+        bool tried = false, found = false;
+        for (int it = 0; it < 4 && Pr < P; ++it, Pr += 4) { tried = true; if (fits(Pr) && out.hp.nP <= hr * unit) { P = Pr; found = true; break; } }
+        if (tried && !found && !fits(P)) return "no patch size fits k_substep_pair";
     }
     return "";
 }
