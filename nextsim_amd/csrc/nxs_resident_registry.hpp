@@ -26,8 +26,7 @@
 //     invisible in /proc here and would be swept although alive.  Foreign-namespace entries expire instead: every entry carries the time its owner last touched it
 //     (CLOCK_BOOTTIME; claim, registration, and every ~10 s of stepping), one that is 300 s old is dropped;
 //   * a version mismatch (another build of the library on the device) does not wipe live entries: this process then keeps a table of its own, as without shared memory;
-//   * flock() is per open file description: a fork()ed child shares its parent's lock and the two are not excluded from each other -- ranks are exec'ed processes
-//     (mpiexec, torchrun) or threads (the mutex), never forks that both use the library.
+//   * flock() is per open file description: a fork()ed child shares its parent's -- so a child opens one of its own the first time it takes the lock (own_description).
 // tests/native/registry_host.cpp drives this file from two processes (tests/test_resident_registry.py): a second process' grid is refused up front, a dead
 // process' claim is reclaimed, the arithmetic of claims and waiting grids.
 #ifndef NXS_RESIDENT_REGISTRY_HPP
@@ -158,6 +157,7 @@ public:
     DeviceTable(const DeviceTable &) = delete;
     DeviceTable &operator=(const DeviceTable &) = delete;
     bool shared() const { return fd_ >= 0; }
+    int lock_fd() const { return fd_; }   // (tests)
     const std::string &name() const { return name_; }
 
     // a handle exists on the device (nxs_dyn_create); multi_rank is brought up to date by claim()
@@ -263,9 +263,17 @@ public:
 private:
     struct Guard {  // this process' threads by the mutex, other processes by flock (per open file description: it does not separate threads)
         DeviceTable *t;
-        explicit Guard(DeviceTable *tt) : t(tt) { t->mu_.lock(); if (t->fd_ >= 0) while (flock(t->fd_, LOCK_EX) != 0 && errno == EINTR) {} }
+        explicit Guard(DeviceTable *tt) : t(tt) { t->mu_.lock(); t->own_description(); if (t->fd_ >= 0) while (flock(t->fd_, LOCK_EX) != 0 && errno == EINTR) {} }
         ~Guard() { if (t->fd_ >= 0) flock(t->fd_, LOCK_UN); t->mu_.unlock(); }
     };
+    // flock() is per open file description and a fork()ed child shares its parent's: the first time a child comes here it opens a description of its own (the mapping
+    // is shared memory and stays) and forgets the parent's start time
+    void own_description() {
+        const int me = (int)getpid();
+        if (me == open_pid_) return;
+        open_pid_ = me; start_ = 0;
+        if (fd_ >= 0) { const int nfd = shm_open(name_.c_str(), O_RDWR, 0600); if (nfd >= 0) { close(fd_); fd_ = nfd; } }
+    }
     uint64_t my_start() { if (!start_) start_ = process_start_time((int)getpid()); return start_; }
     Entry *find(uint64_t handle) {
         for (Entry &e : tab_->e) if (e.in_use && e.pid == (int32_t)getpid() && e.pidns == my_pid_namespace() && e.handle == handle && e.start == my_start()) return &e;
@@ -295,6 +303,7 @@ private:
         }
     }
     std::string name_;
+    int open_pid_ = (int)getpid();
     int fd_ = -1;
     Table *tab_ = nullptr;
     Table local_{};

@@ -8,6 +8,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <sys/file.h>
+#include <sys/wait.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "nxs_resident_registry.hpp"
 
@@ -74,6 +78,22 @@ int main(int argc, char **argv) {
         T.remove(b); T.remove(c);
         CHECK(T.handles() == 2 && T.claimed() > 0.78);            // a + the live foreign entry
         T.remove(a);
+        if (T.shared()) {   // a fork()ed child is excluded by the lock like any other process: it blocks while the parent holds it (with the parent's description it would walk through)
+            CHECK(flock(T.lock_fd(), LOCK_EX) == 0);
+            const pid_t child = fork();
+            if (child == 0) {
+                struct timespec t0, t1;
+                clock_gettime(CLOCK_MONOTONIC, &t0);
+                (void)T.handles();
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                _exit((t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec) >= 0.2 ? 0 : 1);
+            }
+            CHECK(child > 0);
+            usleep(400000);
+            CHECK(flock(T.lock_fd(), LOCK_UN) == 0);
+            int status = 0;
+            CHECK(waitpid(child, &status, 0) == child && WIFEXITED(status) && WEXITSTATUS(status) == 0);
+        }
         printf("selftest ok (%s)\n", T.shared() ? "shared memory" : "process-local");
         return 0;
     }
