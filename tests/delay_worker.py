@@ -1,7 +1,7 @@
 """Worker of tests/test_gpu_protocol_delays.py: one PROCESS of a multi-rank GPU run that walks a list of cases over ONE set-up.
 
 A case = (kernel variant, options per rank, ONE rank delayed at ONE named point of the exchange protocols -- option "ipc_delay", include/nxs_dyn.h).  Every
-case starts from the same state, runs one step and is compared BIT FOR BIT with the first case of the first phase (the separate push / pull kernels, nobody
+case starts from the same state, runs one step (or case["steps"] of them) and is compared BIT FOR BIT with the first case of the first phase (the separate push / pull kernels, nobody
 delayed).  A phase may re-create round 4's defect: the halo lists taken as given (test door "halo_one_directional"), connected with the caller-side bookkeeping.
 
 Same process layout as mr_worker.py: NXS_RANKS_PER_PROC ranks per process as threads, gloo between the processes."""
@@ -85,7 +85,8 @@ def run_rank(li, report):
             fe.set_option("prepare", 1)
             all_gather(0)                       # nobody steps before every rank's state is resident and its tables are built
             try:
-                fe.step()
+                for _ in range(int(case.get("steps", 1))):
+                    fe.step()
                 fe.synchronize()
             except dynamics.NxsError as e:
                 res["error"] = str(e)
