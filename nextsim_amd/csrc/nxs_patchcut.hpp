@@ -712,11 +712,9 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
                 if (last_built != P && !fits(P)) return "no patch size fits k_substep_pair";
             }
             out.P_fit = P;
-            // One or two rounds of workgroups: whole rounds (a round that is a fraction full costs almost a full one -- 492 k triangles: 583
-            // patches of 424 nodes 2.43 ms of sub-steps, 1 013 of 244 nodes 2.26; 730 k: 864 of 424 3.15, 1 018 of 360 3.00).  From three rounds
-            // on the largest patches win (1.08 M triangles: 1 270 of 428 4.14, 1 494-1 527 of 356-364 4.32-4.35; 2 km likewise).
+            // One round of workgroups or less: a whole round (a round that is a fraction full costs almost a full one).
             const int slots = wg_per_cu * cus, k = (hp.nP + slots - 1) / slots;
-            if (k <= 2 && hp.nP > 0 && hp.nP != k * slots) {
+            if (k == 1 && hp.nP > 0 && hp.nP != k * slots) {
                 int Pr = (int)((((long long)m.Nn + (long long)k * slots - 1) / ((long long)k * slots) + 3) & ~3ll);
                 Pr = std::max(64, Pr);
                 bool tried = false;
@@ -725,11 +723,13 @@ inline std::string plan_patches2(const MeshView &m, bool used_hilbert, int pair_
                     if (fits(Pr) && hp.nP <= k * slots) { P = Pr; break; }
                 }
                 if (tried && P == out.P_fit && !fits(P)) return "no patch size fits k_substep_pair";   // (the trials rebuilt hp: back to the size kept)
-            } else if (k >= 3) {
-                // Three rounds or more: the time of a launch steps up whenever the number of patches crosses a multiple of HALF a round (one workgroup per CU: a CU then
+            } else if (k >= 2) {
+                // More than one round: the time of a launch steps up whenever the number of patches crosses a multiple of HALF a round (one workgroup per CU: a CU then
                 // runs one more patch behind the others), and falls slowly towards the next multiple (smaller patches, as many per CU).  2 km, sub-steps per step: 1 707
                 // patches of 428 nodes 4.28 ms, 1 756-1 773 of 416-412 4.22, 1 790 of 408 4.25 | 1 808 of 404 4.51 ... 2 029 of 360 4.40 | 2 123 of 344 4.62
                 // (profiles/r05_experiments/r5_pair_nodes_2km.log).  So: the smallest patches that stay under the multiple the largest ones are under, 1.5 % short of it.
+                // Two rounds likewise: 493 k triangles, ms per step: 1 015 patches of 244 nodes (two whole rounds) 1.88, 774 of 320 2.05 | 755 of 328 (three half
+                // rounds) 1.82, 737 of 336 1.91 (r5_single_492k.log); 730 k: 1 018 of 360 2.43 ms of sub-steps, 944 of 388 2.47 (four half rounds = two whole ones).
                 const int unit = std::max(slots / 2, 1), hr = (hp.nP + unit - 1) / unit;
                 const long long target = (long long)(0.985 * (double)hr * unit);
                 int Pr = (int)((((long long)m.Nn + target - 1) / std::max(target, 1ll) + 3) & ~3ll);

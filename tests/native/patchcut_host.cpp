@@ -302,11 +302,11 @@ int pc_run(const int32_t *indices, const uint8_t *ghost3, const double *x, const
                 for (int q = 0; q < pk.hp.nP; ++q) own_max = std::max(own_max, pk.hp.ncnt[(size_t)q * 3]);
                 REQUIRE(pk.pair_kernel && pk.threads == 512 && pk.lds == pair_lds_of(pk.hp) && pk.lds <= 80 * 1024 && pair_kernel_fits(pk.hp, own_max),
                         "pair plan: P=%d lds=%zu EDmax=%d ESmax=%d NSmax=%d own=%d", pk.P, pk.lds, pk.hp.EDmax, pk.hp.ESmax, pk.hp.NSmax, own_max);
-                // the size is the largest that fits, or smaller for the sake of the rounds of workgroups: one or two WHOLE rounds, or -- three rounds and more --
+                // the size is the largest that fits, or smaller for the sake of the rounds of workgroups: one WHOLE round, or -- more than a round --
                 // just under a multiple of half a round (one workgroup per CU)
                 REQUIRE(pk.P_fit >= pk.P && pk.P >= 64, "pair plan: P=%d P_fit=%d", pk.P, pk.P_fit);
                 const int slots = 2 * std::max(cus, 1), unit = std::max(cus, 1), hr = (pk.hp.nP + unit - 1) / unit;
-                if (pk.P < pk.P_fit && pk.hp.nP > 2 * slots)
+                if (pk.P < pk.P_fit && pk.hp.nP > slots)
                     REQUIRE(pk.hp.nP <= hr * unit && (double)pk.hp.nP >= 0.9 * hr * unit - 1., "pair plan: %d patches of %d nodes (largest that fit: %d) on %d slots", pk.hp.nP, pk.P, pk.P_fit, slots);
             }
             if (w5.empty()) {   // the ready-made fan indices of k_substep_pair / k_substep_multi: every entry names a corner force of the patch or the pair of zeros
